@@ -1,0 +1,195 @@
+"""ctypes loader for the CPU oracle (oracle/d3il_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg - never by
+the product package ``d3il_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libd3il_oracle.so")
+    src = os.path.join(_HERE, "d3il_oracle.c")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "d3il_model_blob.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libd3il_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_create.restype = C.c_void_p
+        for name in ("orc_nq", "orc_nv", "orc_get_contacts", "orc_get_efc", "orc_solver_iter",
+                     "orc_unsupported_pairs", "orc_supported_pairs"):
+            getattr(_LIB, name).restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """One scalar environment."""
+
+    def __init__(self, blob):
+        self.L = lib()
+        self.blob = blob
+        self.h = C.c_void_p(self.L.orc_create(C.byref(blob)))
+        if not self.h:
+            raise RuntimeError("orc_create failed (blob magic/version)")
+        self.nq, self.nv = self.L.orc_nq(self.h), self.L.orc_nv(self.h)
+
+    def __del__(self):
+        try:
+            self.L.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    # ---- physics level
+    def set_state(self, qpos, qvel):
+        qpos, qvel = np.ascontiguousarray(qpos, float), np.ascontiguousarray(qvel, float)
+        self.L.orc_set_qpos_qvel(self.h, _p(qpos), _p(qvel))
+
+    def set_ctrl(self, ctrl):
+        ctrl = np.ascontiguousarray(ctrl, float)
+        self.L.orc_set_ctrl(self.h, _p(ctrl))
+
+    def forward(self):
+        self.L.orc_forward(self.h)
+
+    def mj_step(self):
+        self.L.orc_mj_step(self.h)
+
+    def state(self):
+        qpos, qvel = np.zeros(self.nq), np.zeros(self.nv)
+        self.L.orc_get_qpos_qvel(self.h, _p(qpos), _p(qvel))
+        return qpos, qvel
+
+    def M(self):
+        M = np.zeros((self.nv, self.nv))
+        self.L.orc_get_M(self.h, _p(M))
+        return M
+
+    def vec(self, name):
+        which = {"qfrc_bias": 0, "qacc": 1, "qacc_smooth": 2, "qfrc_constraint": 3, "qfrc_actuator": 4,
+                 "dof_invweight0": 5}[name]
+        out = np.zeros(self.nv)
+        self.L.orc_get_vec(self.h, which, _p(out))
+        return out
+
+    def body(self, b):
+        xpos, xquat, invw = np.zeros(3), np.zeros(4), np.zeros(2)
+        self.L.orc_get_body(self.h, int(b), _p(xpos), _p(xquat), _p(invw))
+        return xpos, xquat, invw
+
+    def contacts(self):
+        out = np.zeros((16, 10))
+        n = self.L.orc_get_contacts(self.h, _p(out))
+        return out[:n]
+
+    def efc(self):
+        f, a, d = np.zeros(96), np.zeros(96), np.zeros(96)
+        n = self.L.orc_get_efc(self.h, _p(f), _p(a), _p(d))
+        return f[:n], a[:n], d[:n]
+
+    def solver_iter(self):
+        return self.L.orc_solver_iter(self.h)
+
+    def pairs(self, supported=True):
+        out = np.zeros((1024, 2), dtype=np.int32)
+        fn = self.L.orc_supported_pairs if supported else self.L.orc_unsupported_pairs
+        n = fn(self.h, _p(out), 1024)
+        return out[:min(n, 1024)]
+
+    # ---- controller level
+    def fk(self, q):
+        q = np.ascontiguousarray(q, float)
+        pos, quat = np.zeros(3), np.zeros(4)
+        self.L.orc_fk(self.h, _p(q), _p(pos), _p(quat))
+        return pos, quat
+
+    def jac(self, q):
+        q = np.ascontiguousarray(q, float)
+        J = np.zeros((6, 7))
+        self.L.orc_jac(self.h, _p(q), _p(J))
+        return J
+
+    def ik_reset(self):
+        self.L.orc_ik_reset(self.h)
+
+    def ik_setpoint(self, a):
+        a = np.ascontiguousarray(a, float)
+        self.L.orc_ik_setpoint(self.h, _p(a))
+
+    def set_robot_state(self, jpos, jvel, fpos=None, fvel=None, setw=0.001, grasp=False):
+        jpos, jvel = np.ascontiguousarray(jpos, float), np.ascontiguousarray(jvel, float)
+        if fpos is None:
+            self.L.orc_set_robot_state(self.h, _p(jpos), _p(jvel), None, None, C.c_double(setw), int(grasp))
+        else:
+            fpos, fvel = np.ascontiguousarray(fpos, float), np.ascontiguousarray(fvel, float)
+            self.L.orc_set_robot_state(self.h, _p(jpos), _p(jvel), _p(fpos), _p(fvel), C.c_double(setw), int(grasp))
+
+    def ik_control(self):
+        tau = np.zeros(7)
+        self.L.orc_ik_control(self.h, _p(tau))
+        return tau
+
+    def ik_state(self):
+        a, b = np.zeros(7), np.zeros(7)
+        self.L.orc_get_ik_state(self.h, _p(a), _p(b))
+        return a, b
+
+    def pd_control(self, q_des, qd_des):
+        q_des, qd_des = np.ascontiguousarray(q_des, float), np.ascontiguousarray(qd_des, float)
+        self.L.orc_pd_setpoint(self.h, _p(q_des), _p(qd_des))
+        tau = np.zeros(7)
+        self.L.orc_pd_control(self.h, _p(tau))
+        return tau
+
+    def finger_ctrl(self):
+        f = np.zeros(2)
+        self.L.orc_finger_ctrl(self.h, _p(f))
+        return f
+
+    def check_mode(self, cpos, reset=False):
+        cpos = np.ascontiguousarray(cpos, float)
+        mode = np.zeros(9)
+        succ = C.c_int(0)
+        self.L.orc_check_mode(self.h, _p(cpos), int(reset), _p(mode), C.byref(succ))
+        return mode, bool(succ.value)
+
+    # ---- env level (Avoiding)
+    def env_start(self, init_qpos):
+        init_qpos = np.ascontiguousarray(init_qpos, float)
+        self.L.orc_env_start(self.h, _p(init_qpos))
+
+    def env_reset(self):
+        obs = np.zeros(2, dtype=np.float32)
+        self.L.orc_env_reset(self.h, _p(obs))
+        return obs
+
+    def env_step(self, action):
+        action = np.ascontiguousarray(action, float)
+        obs = np.zeros(2, dtype=np.float32)
+        mode = np.zeros(9)
+        done, succ = C.c_int(0), C.c_int(0)
+        self.L.orc_env_step(self.h, _p(action), _p(obs), C.byref(done), _p(mode), C.byref(succ))
+        return obs, bool(done.value), mode, bool(succ.value)
+
+    def env_state(self):
+        s = np.zeros(42)
+        self.L.orc_env_get_state(self.h, _p(s))
+        f = np.zeros(8, dtype=np.int32)
+        self.L.orc_env_get_flags(self.h, _p(f))
+        return s, f
