@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""bench.py - env-steps/s of the fused Avoiding step() on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--no-cpu-baseline]
+
+A "step" is one pass of the hot path over one batch: for every one of the 4096 environments per GPU the
+device-side random policy writes the action (Philox, seed 42, counter = global env index x t), d3il_step runs
+the 35 fused physics sub-steps, and finished environments are auto-reset (masked d3il_reset +
+d3il_policy_begin), everything enqueued on one HIP stream with the state resident in HBM.  N > 1: one process
+per GPU (torch.distributed / RCCL), env shards are independent (weak scaling, 4096 envs per GPU), the only
+collective is the final int64 count all-reduce, outside the per-step path but inside the timed region.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+# algorithmic HBM bytes per env step: state read + written once (42 f64 + flags + step
+# counter = 344 B each way), action 56 B read, obs 8 B + done/success/mode 4 B written
+ALG_BYTES_PER_ENV_STEP = 2 * (42 * 8 + 4 + 4) + 56 + 8 + 4
+
+
+def cpu_baseline(blob, init_qpos, budget_s=12.0):
+    """Oracle (scalar C port of the reference path) timed on one host core on a bounded sample of the same
+    workload: one environment, random policy, as many env steps as fit in ~budget_s."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    o = Oracle(blob)
+    o.env_start(init_qpos)
+    o.env_reset()
+    s, _ = o.env_state()
+    des = s[25:28].copy()
+    rng = np.random.default_rng(42)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        des[:2] += rng.uniform(-0.01, 0.01, 2)
+        _, done, _, _ = o.env_step(np.array([des[0], des[1], des[2], 0, 1, 0, 0]))
+        n += 1
+        if done:
+            o.env_reset()
+            s, _ = o.env_state()
+            des = s[25:28].copy()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "1 env, random policy, %d env steps (35 sub-steps each) in %.1f s on one host core of %d; "
+                      "scalar C oracle (oracle/d3il_oracle.c); the Python reference is bounded above by 146 "
+                      "env-steps/s/core (BASELINE.md section 2)" % (n, dt, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auto-reset", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from d3il_amd import distributed as D
+    from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
+
+    if not torch.cuda.is_available():
+        print("bench.py needs a HIP device (there is no CPU fallback for the rollout path)", file=sys.stderr)
+        sys.exit(2)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    rank, world = D.init_from_env("nccl")
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda:%d" % local_rank)
+    n = args.envs
+    env = ObstacleAvoidanceVecEnv(n, device=dev)
+    q, iters, err = env.start()
+    env_offset = rank * n
+    actions = torch.zeros(n, 7, dtype=torch.float64, device=dev)
+    counts = torch.zeros(514, dtype=torch.int64, device=dev)
+    total_done = torch.zeros((), dtype=torch.int64, device=dev)
+    total_succ = torch.zeros((), dtype=torch.int64, device=dev)
+
+    def one_step(t):
+        env.policy_action(42, env_offset, t, actions)
+        _, _, done, (mode, succ) = env.step(actions)
+        if not args.no_auto_reset:
+            total_done.add_(done.sum())
+            total_succ.add_((succ * done).sum())
+            env.reset(done)
+            env.policy_begin(done)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    env.reset(); env.policy_begin()
+    for t in range(args.warmup):
+        one_step(t)
+    total_done.zero_(); total_succ.zero_()
+    env.set_timing(True)
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        one_step(args.warmup + t)
+        # HIP events are recorded by the library around the step kernel on the launch stream; reading the
+        # previous pair costs one event sync on an already finished kernel every 16 steps
+        if t % 16 == 15:
+            kernel_ms.append(env.last_step_ms())
+    env.count_metrics(counts)
+    D.reduce_counts(counts)
+    barrier()
+    dt = time.perf_counter() - t0
+    env.set_timing(False)
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t_max.item())
+    st, fl, sc = env.get_state()
+    ok = bool(np.isfinite(st).all()) and not bool((fl & (1 << 16)).any())
+    if rank == 0:
+        value = world * n * args.steps / dt
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        achieved = ALG_BYTES_PER_ENV_STEP * n / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Avoiding task, %d envs per GPU, random policy (Philox seed 42), state obs, "
+                                   "35 fused physics sub-steps per env step, auto-reset" % n,
+                       "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world,
+                       "auto_reset": not args.no_auto_reset, "finite_and_solver_ok": ok,
+                       "episodes_finished_rank0": int(total_done.item()), "episodes_success_rank0": int(total_succ.item())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_avoiding_step<true>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n,
+                         "note": "path is FP64-VALU/latency bound, not HBM bound: <1 KB of HBM per env step with "
+                                 "all 35 sub-steps fused (DESIGN.md section 4); fp64_valu_frac is the binding roofline",
+                         "fp64_valu_frac": None},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(env.blob, q)
+        print(json.dumps(line))
+    env.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

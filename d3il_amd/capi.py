@@ -1,0 +1,72 @@
+"""ctypes binding of libd3il_rollout.so (include/d3il_rollout.h).
+
+This is the reference-side binding a maintainer would add; it contains no
+compute.  Loading fails loudly when the library is missing - there is no Python/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .model.blob import ModelBlob
+
+_LIB = None
+
+
+class Buffers(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("stride", C.c_int32), ("obs_dim", C.c_int32), ("action_dim", C.c_int32),
+                ("obs", C.c_void_p), ("done", C.c_void_p), ("success", C.c_void_p), ("mode", C.c_void_p),
+                ("state", C.c_void_p), ("flags", C.c_void_p), ("step_count", C.c_void_p), ("policy_des", C.c_void_p)]
+
+
+STATE_F64 = 42
+STATE_QPOS, STATE_QVEL, STATE_BIAS, STATE_TCP, STATE_IK_Q, STATE_IK_QD = 0, 9, 18, 25, 28, 35
+FLAG_MODE_MASK, FLAG_TERMINATED, FLAG_SUCCESS, FLAG_ROD_CONTACT = 0x1FF, 1 << 12, 1 << 13, 1 << 14
+FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
+
+EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
+           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_count_metrics", "d3il_set_timing",
+           "d3il_last_step_ms", "d3il_set_option", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
+
+
+class D3ilError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libd3il_rollout.so")
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise D3ilError("%s is missing: build it with `python -m d3il_amd.build` (hipcc, gfx950). "
+                            "There is no CPU fallback for the rollout path." % path)
+        L = C.CDLL(path)
+        L.d3il_last_error.restype = C.c_char_p
+        L.d3il_blob_sizeof.restype = C.c_size_t
+        L.d3il_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.d3il_destroy.argtypes = [C.c_void_p]
+        L.d3il_start.argtypes = [C.c_void_p, C.c_void_p]
+        L.d3il_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_get_buffers.argtypes = [C.c_void_p, C.POINTER(Buffers)]
+        L.d3il_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_policy_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_policy_action.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.d3il_count_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.d3il_last_step_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.d3il_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        if L.d3il_blob_sizeof() != C.sizeof(ModelBlob):
+            raise D3ilError("model blob layout mismatch between include/d3il_model_blob.h and d3il_amd/model/blob.py")
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int):
+    if rc != 0:
+        raise D3ilError("libd3il_rollout error %d: %s" % (rc, load().d3il_last_error().decode()))

@@ -1,0 +1,920 @@
+// panda_step.h - per-environment math of the fused Avoiding step (one environment per lane).
+//
+// Everything here is __host__ __device__ and fully unrollable: in the HIP kernels each lane keeps
+// its environment in registers, the constant block (PandaConsts) arrives through scalar loads.
+// The same functions are compiled for the host ONLY to (a) finish the constant block at
+// d3il_create (inverse weights at qpos0) and (b) by tests/hostcheck, which is not part of the
+// product path.
+//
+// Formulation (deliberately different from the oracle's world-frame, MuJoCo-style restatement):
+// link-frame recursive Newton-Euler for the bias forces, link-frame composite-rigid-body for the
+// mass matrix, packed LDL^T, primal Newton on the soft-constraint problem with an exact 1-D line
+// search.  Reference path being replaced, per physics sub-step:
+//   MjRobot.prepare_step  (sims/mj_beta/MjRobot.py:125-131)
+//     CartPosQuatImpedenceController.getControl (controllers/IKControllers.py:163-323)
+//     JointPDController.getControl              (controllers/Controller.py:164-185)
+//     RobotBase.fing_ctrl_step/preprocessCommand (core/Robots.py:441-476,530-572)
+//   mujoco.mj_step        (sims/mj_beta/MjScene.py:110-111)  [ext: MuJoCo 2.3.2]
+//   MjRobot.receiveState  (sims/mj_beta/MjRobot.py:133-184)
+#pragma once
+#include "panda_consts.h"
+
+namespace d3il {
+
+// flag bits of EnvState::flags
+enum : unsigned {
+  F_MODE_MASK = 0x1FFu, F_L1 = 1u << 9, F_L2 = 1u << 10, F_L3 = 1u << 11, F_TERMINATED = 1u << 12,
+  F_SUCCESS = 1u << 13, F_ROD_CONTACT = 1u << 14, F_IK_VALID = 1u << 15, F_SOLVER_FAIL = 1u << 16,
+  F_MULTI_CONTACT = 1u << 17,
+};
+
+// number of f64 state fields per environment and their order in the SoA state buffer
+// (shared with the oracle's orc_env_get_state): qpos[9] qvel[9] bias[7] tcp[3] ik_q[7] ik_qd[7]
+constexpr int STATE_F64 = 42;
+
+struct EnvState {
+  double q[NDOF], v[NDOF], bias[NARM], tcp[3], ikq[NARM], ikqd[NARM];
+  unsigned flags;
+  int step;
+};
+
+// ------------------------------------------------------------------ tiny vector helpers
+D3IL_HD void cross3(const double* a, const double* b, double* r) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+D3IL_HD double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// r = E v  (E row-major 3x3)
+D3IL_HD void mulE(const double* E, const double* v, double* r) {
+  double x = E[0] * v[0] + E[1] * v[1] + E[2] * v[2], y = E[3] * v[0] + E[4] * v[1] + E[5] * v[2], z = E[6] * v[0] + E[7] * v[1] + E[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+// r = E^T v
+D3IL_HD void mulEt(const double* E, const double* v, double* r) {
+  double x = E[0] * v[0] + E[3] * v[1] + E[6] * v[2], y = E[1] * v[0] + E[4] * v[1] + E[7] * v[2], z = E[2] * v[0] + E[5] * v[1] + E[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+// E = Q * Rz(angle): parent <- link
+D3IL_HD void joint_rot(const double* Q, double s, double c, double* E) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) { E[3 * r] = c * Q[3 * r] + s * Q[3 * r + 1]; E[3 * r + 1] = c * Q[3 * r + 1] - s * Q[3 * r]; E[3 * r + 2] = Q[3 * r + 2]; }
+}
+// symmetric 3x3 (xx yy zz xy xz yz) times vector
+D3IL_HD void sym3v(const double* I, const double* v, double* r) {
+  double x = I[0] * v[0] + I[3] * v[1] + I[4] * v[2], y = I[3] * v[0] + I[1] * v[1] + I[5] * v[2], z = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+D3IL_HD double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+D3IL_HD int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // packed lower-triangular index, r >= c
+
+// ------------------------------------------------------------------ controller kinematics (URDF chain, core/Model.py:37-66)
+// pos/R of the grasp-target frame, world joint axes and origins
+D3IL_HD void ik_chain(const PandaConsts& c, const double* q, double* p, double* R, double (*ax)[3], double (*og)[3]) {
+  R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+  p[0] = p[1] = p[2] = 0;
+#pragma unroll
+  for (int k = 0; k < NARM; k++) {
+    double t[3]; mulE(R, c.Kx[k], t);
+    p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+    double Rn[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) Rn[3 * r + cc] = R[3 * r] * c.KR[k][cc] + R[3 * r + 1] * c.KR[k][3 + cc] + R[3 * r + 2] * c.KR[k][6 + cc];
+    ax[k][0] = Rn[2]; ax[k][1] = Rn[5]; ax[k][2] = Rn[8];
+    og[k][0] = p[0]; og[k][1] = p[1]; og[k][2] = p[2];
+    double s = sin(q[k]), co = cos(q[k]);
+    joint_rot(Rn, s, co, R);
+  }
+  double t[3]; mulE(R, c.tool_x, t);
+  p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+  double Rn[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) Rn[3 * r + cc] = R[3 * r] * c.tool_R[cc] + R[3 * r + 1] * c.tool_R[3 + cc] + R[3 * r + 2] * c.tool_R[6 + cc];
+#pragma unroll
+  for (int i = 0; i < 9; i++) R[i] = Rn[i];
+}
+// Eigen::Quaternion(Matrix3) branch rule, what pinocchio.Quaternion(R) evaluates (Model.py:47-53) [ext]
+D3IL_HD void mat2quat(const double* R, double* q) {
+  double t = R[0] + R[4] + R[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0); q[0] = 0.5 * t; t = 0.5 / t;
+    q[1] = (R[7] - R[5]) * t; q[2] = (R[2] - R[6]) * t; q[3] = (R[3] - R[1]) * t;
+  } else if (R[0] >= R[4] && R[0] >= R[8]) {     // i = 0
+    t = sqrt(R[0] - R[4] - R[8] + 1.0); q[1] = 0.5 * t; t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t; q[2] = (R[3] + R[1]) * t; q[3] = (R[6] + R[2]) * t;
+  } else if (R[4] > R[0] && R[4] >= R[8]) {      // i = 1
+    t = sqrt(R[4] - R[8] - R[0] + 1.0); q[2] = 0.5 * t; t = 0.5 / t;
+    q[0] = (R[2] - R[6]) * t; q[3] = (R[7] + R[5]) * t; q[1] = (R[1] + R[3]) * t;
+  } else {                                        // i = 2
+    t = sqrt(R[8] - R[0] - R[4] + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+    q[0] = (R[3] - R[1]) * t; q[1] = (R[2] + R[6]) * t; q[2] = (R[5] + R[7]) * t;
+  }
+}
+D3IL_HD void quat_error(const double* c, const double* d, double* e) {  // utils/geometric_transformation.py:14-46
+  e[0] = c[0] * d[1] - d[0] * c[1] - c[3] * d[2] + c[2] * d[3];
+  e[1] = c[0] * d[2] - d[0] * c[2] + c[3] * d[1] - c[1] * d[3];
+  e[2] = c[0] * d[3] - d[0] * c[3] - c[2] * d[1] + c[1] * d[2];
+}
+
+// x = (U clip(S) U^T)^-1 b for the SPD 6x6 A (packed lower, 21): the reference rebuilds the matrix from its
+// SVD with clipped singular values and calls np.linalg.solve (IKControllers.py:230-266).
+// Fast path: if lmin(A) > minsv and lmax(A) < maxsv no value is clipped and x = A^-1 b (LDL^T).  lmin > minsv
+// <=> A - minsv I is positive definite <=> all its LDL^T pivots are positive (exact test); trace(A) < maxsv
+// is a sufficient test for lmax.  Otherwise: cyclic Jacobi eigen-decomposition.
+template <bool FAST>
+D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double maxsv, double* x) {
+  bool need_eig = true;
+  if (FAST) {
+    // pivots of A - minsv I
+    double L[21], d[6];
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double s = A[tri(j, j)] - minsv;
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[tri(j, k)] * L[tri(j, k)] * d[k];
+      d[j] = s; pd = pd && (s > 0);
+      double inv = 1.0 / s;
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        double t = A[tri(i, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) t -= L[tri(i, k)] * L[tri(j, k)] * d[k];
+        L[tri(i, j)] = t * inv;
+      }
+    }
+    double tr = A[tri(0, 0)] + A[tri(1, 1)] + A[tri(2, 2)] + A[tri(3, 3)] + A[tri(4, 4)] + A[tri(5, 5)];
+    if (pd && tr < maxsv) {
+      need_eig = false;
+      // LDL^T of A itself and solve
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        double s = A[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= L[tri(j, k)] * L[tri(j, k)] * d[k];
+        d[j] = s;
+        double inv = 1.0 / s;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+          double t = A[tri(i, j)];
+#pragma unroll
+          for (int k = 0; k < j; k++) t -= L[tri(i, k)] * L[tri(j, k)] * d[k];
+          L[tri(i, j)] = t * inv;
+        }
+      }
+      double y[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) { double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[tri(i, k)] * y[k]; y[i] = s; }
+#pragma unroll
+      for (int i = 0; i < 6; i++) y[i] /= d[i];
+#pragma unroll
+      for (int i = 5; i >= 0; i--) { double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= L[tri(k, i)] * x[k]; x[i] = s; }
+    }
+  }
+  if (need_eig) {
+    double M[6][6], V[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) { M[i][j] = A[i >= j ? tri(i, j) : tri(j, i)]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; sweep++) {
+      double off = 0, dg = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) { dg += M[i][i] * M[i][i];
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) off += M[i][j] * M[i][j]; }
+      if (off <= 1e-34 * dg) break;
+#pragma unroll
+      for (int p = 0; p < 5; p++)
+#pragma unroll
+        for (int q = p + 1; q < 6; q++) {
+          double apq = M[p][q];
+          if (apq != 0.0) {
+            double theta = (M[q][q] - M[p][p]) / (2 * apq);
+            double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+            double cs = 1 / sqrt(t * t + 1), sn = t * cs;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { double a = M[k][p], bb = M[k][q]; M[k][p] = cs * a - sn * bb; M[k][q] = sn * a + cs * bb; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { double a = M[p][k], bb = M[q][k]; M[p][k] = cs * a - sn * bb; M[q][k] = sn * a + cs * bb; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { double a = V[k][p], bb = V[k][q]; V[k][p] = cs * a - sn * bb; V[k][q] = sn * a + cs * bb; }
+          }
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { double s = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) s += V[a][i] * b[a]; y[i] = s / clampd(M[i][i], minsv, maxsv); }
+#pragma unroll
+    for (int a = 0; a < 6; a++) { double s = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) s += V[a][i] * y[i]; x[a] = s; }
+  }
+}
+
+// One call of CartPosQuatImpedenceController.getControl up to (and including) the set-point handed to the
+// joint PD law: advances the virtual joint target ikq by ik_iters damped-least-squares iterations.
+template <bool FAST>
+D3IL_HD void ik_update(const PandaConsts& c, const double* des_pos, const double* des_quat_in, const double* cur_q,
+                       unsigned& flags, double* ikq, double* ikqd) {
+  double q[NARM], old_q[NARM];
+  if (!(flags & F_IK_VALID)) {
+#pragma unroll
+    for (int k = 0; k < NARM; k++) ikq[k] = cur_q[k];
+    flags |= F_IK_VALID;
+  }
+#pragma unroll
+  for (int k = 0; k < NARM; k++) { old_q[k] = ikq[k]; q[k] = ikq[k]; }
+  double dq[4] = {des_quat_in[0], des_quat_in[1], des_quat_in[2], des_quat_in[3]};
+  for (int it = 0; it < c.ik_iters; it++) {
+    double pos[3], R[9], ax[NARM][3], og[NARM][3], cq[4];
+    ik_chain(c, q, pos, R, ax, og);
+    mat2quat(R, cq);
+    double dm = 0, dp = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { dm += (cq[k] - dq[k]) * (cq[k] - dq[k]); dp += (cq[k] + dq[k]) * (cq[k] + dq[k]); }
+    if (sqrt(dm) > sqrt(dp)) { dq[0] = -dq[0]; dq[1] = -dq[1]; dq[2] = -dq[2]; dq[3] = -dq[3]; }
+    double qe[3], target[6];
+    quat_error(cq, dq, qe);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      target[k] = c.ik_ppos[k] * clampd(des_pos[k] - pos[k], -0.01, 0.01);
+      target[3 + k] = c.ik_pquat[k] * clampd(qe[k], -0.1, 0.1);
+    }
+    double J[6][NARM];
+#pragma unroll
+    for (int k = 0; k < NARM; k++) {
+      double d[3] = {pos[0] - og[k][0], pos[1] - og[k][1], pos[2] - og[k][2]}, cr[3];
+      cross3(ax[k], d, cr);
+      J[0][k] = cr[0]; J[1][k] = cr[1]; J[2][k] = cr[2]; J[3][k] = ax[k][0]; J[4][k] = ax[k][1]; J[5][k] = ax[k][2];
+    }
+    double A[21];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b <= a; b++) {
+        double s = a == b ? c.ik_Jreg : 0.0;
+#pragma unroll
+        for (int k = 0; k < NARM; k++) s += J[a][k] * J[b][k];
+        A[tri(a, b)] = s;
+      }
+    double qn[NARM], rhs[6], x[6];
+#pragma unroll
+    for (int k = 0; k < NARM; k++) qn[k] = c.ik_pnull[k] * clampd(c.ik_rest[k] - q[k], -0.2, 0.2);
+#pragma unroll
+    for (int a = 0; a < 6; a++) { double s = target[a];
+#pragma unroll
+      for (int k = 0; k < NARM; k++) s -= J[a][k] * qn[k]; rhs[a] = s; }
+    ik_solve6<FAST>(A, rhs, c.ik_minsv, c.ik_maxsv, x);
+    double qd[NARM], nrm = 0;
+#pragma unroll
+    for (int k = 0; k < NARM; k++) { double s = qn[k];
+#pragma unroll
+      for (int a = 0; a < 6; a++) s += J[a][k] * x[a]; qd[k] = s; nrm += s * s; }
+    nrm = sqrt(nrm);
+    if (nrm > 3) {
+#pragma unroll
+      for (int k = 0; k < NARM; k++) qd[k] = qd[k] * 3 / nrm;
+    }
+#pragma unroll
+    for (int k = 0; k < NARM; k++) q[k] = clampd(q[k] + c.ik_lr * qd[k], c.q_min[k], c.q_max[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NARM; k++) { ikqd[k] = (q[k] - old_q[k]) / c.timestep; ikq[k] = q[k]; }
+}
+
+// ------------------------------------------------------------------ dynamics (MJCF chain), link-frame recursions
+struct DynOut {
+  double M[45];        // packed lower, dof order: 7 arm, finger1, finger2
+  double bias[NDOF];   // Coriolis + centrifugal + gravity (qfrc_bias)
+  double R7[9], p7[3]; // world <- link 7
+};
+
+// world pose of link 7 plus (optionally) world joint axes / origins for point Jacobians
+D3IL_HD void world_chain(const PandaConsts& c, const double* sn, const double* cs, double* R7, double* p7, double (*ax)[3], double (*og)[3]) {
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < NARM; i++) {
+    double t[3]; mulE(R, c.P[i], t);
+    p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+    double E[9], Rn[9];
+    joint_rot(c.Q[i], sn[i], cs[i], E);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) Rn[3 * r + cc] = R[3 * r] * E[cc] + R[3 * r + 1] * E[3 + cc] + R[3 * r + 2] * E[6 + cc];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = Rn[k];
+    if (ax) { ax[i][0] = R[2]; ax[i][1] = R[5]; ax[i][2] = R[8]; og[i][0] = p[0]; og[i][1] = p[1]; og[i][2] = p[2]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) R7[k] = R[k];
+  p7[0] = p[0]; p7[1] = p[1]; p7[2] = p[2];
+}
+
+D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, DynOut& o) {
+  double sn[NARM], cs[NARM];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) { sn[i] = sin(q[i]); cs[i] = cos(q[i]); }
+  world_chain(c, sn, cs, o.R7, o.p7, nullptr, nullptr);
+
+  // ---- RNEA forward pass (velocities, accelerations with qacc = 0, base acceleration = -gravity)
+  double F[NARM][3], N[NARM][3];   // link force and moment about the link origin, link axes
+  double w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, a[3] = {-c.gravity[0], -c.gravity[1], -c.gravity[2]};
+  double w7[3], al7[3], a7[3];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) {
+    double E[9]; joint_rot(c.Q[i], sn[i], cs[i], E);
+    double t1[3], t2[3], ap[3];
+    cross3(al, c.P[i], t1); cross3(w, c.P[i], t2); cross3(w, t2, t2);
+    ap[0] = a[0] + t1[0] + t2[0]; ap[1] = a[1] + t1[1] + t2[1]; ap[2] = a[2] + t1[2] + t2[2];
+    double wn[3], aln[3];
+    mulEt(E, w, wn); wn[2] += v[i];
+    mulEt(E, al, aln); aln[0] += wn[1] * v[i]; aln[1] -= wn[0] * v[i];
+    mulEt(E, ap, a);
+    w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; al[0] = aln[0]; al[1] = aln[1]; al[2] = aln[2];
+    // body wrench
+    double ac[3], Iw[3], Ia[3];
+    cross3(al, c.com[i], t1); cross3(w, c.com[i], t2); cross3(w, t2, t2);
+    ac[0] = a[0] + t1[0] + t2[0]; ac[1] = a[1] + t1[1] + t2[1]; ac[2] = a[2] + t1[2] + t2[2];
+    F[i][0] = c.mass[i] * ac[0]; F[i][1] = c.mass[i] * ac[1]; F[i][2] = c.mass[i] * ac[2];
+    sym3v(c.Ic[i], w, Iw); sym3v(c.Ic[i], al, Ia);
+    cross3(w, Iw, t1); cross3(c.com[i], F[i], t2);
+    N[i][0] = Ia[0] + t1[0] + t2[0]; N[i][1] = Ia[1] + t1[1] + t2[1]; N[i][2] = Ia[2] + t1[2] + t2[2];
+  }
+  w7[0] = w[0]; w7[1] = w[1]; w7[2] = w[2]; al7[0] = al[0]; al7[1] = al[1]; al7[2] = al[2]; a7[0] = a[0]; a7[1] = a[1]; a7[2] = a[2];
+  // fingers: prismatic leaves of link 7
+  double rf[NFING][3];
+#pragma unroll
+  for (int k = 0; k < NFING; k++) {
+    const double* ax = c.f_axis[k];
+    double qf = q[NARM + k], vf = v[NARM + k];
+    rf[k][0] = c.f_com0[k][0] + ax[0] * qf; rf[k][1] = c.f_com0[k][1] + ax[1] * qf; rf[k][2] = c.f_com0[k][2] + ax[2] * qf;
+    double t1[3], t2[3], t3[3], ac[3], Ff[3], Iw[3], Ia[3];
+    cross3(al7, rf[k], t1); cross3(w7, rf[k], t2); cross3(w7, t2, t2); cross3(w7, ax, t3);
+    ac[0] = a7[0] + t1[0] + t2[0] + 2 * vf * t3[0]; ac[1] = a7[1] + t1[1] + t2[1] + 2 * vf * t3[1]; ac[2] = a7[2] + t1[2] + t2[2] + 2 * vf * t3[2];
+    Ff[0] = c.f_mass[k] * ac[0]; Ff[1] = c.f_mass[k] * ac[1]; Ff[2] = c.f_mass[k] * ac[2];
+    o.bias[NARM + k] = dot3(Ff, ax);
+    sym3v(c.f_Ic[k], w7, Iw); sym3v(c.f_Ic[k], al7, Ia);
+    cross3(w7, Iw, t1); cross3(rf[k], Ff, t2);
+    F[NARM - 1][0] += Ff[0]; F[NARM - 1][1] += Ff[1]; F[NARM - 1][2] += Ff[2];
+    N[NARM - 1][0] += Ia[0] + t1[0] + t2[0]; N[NARM - 1][1] += Ia[1] + t1[1] + t2[1]; N[NARM - 1][2] += Ia[2] + t1[2] + t2[2];
+  }
+  // ---- RNEA backward pass
+#pragma unroll
+  for (int i = NARM - 1; i >= 0; i--) {
+    o.bias[i] = N[i][2];
+    if (i > 0) {
+      double E[9]; joint_rot(c.Q[i], sn[i], cs[i], E);
+      double f[3], n[3], t[3];
+      mulE(E, F[i], f); mulE(E, N[i], n); cross3(c.P[i], f, t);
+      F[i - 1][0] += f[0]; F[i - 1][1] += f[1]; F[i - 1][2] += f[2];
+      N[i - 1][0] += n[0] + t[0]; N[i - 1][1] += n[1] + t[1]; N[i - 1][2] += n[2] + t[2];
+    }
+  }
+
+  // ---- CRBA: composite inertia (mass, h = m c, Io about the link origin) from the tip down
+  double cm = 0, ch[3] = {0, 0, 0}, cI[6] = {0, 0, 0, 0, 0, 0};
+  // finger columns (constant in the link-7 frame: n = m (com0 x axis), f = m axis) and finger composites
+  double colF[NFING][3], colN[NFING][3];
+#pragma unroll
+  for (int k = 0; k < NFING; k++) {
+    const double* ax = c.f_axis[k];
+    double m = c.f_mass[k];
+    colF[k][0] = m * ax[0]; colF[k][1] = m * ax[1]; colF[k][2] = m * ax[2];
+    cross3(rf[k], colF[k], colN[k]);
+    o.M[tri(NARM + k, NARM + k)] = m;
+    double rr = dot3(rf[k], rf[k]);
+    cm += m; ch[0] += m * rf[k][0]; ch[1] += m * rf[k][1]; ch[2] += m * rf[k][2];
+    cI[0] += c.f_Ic[k][0] + m * (rr - rf[k][0] * rf[k][0]); cI[1] += c.f_Ic[k][1] + m * (rr - rf[k][1] * rf[k][1]); cI[2] += c.f_Ic[k][2] + m * (rr - rf[k][2] * rf[k][2]);
+    cI[3] += c.f_Ic[k][3] - m * rf[k][0] * rf[k][1]; cI[4] += c.f_Ic[k][4] - m * rf[k][0] * rf[k][2]; cI[5] += c.f_Ic[k][5] - m * rf[k][1] * rf[k][2];
+  }
+  o.M[tri(NARM + 1, NARM)] = 0;
+#pragma unroll
+  for (int i = NARM - 1; i >= 0; i--) {
+    // add link i's own inertia
+    {
+      const double* cc = c.com[i]; double m = c.mass[i], rr = dot3(cc, cc);
+      cm += m; ch[0] += m * cc[0]; ch[1] += m * cc[1]; ch[2] += m * cc[2];
+      cI[0] += c.Ic[i][0] + m * (rr - cc[0] * cc[0]); cI[1] += c.Ic[i][1] + m * (rr - cc[1] * cc[1]); cI[2] += c.Ic[i][2] + m * (rr - cc[2] * cc[2]);
+      cI[3] += c.Ic[i][3] - m * cc[0] * cc[1]; cI[4] += c.Ic[i][4] - m * cc[0] * cc[2]; cI[5] += c.Ic[i][5] - m * cc[1] * cc[2];
+    }
+    // column of joint i: unit acceleration about z through the origin
+    double f[3] = {-ch[1], ch[0], 0}, n[3] = {cI[4], cI[5], cI[2]};
+    o.M[tri(i, i)] = n[2];
+    // finger columns enter the chain at link 7
+    if (i == NARM - 1) {
+#pragma unroll
+      for (int k = 0; k < NFING; k++) o.M[tri(NARM + k, i)] = colN[k][2];
+    }
+    // propagate this joint's column up to the base
+    {
+      double ff[3] = {f[0], f[1], f[2]}, nn[3] = {n[0], n[1], n[2]};
+#pragma unroll
+      for (int j = i; j > 0; j--) {
+        double E[9]; joint_rot(c.Q[j], sn[j], cs[j], E);
+        double f2[3], n2[3], t[3];
+        mulE(E, ff, f2); mulE(E, nn, n2); cross3(c.P[j], f2, t);
+        ff[0] = f2[0]; ff[1] = f2[1]; ff[2] = f2[2]; nn[0] = n2[0] + t[0]; nn[1] = n2[1] + t[1]; nn[2] = n2[2] + t[2];
+        o.M[tri(i, j - 1)] = nn[2];
+      }
+    }
+    if (i == NARM - 1) {
+#pragma unroll
+      for (int k = 0; k < NFING; k++) {
+        double ff[3] = {colF[k][0], colF[k][1], colF[k][2]}, nn[3] = {colN[k][0], colN[k][1], colN[k][2]};
+#pragma unroll
+        for (int j = NARM - 1; j > 0; j--) {
+          double E[9]; joint_rot(c.Q[j], sn[j], cs[j], E);
+          double f2[3], n2[3], t[3];
+          mulE(E, ff, f2); mulE(E, nn, n2); cross3(c.P[j], f2, t);
+          ff[0] = f2[0]; ff[1] = f2[1]; ff[2] = f2[2]; nn[0] = n2[0] + t[0]; nn[1] = n2[1] + t[1]; nn[2] = n2[2] + t[2];
+          o.M[tri(NARM + k, j - 1)] = nn[2];
+        }
+      }
+    }
+    // move the composite to the parent frame
+    if (i > 0) {
+      double E[9]; joint_rot(c.Q[i], sn[i], cs[i], E);
+      double h2[3]; mulE(E, ch, h2);
+      // Io' = E Io E^T
+      double I9[9] = {cI[0], cI[3], cI[4], cI[3], cI[1], cI[5], cI[4], cI[5], cI[2]}, T[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) T[3 * r + cc] = E[3 * r] * I9[cc] + E[3 * r + 1] * I9[3 + cc] + E[3 * r + 2] * I9[6 + cc];
+      double J0 = T[0] * E[0] + T[1] * E[1] + T[2] * E[2], J1 = T[3] * E[3] + T[4] * E[4] + T[5] * E[5], J2 = T[6] * E[6] + T[7] * E[7] + T[8] * E[8];
+      double J3 = T[0] * E[3] + T[1] * E[4] + T[2] * E[5], J4 = T[0] * E[6] + T[1] * E[7] + T[2] * E[8], J5 = T[3] * E[6] + T[4] * E[7] + T[5] * E[8];
+      const double* P = c.P[i];
+      double ph = dot3(P, h2), pp = dot3(P, P), s = 2 * ph + cm * pp;
+      cI[0] = J0 + s - (2 * P[0] * h2[0] + cm * P[0] * P[0]); cI[1] = J1 + s - (2 * P[1] * h2[1] + cm * P[1] * P[1]); cI[2] = J2 + s - (2 * P[2] * h2[2] + cm * P[2] * P[2]);
+      cI[3] = J3 - (P[0] * h2[1] + h2[0] * P[1] + cm * P[0] * P[1]); cI[4] = J4 - (P[0] * h2[2] + h2[0] * P[2] + cm * P[0] * P[2]); cI[5] = J5 - (P[1] * h2[2] + h2[1] * P[2] + cm * P[1] * P[2]);
+      ch[0] = h2[0] + cm * P[0]; ch[1] = h2[1] + cm * P[1]; ch[2] = h2[2] + cm * P[2];
+    }
+  }
+}
+
+// packed LDL^T of a 9x9 SPD matrix: L unit lower (strict part stored), d pivots.  Returns false if a pivot <= 0.
+D3IL_HD bool ldl9(const double* A, double* L, double* d) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NDOF; j++) {
+    double s = A[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= L[tri(j, k)] * L[tri(j, k)] * d[k];
+    d[j] = s; ok = ok && (s > 0);
+    double inv = 1.0 / s;
+#pragma unroll
+    for (int i = j + 1; i < NDOF; i++) {
+      double t = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= L[tri(i, k)] * L[tri(j, k)] * d[k];
+      L[tri(i, j)] = t * inv;
+    }
+  }
+  return ok;
+}
+D3IL_HD void ldl9_solve(const double* L, const double* d, double* x) {
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) { double s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k]; x[i] = s; }
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) x[i] /= d[i];
+#pragma unroll
+  for (int i = NDOF - 1; i >= 0; i--) { double s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < NDOF; k++) s -= L[tri(k, i)] * x[k]; x[i] = s; }
+}
+D3IL_HD void symv9(const double* A, const double* x, double* y) {
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) { double s = 0;
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) s += A[i >= k ? tri(i, k) : tri(k, i)] * x[k]; y[i] = s; }
+}
+
+// MuJoCo impedance d(r) from solimp (already clamped): engine_core_constraint getimpedance [ext]
+D3IL_HD double impedance(const double* si, double r) {
+  if (si[0] == si[1] || si[2] <= 1e-15) return 0.5 * (si[0] + si[1]);
+  double x = fabs(r) / si[2];
+  if (x >= 1) return si[1];
+  if (x <= 0) return si[0];
+  double y;
+  if (si[4] == 1) y = x;
+  else if (x <= si[3]) y = (si[4] == 2 ? x * x : pow(x, si[4])) / (si[4] == 2 ? si[3] : pow(si[3], si[4] - 1));
+  else { double u = 1 - x, m = 1 - si[3]; y = 1 - (si[4] == 2 ? u * u : pow(u, si[4])) / (si[4] == 2 ? m : pow(m, si[4] - 1)); }
+  return si[0] + y * (si[1] - si[0]);
+}
+
+// rod <-> obstacle: capsule formula on the clamped closest points of the two axis segments
+// (lateral regime; see DESIGN.md "Collision coverage").  Returns true if dist < margin.
+D3IL_HD bool rod_obstacle(const double* c1, const double* u, double r1, double h1, const double* c2, const double* vv, double r2, double h2,
+                          double margin, double* dist, double* nrm, double* pos) {
+  double r[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+  double b = dot3(u, vv), cc = dot3(u, r), f = dot3(vv, r), den = 1 - b * b, s, t;
+  if (den > 1e-12) s = clampd((b * f - cc) / den, -h1, h1);
+  else {
+    double lo = fmax(-h1, -cc - h2), hi = fmin(h1, -cc + h2);
+    s = lo <= hi ? 0.5 * (lo + hi) : (fabs(lo - h1) < fabs(hi + h1) ? h1 : -h1);
+  }
+  t = b * s + f;
+  if (t < -h2) { t = -h2; s = clampd(b * t - cc, -h1, h1); }
+  else if (t > h2) { t = h2; s = clampd(b * t - cc, -h1, h1); }
+  double p1[3] = {c1[0] + s * u[0], c1[1] + s * u[1], c1[2] + s * u[2]};
+  double d[3] = {c2[0] + t * vv[0] - p1[0], c2[1] + t * vv[1] - p1[1], c2[2] + t * vv[2] - p1[2]};
+  double len = sqrt(dot3(d, d));
+  *dist = len - r1 - r2;
+  if (!(*dist < margin) || len < 1e-15) return false;
+  nrm[0] = d[0] / len; nrm[1] = d[1] / len; nrm[2] = d[2] / len;
+  double off = r1 + 0.5 * (*dist);
+  pos[0] = p1[0] + nrm[0] * off; pos[1] = p1[1] + nrm[1] * off; pos[2] = p1[2] + nrm[2] * off;
+  return true;
+}
+
+// data of the (single) rod contact handed to the solver
+struct RodContact {
+  bool active;
+  double J[3][NARM];   // rows: normal, tangent1, tangent2 (elliptic cone, condim 3)
+  double D[3], aref[3], mu, fric[2];
+};
+
+// Constraint solve: min_x 1/2 (x-a0)^T M (x-a0) + sum_i s_i(J_i x - aref_i) with joint-limit rows (unilateral
+// quadratics) and at most one elliptic contact.  MuJoCo reaches the same (unique) optimum with its Newton solver.
+// Returns qfrc_constraint; lim_* arrays are per dof (lim_sign = 0 when the row is absent).
+D3IL_HD bool solve_constraints(const double* M, const double* a0, const double* fs_norm_ref, const double* lim_sign, const double* lim_D,
+                               const double* lim_aref, const RodContact& rc, double* fc_out) {
+  double x[NDOF], Ma[NDOF], grad[NDOF], p[NDOF], fl[NDOF], hl[NDOF];
+  double fcn[3] = {0, 0, 0}, Hc[6] = {0, 0, 0, 0, 0, 0};  // contact force and Hessian block (00 11 22 01 02 12)
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) x[i] = a0[i];
+  double gtol = 1e-13 * (1.0 + *fs_norm_ref);
+  bool ok = true;
+  auto eval_contact = [&](const double* jar, double* force, double* H) {
+    double mu = rc.mu, U0 = jar[0] * mu, U1 = jar[1] * rc.fric[0], U2 = jar[2] * rc.fric[1];
+    double T = sqrt(U1 * U1 + U2 * U2), Nn = U0;
+    force[0] = force[1] = force[2] = 0;
+    if (H) { H[0] = H[1] = H[2] = H[3] = H[4] = H[5] = 0; }
+    if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return;
+    if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
+      force[0] = -rc.D[0] * jar[0]; force[1] = -rc.D[1] * jar[1]; force[2] = -rc.D[2] * jar[2];
+      if (H) { H[0] = rc.D[0]; H[1] = rc.D[1]; H[2] = rc.D[2]; }
+      return;
+    }
+    double Dm = rc.D[0] / fmax(1e-15, mu * mu * (1 + mu * mu)), NmT = Nn - mu * T;
+    double g0 = mu, g1 = -mu * rc.fric[0] * U1 / T, g2 = -mu * rc.fric[1] * U2 / T;
+    force[0] = -Dm * NmT * g0; force[1] = -Dm * NmT * g1; force[2] = -Dm * NmT * g2;
+    if (H) {
+      double k = -mu * NmT, T3 = T * T * T;
+      H[0] = Dm * g0 * g0; H[3] = Dm * g0 * g1; H[4] = Dm * g0 * g2;
+      H[1] = Dm * (g1 * g1 + k * rc.fric[0] * rc.fric[0] * (1 / T - U1 * U1 / T3));
+      H[2] = Dm * (g2 * g2 + k * rc.fric[1] * rc.fric[1] * (1 / T - U2 * U2 / T3));
+      H[5] = Dm * (g1 * g2 + k * rc.fric[0] * rc.fric[1] * (-U1 * U2 / T3));
+    }
+  };
+  for (int it = 0; it < 12; it++) {
+    // row residuals, forces, Hessian diagonal
+    double jc[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) {
+      double jar = lim_sign[i] * x[i] - lim_aref[i];
+      bool act = lim_sign[i] != 0 && jar < 0;
+      fl[i] = act ? -lim_D[i] * jar : 0.0; hl[i] = act ? lim_D[i] : 0.0;
+    }
+    if (rc.active) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) { double s = -rc.aref[r];
+#pragma unroll
+        for (int k = 0; k < NARM; k++) s += rc.J[r][k] * x[k]; jc[r] = s; }
+      eval_contact(jc, fcn, Hc);
+    }
+    double dx[NDOF];
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) dx[i] = x[i] - a0[i];
+    symv9(M, dx, Ma);
+    double gn = 0;
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) {
+      double g = Ma[i] - lim_sign[i] * fl[i];
+      if (rc.active && i < NARM) g -= rc.J[0][i] * fcn[0] + rc.J[1][i] * fcn[1] + rc.J[2][i] * fcn[2];
+      grad[i] = g; gn += g * g;
+    }
+    if (sqrt(gn) <= gtol) break;
+    // H = M + diag(hl) + Jc^T Hc Jc
+    double H[45], L[45], d[NDOF];
+#pragma unroll
+    for (int i = 0; i < 45; i++) H[i] = M[i];
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) H[tri(i, i)] += hl[i];
+    if (rc.active) {
+      double T0[NARM], T1[NARM], T2[NARM];
+#pragma unroll
+      for (int k = 0; k < NARM; k++) {
+        T0[k] = Hc[0] * rc.J[0][k] + Hc[3] * rc.J[1][k] + Hc[4] * rc.J[2][k];
+        T1[k] = Hc[3] * rc.J[0][k] + Hc[1] * rc.J[1][k] + Hc[5] * rc.J[2][k];
+        T2[k] = Hc[4] * rc.J[0][k] + Hc[5] * rc.J[1][k] + Hc[2] * rc.J[2][k];
+      }
+#pragma unroll
+      for (int a = 0; a < NARM; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) H[tri(a, b)] += rc.J[0][a] * T0[b] + rc.J[1][a] * T1[b] + rc.J[2][a] * T2[b];
+    }
+    if (!ldl9(H, L, d)) { ok = false; break; }
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) p[i] = -grad[i];
+    ldl9_solve(L, d, p);
+    // exact line search on the convex 1-D restriction
+    double Mp[NDOF], Jp[3] = {0, 0, 0};
+    symv9(M, p, Mp);
+    double pMp = 0, pMa = 0;
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) { pMp += p[i] * Mp[i]; pMa += p[i] * Ma[i]; }
+    if (rc.active) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) { double s = 0;
+#pragma unroll
+        for (int k = 0; k < NARM; k++) s += rc.J[r][k] * p[k]; Jp[r] = s; }
+    }
+    double alpha = 0, lo = 0, hi = -1, best = 1;
+    for (int ls = 0; ls < 40; ls++) {
+      double d1 = pMa + alpha * pMp, d2 = pMp;
+#pragma unroll
+      for (int i = 0; i < NDOF; i++) {
+        double sp = lim_sign[i] * p[i];
+        double jar = lim_sign[i] * x[i] - lim_aref[i] + alpha * sp;
+        if (lim_sign[i] != 0 && jar < 0) { d1 += lim_D[i] * jar * sp; d2 += lim_D[i] * sp * sp; }
+      }
+      if (rc.active) {
+        double jt[3] = {jc[0] + alpha * Jp[0], jc[1] + alpha * Jp[1], jc[2] + alpha * Jp[2]}, ft[3], Ht[6];
+        eval_contact(jt, ft, Ht);
+        d1 -= ft[0] * Jp[0] + ft[1] * Jp[1] + ft[2] * Jp[2];
+        d2 += Ht[0] * Jp[0] * Jp[0] + Ht[1] * Jp[1] * Jp[1] + Ht[2] * Jp[2] * Jp[2] + 2 * (Ht[3] * Jp[0] * Jp[1] + Ht[4] * Jp[0] * Jp[2] + Ht[5] * Jp[1] * Jp[2]);
+      }
+      best = alpha;
+      if (fabs(d1) <= 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 / d2;
+      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) x[i] += best * p[i];
+  }
+  // forces at the solution
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) {
+    double jar = lim_sign[i] * x[i] - lim_aref[i];
+    fc_out[i] = (lim_sign[i] != 0 && jar < 0) ? -lim_D[i] * jar * lim_sign[i] : 0.0;
+  }
+  if (rc.active) {
+    double jc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { double s = -rc.aref[r];
+#pragma unroll
+      for (int k = 0; k < NARM; k++) s += rc.J[r][k] * x[k]; jc[r] = s; }
+    eval_contact(jc, fcn, nullptr);
+#pragma unroll
+    for (int k = 0; k < NARM; k++) fc_out[k] += rc.J[0][k] * fcn[0] + rc.J[1][k] * fcn[1] + rc.J[2][k] * fcn[2];
+  }
+  return ok;
+}
+
+// mju_makeFrame: tangents for a given normal [ext]
+D3IL_HD void make_frame(const double* n, double* t1, double* t2) {
+  double y[3] = {0, 0, 0};
+  if (n[1] < 0.5 && n[1] > -0.5) y[1] = 1; else y[2] = 1;
+  double d = dot3(n, y);
+  y[0] -= d * n[0]; y[1] -= d * n[1]; y[2] -= d * n[2];
+  double l = sqrt(dot3(y, y));
+  t1[0] = y[0] / l; t1[1] = y[1] / l; t1[2] = y[2] / l;
+  cross3(n, t1, t2);
+}
+
+// One mj_step (forward dynamics with the ctrl computed by the caller + semi-implicit Euler with implicit joint
+// damping) followed by the state read-back.  `tau` = controller torque WITHOUT gravity compensation for the arm,
+// `ffing` = raw finger command.  Updates q, v, bias (qfrc_bias of THIS forward pass), tcp (pre-integration pose).
+D3IL_HD void physics_substep(const PandaConsts& c, EnvState& st, const double* tau, const double* ffing) {
+  DynOut dyn;
+  dynamics(c, st.q, st.v, dyn);
+  // actuation: ctrl = tau + (stale) qfrc_bias for the arm, raw for fingers; motors clamp to forcerange
+  double fs[NDOF];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) fs[k] = clampd(tau[k] + st.bias[k], c.force_lo[k], c.force_hi[k]) - dyn.bias[k];
+#pragma unroll
+  for (int k = 0; k < NFING; k++) fs[NARM + k] = clampd(ffing[k], c.force_lo[NARM + k], c.force_hi[NARM + k]) - dyn.bias[NARM + k] - c.f_damping[k] * st.v[NARM + k];
+  // read-back quantities of this forward pass (one sub-step stale w.r.t. the integrated state)
+#pragma unroll
+  for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
+  {
+    double t[3]; mulE(dyn.R7, c.tcp7, t);
+    st.tcp[0] = dyn.p7[0] + t[0]; st.tcp[1] = dyn.p7[1] + t[1]; st.tcp[2] = dyn.p7[2] + t[2];
+  }
+  // ---- constraints: joint limits
+  double lim_sign[NDOF], lim_D[NDOF], lim_aref[NDOF];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) {
+    double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
+    double sign = 0, dist = 0;
+    if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
+    else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
+    lim_sign[k] = sign; lim_D[k] = 0; lim_aref[k] = 0;
+    if (sign != 0) {
+      any = true;
+      double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
+      double R = fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
+      lim_D[k] = 1 / R;
+      lim_aref[k] = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
+    }
+  }
+  // ---- constraints: rod <-> obstacle contact (deepest one)
+  RodContact rc; rc.active = false;
+  st.flags &= ~F_ROD_CONTACT;
+  if (c.n_obst > 0) {
+    double rcw[3], ruw[3];
+    mulE(dyn.R7, c.rod_c7, rcw); rcw[0] += dyn.p7[0]; rcw[1] += dyn.p7[1]; rcw[2] += dyn.p7[2];
+    mulE(dyn.R7, c.rod_u7, ruw);
+    double bd = 1e300, bn[3] = {0, 0, 0}, bp[3] = {0, 0, 0}; int bo = -1, ncon = 0;
+    for (int o = 0; o < c.n_obst; o++) {
+      double dist, nrm[3], pos[3];
+      // geom1 = obstacle (lower geom id), geom2 = rod: normal points obstacle -> rod
+      if (rod_obstacle(c.ob_c[o], c.ob_u[o], c.ob_r[o], c.ob_h[o], rcw, ruw, c.rod_r, c.rod_h, c.ct_margin[o], &dist, nrm, pos)) {
+        ncon++;
+        if (dist < bd) { bd = dist; bo = o; bn[0] = nrm[0]; bn[1] = nrm[1]; bn[2] = nrm[2]; bp[0] = pos[0]; bp[1] = pos[1]; bp[2] = pos[2]; }
+      }
+    }
+    if (ncon > 1) st.flags |= F_MULTI_CONTACT;
+    if (bo >= 0) {
+      st.flags |= F_ROD_CONTACT;
+      any = true; rc.active = true;
+      double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3], t1[3], t2[3];
+#pragma unroll
+      for (int i = 0; i < NARM; i++) { sn[i] = sin(st.q[i]); cs[i] = cos(st.q[i]); }
+      world_chain(c, sn, cs, R7, p7, ax, og);
+      make_frame(bn, t1, t2);
+      double vel[3] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < NARM; k++) {
+        double dd[3] = {bp[0] - og[k][0], bp[1] - og[k][1], bp[2] - og[k][2]}, col[3];
+        cross3(ax[k], dd, col);
+        rc.J[0][k] = dot3(bn, col); rc.J[1][k] = dot3(t1, col); rc.J[2][k] = dot3(t2, col);
+        vel[0] += rc.J[0][k] * st.v[k]; vel[1] += rc.J[1][k] * st.v[k]; vel[2] += rc.J[2][k] * st.v[k];
+      }
+      double imp = impedance(c.ct_solimp[bo], bd - c.ct_margin[bo]);
+      double Rn = fmax(1e-15, (1 - imp) / imp * c.rod_invweight0);
+      double Rt = Rn / fmax(1e-15, c.impratio);
+      double f0 = c.ct_fric[bo][0];
+      rc.mu = f0 * sqrt(Rt / Rn); rc.fric[0] = f0; rc.fric[1] = f0;
+      rc.D[0] = 1 / Rn; rc.D[1] = 1 / Rt; rc.D[2] = 1 / Rt;
+      rc.aref[0] = -c.ct_B[bo] * vel[0] - c.ct_K[bo] * imp * (bd - c.ct_margin[bo]);
+      rc.aref[1] = -c.ct_B[bo] * vel[1]; rc.aref[2] = -c.ct_B[bo] * vel[2];
+    }
+  }
+  // ---- accelerations
+  double fc[NDOF];
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) fc[k] = 0;
+  double L[45], d[NDOF];
+  if (any) {
+    double a0[NDOF], fn = 0;
+    if (!ldl9(dyn.M, L, d)) st.flags |= F_SOLVER_FAIL;
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) { a0[k] = fs[k]; fn += fs[k] * fs[k]; }
+    fn = sqrt(fn);
+    ldl9_solve(L, d, a0);
+    if (!solve_constraints(dyn.M, a0, &fn, lim_sign, lim_D, lim_aref, rc, fc)) st.flags |= F_SOLVER_FAIL;
+  }
+  // Euler with implicit joint damping: (M + h B) qacc = qfrc_smooth + qfrc_constraint  (mj_EulerSkip [ext])
+  double Md[45], qacc[NDOF];
+#pragma unroll
+  for (int i = 0; i < 45; i++) Md[i] = dyn.M[i];
+#pragma unroll
+  for (int k = 0; k < NFING; k++) Md[tri(NARM + k, NARM + k)] += c.timestep * c.f_damping[k];
+  if (!ldl9(Md, L, d)) st.flags |= F_SOLVER_FAIL;
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) qacc[k] = fs[k] + fc[k];
+  ldl9_solve(L, d, qacc);
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) { st.v[k] += c.timestep * qacc[k]; st.q[k] += c.timestep * st.v[k]; }
+}
+
+// controllers feeding one physics sub-step (Scene.next_step, core/Scene.py:121-138)
+template <bool IK, bool FAST>
+D3IL_HD void substep(const PandaConsts& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp) {
+  double tau[NARM], ff[NFING];
+  if (IK) {
+    ik_update<FAST>(c, des_pos, des_quat, st.q, st.flags, st.ikq, st.ikqd);
+#pragma unroll
+    for (int k = 0; k < NARM; k++) tau[k] = c.pd_p[k] * (st.ikq[k] - st.q[k]) + c.pd_d[k] * (st.ikqd[k] - st.v[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NARM; k++) tau[k] = c.pd_p[k] * (pd_q[k] - st.q[k]) + c.pd_d[k] * (0.0 - st.v[k]);
+  }
+  // RobotBase.fing_ctrl_step (Robots.py:441-476)
+  double mean = 0.5 * (st.q[NARM] + st.q[NARM + 1]);
+#pragma unroll
+  for (int k = 0; k < NFING; k++) {
+    double w = st.q[NARM + k], wv = st.v[NARM + k];
+    double f1 = 500 * (mean - w), f2;
+    if (mean - set_width > 0.005) f2 = grasp ? -20.0 : 10 * (-0.2 - wv);
+    else f2 = clampd(500 * (set_width - w) - 10 * wv, -5, 5);
+    ff[k] = f1 + f2;
+  }
+  physics_substep(c, st, tau, ff);
+}
+
+// ObstacleAvoidanceEnv.check_mode (avoiding.py:173-202), literal comparisons
+D3IL_HD void check_mode(const PandaConsts& c, EnvState& st) {
+  const double* f = c.task_f;
+  double x = st.tcp[0], y = st.tcp[1];
+  if (y - 0.03 <= f[0] && f[0] <= y + 0.03 && !(st.flags & F_L1)) {
+    if (x < f[4]) st.flags |= 1u << 0; else if (x > f[4]) st.flags |= 1u << 1;
+    st.flags |= F_L1;
+  }
+  if (y - 0.03 <= f[1] && f[1] <= y + 0.03 && !(st.flags & F_L2)) {
+    if (x < f[5]) st.flags |= 1u << 2; else if (f[5] < x && x < f[6]) st.flags |= 1u << 3; else if (x > f[6]) st.flags |= 1u << 4;
+    st.flags |= F_L2;
+  }
+  if (y >= f[2] && !(st.flags & F_L3)) {
+    if (x < f[7]) st.flags |= 1u << 5;
+    if (f[7] < x && x < f[8]) st.flags |= 1u << 6; else if (f[8] < x && x < f[9]) st.flags |= 1u << 7; else if (x > f[7]) st.flags |= 1u << 8;
+    st.flags |= F_L3;
+  }
+}
+
+// ObstacleAvoidanceEnv.step (avoiding.py:168-171) over GymEnvWrapper.step (gyms/gym_env_wrapper.py:45-100)
+template <bool FAST>
+D3IL_HD void env_step(const PandaConsts& c, EnvState& st, const double* action, float* obs, unsigned char* done) {
+  obs[0] = (float)st.tcp[0]; obs[1] = (float)st.tcp[1];
+  bool fin = (st.flags & F_TERMINATED) != 0;
+  if (!fin) {  // _check_early_termination (avoiding.py:236-246)
+    bool succ = st.tcp[1] > c.task_f[3];
+    if (succ || (st.flags & F_ROD_CONTACT)) { if (succ) st.flags |= F_SUCCESS; st.flags |= F_TERMINATED; fin = true; }
+  }
+  if (!fin && st.step >= c.max_steps - 1) fin = true;
+  *done = fin ? 1 : 0;
+  double dp[3] = {action[0], action[1], action[2]};
+  double n = sqrt(action[3] * action[3] + action[4] * action[4] + action[5] * action[5] + action[6] * action[6]);
+  double dq[4] = {action[3] / n, action[4] / n, action[5] / n, action[6] / n};
+  for (int s = 0; s < c.n_substeps; s++) substep<true, FAST>(c, st, dp, dq, nullptr, 0.04, false);
+  st.step += 1;
+  check_mode(c, st);
+}
+
+// ObstacleAvoidanceEnv.reset (avoiding.py:248-262): scene.reset, beam to init_qpos, one PD-hold sub-step
+D3IL_HD void env_reset(const PandaConsts& c, EnvState& st, const double* init_qpos, float* obs) {
+#pragma unroll
+  for (int k = 0; k < NARM; k++) { st.q[k] = init_qpos[k]; st.ikq[k] = 0; st.ikqd[k] = 0; }
+  st.q[NARM] = 0; st.q[NARM + 1] = 0;
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) st.v[k] = 0;
+  st.flags = 0; st.step = 0;
+  // mj_forward at the beamed state (MjScene.set_state, MjScene.py:294-299): qfrc_bias used by the first command
+  DynOut dyn;
+  dynamics(c, st.q, st.v, dyn);
+#pragma unroll
+  for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
+  substep<false, true>(c, st, nullptr, nullptr, init_qpos, 0.001, false);
+  obs[0] = (float)st.tcp[0]; obs[1] = (float)st.tcp[1];
+}
+
+// ------------------------------------------------------------------ host: finish the constant block
+#if defined(__HIPCC__)
+#define D3IL_HOST __host__
+#else
+#define D3IL_HOST
+#endif
+D3IL_HOST inline void finish_invweights(PandaConsts& c) {
+  double q[NDOF] = {0}, v[NDOF] = {0};
+  DynOut dyn;
+  dynamics(c, q, v, dyn);
+  double L[45], d[NDOF], Minv[NDOF][NDOF];
+  ldl9(dyn.M, L, d);
+  for (int col = 0; col < NDOF; col++) {
+    double e[NDOF] = {0}; e[col] = 1; ldl9_solve(L, d, e);
+    for (int r = 0; r < NDOF; r++) Minv[r][col] = e[r];
+  }
+  for (int k = 0; k < NDOF; k++) c.dof_invweight0[k] = Minv[k][k];
+  // translational inverse weight of the rod body at its COM (= rod geom centre): mean diag of J Minv J^T
+  double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3];
+  for (int i = 0; i < NARM; i++) { sn[i] = 0; cs[i] = 1; }
+  world_chain(c, sn, cs, R7, p7, ax, og);
+  double pc[3]; mulE(R7, c.rod_c7, pc); pc[0] += p7[0]; pc[1] += p7[1]; pc[2] += p7[2];
+  double J[3][NARM];
+  for (int k = 0; k < NARM; k++) { double dd[3] = {pc[0] - og[k][0], pc[1] - og[k][1], pc[2] - og[k][2]}, col[3]; cross3(ax[k], dd, col); J[0][k] = col[0]; J[1][k] = col[1]; J[2][k] = col[2]; }
+  double tr = 0;
+  for (int r = 0; r < 3; r++) for (int a = 0; a < NARM; a++) for (int b = 0; b < NARM; b++) tr += J[r][a] * Minv[a][b] * J[r][b];
+  c.rod_invweight0 = fmax(1e-15, tr / 3);
+}
+
+}  // namespace d3il

@@ -1,0 +1,324 @@
+// rollout.hip - HIP kernels (gfx950) and the C ABI of libd3il_rollout.so.
+//
+// One environment per lane, one wavefront (64 lanes) per workgroup: at N = 4096 that is 64 workgroups on 64
+// different CUs, each wave alone on its SIMD (the path is FP64 VALU / latency bound, not HBM bound: the whole
+// env step touches < 1 KB of HBM per environment).  State is SoA [field][env] so that every field is one
+// coalesced 512-byte row per wave; the constant block is read with scalar loads.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include "../../include/d3il_rollout.h"
+#include "panda_step.h"
+
+namespace d3il {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ void load_state(const double* __restrict__ state, const unsigned* __restrict__ flags,
+                                           const int* __restrict__ steps, int stride, int e, EnvState& st) {
+  const double* s = state + e;
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) st.q[i] = s[(D3IL_STATE_QPOS + i) * (size_t)stride];
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) st.v[i] = s[(D3IL_STATE_QVEL + i) * (size_t)stride];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) st.bias[i] = s[(D3IL_STATE_BIAS + i) * (size_t)stride];
+#pragma unroll
+  for (int i = 0; i < 3; i++) st.tcp[i] = s[(D3IL_STATE_TCP + i) * (size_t)stride];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) st.ikq[i] = s[(D3IL_STATE_IK_Q + i) * (size_t)stride];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) st.ikqd[i] = s[(D3IL_STATE_IK_QD + i) * (size_t)stride];
+  st.flags = flags[e]; st.step = steps[e];
+}
+__device__ __forceinline__ void store_state(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+                                            int stride, int e, const EnvState& st) {
+  double* s = state + e;
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) s[(D3IL_STATE_QPOS + i) * (size_t)stride] = st.q[i];
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) s[(D3IL_STATE_QVEL + i) * (size_t)stride] = st.v[i];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) s[(D3IL_STATE_BIAS + i) * (size_t)stride] = st.bias[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) s[(D3IL_STATE_TCP + i) * (size_t)stride] = st.tcp[i];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) s[(D3IL_STATE_IK_Q + i) * (size_t)stride] = st.ikq[i];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) s[(D3IL_STATE_IK_QD + i) * (size_t)stride] = st.ikqd[i];
+  flags[e] = st.flags; steps[e] = st.step;
+}
+__device__ __forceinline__ void store_outputs(const EnvState& st, int e, const float* o, unsigned char dn, float* __restrict__ obs,
+                                              unsigned char* __restrict__ done, unsigned char* __restrict__ success, unsigned short* __restrict__ mode) {
+  obs[2 * e] = o[0]; obs[2 * e + 1] = o[1];
+  done[e] = dn; success[e] = (st.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)(st.flags & F_MODE_MASK);
+}
+
+// env.step() for the Avoiding task: controller + physics fused over all sub-steps, state stays in registers.
+template <bool FAST>
+__global__ __launch_bounds__(WAVE) void k_avoiding_step(const PandaConsts* __restrict__ cp, double* __restrict__ state,
+                                                        unsigned* __restrict__ flags, int* __restrict__ steps,
+                                                        const double* __restrict__ actions, float* __restrict__ obs,
+                                                        unsigned char* __restrict__ done, unsigned char* __restrict__ success,
+                                                        unsigned short* __restrict__ mode, int n, int stride) {
+  int e = blockIdx.x * WAVE + threadIdx.x;
+  if (e >= n) return;
+  const PandaConsts& c = *cp;
+  EnvState st;
+  load_state(state, flags, steps, stride, e, st);
+  double act[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
+  float o[2]; unsigned char dn;
+  env_step<FAST>(c, st, act, o, &dn);
+  store_state(state, flags, steps, stride, e, st);
+  store_outputs(st, e, o, dn, obs, done, success, mode);
+}
+
+// env.reset() for masked environments
+__global__ __launch_bounds__(WAVE) void k_avoiding_reset(const PandaConsts* __restrict__ cp, const double* __restrict__ init_qpos,
+                                                         const unsigned char* __restrict__ mask, double* __restrict__ state,
+                                                         unsigned* __restrict__ flags, int* __restrict__ steps, float* __restrict__ obs,
+                                                         unsigned char* __restrict__ done, unsigned char* __restrict__ success,
+                                                         unsigned short* __restrict__ mode, int n, int stride) {
+  int e = blockIdx.x * WAVE + threadIdx.x;
+  if (e >= n) return;
+  if (mask && !mask[e]) return;
+  const PandaConsts& c = *cp;
+  EnvState st;
+  double iq[NARM];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
+  float o[2];
+  env_reset(c, st, iq, o);
+  store_state(state, flags, steps, stride, e, st);
+  store_outputs(st, e, o, 0, obs, done, success, mode);
+}
+
+// ---- random-policy harness (avoiding_sim.py:51-66 with a uniform random agent)
+__device__ __forceinline__ void philox4x32_10(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned* out) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void k_policy_begin(const unsigned char* __restrict__ mask, const double* __restrict__ state, double* __restrict__ des, int n, int stride) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n || (mask && !mask[e])) return;
+#pragma unroll
+  for (int k = 0; k < 3; k++) des[k * (size_t)stride + e] = state[(D3IL_STATE_TCP + k) * (size_t)stride + e];
+}
+__global__ void k_policy_action(double* __restrict__ des, double* __restrict__ actions, unsigned long long seed, unsigned long long env_offset,
+                                unsigned t, int n, int stride) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  unsigned long long ge = env_offset + (unsigned long long)e;
+  unsigned r[4];
+  philox4x32_10((unsigned)seed, (unsigned)(seed >> 32), (unsigned)ge, (unsigned)(ge >> 32), t, 0u, r);
+  // two uniforms in [0,1) with 32 random bits each -> delta in [-0.01, 0.01)
+  double u0 = r[0] * (1.0 / 4294967296.0), u1 = r[1] * (1.0 / 4294967296.0);
+  double x = des[e] + (0.02 * u0 - 0.01), y = des[(size_t)stride + e] + (0.02 * u1 - 0.01), z = des[2 * (size_t)stride + e];
+  des[e] = x; des[(size_t)stride + e] = y;
+  double* a = actions + (size_t)e * 7;
+  a[0] = x; a[1] = y; a[2] = z; a[3] = 0; a[4] = 1; a[5] = 0; a[6] = 0;
+}
+__global__ void k_count_metrics(const unsigned char* __restrict__ done, const unsigned* __restrict__ flags, long long* __restrict__ counts, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  if (done[e]) atomicAdd((unsigned long long*)&counts[0], 1ull);
+  if (flags[e] & F_SUCCESS) {
+    atomicAdd((unsigned long long*)&counts[1], 1ull);
+    atomicAdd((unsigned long long*)&counts[2 + (flags[e] & F_MODE_MASK)], 1ull);
+  }
+}
+
+}  // namespace d3il
+
+// ====================================================================== C ABI
+using namespace d3il;
+
+struct d3il_handle_s {
+  int task_id, n, stride, device;
+  PandaConsts hc;          // host copy
+  PandaConsts* dc;         // device copy
+  double* d_init_qpos;
+  bool started;
+  d3il_buffers buf;
+  bool fast, timing;
+  hipEvent_t ev0, ev1;
+  bool ev_valid;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(D3IL_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" {
+
+const char* d3il_last_error(void) { return g_err.c_str(); }
+size_t d3il_blob_sizeof(void) { return sizeof(d3il_model_blob); }
+int d3il_version(void) { return 1; }
+
+int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, size_t blob_len, d3il_handle* out) {
+  if (!out || !model_blob) return fail(D3IL_EINVAL, "d3il_create: null argument");
+  *out = nullptr;
+  if (blob_len != sizeof(d3il_model_blob)) return fail(D3IL_EBLOB, "d3il_create: blob size mismatch");
+  if (n_envs <= 0) return fail(D3IL_EINVAL, "d3il_create: n_envs must be positive");
+  const d3il_model_blob& m = *(const d3il_model_blob*)model_blob;
+  if (task_id != D3IL_TASK_AVOIDING || m.task_id != D3IL_TASK_AVOIDING) return fail(D3IL_EUNSUPPORTED, "d3il_create: only the Avoiding task is implemented in this build");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(D3IL_ENODEVICE, "d3il_create: no HIP device available (there is no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(D3IL_ENODEVICE, "d3il_create: device_id out of range");
+  HIPCHK(hipSetDevice(device_id));
+  d3il_handle_s* h = new d3il_handle_s();
+  std::memset(&h->buf, 0, sizeof h->buf);
+  const char* err = "";
+  int rc = build_panda_consts(m, h->hc, &err);
+  if (rc) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  finish_invweights(h->hc);
+  h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
+  h->started = false; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
+  size_t S = (size_t)h->stride;
+  d3il_buffers& b = h->buf;
+  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = 2; b.action_dim = 7;
+  HIPCHK(hipMalloc(&h->dc, sizeof(PandaConsts)));
+  HIPCHK(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
+  HIPCHK(hipMalloc(&b.obs, S * 2 * sizeof(float)));
+  HIPCHK(hipMalloc(&b.done, S)); HIPCHK(hipMalloc(&b.success, S));
+  HIPCHK(hipMalloc(&b.mode, S * sizeof(uint16_t)));
+  HIPCHK(hipMalloc(&b.state, S * D3IL_STATE_F64 * sizeof(double)));
+  HIPCHK(hipMalloc(&b.flags, S * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&b.step_count, S * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&b.policy_des, S * 3 * sizeof(double)));
+  HIPCHK(hipMemset(b.obs, 0, S * 2 * sizeof(float))); HIPCHK(hipMemset(b.done, 0, S)); HIPCHK(hipMemset(b.success, 0, S));
+  HIPCHK(hipMemset(b.mode, 0, S * sizeof(uint16_t))); HIPCHK(hipMemset(b.state, 0, S * D3IL_STATE_F64 * sizeof(double)));
+  HIPCHK(hipMemset(b.flags, 0, S * sizeof(uint32_t))); HIPCHK(hipMemset(b.step_count, 0, S * sizeof(int32_t)));
+  HIPCHK(hipMemset(b.policy_des, 0, S * 3 * sizeof(double)));
+  HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+  *out = h;
+  return D3IL_OK;
+}
+
+int d3il_destroy(d3il_handle h) {
+  if (!h) return fail(D3IL_EINVAL, "d3il_destroy: null handle");
+  (void)hipSetDevice(h->device);
+  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des};
+  for (void* p : ptrs) (void)hipFree(p);
+  (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
+  delete h;
+  return D3IL_OK;
+}
+
+int d3il_start(d3il_handle h, const double* init_qpos7) {
+  if (!h || !init_qpos7) return fail(D3IL_EINVAL, "d3il_start: null argument");
+  for (int k = 0; k < 7; k++) if (!(init_qpos7[k] == init_qpos7[k])) return fail(D3IL_EINVAL, "d3il_start: init_qpos contains NaN");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(h->d_init_qpos, init_qpos7, 7 * sizeof(double), hipMemcpyHostToDevice));
+  h->started = true;
+  return D3IL_OK;
+}
+
+int d3il_reset(d3il_handle h, const uint8_t* env_mask, const float* contexts, void* stream) {
+  if (!h) return fail(D3IL_EINVAL, "d3il_reset: null handle");
+  if (!h->started) return fail(D3IL_ESTATE, "d3il_reset: d3il_start() has not been called (env.start() before env.reset())");
+  if (contexts) return fail(D3IL_EUNSUPPORTED, "d3il_reset: the Avoiding task takes no contexts");
+  HIPCHK(hipSetDevice(h->device));
+  d3il_buffers& b = h->buf;
+  hipLaunchKernelGGL(k_avoiding_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->dc, h->d_init_qpos, env_mask, b.state, b.flags,
+                     b.step_count, b.obs, b.done, b.success, b.mode, h->n, h->stride);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+
+int d3il_step(d3il_handle h, const double* actions, void* stream) {
+  if (!h || !actions) return fail(D3IL_EINVAL, "d3il_step: null argument");
+  if (!h->started) return fail(D3IL_ESTATE, "d3il_step: d3il_start() has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  d3il_buffers& b = h->buf;
+  hipStream_t s = (hipStream_t)stream;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+  if (h->fast)
+    hipLaunchKernelGGL(k_avoiding_step<true>, dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                       b.success, b.mode, h->n, h->stride);
+  else
+    hipLaunchKernelGGL(k_avoiding_step<false>, dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                       b.success, b.mode, h->n, h->stride);
+  HIPCHK(hipGetLastError());
+  if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+  return D3IL_OK;
+}
+
+int d3il_get_buffers(d3il_handle h, d3il_buffers* out) {
+  if (!h || !out) return fail(D3IL_EINVAL, "d3il_get_buffers: null argument");
+  *out = h->buf;
+  return D3IL_OK;
+}
+
+int d3il_get_state(d3il_handle h, double* state, uint32_t* flags, int32_t* steps) {
+  if (!h) return fail(D3IL_EINVAL, "d3il_get_state: null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (state) HIPCHK(hipMemcpy2D(state, (size_t)h->n * 8, h->buf.state, (size_t)h->stride * 8, (size_t)h->n * 8, D3IL_STATE_F64, hipMemcpyDeviceToHost));
+  if (flags) HIPCHK(hipMemcpy(flags, h->buf.flags, (size_t)h->n * 4, hipMemcpyDeviceToHost));
+  if (steps) HIPCHK(hipMemcpy(steps, h->buf.step_count, (size_t)h->n * 4, hipMemcpyDeviceToHost));
+  return D3IL_OK;
+}
+int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, const int32_t* steps) {
+  if (!h) return fail(D3IL_EINVAL, "d3il_set_state: null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (state) HIPCHK(hipMemcpy2D(h->buf.state, (size_t)h->stride * 8, state, (size_t)h->n * 8, (size_t)h->n * 8, D3IL_STATE_F64, hipMemcpyHostToDevice));
+  if (flags) HIPCHK(hipMemcpy(h->buf.flags, flags, (size_t)h->n * 4, hipMemcpyHostToDevice));
+  if (steps) HIPCHK(hipMemcpy(h->buf.step_count, steps, (size_t)h->n * 4, hipMemcpyHostToDevice));
+  return D3IL_OK;
+}
+
+int d3il_policy_begin(d3il_handle h, const uint8_t* env_mask, void* stream) {
+  if (!h) return fail(D3IL_EINVAL, "d3il_policy_begin: null handle");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_policy_begin, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_mask, h->buf.state, h->buf.policy_des, h->n, h->stride);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, void* stream) {
+  if (!h || !actions) return fail(D3IL_EINVAL, "d3il_policy_action: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_policy_action, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->buf.policy_des, actions, (unsigned long long)seed,
+                     (unsigned long long)env_offset, t, h->n, h->stride);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream) {
+  if (!h || !out_counts_device) return fail(D3IL_EINVAL, "d3il_count_metrics: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemsetAsync(out_counts_device, 0, (2 + 512) * sizeof(int64_t), (hipStream_t)stream));
+  hipLaunchKernelGGL(k_count_metrics, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->buf.done, h->buf.flags, (long long*)out_counts_device, h->n);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_set_timing(d3il_handle h, int enabled) {
+  if (!h) return fail(D3IL_EINVAL, "d3il_set_timing: null handle");
+  h->timing = enabled != 0; h->ev_valid = false;
+  return D3IL_OK;
+}
+int d3il_last_step_ms(d3il_handle h, float* ms) {
+  if (!h || !ms) return fail(D3IL_EINVAL, "d3il_last_step_ms: null argument");
+  if (!h->ev_valid) return fail(D3IL_ESTATE, "d3il_last_step_ms: timing not enabled or no step recorded");
+  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return D3IL_OK;
+}
+int d3il_set_option(d3il_handle h, const char* name, int value) {
+  if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
+  if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
+  return fail(D3IL_EINVAL, std::string("d3il_set_option: unknown option ") + name);
+}
+
+}  // extern "C"

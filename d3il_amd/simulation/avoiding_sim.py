@@ -1,0 +1,96 @@
+"""Batched counterpart of ``Avoiding_Sim`` (simulation/avoiding_sim.py:20-144).
+
+The reference spawns ``n_cores`` processes with one MuJoCo env each and rolls ``n_trajectories`` episodes
+out sequentially; here every rollout is one lane of the GPU environment batch and all of them advance
+together.  The rollout loop (obs || desired-xy concat, delta -> absolute action, frozen z and quaternion,
+avoiding_sim.py:51-66) and the metric tail (:126-144) are kept; agents are called once per step on the whole
+batch through ``predict_batch`` when they provide it, else row by row through the reference's
+``predict(np.ndarray) -> np.ndarray[1, 2]`` protocol (agents/base_agent.py:110-122).
+
+Multi-GPU: launched one process per GPU (torch.distributed, backend nccl = RCCL); every rank rolls out its
+contiguous shard of rollouts and the integer success / mode-histogram counts are summed with ONE all-reduce
+(int64, 514 elements), so the result is bit-exact and independent of the number of ranks.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import torch
+
+from ..distributed import reduce_counts, shard_range, world_info
+from ..envs.avoiding import ObstacleAvoidanceVecEnv
+from .base_sim import BaseSim
+from .metrics import avoiding_metrics
+
+log = logging.getLogger(__name__)
+
+
+class Avoiding_Sim(BaseSim):
+    def __init__(self, seed: int, device: str, render: bool, n_cores: int = 1, n_trajectories: int = 30,
+                 max_steps_per_episode: int = 250):
+        super().__init__(seed, device, render, n_cores)
+        self.n_trajectories = n_trajectories
+        self.max_steps_per_episode = max_steps_per_episode
+        self.last_rollout = None
+
+    def _predict(self, agent, obs4: torch.Tensor) -> torch.Tensor:
+        if hasattr(agent, "predict_batch"):
+            out = agent.predict_batch(obs4)
+            return out.to(device=obs4.device, dtype=torch.float64).reshape(obs4.shape[0], 2)
+        rows = obs4.detach().cpu().numpy()
+        acts = np.stack([np.asarray(agent.predict(r)).reshape(-1)[:2] for r in rows])
+        return torch.as_tensor(acts, dtype=torch.float64, device=obs4.device)
+
+    def test_agent(self, agent):
+        log.info("Starting trained model evaluation")
+        rank, world = world_info()
+        lo, hi = shard_range(self.n_trajectories, rank, world)
+        n = hi - lo
+        dev = torch.device(self.device)
+        env = ObstacleAvoidanceVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
+        env.start()
+        if hasattr(agent, "reset"):
+            agent.reset()
+        obs = env.reset()
+        pred_action = env.robot_state().clone()                       # TCP xyz, avoiding_sim.py:53
+        fixed_z = pred_action[:, 2:3].clone()
+        des_xy = pred_action[:, :2].clone()
+        quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
+        finished = torch.zeros(n, dtype=torch.bool, device=dev)
+        mode_code = torch.zeros(n, dtype=torch.int32, device=dev)
+        success = torch.zeros(n, dtype=torch.bool, device=dev)
+        # the reference stores c_pos in a 150-row buffer and crashes on longer episodes (avoiding_sim.py:73,87);
+        # this buffer is sized max_steps + 1 instead (documented divergence)
+        c_pos = torch.zeros(n, self.max_steps_per_episode + 1, 2, dtype=torch.float64, device=dev)
+        c_pos[:, 0] = env.robot_state()[:, :2]
+        n_pos = torch.ones(n, dtype=torch.int64, device=dev)
+        for t in range(self.max_steps_per_episode):
+            # avoiding_sim.py:61: np.concatenate((f64 desired xy, f32 obs)) -> f64[4]
+            obs4 = torch.cat((des_xy, obs.to(torch.float64)), dim=1)
+            delta = self._predict(agent, obs4)
+            des_new = delta + obs4[:, :2]                              # avoiding_sim.py:64
+            des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
+            action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
+            obs, _, done, (mode, succ) = env.step(action)
+            active = ~finished
+            c_pos[torch.arange(n, device=dev)[active], n_pos[active]] = env.robot_state()[active, :2]
+            n_pos += active.to(torch.int64)
+            newly = active & done.bool()
+            mode_code = torch.where(newly, mode.to(torch.int32), mode_code)
+            success = torch.where(newly, succ.bool(), success)
+            finished |= done.bool()
+            if bool(finished.all()):
+                break
+        counts = torch.zeros(514, dtype=torch.int64, device=dev)
+        counts[0] = n
+        counts[1] = success.sum()
+        counts[2:] = torch.bincount(mode_code[success].to(torch.int64), minlength=512)
+        reduce_counts(counts)
+        c = counts.cpu().numpy()
+        success_rate, entropy = avoiding_metrics(int(c[0]), int(c[1]), c[2:])
+        self.last_rollout = dict(success=success, mode_code=mode_code, c_pos=c_pos, n_pos=n_pos, counts=c, shard=(lo, hi))
+        log.info("Successrate %s entropy %s", success_rate, entropy)
+        successes = success.to(torch.float32)
+        env.close()
+        return successes, entropy

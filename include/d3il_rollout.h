@@ -1,0 +1,119 @@
+/* d3il_rollout.h - C ABI of libd3il_rollout.so, the MI355X-native batched replacement for the D3IL
+ * evaluation env.step() path.  Plain C, plain pointers and sizes; no torch types.
+ *
+ * The reference has no FFI layer: its operator boundary is the Gym-style Python protocol of the task
+ * envs.  Each entry point below names the reference interface it replaces (paths relative to
+ * /root/reference); the Python mirror of those classes lives in d3il_amd/envs and d3il_amd/simulation.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative D3IL_E* code on failure; d3il_last_error() gives
+ *    the message of the calling thread's last failure.
+ *  - the library owns all device memory it hands out through d3il_get_buffers(); the caller owns the
+ *    action buffer.  Device pointers are valid until d3il_destroy().
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Kernels are only enqueued;
+ *    the caller synchronises (PyTorch: pass torch.cuda.current_stream().cuda_stream so that
+ *    agent.predict() consumes observations in place without extra synchronisation).
+ *  - one host thread per handle; calls on one handle are not re-entrant.
+ *  - there is NO CPU fallback: d3il_create fails with D3IL_ENODEVICE when no HIP device is usable.
+ *
+ * State layout (device, f64): structure-of-arrays [D3IL_STATE_F64][stride], stride = n_envs rounded up
+ * to 64, field order D3IL_STATE_*; one lane owns one environment, loads/stores are coalesced.
+ */
+#ifndef D3IL_ROLLOUT_H
+#define D3IL_ROLLOUT_H
+#include <stddef.h>
+#include <stdint.h>
+#include "d3il_model_blob.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct d3il_handle_s* d3il_handle;
+
+enum {
+  D3IL_OK = 0, D3IL_EINVAL = -1, D3IL_EBLOB = -2, D3IL_ENODEVICE = -3, D3IL_EHIP = -4, D3IL_EUNSUPPORTED = -5,
+  D3IL_ESTATE = -6
+};
+
+/* f64 state fields per environment, in SoA order */
+enum {
+  D3IL_STATE_QPOS = 0,    /* 9: 7 arm joints, 2 fingers */
+  D3IL_STATE_QVEL = 9,    /* 9 */
+  D3IL_STATE_BIAS = 18,   /* 7: qfrc_bias of the last forward pass (gravity compensation is one sub-step stale) */
+  D3IL_STATE_TCP = 25,    /* 3: TCP xpos of the last forward pass (what MjRobot.receiveState reads) */
+  D3IL_STATE_IK_Q = 28,   /* 7: CartPosQuatImpedenceController.old_q */
+  D3IL_STATE_IK_QD = 35,  /* 7: CartPosQuatImpedenceController.old_des_joint_vel */
+  D3IL_STATE_F64 = 42
+};
+/* bits of the per-environment u32 flag word */
+enum {
+  D3IL_FLAG_MODE_MASK = 0x1FF,       /* 9 sticky mode bits, avoiding.py:173-202 */
+  D3IL_FLAG_L1 = 1 << 9, D3IL_FLAG_L2 = 1 << 10, D3IL_FLAG_L3 = 1 << 11,
+  D3IL_FLAG_TERMINATED = 1 << 12, D3IL_FLAG_SUCCESS = 1 << 13, D3IL_FLAG_ROD_CONTACT = 1 << 14,
+  D3IL_FLAG_IK_VALID = 1 << 15, D3IL_FLAG_SOLVER_FAIL = 1 << 16, D3IL_FLAG_MULTI_CONTACT = 1 << 17
+};
+
+typedef struct d3il_buffers {
+  int32_t n_envs, stride, obs_dim, action_dim;
+  float* obs;            /* [n_envs][obs_dim] f32, what get_observation() returns (avoiding.py:117-119) */
+  uint8_t* done;         /* [n_envs] result of is_finished() of the last step (gym_env_wrapper.py:124-137) */
+  uint8_t* success;      /* [n_envs] info[1] (avoiding.py:171) */
+  uint16_t* mode;        /* [n_envs] 9-bit mode encoding, bit i = mode_encoding[i] (info[0]) */
+  double* state;         /* [D3IL_STATE_F64][stride] */
+  uint32_t* flags;       /* [stride] */
+  int32_t* step_count;   /* [stride] env_step_counter */
+  double* policy_des;    /* [3][stride] random-policy harness state: desired x, y and fixed z */
+} d3il_buffers;
+
+/* Replaces: env construction + scene.start() (avoiding.py:52-92, core/Scene.py:95-108,
+ * mj_scene_parser.py:36-53 building MjModel).  model_blob is a d3il_model_blob. */
+int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, size_t blob_len, d3il_handle* out);
+int d3il_destroy(d3il_handle h);
+
+/* Replaces the part of env.start() that survives it: robot.init_qpos (avoiding.py:121-166).
+ * The offline IK that produces init_qpos is host-side, cold (d3il_amd/controllers/offline_ik.py). */
+int d3il_start(d3il_handle h, const double* init_qpos7);
+
+/* Replaces env.reset() (avoiding.py:248-262).  env_mask: device u8[n_envs] (non-zero = reset that env) or
+ * NULL for all.  contexts: unused for Avoiding (NULL). */
+int d3il_reset(d3il_handle h, const uint8_t* env_mask, const float* contexts, void* stream);
+
+/* Replaces env.step(action) (avoiding.py:168-171 over gym_env_wrapper.py:45-100): n_substeps fused physics
+ * sub-steps.  actions: device f64[n_envs][7] = desired TCP (x, y, z, qw, qx, qy, qz), the array the harness
+ * builds at avoiding_sim.py:64-66. */
+int d3il_step(d3il_handle h, const double* actions, void* stream);
+
+int d3il_get_buffers(d3il_handle h, d3il_buffers* out);
+
+/* Golden replay / checkpointing: copies the SoA state + flags + step counters to/from host memory
+ * (state: f64[D3IL_STATE_F64][n_envs] packed with stride n_envs; flags u32[n_envs]; steps i32[n_envs]). */
+int d3il_get_state(d3il_handle h, double* state, uint32_t* flags, int32_t* steps);
+int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, const int32_t* steps);
+
+/* Device-side random-policy harness of BASELINE config 2, counterpart of the rollout loop in
+ * simulation/avoiding_sim.py:51-66 with agent.predict := U(-0.01, 0.01)^2 (Philox4x32-10, key = seed,
+ * counter = (env_offset + env, t)).  policy_begin latches des = TCP xyz for masked envs (avoiding_sim.py:53-54);
+ * policy_action advances des_xy and writes actions[n_envs][7]. */
+int d3il_policy_begin(d3il_handle h, const uint8_t* env_mask, void* stream);
+int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, void* stream);
+
+/* Integer metric counts on device: out_counts i64[2 + 512] = {n_done, n_success, histogram of 9-bit mode codes
+ * among successful envs}; input to the cross-GPU reduction (one RCCL all-reduce, done by the Python layer)
+ * and to success-rate / entropy (avoiding_sim.py:128-135). */
+int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream);
+
+/* Timing of the last d3il_step kernel launch on its own stream (HIP events recorded around the launch when
+ * enabled); used by bench.py for the roofline figure. */
+int d3il_set_timing(d3il_handle h, int enabled);
+int d3il_last_step_ms(d3il_handle h, float* ms);
+
+int d3il_set_option(d3il_handle h, const char* name, int value);  /* "ik_fast_path" (default 1) */
+const char* d3il_last_error(void);
+size_t d3il_blob_sizeof(void);
+int d3il_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def avoiding_blob():
+    from d3il_amd.model import blob
+    return blob.load("avoiding")
+
+
+@pytest.fixture(scope="session")
+def avoiding_json():
+    from d3il_amd.model import blob
+    return blob.load_json("avoiding")
+
+
+@pytest.fixture(scope="session")
+def init_qpos():
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_offline_ik.npz"))
+    return g["avoiding__traj_last"].copy()
+
+
+@pytest.fixture()
+def oracle(avoiding_blob):
+    from oracle.oracle import Oracle
+    return Oracle(avoiding_blob)
+
+
+@pytest.fixture(scope="session")
+def hostcheck(avoiding_blob):
+    from tests.hostcheck.hostcheck import HostCheck
+    return HostCheck(avoiding_blob)

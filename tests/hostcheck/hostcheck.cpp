@@ -1,0 +1,84 @@
+// hostcheck.cpp - TEST-ONLY host build of the kernels' per-environment math (d3il_amd/csrc/panda_step.h).
+// Lets the CPU test-suite compare the exact device formulation against the oracle without a GPU.
+// It is NOT part of the product: libd3il_rollout.so never links or calls this file, and the product
+// fails loudly when no HIP device is present.
+#include <cstdlib>
+#include <cstring>
+#include "../../d3il_amd/csrc/panda_step.h"
+
+using namespace d3il;
+
+static void unpack(const double* s, const int* f, EnvState& st) {
+  int k = 0;
+  for (int i = 0; i < NDOF; i++) st.q[i] = s[k++];
+  for (int i = 0; i < NDOF; i++) st.v[i] = s[k++];
+  for (int i = 0; i < NARM; i++) st.bias[i] = s[k++];
+  for (int i = 0; i < 3; i++) st.tcp[i] = s[k++];
+  for (int i = 0; i < NARM; i++) st.ikq[i] = s[k++];
+  for (int i = 0; i < NARM; i++) st.ikqd[i] = s[k++];
+  st.flags = (unsigned)f[0]; st.step = f[1];
+}
+static void pack(const EnvState& st, double* s, int* f) {
+  int k = 0;
+  for (int i = 0; i < NDOF; i++) s[k++] = st.q[i];
+  for (int i = 0; i < NDOF; i++) s[k++] = st.v[i];
+  for (int i = 0; i < NARM; i++) s[k++] = st.bias[i];
+  for (int i = 0; i < 3; i++) s[k++] = st.tcp[i];
+  for (int i = 0; i < NARM; i++) s[k++] = st.ikq[i];
+  for (int i = 0; i < NARM; i++) s[k++] = st.ikqd[i];
+  f[0] = (int)st.flags; f[1] = st.step;
+}
+
+extern "C" {
+void* hc_create(const d3il_model_blob* blob, const char** err) {
+  PandaConsts* c = (PandaConsts*)std::malloc(sizeof(PandaConsts));
+  static const char* e = "";
+  int rc = build_panda_consts(*blob, *c, &e);
+  if (rc) { *err = e; std::free(c); return nullptr; }
+  finish_invweights(*c);
+  return c;
+}
+void hc_destroy(void* c) { std::free(c); }
+int hc_sizeof_consts() { return (int)sizeof(PandaConsts); }
+void hc_get_consts(const void* c, double* dof_invw, double* rod_invw, double* masses, double* coms) {
+  const PandaConsts& p = *(const PandaConsts*)c;
+  std::memcpy(dof_invw, p.dof_invweight0, sizeof p.dof_invweight0); *rod_invw = p.rod_invweight0;
+  std::memcpy(masses, p.mass, sizeof p.mass); std::memcpy(coms, p.com, sizeof p.com);
+}
+void hc_dynamics(const void* c, const double* q, const double* v, double* M81, double* bias, double* tcp) {
+  const PandaConsts& p = *(const PandaConsts*)c;
+  DynOut d; dynamics(p, q, v, d);
+  for (int r = 0; r < NDOF; r++) for (int k = 0; k < NDOF; k++) M81[r * NDOF + k] = d.M[r >= k ? tri(r, k) : tri(k, r)];
+  std::memcpy(bias, d.bias, sizeof d.bias);
+  double t[3]; mulE(d.R7, p.tcp7, t); for (int k = 0; k < 3; k++) tcp[k] = d.p7[k] + t[k];
+}
+void hc_ik_fk(const void* c, const double* q, double* pos, double* quat, double* J42) {
+  const PandaConsts& p = *(const PandaConsts*)c;
+  double R[9], ax[NARM][3], og[NARM][3];
+  ik_chain(p, q, pos, R, ax, og); mat2quat(R, quat);
+  for (int k = 0; k < NARM; k++) { double d[3] = {pos[0] - og[k][0], pos[1] - og[k][1], pos[2] - og[k][2]}, cr[3]; cross3(ax[k], d, cr);
+    for (int r = 0; r < 3; r++) { J42[r * NARM + k] = cr[r]; J42[(3 + r) * NARM + k] = ax[k][r]; } }
+}
+// one controller call: returns PD torque (without gravity compensation), updates ikq/ikqd/flags
+void hc_ik_control(const void* c, const double* setpoint, const double* cur_q, const double* cur_v, double* ikq, double* ikqd, int* flags, int fast, double* tau) {
+  const PandaConsts& p = *(const PandaConsts*)c;
+  unsigned f = (unsigned)*flags;
+  double n = std::sqrt(setpoint[3] * setpoint[3] + setpoint[4] * setpoint[4] + setpoint[5] * setpoint[5] + setpoint[6] * setpoint[6]);
+  double dq[4] = {setpoint[3] / n, setpoint[4] / n, setpoint[5] / n, setpoint[6] / n};
+  if (fast) ik_update<true>(p, setpoint, dq, cur_q, f, ikq, ikqd); else ik_update<false>(p, setpoint, dq, cur_q, f, ikq, ikqd);
+  for (int k = 0; k < NARM; k++) tau[k] = p.pd_p[k] * (ikq[k] - cur_q[k]) + p.pd_d[k] * (ikqd[k] - cur_v[k]);
+  *flags = (int)f;
+}
+void hc_physics_substep(const void* c, double* s, int* f, const double* tau, const double* ffing) {
+  EnvState st; unpack(s, f, st); physics_substep(*(const PandaConsts*)c, st, tau, ffing); pack(st, s, f);
+}
+void hc_env_reset(const void* c, const double* init_qpos, double* s, int* f, float* obs) {
+  EnvState st; std::memset(&st, 0, sizeof st);
+  env_reset(*(const PandaConsts*)c, st, init_qpos, obs); pack(st, s, f);
+}
+void hc_env_step(const void* c, double* s, int* f, const double* action, float* obs, unsigned char* done, int fast) {
+  EnvState st; unpack(s, f, st);
+  if (fast) env_step<true>(*(const PandaConsts*)c, st, action, obs, done); else env_step<false>(*(const PandaConsts*)c, st, action, obs, done);
+  pack(st, s, f);
+}
+}

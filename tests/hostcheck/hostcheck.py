@@ -1,0 +1,79 @@
+"""ctypes loader for the TEST-ONLY host build of the kernel math (tests/hostcheck/hostcheck.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libd3il_hostcheck.so")
+    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.hc_create.restype = C.c_void_p
+        _LIB.hc_sizeof_consts.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HostCheck:
+    def __init__(self, blob):
+        self.L = lib()
+        err = C.c_char_p()
+        self.h = C.c_void_p(self.L.hc_create(C.byref(blob), C.byref(err)))
+        if not self.h:
+            raise RuntimeError("hc_create: %s" % (err.value.decode() if err.value else "?"))
+
+    def consts(self):
+        a, b, m, c = np.zeros(9), np.zeros(1), np.zeros(7), np.zeros((7, 3))
+        self.L.hc_get_consts(self.h, _p(a), _p(b), _p(m), _p(c))
+        return a, b[0], m, c
+
+    def dynamics(self, q, v):
+        q, v = np.ascontiguousarray(q, float), np.ascontiguousarray(v, float)
+        M, b, t = np.zeros((9, 9)), np.zeros(9), np.zeros(3)
+        self.L.hc_dynamics(self.h, _p(q), _p(v), _p(M), _p(b), _p(t))
+        return M, b, t
+
+    def ik_fk(self, q):
+        q = np.ascontiguousarray(q, float)
+        pos, quat, J = np.zeros(3), np.zeros(4), np.zeros((6, 7))
+        self.L.hc_ik_fk(self.h, _p(q), _p(pos), _p(quat), _p(J))
+        return pos, quat, J
+
+    def ik_control(self, setpoint, cur_q, cur_v, ikq, ikqd, flags, fast):
+        sp, cq, cv = (np.ascontiguousarray(x, float) for x in (setpoint, cur_q, cur_v))
+        f = C.c_int(flags)
+        tau = np.zeros(7)
+        self.L.hc_ik_control(self.h, _p(sp), _p(cq), _p(cv), _p(ikq), _p(ikqd), C.byref(f), int(fast), _p(tau))
+        return tau, f.value
+
+    def physics_substep(self, s, f, tau, ff):
+        tau, ff = np.ascontiguousarray(tau, float), np.ascontiguousarray(ff, float)
+        self.L.hc_physics_substep(self.h, _p(s), _p(f), _p(tau), _p(ff))
+
+    def env_reset(self, init_qpos):
+        init_qpos = np.ascontiguousarray(init_qpos, float)
+        s, f, obs = np.zeros(42), np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.float32)
+        self.L.hc_env_reset(self.h, _p(init_qpos), _p(s), _p(f), _p(obs))
+        return s, f, obs
+
+    def env_step(self, s, f, action, fast=True):
+        action = np.ascontiguousarray(action, float)
+        obs, done = np.zeros(2, dtype=np.float32), np.zeros(1, dtype=np.uint8)
+        self.L.hc_env_step(self.h, _p(s), _p(f), _p(action), _p(obs), _p(done), int(fast))
+        return obs, bool(done[0])

@@ -1,0 +1,170 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the committed
+golden fixtures.  Tolerance: the north star asks for 1e-4 on trajectory state; oracle and kernels are both
+f64 and agree to ~1e-10, the tests assert 1e-8.  Integer outputs (done, success, mode, counters) bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def lib_loaded():
+    from d3il_amd import capi
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return capi.load()      # raises loudly if the HIP extension is missing
+
+
+def _env(n, **kw):
+    from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
+    return ObstacleAvoidanceVecEnv(n, device=0, **kw)
+
+
+def test_start_computes_reference_init_qpos(lib_loaded):
+    env = _env(64)
+    q, iters, err = env.start()
+    g = np.load(os.path.join(G, "ref_offline_ik.npz"))
+    assert iters == int(g["avoiding__iters"])
+    np.testing.assert_allclose(q, g["avoiding__traj_last"], atol=1e-12)
+    env.close()
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("name", ["random", "collide", "succeed", "zigzag"])
+def test_golden_rollouts(lib_loaded, name, fast):
+    """Replay the committed oracle rollouts: every env of the batch gets the same actions."""
+    g = np.load(os.path.join(G, "oracle_avoiding_rollout.npz"))
+    n = 128
+    env = _env(n)
+    env.set_option("ik_fast_path", fast)
+    env.set_init_qpos(g["init_qpos"])
+    obs = env.reset()
+    torch.cuda.synchronize()
+    st, fl, sc = env.get_state()
+    np.testing.assert_allclose(st[:, 0], g[name + "__states"][0], atol=TOL)
+    assert np.array_equal(obs[0].cpu().numpy(), g[name + "__obs"][0])
+    acts = g[name + "__actions"]
+    for t in range(len(acts)):
+        a = torch.as_tensor(np.tile(acts[t], (n, 1)), dtype=torch.float64, device=env.device).contiguous()
+        obs, _, done, (mode, succ) = env.step(a)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        for e in (0, 63, 64, n - 1):
+            np.testing.assert_allclose(st[:, e], g[name + "__states"][t + 1], atol=TOL, err_msg="%s step %d env %d" % (name, t, e))
+        assert np.array_equal(obs[5].cpu().numpy(), g[name + "__obs"][t + 1])
+        assert bool(done[5]) == bool(g[name + "__done"][t + 1]) and bool(succ[5]) == bool(g[name + "__succ"][t + 1])
+        code = int((g[name + "__mode"][t + 1].astype(np.int64) * (1 << np.arange(9))).sum())
+        assert int(mode[5]) == code
+        assert (sc == t + 1).all() and not (fl & (1 << 16)).any()
+        assert (st == st[:, :1]).all()        # identical inputs -> bit-identical lanes
+    env.close()
+
+
+def test_random_policy_rollout_vs_oracle(lib_loaded, init_qpos):
+    """Device-side random policy (Philox) on 256 envs for a full episode with auto-reset; 6 envs are replayed on the
+    oracle with the actions read back from the device."""
+    from oracle.oracle import Oracle
+    n, T = 256, 260
+    env = _env(n)
+    env.set_init_qpos(init_qpos)
+    env.reset(); env.policy_begin()
+    actions = torch.zeros(n, 7, dtype=torch.float64, device=env.device)
+    picks = [0, 1, 77, 128, 200, 255]
+    orcs = []
+    for e in picks:
+        o = Oracle(env.blob); o.env_start(init_qpos); o.env_reset(); orcs.append(o)
+    n_done = 0
+    for t in range(T):
+        env.policy_action(42, 0, t, actions)
+        obs, _, done, (mode, succ) = env.step(actions)
+        torch.cuda.synchronize()
+        a_host = actions.cpu().numpy()
+        st, fl, sc = env.get_state()
+        d_host = done.cpu().numpy().astype(bool)
+        for o, e in zip(orcs, picks):
+            ob, dn, md, su = o.env_step(a_host[e])
+            so, fo = o.env_state()
+            np.testing.assert_allclose(st[:, e], so, atol=TOL, err_msg="t=%d env=%d" % (t, e))
+            assert dn == d_host[e] and np.array_equal(ob, obs[e].cpu().numpy())
+            assert int(mode[e]) == int((md.astype(np.int64) * (1 << np.arange(9))).sum()) and bool(succ[e]) == su
+            if dn:
+                o.env_reset()
+        n_done += int(d_host.sum())
+        if d_host.any():                      # auto-reset finished envs, re-latch the harness' desired pose
+            env.reset(done); env.policy_begin(done)
+            torch.cuda.synchronize()
+            st2, fl2, sc2 = env.get_state()
+            assert (sc2[d_host] == 0).all() and (sc2[~d_host] == sc[~d_host]).all()
+            assert np.array_equal(st2[:, ~d_host], st[:, ~d_host])     # masked reset leaves the others untouched
+    assert n_done >= n        # every env finished at least once (250-step cap)
+    env.close()
+
+
+def test_full_size_properties(lib_loaded, init_qpos):
+    """BASELINE size (4096 envs): size-independent properties - determinism, batch-composition invariance,
+    fast-path == eigen-path, state get/set round trip, sanity of outputs."""
+    n, T = 4096, 12
+
+    def run(n_envs, offset, fast=1, keep=None):
+        env = _env(n_envs)
+        env.set_option("ik_fast_path", fast)
+        env.set_init_qpos(init_qpos)
+        env.reset(); env.policy_begin()
+        a = torch.zeros(n_envs, 7, dtype=torch.float64, device=env.device)
+        for t in range(T):
+            env.policy_action(42, offset, t, a)
+            env.step(a)
+        torch.cuda.synchronize()
+        out = env.get_state() + (env.obs.cpu().numpy().copy(), env.done.cpu().numpy().copy())
+        if keep is not None:
+            keep.append(env)
+        else:
+            env.close()
+        return out
+
+    keep = []
+    s1, f1, c1, o1, d1 = run(n, 0, keep=keep)
+    s2, f2, c2, o2, d2 = run(n, 0)
+    assert np.array_equal(s1, s2) and np.array_equal(f1, f2) and np.array_equal(o1, o2)          # deterministic
+    s3, f3, c3, o3, d3 = run(1024, 2048)                                                          # shard of the same global envs
+    assert np.array_equal(s3, s1[:, 2048:3072]) and np.array_equal(f3, f1[2048:3072])
+    s4, f4, c4, o4, d4 = run(n, 0, fast=0)
+    np.testing.assert_allclose(s4, s1, atol=1e-9)
+    assert np.isfinite(s1).all() and (c1 == T).all() and not (f1 & (1 << 16)).any()
+    assert len(np.unique(s1[25])) > 4000                                                           # envs really differ
+    env = keep[0]
+    env.set_state(s2, f2, c2)
+    s5, f5, c5 = env.get_state()
+    assert np.array_equal(s5, s2) and np.array_equal(f5, f2) and np.array_equal(c5, c2)
+    counts = env.count_metrics().cpu().numpy()
+    assert counts[0] == int(d1.sum()) and counts[1] == int(((f1 >> 13) & 1).sum()) and counts[2:].sum() == counts[1]
+    env.close()
+
+
+def test_sim_harness_end_to_end(lib_loaded):
+    """Avoiding_Sim.test_agent with a scripted batch agent: straight line through the left gap -> every rollout
+    succeeds with the same mode code; metrics follow the reference formulas."""
+    from d3il_amd.simulation.avoiding_sim import Avoiding_Sim
+
+    class LineAgent:
+        def reset(self):
+            pass
+
+        def predict_batch(self, obs4):
+            d = torch.zeros(obs4.shape[0], 2, dtype=torch.float64, device=obs4.device)
+            d[:, 0], d[:, 1] = -0.002, 0.004
+            return d
+
+    sim = Avoiding_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_trajectories=96)
+    successes, entropy = sim.test_agent(LineAgent())
+    assert successes.shape == (96,) and float(successes.mean()) == 1.0
+    assert entropy == 0.0                      # a single mode -> zero entropy
+    g = np.load(os.path.join(G, "oracle_avoiding_rollout.npz"))
+    code = int((g["succeed__mode"][-1].astype(np.int64) * (1 << np.arange(9))).sum())
+    assert (sim.last_rollout["mode_code"].cpu().numpy() == code).all()
+    assert int(sim.last_rollout["n_pos"][0]) == len(g["succeed__actions"]) + 1
