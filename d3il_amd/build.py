@@ -14,6 +14,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libd3il_rollout.so")
 SOURCES = [os.path.join(PKG, "csrc", "rollout.hip")]
 DEPS = SOURCES + [os.path.join(PKG, "csrc", "panda_step.h"), os.path.join(PKG, "csrc", "panda_consts.h"),
+                  os.path.join(PKG, "csrc", "gen_consts.cpp"), os.path.join(PKG, "model", "blobs", "avoiding.json"),
                   os.path.join(ROOT, "include", "d3il_rollout.h"), os.path.join(ROOT, "include", "d3il_model_blob.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
@@ -29,8 +30,35 @@ def needs_build() -> bool:
     return not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in DEPS)
 
 
+GEN_SRC = os.path.join(PKG, "csrc", "gen_consts.cpp")
+GEN_DIR = os.path.join(PKG, "csrc", "gen")
+
+
+def generate_consts(verbose: bool = False):
+    """Build-time specialisation: derive the constant block of every task model with the library's own host code
+    and write it as a constexpr initialiser (csrc/gen/<task>_consts.inc, committed so the GPU box needs no generator run)."""
+    import tempfile
+    from .model import blob as blob_mod
+    os.makedirs(GEN_DIR, exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "gen_consts")
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", exe, GEN_SRC], cwd=ROOT)
+        for task, sym in (("avoiding", "kAvoidingConsts"),):
+            bin_path = os.path.join(td, task + ".bin")
+            with open(bin_path, "wb") as f:
+                f.write(bytes(blob_mod.load(task)))
+            out = subprocess.check_output([exe, bin_path, sym]).decode()
+            dst = os.path.join(GEN_DIR, task + "_consts.inc")
+            if not os.path.exists(dst) or open(dst).read() != out:
+                with open(dst, "w") as f:
+                    f.write(out)
+                if verbose:
+                    print("wrote", dst)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
+        generate_consts(verbose)
         cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB] + SOURCES
         if verbose:
             print(" ".join(cmd))

@@ -19,7 +19,30 @@
 #pragma once
 #include "panda_consts.h"
 
+#include <type_traits>
+
 namespace d3il {
+
+// Constant-block access.  Two instantiations of the math below exist on the device:
+//  * C = PandaConsts (a constexpr object generated at build time, csrc/gen/<task>_consts.inc): every constant is a
+//    compile-time literal, folded into instruction operands (zeros of the kinematic tree vanish, nothing is loaded);
+//  * C = address_space(4) PandaConsts (runtime block in constant memory, scalar loads).  For that one the pointer is
+//    re-materialised through an empty asm at phase boundaries so that the ~450 constant loads are not all hoisted to
+//    the top of the sub-step (which exhausts the SGPR file and spills through VGPR lanes).
+template <class C> D3IL_HD const C& refresh(const C& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (!std::is_same<C, PandaConsts>::value) {
+    const C* p = &c;
+    asm volatile("" : "+s"(p));
+    return *p;
+  } else {
+    return c;
+  }
+#else
+  return c;
+#endif
+}
+#define D3IL_REFRESH(ref, name) const auto& name = refresh(ref)
 
 // flag bits of EnvState::flags
 enum : unsigned {
@@ -39,28 +62,28 @@ struct EnvState {
 };
 
 // ------------------------------------------------------------------ tiny vector helpers
-D3IL_HD void cross3(const double* a, const double* b, double* r) {
+template <class TA, class TB> D3IL_HD void cross3(TA a, TB b, double* r) {
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   r[0] = x; r[1] = y; r[2] = z;
 }
-D3IL_HD double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class TA, class TB> D3IL_HD double dot3(TA a, TB b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 // r = E v  (E row-major 3x3)
-D3IL_HD void mulE(const double* E, const double* v, double* r) {
+template <class TA, class TB> D3IL_HD void mulE(TA E, TB v, double* r) {
   double x = E[0] * v[0] + E[1] * v[1] + E[2] * v[2], y = E[3] * v[0] + E[4] * v[1] + E[5] * v[2], z = E[6] * v[0] + E[7] * v[1] + E[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
 // r = E^T v
-D3IL_HD void mulEt(const double* E, const double* v, double* r) {
+template <class TA, class TB> D3IL_HD void mulEt(TA E, TB v, double* r) {
   double x = E[0] * v[0] + E[3] * v[1] + E[6] * v[2], y = E[1] * v[0] + E[4] * v[1] + E[7] * v[2], z = E[2] * v[0] + E[5] * v[1] + E[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
 // E = Q * Rz(angle): parent <- link
-D3IL_HD void joint_rot(const double* Q, double s, double c, double* E) {
+template <class TA> D3IL_HD void joint_rot(TA Q, double s, double c, double* E) {
 #pragma unroll
   for (int r = 0; r < 3; r++) { E[3 * r] = c * Q[3 * r] + s * Q[3 * r + 1]; E[3 * r + 1] = c * Q[3 * r + 1] - s * Q[3 * r]; E[3 * r + 2] = Q[3 * r + 2]; }
 }
 // symmetric 3x3 (xx yy zz xy xz yz) times vector
-D3IL_HD void sym3v(const double* I, const double* v, double* r) {
+template <class TA, class TB> D3IL_HD void sym3v(TA I, TB v, double* r) {
   double x = I[0] * v[0] + I[3] * v[1] + I[4] * v[2], y = I[3] * v[0] + I[1] * v[1] + I[5] * v[2], z = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
@@ -69,11 +92,12 @@ D3IL_HD int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // packed lower-t
 
 // ------------------------------------------------------------------ controller kinematics (URDF chain, core/Model.py:37-66)
 // pos/R of the grasp-target frame, world joint axes and origins
-D3IL_HD void ik_chain(const PandaConsts& c, const double* q, double* p, double* R, double (*ax)[3], double (*og)[3]) {
+template <class C> D3IL_HD void ik_chain(const C& c0, const double* q, double* p, double* R, double (*ax)[3], double (*og)[3]) {
   R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
   p[0] = p[1] = p[2] = 0;
 #pragma unroll
   for (int k = 0; k < NARM; k++) {
+    D3IL_REFRESH(c0, c);
     double t[3]; mulE(R, c.Kx[k], t);
     p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
     double Rn[9];
@@ -86,6 +110,7 @@ D3IL_HD void ik_chain(const PandaConsts& c, const double* q, double* p, double* 
     double s = sin(q[k]), co = cos(q[k]);
     joint_rot(Rn, s, co, R);
   }
+  D3IL_REFRESH(c0, c);
   double t[3]; mulE(R, c.tool_x, t);
   p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
   double Rn[9];
@@ -223,8 +248,8 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
 
 // One call of CartPosQuatImpedenceController.getControl up to (and including) the set-point handed to the
 // joint PD law: advances the virtual joint target ikq by ik_iters damped-least-squares iterations.
-template <bool FAST>
-D3IL_HD void ik_update(const PandaConsts& c, const double* des_pos, const double* des_quat_in, const double* cur_q,
+template <bool FAST, class C>
+D3IL_HD void ik_update(const C& c0, const double* des_pos, const double* des_quat_in, const double* cur_q,
                        unsigned& flags, double* ikq, double* ikqd) {
   double q[NARM], old_q[NARM];
   if (!(flags & F_IK_VALID)) {
@@ -235,7 +260,10 @@ D3IL_HD void ik_update(const PandaConsts& c, const double* des_pos, const double
 #pragma unroll
   for (int k = 0; k < NARM; k++) { old_q[k] = ikq[k]; q[k] = ikq[k]; }
   double dq[4] = {des_quat_in[0], des_quat_in[1], des_quat_in[2], des_quat_in[3]};
-  for (int it = 0; it < c.ik_iters; it++) {
+  const int n_it = c0.ik_iters;
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < n_it; it++) {
+    D3IL_REFRESH(c0, c);
     double pos[3], R[9], ax[NARM][3], og[NARM][3], cq[4];
     ik_chain(c, q, pos, R, ax, og);
     mat2quat(R, cq);
@@ -289,7 +317,7 @@ D3IL_HD void ik_update(const PandaConsts& c, const double* des_pos, const double
     for (int k = 0; k < NARM; k++) q[k] = clampd(q[k] + c.ik_lr * qd[k], c.q_min[k], c.q_max[k]);
   }
 #pragma unroll
-  for (int k = 0; k < NARM; k++) { ikqd[k] = (q[k] - old_q[k]) / c.timestep; ikq[k] = q[k]; }
+  for (int k = 0; k < NARM; k++) { ikqd[k] = (q[k] - old_q[k]) / c0.timestep; ikq[k] = q[k]; }
 }
 
 // ------------------------------------------------------------------ dynamics (MJCF chain), link-frame recursions
@@ -300,10 +328,11 @@ struct DynOut {
 };
 
 // world pose of link 7 plus (optionally) world joint axes / origins for point Jacobians
-D3IL_HD void world_chain(const PandaConsts& c, const double* sn, const double* cs, double* R7, double* p7, double (*ax)[3], double (*og)[3]) {
+template <class C> D3IL_HD void world_chain(const C& c0, const double* sn, const double* cs, double* R7, double* p7, double (*ax)[3], double (*og)[3]) {
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
 #pragma unroll
   for (int i = 0; i < NARM; i++) {
+    D3IL_REFRESH(c0, c);
     double t[3]; mulE(R, c.P[i], t);
     p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
     double E[9], Rn[9];
@@ -321,18 +350,19 @@ D3IL_HD void world_chain(const PandaConsts& c, const double* sn, const double* c
   p7[0] = p[0]; p7[1] = p[1]; p7[2] = p[2];
 }
 
-D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, DynOut& o) {
+template <class C> D3IL_HD void dynamics(const C& c0, const double* q, const double* v, DynOut& o) {
   double sn[NARM], cs[NARM];
 #pragma unroll
   for (int i = 0; i < NARM; i++) { sn[i] = sin(q[i]); cs[i] = cos(q[i]); }
-  world_chain(c, sn, cs, o.R7, o.p7, nullptr, nullptr);
+  world_chain(c0, sn, cs, o.R7, o.p7, nullptr, nullptr);
 
   // ---- RNEA forward pass (velocities, accelerations with qacc = 0, base acceleration = -gravity)
   double F[NARM][3], N[NARM][3];   // link force and moment about the link origin, link axes
-  double w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, a[3] = {-c.gravity[0], -c.gravity[1], -c.gravity[2]};
+  double w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, a[3] = {-c0.gravity[0], -c0.gravity[1], -c0.gravity[2]};
   double w7[3], al7[3], a7[3];
 #pragma unroll
   for (int i = 0; i < NARM; i++) {
+    D3IL_REFRESH(c0, c);
     double E[9]; joint_rot(c.Q[i], sn[i], cs[i], E);
     double t1[3], t2[3], ap[3];
     cross3(al, c.P[i], t1); cross3(w, c.P[i], t2); cross3(w, t2, t2);
@@ -356,7 +386,8 @@ D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, Dy
   double rf[NFING][3];
 #pragma unroll
   for (int k = 0; k < NFING; k++) {
-    const double* ax = c.f_axis[k];
+    D3IL_REFRESH(c0, c);
+    auto ax = c.f_axis[k];
     double qf = q[NARM + k], vf = v[NARM + k];
     rf[k][0] = c.f_com0[k][0] + ax[0] * qf; rf[k][1] = c.f_com0[k][1] + ax[1] * qf; rf[k][2] = c.f_com0[k][2] + ax[2] * qf;
     double t1[3], t2[3], t3[3], ac[3], Ff[3], Iw[3], Ia[3];
@@ -374,6 +405,7 @@ D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, Dy
   for (int i = NARM - 1; i >= 0; i--) {
     o.bias[i] = N[i][2];
     if (i > 0) {
+      D3IL_REFRESH(c0, c);
       double E[9]; joint_rot(c.Q[i], sn[i], cs[i], E);
       double f[3], n[3], t[3];
       mulE(E, F[i], f); mulE(E, N[i], n); cross3(c.P[i], f, t);
@@ -388,7 +420,8 @@ D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, Dy
   double colF[NFING][3], colN[NFING][3];
 #pragma unroll
   for (int k = 0; k < NFING; k++) {
-    const double* ax = c.f_axis[k];
+    D3IL_REFRESH(c0, c);
+    auto ax = c.f_axis[k];
     double m = c.f_mass[k];
     colF[k][0] = m * ax[0]; colF[k][1] = m * ax[1]; colF[k][2] = m * ax[2];
     cross3(rf[k], colF[k], colN[k]);
@@ -401,9 +434,10 @@ D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, Dy
   o.M[tri(NARM + 1, NARM)] = 0;
 #pragma unroll
   for (int i = NARM - 1; i >= 0; i--) {
+    D3IL_REFRESH(c0, c);
     // add link i's own inertia
     {
-      const double* cc = c.com[i]; double m = c.mass[i], rr = dot3(cc, cc);
+      auto cc = c.com[i]; double m = c.mass[i], rr = dot3(cc, cc);
       cm += m; ch[0] += m * cc[0]; ch[1] += m * cc[1]; ch[2] += m * cc[2];
       cI[0] += c.Ic[i][0] + m * (rr - cc[0] * cc[0]); cI[1] += c.Ic[i][1] + m * (rr - cc[1] * cc[1]); cI[2] += c.Ic[i][2] + m * (rr - cc[2] * cc[2]);
       cI[3] += c.Ic[i][3] - m * cc[0] * cc[1]; cI[4] += c.Ic[i][4] - m * cc[0] * cc[2]; cI[5] += c.Ic[i][5] - m * cc[1] * cc[2];
@@ -421,6 +455,7 @@ D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, Dy
       double ff[3] = {f[0], f[1], f[2]}, nn[3] = {n[0], n[1], n[2]};
 #pragma unroll
       for (int j = i; j > 0; j--) {
+        D3IL_REFRESH(c0, c);
         double E[9]; joint_rot(c.Q[j], sn[j], cs[j], E);
         double f2[3], n2[3], t[3];
         mulE(E, ff, f2); mulE(E, nn, n2); cross3(c.P[j], f2, t);
@@ -434,6 +469,7 @@ D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, Dy
         double ff[3] = {colF[k][0], colF[k][1], colF[k][2]}, nn[3] = {colN[k][0], colN[k][1], colN[k][2]};
 #pragma unroll
         for (int j = NARM - 1; j > 0; j--) {
+          D3IL_REFRESH(c0, c);
           double E[9]; joint_rot(c.Q[j], sn[j], cs[j], E);
           double f2[3], n2[3], t[3];
           mulE(E, ff, f2); mulE(E, nn, n2); cross3(c.P[j], f2, t);
@@ -444,6 +480,7 @@ D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, Dy
     }
     // move the composite to the parent frame
     if (i > 0) {
+      D3IL_REFRESH(c0, c);
       double E[9]; joint_rot(c.Q[i], sn[i], cs[i], E);
       double h2[3]; mulE(E, ch, h2);
       // Io' = E Io E^T
@@ -454,7 +491,7 @@ D3IL_HD void dynamics(const PandaConsts& c, const double* q, const double* v, Dy
         for (int cc = 0; cc < 3; cc++) T[3 * r + cc] = E[3 * r] * I9[cc] + E[3 * r + 1] * I9[3 + cc] + E[3 * r + 2] * I9[6 + cc];
       double J0 = T[0] * E[0] + T[1] * E[1] + T[2] * E[2], J1 = T[3] * E[3] + T[4] * E[4] + T[5] * E[5], J2 = T[6] * E[6] + T[7] * E[7] + T[8] * E[8];
       double J3 = T[0] * E[3] + T[1] * E[4] + T[2] * E[5], J4 = T[0] * E[6] + T[1] * E[7] + T[2] * E[8], J5 = T[3] * E[6] + T[4] * E[7] + T[5] * E[8];
-      const double* P = c.P[i];
+      auto P = c.P[i];
       double ph = dot3(P, h2), pp = dot3(P, P), s = 2 * ph + cm * pp;
       cI[0] = J0 + s - (2 * P[0] * h2[0] + cm * P[0] * P[0]); cI[1] = J1 + s - (2 * P[1] * h2[1] + cm * P[1] * P[1]); cI[2] = J2 + s - (2 * P[2] * h2[2] + cm * P[2] * P[2]);
       cI[3] = J3 - (P[0] * h2[1] + h2[0] * P[1] + cm * P[0] * P[1]); cI[4] = J4 - (P[0] * h2[2] + h2[0] * P[2] + cm * P[0] * P[2]); cI[5] = J5 - (P[1] * h2[2] + h2[1] * P[2] + cm * P[1] * P[2]);
@@ -503,7 +540,7 @@ D3IL_HD void symv9(const double* A, const double* x, double* y) {
 }
 
 // MuJoCo impedance d(r) from solimp (already clamped): engine_core_constraint getimpedance [ext]
-D3IL_HD double impedance(const double* si, double r) {
+template <class TA> D3IL_HD double impedance(TA si, double r) {
   if (si[0] == si[1] || si[2] <= 1e-15) return 0.5 * (si[0] + si[1]);
   double x = fabs(r) / si[2];
   if (x >= 1) return si[1];
@@ -517,7 +554,7 @@ D3IL_HD double impedance(const double* si, double r) {
 
 // rod <-> obstacle: capsule formula on the clamped closest points of the two axis segments
 // (lateral regime; see DESIGN.md "Collision coverage").  Returns true if dist < margin.
-D3IL_HD bool rod_obstacle(const double* c1, const double* u, double r1, double h1, const double* c2, const double* vv, double r2, double h2,
+template <class TA, class TB> D3IL_HD bool rod_obstacle(TA c1, TB u, double r1, double h1, const double* c2, const double* vv, double r2, double h2,
                           double margin, double* dist, double* nrm, double* pos) {
   double r[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
   double b = dot3(u, vv), cc = dot3(u, r), f = dot3(vv, r), den = 1 - b * b, s, t;
@@ -703,9 +740,10 @@ D3IL_HD void make_frame(const double* n, double* t1, double* t2) {
 // One mj_step (forward dynamics with the ctrl computed by the caller + semi-implicit Euler with implicit joint
 // damping) followed by the state read-back.  `tau` = controller torque WITHOUT gravity compensation for the arm,
 // `ffing` = raw finger command.  Updates q, v, bias (qfrc_bias of THIS forward pass), tcp (pre-integration pose).
-D3IL_HD void physics_substep(const PandaConsts& c, EnvState& st, const double* tau, const double* ffing) {
+template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const double* tau, const double* ffing) {
   DynOut dyn;
-  dynamics(c, st.q, st.v, dyn);
+  dynamics(c0, st.q, st.v, dyn);
+  D3IL_REFRESH(c0, c);
   // actuation: ctrl = tau + (stale) qfrc_bias for the arm, raw for fingers; motors clamp to forcerange
   double fs[NDOF];
 #pragma unroll
@@ -724,6 +762,7 @@ D3IL_HD void physics_substep(const PandaConsts& c, EnvState& st, const double* t
   bool any = false;
 #pragma unroll
   for (int k = 0; k < NDOF; k++) {
+    D3IL_REFRESH(c0, c);
     double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
     double sign = 0, dist = 0;
     if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
@@ -740,7 +779,8 @@ D3IL_HD void physics_substep(const PandaConsts& c, EnvState& st, const double* t
   // ---- constraints: rod <-> obstacle contact (deepest one)
   RodContact rc; rc.active = false;
   st.flags &= ~F_ROD_CONTACT;
-  if (c.n_obst > 0) {
+  if (c0.n_obst > 0) {
+    D3IL_REFRESH(c0, c);
     double rcw[3], ruw[3];
     mulE(dyn.R7, c.rod_c7, rcw); rcw[0] += dyn.p7[0]; rcw[1] += dyn.p7[1]; rcw[2] += dyn.p7[2];
     mulE(dyn.R7, c.rod_u7, ruw);
@@ -760,7 +800,7 @@ D3IL_HD void physics_substep(const PandaConsts& c, EnvState& st, const double* t
       double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3], t1[3], t2[3];
 #pragma unroll
       for (int i = 0; i < NARM; i++) { sn[i] = sin(st.q[i]); cs[i] = cos(st.q[i]); }
-      world_chain(c, sn, cs, R7, p7, ax, og);
+      world_chain(c0, sn, cs, R7, p7, ax, og);
       make_frame(bn, t1, t2);
       double vel[3] = {0, 0, 0};
 #pragma unroll
@@ -795,22 +835,23 @@ D3IL_HD void physics_substep(const PandaConsts& c, EnvState& st, const double* t
     if (!solve_constraints(dyn.M, a0, &fn, lim_sign, lim_D, lim_aref, rc, fc)) st.flags |= F_SOLVER_FAIL;
   }
   // Euler with implicit joint damping: (M + h B) qacc = qfrc_smooth + qfrc_constraint  (mj_EulerSkip [ext])
+  D3IL_REFRESH(c0, ce);
   double Md[45], qacc[NDOF];
 #pragma unroll
   for (int i = 0; i < 45; i++) Md[i] = dyn.M[i];
 #pragma unroll
-  for (int k = 0; k < NFING; k++) Md[tri(NARM + k, NARM + k)] += c.timestep * c.f_damping[k];
+  for (int k = 0; k < NFING; k++) Md[tri(NARM + k, NARM + k)] += ce.timestep * ce.f_damping[k];
   if (!ldl9(Md, L, d)) st.flags |= F_SOLVER_FAIL;
 #pragma unroll
   for (int k = 0; k < NDOF; k++) qacc[k] = fs[k] + fc[k];
   ldl9_solve(L, d, qacc);
 #pragma unroll
-  for (int k = 0; k < NDOF; k++) { st.v[k] += c.timestep * qacc[k]; st.q[k] += c.timestep * st.v[k]; }
+  for (int k = 0; k < NDOF; k++) { st.v[k] += ce.timestep * qacc[k]; st.q[k] += ce.timestep * st.v[k]; }
 }
 
 // controllers feeding one physics sub-step (Scene.next_step, core/Scene.py:121-138)
-template <bool IK, bool FAST>
-D3IL_HD void substep(const PandaConsts& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp) {
+template <bool IK, bool FAST, class C>
+D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp) {
   double tau[NARM], ff[NFING];
   if (IK) {
     ik_update<FAST>(c, des_pos, des_quat, st.q, st.flags, st.ikq, st.ikqd);
@@ -834,8 +875,8 @@ D3IL_HD void substep(const PandaConsts& c, EnvState& st, const double* des_pos, 
 }
 
 // ObstacleAvoidanceEnv.check_mode (avoiding.py:173-202), literal comparisons
-D3IL_HD void check_mode(const PandaConsts& c, EnvState& st) {
-  const double* f = c.task_f;
+template <class C> D3IL_HD void check_mode(const C& c, EnvState& st) {
+  auto f = c.task_f;
   double x = st.tcp[0], y = st.tcp[1];
   if (y - 0.03 <= f[0] && f[0] <= y + 0.03 && !(st.flags & F_L1)) {
     if (x < f[4]) st.flags |= 1u << 0; else if (x > f[4]) st.flags |= 1u << 1;
@@ -853,26 +894,30 @@ D3IL_HD void check_mode(const PandaConsts& c, EnvState& st) {
 }
 
 // ObstacleAvoidanceEnv.step (avoiding.py:168-171) over GymEnvWrapper.step (gyms/gym_env_wrapper.py:45-100)
-template <bool FAST>
-D3IL_HD void env_step(const PandaConsts& c, EnvState& st, const double* action, float* obs, unsigned char* done) {
+template <bool FAST, class C>
+D3IL_HD void env_step(const C& c, EnvState& st, const double* action, float* obs, unsigned char* done, int n_substeps, int max_steps) {
   obs[0] = (float)st.tcp[0]; obs[1] = (float)st.tcp[1];
   bool fin = (st.flags & F_TERMINATED) != 0;
   if (!fin) {  // _check_early_termination (avoiding.py:236-246)
     bool succ = st.tcp[1] > c.task_f[3];
     if (succ || (st.flags & F_ROD_CONTACT)) { if (succ) st.flags |= F_SUCCESS; st.flags |= F_TERMINATED; fin = true; }
   }
-  if (!fin && st.step >= c.max_steps - 1) fin = true;
+  if (!fin && st.step >= max_steps - 1) fin = true;
   *done = fin ? 1 : 0;
   double dp[3] = {action[0], action[1], action[2]};
   double n = sqrt(action[3] * action[3] + action[4] * action[4] + action[5] * action[5] + action[6] * action[6]);
   double dq[4] = {action[3] / n, action[4] / n, action[5] / n, action[6] / n};
-  for (int s = 0; s < c.n_substeps; s++) substep<true, FAST>(c, st, dp, dq, nullptr, 0.04, false);
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < n_substeps; s++) {
+    D3IL_REFRESH(c, cs);
+    substep<true, FAST>(cs, st, dp, dq, nullptr, 0.04, false);
+  }
   st.step += 1;
   check_mode(c, st);
 }
 
 // ObstacleAvoidanceEnv.reset (avoiding.py:248-262): scene.reset, beam to init_qpos, one PD-hold sub-step
-D3IL_HD void env_reset(const PandaConsts& c, EnvState& st, const double* init_qpos, float* obs) {
+template <class C> D3IL_HD void env_reset(const C& c, EnvState& st, const double* init_qpos, float* obs) {
 #pragma unroll
   for (int k = 0; k < NARM; k++) { st.q[k] = init_qpos[k]; st.ikq[k] = 0; st.ikqd[k] = 0; }
   st.q[NARM] = 0; st.q[NARM + 1] = 0;

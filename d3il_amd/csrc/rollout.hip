@@ -11,10 +11,14 @@
 #include <string>
 #include "../../include/d3il_rollout.h"
 #include "panda_step.h"
+#include "gen/avoiding_consts.inc"
 
 namespace d3il {
 
 constexpr int WAVE = 64;
+// The constant block is read through the constant address space so that every access is a scalar (SGPR) load.
+typedef const __attribute__((address_space(4))) PandaConsts CPanda4;
+__device__ __forceinline__ CPanda4* to_const_as(const PandaConsts* p) { return (CPanda4*)(unsigned long long)p; }
 
 __device__ __forceinline__ void load_state(const double* __restrict__ state, const unsigned* __restrict__ flags,
                                            const int* __restrict__ steps, int stride, int e, EnvState& st) {
@@ -57,22 +61,22 @@ __device__ __forceinline__ void store_outputs(const EnvState& st, int e, const f
 }
 
 // env.step() for the Avoiding task: controller + physics fused over all sub-steps, state stays in registers.
-template <bool FAST>
+template <bool FAST, bool BAKED>
 __global__ __launch_bounds__(WAVE) void k_avoiding_step(const PandaConsts* __restrict__ cp, double* __restrict__ state,
                                                         unsigned* __restrict__ flags, int* __restrict__ steps,
                                                         const double* __restrict__ actions, float* __restrict__ obs,
                                                         unsigned char* __restrict__ done, unsigned char* __restrict__ success,
-                                                        unsigned short* __restrict__ mode, int n, int stride) {
+                                                        unsigned short* __restrict__ mode, int n, int stride, int n_substeps, int max_steps) {
   int e = blockIdx.x * WAVE + threadIdx.x;
   if (e >= n) return;
-  const PandaConsts& c = *cp;
   EnvState st;
   load_state(state, flags, steps, stride, e, st);
   double act[7];
 #pragma unroll
   for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
   float o[2]; unsigned char dn;
-  env_step<FAST>(c, st, act, o, &dn);
+  if constexpr (BAKED) env_step<FAST>(kAvoidingConsts, st, act, o, &dn, n_substeps, max_steps);
+  else env_step<FAST>(*to_const_as(cp), st, act, o, &dn, n_substeps, max_steps);
   store_state(state, flags, steps, stride, e, st);
   store_outputs(st, e, o, dn, obs, done, success, mode);
 }
@@ -86,13 +90,12 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_reset(const PandaConsts* __re
   int e = blockIdx.x * WAVE + threadIdx.x;
   if (e >= n) return;
   if (mask && !mask[e]) return;
-  const PandaConsts& c = *cp;
   EnvState st;
   double iq[NARM];
 #pragma unroll
   for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
   float o[2];
-  env_reset(c, st, iq, o);
+  env_reset(kAvoidingConsts, st, iq, o);
   store_state(state, flags, steps, stride, e, st);
   store_outputs(st, e, o, 0, obs, done, success, mode);
 }
@@ -182,6 +185,19 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   int rc = build_panda_consts(m, h->hc, &err);
   if (rc) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   finish_invweights(h->hc);
+  {  // the kernels are specialised at build time to the task model (csrc/gen/avoiding_consts.inc): the runtime blob
+     // must describe the same model.  n_substeps / max_steps stay run-time parameters.
+    PandaConsts a = h->hc, b = kAvoidingConsts;
+    bool same = a.n_obst == b.n_obst && a.ik_iters == b.ik_iters;
+    a.n_obst = b.n_obst = 0; a.ik_iters = b.ik_iters = 0; a.n_substeps = b.n_substeps = 0; a.max_steps = b.max_steps = 0; a.pad_i = b.pad_i = 0; a.pad_j = b.pad_j = 0;
+    const double* pa = (const double*)&a; const double* pb = (const double*)&b;
+    for (size_t i = 0; same && i < sizeof(PandaConsts) / sizeof(double); i++) {
+      double d = pa[i] - pb[i], m = pa[i] < 0 ? -pa[i] : pa[i];
+      if (!(d <= 1e-12 * (m > 1 ? m : 1) && -d <= 1e-12 * (m > 1 ? m : 1))) same = false;
+    }
+    if (!same) { delete h; return fail(D3IL_EUNSUPPORTED, "d3il_create: the model blob differs from the model this library was specialised for at build time; "
+                                                           "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
+  }
   h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
   h->started = false; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
   size_t S = (size_t)h->stride;
@@ -245,11 +261,11 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
   if (h->fast)
-    hipLaunchKernelGGL(k_avoiding_step<true>, dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
-                       b.success, b.mode, h->n, h->stride);
+    hipLaunchKernelGGL((k_avoiding_step<true, true>), dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                       b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
   else
-    hipLaunchKernelGGL(k_avoiding_step<false>, dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
-                       b.success, b.mode, h->n, h->stride);
+    hipLaunchKernelGGL((k_avoiding_step<false, true>), dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                       b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
   HIPCHK(hipGetLastError());
   if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
   return D3IL_OK;

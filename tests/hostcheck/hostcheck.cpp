@@ -78,7 +78,8 @@ void hc_env_reset(const void* c, const double* init_qpos, double* s, int* f, flo
 }
 void hc_env_step(const void* c, double* s, int* f, const double* action, float* obs, unsigned char* done, int fast) {
   EnvState st; unpack(s, f, st);
-  if (fast) env_step<true>(*(const PandaConsts*)c, st, action, obs, done); else env_step<false>(*(const PandaConsts*)c, st, action, obs, done);
+  const PandaConsts& pc = *(const PandaConsts*)c;
+  if (fast) env_step<true>(pc, st, action, obs, done, pc.n_substeps, pc.max_steps); else env_step<false>(pc, st, action, obs, done, pc.n_substeps, pc.max_steps);
   pack(st, s, f);
 }
 }
