@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
+    ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,6 +85,8 @@ def main():
     n = args.envs
     env = ObstacleAvoidanceVecEnv(n, device=dev)
     q, iters, err = env.start()
+    if args.lds_pad is not None:
+        env.set_option("lds_pad_bytes", args.lds_pad)
     env_offset = rank * n
     actions = torch.zeros(n, 7, dtype=torch.float64, device=dev)
     counts = torch.zeros(514, dtype=torch.int64, device=dev)
@@ -143,7 +146,8 @@ def main():
                        "auto_reset": not args.no_auto_reset, "finite_and_solver_ok": ok,
                        "episodes_finished_rank0": int(total_done.item()), "episodes_success_rank0": int(total_succ.item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_avoiding_step<true>", "kernel_ms": k_ms,
+                         "traffic": None, "kernel": "k_avoiding_step<true,true>", "kernel_ms": k_ms,
+                         "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n,
                          "note": "path is FP64-VALU/latency bound, not HBM bound: <1 KB of HBM per env step with "
                                  "all 35 sub-steps fused (DESIGN.md section 4); fp64_valu_frac is the binding roofline",

@@ -16,7 +16,11 @@ SOURCES = [os.path.join(PKG, "csrc", "rollout.hip")]
 DEPS = SOURCES + [os.path.join(PKG, "csrc", "panda_step.h"), os.path.join(PKG, "csrc", "panda_consts.h"),
                   os.path.join(PKG, "csrc", "gen_consts.cpp"), os.path.join(PKG, "model", "blobs", "avoiding.json"),
                   os.path.join(ROOT, "include", "d3il_rollout.h"), os.path.join(ROOT, "include", "d3il_model_blob.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+# -disable-machine-licm / -disable-machine-sink: with the model constants baked in as literals, MachineLICM hoists
+# their materialisation (s_mov pairs) out of the sub-step loop and then spills ~350 SGPRs through VGPR lanes;
+# keeping them next to their use costs nothing (they are re-materialisable) and removes the spills.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+               "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-machine-sink"]
 
 
 def hipcc() -> str:

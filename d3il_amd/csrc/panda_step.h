@@ -21,6 +21,21 @@
 
 #include <type_traits>
 
+// Rare, register-hungry paths (Jacobi eigen-solver, general constraint Newton) are kept out of line so that the hot
+// path of the fused kernel stays in registers; they take their operands through private memory.
+#if defined(__HIPCC__)
+#define D3IL_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define D3IL_NOINLINE __attribute__((noinline))
+#endif
+
+#if defined(D3IL_HOST_STATS)
+#define D3IL_STAT(x) (x)
+namespace d3il { struct Stats { long newton_calls, newton_iters, ls_iters, eig_calls, ik_calls, contact_calls; }; inline Stats g_stats = {0, 0, 0, 0, 0, 0}; }
+#else
+#define D3IL_STAT(x) ((void)0)
+#endif
+
 namespace d3il {
 
 // Constant-block access.  Two instantiations of the math below exist on the device:
@@ -145,104 +160,153 @@ D3IL_HD void quat_error(const double* c, const double* d, double* e) {  // utils
 }
 
 // x = (U clip(S) U^T)^-1 b for the SPD 6x6 A (packed lower, 21): the reference rebuilds the matrix from its
-// SVD with clipped singular values and calls np.linalg.solve (IKControllers.py:230-266).
-// Fast path: if lmin(A) > minsv and lmax(A) < maxsv no value is clipped and x = A^-1 b (LDL^T).  lmin > minsv
-// <=> A - minsv I is positive definite <=> all its LDL^T pivots are positive (exact test); trace(A) < maxsv
-// is a sufficient test for lmax.  Otherwise: cyclic Jacobi eigen-decomposition.
+// SVD with clipped singular values and calls np.linalg.solve (IKControllers.py:230-266).  For an SPD matrix this is
+// x = sum_i (v_i . b) / clip(l_i, lo, hi) v_i over its eigenpairs.  Three paths, all evaluating that same function:
+//  1. no eigenvalue outside [lo, hi]  ->  x = A^-1 b (LDL^T).  The number of eigenvalues below lo is the number of
+//     negative pivots of LDL^T(A - lo I) (Sylvester's law of inertia, exact); trace(A) < hi bounds the largest.
+//  2. exactly one eigenvalue l1 < lo  ->  x = A^-1 b + (1/lo - 1/l1) (v1 . b) v1 with (l1, v1) from inverse
+//     iteration followed by Rayleigh-quotient iteration; accepted only if the eigen-residual is at round-off level.
+//  3. anything else (or path 2 not accepted)  ->  cyclic Jacobi eigen-decomposition.
+D3IL_HD bool ldl6(const double* A, double shift, double* L, double* d, int* n_neg) {
+  bool ok = true; int neg = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double s = A[tri(j, j)] - shift;
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= L[tri(j, k)] * L[tri(j, k)] * d[k];
+    if (fabs(s) < 1e-30) { s = 1e-30; ok = false; }
+    d[j] = s; neg += s < 0 ? 1 : 0;
+    double inv = 1.0 / s;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double t = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= L[tri(i, k)] * L[tri(j, k)] * d[k];
+      L[tri(i, j)] = t * inv;
+    }
+  }
+  *n_neg = neg;
+  return ok;
+}
+D3IL_HD void ldl6_solve(const double* L, const double* d, const double* b, double* x) {
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[tri(i, k)] * y[k]; y[i] = s; }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] /= d[i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) { double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= L[tri(k, i)] * x[k]; x[i] = s; }
+}
+D3IL_HD void symv6(const double* A, const double* x, double* y) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) { double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += A[i >= k ? tri(i, k) : tri(k, i)] * x[k]; y[i] = s; }
+}
+D3IL_NOINLINE inline void jacobi_solve6(const double* A, const double* b, double minsv, double maxsv, double* x) {
+  D3IL_STAT(g_stats.eig_calls++);
+  double M[6][6], V[6][6];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) { M[i][j] = A[i >= j ? tri(i, j) : tri(j, i)]; V[i][j] = i == j ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0, dg = 0;
+    for (int i = 0; i < 6; i++) { dg += M[i][i] * M[i][i];
+      for (int j = i + 1; j < 6; j++) off += M[i][j] * M[i][j]; }
+    if (off <= 1e-34 * dg) break;
+    for (int p = 0; p < 5; p++)
+      for (int q = p + 1; q < 6; q++) {
+        double apq = M[p][q];
+        if (apq != 0.0) {
+          double theta = (M[q][q] - M[p][p]) / (2 * apq);
+          double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+          double cs = 1 / sqrt(t * t + 1), sn = t * cs;
+          for (int k = 0; k < 6; k++) { double a = M[k][p], bb = M[k][q]; M[k][p] = cs * a - sn * bb; M[k][q] = sn * a + cs * bb; }
+          for (int k = 0; k < 6; k++) { double a = M[p][k], bb = M[q][k]; M[p][k] = cs * a - sn * bb; M[q][k] = sn * a + cs * bb; }
+          for (int k = 0; k < 6; k++) { double a = V[k][p], bb = V[k][q]; V[k][p] = cs * a - sn * bb; V[k][q] = sn * a + cs * bb; }
+        }
+      }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) { double s = 0;
+    for (int a = 0; a < 6; a++) s += V[a][i] * b[a]; y[i] = s / clampd(M[i][i], minsv, maxsv); }
+  for (int a = 0; a < 6; a++) { double s = 0;
+    for (int i = 0; i < 6; i++) s += V[a][i] * y[i]; x[a] = s; }
+}
 template <bool FAST>
 D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double maxsv, double* x) {
   bool need_eig = true;
   if (FAST) {
-    // pivots of A - minsv I
     double L[21], d[6];
-    bool pd = true;
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      double s = A[tri(j, j)] - minsv;
-#pragma unroll
-      for (int k = 0; k < j; k++) s -= L[tri(j, k)] * L[tri(j, k)] * d[k];
-      d[j] = s; pd = pd && (s > 0);
-      double inv = 1.0 / s;
-#pragma unroll
-      for (int i = j + 1; i < 6; i++) {
-        double t = A[tri(i, j)];
-#pragma unroll
-        for (int k = 0; k < j; k++) t -= L[tri(i, k)] * L[tri(j, k)] * d[k];
-        L[tri(i, j)] = t * inv;
-      }
-    }
+    int neg = 0;
+    bool okp = ldl6(A, minsv, L, d, &neg);
     double tr = A[tri(0, 0)] + A[tri(1, 1)] + A[tri(2, 2)] + A[tri(3, 3)] + A[tri(4, 4)] + A[tri(5, 5)];
-    if (pd && tr < maxsv) {
-      need_eig = false;
-      // LDL^T of A itself and solve
+    if (okp && tr < maxsv && neg <= 1) {
+      int dummy;
+      bool ok0 = ldl6(A, 0.0, L, d, &dummy);
+      if (neg == 0) { ldl6_solve(L, d, b, x); need_eig = !ok0; }
+      else if (ok0) {
+        // smallest eigenpair: two inverse-iteration steps starting from b, then Rayleigh-quotient iteration
+        double v[6], w[6], nr = 0;
+        ldl6_solve(L, d, b, w);
+        ldl6_solve(L, d, w, v);
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        double s = A[tri(j, j)];
+        for (int i = 0; i < 6; i++) nr += v[i] * v[i];
+        nr = 1.0 / sqrt(nr);
 #pragma unroll
-        for (int k = 0; k < j; k++) s -= L[tri(j, k)] * L[tri(j, k)] * d[k];
-        d[j] = s;
-        double inv = 1.0 / s;
+        for (int i = 0; i < 6; i++) v[i] *= nr;
+        double lam = 0;
+        for (int it = 0; it < 4; it++) {
+          symv6(A, v, w);
+          lam = 0;
 #pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-          double t = A[tri(i, j)];
+          for (int i = 0; i < 6; i++) lam += v[i] * w[i];
+          double L2[21], d2[6], u[6];
+          int n2;
+          ldl6(A, lam, L2, d2, &n2);
+          ldl6_solve(L2, d2, v, u);
+          nr = 0;
 #pragma unroll
-          for (int k = 0; k < j; k++) t -= L[tri(i, k)] * L[tri(j, k)] * d[k];
-          L[tri(i, j)] = t * inv;
+          for (int i = 0; i < 6; i++) nr += u[i] * u[i];
+          nr = 1.0 / sqrt(nr);
+#pragma unroll
+          for (int i = 0; i < 6; i++) v[i] = u[i] * nr;
+        }
+        symv6(A, v, w);
+        lam = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) lam += v[i] * w[i];
+        double res = 0, vb = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { res = fmax(res, fabs(w[i] - lam * v[i])); vb += v[i] * b[i]; }
+        if (res <= 1e-14 * tr && lam < minsv && lam > 0) {
+          // x = A^-1 (b - (v.b) v) + (v.b)/lo v : the clipped direction is removed BEFORE the solve (no cancellation)
+          double bp[6], xp[6], vx = 0;
+#pragma unroll
+          for (int i = 0; i < 6; i++) bp[i] = b[i] - vb * v[i];
+          ldl6_solve(L, d, bp, xp);
+#pragma unroll
+          for (int i = 0; i < 6; i++) vx += v[i] * xp[i];
+          double g = vb / minsv - vx;
+#pragma unroll
+          for (int i = 0; i < 6; i++) x[i] = xp[i] + g * v[i];
+          need_eig = false;
         }
       }
-      double y[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++) { double s = b[i];
-#pragma unroll
-        for (int k = 0; k < i; k++) s -= L[tri(i, k)] * y[k]; y[i] = s; }
-#pragma unroll
-      for (int i = 0; i < 6; i++) y[i] /= d[i];
-#pragma unroll
-      for (int i = 5; i >= 0; i--) { double s = y[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; k++) s -= L[tri(k, i)] * x[k]; x[i] = s; }
     }
   }
   if (need_eig) {
-    double M[6][6], V[6][6];
+    double Am[21], bm[6], xm[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 21; i++) Am[i] = A[i];
 #pragma unroll
-      for (int j = 0; j < 6; j++) { M[i][j] = A[i >= j ? tri(i, j) : tri(j, i)]; V[i][j] = i == j ? 1.0 : 0.0; }
-    for (int sweep = 0; sweep < 30; sweep++) {
-      double off = 0, dg = 0;
+    for (int i = 0; i < 6; i++) bm[i] = b[i];
+    jacobi_solve6(Am, bm, minsv, maxsv, xm);
 #pragma unroll
-      for (int i = 0; i < 6; i++) { dg += M[i][i] * M[i][i];
-#pragma unroll
-        for (int j = i + 1; j < 6; j++) off += M[i][j] * M[i][j]; }
-      if (off <= 1e-34 * dg) break;
-#pragma unroll
-      for (int p = 0; p < 5; p++)
-#pragma unroll
-        for (int q = p + 1; q < 6; q++) {
-          double apq = M[p][q];
-          if (apq != 0.0) {
-            double theta = (M[q][q] - M[p][p]) / (2 * apq);
-            double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-            double cs = 1 / sqrt(t * t + 1), sn = t * cs;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { double a = M[k][p], bb = M[k][q]; M[k][p] = cs * a - sn * bb; M[k][q] = sn * a + cs * bb; }
-#pragma unroll
-            for (int k = 0; k < 6; k++) { double a = M[p][k], bb = M[q][k]; M[p][k] = cs * a - sn * bb; M[q][k] = sn * a + cs * bb; }
-#pragma unroll
-            for (int k = 0; k < 6; k++) { double a = V[k][p], bb = V[k][q]; V[k][p] = cs * a - sn * bb; V[k][q] = sn * a + cs * bb; }
-          }
-        }
-    }
-    double y[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) { double s = 0;
-#pragma unroll
-      for (int a = 0; a < 6; a++) s += V[a][i] * b[a]; y[i] = s / clampd(M[i][i], minsv, maxsv); }
-#pragma unroll
-    for (int a = 0; a < 6; a++) { double s = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++) s += V[a][i] * y[i]; x[a] = s; }
+    for (int i = 0; i < 6; i++) x[i] = xm[i];
   }
 }
 
@@ -587,14 +651,19 @@ struct RodContact {
 // Constraint solve: min_x 1/2 (x-a0)^T M (x-a0) + sum_i s_i(J_i x - aref_i) with joint-limit rows (unilateral
 // quadratics) and at most one elliptic contact.  MuJoCo reaches the same (unique) optimum with its Newton solver.
 // Returns qfrc_constraint; lim_* arrays are per dof (lim_sign = 0 when the row is absent).
-D3IL_HD bool solve_constraints(const double* M, const double* a0, const double* fs_norm_ref, const double* lim_sign, const double* lim_D,
-                               const double* lim_aref, const RodContact& rc, double* fc_out) {
+// `warm` (10 doubles: previous solution + validity flag) carries the last optimum of this environment inside one env
+// step; like MuJoCo's qacc_warmstart it only selects the starting point (whichever of warm / a0 has the lower cost),
+// the optimum itself is unique.
+D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, const double* fs_norm_ref, const double* lim_sign, const double* lim_D,
+                                            const double* lim_aref, const RodContact& rc, double* fc_out, double* warm) {
   double x[NDOF], Ma[NDOF], grad[NDOF], p[NDOF], fl[NDOF], hl[NDOF];
   double fcn[3] = {0, 0, 0}, Hc[6] = {0, 0, 0, 0, 0, 0};  // contact force and Hessian block (00 11 22 01 02 12)
 #pragma unroll
   for (int i = 0; i < NDOF; i++) x[i] = a0[i];
-  double gtol = 1e-13 * (1.0 + *fs_norm_ref);
+  double gtol = 1e-11 * (1.0 + *fs_norm_ref);
   bool ok = true;
+  D3IL_STAT(g_stats.newton_calls++);
+  D3IL_STAT(g_stats.contact_calls += rc.active ? 1 : 0);
   auto eval_contact = [&](const double* jar, double* force, double* H) {
     double mu = rc.mu, U0 = jar[0] * mu, U1 = jar[1] * rc.fric[0], U2 = jar[2] * rc.fric[1];
     double T = sqrt(U1 * U1 + U2 * U2), Nn = U0;
@@ -617,6 +686,28 @@ D3IL_HD bool solve_constraints(const double* M, const double* a0, const double* 
       H[5] = Dm * (g1 * g2 + k * rc.fric[0] * rc.fric[1] * (-U1 * U2 / T3));
     }
   };
+  if (warm[NDOF] != 0.0) {
+    auto total_cost = [&](const double* y) {
+      double dy[NDOF], My[NDOF], cst = 0;
+      for (int i = 0; i < NDOF; i++) dy[i] = y[i] - a0[i];
+      symv9(M, dy, My);
+      for (int i = 0; i < NDOF; i++) {
+        cst += 0.5 * dy[i] * My[i];
+        double jar = lim_sign[i] * y[i] - lim_aref[i];
+        if (lim_sign[i] != 0 && jar < 0) cst += 0.5 * lim_D[i] * jar * jar;
+      }
+      if (rc.active) {
+        double jr[3];
+        for (int r = 0; r < 3; r++) { double t = -rc.aref[r]; for (int k = 0; k < NARM; k++) t += rc.J[r][k] * y[k]; jr[r] = t; }
+        double mu = rc.mu, U1 = jr[1] * rc.fric[0], U2 = jr[2] * rc.fric[1], T = sqrt(U1 * U1 + U2 * U2), Nn = jr[0] * mu;
+        if (Nn >= mu * T || (T <= 0 && Nn >= 0)) {}
+        else if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) cst += 0.5 * (rc.D[0] * jr[0] * jr[0] + rc.D[1] * jr[1] * jr[1] + rc.D[2] * jr[2] * jr[2]);
+        else { double Dm = rc.D[0] / fmax(1e-15, mu * mu * (1 + mu * mu)), NmT = Nn - mu * T; cst += 0.5 * Dm * NmT * NmT; }
+      }
+      return cst;
+    };
+    if (total_cost(warm) < total_cost(a0)) { for (int i = 0; i < NDOF; i++) x[i] = warm[i]; }
+  }
   for (int it = 0; it < 12; it++) {
     // row residuals, forces, Hessian diagonal
     double jc[3] = {0, 0, 0};
@@ -645,6 +736,7 @@ D3IL_HD bool solve_constraints(const double* M, const double* a0, const double* 
       grad[i] = g; gn += g * g;
     }
     if (sqrt(gn) <= gtol) break;
+    D3IL_STAT(g_stats.newton_iters++);
     // H = M + diag(hl) + Jc^T Hc Jc
     double H[45], L[45], d[NDOF];
 #pragma unroll
@@ -682,6 +774,7 @@ D3IL_HD bool solve_constraints(const double* M, const double* a0, const double* 
     }
     double alpha = 0, lo = 0, hi = -1, best = 1;
     for (int ls = 0; ls < 40; ls++) {
+      D3IL_STAT(g_stats.ls_iters++);
       double d1 = pMa + alpha * pMp, d2 = pMp;
 #pragma unroll
       for (int i = 0; i < NDOF; i++) {
@@ -704,9 +797,13 @@ D3IL_HD bool solve_constraints(const double* M, const double* a0, const double* 
       if (na == alpha) break;
       alpha = na;
     }
+    double stepmax = 0, xmax = 0;
 #pragma unroll
-    for (int i = 0; i < NDOF; i++) x[i] += best * p[i];
+    for (int i = 0; i < NDOF; i++) { x[i] += best * p[i]; stepmax = fmax(stepmax, fabs(best * p[i])); xmax = fmax(xmax, fabs(x[i])); }
+    if (stepmax <= 1e-13 * (1.0 + xmax)) break;   // converged to round-off: further iterations cannot move the iterate
   }
+  for (int i = 0; i < NDOF; i++) warm[i] = x[i];
+  warm[NDOF] = 1.0;
   // forces at the solution
 #pragma unroll
   for (int i = 0; i < NDOF; i++) {
@@ -737,10 +834,44 @@ D3IL_HD void make_frame(const double* n, double* t1, double* t2) {
   cross3(n, t1, t2);
 }
 
+// Rod contact set-up (rare path): Jacobian rows, regularisation and reference acceleration of the deepest contact.
+template <class C>
+D3IL_NOINLINE inline void make_rod_contact(const C& c, const double* q, const double* v, int bo, double bd, const double* bn, const double* bp, RodContact* rcp) {
+  RodContact& rc = *rcp;
+  rc.active = true;
+  double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3], t1[3], t2[3];
+  for (int i = 0; i < NARM; i++) { sn[i] = sin(q[i]); cs[i] = cos(q[i]); }
+  world_chain(c, sn, cs, R7, p7, ax, og);
+  make_frame(bn, t1, t2);
+  double vel[3] = {0, 0, 0};
+  for (int k = 0; k < NARM; k++) {
+    double dd[3] = {bp[0] - og[k][0], bp[1] - og[k][1], bp[2] - og[k][2]}, col[3];
+    cross3(ax[k], dd, col);
+    rc.J[0][k] = dot3(bn, col); rc.J[1][k] = dot3(t1, col); rc.J[2][k] = dot3(t2, col);
+    vel[0] += rc.J[0][k] * v[k]; vel[1] += rc.J[1][k] * v[k]; vel[2] += rc.J[2][k] * v[k];
+  }
+  double imp = impedance(c.ct_solimp[bo], bd - c.ct_margin[bo]);
+  double Rn = fmax(1e-15, (1 - imp) / imp * c.rod_invweight0);
+  double Rt = Rn / fmax(1e-15, c.impratio);
+  double f0 = c.ct_fric[bo][0];
+  rc.mu = f0 * sqrt(Rt / Rn); rc.fric[0] = f0; rc.fric[1] = f0;
+  rc.D[0] = 1 / Rn; rc.D[1] = 1 / Rt; rc.D[2] = 1 / Rt;
+  rc.aref[0] = -c.ct_B[bo] * vel[0] - c.ct_K[bo] * imp * (bd - c.ct_margin[bo]);
+  rc.aref[1] = -c.ct_B[bo] * vel[1]; rc.aref[2] = -c.ct_B[bo] * vel[2];
+}
+
 // One mj_step (forward dynamics with the ctrl computed by the caller + semi-implicit Euler with implicit joint
 // damping) followed by the state read-back.  `tau` = controller torque WITHOUT gravity compensation for the arm,
 // `ffing` = raw finger command.  Updates q, v, bias (qfrc_bias of THIS forward pass), tcp (pre-integration pose).
-template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const double* tau, const double* ffing) {
+//
+// Constraint handling.  The soft-constraint problem min 1/2 (a-a0)'M(a-a0) + sum_i s_i(J_i a - aref_i) is strictly
+// convex, so any exact method reproduces MuJoCo's Newton optimum.  Hot path: the only rows are finger joint limits
+// (the fingers rest on their 0.04 m stop for most of an episode).  Their Jacobians are unit vectors on the last two
+// dofs, so the optimum follows from the 2x2 block W = (M^-1)_FF, read off the LDL^T factors, by checking the four
+// active sets - no iteration.  The same factors, with the last two pivots updated for the implicit damping term h B,
+// give the integration solve: one 9x9 factorisation per sub-step.  Arm limit rows or a rod contact (rare) take the
+// general out-of-line Newton path.
+template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const double* tau, const double* ffing, double* warm) {
   DynOut dyn;
   dynamics(c0, st.q, st.v, dyn);
   D3IL_REFRESH(c0, c);
@@ -757,91 +888,116 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
     double t[3]; mulE(dyn.R7, c.tcp7, t);
     st.tcp[0] = dyn.p7[0] + t[0]; st.tcp[1] = dyn.p7[1] + t[1]; st.tcp[2] = dyn.p7[2] + t[2];
   }
-  // ---- constraints: joint limits
-  double lim_sign[NDOF], lim_D[NDOF], lim_aref[NDOF];
-  bool any = false;
+  // ---- which constraints exist?
+  bool arm_rows = false;
 #pragma unroll
-  for (int k = 0; k < NDOF; k++) {
-    D3IL_REFRESH(c0, c);
-    double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
+  for (int k = 0; k < NARM; k++) arm_rows = arm_rows || (st.q[k] - c.jnt_range[k][0] < c.lim_margin[k]) || (c.jnt_range[k][1] - st.q[k] < c.lim_margin[k]);
+  double fsign[NFING], fD[NFING], faref[NFING];
+#pragma unroll
+  for (int k = 0; k < NFING; k++) {
+    int j = NARM + k;
+    double dlo = st.q[j] - c.jnt_range[j][0], dhi = c.jnt_range[j][1] - st.q[j];
     double sign = 0, dist = 0;
-    if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
-    else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
-    lim_sign[k] = sign; lim_D[k] = 0; lim_aref[k] = 0;
+    if (dlo < c.lim_margin[j]) { sign = 1; dist = dlo; }
+    else if (dhi < c.lim_margin[j]) { sign = -1; dist = dhi; }
+    fsign[k] = sign; fD[k] = 0; faref[k] = 0;
     if (sign != 0) {
-      any = true;
-      double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
-      double R = fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
-      lim_D[k] = 1 / R;
-      lim_aref[k] = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
+      double imp = impedance(c.lim_solimp[j], dist - c.lim_margin[j]);
+      fD[k] = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[j]);
+      faref[k] = -c.lim_B[j] * (sign * st.v[j]) - c.lim_K[j] * imp * (dist - c.lim_margin[j]);
     }
   }
-  // ---- constraints: rod <-> obstacle contact (deepest one)
-  RodContact rc; rc.active = false;
+  // rod <-> obstacle: deepest penetrating pair (geom1 = obstacle, lower geom id; normal points obstacle -> rod)
+  double bd = 1e300, bn[3] = {0, 0, 0}, bp[3] = {0, 0, 0}; int bo = -1, ncon = 0;
   st.flags &= ~F_ROD_CONTACT;
   if (c0.n_obst > 0) {
-    D3IL_REFRESH(c0, c);
     double rcw[3], ruw[3];
     mulE(dyn.R7, c.rod_c7, rcw); rcw[0] += dyn.p7[0]; rcw[1] += dyn.p7[1]; rcw[2] += dyn.p7[2];
     mulE(dyn.R7, c.rod_u7, ruw);
-    double bd = 1e300, bn[3] = {0, 0, 0}, bp[3] = {0, 0, 0}; int bo = -1, ncon = 0;
-    for (int o = 0; o < c.n_obst; o++) {
+    for (int o = 0; o < c0.n_obst; o++) {
       double dist, nrm[3], pos[3];
-      // geom1 = obstacle (lower geom id), geom2 = rod: normal points obstacle -> rod
       if (rod_obstacle(c.ob_c[o], c.ob_u[o], c.ob_r[o], c.ob_h[o], rcw, ruw, c.rod_r, c.rod_h, c.ct_margin[o], &dist, nrm, pos)) {
         ncon++;
         if (dist < bd) { bd = dist; bo = o; bn[0] = nrm[0]; bn[1] = nrm[1]; bn[2] = nrm[2]; bp[0] = pos[0]; bp[1] = pos[1]; bp[2] = pos[2]; }
       }
     }
     if (ncon > 1) st.flags |= F_MULTI_CONTACT;
-    if (bo >= 0) {
-      st.flags |= F_ROD_CONTACT;
-      any = true; rc.active = true;
-      double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3], t1[3], t2[3];
-#pragma unroll
-      for (int i = 0; i < NARM; i++) { sn[i] = sin(st.q[i]); cs[i] = cos(st.q[i]); }
-      world_chain(c0, sn, cs, R7, p7, ax, og);
-      make_frame(bn, t1, t2);
-      double vel[3] = {0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < NARM; k++) {
-        double dd[3] = {bp[0] - og[k][0], bp[1] - og[k][1], bp[2] - og[k][2]}, col[3];
-        cross3(ax[k], dd, col);
-        rc.J[0][k] = dot3(bn, col); rc.J[1][k] = dot3(t1, col); rc.J[2][k] = dot3(t2, col);
-        vel[0] += rc.J[0][k] * st.v[k]; vel[1] += rc.J[1][k] * st.v[k]; vel[2] += rc.J[2][k] * st.v[k];
-      }
-      double imp = impedance(c.ct_solimp[bo], bd - c.ct_margin[bo]);
-      double Rn = fmax(1e-15, (1 - imp) / imp * c.rod_invweight0);
-      double Rt = Rn / fmax(1e-15, c.impratio);
-      double f0 = c.ct_fric[bo][0];
-      rc.mu = f0 * sqrt(Rt / Rn); rc.fric[0] = f0; rc.fric[1] = f0;
-      rc.D[0] = 1 / Rn; rc.D[1] = 1 / Rt; rc.D[2] = 1 / Rt;
-      rc.aref[0] = -c.ct_B[bo] * vel[0] - c.ct_K[bo] * imp * (bd - c.ct_margin[bo]);
-      rc.aref[1] = -c.ct_B[bo] * vel[1]; rc.aref[2] = -c.ct_B[bo] * vel[2];
-    }
+    if (bo >= 0) st.flags |= F_ROD_CONTACT;
   }
-  // ---- accelerations
+  // ---- factorise M once
+  double L[45], d[NDOF];
+  if (!ldl9(dyn.M, L, d)) st.flags |= F_SOLVER_FAIL;
   double fc[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; k++) fc[k] = 0;
-  double L[45], d[NDOF];
-  if (any) {
-    double a0[NDOF], fn = 0;
-    if (!ldl9(dyn.M, L, d)) st.flags |= F_SOLVER_FAIL;
-#pragma unroll
-    for (int k = 0; k < NDOF; k++) { a0[k] = fs[k]; fn += fs[k] * fs[k]; }
+  if (arm_rows || bo >= 0) {
+    // general path (rare, out of line): all limit rows + the rod contact through the primal Newton solver
+    double Mm[45], a0[NDOF], lim_sign[NDOF], lim_D[NDOF], lim_aref[NDOF], fcm[NDOF], fn = 0, qm[NDOF], vm[NDOF];
+    for (int i = 0; i < 45; i++) Mm[i] = dyn.M[i];
+    for (int k = 0; k < NDOF; k++) { a0[k] = fs[k]; fn += fs[k] * fs[k]; qm[k] = st.q[k]; vm[k] = st.v[k]; }
     fn = sqrt(fn);
     ldl9_solve(L, d, a0);
-    if (!solve_constraints(dyn.M, a0, &fn, lim_sign, lim_D, lim_aref, rc, fc)) st.flags |= F_SOLVER_FAIL;
+    for (int k = 0; k < NDOF; k++) {
+      double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
+      double sign = 0, dist = 0;
+      if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
+      else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
+      lim_sign[k] = sign; lim_D[k] = 0; lim_aref[k] = 0;
+      if (sign != 0) {
+        double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
+        lim_D[k] = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
+        lim_aref[k] = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
+      }
+    }
+    RodContact rc; rc.active = false;
+    if (bo >= 0) make_rod_contact(c0, qm, vm, bo, bd, bn, bp, &rc);
+    if (!solve_constraints(Mm, a0, &fn, lim_sign, lim_D, lim_aref, rc, fcm, warm)) st.flags |= F_SOLVER_FAIL;
+    for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
+  } else if (fsign[0] != 0 || fsign[1] != 0) {
+    // finger-limit rows only: exact active-set solution on the 2x2 block W = (M^-1)_FF
+    D3IL_STAT(g_stats.newton_calls++);
+    double l87 = L[tri(8, 7)];
+    double W00 = 1 / d[7] + l87 * l87 / d[8], W01 = -l87 / d[8], W11 = 1 / d[8];
+    // a0_F = (M^-1 fs)_F : full solve needed (a0 depends on all of fs)
+    double a0[NDOF];
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) a0[k] = fs[k];
+    ldl9_solve(L, d, a0);
+    double s0 = fsign[0], s1 = fsign[1];
+    double r0 = s0 * a0[7] - faref[0], r1 = s1 * a0[8] - faref[1];   // row residuals at zero constraint force
+    // with forces f = (f0, f1) >= 0 on the rows: jar_i = r_i + sum_j (s_i W_ij s_j) f_j,  f_i = D_i max(0, -jar_i)
+    double G00 = W00 * s0 * s0, G01 = W01 * s0 * s1, G11 = W11 * s1 * s1;
+    double f0 = 0, f1 = 0;
+    bool have0 = s0 != 0, have1 = s1 != 0, done = false;
+    if (have0 && have1) {   // both active: (I + D G) f = -D r
+      double a = 1 + fD[0] * G00, b = fD[0] * G01, cc = fD[1] * G01, dd = 1 + fD[1] * G11;
+      double det = a * dd - b * cc, y0 = -fD[0] * r0, y1 = -fD[1] * r1;
+      double g0 = (dd * y0 - b * y1) / det, g1 = (a * y1 - cc * y0) / det;
+      if (g0 > 0 && g1 > 0) { f0 = g0; f1 = g1; done = true; }
+    }
+    if (!done && have0) {   // only row 0 active
+      double g0 = -fD[0] * r0 / (1 + fD[0] * G00);
+      if (g0 > 0 && (!have1 || r1 + G01 * g0 >= 0)) { f0 = g0; f1 = 0; done = true; }
+    }
+    if (!done && have1) {   // only row 1 active
+      double g1 = -fD[1] * r1 / (1 + fD[1] * G11);
+      if (g1 > 0 && (!have0 || r0 + G01 * g1 >= 0)) { f1 = g1; f0 = 0; done = true; }
+    }
+    fc[7] = s0 * f0; fc[8] = s1 * f1;
   }
-  // Euler with implicit joint damping: (M + h B) qacc = qfrc_smooth + qfrc_constraint  (mj_EulerSkip [ext])
+  // Euler with implicit joint damping: (M + h B) qacc = qfrc_smooth + qfrc_constraint  (mj_EulerSkip [ext]).  B acts on
+  // the fingers only = the last two dofs, so only the last two pivots and l87 of the LDL^T factors change.
   D3IL_REFRESH(c0, ce);
-  double Md[45], qacc[NDOF];
-#pragma unroll
-  for (int i = 0; i < 45; i++) Md[i] = dyn.M[i];
-#pragma unroll
-  for (int k = 0; k < NFING; k++) Md[tri(NARM + k, NARM + k)] += ce.timestep * ce.f_damping[k];
-  if (!ldl9(Md, L, d)) st.flags |= F_SOLVER_FAIL;
+  {
+    double hb0 = ce.timestep * ce.f_damping[0], hb1 = ce.timestep * ce.f_damping[1];
+    double l87 = L[tri(8, 7)];
+    double S11 = d[8] + l87 * l87 * d[7];      // Schur complement entry (8,8) of M
+    double d7n = d[7] + hb0;
+    double l87n = l87 * d[7] / d7n;
+    double d8n = S11 + hb1 - l87n * l87n * d7n;
+    d[7] = d7n; d[8] = d8n; L[tri(8, 7)] = l87n;
+  }
+  double qacc[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; k++) qacc[k] = fs[k] + fc[k];
   ldl9_solve(L, d, qacc);
@@ -851,7 +1007,7 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
 
 // controllers feeding one physics sub-step (Scene.next_step, core/Scene.py:121-138)
 template <bool IK, bool FAST, class C>
-D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp) {
+D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp, double* warm) {
   double tau[NARM], ff[NFING];
   if (IK) {
     ik_update<FAST>(c, des_pos, des_quat, st.q, st.flags, st.ikq, st.ikqd);
@@ -871,7 +1027,7 @@ D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const doub
     else f2 = clampd(500 * (set_width - w) - 10 * wv, -5, 5);
     ff[k] = f1 + f2;
   }
-  physics_substep(c, st, tau, ff);
+  physics_substep(c, st, tau, ff, warm);
 }
 
 // ObstacleAvoidanceEnv.check_mode (avoiding.py:173-202), literal comparisons
@@ -907,10 +1063,12 @@ D3IL_HD void env_step(const C& c, EnvState& st, const double* action, float* obs
   double dp[3] = {action[0], action[1], action[2]};
   double n = sqrt(action[3] * action[3] + action[4] * action[4] + action[5] * action[5] + action[6] * action[6]);
   double dq[4] = {action[3] / n, action[4] / n, action[5] / n, action[6] / n};
+  double warm[NDOF + 1];
+  warm[NDOF] = 0.0;
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
     D3IL_REFRESH(c, cs);
-    substep<true, FAST>(cs, st, dp, dq, nullptr, 0.04, false);
+    substep<true, FAST>(cs, st, dp, dq, nullptr, 0.04, false, warm);
   }
   st.step += 1;
   check_mode(c, st);
@@ -929,7 +1087,9 @@ template <class C> D3IL_HD void env_reset(const C& c, EnvState& st, const double
   dynamics(c, st.q, st.v, dyn);
 #pragma unroll
   for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
-  substep<false, true>(c, st, nullptr, nullptr, init_qpos, 0.001, false);
+  double warm[NDOF + 1];
+  warm[NDOF] = 0.0;
+  substep<false, true>(c, st, nullptr, nullptr, init_qpos, 0.001, false, warm);
   obs[0] = (float)st.tcp[0]; obs[1] = (float)st.tcp[1];
 }
 

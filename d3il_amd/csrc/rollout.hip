@@ -154,6 +154,7 @@ struct d3il_handle_s {
   bool started;
   d3il_buffers buf;
   bool fast, timing;
+  int lds_pad;            // dynamic LDS bytes requested per workgroup: spreads the single-wave workgroups over CUs
   hipEvent_t ev0, ev1;
   bool ev_valid;
 };
@@ -199,7 +200,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
                                                            "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
   h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
-  h->started = false; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
+  h->started = false; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
   b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = 2; b.action_dim = 7;
@@ -259,12 +260,21 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
   hipStream_t s = (hipStream_t)stream;
+  // Workgroup placement: a workgroup is one wave; the dispatcher packs several of them onto one CU (and SIMD) before
+  // moving on, which halves the per-wave issue rate when only a few hundred waves exist.  Requesting LDS that is not
+  // otherwise needed caps the workgroups per CU so that the waves spread over all 256 CUs / 1024 SIMDs.
+  int nwg = h->stride / WAVE, lds = h->lds_pad;
+  if (lds < 0) {
+    int per_cu = (nwg + 255) / 256;                       // workgroups each CU has to host
+    lds = per_cu >= 8 ? 0 : (160 * 1024 / per_cu) - 1024;  // leave slack below the 160 KiB per-CU pool
+    if (lds > 64 * 1024) lds = 64 * 1024;
+  }
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
   if (h->fast)
-    hipLaunchKernelGGL((k_avoiding_step<true, true>), dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+    hipLaunchKernelGGL((k_avoiding_step<true, true>), dim3(h->stride / WAVE), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                        b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
   else
-    hipLaunchKernelGGL((k_avoiding_step<false, true>), dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+    hipLaunchKernelGGL((k_avoiding_step<false, true>), dim3(h->stride / WAVE), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                        b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
   HIPCHK(hipGetLastError());
   if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
@@ -334,6 +344,7 @@ int d3il_last_step_ms(d3il_handle h, float* ms) {
 int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
+  if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }
   return fail(D3IL_EINVAL, std::string("d3il_set_option: unknown option ") + name);
 }
 

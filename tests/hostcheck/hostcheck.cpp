@@ -2,6 +2,7 @@
 // Lets the CPU test-suite compare the exact device formulation against the oracle without a GPU.
 // It is NOT part of the product: libd3il_rollout.so never links or calls this file, and the product
 // fails loudly when no HIP device is present.
+#define D3IL_HOST_STATS 1
 #include <cstdlib>
 #include <cstring>
 #include "../../d3il_amd/csrc/panda_step.h"
@@ -39,6 +40,7 @@ void* hc_create(const d3il_model_blob* blob, const char** err) {
   return c;
 }
 void hc_destroy(void* c) { std::free(c); }
+void hc_stats(long* out, int reset) { out[0] = g_stats.newton_calls; out[1] = g_stats.newton_iters; out[2] = g_stats.ls_iters; out[3] = g_stats.eig_calls; out[4] = g_stats.ik_calls; out[5] = g_stats.contact_calls; if (reset) g_stats = Stats{0, 0, 0, 0, 0, 0}; }
 int hc_sizeof_consts() { return (int)sizeof(PandaConsts); }
 void hc_get_consts(const void* c, double* dof_invw, double* rod_invw, double* masses, double* coms) {
   const PandaConsts& p = *(const PandaConsts*)c;
@@ -69,8 +71,9 @@ void hc_ik_control(const void* c, const double* setpoint, const double* cur_q, c
   for (int k = 0; k < NARM; k++) tau[k] = p.pd_p[k] * (ikq[k] - cur_q[k]) + p.pd_d[k] * (ikqd[k] - cur_v[k]);
   *flags = (int)f;
 }
+void hc_solve6(const double* A21, const double* b, double lo, double hi, double* x, int fast) { if (fast) ik_solve6<true>(A21, b, lo, hi, x); else ik_solve6<false>(A21, b, lo, hi, x); }
 void hc_physics_substep(const void* c, double* s, int* f, const double* tau, const double* ffing) {
-  EnvState st; unpack(s, f, st); physics_substep(*(const PandaConsts*)c, st, tau, ffing); pack(st, s, f);
+  EnvState st; unpack(s, f, st); double warm[NDOF + 1]; warm[NDOF] = 0; physics_substep(*(const PandaConsts*)c, st, tau, ffing, warm); pack(st, s, f);
 }
 void hc_env_reset(const void* c, const double* init_qpos, double* s, int* f, float* obs) {
   EnvState st; std::memset(&st, 0, sizeof st);
