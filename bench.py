@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
+    ap.add_argument("--lanes", type=int, default=None, help="environments per wave (default 64)")
     ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
     args = ap.parse_args()
 
@@ -85,6 +86,8 @@ def main():
     n = args.envs
     env = ObstacleAvoidanceVecEnv(n, device=dev)
     q, iters, err = env.start()
+    if args.lanes is not None:
+        env.set_option("lanes_per_wave", args.lanes)
     if args.lds_pad is not None:
         env.set_option("lds_pad_bytes", args.lds_pad)
     env_offset = rank * n

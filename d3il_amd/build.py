@@ -70,5 +70,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_stats_variant(verbose: bool = False) -> str:
+    """Diagnostics library with device-side path counters (not used by the product or the tests)."""
+    out = os.path.join(PKG, "libd3il_rollout_stats.so")
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-DD3IL_DEVICE_STATS", "-o", out] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=ROOT)
+    return out
+
+
 if __name__ == "__main__":
+    import sys
     print(build(force=True, verbose=True))
+    if "--stats" in sys.argv:
+        print(build_stats_variant(verbose=True))

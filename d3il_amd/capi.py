@@ -26,7 +26,7 @@ FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
 
 EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
            "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_count_metrics", "d3il_set_timing",
-           "d3il_last_step_ms", "d3il_set_option", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
+           "d3il_last_step_ms", "d3il_set_option", "d3il_debug_stats", "d3il_debug_wave_stats", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
 
 
 class D3ilError(RuntimeError):
@@ -34,7 +34,8 @@ class D3ilError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libd3il_rollout.so")
+    name = "libd3il_rollout_stats.so" if os.environ.get("D3IL_STATS_LIB") == "1" else "libd3il_rollout.so"
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
 
 
 def load():

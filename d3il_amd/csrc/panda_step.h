@@ -29,11 +29,31 @@
 #define D3IL_NOINLINE __attribute__((noinline))
 #endif
 
+// D3IL_RARE: paths that were measured both ways; inline by default (the out-of-line call costs more in register
+// save/restore traffic than it saves), -DD3IL_RARE_OUTLINE switches them out of line.
+#if defined(D3IL_RARE_OUTLINE)
+#define D3IL_RARE D3IL_NOINLINE inline
+#else
+#define D3IL_RARE D3IL_HD
+#endif
+
 #if defined(D3IL_HOST_STATS)
 #define D3IL_STAT(x) (x)
+#define D3IL_DSTAT(i) ((void)0)
 namespace d3il { struct Stats { long newton_calls, newton_iters, ls_iters, eig_calls, ik_calls, contact_calls; }; inline Stats g_stats = {0, 0, 0, 0, 0, 0}; }
+#elif defined(D3IL_DEVICE_STATS) && defined(__HIPCC__)
+// diagnostics build only (python -m d3il_amd.build --stats): counts lanes [2i] and waves [2i+1] entering rare paths
+namespace d3il { __device__ unsigned long long g_dev_stats[32]; __device__ unsigned long long g_dev_wave[4096][10]; }
+#define D3IL_STAT(x) ((void)0)
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define D3IL_DSTAT(i) ((void)0)
+#else
+#define D3IL_DSTAT(i) do { atomicAdd(&d3il::g_dev_stats[2 * (i)], 1ull); \
+    if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0) { atomicAdd(&d3il::g_dev_stats[2 * (i) + 1], 1ull); if (blockIdx.x < 4096) atomicAdd(&d3il::g_dev_wave[blockIdx.x][i], 1ull); } } while (0)
+#endif
 #else
 #define D3IL_STAT(x) ((void)0)
+#define D3IL_DSTAT(i) ((void)0)
 #endif
 
 namespace d3il {
@@ -107,7 +127,7 @@ D3IL_HD int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // packed lower-t
 
 // ------------------------------------------------------------------ controller kinematics (URDF chain, core/Model.py:37-66)
 // pos/R of the grasp-target frame, world joint axes and origins
-template <class C> D3IL_HD void ik_chain(const C& c0, const double* q, double* p, double* R, double (*ax)[3], double (*og)[3]) {
+template <class C> D3IL_HD void ik_chain(const C& c0, const double* sq, const double* cq, double* p, double* R, double (*ax)[3], double (*og)[3]) {
   R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
   p[0] = p[1] = p[2] = 0;
 #pragma unroll
@@ -122,8 +142,7 @@ template <class C> D3IL_HD void ik_chain(const C& c0, const double* q, double* p
       for (int cc = 0; cc < 3; cc++) Rn[3 * r + cc] = R[3 * r] * c.KR[k][cc] + R[3 * r + 1] * c.KR[k][3 + cc] + R[3 * r + 2] * c.KR[k][6 + cc];
     ax[k][0] = Rn[2]; ax[k][1] = Rn[5]; ax[k][2] = Rn[8];
     og[k][0] = p[0]; og[k][1] = p[1]; og[k][2] = p[2];
-    double s = sin(q[k]), co = cos(q[k]);
-    joint_rot(Rn, s, co, R);
+    joint_rot(Rn, sq[k], cq[k], R);
   }
   D3IL_REFRESH(c0, c);
   double t[3]; mulE(R, c.tool_x, t);
@@ -209,6 +228,7 @@ D3IL_HD void symv6(const double* A, const double* x, double* y) {
 }
 D3IL_NOINLINE inline void jacobi_solve6(const double* A, const double* b, double minsv, double maxsv, double* x) {
   D3IL_STAT(g_stats.eig_calls++);
+  D3IL_DSTAT(0);
   double M[6][6], V[6][6];
   for (int i = 0; i < 6; i++)
     for (int j = 0; j < 6; j++) { M[i][j] = A[i >= j ? tri(i, j) : tri(j, i)]; V[i][j] = i == j ? 1.0 : 0.0; }
@@ -250,6 +270,7 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
       if (neg == 0) { ldl6_solve(L, d, b, x); need_eig = !ok0; }
       else if (ok0) {
         // smallest eigenpair: two inverse-iteration steps starting from b, then Rayleigh-quotient iteration
+        D3IL_DSTAT(1);
         double v[6], w[6], nr = 0;
         ldl6_solve(L, d, b, w);
         ldl6_solve(L, d, w, v);
@@ -258,12 +279,16 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
         nr = 1.0 / sqrt(nr);
 #pragma unroll
         for (int i = 0; i < 6; i++) v[i] *= nr;
-        double lam = 0;
-        for (int it = 0; it < 4; it++) {
+        double lam = 0, res = 0, vb = 0;
+        for (int it = 0; it < 5; it++) {
           symv6(A, v, w);
           lam = 0;
 #pragma unroll
           for (int i = 0; i < 6; i++) lam += v[i] * w[i];
+          res = 0;
+#pragma unroll
+          for (int i = 0; i < 6; i++) res = fmax(res, fabs(w[i] - lam * v[i]));
+          if (res <= 1e-14 * tr || it == 4) break;
           double L2[21], d2[6], u[6];
           int n2;
           ldl6(A, lam, L2, d2, &n2);
@@ -275,13 +300,8 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
 #pragma unroll
           for (int i = 0; i < 6; i++) v[i] = u[i] * nr;
         }
-        symv6(A, v, w);
-        lam = 0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) lam += v[i] * w[i];
-        double res = 0, vb = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) { res = fmax(res, fabs(w[i] - lam * v[i])); vb += v[i] * b[i]; }
+        for (int i = 0; i < 6; i++) vb += v[i] * b[i];
         if (res <= 1e-14 * tr && lam < minsv && lam > 0) {
           // x = A^-1 (b - (v.b) v) + (v.b)/lo v : the clipped direction is removed BEFORE the solve (no cancellation)
           double bp[6], xp[6], vx = 0;
@@ -324,19 +344,25 @@ D3IL_HD void ik_update(const C& c0, const double* des_pos, const double* des_qua
 #pragma unroll
   for (int k = 0; k < NARM; k++) { old_q[k] = ikq[k]; q[k] = ikq[k]; }
   double dq[4] = {des_quat_in[0], des_quat_in[1], des_quat_in[2], des_quat_in[3]};
+  // sin/cos of the virtual joint angles: exact once per call, then advanced by the angle-addition formulas with a
+  // short Taylor series of the (tiny) increment: |dq| <= ik_lr * 3 (norm clip) - truncation error < 1e-25 relative.
+  double sq[NARM], cq[NARM];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) sincos(q[k], &sq[k], &cq[k]);
+  const bool small_step = c0.ik_lr * 3.0 <= 0.01;
   const int n_it = c0.ik_iters;
 #pragma clang loop unroll(disable)
   for (int it = 0; it < n_it; it++) {
     D3IL_REFRESH(c0, c);
-    double pos[3], R[9], ax[NARM][3], og[NARM][3], cq[4];
-    ik_chain(c, q, pos, R, ax, og);
-    mat2quat(R, cq);
+    double pos[3], R[9], ax[NARM][3], og[NARM][3], cq4[4];
+    ik_chain(c, sq, cq, pos, R, ax, og);
+    mat2quat(R, cq4);
     double dm = 0, dp = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { dm += (cq[k] - dq[k]) * (cq[k] - dq[k]); dp += (cq[k] + dq[k]) * (cq[k] + dq[k]); }
+    for (int k = 0; k < 4; k++) { dm += (cq4[k] - dq[k]) * (cq4[k] - dq[k]); dp += (cq4[k] + dq[k]) * (cq4[k] + dq[k]); }
     if (sqrt(dm) > sqrt(dp)) { dq[0] = -dq[0]; dq[1] = -dq[1]; dq[2] = -dq[2]; dq[3] = -dq[3]; }
     double qe[3], target[6];
-    quat_error(cq, dq, qe);
+    quat_error(cq4, dq, qe);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       target[k] = c.ik_ppos[k] * clampd(des_pos[k] - pos[k], -0.01, 0.01);
@@ -378,7 +404,19 @@ D3IL_HD void ik_update(const C& c0, const double* des_pos, const double* des_qua
       for (int k = 0; k < NARM; k++) qd[k] = qd[k] * 3 / nrm;
     }
 #pragma unroll
-    for (int k = 0; k < NARM; k++) q[k] = clampd(q[k] + c.ik_lr * qd[k], c.q_min[k], c.q_max[k]);
+    for (int k = 0; k < NARM; k++) {
+      double qn2 = clampd(q[k] + c.ik_lr * qd[k], c.q_min[k], c.q_max[k]);
+      if (it + 1 < n_it) {
+        if (small_step) {
+          double dl = qn2 - q[k], d2 = dl * dl;
+          double sd = dl * (1.0 - d2 * (1.0 / 6.0) * (1.0 - d2 * (1.0 / 20.0) * (1.0 - d2 * (1.0 / 42.0))));
+          double cd = 1.0 - d2 * 0.5 * (1.0 - d2 * (1.0 / 12.0) * (1.0 - d2 * (1.0 / 30.0) * (1.0 - d2 * (1.0 / 56.0))));
+          double s2 = sq[k] * cd + cq[k] * sd, c2 = cq[k] * cd - sq[k] * sd;
+          sq[k] = s2; cq[k] = c2;
+        } else sincos(qn2, &sq[k], &cq[k]);
+      }
+      q[k] = qn2;
+    }
   }
 #pragma unroll
   for (int k = 0; k < NARM; k++) { ikqd[k] = (q[k] - old_q[k]) / c0.timestep; ikq[k] = q[k]; }
@@ -417,7 +455,7 @@ template <class C> D3IL_HD void world_chain(const C& c0, const double* sn, const
 template <class C> D3IL_HD void dynamics(const C& c0, const double* q, const double* v, DynOut& o) {
   double sn[NARM], cs[NARM];
 #pragma unroll
-  for (int i = 0; i < NARM; i++) { sn[i] = sin(q[i]); cs[i] = cos(q[i]); }
+  for (int i = 0; i < NARM; i++) sincos(q[i], &sn[i], &cs[i]);
   world_chain(c0, sn, cs, o.R7, o.p7, nullptr, nullptr);
 
   // ---- RNEA forward pass (velocities, accelerations with qacc = 0, base acceleration = -gravity)
@@ -654,8 +692,26 @@ struct RodContact {
 // `warm` (10 doubles: previous solution + validity flag) carries the last optimum of this environment inside one env
 // step; like MuJoCo's qacc_warmstart it only selects the starting point (whichever of warm / a0 has the lower cost),
 // the optimum itself is unique.
-D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, const double* fs_norm_ref, const double* lim_sign, const double* lim_D,
-                                            const double* lim_aref, const RodContact& rc, double* fc_out, double* warm) {
+D3IL_NOINLINE inline bool solve_constraints(const double* __restrict__ M_in, const double* __restrict__ a0_in, const double* __restrict__ fs_norm_ref,
+                                            const double* __restrict__ lim_sign_in, const double* __restrict__ lim_D_in, const double* __restrict__ lim_aref_in,
+                                            const RodContact& rc_in, double* __restrict__ fc_out, double* __restrict__ warm) {
+  // operands arrive through private memory (out-of-line call): pull them into registers once
+  double M[45], a0[NDOF], lim_sign[NDOF], lim_D[NDOF], lim_aref[NDOF];
+#pragma unroll
+  for (int i = 0; i < 45; i++) M[i] = M_in[i];
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) { a0[i] = a0_in[i]; lim_sign[i] = lim_sign_in[i]; lim_D[i] = lim_D_in[i]; lim_aref[i] = lim_aref_in[i]; }
+  RodContact rc;
+  rc.active = rc_in.active;
+  if (rc.active) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int k = 0; k < NARM; k++) rc.J[r][k] = rc_in.J[r][k];
+      rc.D[r] = rc_in.D[r]; rc.aref[r] = rc_in.aref[r];
+    }
+    rc.mu = rc_in.mu; rc.fric[0] = rc_in.fric[0]; rc.fric[1] = rc_in.fric[1];
+  }
   double x[NDOF], Ma[NDOF], grad[NDOF], p[NDOF], fl[NDOF], hl[NDOF];
   double fcn[3] = {0, 0, 0}, Hc[6] = {0, 0, 0, 0, 0, 0};  // contact force and Hessian block (00 11 22 01 02 12)
 #pragma unroll
@@ -664,6 +720,7 @@ D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, c
   bool ok = true;
   D3IL_STAT(g_stats.newton_calls++);
   D3IL_STAT(g_stats.contact_calls += rc.active ? 1 : 0);
+  D3IL_DSTAT(2);
   auto eval_contact = [&](const double* jar, double* force, double* H) {
     double mu = rc.mu, U0 = jar[0] * mu, U1 = jar[1] * rc.fric[0], U2 = jar[2] * rc.fric[1];
     double T = sqrt(U1 * U1 + U2 * U2), Nn = U0;
@@ -689,8 +746,10 @@ D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, c
   if (warm[NDOF] != 0.0) {
     auto total_cost = [&](const double* y) {
       double dy[NDOF], My[NDOF], cst = 0;
+#pragma unroll
       for (int i = 0; i < NDOF; i++) dy[i] = y[i] - a0[i];
       symv9(M, dy, My);
+#pragma unroll
       for (int i = 0; i < NDOF; i++) {
         cst += 0.5 * dy[i] * My[i];
         double jar = lim_sign[i] * y[i] - lim_aref[i];
@@ -698,7 +757,10 @@ D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, c
       }
       if (rc.active) {
         double jr[3];
-        for (int r = 0; r < 3; r++) { double t = -rc.aref[r]; for (int k = 0; k < NARM; k++) t += rc.J[r][k] * y[k]; jr[r] = t; }
+#pragma unroll
+        for (int r = 0; r < 3; r++) { double t = -rc.aref[r];
+#pragma unroll
+          for (int k = 0; k < NARM; k++) t += rc.J[r][k] * y[k]; jr[r] = t; }
         double mu = rc.mu, U1 = jr[1] * rc.fric[0], U2 = jr[2] * rc.fric[1], T = sqrt(U1 * U1 + U2 * U2), Nn = jr[0] * mu;
         if (Nn >= mu * T || (T <= 0 && Nn >= 0)) {}
         else if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) cst += 0.5 * (rc.D[0] * jr[0] * jr[0] + rc.D[1] * jr[1] * jr[1] + rc.D[2] * jr[2] * jr[2]);
@@ -706,7 +768,13 @@ D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, c
       }
       return cst;
     };
-    if (total_cost(warm) < total_cost(a0)) { for (int i = 0; i < NDOF; i++) x[i] = warm[i]; }
+    double wl[NDOF];
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) wl[i] = warm[i];
+    if (total_cost(wl) < total_cost(a0)) {
+#pragma unroll
+      for (int i = 0; i < NDOF; i++) x[i] = wl[i];
+    }
   }
   for (int it = 0; it < 12; it++) {
     // row residuals, forces, Hessian diagonal
@@ -737,6 +805,7 @@ D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, c
     }
     if (sqrt(gn) <= gtol) break;
     D3IL_STAT(g_stats.newton_iters++);
+    D3IL_DSTAT(3);
     // H = M + diag(hl) + Jc^T Hc Jc
     double H[45], L[45], d[NDOF];
 #pragma unroll
@@ -775,6 +844,7 @@ D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, c
     double alpha = 0, lo = 0, hi = -1, best = 1;
     for (int ls = 0; ls < 40; ls++) {
       D3IL_STAT(g_stats.ls_iters++);
+      D3IL_DSTAT(6);
       double d1 = pMa + alpha * pMp, d2 = pMp;
 #pragma unroll
       for (int i = 0; i < NDOF; i++) {
@@ -802,6 +872,7 @@ D3IL_NOINLINE inline bool solve_constraints(const double* M, const double* a0, c
     for (int i = 0; i < NDOF; i++) { x[i] += best * p[i]; stepmax = fmax(stepmax, fabs(best * p[i])); xmax = fmax(xmax, fabs(x[i])); }
     if (stepmax <= 1e-13 * (1.0 + xmax)) break;   // converged to round-off: further iterations cannot move the iterate
   }
+#pragma unroll
   for (int i = 0; i < NDOF; i++) warm[i] = x[i];
   warm[NDOF] = 1.0;
   // forces at the solution
@@ -834,11 +905,255 @@ D3IL_HD void make_frame(const double* n, double* t1, double* t2) {
   cross3(n, t1, t2);
 }
 
+// Contact sub-steps: one elliptic rod contact (3 rows) + the two finger-limit rows (D = 0 when absent) solved in the
+// 5-dimensional constraint space.  At the optimum M (x - a0) = J^T f, so x = a0 + M^-1 J^T f and the row residuals are
+// y = J x - aref = r + A f with A = J M^-1 J^T (5x5, SPD), r = J a0 - aref, f = -grad s(y).  Eliminating f, y minimises
+//   Phi(y) = 1/2 (y - r)^T A^-1 (y - r) + s(y)      (strictly convex, same optimum as the 9-dof primal problem),
+// which is minimised by Newton with an exact line search on 5x5 matrices.  Returns qfrc_constraint = J^T f.
+// `warm` (6 doubles: f of the previous sub-step + validity) only selects the starting point.
+D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __restrict__ d_in, const double* __restrict__ a0_in,
+                                         const RodContact& rc_in, const double* __restrict__ fsign, const double* __restrict__ fD,
+                                         const double* __restrict__ faref, double gscale, double* __restrict__ fc_out, double* __restrict__ warm) {
+  double L[45], d[NDOF], a0[NDOF];
+#pragma unroll
+  for (int i = 0; i < 45; i++) L[i] = L_in[i];
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) { d[i] = d_in[i]; a0[i] = a0_in[i]; }
+  double Jc[3][NARM], Dr[5], aref[5], s7 = fsign[0], s8 = fsign[1];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int k = 0; k < NARM; k++) Jc[r][k] = rc_in.J[r][k];
+    Dr[r] = rc_in.D[r]; aref[r] = rc_in.aref[r];
+  }
+  Dr[3] = fD[0]; Dr[4] = fD[1]; aref[3] = faref[0]; aref[4] = faref[1];
+  const double mu = rc_in.mu, fr0 = rc_in.fric[0], fr1 = rc_in.fric[1];
+  // rows 3,4: finger limits, Jacobian s7 e_7 / s8 e_8 (unit vector with the limit's sign; +1 when the row is absent)
+  const double j3 = s7 != 0 ? s7 : 1.0, j4 = s8 != 0 ? s8 : 1.0;
+  // A = J M^-1 J^T and r = J a0 - aref, one column of M^-1 J^T at a time
+  double A[15], r[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    double u[NDOF];
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) u[k] = j < 3 ? (k < NARM ? Jc[j < 3 ? j : 0][k] : 0.0) : ((j == 3 && k == 7) ? j3 : (j == 4 && k == 8) ? j4 : 0.0);
+    ldl9_solve(L, d, u);
+#pragma unroll
+    for (int i = j; i < 5; i++) {
+      double t = 0;
+      if (i < 3) {
+#pragma unroll
+        for (int k = 0; k < NARM; k++) t += Jc[i < 3 ? i : 0][k] * u[k];
+      } else t = i == 3 ? j3 * u[7] : j4 * u[8];
+      A[tri(i, j)] = t;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) { double t = -aref[i];
+#pragma unroll
+    for (int k = 0; k < NARM; k++) t += Jc[i][k] * a0[k]; r[i] = t; }
+  r[3] = j3 * a0[7] - aref[3]; r[4] = j4 * a0[8] - aref[4];
+  // Ainv (packed symmetric) from the LDL^T of A
+  double LA[15], dA[5], Ai[15];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    double t = A[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) t -= LA[tri(j, k)] * LA[tri(j, k)] * dA[k];
+    dA[j] = t; ok = ok && t > 0;
+    double inv = 1.0 / t;
+#pragma unroll
+    for (int i = j + 1; i < 5; i++) {
+      double v = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) v -= LA[tri(i, k)] * LA[tri(j, k)] * dA[k];
+      LA[tri(i, j)] = v * inv;
+    }
+  }
+  auto solveA = [&](double* x) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) { double t = x[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) t -= LA[tri(i, k)] * x[k]; x[i] = t; }
+#pragma unroll
+    for (int i = 0; i < 5; i++) x[i] /= dA[i];
+#pragma unroll
+    for (int i = 4; i >= 0; i--) { double t = x[i];
+#pragma unroll
+      for (int k = i + 1; k < 5; k++) t -= LA[tri(k, i)] * x[k]; x[i] = t; }
+  };
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    double e[5] = {0, 0, 0, 0, 0}; e[j] = 1; solveA(e);
+#pragma unroll
+    for (int i = j; i < 5; i++) Ai[tri(i, j)] = e[i];
+  }
+  // s(y), -grad (force) and Hessian blocks: cone on rows 0-2, unilateral quadratics on rows 3-4
+  auto eval = [&](const double* y, double* f, double* Hc /*6*/, double* hl /*2*/, bool want_h) {
+    double cst = 0;
+    double U0 = y[0] * mu, U1 = y[1] * fr0, U2 = y[2] * fr1, T = sqrt(U1 * U1 + U2 * U2), Nn = U0;
+    f[0] = f[1] = f[2] = 0;
+    if (want_h) { Hc[0] = Hc[1] = Hc[2] = Hc[3] = Hc[4] = Hc[5] = 0; }
+    if (Nn >= mu * T || (T <= 0 && Nn >= 0)) {}
+    else if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
+      cst += 0.5 * (Dr[0] * y[0] * y[0] + Dr[1] * y[1] * y[1] + Dr[2] * y[2] * y[2]);
+      f[0] = -Dr[0] * y[0]; f[1] = -Dr[1] * y[1]; f[2] = -Dr[2] * y[2];
+      if (want_h) { Hc[0] = Dr[0]; Hc[1] = Dr[1]; Hc[2] = Dr[2]; }
+    } else {
+      double Dm = Dr[0] / fmax(1e-15, mu * mu * (1 + mu * mu)), NmT = Nn - mu * T;
+      double g0 = mu, g1 = -mu * fr0 * U1 / T, g2 = -mu * fr1 * U2 / T;
+      cst += 0.5 * Dm * NmT * NmT;
+      f[0] = -Dm * NmT * g0; f[1] = -Dm * NmT * g1; f[2] = -Dm * NmT * g2;
+      if (want_h) {
+        double k = -mu * NmT, T3 = T * T * T;
+        Hc[0] = Dm * g0 * g0; Hc[3] = Dm * g0 * g1; Hc[4] = Dm * g0 * g2;
+        Hc[1] = Dm * (g1 * g1 + k * fr0 * fr0 * (1 / T - U1 * U1 / T3));
+        Hc[2] = Dm * (g2 * g2 + k * fr1 * fr1 * (1 / T - U2 * U2 / T3));
+        Hc[5] = Dm * (g1 * g2 + k * fr0 * fr1 * (-U1 * U2 / T3));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      double yi = y[3 + i]; bool act = Dr[3 + i] != 0 && yi < 0;
+      f[3 + i] = act ? -Dr[3 + i] * yi : 0.0;
+      if (want_h) hl[i] = act ? Dr[3 + i] : 0.0;
+      if (act) cst += 0.5 * Dr[3 + i] * yi * yi;
+    }
+    return cst;
+  };
+  auto symvAi = [&](const double* x, double* y) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) { double t = 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++) t += Ai[i >= k ? tri(i, k) : tri(k, i)] * x[k]; y[i] = t; }
+  };
+  auto phi = [&](const double* y) {
+    double dy[5], w[5], f[5], t = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) dy[i] = y[i] - r[i];
+    symvAi(dy, w);
+#pragma unroll
+    for (int i = 0; i < 5; i++) t += 0.5 * dy[i] * w[i];
+    return t + eval(y, f, nullptr, nullptr, false);
+  };
+  D3IL_DSTAT(2);
+  D3IL_STAT(g_stats.newton_calls++); D3IL_STAT(g_stats.contact_calls++);
+  double y[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) y[i] = r[i];
+  if (warm[5] != 0.0) {   // y_w = r + A f_w
+    double yw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { double t = r[i];
+#pragma unroll
+      for (int k = 0; k < 5; k++) t += A[i >= k ? tri(i, k) : tri(k, i)] * warm[k]; yw[i] = t; }
+    if (phi(yw) < phi(y)) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) y[i] = yw[i];
+    }
+  }
+  double f[5];
+  const double gtol = 1e-10 * gscale;
+  for (int it = 0; it < 12; it++) {
+    double Hc[6], hl[2], dy[5], g[5];
+    eval(y, f, Hc, hl, true);
+#pragma unroll
+    for (int i = 0; i < 5; i++) dy[i] = y[i] - r[i];
+    symvAi(dy, g);
+    double gn = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { g[i] -= f[i]; gn += g[i] * g[i]; }
+    // in force units: A g has the scale of an acceleration residual; compare the constraint-space gradient through A
+    double Ag[5], an = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { double t = 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++) t += A[i >= k ? tri(i, k) : tri(k, i)] * g[k]; Ag[i] = t; an += t * t; }
+    if (sqrt(an) <= gtol) break;
+    D3IL_DSTAT(3); D3IL_STAT(g_stats.newton_iters++);
+    // H = Ainv + Hs ; p = -H^-1 g   (5x5 LDL^T)
+    double H[15], LH[15], dH[5], p[5];
+#pragma unroll
+    for (int i = 0; i < 15; i++) H[i] = Ai[i];
+    H[tri(0, 0)] += Hc[0]; H[tri(1, 1)] += Hc[1]; H[tri(2, 2)] += Hc[2]; H[tri(1, 0)] += Hc[3]; H[tri(2, 0)] += Hc[4]; H[tri(2, 1)] += Hc[5];
+    H[tri(3, 3)] += hl[0]; H[tri(4, 4)] += hl[1];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      double t = H[tri(j, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= LH[tri(j, k)] * LH[tri(j, k)] * dH[k];
+      dH[j] = t; ok = ok && t > 0;
+      double inv = 1.0 / t;
+#pragma unroll
+      for (int i = j + 1; i < 5; i++) {
+        double v = H[tri(i, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) v -= LH[tri(i, k)] * LH[tri(j, k)] * dH[k];
+        LH[tri(i, j)] = v * inv;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) { double t = -g[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) t -= LH[tri(i, k)] * p[k]; p[i] = t; }
+#pragma unroll
+    for (int i = 0; i < 5; i++) p[i] /= dH[i];
+#pragma unroll
+    for (int i = 4; i >= 0; i--) { double t = p[i];
+#pragma unroll
+      for (int k = i + 1; k < 5; k++) t -= LH[tri(k, i)] * p[k]; p[i] = t; }
+    // exact line search
+    double Aip[5], pAp = 0, pAd = 0;
+    symvAi(p, Aip);
+#pragma unroll
+    for (int i = 0; i < 5; i++) { pAp += p[i] * Aip[i]; pAd += Aip[i] * dy[i]; }
+    double gp0 = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) gp0 += g[i] * p[i];
+    double alpha = 1, lo = 0, hi = -1, best = 1;   // phi'(0) = g.p < 0 is known: start at the full Newton step
+    for (int ls = 0; ls < 40; ls++) {
+      D3IL_DSTAT(6); D3IL_STAT(g_stats.ls_iters++);
+      double yt[5], ft[5], Ht[6], ht[2];
+#pragma unroll
+      for (int i = 0; i < 5; i++) yt[i] = y[i] + alpha * p[i];
+      eval(yt, ft, Ht, ht, true);
+      double d1 = pAd + alpha * pAp, d2 = pAp;
+#pragma unroll
+      for (int i = 0; i < 5; i++) d1 -= ft[i] * p[i];
+      d2 += Ht[0] * p[0] * p[0] + Ht[1] * p[1] * p[1] + Ht[2] * p[2] * p[2] + 2 * (Ht[3] * p[0] * p[1] + Ht[4] * p[0] * p[2] + Ht[5] * p[1] * p[2]) + ht[0] * p[3] * p[3] + ht[1] * p[4] * p[4];
+      best = alpha;
+      // inexact line search: with the exact Hessian the full step passes this test near the optimum, so the outer
+      // iteration keeps its quadratic rate; far from it a 1e-3 reduction of the directional derivative is plenty
+      if (fabs(d1) <= 1e-3 * fabs(gp0)) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 / d2;
+      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+    double stepmax = 0, ymax = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { y[i] += best * p[i]; stepmax = fmax(stepmax, fabs(best * p[i])); ymax = fmax(ymax, fabs(y[i])); }
+    if (stepmax <= 1e-13 * (1.0 + ymax)) break;
+  }
+  eval(y, f, nullptr, nullptr, false);
+#pragma unroll
+  for (int i = 0; i < 5; i++) warm[i] = f[i];
+  warm[5] = 1.0;
+#pragma unroll
+  for (int k = 0; k < NARM; k++) fc_out[k] = Jc[0][k] * f[0] + Jc[1][k] * f[1] + Jc[2][k] * f[2];
+  fc_out[7] = j3 * f[3]; fc_out[8] = j4 * f[4];
+  return ok;
+}
+
 // Rod contact set-up (rare path): Jacobian rows, regularisation and reference acceleration of the deepest contact.
 template <class C>
-D3IL_NOINLINE inline void make_rod_contact(const C& c, const double* q, const double* v, int bo, double bd, const double* bn, const double* bp, RodContact* rcp) {
+D3IL_RARE void make_rod_contact(const C& c, const double* q, const double* v, int bo, double bd, const double* bn, const double* bp, RodContact* rcp) {
   RodContact& rc = *rcp;
   rc.active = true;
+  D3IL_DSTAT(5);
   double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3], t1[3], t2[3];
   for (int i = 0; i < NARM; i++) { sn[i] = sin(q[i]); cs[i] = cos(q[i]); }
   world_chain(c, sn, cs, R7, p7, ax, og);
@@ -872,6 +1187,7 @@ D3IL_NOINLINE inline void make_rod_contact(const C& c, const double* q, const do
 // give the integration solve: one 9x9 factorisation per sub-step.  Arm limit rows or a rod contact (rare) take the
 // general out-of-line Newton path.
 template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const double* tau, const double* ffing, double* warm) {
+  D3IL_DSTAT(7);
   DynOut dyn;
   dynamics(c0, st.q, st.v, dyn);
   D3IL_REFRESH(c0, c);
@@ -930,8 +1246,22 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
   double fc[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; k++) fc[k] = 0;
-  if (arm_rows || bo >= 0) {
-    // general path (rare, out of line): all limit rows + the rod contact through the primal Newton solver
+  if (bo >= 0 && !arm_rows) {
+    // rod contact (+ finger limit rows): 5-dimensional constraint-space Newton, out of line
+    double Lm[45], dm[NDOF], a0[NDOF], fcm[NDOF], qm[NDOF], vm[NDOF], fn = 0;
+    for (int i = 0; i < 45; i++) Lm[i] = L[i];
+    for (int k = 0; k < NDOF; k++) { dm[k] = d[k]; a0[k] = fs[k]; fn += fs[k] * fs[k]; qm[k] = st.q[k]; vm[k] = st.v[k]; fcm[k] = 0; }
+    ldl9_solve(L, d, a0);
+    // gradient scale in acceleration units: |fs| / (mean diagonal of M)
+    double md = 0;
+    for (int k = 0; k < NDOF; k++) md += dyn.M[tri(k, k)];
+    double gscale = (1.0 + sqrt(fn)) / (md / NDOF);
+    RodContact rc; rc.active = false;
+    make_rod_contact(c0, qm, vm, bo, bd, bn, bp, &rc);
+    if (!solve_contact5(Lm, dm, a0, rc, fsign, fD, faref, gscale, fcm, warm)) st.flags |= F_SOLVER_FAIL;
+    for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
+  } else if (arm_rows) {
+    // arm joint-limit rows (very rare): all limit rows + the rod contact through the 9-dof primal Newton solver
     double Mm[45], a0[NDOF], lim_sign[NDOF], lim_D[NDOF], lim_aref[NDOF], fcm[NDOF], fn = 0, qm[NDOF], vm[NDOF];
     for (int i = 0; i < 45; i++) Mm[i] = dyn.M[i];
     for (int k = 0; k < NDOF; k++) { a0[k] = fs[k]; fn += fs[k] * fs[k]; qm[k] = st.q[k]; vm[k] = st.v[k]; }
@@ -951,11 +1281,13 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
     }
     RodContact rc; rc.active = false;
     if (bo >= 0) make_rod_contact(c0, qm, vm, bo, bd, bn, bp, &rc);
-    if (!solve_constraints(Mm, a0, &fn, lim_sign, lim_D, lim_aref, rc, fcm, warm)) st.flags |= F_SOLVER_FAIL;
+    double warm9[NDOF + 1]; warm9[NDOF] = 0.0;
+    if (!solve_constraints(Mm, a0, &fn, lim_sign, lim_D, lim_aref, rc, fcm, warm9)) st.flags |= F_SOLVER_FAIL;
     for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
   } else if (fsign[0] != 0 || fsign[1] != 0) {
     // finger-limit rows only: exact active-set solution on the 2x2 block W = (M^-1)_FF
     D3IL_STAT(g_stats.newton_calls++);
+    D3IL_DSTAT(4);
     double l87 = L[tri(8, 7)];
     double W00 = 1 / d[7] + l87 * l87 / d[8], W01 = -l87 / d[8], W11 = 1 / d[8];
     // a0_F = (M^-1 fs)_F : full solve needed (a0 depends on all of fs)
@@ -1063,8 +1395,8 @@ D3IL_HD void env_step(const C& c, EnvState& st, const double* action, float* obs
   double dp[3] = {action[0], action[1], action[2]};
   double n = sqrt(action[3] * action[3] + action[4] * action[4] + action[5] * action[5] + action[6] * action[6]);
   double dq[4] = {action[3] / n, action[4] / n, action[5] / n, action[6] / n};
-  double warm[NDOF + 1];
-  warm[NDOF] = 0.0;
+  double warm[6];
+  warm[5] = 0.0;
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
     D3IL_REFRESH(c, cs);
@@ -1087,8 +1419,8 @@ template <class C> D3IL_HD void env_reset(const C& c, EnvState& st, const double
   dynamics(c, st.q, st.v, dyn);
 #pragma unroll
   for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
-  double warm[NDOF + 1];
-  warm[NDOF] = 0.0;
+  double warm[6];
+  warm[5] = 0.0;
   substep<false, true>(c, st, nullptr, nullptr, init_qpos, 0.001, false, warm);
   obs[0] = (float)st.tcp[0]; obs[1] = (float)st.tcp[1];
 }

@@ -66,17 +66,23 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_step(const PandaConsts* __res
                                                         unsigned* __restrict__ flags, int* __restrict__ steps,
                                                         const double* __restrict__ actions, float* __restrict__ obs,
                                                         unsigned char* __restrict__ done, unsigned char* __restrict__ success,
-                                                        unsigned short* __restrict__ mode, int n, int stride, int n_substeps, int max_steps) {
-  int e = blockIdx.x * WAVE + threadIdx.x;
-  if (e >= n) return;
+                                                        unsigned short* __restrict__ mode, int n, int stride, int n_substeps, int max_steps, int lanes) {
+  int e = blockIdx.x * lanes + threadIdx.x;
+  if ((int)threadIdx.x >= lanes || e >= n) return;
   EnvState st;
   load_state(state, flags, steps, stride, e, st);
   double act[7];
 #pragma unroll
   for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
   float o[2]; unsigned char dn;
+#if defined(D3IL_DEVICE_STATS)
+  unsigned long long t0 = wall_clock64();
+#endif
   if constexpr (BAKED) env_step<FAST>(kAvoidingConsts, st, act, o, &dn, n_substeps, max_steps);
   else env_step<FAST>(*to_const_as(cp), st, act, o, &dn, n_substeps, max_steps);
+#if defined(D3IL_DEVICE_STATS)
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_dev_wave[blockIdx.x][9] = wall_clock64() - t0;
+#endif
   store_state(state, flags, steps, stride, e, st);
   store_outputs(st, e, o, dn, obs, done, success, mode);
 }
@@ -154,6 +160,7 @@ struct d3il_handle_s {
   bool started;
   d3il_buffers buf;
   bool fast, timing;
+  int lanes;              // active lanes (environments) per wave: 64, or fewer to spread a small batch over more SIMDs
   int lds_pad;            // dynamic LDS bytes requested per workgroup: spreads the single-wave workgroups over CUs
   hipEvent_t ev0, ev1;
   bool ev_valid;
@@ -200,7 +207,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
                                                            "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
   h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
-  h->started = false; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
+  h->started = false; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
   b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = 2; b.action_dim = 7;
@@ -263,7 +270,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   // Workgroup placement: a workgroup is one wave; the dispatcher packs several of them onto one CU (and SIMD) before
   // moving on, which halves the per-wave issue rate when only a few hundred waves exist.  Requesting LDS that is not
   // otherwise needed caps the workgroups per CU so that the waves spread over all 256 CUs / 1024 SIMDs.
-  int nwg = h->stride / WAVE, lds = h->lds_pad;
+  int nwg = (h->n + h->lanes - 1) / h->lanes, lds = h->lds_pad;
   if (lds < 0) {
     int per_cu = (nwg + 255) / 256;                       // workgroups each CU has to host
     lds = per_cu >= 8 ? 0 : (160 * 1024 / per_cu) - 1024;  // leave slack below the 160 KiB per-CU pool
@@ -271,11 +278,11 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   }
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
   if (h->fast)
-    hipLaunchKernelGGL((k_avoiding_step<true, true>), dim3(h->stride / WAVE), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
-                       b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    hipLaunchKernelGGL((k_avoiding_step<true, true>), dim3(nwg), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                       b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, h->lanes);
   else
-    hipLaunchKernelGGL((k_avoiding_step<false, true>), dim3(h->stride / WAVE), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
-                       b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    hipLaunchKernelGGL((k_avoiding_step<false, true>), dim3(nwg), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                       b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, h->lanes);
   HIPCHK(hipGetLastError());
   if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
   return D3IL_OK;
@@ -341,10 +348,38 @@ int d3il_last_step_ms(d3il_handle h, float* ms) {
   HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
   return D3IL_OK;
 }
+int d3il_debug_wave_stats(uint64_t* out, int nwaves, int reset) {
+#if defined(D3IL_DEVICE_STATS)
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(d3il::g_dev_wave), (size_t)nwaves * 10 * sizeof(unsigned long long)));
+  if (reset) { static unsigned long long z[4096][10]; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d3il::g_dev_wave), z, sizeof z)); }
+  return D3IL_OK;
+#else
+  (void)out; (void)nwaves; (void)reset;
+  return fail(D3IL_EUNSUPPORTED, "d3il_debug_wave_stats: library built without D3IL_DEVICE_STATS");
+#endif
+}
+
+/* diagnostics build only: copies (and optionally clears) the device path counters; returns EUNSUPPORTED otherwise */
+int d3il_debug_stats(uint64_t* out32, int reset) {
+#if defined(D3IL_DEVICE_STATS)
+  unsigned long long tmp[32];
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(tmp, HIP_SYMBOL(d3il::g_dev_stats), sizeof tmp));
+  for (int i = 0; i < 32; i++) out32[i] = tmp[i];
+  if (reset) { unsigned long long z[32] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d3il::g_dev_stats), z, sizeof z)); }
+  return D3IL_OK;
+#else
+  (void)out32; (void)reset;
+  return fail(D3IL_EUNSUPPORTED, "d3il_debug_stats: library built without D3IL_DEVICE_STATS");
+#endif
+}
+
 int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }
+  if (std::strcmp(name, "lanes_per_wave") == 0) { if (value < 1 || value > WAVE) return fail(D3IL_EINVAL, "lanes_per_wave must be in 1..64"); h->lanes = value; return D3IL_OK; }
   return fail(D3IL_EINVAL, std::string("d3il_set_option: unknown option ") + name);
 }
 

@@ -56,8 +56,9 @@ void hc_dynamics(const void* c, const double* q, const double* v, double* M81, d
 }
 void hc_ik_fk(const void* c, const double* q, double* pos, double* quat, double* J42) {
   const PandaConsts& p = *(const PandaConsts*)c;
-  double R[9], ax[NARM][3], og[NARM][3];
-  ik_chain(p, q, pos, R, ax, og); mat2quat(R, quat);
+  double R[9], ax[NARM][3], og[NARM][3], sq[NARM], cq[NARM];
+  for (int k = 0; k < NARM; k++) { sq[k] = std::sin(q[k]); cq[k] = std::cos(q[k]); }
+  ik_chain(p, sq, cq, pos, R, ax, og); mat2quat(R, quat);
   for (int k = 0; k < NARM; k++) { double d[3] = {pos[0] - og[k][0], pos[1] - og[k][1], pos[2] - og[k][2]}, cr[3]; cross3(ax[k], d, cr);
     for (int r = 0; r < 3; r++) { J42[r * NARM + k] = cr[r]; J42[(3 + r) * NARM + k] = ax[k][r]; } }
 }
@@ -73,7 +74,7 @@ void hc_ik_control(const void* c, const double* setpoint, const double* cur_q, c
 }
 void hc_solve6(const double* A21, const double* b, double lo, double hi, double* x, int fast) { if (fast) ik_solve6<true>(A21, b, lo, hi, x); else ik_solve6<false>(A21, b, lo, hi, x); }
 void hc_physics_substep(const void* c, double* s, int* f, const double* tau, const double* ffing) {
-  EnvState st; unpack(s, f, st); double warm[NDOF + 1]; warm[NDOF] = 0; physics_substep(*(const PandaConsts*)c, st, tau, ffing, warm); pack(st, s, f);
+  EnvState st; unpack(s, f, st); double warm[6]; warm[5] = 0; physics_substep(*(const PandaConsts*)c, st, tau, ffing, warm); pack(st, s, f);
 }
 void hc_env_reset(const void* c, const double* init_qpos, double* s, int* f, float* obs) {
   EnvState st; std::memset(&st, 0, sizeof st);

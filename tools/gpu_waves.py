@@ -1,0 +1,24 @@
+"""Diagnostics: per-wave duration vs rare-path counts for late-episode steps (stats build)."""
+import ctypes as C, os, sys, numpy as np, torch
+os.environ["D3IL_STATS_LIB"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from d3il_amd import capi
+from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
+n = 4096
+env = ObstacleAvoidanceVecEnv(n, device=0)
+L = capi.load()
+env.start(); env.reset(); env.policy_begin()
+a = torch.zeros(n, 7, dtype=torch.float64, device=env.device)
+W = np.zeros((64, 10), dtype=np.uint64)
+names = ["jacobi", "deflate", "general", "newton_it", "finger", "contact", "ls_it", "substep", "-", "ticks"]
+for t in range(260):
+    env.policy_action(42, 0, t, a)
+    L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), 64, 1)
+    _, _, done, _ = env.step(a)
+    L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), 64, 1)
+    env.reset(done); env.policy_begin(done)
+    if t in (30, 150, 200, 250):
+        order = np.argsort(W[:, 9])
+        print("t", t, "ticks min/median/max", W[order[0], 9], W[order[32], 9], W[order[-1], 9])
+        for w in list(order[:2]) + list(order[30:32]) + list(order[-4:]):
+            print("   wave %2d ticks %9d " % (w, W[w, 9]) + " ".join("%s %d" % (names[i], W[w, i]) for i in (0, 1, 2, 3, 5, 6)))
