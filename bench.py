@@ -138,6 +138,14 @@ def main():
     if rank == 0:
         value = world * n * args.steps / dt
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc runs)
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_bench300.json")) as f:
+                pm = json.load(f)
+            if n == 4096:
+                traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+        except Exception:
+            pass
         achieved = ALG_BYTES_PER_ENV_STEP * n / (k_ms * 1e-3) / 1e9
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -149,7 +157,7 @@ def main():
                        "auto_reset": not args.no_auto_reset, "finite_and_solver_ok": ok,
                        "episodes_finished_rank0": int(total_done.item()), "episodes_success_rank0": int(total_succ.item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_avoiding_step<true,true>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "k_avoiding_step<true,true>", "kernel_ms": k_ms,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n,
                          "note": "path is FP64-VALU/latency bound, not HBM bound: <1 KB of HBM per env step with "

@@ -168,3 +168,69 @@ def test_sim_harness_end_to_end(lib_loaded):
     code = int((g["succeed__mode"][-1].astype(np.int64) * (1 << np.arange(9))).sum())
     assert (sim.last_rollout["mode_code"].cpu().numpy() == code).all()
     assert int(sim.last_rollout["n_pos"][0]) == len(g["succeed__actions"]) + 1
+
+
+def test_all_waves_identical_at_full_size(lib_loaded):
+    """4096 envs (64 waves) fed identical actions: every lane of every wave must reproduce the golden rollout bit for
+    bit equal to lane 0 - guards against lane/wave dependent corruption (register spilling hazards)."""
+    g = np.load(os.path.join(G, "oracle_avoiding_rollout.npz"))
+    n = 4096
+    env = _env(n)
+    env.set_init_qpos(g["init_qpos"])
+    for name in ("collide", "zigzag"):
+        env.reset()
+        acts = g[name + "__actions"]
+        for t in range(len(acts)):
+            a = torch.as_tensor(np.tile(acts[t], (n, 1)), dtype=torch.float64, device=env.device).contiguous()
+            env.step(a)
+            if t % 8 == 7 or t == len(acts) - 1:
+                torch.cuda.synchronize()
+                st, fl, sc = env.get_state()
+                assert (st == st[:, :1]).all() and (fl == fl[0]).all(), "%s step %d" % (name, t)
+                np.testing.assert_allclose(st[:, 0], g[name + "__states"][t + 1], atol=TOL)
+    env.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 1000])
+def test_ragged_batch_sizes_and_masks(lib_loaded, init_qpos, n):
+    """n_envs not a multiple of the wave size; masked reset of a subset; step cap; per-env results independent of n."""
+    g = np.load(os.path.join(G, "oracle_avoiding_rollout.npz"))
+    env = _env(n, max_steps_per_episode=20)
+    env.set_init_qpos(g["init_qpos"])
+    env.reset()
+    acts = g["succeed__actions"]
+    for t in range(25):
+        a = torch.as_tensor(np.tile(acts[t], (n, 1)), dtype=torch.float64, device=env.device).contiguous()
+        obs, _, done, (mode, succ) = env.step(a)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        np.testing.assert_allclose(st[:, n - 1], g["succeed__states"][t + 1], atol=TOL)
+        assert bool(done.all()) == (t >= 19) and bool(done.any()) == (t >= 19)      # counter >= max_steps - 1
+    mask = torch.zeros(n, dtype=torch.uint8, device=env.device)
+    mask[::2] = 1
+    env.reset(mask)
+    torch.cuda.synchronize()
+    st2, fl2, sc2 = env.get_state()
+    m = mask.cpu().numpy().astype(bool)
+    assert (sc2[m] == 0).all() and (sc2[~m] == 25).all()
+    np.testing.assert_allclose(st2[:, 0], g["succeed__states"][0], atol=TOL)
+    if n > 1:
+        assert np.array_equal(st2[:, 1], st[:, 1])
+    env.close()
+
+
+def test_api_errors(lib_loaded):
+    import ctypes as C
+    from d3il_amd import capi
+    from d3il_amd.model import blob
+    L = capi.load()
+    b = blob.load("avoiding")
+    h = C.c_void_p()
+    assert L.d3il_create(0, 0, 0, C.byref(b), C.sizeof(b), C.byref(h)) == -1          # n_envs <= 0
+    assert L.d3il_create(0, 8, 0, C.byref(b), 17, C.byref(h)) == -2                     # blob size
+    assert L.d3il_create(1, 8, 0, C.byref(b), C.sizeof(b), C.byref(h)) == -5           # task not implemented
+    b2 = blob.load("avoiding"); b2.body_mass[35] *= 1.01
+    assert L.d3il_create(0, 8, 0, C.byref(b2), C.sizeof(b2), C.byref(h)) == -5 and b"specialised" in L.d3il_last_error()
+    assert L.d3il_create(0, 8, 0, C.byref(b), C.sizeof(b), C.byref(h)) == 0
+    assert L.d3il_reset(h, None, None, None) == -6 and b"d3il_start" in L.d3il_last_error()   # env.start() first
+    assert L.d3il_destroy(h) == 0
