@@ -34,6 +34,8 @@ class D3ilError(RuntimeError):
 
 
 def lib_path() -> str:
+    if os.environ.get("D3IL_LIB_PATH"):       # A/B measurements of two builds on the same GPU box
+        return os.environ["D3IL_LIB_PATH"]
     name = "libd3il_rollout_stats.so" if os.environ.get("D3IL_STATS_LIB") == "1" else "libd3il_rollout.so"
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
 

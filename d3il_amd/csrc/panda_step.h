@@ -186,7 +186,7 @@ D3IL_HD void quat_error(const double* c, const double* d, double* e) {  // utils
 //  2. exactly one eigenvalue l1 < lo  ->  x = A^-1 b + (1/lo - 1/l1) (v1 . b) v1 with (l1, v1) from inverse
 //     iteration followed by Rayleigh-quotient iteration; accepted only if the eigen-residual is at round-off level.
 //  3. anything else (or path 2 not accepted)  ->  cyclic Jacobi eigen-decomposition.
-D3IL_HD bool ldl6(const double* A, double shift, double* L, double* d, int* n_neg) {
+D3IL_HD bool ldl6(const double* A, double shift, double* L, double* d, double* id, int* n_neg) {
   bool ok = true; int neg = 0;
 #pragma unroll
   for (int j = 0; j < 6; j++) {
@@ -196,6 +196,7 @@ D3IL_HD bool ldl6(const double* A, double shift, double* L, double* d, int* n_ne
     if (fabs(s) < 1e-30) { s = 1e-30; ok = false; }
     d[j] = s; neg += s < 0 ? 1 : 0;
     double inv = 1.0 / s;
+    id[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       double t = A[tri(i, j)];
@@ -207,14 +208,14 @@ D3IL_HD bool ldl6(const double* A, double shift, double* L, double* d, int* n_ne
   *n_neg = neg;
   return ok;
 }
-D3IL_HD void ldl6_solve(const double* L, const double* d, const double* b, double* x) {
+D3IL_HD void ldl6_solve(const double* L, const double* id, const double* b, double* x) {
   double y[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) { double s = b[i];
 #pragma unroll
     for (int k = 0; k < i; k++) s -= L[tri(i, k)] * y[k]; y[i] = s; }
 #pragma unroll
-  for (int i = 0; i < 6; i++) y[i] /= d[i];
+  for (int i = 0; i < 6; i++) y[i] *= id[i];
 #pragma unroll
   for (int i = 5; i >= 0; i--) { double s = y[i];
 #pragma unroll
@@ -260,20 +261,20 @@ template <bool FAST>
 D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double maxsv, double* x) {
   bool need_eig = true;
   if (FAST) {
-    double L[21], d[6];
+    double L[21], d[6], id[6];
     int neg = 0;
-    bool okp = ldl6(A, minsv, L, d, &neg);
+    bool okp = ldl6(A, minsv, L, d, id, &neg);
     double tr = A[tri(0, 0)] + A[tri(1, 1)] + A[tri(2, 2)] + A[tri(3, 3)] + A[tri(4, 4)] + A[tri(5, 5)];
     if (okp && tr < maxsv && neg <= 1) {
       int dummy;
-      bool ok0 = ldl6(A, 0.0, L, d, &dummy);
-      if (neg == 0) { ldl6_solve(L, d, b, x); need_eig = !ok0; }
+      bool ok0 = ldl6(A, 0.0, L, d, id, &dummy);
+      if (neg == 0) { ldl6_solve(L, id, b, x); need_eig = !ok0; }
       else if (ok0) {
         // smallest eigenpair: two inverse-iteration steps starting from b, then Rayleigh-quotient iteration
         D3IL_DSTAT(1);
         double v[6], w[6], nr = 0;
-        ldl6_solve(L, d, b, w);
-        ldl6_solve(L, d, w, v);
+        ldl6_solve(L, id, b, w);
+        ldl6_solve(L, id, w, v);
 #pragma unroll
         for (int i = 0; i < 6; i++) nr += v[i] * v[i];
         nr = 1.0 / sqrt(nr);
@@ -289,10 +290,10 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
 #pragma unroll
           for (int i = 0; i < 6; i++) res = fmax(res, fabs(w[i] - lam * v[i]));
           if (res <= 1e-14 * tr || it == 4) break;
-          double L2[21], d2[6], u[6];
+          double L2[21], d2[6], id2[6], u[6];
           int n2;
-          ldl6(A, lam, L2, d2, &n2);
-          ldl6_solve(L2, d2, v, u);
+          ldl6(A, lam, L2, d2, id2, &n2);
+          ldl6_solve(L2, id2, v, u);
           nr = 0;
 #pragma unroll
           for (int i = 0; i < 6; i++) nr += u[i] * u[i];
@@ -307,7 +308,7 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
           double bp[6], xp[6], vx = 0;
 #pragma unroll
           for (int i = 0; i < 6; i++) bp[i] = b[i] - vb * v[i];
-          ldl6_solve(L, d, bp, xp);
+          ldl6_solve(L, id, bp, xp);
 #pragma unroll
           for (int i = 0; i < 6; i++) vx += v[i] * xp[i];
           double g = vb / minsv - vx;
@@ -603,7 +604,7 @@ template <class C> D3IL_HD void dynamics(const C& c0, const double* q, const dou
 }
 
 // packed LDL^T of a 9x9 SPD matrix: L unit lower (strict part stored), d pivots.  Returns false if a pivot <= 0.
-D3IL_HD bool ldl9(const double* A, double* L, double* d) {
+D3IL_HD bool ldl9(const double* A, double* L, double* d, double* id) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < NDOF; j++) {
@@ -612,6 +613,7 @@ D3IL_HD bool ldl9(const double* A, double* L, double* d) {
     for (int k = 0; k < j; k++) s -= L[tri(j, k)] * L[tri(j, k)] * d[k];
     d[j] = s; ok = ok && (s > 0);
     double inv = 1.0 / s;
+    id[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < NDOF; i++) {
       double t = A[tri(i, j)];
@@ -622,13 +624,13 @@ D3IL_HD bool ldl9(const double* A, double* L, double* d) {
   }
   return ok;
 }
-D3IL_HD void ldl9_solve(const double* L, const double* d, double* x) {
+D3IL_HD void ldl9_solve(const double* L, const double* id, double* x) {
 #pragma unroll
   for (int i = 0; i < NDOF; i++) { double s = x[i];
 #pragma unroll
     for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k]; x[i] = s; }
 #pragma unroll
-  for (int i = 0; i < NDOF; i++) x[i] /= d[i];
+  for (int i = 0; i < NDOF; i++) x[i] *= id[i];
 #pragma unroll
   for (int i = NDOF - 1; i >= 0; i--) { double s = x[i];
 #pragma unroll
@@ -807,7 +809,7 @@ D3IL_NOINLINE inline bool solve_constraints(const double* __restrict__ M_in, con
     D3IL_STAT(g_stats.newton_iters++);
     D3IL_DSTAT(3);
     // H = M + diag(hl) + Jc^T Hc Jc
-    double H[45], L[45], d[NDOF];
+    double H[45], L[45], d[NDOF], id[NDOF];
 #pragma unroll
     for (int i = 0; i < 45; i++) H[i] = M[i];
 #pragma unroll
@@ -825,10 +827,10 @@ D3IL_NOINLINE inline bool solve_constraints(const double* __restrict__ M_in, con
 #pragma unroll
         for (int b = 0; b <= a; b++) H[tri(a, b)] += rc.J[0][a] * T0[b] + rc.J[1][a] * T1[b] + rc.J[2][a] * T2[b];
     }
-    if (!ldl9(H, L, d)) { ok = false; break; }
+    if (!ldl9(H, L, d, id)) { ok = false; break; }
 #pragma unroll
     for (int i = 0; i < NDOF; i++) p[i] = -grad[i];
-    ldl9_solve(L, d, p);
+    ldl9_solve(L, id, p);
     // exact line search on the convex 1-D restriction
     double Mp[NDOF], Jp[3] = {0, 0, 0};
     symv9(M, p, Mp);
@@ -911,14 +913,14 @@ D3IL_HD void make_frame(const double* n, double* t1, double* t2) {
 //   Phi(y) = 1/2 (y - r)^T A^-1 (y - r) + s(y)      (strictly convex, same optimum as the 9-dof primal problem),
 // which is minimised by Newton with an exact line search on 5x5 matrices.  Returns qfrc_constraint = J^T f.
 // `warm` (6 doubles: f of the previous sub-step + validity) only selects the starting point.
-D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __restrict__ d_in, const double* __restrict__ a0_in,
+D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __restrict__ id_in, const double* __restrict__ a0_in,
                                          const RodContact& rc_in, const double* __restrict__ fsign, const double* __restrict__ fD,
                                          const double* __restrict__ faref, double gscale, double* __restrict__ fc_out, double* __restrict__ warm) {
-  double L[45], d[NDOF], a0[NDOF];
+  double L[45], id[NDOF], a0[NDOF];
 #pragma unroll
   for (int i = 0; i < 45; i++) L[i] = L_in[i];
 #pragma unroll
-  for (int i = 0; i < NDOF; i++) { d[i] = d_in[i]; a0[i] = a0_in[i]; }
+  for (int i = 0; i < NDOF; i++) { id[i] = id_in[i]; a0[i] = a0_in[i]; }
   double Jc[3][NARM], Dr[5], aref[5], s7 = fsign[0], s8 = fsign[1];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -928,6 +930,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
   }
   Dr[3] = fD[0]; Dr[4] = fD[1]; aref[3] = faref[0]; aref[4] = faref[1];
   const double mu = rc_in.mu, fr0 = rc_in.fric[0], fr1 = rc_in.fric[1];
+  const double Dm = rc_in.D[0] / fmax(1e-15, mu * mu * (1 + mu * mu));   // middle-zone stiffness of the cone
   // rows 3,4: finger limits, Jacobian s7 e_7 / s8 e_8 (unit vector with the limit's sign; +1 when the row is absent)
   const double j3 = s7 != 0 ? s7 : 1.0, j4 = s8 != 0 ? s8 : 1.0;
   // A = J M^-1 J^T and r = J a0 - aref, one column of M^-1 J^T at a time
@@ -937,7 +940,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
     double u[NDOF];
 #pragma unroll
     for (int k = 0; k < NDOF; k++) u[k] = j < 3 ? (k < NARM ? Jc[j < 3 ? j : 0][k] : 0.0) : ((j == 3 && k == 7) ? j3 : (j == 4 && k == 8) ? j4 : 0.0);
-    ldl9_solve(L, d, u);
+    ldl9_solve(L, id, u);
 #pragma unroll
     for (int i = j; i < 5; i++) {
       double t = 0;
@@ -954,7 +957,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
     for (int k = 0; k < NARM; k++) t += Jc[i][k] * a0[k]; r[i] = t; }
   r[3] = j3 * a0[7] - aref[3]; r[4] = j4 * a0[8] - aref[4];
   // Ainv (packed symmetric) from the LDL^T of A
-  double LA[15], dA[5], Ai[15];
+  double LA[15], dA[5], idA[5], Ai[15];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 5; j++) {
@@ -963,6 +966,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
     for (int k = 0; k < j; k++) t -= LA[tri(j, k)] * LA[tri(j, k)] * dA[k];
     dA[j] = t; ok = ok && t > 0;
     double inv = 1.0 / t;
+    idA[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 5; i++) {
       double v = A[tri(i, j)];
@@ -977,7 +981,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
 #pragma unroll
       for (int k = 0; k < i; k++) t -= LA[tri(i, k)] * x[k]; x[i] = t; }
 #pragma unroll
-    for (int i = 0; i < 5; i++) x[i] /= dA[i];
+    for (int i = 0; i < 5; i++) x[i] *= idA[i];
 #pragma unroll
     for (int i = 4; i >= 0; i--) { double t = x[i];
 #pragma unroll
@@ -1001,16 +1005,16 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
       f[0] = -Dr[0] * y[0]; f[1] = -Dr[1] * y[1]; f[2] = -Dr[2] * y[2];
       if (want_h) { Hc[0] = Dr[0]; Hc[1] = Dr[1]; Hc[2] = Dr[2]; }
     } else {
-      double Dm = Dr[0] / fmax(1e-15, mu * mu * (1 + mu * mu)), NmT = Nn - mu * T;
-      double g0 = mu, g1 = -mu * fr0 * U1 / T, g2 = -mu * fr1 * U2 / T;
+      double NmT = Nn - mu * T, iT = 1.0 / T;
+      double g0 = mu, g1 = -mu * fr0 * U1 * iT, g2 = -mu * fr1 * U2 * iT;
       cst += 0.5 * Dm * NmT * NmT;
       f[0] = -Dm * NmT * g0; f[1] = -Dm * NmT * g1; f[2] = -Dm * NmT * g2;
       if (want_h) {
-        double k = -mu * NmT, T3 = T * T * T;
+        double k = -mu * NmT, iT3 = iT * iT * iT;
         Hc[0] = Dm * g0 * g0; Hc[3] = Dm * g0 * g1; Hc[4] = Dm * g0 * g2;
-        Hc[1] = Dm * (g1 * g1 + k * fr0 * fr0 * (1 / T - U1 * U1 / T3));
-        Hc[2] = Dm * (g2 * g2 + k * fr1 * fr1 * (1 / T - U2 * U2 / T3));
-        Hc[5] = Dm * (g1 * g2 + k * fr0 * fr1 * (-U1 * U2 / T3));
+        Hc[1] = Dm * (g1 * g1 + k * fr0 * fr0 * (iT - U1 * U1 * iT3));
+        Hc[2] = Dm * (g2 * g2 + k * fr1 * fr1 * (iT - U2 * U2 * iT3));
+        Hc[5] = Dm * (g1 * g2 + k * fr0 * fr1 * (-U1 * U2 * iT3));
       }
     }
 #pragma unroll
@@ -1073,7 +1077,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
     if (sqrt(an) <= gtol) break;
     D3IL_DSTAT(3); D3IL_STAT(g_stats.newton_iters++);
     // H = Ainv + Hs ; p = -H^-1 g   (5x5 LDL^T)
-    double H[15], LH[15], dH[5], p[5];
+    double H[15], LH[15], dH[5], idH[5], p[5];
 #pragma unroll
     for (int i = 0; i < 15; i++) H[i] = Ai[i];
     H[tri(0, 0)] += Hc[0]; H[tri(1, 1)] += Hc[1]; H[tri(2, 2)] += Hc[2]; H[tri(1, 0)] += Hc[3]; H[tri(2, 0)] += Hc[4]; H[tri(2, 1)] += Hc[5];
@@ -1085,6 +1089,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
       for (int k = 0; k < j; k++) t -= LH[tri(j, k)] * LH[tri(j, k)] * dH[k];
       dH[j] = t; ok = ok && t > 0;
       double inv = 1.0 / t;
+      idH[j] = inv;
 #pragma unroll
       for (int i = j + 1; i < 5; i++) {
         double v = H[tri(i, j)];
@@ -1098,7 +1103,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
 #pragma unroll
       for (int k = 0; k < i; k++) t -= LH[tri(i, k)] * p[k]; p[i] = t; }
 #pragma unroll
-    for (int i = 0; i < 5; i++) p[i] /= dH[i];
+    for (int i = 0; i < 5; i++) p[i] *= idH[i];
 #pragma unroll
     for (int i = 4; i >= 0; i--) { double t = p[i];
 #pragma unroll
@@ -1241,8 +1246,8 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
     if (bo >= 0) st.flags |= F_ROD_CONTACT;
   }
   // ---- factorise M once
-  double L[45], d[NDOF];
-  if (!ldl9(dyn.M, L, d)) st.flags |= F_SOLVER_FAIL;
+  double L[45], d[NDOF], id[NDOF];
+  if (!ldl9(dyn.M, L, d, id)) st.flags |= F_SOLVER_FAIL;
   double fc[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; k++) fc[k] = 0;
@@ -1250,8 +1255,8 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
     // rod contact (+ finger limit rows): 5-dimensional constraint-space Newton, out of line
     double Lm[45], dm[NDOF], a0[NDOF], fcm[NDOF], qm[NDOF], vm[NDOF], fn = 0;
     for (int i = 0; i < 45; i++) Lm[i] = L[i];
-    for (int k = 0; k < NDOF; k++) { dm[k] = d[k]; a0[k] = fs[k]; fn += fs[k] * fs[k]; qm[k] = st.q[k]; vm[k] = st.v[k]; fcm[k] = 0; }
-    ldl9_solve(L, d, a0);
+    for (int k = 0; k < NDOF; k++) { dm[k] = id[k]; a0[k] = fs[k]; fn += fs[k] * fs[k]; qm[k] = st.q[k]; vm[k] = st.v[k]; fcm[k] = 0; }
+    ldl9_solve(L, id, a0);
     // gradient scale in acceleration units: |fs| / (mean diagonal of M)
     double md = 0;
     for (int k = 0; k < NDOF; k++) md += dyn.M[tri(k, k)];
@@ -1266,7 +1271,7 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
     for (int i = 0; i < 45; i++) Mm[i] = dyn.M[i];
     for (int k = 0; k < NDOF; k++) { a0[k] = fs[k]; fn += fs[k] * fs[k]; qm[k] = st.q[k]; vm[k] = st.v[k]; }
     fn = sqrt(fn);
-    ldl9_solve(L, d, a0);
+    ldl9_solve(L, id, a0);
     for (int k = 0; k < NDOF; k++) {
       double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
       double sign = 0, dist = 0;
@@ -1289,12 +1294,12 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
     D3IL_STAT(g_stats.newton_calls++);
     D3IL_DSTAT(4);
     double l87 = L[tri(8, 7)];
-    double W00 = 1 / d[7] + l87 * l87 / d[8], W01 = -l87 / d[8], W11 = 1 / d[8];
+    double W00 = id[7] + l87 * l87 * id[8], W01 = -l87 * id[8], W11 = id[8];
     // a0_F = (M^-1 fs)_F : full solve needed (a0 depends on all of fs)
     double a0[NDOF];
 #pragma unroll
     for (int k = 0; k < NDOF; k++) a0[k] = fs[k];
-    ldl9_solve(L, d, a0);
+    ldl9_solve(L, id, a0);
     double s0 = fsign[0], s1 = fsign[1];
     double r0 = s0 * a0[7] - faref[0], r1 = s1 * a0[8] - faref[1];   // row residuals at zero constraint force
     // with forces f = (f0, f1) >= 0 on the rows: jar_i = r_i + sum_j (s_i W_ij s_j) f_j,  f_i = D_i max(0, -jar_i)
@@ -1324,15 +1329,15 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
     double hb0 = ce.timestep * ce.f_damping[0], hb1 = ce.timestep * ce.f_damping[1];
     double l87 = L[tri(8, 7)];
     double S11 = d[8] + l87 * l87 * d[7];      // Schur complement entry (8,8) of M
-    double d7n = d[7] + hb0;
-    double l87n = l87 * d[7] / d7n;
+    double d7n = d[7] + hb0, i7 = 1.0 / d7n;
+    double l87n = l87 * d[7] * i7;
     double d8n = S11 + hb1 - l87n * l87n * d7n;
-    d[7] = d7n; d[8] = d8n; L[tri(8, 7)] = l87n;
+    d[7] = d7n; d[8] = d8n; id[7] = i7; id[8] = 1.0 / d8n; L[tri(8, 7)] = l87n;
   }
   double qacc[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; k++) qacc[k] = fs[k] + fc[k];
-  ldl9_solve(L, d, qacc);
+  ldl9_solve(L, id, qacc);
 #pragma unroll
   for (int k = 0; k < NDOF; k++) { st.v[k] += ce.timestep * qacc[k]; st.q[k] += ce.timestep * st.v[k]; }
 }
@@ -1435,10 +1440,10 @@ D3IL_HOST inline void finish_invweights(PandaConsts& c) {
   double q[NDOF] = {0}, v[NDOF] = {0};
   DynOut dyn;
   dynamics(c, q, v, dyn);
-  double L[45], d[NDOF], Minv[NDOF][NDOF];
-  ldl9(dyn.M, L, d);
+  double L[45], d[NDOF], id[NDOF], Minv[NDOF][NDOF];
+  ldl9(dyn.M, L, d, id);
   for (int col = 0; col < NDOF; col++) {
-    double e[NDOF] = {0}; e[col] = 1; ldl9_solve(L, d, e);
+    double e[NDOF] = {0}; e[col] = 1; ldl9_solve(L, id, e);
     for (int r = 0; r < NDOF; r++) Minv[r][col] = e[r];
   }
   for (int k = 0; k < NDOF; k++) c.dof_invweight0[k] = Minv[k][k];
