@@ -19,8 +19,12 @@ DEPS = SOURCES + [os.path.join(PKG, "csrc", "panda_step.h"), os.path.join(PKG, "
 # -disable-machine-licm / -disable-machine-sink: with the model constants baked in as literals, MachineLICM hoists
 # their materialisation (s_mov pairs) out of the sub-step loop and then spills ~350 SGPRs through VGPR lanes;
 # keeping them next to their use costs nothing (they are re-materialisable) and removes the spills.
+# -fno-signed-zeros / -ffinite-math-only (device pass only): value-preserving for finite data; they let the compiler
+# drop the multiplications by the exact zeros of the baked kinematic constants (x * 0 -> 0, x + 0 -> x): -17 % FP64
+# instructions.  The kernels never produce or consume NaN/Inf on purpose (solver failures are flagged, not encoded).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-               "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-machine-sink"]
+               "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-machine-sink",
+               "-Xarch_device", "-fno-signed-zeros", "-Xarch_device", "-ffinite-math-only"]
 
 
 def hipcc() -> str:

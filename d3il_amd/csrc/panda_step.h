@@ -29,13 +29,15 @@
 #define D3IL_NOINLINE __attribute__((noinline))
 #endif
 
-// D3IL_RARE: the contact path, measured both ways on the same MI355X (bench.py, 4096 envs, full episodes): out of line
-// 2.36 M env-steps/s vs inlined 2.16 M (the inlined body raises the register pressure of every sub-step).
-// -DD3IL_RARE_INLINE switches it back for A/B runs.
-#if defined(D3IL_RARE_INLINE)
-#define D3IL_RARE D3IL_HD
-#else
+// D3IL_RARE: the contact path (make_rod_contact, solve_contact5).  Same-box A/B on MI355X (bench.py, 4096 envs, full
+// episodes, device flags of d3il_amd/build.py): inlined 2.33 M env-steps/s, out of line 2.13 M.  NOTE: an out-of-line
+// build WITHOUT the finite-math device flags was observed to be miscompiled by hipcc 7.2 (one state register, qpos[1],
+// corrupted at the end of the step; every other value exact) - the GPU suite's golden-rollout tests catch this class
+// of failure; keep them green for any change of flags or inlining.  -DD3IL_RARE_OUTLINE selects the out-of-line form.
+#if defined(D3IL_RARE_OUTLINE)
 #define D3IL_RARE D3IL_NOINLINE inline
+#else
+#define D3IL_RARE D3IL_HD
 #endif
 
 #if defined(D3IL_HOST_STATS)

@@ -187,6 +187,10 @@ class Oracle:
         self.L.orc_env_step(self.h, _p(action), _p(obs), C.byref(done), _p(mode), C.byref(succ))
         return obs, bool(done.value), mode, bool(succ.value)
 
+    def env_set_state(self, state42, flags, step):
+        state42 = np.ascontiguousarray(state42, float)
+        self.L.orc_env_set_state(self.h, _p(state42), C.c_uint(int(flags)), int(step))
+
     def env_state(self):
         s = np.zeros(42)
         self.L.orc_env_get_state(self.h, _p(s))

@@ -234,3 +234,50 @@ def test_api_errors(lib_loaded):
     assert L.d3il_create(0, 8, 0, C.byref(b), C.sizeof(b), C.byref(h)) == 0
     assert L.d3il_reset(h, None, None, None) == -6 and b"d3il_start" in L.d3il_last_error()   # env.start() first
     assert L.d3il_destroy(h) == 0
+
+
+def test_arbitrary_states_incl_arm_joint_limits(lib_loaded, init_qpos):
+    """set_state -> step from mid-episode states (some with arm joints beyond their range: the rare general constraint
+    path, some in rod contact), each env checked against the oracle started from the same state."""
+    from oracle.oracle import Oracle
+    g = np.load(os.path.join(G, "oracle_avoiding_rollout.npz"))
+    rng = np.random.default_rng(5)
+    n = 96
+    env = _env(n)
+    env.set_init_qpos(init_qpos)
+    env.reset()
+    torch.cuda.synchronize()
+    states = np.zeros((42, n)); flags = np.zeros(n, dtype=np.uint32); steps = np.zeros(n, dtype=np.int32); acts = np.zeros((n, 7))
+    names = ["random", "collide", "succeed", "zigzag"]
+    for e in range(n):
+        name = names[e % 4]
+        T = len(g[name + "__actions"])
+        t = int(rng.integers(1, T - 3)) if e % 8 else T - 3          # every 8th env: just before the episode ends
+        s = g[name + "__states"][t].copy()
+        if e % 3 == 0:                                               # push one arm joint beyond its MJCF range
+            idx, val = [(5, 3.83), (3, 0.09), (1, -1.84), (0, 2.97)][(e // 3) % 4]
+            s[idx] = val; s[9 + idx] = rng.normal(scale=0.3)
+            s[28 + idx] = min(max(val, env.blob.ctrl_qmin[idx]), env.blob.ctrl_qmax[idx])
+        else:
+            s[9:18] += rng.normal(scale=0.02, size=9)
+        f = g[name + "__flags"][t]
+        mode = int((g[name + "__mode"][t].astype(np.int64) * (1 << np.arange(9))).sum())
+        flags[e] = mode | (int(f[4]) << 9) | (int(f[5]) << 10) | (int(f[6]) << 11) | (int(f[1]) << 12) | (int(f[2]) << 13) | (int(f[3]) << 14) | (1 << 15)
+        states[:, e] = s; steps[e] = t; acts[e] = g[name + "__actions"][t]
+    env.set_state(states, flags, steps)
+    a = torch.as_tensor(acts, dtype=torch.float64, device=env.device).contiguous()
+    orcs = []
+    for e in range(n):
+        o = Oracle(env.blob); o.env_start(init_qpos); o.env_reset(); o.env_set_state(states[:, e], int(flags[e]), int(steps[e])); orcs.append(o)
+    for k in range(2):
+        obs, _, done, (mode, succ) = env.step(a)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        for e, o in enumerate(orcs):
+            ob, dn, md, su = o.env_step(acts[e])
+            so, fo = o.env_state()
+            np.testing.assert_allclose(st[:, e], so, atol=TOL, err_msg="env %d pass %d" % (e, k))
+            assert dn == bool(done[e]) and su == bool(succ[e]) and np.array_equal(ob, obs[e].cpu().numpy())
+            assert int(mode[e]) == int((md.astype(np.int64) * (1 << np.arange(9))).sum())
+        assert not (fl & (1 << 16)).any()
+    env.close()

@@ -75,3 +75,32 @@ def test_episode_matches_oracle(hostcheck, oracle, init_qpos, policy, fast):
         assert ended is not None and succ_o and bin(int(f[0]) & 0x1FF).count("1") == 3
     if policy == "random":
         assert ended == 249                                                   # step cap (max_steps - 1)
+
+
+def _limit_cases(blob, g):
+    s0 = g["random__states"][40].copy()
+    out = []
+    for idx, val, vel in ((5, 3.83, 0.5), (3, 0.09, 0.3), (1, -1.84, -0.2), (0, 2.97, 0.1)):
+        s = s0.copy()
+        s[idx], s[9 + idx] = val, vel
+        s[28 + idx] = min(max(val, blob.ctrl_qmin[idx]), blob.ctrl_qmax[idx])
+        out.append(s)
+    return out
+
+
+def test_arm_joint_limit_path_matches_oracle(hostcheck, oracle, avoiding_blob, init_qpos):
+    """Arm joints pushed beyond their MJCF range: the rare 9-dof Newton path of the kernels vs the oracle's rows."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_avoiding_rollout.npz"))
+    oracle.env_start(init_qpos); oracle.env_reset()
+    for s in _limit_cases(avoiding_blob, g):
+        fl = 1 << 15
+        oracle.env_set_state(s, fl, 40)
+        sh, f = s.copy(), np.array([fl, 40], dtype=np.int32)
+        for t in range(3):
+            a = g["random__actions"][40 + t]
+            oracle.env_step(a)
+            so, fo = oracle.env_state()
+            hostcheck.env_step(sh, f, a, True)
+            np.testing.assert_allclose(sh, so, atol=1e-9)
+            assert not (f[0] & (1 << 16))

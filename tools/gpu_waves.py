@@ -1,6 +1,6 @@
 """Diagnostics: per-wave duration vs rare-path counts for late-episode steps (stats build)."""
 import ctypes as C, os, sys, numpy as np, torch
-os.environ["D3IL_STATS_LIB"] = "1"
+os.environ.setdefault("D3IL_STATS_LIB", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from d3il_amd import capi
 from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
