@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
     ap.add_argument("--lanes", type=int, default=None, help="environments per wave (default 64)")
+    ap.add_argument("--split", type=int, default=None, help="1: two-wave controller||physics kernel, 0: fused kernel, default auto")
     ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
     args = ap.parse_args()
 
@@ -88,6 +89,8 @@ def main():
     q, iters, err = env.start()
     if args.lanes is not None:
         env.set_option("lanes_per_wave", args.lanes)
+    if args.split is not None:
+        env.set_option("split_waves", args.split)
     if args.lds_pad is not None:
         env.set_option("lds_pad_bytes", args.lds_pad)
     env_offset = rank * n

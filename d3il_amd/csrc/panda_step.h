@@ -1345,18 +1345,12 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
   for (int k = 0; k < NDOF; k++) { st.v[k] += ce.timestep * qacc[k]; st.q[k] += ce.timestep * st.v[k]; }
 }
 
-// controllers feeding one physics sub-step (Scene.next_step, core/Scene.py:121-138)
-template <bool IK, bool FAST, class C>
-D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp, double* warm) {
+// joint PD on the IK set-point + finger PD + one physics sub-step (the part of Scene.next_step after the IK update)
+template <class C>
+D3IL_HD void control_and_physics(const C& c, EnvState& st, const double* q_des, const double* qd_des, double set_width, bool grasp, double* warm) {
   double tau[NARM], ff[NFING];
-  if (IK) {
-    ik_update<FAST>(c, des_pos, des_quat, st.q, st.flags, st.ikq, st.ikqd);
 #pragma unroll
-    for (int k = 0; k < NARM; k++) tau[k] = c.pd_p[k] * (st.ikq[k] - st.q[k]) + c.pd_d[k] * (st.ikqd[k] - st.v[k]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < NARM; k++) tau[k] = c.pd_p[k] * (pd_q[k] - st.q[k]) + c.pd_d[k] * (0.0 - st.v[k]);
-  }
+  for (int k = 0; k < NARM; k++) tau[k] = c.pd_p[k] * (q_des[k] - st.q[k]) + c.pd_d[k] * (qd_des[k] - st.v[k]);
   // RobotBase.fing_ctrl_step (Robots.py:441-476)
   double mean = 0.5 * (st.q[NARM] + st.q[NARM + 1]);
 #pragma unroll
@@ -1368,6 +1362,18 @@ D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const doub
     ff[k] = f1 + f2;
   }
   physics_substep(c, st, tau, ff, warm);
+}
+
+// controllers feeding one physics sub-step (Scene.next_step, core/Scene.py:121-138)
+template <bool IK, bool FAST, class C>
+D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp, double* warm) {
+  if (IK) {
+    ik_update<FAST>(c, des_pos, des_quat, st.q, st.flags, st.ikq, st.ikqd);
+    control_and_physics(c, st, st.ikq, st.ikqd, set_width, grasp, warm);
+  } else {
+    double zero[NARM] = {0, 0, 0, 0, 0, 0, 0};
+    control_and_physics(c, st, pd_q, zero, set_width, grasp, warm);
+  }
 }
 
 // ObstacleAvoidanceEnv.check_mode (avoiding.py:173-202), literal comparisons
@@ -1389,29 +1395,43 @@ template <class C> D3IL_HD void check_mode(const C& c, EnvState& st) {
   }
 }
 
-// ObstacleAvoidanceEnv.step (avoiding.py:168-171) over GymEnvWrapper.step (gyms/gym_env_wrapper.py:45-100)
-template <bool FAST, class C>
-D3IL_HD void env_step(const C& c, EnvState& st, const double* action, float* obs, unsigned char* done, int n_substeps, int max_steps) {
+// GymEnvWrapper.step before the physics (gyms/gym_env_wrapper.py:88-90): observation and is_finished() of the state
+// produced by the PREVIOUS call; ObstacleAvoidanceEnv._check_early_termination (avoiding.py:236-246)
+template <class C> D3IL_HD void step_begin(const C& c, EnvState& st, float* obs, unsigned char* done, int max_steps) {
   obs[0] = (float)st.tcp[0]; obs[1] = (float)st.tcp[1];
   bool fin = (st.flags & F_TERMINATED) != 0;
-  if (!fin) {  // _check_early_termination (avoiding.py:236-246)
+  if (!fin) {
     bool succ = st.tcp[1] > c.task_f[3];
     if (succ || (st.flags & F_ROD_CONTACT)) { if (succ) st.flags |= F_SUCCESS; st.flags |= F_TERMINATED; fin = true; }
   }
   if (!fin && st.step >= max_steps - 1) fin = true;
   *done = fin ? 1 : 0;
-  double dp[3] = {action[0], action[1], action[2]};
+}
+// controller.setSetPoint(action) (IKControllers.py:346-362): position + normalised quaternion
+D3IL_HD void make_setpoint(const double* action, double* des) {
   double n = sqrt(action[3] * action[3] + action[4] * action[4] + action[5] * action[5] + action[6] * action[6]);
-  double dq[4] = {action[3] / n, action[4] / n, action[5] / n, action[6] / n};
+  des[0] = action[0]; des[1] = action[1]; des[2] = action[2];
+  des[3] = action[3] / n; des[4] = action[4] / n; des[5] = action[5] / n; des[6] = action[6] / n;
+}
+template <class C> D3IL_HD void step_end(const C& c, EnvState& st) {
+  st.step += 1;
+  check_mode(c, st);
+}
+
+// ObstacleAvoidanceEnv.step (avoiding.py:168-171) over GymEnvWrapper.step (gyms/gym_env_wrapper.py:45-100)
+template <bool FAST, class C>
+D3IL_HD void env_step(const C& c, EnvState& st, const double* action, float* obs, unsigned char* done, int n_substeps, int max_steps) {
+  step_begin(c, st, obs, done, max_steps);
+  double des[7];
+  make_setpoint(action, des);
   double warm[6];
   warm[5] = 0.0;
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
     D3IL_REFRESH(c, cs);
-    substep<true, FAST>(cs, st, dp, dq, nullptr, 0.04, false, warm);
+    substep<true, FAST>(cs, st, des, des + 3, nullptr, 0.04, false, warm);
   }
-  st.step += 1;
-  check_mode(c, st);
+  step_end(c, st);
 }
 
 // ObstacleAvoidanceEnv.reset (avoiding.py:248-262): scene.reset, beam to init_qpos, one PD-hold sub-step

@@ -87,6 +87,87 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_step(const PandaConsts* __res
   store_outputs(st, e, o, dn, obs, done, success, mode);
 }
 
+// env.step(), two cooperating waves per 64 environments.
+//
+// The reference's Cartesian controller integrates its virtual joint target open loop (joint_filter_coefficient = 1,
+// IKControllers.py:171-176): the sequence of PD set-points of one env step depends only on the action
+// and the controller state at the start of the step, not on the physics.  So the IK chain (60 % of a sub-step's
+// instructions) and the physics chain (40 %) are two independent sequential pipelines.  Wave 0 of the workgroup runs the
+// controller and publishes (q_des, qd_des) of sub-step s into an LDS slot; wave 1 runs forward dynamics, constraints
+// and integration of sub-step s-1 meanwhile and picks the set-point up after one workgroup barrier per sub-step.
+// The critical path per sub-step drops from IK + physics to max(IK, physics); at small N (4096 envs = 64 workgroups on
+// 256 CUs) the extra wave runs on an otherwise idle SIMD.
+template <bool FAST>
+__global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaConsts* __restrict__ cp, double* __restrict__ state,
+                                                                  unsigned* __restrict__ flags, int* __restrict__ steps,
+                                                                  const double* __restrict__ actions, float* __restrict__ obs,
+                                                                  unsigned char* __restrict__ done, unsigned char* __restrict__ success,
+                                                                  unsigned short* __restrict__ mode, int n, int stride, int n_substeps, int max_steps) {
+  __shared__ double xch[2][2 * NARM][WAVE];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int role = threadIdx.x / WAVE;          // wave-uniform: 0 controller, 1 physics
+  int e = blockIdx.x * WAVE + lane;
+  const bool live = e < n;
+  if (!live) e = n - 1;                         // keep every lane in the barriers; dead lanes recompute env n-1 and store nothing
+  const PandaConsts& c = kAvoidingConsts;
+  (void)cp;
+  if (role == 0) {
+    const double* sp = state + e;
+    double ikq[NARM], ikqd[NARM], q0[NARM], act[7], des[7];
+#pragma unroll
+    for (int i = 0; i < NARM; i++) {
+      ikq[i] = sp[(D3IL_STATE_IK_Q + i) * (size_t)stride]; ikqd[i] = sp[(D3IL_STATE_IK_QD + i) * (size_t)stride];
+      q0[i] = sp[(D3IL_STATE_QPOS + i) * (size_t)stride];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
+    unsigned fl = flags[e];
+    make_setpoint(act, des);
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < n_substeps; s++) {
+      ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd);
+      const int b = s & 1;
+#pragma unroll
+      for (int k = 0; k < NARM; k++) { xch[b][k][lane] = ikq[k]; xch[b][NARM + k][lane] = ikqd[k]; }
+      __syncthreads();
+    }
+    if (live) {
+      double* so = state + e;
+#pragma unroll
+      for (int i = 0; i < NARM; i++) { so[(D3IL_STATE_IK_Q + i) * (size_t)stride] = ikq[i]; so[(D3IL_STATE_IK_QD + i) * (size_t)stride] = ikqd[i]; }
+    }
+  } else {
+    EnvState st;
+    load_state(state, flags, steps, stride, e, st);
+    float o[2]; unsigned char dn;
+    step_begin(c, st, o, &dn, max_steps);
+    double warm[6];
+    warm[5] = 0.0;
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < n_substeps; s++) {
+      __syncthreads();
+      const int b = s & 1;
+      double qd[NARM], qdd[NARM];
+#pragma unroll
+      for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][lane]; qdd[k] = xch[b][NARM + k][lane]; }
+      control_and_physics(c, st, qd, qdd, 0.04, false, warm);
+    }
+    st.flags |= F_IK_VALID;                     // set by the controller wave's first ik_update in the fused kernel
+    step_end(c, st);
+    if (live) {
+      double* so = state + e;
+#pragma unroll
+      for (int i = 0; i < NDOF; i++) { so[(D3IL_STATE_QPOS + i) * (size_t)stride] = st.q[i]; so[(D3IL_STATE_QVEL + i) * (size_t)stride] = st.v[i]; }
+#pragma unroll
+      for (int i = 0; i < NARM; i++) so[(D3IL_STATE_BIAS + i) * (size_t)stride] = st.bias[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) so[(D3IL_STATE_TCP + i) * (size_t)stride] = st.tcp[i];
+      flags[e] = st.flags; steps[e] = st.step;
+      store_outputs(st, e, o, dn, obs, done, success, mode);
+    }
+  }
+}
+
 // env.reset() for masked environments
 __global__ __launch_bounds__(WAVE) void k_avoiding_reset(const PandaConsts* __restrict__ cp, const double* __restrict__ init_qpos,
                                                          const unsigned char* __restrict__ mask, double* __restrict__ state,
@@ -160,6 +241,7 @@ struct d3il_handle_s {
   bool started;
   d3il_buffers buf;
   bool fast, timing;
+  int split;              // -1 auto, 0 fused single-wave kernel, 1 two-wave (controller || physics) kernel
   int lanes;              // active lanes (environments) per wave: 64, or fewer to spread a small batch over more SIMDs
   int lds_pad;            // dynamic LDS bytes requested per workgroup: spreads the single-wave workgroups over CUs
   hipEvent_t ev0, ev1;
@@ -207,7 +289,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
                                                            "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
   h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
-  h->started = false; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
+  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
   b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = 2; b.action_dim = 7;
@@ -277,7 +359,12 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     if (lds > 64 * 1024) lds = 64 * 1024;
   }
   if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
-  if (h->fast)
+  // two-wave kernel while the chip has idle SIMDs (< 512 workgroups = 32768 envs), fused kernel at saturation
+  bool split = h->fast && h->lanes == WAVE && (h->split == 1 || (h->split < 0 && nwg <= 512));
+  if (split)
+    hipLaunchKernelGGL((k_avoiding_step_split<true>), dim3(nwg), dim3(2 * WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                       b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+  else if (h->fast)
     hipLaunchKernelGGL((k_avoiding_step<true, true>), dim3(nwg), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                        b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, h->lanes);
   else
@@ -378,6 +465,7 @@ int d3il_debug_stats(uint64_t* out32, int reset) {
 int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
+  if (std::strcmp(name, "split_waves") == 0) { h->split = value; return D3IL_OK; }
   if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }
   if (std::strcmp(name, "lanes_per_wave") == 0) { if (value < 1 || value > WAVE) return fail(D3IL_EINVAL, "lanes_per_wave must be in 1..64"); h->lanes = value; return D3IL_OK; }
   return fail(D3IL_EINVAL, std::string("d3il_set_option: unknown option ") + name);

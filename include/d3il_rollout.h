@@ -108,7 +108,7 @@ int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream);
 int d3il_set_timing(d3il_handle h, int enabled);
 int d3il_last_step_ms(d3il_handle h, float* ms);
 
-int d3il_set_option(d3il_handle h, const char* name, int value);  /* "ik_fast_path" (default 1), "lanes_per_wave", "lds_pad_bytes" */
+int d3il_set_option(d3il_handle h, const char* name, int value);  /* "ik_fast_path" (default 1), "split_waves" (-1 auto, 0, 1), "lanes_per_wave", "lds_pad_bytes" */
 /* Diagnostics builds only (-DD3IL_DEVICE_STATS): per-path lane/wave counters of the step kernel. */
 int d3il_debug_stats(uint64_t* out32, int reset);
 int d3il_debug_wave_stats(uint64_t* out_nwaves_x10, int nwaves, int reset);
