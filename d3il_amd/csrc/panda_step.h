@@ -261,7 +261,7 @@ D3IL_NOINLINE inline void jacobi_solve6(const double* A, const double* b, double
     for (int i = 0; i < 6; i++) s += V[a][i] * y[i]; x[a] = s; }
 }
 template <bool FAST>
-D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double maxsv, double* x) {
+D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double maxsv, double* x, double* vwarm = nullptr) {
   bool need_eig = true;
   if (FAST) {
     double L[21], d[6], id[6];
@@ -275,14 +275,21 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
       else if (ok0) {
         // smallest eigenpair: two inverse-iteration steps starting from b, then Rayleigh-quotient iteration
         D3IL_DSTAT(1);
+        // start vector: the eigenvector accepted by the previous solve of this environment if there is one (the matrix
+        // changes little between IK iterations), else two inverse-iteration steps starting from b
         double v[6], w[6], nr = 0;
-        ldl6_solve(L, id, b, w);
-        ldl6_solve(L, id, w, v);
+        if (vwarm && vwarm[6] != 0.0) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) nr += v[i] * v[i];
-        nr = 1.0 / sqrt(nr);
+          for (int i = 0; i < 6; i++) v[i] = vwarm[i];
+        } else {
+          ldl6_solve(L, id, b, w);
+          ldl6_solve(L, id, w, v);
 #pragma unroll
-        for (int i = 0; i < 6; i++) v[i] *= nr;
+          for (int i = 0; i < 6; i++) nr += v[i] * v[i];
+          nr = 1.0 / sqrt(nr);
+#pragma unroll
+          for (int i = 0; i < 6; i++) v[i] *= nr;
+        }
         double lam = 0, res = 0, vb = 0;
         for (int it = 0; it < 5; it++) {
           symv6(A, v, w);
@@ -318,11 +325,17 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
 #pragma unroll
           for (int i = 0; i < 6; i++) x[i] = xp[i] + g * v[i];
           need_eig = false;
+          if (vwarm) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) vwarm[i] = v[i];
+            vwarm[6] = 1.0;
+          }
         }
       }
     }
   }
   if (need_eig) {
+    if (vwarm) vwarm[6] = 0.0;
     double Am[21], bm[6], xm[6];
 #pragma unroll
     for (int i = 0; i < 21; i++) Am[i] = A[i];
@@ -338,7 +351,7 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
 // joint PD law: advances the virtual joint target ikq by ik_iters damped-least-squares iterations.
 template <bool FAST, class C>
 D3IL_HD void ik_update(const C& c0, const double* des_pos, const double* des_quat_in, const double* cur_q,
-                       unsigned& flags, double* ikq, double* ikqd) {
+                       unsigned& flags, double* ikq, double* ikqd, double* vwarm = nullptr) {
   double q[NARM], old_q[NARM];
   if (!(flags & F_IK_VALID)) {
 #pragma unroll
@@ -396,7 +409,7 @@ D3IL_HD void ik_update(const C& c0, const double* des_pos, const double* des_qua
     for (int a = 0; a < 6; a++) { double s = target[a];
 #pragma unroll
       for (int k = 0; k < NARM; k++) s -= J[a][k] * qn[k]; rhs[a] = s; }
-    ik_solve6<FAST>(A, rhs, c.ik_minsv, c.ik_maxsv, x);
+    ik_solve6<FAST>(A, rhs, c.ik_minsv, c.ik_maxsv, x, vwarm);
     double qd[NARM], nrm = 0;
 #pragma unroll
     for (int k = 0; k < NARM; k++) { double s = qn[k];
@@ -1366,9 +1379,9 @@ D3IL_HD void control_and_physics(const C& c, EnvState& st, const double* q_des, 
 
 // controllers feeding one physics sub-step (Scene.next_step, core/Scene.py:121-138)
 template <bool IK, bool FAST, class C>
-D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp, double* warm) {
+D3IL_HD void substep(const C& c, EnvState& st, const double* des_pos, const double* des_quat, const double* pd_q, double set_width, bool grasp, double* warm, double* vwarm = nullptr) {
   if (IK) {
-    ik_update<FAST>(c, des_pos, des_quat, st.q, st.flags, st.ikq, st.ikqd);
+    ik_update<FAST>(c, des_pos, des_quat, st.q, st.flags, st.ikq, st.ikqd, vwarm);
     control_and_physics(c, st, st.ikq, st.ikqd, set_width, grasp, warm);
   } else {
     double zero[NARM] = {0, 0, 0, 0, 0, 0, 0};
@@ -1424,12 +1437,12 @@ D3IL_HD void env_step(const C& c, EnvState& st, const double* action, float* obs
   step_begin(c, st, obs, done, max_steps);
   double des[7];
   make_setpoint(action, des);
-  double warm[6];
-  warm[5] = 0.0;
+  double warm[6], vwarm[7];
+  warm[5] = 0.0; vwarm[6] = 0.0;
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
     D3IL_REFRESH(c, cs);
-    substep<true, FAST>(cs, st, des, des + 3, nullptr, 0.04, false, warm);
+    substep<true, FAST>(cs, st, des, des + 3, nullptr, 0.04, false, warm, vwarm);
   }
   step_end(c, st);
 }

@@ -123,9 +123,11 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
     for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
     unsigned fl = flags[e];
     make_setpoint(act, des);
+    double vwarm[7];
+    vwarm[6] = 0.0;
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
-      ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd);
+      ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd, vwarm);
       const int b = s & 1;
 #pragma unroll
       for (int k = 0; k < NARM; k++) { xch[b][k][lane] = ikq[k]; xch[b][NARM + k][lane] = ikqd[k]; }
