@@ -444,6 +444,7 @@ struct DynOut {
   double M[45];        // packed lower, dof order: 7 arm, finger1, finger2
   double bias[NDOF];   // Coriolis + centrifugal + gravity (qfrc_bias)
   double R7[9], p7[3]; // world <- link 7
+  double sn[NARM], cs[NARM];  // sin/cos of the arm joints (reused by the contact Jacobian)
 };
 
 // world pose of link 7 plus (optionally) world joint axes / origins for point Jacobians
@@ -472,7 +473,7 @@ template <class C> D3IL_HD void world_chain(const C& c0, const double* sn, const
 template <class C> D3IL_HD void dynamics(const C& c0, const double* q, const double* v, DynOut& o) {
   double sn[NARM], cs[NARM];
 #pragma unroll
-  for (int i = 0; i < NARM; i++) sincos(q[i], &sn[i], &cs[i]);
+  for (int i = 0; i < NARM; i++) { sincos(q[i], &sn[i], &cs[i]); o.sn[i] = sn[i]; o.cs[i] = cs[i]; }
   world_chain(c0, sn, cs, o.R7, o.p7, nullptr, nullptr);
 
   // ---- RNEA forward pass (velocities, accelerations with qacc = 0, base acceleration = -gravity)
@@ -950,23 +951,30 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
   // rows 3,4: finger limits, Jacobian s7 e_7 / s8 e_8 (unit vector with the limit's sign; +1 when the row is absent)
   const double j3 = s7 != 0 ? s7 : 1.0, j4 = s8 != 0 ? s8 : 1.0;
   // A = J M^-1 J^T and r = J a0 - aref, one column of M^-1 J^T at a time
-  double A[15], r[5];
+  // A = J M^-1 J^T = (L^-1 J^T)^T D^-1 (L^-1 J^T): forward substitutions only
+  double A[15], r[5], W[5][NDOF];
 #pragma unroll
-  for (int j = 0; j < 5; j++) {
-    double u[NDOF];
+  for (int j = 0; j < 3; j++) {
 #pragma unroll
-    for (int k = 0; k < NDOF; k++) u[k] = j < 3 ? (k < NARM ? Jc[j < 3 ? j : 0][k] : 0.0) : ((j == 3 && k == 7) ? j3 : (j == 4 && k == 8) ? j4 : 0.0);
-    ldl9_solve(L, id, u);
+    for (int i = 0; i < NDOF; i++) {
+      double t = i < NARM ? Jc[j][i < NARM ? i : 0] : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; k++) t -= L[tri(i, k)] * W[j][k];
+      W[j][i] = t;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) { W[3][i] = 0; W[4][i] = 0; }
+  W[3][7] = j3; W[3][8] = -L[tri(8, 7)] * j3; W[4][8] = j4;
+#pragma unroll
+  for (int j = 0; j < 5; j++)
 #pragma unroll
     for (int i = j; i < 5; i++) {
       double t = 0;
-      if (i < 3) {
 #pragma unroll
-        for (int k = 0; k < NARM; k++) t += Jc[i < 3 ? i : 0][k] * u[k];
-      } else t = i == 3 ? j3 * u[7] : j4 * u[8];
+      for (int k = (i >= 3 ? 7 : 0); k < NDOF; k++) t += W[i][k] * W[j][k] * id[k];
       A[tri(i, j)] = t;
     }
-  }
 #pragma unroll
   for (int i = 0; i < 3; i++) { double t = -aref[i];
 #pragma unroll
@@ -1171,12 +1179,11 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
 
 // Rod contact set-up (rare path): Jacobian rows, regularisation and reference acceleration of the deepest contact.
 template <class C>
-D3IL_RARE void make_rod_contact(const C& c, const double* q, const double* v, int bo, double bd, const double* bn, const double* bp, RodContact* rcp) {
+D3IL_RARE void make_rod_contact(const C& c, const double* sn, const double* cs, const double* v, int bo, double bd, const double* bn, const double* bp, RodContact* rcp) {
   RodContact& rc = *rcp;
   rc.active = true;
   D3IL_DSTAT(5);
-  double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3], t1[3], t2[3];
-  for (int i = 0; i < NARM; i++) { sn[i] = sin(q[i]); cs[i] = cos(q[i]); }
+  double R7[9], p7[3], ax[NARM][3], og[NARM][3], t1[3], t2[3];
   world_chain(c, sn, cs, R7, p7, ax, og);
   make_frame(bn, t1, t2);
   double vel[3] = {0, 0, 0};
@@ -1278,7 +1285,7 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
     for (int k = 0; k < NDOF; k++) md += dyn.M[tri(k, k)];
     double gscale = (1.0 + sqrt(fn)) / (md / NDOF);
     RodContact rc; rc.active = false;
-    make_rod_contact(c0, qm, vm, bo, bd, bn, bp, &rc);
+    make_rod_contact(c0, dyn.sn, dyn.cs, vm, bo, bd, bn, bp, &rc);
     if (!solve_contact5(Lm, dm, a0, rc, fsign, fD, faref, gscale, fcm, warm)) st.flags |= F_SOLVER_FAIL;
     for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
   } else if (arm_rows) {
@@ -1301,7 +1308,7 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
       }
     }
     RodContact rc; rc.active = false;
-    if (bo >= 0) make_rod_contact(c0, qm, vm, bo, bd, bn, bp, &rc);
+    if (bo >= 0) make_rod_contact(c0, dyn.sn, dyn.cs, vm, bo, bd, bn, bp, &rc);
     double warm9[NDOF + 1]; warm9[NDOF] = 0.0;
     if (!solve_constraints(Mm, a0, &fn, lim_sign, lim_D, lim_aref, rc, fcm, warm9)) st.flags |= F_SOLVER_FAIL;
     for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
