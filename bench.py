@@ -5,8 +5,7 @@
 
 A "step" is one pass of the hot path over one batch: for every one of the 4096 environments per GPU the
 device-side random policy writes the action (Philox, seed 42, counter = global env index x t), d3il_step runs
-the 35 fused physics sub-steps, and finished environments are auto-reset (masked d3il_reset +
-d3il_policy_begin), everything enqueued on one HIP stream with the state resident in HBM.  N > 1: one process
+the 35 fused physics sub-steps, and finished environments are auto-reset (d3il_auto_reset), everything enqueued on one HIP stream with the state resident in HBM.  N > 1: one process
 per GPU (torch.distributed / RCCL), env shards are independent (weak scaling, 4096 envs per GPU), the only
 collective is the final int64 count all-reduce, outside the per-step path but inside the timed region.
 Prints ONE JSON line on rank 0.
@@ -96,17 +95,13 @@ def main():
     env_offset = rank * n
     actions = torch.zeros(n, 7, dtype=torch.float64, device=dev)
     counts = torch.zeros(514, dtype=torch.int64, device=dev)
-    total_done = torch.zeros((), dtype=torch.int64, device=dev)
-    total_succ = torch.zeros((), dtype=torch.int64, device=dev)
+    episodes = torch.zeros(2, dtype=torch.int64, device=dev)   # finished, successful
 
     def one_step(t):
         env.policy_action(42, env_offset, t, actions)
-        _, _, done, (mode, succ) = env.step(actions)
+        env.step(actions)
         if not args.no_auto_reset:
-            total_done.add_(done.sum())
-            total_succ.add_((succ * done).sum())
-            env.reset(done)
-            env.policy_begin(done)
+            env.auto_reset(episodes)
 
     def barrier():
         if world > 1:
@@ -116,7 +111,7 @@ def main():
     env.reset(); env.policy_begin()
     for t in range(args.warmup):
         one_step(t)
-    total_done.zero_(); total_succ.zero_()
+    episodes.zero_()
     env.set_timing(True)
     kernel_ms = []
     barrier()
@@ -158,7 +153,7 @@ def main():
                                    "35 fused physics sub-steps per env step, auto-reset" % n,
                        "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world,
                        "auto_reset": not args.no_auto_reset, "finite_and_solver_ok": ok,
-                       "episodes_finished_rank0": int(total_done.item()), "episodes_success_rank0": int(total_succ.item())},
+                       "episodes_finished_rank0": int(episodes[0].item()), "episodes_success_rank0": int(episodes[1].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_avoiding_step<true,true>", "kernel_ms": k_ms,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,

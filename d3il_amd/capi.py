@@ -25,7 +25,7 @@ FLAG_MODE_MASK, FLAG_TERMINATED, FLAG_SUCCESS, FLAG_ROD_CONTACT = 0x1FF, 1 << 12
 FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
 
 EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
-           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_count_metrics", "d3il_set_timing",
+           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_auto_reset", "d3il_count_metrics", "d3il_set_timing",
            "d3il_last_step_ms", "d3il_set_option", "d3il_debug_stats", "d3il_debug_wave_stats", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
 
 
@@ -61,6 +61,7 @@ def load():
         L.d3il_policy_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.d3il_policy_action.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.d3il_count_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_auto_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.d3il_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.d3il_last_step_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.d3il_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]

@@ -111,6 +111,9 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
   if (!live) e = n - 1;                         // keep every lane in the barriers; dead lanes recompute env n-1 and store nothing
   const PandaConsts& c = kAvoidingConsts;
   (void)cp;
+#if defined(D3IL_DEVICE_STATS)
+  unsigned long long t0 = wall_clock64(), tw = 0;
+#endif
   if (role == 0) {
     const double* sp = state + e;
     double ikq[NARM], ikqd[NARM], q0[NARM], act[7], des[7];
@@ -131,8 +134,17 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
       const int b = s & 1;
 #pragma unroll
       for (int k = 0; k < NARM; k++) { xch[b][k][lane] = ikq[k]; xch[b][NARM + k][lane] = ikqd[k]; }
+#if defined(D3IL_DEVICE_STATS)
+      unsigned long long tb = wall_clock64();
+#endif
       __syncthreads();
+#if defined(D3IL_DEVICE_STATS)
+      tw += wall_clock64() - tb;
+#endif
     }
+#if defined(D3IL_DEVICE_STATS)
+    if (lane == 0 && blockIdx.x < 4096) { g_dev_wave[blockIdx.x][8] = wall_clock64() - t0 - tw; }
+#endif
     if (live) {
       double* so = state + e;
 #pragma unroll
@@ -147,13 +159,22 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
     warm[5] = 0.0;
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
+#if defined(D3IL_DEVICE_STATS)
+      unsigned long long tb = wall_clock64();
+#endif
       __syncthreads();
+#if defined(D3IL_DEVICE_STATS)
+      tw += wall_clock64() - tb;
+#endif
       const int b = s & 1;
       double qd[NARM], qdd[NARM];
 #pragma unroll
       for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][lane]; qdd[k] = xch[b][NARM + k][lane]; }
       control_and_physics(c, st, qd, qdd, 0.04, false, warm);
     }
+#if defined(D3IL_DEVICE_STATS)
+    if (lane == 0 && blockIdx.x < 4096) { g_dev_wave[blockIdx.x][9] = wall_clock64() - t0 - tw; }
+#endif
     st.flags |= F_IK_VALID;                     // set by the controller wave's first ik_update in the fused kernel
     step_end(c, st);
     if (live) {
@@ -187,6 +208,31 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_reset(const PandaConsts* __re
   env_reset(kAvoidingConsts, st, iq, o);
   store_state(state, flags, steps, stride, e, st);
   store_outputs(st, e, o, 0, obs, done, success, mode);
+}
+
+// Auto-reset of finished environments (the rollout loop's `env.reset()` at avoiding_sim.py:51 for the next trajectory),
+// fused with the harness bookkeeping: episode counters += (finished, successful), desired pose := TCP after the reset
+// (avoiding_sim.py:53-54).  One launch instead of reset + policy_begin + three reductions.
+__global__ __launch_bounds__(WAVE) void k_avoiding_auto_reset(const PandaConsts* __restrict__ cp, const double* __restrict__ init_qpos,
+                                                              double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+                                                              float* __restrict__ obs, unsigned char* __restrict__ done,
+                                                              unsigned char* __restrict__ success, unsigned short* __restrict__ mode,
+                                                              double* __restrict__ des, long long* __restrict__ episode_counts, int n, int stride) {
+  int e = blockIdx.x * WAVE + threadIdx.x;
+  if (e >= n || !done[e]) return;
+  (void)cp;
+  atomicAdd((unsigned long long*)&episode_counts[0], 1ull);
+  if (success[e]) atomicAdd((unsigned long long*)&episode_counts[1], 1ull);
+  EnvState st;
+  double iq[NARM];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
+  float o[2];
+  env_reset(kAvoidingConsts, st, iq, o);
+  store_state(state, flags, steps, stride, e, st);
+  store_outputs(st, e, o, 0, obs, done, success, mode);
+#pragma unroll
+  for (int k = 0; k < 3; k++) des[k * (size_t)stride + e] = st.tcp[k];
 }
 
 // ---- random-policy harness (avoiding_sim.py:51-66 with a uniform random agent)
@@ -417,6 +463,17 @@ int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }
+int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream) {
+  if (!h || !episode_counts_device) return fail(D3IL_EINVAL, "d3il_auto_reset: null argument");
+  if (!h->started) return fail(D3IL_ESTATE, "d3il_auto_reset: d3il_start() has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  d3il_buffers& b = h->buf;
+  hipLaunchKernelGGL(k_avoiding_auto_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->dc, h->d_init_qpos, b.state, b.flags, b.step_count,
+                     b.obs, b.done, b.success, b.mode, b.policy_des, (long long*)episode_counts_device, h->n, h->stride);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+
 int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream) {
   if (!h || !out_counts_device) return fail(D3IL_EINVAL, "d3il_count_metrics: null argument");
   HIPCHK(hipSetDevice(h->device));

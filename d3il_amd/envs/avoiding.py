@@ -89,7 +89,9 @@ class ObstacleAvoidanceVecEnv:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def reset(self, mask: torch.Tensor | None = None, random=True, context=None):
-        """env.reset() for all environments, or for those with mask != 0 (device uint8/bool tensor)."""
+        """env.reset() for all environments, or for those with mask != 0 (device uint8/bool tensor).
+        The done/success/mode outputs of the reset environments are cleared - pass a copy if ``mask`` is ``self.done``
+        and is needed afterwards (e.g. for ``policy_begin``)."""
         mp = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
@@ -142,6 +144,12 @@ class ObstacleAvoidanceVecEnv:
         with torch.cuda.device(self.device):
             capi.check(self.L.d3il_policy_action(self.h, int(seed), int(env_offset), int(t), C.c_void_p(out.data_ptr()), self._stream()))
         return out
+
+    def auto_reset(self, episode_counts: torch.Tensor):
+        """Reset every finished env, re-latch the random-policy set-point, episode_counts (int64[2]) += (finished, successes)."""
+        assert episode_counts.dtype == torch.int64 and episode_counts.numel() >= 2 and episode_counts.device == self.device
+        with torch.cuda.device(self.device):
+            capi.check(self.L.d3il_auto_reset(self.h, C.c_void_p(episode_counts.data_ptr()), self._stream()))
 
     def count_metrics(self, out: torch.Tensor | None = None):
         if out is None:

@@ -98,6 +98,11 @@ int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, co
 int d3il_policy_begin(d3il_handle h, const uint8_t* env_mask, void* stream);
 int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, void* stream);
 
+/* Vectorised-env auto-reset: every environment whose `done` flag is set is reset (as d3il_reset with mask = done), the
+ * random-policy harness re-latches its desired pose, and episode_counts (device i64[2]) += {finished, successful}
+ * episodes.  Counterpart of starting the next trajectory in the rollout loop (avoiding_sim.py:45-54). */
+int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream);
+
 /* Integer metric counts on device: out_counts i64[2 + 512] = {n_done, n_success, histogram of 9-bit mode codes
  * among successful envs}; input to the cross-GPU reduction (one RCCL all-reduce, done by the Python layer)
  * and to success-rate / entropy (avoiding_sim.py:128-135). */

@@ -96,7 +96,8 @@ def test_random_policy_rollout_vs_oracle(lib_loaded, init_qpos):
                 o.env_reset()
         n_done += int(d_host.sum())
         if d_host.any():                      # auto-reset finished envs, re-latch the harness' desired pose
-            env.reset(done); env.policy_begin(done)
+            m = done.clone()                  # reset clears the done flags of the envs it resets: keep the mask
+            env.reset(m); env.policy_begin(m)
             torch.cuda.synchronize()
             st2, fl2, sc2 = env.get_state()
             assert (sc2[d_host] == 0).all() and (sc2[~d_host] == sc[~d_host]).all()
@@ -281,3 +282,30 @@ def test_arbitrary_states_incl_arm_joint_limits(lib_loaded, init_qpos):
             assert int(mode[e]) == int((md.astype(np.int64) * (1 << np.arange(9))).sum())
         assert not (fl & (1 << 16)).any()
     env.close()
+
+
+def test_auto_reset_equals_masked_reset(lib_loaded, init_qpos):
+    """d3il_auto_reset == d3il_reset(mask=done) + d3il_policy_begin(mask=done), plus exact episode counters."""
+    n, T = 512, 270
+    a_env, b_env = _env(n), _env(n)
+    for env in (a_env, b_env):
+        env.set_init_qpos(init_qpos); env.reset(); env.policy_begin()
+    act_a = torch.zeros(n, 7, dtype=torch.float64, device=a_env.device)
+    act_b = torch.zeros_like(act_a)
+    counts = torch.zeros(2, dtype=torch.int64, device=a_env.device)
+    n_done = n_succ = 0
+    for t in range(T):
+        a_env.policy_action(7, 100, t, act_a); b_env.policy_action(7, 100, t, act_b)
+        _, _, done_a, (_, succ_a) = a_env.step(act_a)
+        _, _, done_b, (_, succ_b) = b_env.step(act_b)
+        torch.cuda.synchronize()
+        n_done += int(done_b.sum()); n_succ += int((succ_b * done_b).sum())
+        a_env.auto_reset(counts)
+        m = done_b.clone()                    # reset clears the done flags of the envs it resets: keep the mask
+        b_env.reset(m); b_env.policy_begin(m)
+    torch.cuda.synchronize()
+    sa, fa, ca = a_env.get_state(); sb, fb, cb = b_env.get_state()
+    assert np.array_equal(sa, sb) and np.array_equal(fa, fb) and np.array_equal(ca, cb)
+    assert torch.equal(a_env.policy_des, b_env.policy_des)
+    assert counts.tolist() == [n_done, n_succ] and n_done >= n
+    a_env.close(); b_env.close()
