@@ -136,12 +136,19 @@ def main():
     if rank == 0:
         value = world * n * args.steps / dt
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        traffic = None
+        traffic, valu = None, None
         try:  # HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc runs)
             with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_bench300.json")) as f:
                 pm = json.load(f)
             if n == 4096:
                 traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+                # binding resource: FP64 VALU issue.  Instruction count from the PMC pass, ~2/3 of the VALU stream is FP64
+                # arithmetic (static mix), an FMA counts 2 flop; peak = 78.6 TFLOP/s vector FP64 (whole chip, 1024 SIMDs)
+                insts = pm["SQ_INSTS_VALU"]["mean_per_dispatch"]
+                tflops = insts * 0.66 * 1.6 * 64 / (k_ms * 1e-3) / 1e12
+                valu = {"bound": "fp64_valu", "valu_insts_per_launch": insts, "achieved_tflops_est": tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                        "frac_est": tflops / FP64_VALU_PEAK_TFLOPS, "simds_used": 128, "simds_total": 1024,
+                        "valu_active_frac_of_wave_cycles": pm["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / pm["SQ_WAVE_CYCLES"]["mean_per_dispatch"]}
         except Exception:
             pass
         achieved = ALG_BYTES_PER_ENV_STEP * n / (k_ms * 1e-3) / 1e9
@@ -155,12 +162,12 @@ def main():
                        "auto_reset": not args.no_auto_reset, "finite_and_solver_ok": ok,
                        "episodes_finished_rank0": int(episodes[0].item()), "episodes_success_rank0": int(episodes[1].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_avoiding_step<true,true>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "k_avoiding_step_split<true>" if n <= 32768 else "k_avoiding_step<true,true>", "kernel_ms": k_ms,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n,
-                         "note": "path is FP64-VALU/latency bound, not HBM bound: <1 KB of HBM per env step with "
-                                 "all 35 sub-steps fused (DESIGN.md section 4); fp64_valu_frac is the binding roofline",
-                         "fp64_valu_frac": None},
+                         "note": "path is FP64-VALU issue/latency bound, not HBM bound: 756 B of HBM per env step with all 35 "
+                                 "sub-steps fused in registers (DESIGN.md section 4); see the valu object and profiles/r01",
+                         "valu": valu},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(env.blob, q)

@@ -18,8 +18,8 @@ for t in range(300):
     _, _, done, _ = env.step(a)
     ms = env.last_step_ms()
     L.d3il_debug_stats(buf, 1)
-    env.reset(done); env.policy_begin(done)
+    m = done.clone(); env.reset(m); env.policy_begin(m)
     L.d3il_debug_stats((C.c_uint64 * 32)(), 1)
-    if t % 20 == 0 or t == 299:
+    if t % 20 == 0 or t == 299 or t in (251, 255):
         v = list(buf)
         print(t, "ms %.2f" % ms, " ".join("%s %d/%d" % (names[i], v[2 * i], v[2 * i + 1]) for i in range(8)))

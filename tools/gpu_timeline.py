@@ -12,7 +12,7 @@ for t in range(300):
     _, _, done, _ = env.step(a)
     ms = env.last_step_ms()
     if auto_reset:
-        env.reset(done); env.policy_begin(done)
+        m = done.clone(); env.reset(m); env.policy_begin(m)
     if t % 10 == 0 or t in (248, 249, 250, 251, 252):
         st, fl, sc = env.get_state()
         print(t, "ms %.3f" % ms, "done", int(done.sum()), "tcp x [%.2f %.2f] y [%.2f %.2f]" % (st[25].min(), st[25].max(), st[26].min(), st[26].max()),
