@@ -162,7 +162,7 @@ def main():
                        "auto_reset": not args.no_auto_reset, "finite_and_solver_ok": ok,
                        "episodes_finished_rank0": int(episodes[0].item()), "episodes_success_rank0": int(episodes[1].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_avoiding_step_split<true>" if n <= 32768 else "k_avoiding_step<true,true>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "k_avoiding_step_split<true>", "kernel_ms": k_ms,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n,
                          "note": "path is FP64-VALU issue/latency bound, not HBM bound: 756 B of HBM per env step with all 35 "
