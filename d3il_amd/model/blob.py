@@ -14,7 +14,7 @@ import json
 import os
 
 MAGIC = 0x4C493344  # 'D3IL'
-VERSION = 2
+VERSION = 3
 
 MAXBODY, MAXJNT, MAXGEOM, MAXACT, MAXEXCL, MAXCHAIN, MAXOBST = 64, 16, 80, 12, 16, 16, 8
 
@@ -83,7 +83,10 @@ FIELDS = [
     ("ik_min_sv", F64, (), ""), ("ik_max_sv", F64, (), ""), ("ik_lr", F64, (), ""),
     ("ctrl_qmin", F64, (7,), ""), ("ctrl_qmax", F64, (7,), ""), ("default_qpos", F64, (7,), ""),
     # task constants; Avoiding (avoiding.py:94-107): l1_y l2_y l3_y goal_y l1_x l2_top_x l2_bot_x l3_top_x l3_mid_x l3_bot_x
+    #   Pushing (pushing_objects.py:10-15, pushing.py:251): target_1 xyz, target_2 xyz, target_min_dist
     ("task_f", F64, (32,), ""),
+    # free-joint task objects in observation order (pushing.py:255-280: push_box, push_box2)
+    ("n_obj", I32, (), ""), ("obj_pad", I32, (), ""), ("obj_body", I32, (8,), "body ids"),
 ]
 
 
@@ -231,6 +234,14 @@ def pack(js: dict) -> ModelBlob:
                 "l2_bottom_xpos", "l3_top_xpos", "l3_mid_xpos", "l3_bottom_xpos"]
         for i, k in enumerate(keys):
             b.task_f[i] = tc[k]
+    objs = tc.get("objects", [])
+    b.n_obj = len(objs)
+    for i, o in enumerate(objs):
+        b.obj_body[i] = bname[o]
+    if js["task"] == "pushing":
+        for k in range(3):
+            b.task_f[k], b.task_f[3 + k] = tc["target_pos1"][k], tc["target_pos2"][k]
+        b.task_f[6] = tc["target_min_dist"]
     return b
 
 

@@ -446,6 +446,29 @@ def build_avoiding():
     return to_blob(m, "avoiding", tc)
 
 
+def pushing_objects():
+    """pushing_objects.py:5-61 restated as data, in the order pushing.py:227-235 adds them to the scene."""
+    return [
+        prim_body("push_box", "box", [0.4, -0.3, -0.0072], [0, 1, 0, 0], [0.03, 0.03, 0.03], mass=0.05),
+        prim_body("push_box2", "box", [0.5, -0.3, -0.0072], [0, 1, 0, 0], [0.03, 0.03, 0.03], mass=0.05),
+        prim_body("target_box_1", "box", [0.42, 0.3, 0], [0, 1, 0, 0], [0.05, 0.05, 0.04], static=True, visual_only=True),
+        prim_body("target_box_2", "box", [0.63, 0.3, 0], [0, 1, 0, 0], [0.05, 0.05, 0.04], static=True, visual_only=True),
+    ]
+
+
+def build_pushing():
+    m = build_scene("panda_rod_invisible.xml", pushing_objects(), "pushing")
+    tc = dict(
+        n_substeps=35, max_steps=400,                        # pushing.py:174-175
+        init_end_eff_pos=[0.525, -0.28, 0.12], init_end_eff_quat=[0, 1, 0, 0],  # pushing_objects.py:5, pushing.py:305-317
+        rod_geom="rod:geom_rb0", tcp_body="tcp_rb0",
+        objects=["push_box", "push_box2"],
+        target_pos1=[0.42, 0.3, 0.0], target_pos2=[0.63, 0.3, 0.0],           # pushing_objects.py:11-15
+        target_min_dist=0.05,                                                   # pushing.py:251
+    )
+    return to_blob(m, "pushing", tc)
+
+
 def main():
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "blobs")
     os.makedirs(out_dir, exist_ok=True)
@@ -453,6 +476,10 @@ def main():
     with open(os.path.join(out_dir, "avoiding.json"), "w") as f:
         json.dump(blob, f, indent=1)
     print("avoiding: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
+    blob = build_pushing()
+    with open(os.path.join(out_dir, "pushing.json"), "w") as f:
+        json.dump(blob, f, indent=1)
+    print("pushing: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
 
 
 if __name__ == "__main__":

@@ -18,3 +18,20 @@ def avoiding_metrics(n_rollouts: int, n_success: int, hist512: np.ndarray):
     mode_dist = counts / np.sum(counts)
     entropy = -np.sum(mode_dist * (np.log(mode_dist) / np.log(24)))
     return success_rate, float(entropy)
+
+
+def pushing_metrics(mode_counts, n_success: int, n_rollouts: int, n_trajectories_per_context: int, n_modes: int = 4):
+    """Metric tail of ``Pushing_Sim.test_agent`` (simulation/pushing_sim.py:140-167) from integer counts.
+
+    mode_counts[c][m] = number of *successful* rollouts of context c whose final ``info['mode']`` is m
+    (m in 0..3; rollouts ending with mode -1 count towards the success rate only).  The reference evaluates
+    these formulas in float32 torch; the same dtype is used here.
+    """
+    import torch
+
+    counts = torch.as_tensor(np.asarray(mode_counts), dtype=torch.int64)
+    mode_probs = (counts / n_trajectories_per_context).to(torch.float32)
+    mode_probs = mode_probs / (mode_probs.sum(1).reshape(-1, 1) + 1e-12)
+    entropy = -(mode_probs * torch.log(mode_probs + 1e-12) / torch.log(torch.tensor(n_modes))).sum(1).mean()
+    success_rate = float(torch.tensor(float(n_success), dtype=torch.float32) / n_rollouts)
+    return success_rate, float(entropy), mode_probs

@@ -30,13 +30,30 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_create.restype = C.c_void_p
         for name in ("orc_nq", "orc_nv", "orc_get_contacts", "orc_get_efc", "orc_solver_iter",
-                     "orc_unsupported_pairs", "orc_supported_pairs"):
+                     "orc_unsupported_pairs", "orc_supported_pairs", "orc_test_box_box", "orc_test_cyl_box"):
             getattr(_LIB, name).restype = C.c_int
     return _LIB
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def box_box(p1, q1, s1, p2, q2, s2, margin=0.0):
+    """Collision test hook: contacts [n][7] = dist, pos3, normal3 (normal from box 1 to box 2)."""
+    a = [np.ascontiguousarray(x, float) for x in (p1, q1, s1, p2, q2, s2)]
+    out = np.zeros((16, 7))
+    n = lib().orc_test_box_box(*[_p(x) for x in a], C.c_double(margin), _p(out))
+    return out[:n]
+
+
+def cyl_box(pc, qc, rad, half, pb, qb, sb, margin=0.0):
+    """Collision test hook: [dist, pos3, normal3] (normal from the box to the cylinder) or None."""
+    a = [np.ascontiguousarray(x, float) for x in (pc, qc, pb, qb, sb)]
+    out = np.zeros(7)
+    n = lib().orc_test_cyl_box(_p(a[0]), _p(a[1]), C.c_double(rad), C.c_double(half), _p(a[2]), _p(a[3]), _p(a[4]),
+                               C.c_double(margin), _p(out))
+    return out if n else None
 
 
 class Oracle:
@@ -60,6 +77,10 @@ class Oracle:
     def set_state(self, qpos, qvel):
         qpos, qvel = np.ascontiguousarray(qpos, float), np.ascontiguousarray(qvel, float)
         self.L.orc_set_qpos_qvel(self.h, _p(qpos), _p(qvel))
+
+    def set_gravity(self, g):
+        g = np.ascontiguousarray(g, float)
+        self.L.orc_set_gravity(self.h, _p(g))
 
     def set_ctrl(self, ctrl):
         ctrl = np.ascontiguousarray(ctrl, float)
@@ -94,12 +115,12 @@ class Oracle:
         return xpos, xquat, invw
 
     def contacts(self):
-        out = np.zeros((16, 10))
+        out = np.zeros((40, 10))
         n = self.L.orc_get_contacts(self.h, _p(out))
         return out[:n]
 
     def efc(self):
-        f, a, d = np.zeros(96), np.zeros(96), np.zeros(96)
+        f, a, d = np.zeros(160), np.zeros(160), np.zeros(160)
         n = self.L.orc_get_efc(self.h, _p(f), _p(a), _p(d))
         return f[:n], a[:n], d[:n]
 
@@ -197,3 +218,28 @@ class Oracle:
         f = np.zeros(8, dtype=np.int32)
         self.L.orc_env_get_flags(self.h, _p(f))
         return s, f
+
+    # ---- env level (Pushing)
+    def push_reset(self, ctx):
+        ctx = np.ascontiguousarray(ctx, float).reshape(14)
+        obs = np.zeros(8, dtype=np.float32)
+        self.L.orc_push_reset(self.h, _p(ctx), _p(obs))
+        return obs
+
+    def push_step(self, action):
+        action = np.ascontiguousarray(action, float)
+        obs = np.zeros(8, dtype=np.float32)
+        done, mode, succ = C.c_int(0), C.c_int(0), C.c_int(0)
+        rew, md = C.c_double(0), C.c_double(0)
+        self.L.orc_push_step(self.h, _p(action), _p(obs), C.byref(done), C.byref(rew), C.byref(mode), C.byref(succ), C.byref(md))
+        return obs, rew.value, bool(done.value), dict(mode=mode.value, success=bool(succ.value), mean_distance=md.value)
+
+    def push_logic(self, box14, tcp, reset=False):
+        box14 = np.ascontiguousarray(box14, float).reshape(14)
+        tcp = np.ascontiguousarray(tcp, float)
+        obs = np.zeros(8, dtype=np.float32)
+        succ, mode, first = C.c_int(0), C.c_int(0), C.c_int(0)
+        md, rew = C.c_double(0), C.c_double(0)
+        self.L.orc_push_logic(self.h, _p(box14), _p(tcp), int(reset), _p(obs), C.byref(succ), C.byref(mode), C.byref(first),
+                              C.byref(md), C.byref(rew))
+        return obs, bool(succ.value), mode.value, first.value, md.value, rew.value

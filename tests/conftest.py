@@ -41,3 +41,33 @@ def oracle(avoiding_blob):
 def hostcheck(avoiding_blob):
     from tests.hostcheck.hostcheck import HostCheck
     return HostCheck(avoiding_blob)
+
+
+@pytest.fixture(scope="session")
+def pushing_blob():
+    from d3il_amd.model import blob
+    return blob.load("pushing")
+
+
+@pytest.fixture(scope="session")
+def pushing_json():
+    from d3il_amd.model import blob
+    return blob.load_json("pushing")
+
+
+@pytest.fixture()
+def push_oracle(pushing_blob):
+    from oracle.oracle import Oracle
+    return Oracle(pushing_blob)
+
+
+@pytest.fixture(scope="session")
+def push_contexts():
+    """The 60 evaluation contexts of the reference (environments/dataset/data/pushing/test_contexts.pkl), as the
+    2 x (x, y, z=0, quat) rows BlockContextManager.set_context writes into qpos (pushing.py:99-113)."""
+    import numpy as np
+    c = np.load(os.path.join(ROOT, "tests", "golden", "ref_pushing_task.npz"))["test_contexts"]
+    out = np.zeros((len(c), 14))
+    out[:, 0:2], out[:, 3:7] = c[:, 0:2], c[:, 3:7]
+    out[:, 7:9], out[:, 10:14] = c[:, 7:9], c[:, 10:14]
+    return out

@@ -255,8 +255,98 @@ def gen_avoiding_task():
     print("avoiding task: success_rate %.6f entropy %.9f" % (float(successes.mean()), float(entropy)))
 
 
+def gen_pushing_task():
+    """Block_Push_Env task logic (pushing.py:255-280,335-459) and the metric tail of Pushing_Sim.test_agent
+    (pushing_sim.py:140-178), driven with synthetic box poses through a fake scene."""
+    from envs.gym_pushing_env.gym_pushing.envs.pushing import Block_Push_Env
+    import simulation.pushing_sim as S
+    import torch
+
+    rng = np.random.default_rng(7)
+    env = object.__new__(Block_Push_Env)
+    env.push_box1, env.push_box2, env.target_box_1, env.target_box_2 = "b1", "b2", "t1", "t2"
+    env.target_min_dist = 0.05
+    poses = {"t1": (np.array([0.42, 0.3, 0.0]), np.array([0.0, 1, 0, 0])),
+             "t2": (np.array([0.63, 0.3, 0.0]), np.array([0.0, 1, 0, 0]))}
+    scene = type("S", (), {})()
+    scene.get_obj_pos = lambda o: poses[o][0].copy()
+    scene.get_obj_quat = lambda o: poses[o][1].copy()
+    env.scene = scene
+    tcp = np.zeros(3)
+    env.robot_state = lambda: tcp.copy()
+    E, T = 70, 64
+    box = np.zeros((E, T, 2, 7))
+    rob = np.zeros((E, T, 3))
+    obs = np.zeros((E, T, 8), dtype=np.float32)
+    mode = np.zeros((E, T), dtype=np.int64)
+    first = np.zeros((E, T), dtype=np.int64)
+    meand = np.zeros((E, T))
+    succ = np.zeros((E, T), dtype=bool)
+    rew = np.zeros((E, T))
+    tg = [poses["t1"][0], poses["t2"][0]]
+    for e in range(E):
+        env.first_visit = -1
+        env.terminated = False
+        # each box is dragged towards a target (a random pairing and visiting order) with noise, then on to the other
+        pairing = rng.integers(0, 2)           # 0: b1->t1,b2->t2 ; 1: b1->t2,b2->t1
+        order = rng.integers(0, 2)             # which box moves first
+        p = [np.array([rng.uniform(0.4, 0.5), rng.uniform(-0.15, 0.0), rng.uniform(0.0, 0.02)]),
+             np.array([rng.uniform(0.55, 0.65), rng.uniform(-0.15, 0.0), rng.uniform(0.0, 0.02)])]
+        yaw = [rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi)]
+        tilt = [rng.normal(scale=0.02, size=2) if e % 3 == 0 else np.zeros(2) for _ in range(2)]
+        for t in range(T):
+            mover = order if t < T // 2 else 1 - order
+            goal = tg[mover ^ pairing] + np.array([0, 0, 0.011])
+            d = goal - p[mover]
+            p[mover] = p[mover] + 0.09 * d + rng.normal(scale=0.004, size=3) * (e % 4 != 1)
+            if e % 5 == 4 and t > T // 3:   # wander off again
+                p[mover] += rng.normal(scale=0.03, size=3)
+            for k in range(2):
+                yaw[k] += rng.normal(scale=0.05)
+                q = np.array([np.cos(yaw[k] / 2), tilt[k][0], tilt[k][1], np.sin(yaw[k] / 2)])
+                if e % 7 == 0:
+                    q *= 1 + 1e-3 * rng.normal()      # un-normalised quaternion (qpos is read raw)
+                poses["b%d" % (k + 1)] = (p[k].copy(), q)
+                box[e, t, k, :3], box[e, t, k, 3:] = p[k], q
+            tcp[:] = rng.uniform([0.3, -0.4, 0.1], [0.8, 0.45, 0.14])
+            rob[e, t] = tcp
+            obs[e, t] = env.get_observation()
+            succ[e, t] = env._check_early_termination()
+            mode[e, t], meand[e, t] = env.check_mode()
+            first[e, t] = env.first_visit
+            rew[e, t] = env.get_reward()
+    # metric tail with a stubbed rollout
+    nc, nt = 30, 16
+    me = rng.integers(-1, 4, size=(nc, nt)).astype(np.float32)
+    su = (rng.uniform(size=(nc, nt)) < 0.6).astype(np.float32)
+    su[3] = 0
+    md = rng.uniform(0, 0.3, size=(nc, nt)).astype(np.float32)
+
+    def fake_eval(self, agent, contexts, n_trajectories, mode_encoding, successes, mean_distance, pid, cpu_set):
+        mode_encoding[:] = torch.tensor(me)
+        successes[:] = torch.tensor(su)
+        mean_distance[:] = torch.tensor(md)
+
+    logged = {}
+    S.Pushing_Sim.eval_agent = fake_eval
+    S.wandb.log = lambda d, *a, **k: logged.update(d)
+    sim = S.Pushing_Sim(seed=0, device="cpu", render=False, n_cores=1, n_contexts=nc, n_trajectories_per_context=nt)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim.test_agent(agent=None)
+    ctx = np.load(os.path.join(ref_shims.REF, "environments/dataset/data/pushing/test_contexts.pkl"), allow_pickle=True)
+    ctx_arr = np.array([np.concatenate([np.asarray(a, dtype=np.float64) for a in c]) for c in ctx])   # [60][3+4+3+4]
+    np.savez_compressed(os.path.join(HERE, "ref_pushing_task.npz"), box=box, rob=rob, obs=obs, mode=mode, first=first,
+                        mean_distance=meand, succ=succ, reward=rew, metric_mode=me, metric_succ=su, metric_dist=md,
+                        metric_success_rate=float(logged["Metrics/successes"]), metric_entropy=float(logged["Metrics/entropy"]),
+                        metric_distance=float(logged["Metrics/distance"]), metric_score=float(logged["score"]),
+                        test_contexts=ctx_arr)
+    print("pushing task: success %.4f entropy %.6f; modes seen %s; successes %d" % (
+        logged["Metrics/successes"], logged["Metrics/entropy"], np.unique(mode), succ.sum()))
+
+
 if __name__ == "__main__":
     gen_ik()
     gen_pd_finger()
     gen_offline_ik()
     gen_avoiding_task()
+    gen_pushing_task()
