@@ -243,3 +243,10 @@ class Oracle:
         self.L.orc_push_logic(self.h, _p(box14), _p(tcp), int(reset), _p(obs), C.byref(succ), C.byref(mode), C.byref(first),
                               C.byref(md), C.byref(rew))
         return obs, bool(succ.value), mode.value, first.value, md.value, rew.value
+
+    def push_state(self):
+        s = np.zeros(42 + 13 * 2)
+        self.L.orc_push_get_state(self.h, _p(s))
+        f = np.zeros(8, dtype=np.int32)
+        self.L.orc_push_get_flags(self.h, _p(f))
+        return s, f

@@ -11,7 +11,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libd3il_hostcheck.so")
-    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h")]
+    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "push_step.h")]
     srcs.append(os.path.join(_HERE, "..", "..", "include", "d3il_model_blob.h"))
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
@@ -78,3 +78,34 @@ class HostCheck:
         obs, done = np.zeros(2, dtype=np.float32), np.zeros(1, dtype=np.uint8)
         self.L.hc_env_step(self.h, _p(s), _p(f), _p(action), _p(obs), _p(done), int(fast))
         return obs, bool(done[0])
+
+
+class PushHostCheck:
+    """Host build of the Pushing kernel math (d3il_amd/csrc/push_step.h), one environment."""
+
+    def __init__(self, blob):
+        self.L = lib()
+        self.L.hc_push_create.restype = C.c_void_p
+        err = C.c_char_p()
+        self.h = C.c_void_p(self.L.hc_push_create(C.byref(blob), C.byref(err)))
+        if not self.h:
+            raise RuntimeError("hc_push_create: %s" % (err.value.decode() if err.value else "?"))
+        self.n = self.L.hc_push_state_size()
+        self.s = np.zeros(self.n)
+        self.f = np.zeros(2, dtype=np.int32)
+
+    def reset(self, init_qpos, ctx):
+        init_qpos, ctx = np.ascontiguousarray(init_qpos, float), np.ascontiguousarray(ctx, float).reshape(14)
+        obs = np.zeros(8, dtype=np.float32)
+        self.L.hc_push_reset(self.h, _p(init_qpos), _p(ctx), _p(self.s), _p(self.f), _p(obs))
+        return obs
+
+    def step(self, action, fast=True):
+        action = np.ascontiguousarray(action, float)
+        obs = np.zeros(8, dtype=np.float32)
+        rew, md = C.c_double(0), C.c_double(0)
+        done = C.c_ubyte(0)
+        self.L.hc_push_step(self.h, _p(self.s), _p(self.f), _p(action), _p(obs), C.byref(rew), C.byref(done), C.byref(md), int(fast))
+        fl = int(self.f[0]) & 0xFFFFFFFF
+        info = dict(mode=((fl >> 3) & 7) - 1, success=bool(fl & (1 << 13)), mean_distance=md.value, first_visit=(fl & 7) - 1, flags=fl)
+        return obs, rew.value, bool(done.value), info

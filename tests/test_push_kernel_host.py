@@ -1,0 +1,79 @@
+"""Host build of the Pushing kernel math (d3il_amd/csrc/push_step.h via tests/hostcheck) against the oracle.
+
+The two are independent formulations of the same sub-step: the oracle is a generic world-frame engine (dense constraint
+Jacobian, dense Cholesky, cold-started Newton), the kernel math is specialised (link-frame arm dynamics, sparse contact
+rows, skyline Cholesky of the [cube|cube|arm] Hessian, warm-started Newton).  Agreement to ~1e-9 over thousands of
+sub-steps therefore checks both.  No GPU needed; the GPU run of the same code is covered by tests/test_gpu_parity_pushing.py.
+"""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from tests.hostcheck.hostcheck import PushHostCheck
+
+
+@pytest.fixture(scope="module")
+def push_hc(pushing_blob):
+    return PushHostCheck(pushing_blob)
+
+
+def _chase(obs, des, step=0.006):
+    """scripted policy: move the desired TCP towards the red cube (then through it)"""
+    d = obs[2:4].astype(float) - des
+    n = np.linalg.norm(d)
+    return des + d / max(n, 1e-9) * min(step, n)
+
+
+def test_reset_matches_oracle_on_all_reference_contexts(push_oracle, push_hc, init_qpos, push_contexts):
+    push_oracle.env_start(init_qpos)
+    for ctx in push_contexts:
+        obs_o = push_oracle.push_reset(ctx)
+        obs_h = push_hc.reset(init_qpos, ctx)
+        np.testing.assert_array_equal(obs_o, obs_h)
+        so, fo = push_oracle.push_state()
+        np.testing.assert_allclose(push_hc.s[:68], so, atol=1e-11, rtol=0)
+        assert fo[6] >= 16          # the cubes start sunk into both table slabs (8 contacts each)
+
+
+@pytest.mark.parametrize("ctx_id", [0, 7, 23])
+def test_pushing_rollout_matches_oracle(push_oracle, push_hc, init_qpos, push_contexts, ctx_id):
+    ctx = push_contexts[ctx_id]
+    push_oracle.env_start(init_qpos)
+    obs_o = push_oracle.push_reset(ctx)
+    obs_h = push_hc.reset(init_qpos, ctx)
+    des = obs_o[:2].astype(float)
+    z = float(push_hc.s[27])        # TCP z after reset (D3IL_STATE_TCP + 2)
+    moved = False
+    for t in range(45):
+        des = _chase(obs_o, des)
+        a = np.concatenate([des, [z], [0, 1, 0, 0]])
+        obs_o, rew_o, done_o, info_o = push_oracle.push_step(a)
+        obs_h, rew_h, done_h, info_h = push_hc.step(a)
+        so, fo = push_oracle.push_state()
+        sh = push_hc.s[:68]
+        assert done_o == done_h and info_o["mode"] == info_h["mode"] and info_o["success"] == info_h["success"]
+        assert not (info_h["flags"] & ((1 << 16) | (1 << 18) | (1 << 19))), hex(info_h["flags"])   # solver fail / overflow / off table
+        np.testing.assert_allclose(obs_h, obs_o, atol=1e-6, rtol=1e-6)
+        # positions (arm q, cube pos/quat, TCP) to 1e-7, velocities to 1e-4 (cube angular velocity is the sensitive quantity
+        # while the cube rocks on its contacts)
+        pos_idx = list(range(0, 9)) + list(range(25, 28)) + list(range(42, 49)) + list(range(55, 62))
+        vel_idx = list(range(9, 18)) + list(range(49, 55)) + list(range(62, 68))
+        np.testing.assert_allclose(sh[pos_idx], so[pos_idx], atol=1e-7, rtol=0)
+        np.testing.assert_allclose(sh[vel_idx], so[vel_idx], atol=1e-4, rtol=0)
+        assert abs(rew_o - rew_h) < 1e-7 and abs(info_o["mean_distance"] - info_h["mean_distance"]) < 1e-7
+        moved = moved or abs(so[43] - ctx[1]) > 0.02
+    assert moved        # the rod did push the red cube
+
+
+def test_slow_ik_path_gives_the_same_rollout(push_hc, pushing_blob, init_qpos, push_contexts):
+    other = PushHostCheck(pushing_blob)
+    ctx = push_contexts[3]
+    o1, o2 = push_hc.reset(init_qpos, ctx), other.reset(init_qpos, ctx)
+    des = o1[:2].astype(float)
+    z = float(push_hc.s[27])
+    for t in range(10):
+        des = _chase(o1, des)
+        a = np.concatenate([des, [z], [0, 1, 0, 0]])
+        o1 = push_hc.step(a, fast=True)[0]
+        o2 = other.step(a, fast=False)[0]
+    np.testing.assert_allclose(push_hc.s[:68], other.s[:68], atol=1e-8)
