@@ -16,13 +16,18 @@ _LIB = None
 class Buffers(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("stride", C.c_int32), ("obs_dim", C.c_int32), ("action_dim", C.c_int32),
                 ("obs", C.c_void_p), ("done", C.c_void_p), ("success", C.c_void_p), ("mode", C.c_void_p),
-                ("state", C.c_void_p), ("flags", C.c_void_p), ("step_count", C.c_void_p), ("policy_des", C.c_void_p)]
+                ("state", C.c_void_p), ("flags", C.c_void_p), ("step_count", C.c_void_p), ("policy_des", C.c_void_p),
+                ("info_f64", C.c_void_p), ("n_info_f64", C.c_int32), ("state_rows", C.c_int32)]
 
 
 STATE_F64 = 42
 STATE_QPOS, STATE_QVEL, STATE_BIAS, STATE_TCP, STATE_IK_Q, STATE_IK_QD = 0, 9, 18, 25, 28, 35
 FLAG_MODE_MASK, FLAG_TERMINATED, FLAG_SUCCESS, FLAG_ROD_CONTACT = 0x1FF, 1 << 12, 1 << 13, 1 << 14
 FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
+# Pushing (D3IL_PUSH_STATE_* / D3IL_PFLAG_* in include/d3il_rollout.h)
+PUSH_STATE_BOX, PUSH_STATE_WARM, PUSH_STATE_F64 = 42, 68, 89
+PFLAG_FIRST_MASK, PFLAG_MODE_MASK, PFLAG_WARM_VALID, PFLAG_CON_OVERFLOW, PFLAG_OFF_TABLE = 0x7, 0x38, 1 << 6, 1 << 18, 1 << 19
+TASK_AVOIDING, TASK_PUSHING = 0, 1
 
 EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
            "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_auto_reset", "d3il_count_metrics", "d3il_set_timing",

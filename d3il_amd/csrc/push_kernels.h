@@ -1,0 +1,169 @@
+// push_kernels.h - HIP kernels of the Pushing task (included by rollout.hip).
+//
+// Same execution shape as the Avoiding step: one environment per lane, two cooperating waves per workgroup (the
+// controller wave runs the open-loop IK chain, the physics wave runs dynamics + collision + constraint solve +
+// integration, one workgroup barrier per sub-step, set-points handed over through an LDS slot).  A workgroup owns
+// PUSH_LANES = 24 environments: the coupled constraint solver keeps its per-contact table, the arm mass matrix, the cube
+// Hessian and the elimination matrices of each environment in LDS (670 doubles per environment, lane-strided =>
+// conflict-free ds_read/write_b64), 125.6 KiB per workgroup, i.e. one workgroup per CU; 4096 environments are 171
+// workgroups on 171 of the 256 CUs.  The rarely used memory-resident solver (arm joint at a limit, rod on both cubes) works in an HBM scratch area.
+#pragma once
+#include "push_step.h"
+
+namespace d3il {
+
+constexpr int PUSH_LANES = 24;                                   // environments per workgroup
+constexpr int PUSH_LDS_H = PT_SIZE * PUSH_LANES * 8;             // coupled-solver table
+constexpr int PUSH_LDS_X = 2 * 2 * NARM * PUSH_LANES * 8;        // set-point exchange (double buffered)
+constexpr int PUSH_LDS_STEP = PUSH_LDS_H + PUSH_LDS_X;
+constexpr int PUSH_OBS = 8;
+
+__device__ __forceinline__ void push_load(const double* __restrict__ state, const unsigned* __restrict__ flags, const int* __restrict__ steps,
+                                          int stride, int e, PushState& ps, bool with_ik) {
+  const double* s = state + e;
+  EnvState& st = ps.arm;
+  for (int i = 0; i < NDOF; i++) st.q[i] = s[(D3IL_STATE_QPOS + i) * (size_t)stride];
+  for (int i = 0; i < NDOF; i++) st.v[i] = s[(D3IL_STATE_QVEL + i) * (size_t)stride];
+  for (int i = 0; i < NARM; i++) st.bias[i] = s[(D3IL_STATE_BIAS + i) * (size_t)stride];
+  for (int i = 0; i < 3; i++) st.tcp[i] = s[(D3IL_STATE_TCP + i) * (size_t)stride];
+  if (with_ik) {
+    for (int i = 0; i < NARM; i++) st.ikq[i] = s[(D3IL_STATE_IK_Q + i) * (size_t)stride];
+    for (int i = 0; i < NARM; i++) st.ikqd[i] = s[(D3IL_STATE_IK_QD + i) * (size_t)stride];
+  }
+  int k = PUSH_STATE_BOX;
+  for (int b = 0; b < PUSH_NB; b++) {
+    for (int i = 0; i < 3; i++) ps.box[b].pos[i] = s[(size_t)(k++) * stride];
+    for (int i = 0; i < 4; i++) ps.box[b].quat[i] = s[(size_t)(k++) * stride];
+    for (int i = 0; i < 6; i++) ps.box[b].vel[i] = s[(size_t)(k++) * stride];
+  }
+  st.flags = flags[e]; st.step = steps[e];
+}
+__device__ __forceinline__ void push_store(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps, int stride, int e,
+                                           const PushState& ps, bool with_ik) {
+  double* s = state + e;
+  const EnvState& st = ps.arm;
+  for (int i = 0; i < NDOF; i++) s[(D3IL_STATE_QPOS + i) * (size_t)stride] = st.q[i];
+  for (int i = 0; i < NDOF; i++) s[(D3IL_STATE_QVEL + i) * (size_t)stride] = st.v[i];
+  for (int i = 0; i < NARM; i++) s[(D3IL_STATE_BIAS + i) * (size_t)stride] = st.bias[i];
+  for (int i = 0; i < 3; i++) s[(D3IL_STATE_TCP + i) * (size_t)stride] = st.tcp[i];
+  if (with_ik) {
+    for (int i = 0; i < NARM; i++) s[(D3IL_STATE_IK_Q + i) * (size_t)stride] = st.ikq[i];
+    for (int i = 0; i < NARM; i++) s[(D3IL_STATE_IK_QD + i) * (size_t)stride] = st.ikqd[i];
+  }
+  int k = PUSH_STATE_BOX;
+  for (int b = 0; b < PUSH_NB; b++) {
+    for (int i = 0; i < 3; i++) s[(size_t)(k++) * stride] = ps.box[b].pos[i];
+    for (int i = 0; i < 4; i++) s[(size_t)(k++) * stride] = ps.box[b].quat[i];
+    for (int i = 0; i < 6; i++) s[(size_t)(k++) * stride] = ps.box[b].vel[i];
+  }
+  flags[e] = st.flags; steps[e] = st.step;
+}
+__device__ __forceinline__ void push_store_outputs(const PushState& ps, int e, int stride, const float* o, unsigned char dn, double reward, double mean_distance,
+                                                   float* __restrict__ obs, unsigned char* __restrict__ done, unsigned char* __restrict__ success,
+                                                   unsigned short* __restrict__ mode, double* __restrict__ info) {
+  for (int k = 0; k < PUSH_OBS; k++) obs[(size_t)PUSH_OBS * e + k] = o[k];
+  done[e] = dn; success[e] = (ps.arm.flags & F_SUCCESS) ? 1 : 0;
+  mode[e] = (unsigned short)(short)((int)((ps.arm.flags & PF_MODE_MASK) >> PF_MODE_SHIFT) - 1);   // int16: -1 .. 3
+  info[e] = mean_distance; info[(size_t)stride + e] = reward;
+}
+
+// env.step() for the Pushing task
+template <bool FAST>
+__global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(PushConsts pc, double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+                                                                 const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
+                                                                 unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
+                                                                 double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
+  extern __shared__ double smem[];
+  double* tbl = smem;                                    // [PT_SIZE][PUSH_LANES]
+  double (*xch)[2 * NARM][PUSH_LANES] = (double (*)[2 * NARM][PUSH_LANES])(smem + PT_SIZE * PUSH_LANES);
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int role = threadIdx.x / WAVE;
+  const int e = blockIdx.x * PUSH_LANES + lane;
+  const bool live = lane < PUSH_LANES && e < n;          // the other lanes only take part in the barriers
+  const PandaConsts& c = kAvoidingConsts;                // the arm is the Avoiding arm (same robot XML / gin / URDF)
+  if (role == 0) {
+    double ikq[NARM], ikqd[NARM], q0[NARM], des[7];
+    unsigned fl = 0;
+    double vwarm[7];
+    vwarm[6] = 0.0;
+    if (live) {
+      const double* sp = state + e;
+      double act[7];
+#pragma unroll
+      for (int i = 0; i < NARM; i++) {
+        ikq[i] = sp[(D3IL_STATE_IK_Q + i) * (size_t)stride]; ikqd[i] = sp[(D3IL_STATE_IK_QD + i) * (size_t)stride];
+        q0[i] = sp[(D3IL_STATE_QPOS + i) * (size_t)stride];
+      }
+#pragma unroll
+      for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
+      fl = flags[e];
+      make_setpoint(act, des);
+    }
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < n_substeps; s++) {
+      if (live) {
+        ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd, vwarm);
+        const int b = s & 1;
+#pragma unroll
+        for (int k = 0; k < NARM; k++) { xch[b][k][lane] = ikq[k]; xch[b][NARM + k][lane] = ikqd[k]; }
+      }
+      __syncthreads();
+    }
+    if (live) {
+      double* so = state + e;
+#pragma unroll
+      for (int i = 0; i < NARM; i++) { so[(D3IL_STATE_IK_Q + i) * (size_t)stride] = ikq[i]; so[(D3IL_STATE_IK_QD + i) * (size_t)stride] = ikqd[i]; }
+    }
+  } else {
+    PushState ps;
+    float o[PUSH_OBS]; unsigned char dn = 0; double reward = 0, mean_distance = 0;
+    PushScratch sc{tbl + lane, PUSH_LANES, scratch + (live ? e : 0), stride, state + (size_t)PUSH_STATE_WARM * stride + (live ? e : 0), stride};
+    if (live) {
+      push_load(state, flags, steps, stride, e, ps, false);
+      push_step_begin(pc, ps, o, &reward, &dn, max_steps);
+    }
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < n_substeps; s++) {
+      __syncthreads();
+      if (live) {
+        const int b = s & 1;
+        double qd[NARM], qdd[NARM];
+#pragma unroll
+        for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][lane]; qdd[k] = xch[b][NARM + k][lane]; }
+        push_control_and_physics(c, pc, ps, sc, qd, qdd, 0.04, false);
+      }
+    }
+    if (live) {
+      ps.arm.flags |= F_IK_VALID;
+      push_step_end(pc, ps, &mean_distance);
+      push_store(state, flags, steps, stride, e, ps, false);
+      push_store_outputs(ps, e, stride, o, dn, reward, mean_distance, obs, done, success, mode, info);
+    }
+  }
+}
+
+// env.reset(random=False, context) for masked environments; contexts: f64 [n][14] = 2 x (pos3, quat4)
+__global__ __launch_bounds__(WAVE) void k_pushing_reset(PushConsts pc, const double* __restrict__ init_qpos, const unsigned char* __restrict__ mask,
+                                                        const double* __restrict__ contexts, double* __restrict__ state, unsigned* __restrict__ flags,
+                                                        int* __restrict__ steps, float* __restrict__ obs, unsigned char* __restrict__ done,
+                                                        unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
+                                                        double* __restrict__ scratch, int n, int stride) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x * PUSH_LANES + lane;
+  if (lane >= PUSH_LANES || e >= n) return;
+  if (mask && !mask[e]) return;
+  PushState ps;
+  double iq[NARM], ctx[14];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
+  for (int k = 0; k < 14; k++) ctx[k] = contexts[(size_t)e * 14 + k];
+  PushScratch sc{smem + lane, PUSH_LANES, scratch + e, stride, state + (size_t)PUSH_STATE_WARM * stride + e, stride};
+  float o[PUSH_OBS];
+  ps.arm.flags = 0; ps.arm.step = 0;
+  push_env_reset(kAvoidingConsts, pc, ps, sc, iq, ctx, o);
+  push_store(state, flags, steps, stride, e, ps, true);
+  push_store_outputs(ps, e, stride, o, 0, 0.0, 0.0, obs, done, success, mode, info);
+}
+
+}  // namespace d3il

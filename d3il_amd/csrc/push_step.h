@@ -59,13 +59,13 @@ struct BoxState { double pos[3], quat[4], vel[6]; };
 struct PushState {
   EnvState arm;
   BoxState box[PUSH_NB];
-  double warm[PUSH_NV];
 };
 
 // per-lane views of the two scratch areas: h = Hessian (LDS on the device), g = everything else (HBM)
 struct PushScratch {
   double* h; int hs;
   double* g; int gs;
+  double* w; int ws;     // warm start qacc[21] of the constraint solver: rows PUSH_STATE_WARM.. of the state buffer
 };
 // layout of the g area (doubles per lane)
 constexpr int PG_M = 0;                                 // arm mass matrix, packed lower 9x9
@@ -76,10 +76,13 @@ constexpr int PG_JA = PG_CON + PUSH_MAXCON * PREC;      // arm Jacobian rows of 
 constexpr int PG_A0 = PG_JA + 42;                       // qacc_smooth[21]
 constexpr int PG_X = PG_A0 + PUSH_NV;                   // iterate
 constexpr int PG_GRAD = PG_X + PUSH_NV;                 // gradient, then the Newton direction
-constexpr int PG_SIZE = PG_GRAD + PUSH_NV;              // 774
+constexpr int PG_H = PG_GRAD + PUSH_NV + 72;            // after the PG_AUX block: Hessian of the slow general path (231)
+constexpr int PG_SIZE = PG_H + PUSH_NH;
 
 #define PGS(i) sc.g[(long)(i) * sc.gs]
-#define PHS(i) sc.h[(long)(i) * sc.hs]
+#define PHS(i) PGS(PG_H + (i))
+#define PTS(i) sc.h[(long)(i) * sc.hs]
+#define PWS(i) sc.w[(long)(i) * sc.ws]
 
 enum { CK_SLAB = 0, CK_BOXBOX = 1, CK_ROD = 2 };
 
@@ -239,9 +242,9 @@ D3IL_HD bool cyl_box(const double* pc, const double* axis, double rad, double ha
 }
 
 // ------------------------------------------------------------------------------------------------ constraint rows
-// Jacobian row of a cube (6 entries: linear world, angular body axes) for a world direction f at the world point p
-D3IL_HD void box_row(const double* R, const double* bpos, const double* p, const double* f, double* row) {
-  double r[3] = {p[0] - bpos[0], p[1] - bpos[1], p[2] - bpos[2]}, rxf[3];
+// Jacobian row of a cube (6 entries: linear world, angular body axes) for a world direction f and the arm r = p - centre
+D3IL_HD void box_row_r(const double* R, const double* r, const double* f, double* row) {
+  double rxf[3];
   cross3(r, f, rxf);
   row[0] = f[0]; row[1] = f[1]; row[2] = f[2];
   row[3] = R[0] * rxf[0] + R[3] * rxf[1] + R[6] * rxf[2];
@@ -249,70 +252,284 @@ D3IL_HD void box_row(const double* R, const double* bpos, const double* p, const
   row[5] = R[2] * rxf[0] + R[5] * rxf[1] + R[8] * rxf[2];
 }
 
-// Sparse row of one contact direction over the 21 solver dofs: up to two blocks (offset, length, values).
-struct SRow { int o1, n1, o2, n2; double v1[7], v2[7]; };
-
-// builds the three rows (normal, t1, t2) of contact `ci` from its record; the relative velocity is body2 - body1 with the
-// normal pointing from geom1 to geom2: slab(1) -> cube(2); cube1(1) -> cube2(2); cube(1) -> rod(2)
-D3IL_HD void contact_rows(const PushScratch& sc, int ci, const double (*Rb)[9], const BoxState* box, SRow* rows) {
-  int base = PG_CON + ci * PREC;
-  double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
-  int kind = (int)PGS(base + 13), cube = (int)PGS(base + 14);
-  for (int r = 0; r < 3; r++) {
-    double f[3] = {PGS(base + 3 + 3 * r), PGS(base + 4 + 3 * r), PGS(base + 5 + 3 * r)};
-    SRow& s = rows[r];
-    if (kind == CK_SLAB) {
-      s.o1 = 6 * cube; s.n1 = 6; s.n2 = 0; s.o2 = 0;
-      box_row(Rb[cube], box[cube].pos, p, f, s.v1);
-    } else if (kind == CK_BOXBOX) {
-      s.o1 = 0; s.n1 = 6; s.o2 = 6; s.n2 = 6;
-      box_row(Rb[0], box[0].pos, p, f, s.v1);
-      for (int k = 0; k < 6; k++) s.v1[k] = -s.v1[k];
-      box_row(Rb[1], box[1].pos, p, f, s.v2);
-    } else {
-      s.o1 = 6 * cube; s.n1 = 6; s.o2 = PUSH_ARM0; s.n2 = 7;
-      box_row(Rb[cube], box[cube].pos, p, f, s.v1);
-      for (int k = 0; k < 6; k++) s.v1[k] = -s.v1[k];
-      for (int k = 0; k < 7; k++) s.v2[k] = PGS(PG_JA + cube * 21 + r * 7 + k);
-    }
-  }
-}
-D3IL_HD double srow_dot(const SRow& s, const double* x) {
-  double a = 0;
-  for (int k = 0; k < s.n1; k++) a += s.v1[k] * x[s.o1 + k];
-  for (int k = 0; k < s.n2; k++) a += s.v2[k] * x[s.o2 + k];
-  return a;
-}
-
 // elliptic cone (condim 3, friction mu_geom on both tangents): force and Hessian block at row residuals jar.
-// Returns the cost.  zone: 0 top (free), 1 bottom (quadratic), 2 middle.
-D3IL_HD double cone_eval(const double* jar, double Dn, double Dt, double mu, double fric, double* force, double* Hc /* 3x3 or null */) {
+// Returns the cost.  Zones: top (free), bottom (quadratic), middle.
+D3IL_HD double cone_eval(const double* jar, double Dn, double Dt, double mu, double fric, double* force, double* Hc /* 3x3 */) {
   double U0 = jar[0] * mu, U1 = jar[1] * fric, U2 = jar[2] * fric;
   double N = U0, T = sqrt(U1 * U1 + U2 * U2);
-  if (Hc) for (int i = 0; i < 9; i++) Hc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) Hc[i] = 0;
   if (N >= mu * T || (T <= 0 && N >= 0)) { force[0] = force[1] = force[2] = 0; return 0; }
   if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
     force[0] = -Dn * jar[0]; force[1] = -Dt * jar[1]; force[2] = -Dt * jar[2];
-    if (Hc) { Hc[0] = Dn; Hc[4] = Dt; Hc[8] = Dt; }
+    Hc[0] = Dn; Hc[4] = Dt; Hc[8] = Dt;
     return 0.5 * (Dn * jar[0] * jar[0] + Dt * jar[1] * jar[1] + Dt * jar[2] * jar[2]);
   }
   double Dm = Dn / fmax(1e-15, mu * mu * (1 + mu * mu)), NmT = N - mu * T;
-  double g[3] = {mu, -mu * fric * U1 / T, -mu * fric * U2 / T};
+  double iT = 1 / T, iT3 = iT * iT * iT;
+  double g[3] = {mu, -mu * fric * U1 * iT, -mu * fric * U2 * iT}, U[3] = {0, U1, U2};
+#pragma unroll
   for (int j = 0; j < 3; j++) force[j] = -Dm * NmT * g[j];
-  if (Hc) {
-    double U[3] = {0, U1, U2}, iT = 1 / T, iT3 = iT * iT * iT;
-    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
       double h = g[a] * g[b];
       if (a > 0 && b > 0) h += NmT * (-mu) * fric * fric * ((a == b ? iT : 0) - U[a] * U[b] * iT3);
       Hc[3 * a + b] = Dm * h;
     }
-  }
   return 0.5 * Dm * NmT * NmT;
 }
 
-// ------------------------------------------------------------------------------------------------ skyline Cholesky in the h area
-// first[i] = first column of row i inside the envelope (wave-uniform): cube1 rows 0, cube2 rows (bb ? 0 : 6),
-// arm rows (rod on cube1 ? 0 : rod on cube2 ? 6 : 12)
+// wave-level OR of a per-lane predicate (host: identity)
+D3IL_HD bool wave_any(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __any(p) != 0;
+#else
+  return p;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ cube <-> table slabs
+// box_box() specialised to a cube on one of the two large axis-aligned static slabs, away from the slab edges: the slab top
+// is the reference face (see the separating-axis argument in DESIGN.md), the incident face is the cube face most opposed to
+// +z, nothing is clipped, and each of its four vertices below the slab top is a contact (normal +z, frame z / y / -x,
+// position midway).  Slot i = 4 * slab + vertex.  Same numbers as box_box() in this regime (tests/test_push_kernel_host.py).
+struct CubeSlab {
+  double r[8][3];     // contact position relative to the cube centre
+  double dist[8];     // signed distance (< 0: active)
+};
+struct CubeFace { double Bk[3], B1[3], B2[3], hk, h1, h2, sgi; };
+D3IL_HD void cube_face(const PushConsts& pc, const double* R, CubeFace& f) {   // incident face: the cube face most opposed to +z
+  double bz0 = fabs(R[6]), bz1 = fabs(R[7]), bz2 = fabs(R[8]);
+  int kin = 0; double bestdot = bz0;
+  if (bz1 > bestdot) { bestdot = bz1; kin = 1; }
+  if (bz2 > bestdot) { bestdot = bz2; kin = 2; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double c0 = R[3 * k], c1 = R[3 * k + 1], c2 = R[3 * k + 2];
+    f.Bk[k] = kin == 0 ? c0 : (kin == 1 ? c1 : c2);
+    f.B1[k] = kin == 0 ? c1 : (kin == 1 ? c2 : c0);
+    f.B2[k] = kin == 0 ? c2 : (kin == 1 ? c0 : c1);
+  }
+  f.hk = kin == 0 ? pc.box_half[0] : (kin == 1 ? pc.box_half[1] : pc.box_half[2]);
+  f.h1 = kin == 0 ? pc.box_half[1] : (kin == 1 ? pc.box_half[2] : pc.box_half[0]);
+  f.h2 = kin == 0 ? pc.box_half[2] : (kin == 1 ? pc.box_half[0] : pc.box_half[1]);
+  f.sgi = f.Bk[2] > 0 ? -1.0 : 1.0;
+}
+// slot i = 4 * slab + vertex: contact position relative to the cube centre and signed distance
+D3IL_HD void slot_geom(const PushConsts& pc, const CubeFace& f, const double* pos, int i, double* r, double* dist) {
+  int s = i >> 2, v = i & 3;
+  double c0 = (v == 0 || v == 3) ? 1.0 : -1.0, c1 = v < 2 ? 1.0 : -1.0, x[3];
+  double sc0 = s ? pc.slab_c[1][0] : pc.slab_c[0][0], sc1 = s ? pc.slab_c[1][1] : pc.slab_c[0][1], sc2 = s ? pc.slab_c[1][2] : pc.slab_c[0][2];
+  double sh2 = s ? pc.slab_h[1][2] : pc.slab_h[0][2];
+  const double scv[3] = {sc0, sc1, sc2};
+#pragma unroll
+  for (int k = 0; k < 3; k++) x[k] = pos[k] + f.sgi * f.hk * f.Bk[k] + c0 * f.h1 * f.B1[k] + c1 * f.h2 * f.B2[k] - scv[k];
+  double w = x[2] - sh2;
+  *dist = w;
+  r[0] = sc0 + x[0] - pos[0];
+  r[1] = sc1 + x[1] - pos[1];
+  r[2] = sc2 + (sh2 + 0.5 * w) - pos[2];
+}
+D3IL_HD void cube_slab_contacts(const PushConsts& pc, const double* pos, const double* R, CubeSlab& cs) {
+  CubeFace f;
+  cube_face(pc, R, f);
+#pragma unroll
+  for (int i = 0; i < 8; i++) slot_geom(pc, f, pos, i, cs.r[i], &cs.dist[i]);
+}
+// rows of slot i: normal z, tangents y and -x (make_frame of (0, 0, 1))
+D3IL_HD void slab_rows(const double* R, const double* r, double (*J)[6]) {
+  const double fz[3] = {0, 0, 1}, fy[3] = {0, 1, 0}, fx[3] = {-1, 0, 0};
+  box_row_r(R, r, fz, J[0]); box_row_r(R, r, fy, J[1]); box_row_r(R, r, fx, J[2]);
+}
+
+// One free cube resting / sliding on the slabs, no other contact: 6-dof primal Newton with exact line search, everything
+// in registers.  x: start point in, optimum out (acceleration: linear world, angular body axes).
+D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, const double* vel, const CubeSlab& cs, const double* a0, double* x) {
+  const double Mm[6] = {pc.box_mass, pc.box_mass, pc.box_mass, pc.box_inertia, pc.box_inertia, pc.box_inertia};
+  const double fric = pc.ct_fric[0], mu = fric * sqrt(1 / fmax(1e-15, pc.impratio)), impr = pc.impratio;
+  bool act[8]; double aref[8][3], Dn[8];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    act[i] = cs.dist[i] < 0;
+    any = any || act[i];
+    aref[i][0] = aref[i][1] = aref[i][2] = 0; Dn[i] = 0;
+    if (wave_any(act[i])) {
+      double J[3][6]; slab_rows(R, cs.r[i], J);
+      double imp = impedance(pc.ct_solimp[0], cs.dist[i]);
+      double Rn = fmax(1e-15, (1 - imp) / imp * pc.box_invw_t);
+      double v3[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) { double a = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) a += J[r][k] * vel[k]; v3[r] = a; }
+      aref[i][0] = -pc.ct_B[0] * v3[0] - pc.ct_K[0] * imp * cs.dist[i];
+      aref[i][1] = -pc.ct_B[0] * v3[1]; aref[i][2] = -pc.ct_B[0] * v3[2];
+      Dn[i] = 1 / Rn;
+    }
+  }
+  if (!any) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) x[k] = a0[k];
+    return true;
+  }
+  bool converged = false;
+  D3IL_STAT(g_stats.newton_calls++);
+  for (int it = 0; it < PUSH_MAXIT && !converged; it++) {
+    D3IL_STAT(g_stats.eig_calls++);
+    double g[6], H[21], jar[8][3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) g[k] = Mm[k] * (x[k] - a0[k]);
+#pragma unroll
+    for (int i = 0; i < 21; i++) H[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) H[tri(k, k)] = Mm[k];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      jar[i][0] = jar[i][1] = jar[i][2] = 0;
+      if (wave_any(act[i])) {
+        double J[3][6]; slab_rows(R, cs.r[i], J);
+        double f[3], Hc[9], jr[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) { double a = -aref[i][r];
+#pragma unroll
+          for (int k = 0; k < 6; k++) a += J[r][k] * x[k]; jr[r] = a; jar[i][r] = a; }
+        cone_eval(jr, Dn[i], Dn[i] * impr, mu, fric, f, Hc);
+        if (act[i]) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) g[k] -= J[0][k] * f[0] + J[1][k] * f[1] + J[2][k] * f[2];
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+            double ta[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * J[0][a] + Hc[3 * r + 1] * J[1][a] + Hc[3 * r + 2] * J[2][a];
+#pragma unroll
+            for (int b = 0; b <= a; b++) H[tri(a, b)] += ta[0] * J[0][b] + ta[1] * J[1][b] + ta[2] * J[2][b];
+          }
+        }
+      }
+    }
+    double L[21], d[6], id[6], p[6], ng[6]; int nneg;
+#pragma unroll
+    for (int i = 0; i < 21; i++) L[i] = 0;
+    if (!ldl6(H, 0.0, L, d, id, &nneg) || nneg) return false;
+#pragma unroll
+    for (int k = 0; k < 6; k++) ng[k] = -g[k];
+    ldl6_solve(L, id, ng, p);
+    double pMp = 0, pMa = 0, jp[8][3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { pMp += Mm[k] * p[k] * p[k]; pMa += Mm[k] * p[k] * (x[k] - a0[k]); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      jp[i][0] = jp[i][1] = jp[i][2] = 0;
+      if (wave_any(act[i])) {
+        double J[3][6]; slab_rows(R, cs.r[i], J);
+#pragma unroll
+        for (int r = 0; r < 3; r++) { double a = 0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) a += J[r][k] * p[k]; jp[i][r] = a; }
+      }
+    }
+    double alpha = 1, lo = 0, hi = -1, best = 1;
+    for (int ls = 0; ls < 40; ls++) {
+      D3IL_STAT(g_stats.ik_calls++);
+      double d1 = pMa + alpha * pMp, d2 = pMp;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (wave_any(act[i])) {
+          double jt[3] = {jar[i][0] + alpha * jp[i][0], jar[i][1] + alpha * jp[i][1], jar[i][2] + alpha * jp[i][2]}, ft[3], Hc[9];
+          cone_eval(jt, Dn[i], Dn[i] * impr, mu, fric, ft, Hc);
+          if (act[i]) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[i][r];
+#pragma unroll
+              for (int q = 0; q < 3; q++) d2 += jp[i][r] * Hc[3 * r + q] * jp[i][q]; }
+          }
+        }
+      }
+      best = alpha;
+      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 / d2;
+      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+    double smax = 0, xmax = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { double dxk = best * p[k]; x[k] += dxk; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(x[k])); }
+    // Newton converges quadratically once the full step is accepted: a step below 1e-6 (relative) leaves an error of the
+    // order of its square, so the confirming iteration is skipped
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
+  }
+  return converged;
+}
+
+// ------------------------------------------------------------------------------------------------ general path (memory resident)
+// Used when the rod touches a cube, the cubes touch each other, or an arm joint is at a limit: all 21 dofs in one Newton
+// solve.  Data lives in the scratch areas (contact records, M, a0, x, direction in HBM; Hessian in LDS), the function is
+// out of line and keeps few registers live.  g-area inputs: PG_M, PG_A0, contact records (pos, normal, dist, kind, cube),
+// PG_JA, PG_AUX (cube poses, velocities, limit rows); PG_X holds the start point and receives the optimum.
+constexpr int PG_AUX = PG_GRAD + PUSH_NV;      // R[2][9] pos[2][3] vel21 lim[9][3]
+constexpr int PG_AUX_R = PG_AUX, PG_AUX_POS = PG_AUX + 18, PG_AUX_VEL = PG_AUX + 24, PG_AUX_LIM = PG_AUX + 45;
+
+struct SRow { int o1, o2, n2; double v1[6], v2[7]; };   // block 1: 6 cube dofs at o1; block 2: n2 (0, 6 or 7) dofs at o2
+
+D3IL_HD void contact_rows(const PushScratch& sc, int ci, SRow* rows) {
+  int base = PG_CON + ci * PREC;
+  double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
+  int kind = (int)PGS(base + 13), cube = (int)PGS(base + 14);
+  double Rc[9], r[3], R1[9], r1[3];
+  int cb = kind == CK_BOXBOX ? 0 : cube;
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rc[k] = PGS(PG_AUX_R + 9 * cb + k);
+#pragma unroll
+  for (int k = 0; k < 3; k++) r[k] = p[k] - PGS(PG_AUX_POS + 3 * cb + k);
+  if (kind == CK_BOXBOX) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) R1[k] = PGS(PG_AUX_R + 9 + k);
+#pragma unroll
+    for (int k = 0; k < 3; k++) r1[k] = p[k] - PGS(PG_AUX_POS + 3 + k);
+  }
+#pragma unroll
+  for (int rr = 0; rr < 3; rr++) {
+    double f[3] = {PGS(base + 3 + 3 * rr), PGS(base + 4 + 3 * rr), PGS(base + 5 + 3 * rr)};
+    SRow& s = rows[rr];
+    box_row_r(Rc, r, f, s.v1);
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v2[k] = 0;
+    if (kind == CK_SLAB) { s.o1 = 6 * cube; s.o2 = 0; s.n2 = 0; }
+    else if (kind == CK_BOXBOX) {
+      s.o1 = 0; s.o2 = 6; s.n2 = 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s.v1[k] = -s.v1[k];
+      double t[6]; box_row_r(R1, r1, f, t);
+#pragma unroll
+      for (int k = 0; k < 6; k++) s.v2[k] = t[k];
+    } else {
+      s.o1 = 6 * cube; s.o2 = PUSH_ARM0; s.n2 = 7;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s.v1[k] = -s.v1[k];
+#pragma unroll
+      for (int k = 0; k < 7; k++) s.v2[k] = PGS(PG_JA + cube * 21 + rr * 7 + k);
+    }
+  }
+}
+// row . vector stored in the g area at offset `vec`
+D3IL_HD double srow_dot_g(const PushScratch& sc, const SRow& s, int vec) {
+  double a = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) a += s.v1[k] * PGS(vec + s.o1 + k);
+#pragma unroll
+  for (int k = 0; k < 7; k++) if (k < s.n2) a += s.v2[k] * PGS(vec + s.o2 + k);
+  return a;
+}
+
+// skyline Cholesky in the h area.  first[i] = first column of row i inside the envelope: cube1 rows 0, cube2 rows
+// (bb ? 0 : 6), arm rows (rod on cube1 ? 0 : rod on cube2 ? 6 : 12)
 D3IL_HD int sky_first(int i, bool bb, bool rod1, bool rod2) {
   if (i < 6) return 0;
   if (i < 12) return bb ? 0 : 6;
@@ -332,130 +549,31 @@ D3IL_HD bool sky_chol(const PushScratch& sc, bool bb, bool rod1, bool rod2) {
   }
   return ok;
 }
-D3IL_HD void sky_solve(const PushScratch& sc, bool bb, bool rod1, bool rod2, double* x) {
+// solves in place on the vector at g offset `vec`
+D3IL_HD void sky_solve_g(const PushScratch& sc, bool bb, bool rod1, bool rod2, int vec) {
   for (int i = 0; i < PUSH_NV; i++) {
     int fi = sky_first(i, bb, rod1, rod2);
-    double s = x[i];
-    for (int k = fi; k < i; k++) s -= PHS(tri(i, k)) * x[k];
-    x[i] = s / PHS(tri(i, i));
+    double s = PGS(vec + i);
+    for (int k = fi; k < i; k++) s -= PHS(tri(i, k)) * PGS(vec + k);
+    PGS(vec + i) = s / PHS(tri(i, i));
   }
   for (int i = PUSH_NV - 1; i >= 0; i--) {
-    double xi = x[i] / PHS(tri(i, i));
-    x[i] = xi;
+    double xi = PGS(vec + i) / PHS(tri(i, i));
+    PGS(vec + i) = xi;
     int fi = sky_first(i, bb, rod1, rod2);
-    for (int k = fi; k < i; k++) x[k] -= PHS(tri(i, k)) * xi;
+    for (int k = fi; k < i; k++) PGS(vec + k) -= PHS(tri(i, k)) * xi;
   }
 }
-
-// wave-level OR of a per-lane predicate (host: identity)
-D3IL_HD bool wave_any(bool p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __any(p) != 0;
-#else
-  return p;
-#endif
+D3IL_HD double gM(const PushConsts& pc, const PushScratch& sc, int i, int k) {   // entry (i, k) of the block-diagonal mass matrix
+  if (i < PUSH_ARM0 || k < PUSH_ARM0) return i == k ? ((i % 6) < 3 ? pc.box_mass : pc.box_inertia) : 0.0;
+  int a = i - PUSH_ARM0, b = k - PUSH_ARM0;
+  return PGS(PG_M + (a >= b ? tri(a, b) : tri(b, a)));
 }
 
-// ------------------------------------------------------------------------------------------------ the physics sub-step
-struct LimitRow { double sign, D, aref; };
-
-template <class C>
-D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* tau, const double* ffing) {
-  EnvState& st = ps.arm;
-  double fs[NDOF], tcp_new[3], rodc[3], rodu[3];
-  double h = 0;
-  // ---- arm: dynamics, smooth force, read-backs (as panda_step.h physics_substep)
-  {
-    DynOut dyn;
-    dynamics(c0, st.q, st.v, dyn);
-    D3IL_REFRESH(c0, c);
-    h = c.timestep;
-#pragma unroll
-    for (int k = 0; k < NARM; k++) fs[k] = clampd(tau[k] + st.bias[k], c.force_lo[k], c.force_hi[k]) - dyn.bias[k];
-#pragma unroll
-    for (int k = 0; k < NFING; k++) fs[NARM + k] = clampd(ffing[k], c.force_lo[NARM + k], c.force_hi[NARM + k]) - dyn.bias[NARM + k] - c.f_damping[k] * st.v[NARM + k];
-#pragma unroll
-    for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
-    double t[3]; mulE(dyn.R7, c.tcp7, t);
-    tcp_new[0] = dyn.p7[0] + t[0]; tcp_new[1] = dyn.p7[1] + t[1]; tcp_new[2] = dyn.p7[2] + t[2];
-    mulE(dyn.R7, c.rod_c7, rodc); rodc[0] += dyn.p7[0]; rodc[1] += dyn.p7[1]; rodc[2] += dyn.p7[2];
-    mulE(dyn.R7, c.rod_u7, rodu);
-    for (int i = 0; i < 45; i++) PGS(PG_M + i) = dyn.M[i];
-    // qacc_smooth of the arm
-    double L[45], d[NDOF], id[NDOF], a0[NDOF];
-    if (!ldl9(dyn.M, L, d, id)) st.flags |= F_SOLVER_FAIL;
-#pragma unroll
-    for (int k = 0; k < NDOF; k++) a0[k] = fs[k];
-    ldl9_solve(L, id, a0);
-    for (int k = 0; k < NDOF; k++) PGS(PG_A0 + PUSH_ARM0 + k) = a0[k];
-  }
-  st.tcp[0] = tcp_new[0]; st.tcp[1] = tcp_new[1]; st.tcp[2] = tcp_new[2];
-  D3IL_REFRESH(c0, c);
-  // ---- cubes: kinematics and smooth acceleration (gravity; isotropic inertia has no gyroscopic term)
-  double Rb[PUSH_NB][9];
-  for (int b = 0; b < PUSH_NB; b++) {
-    quat2mat(ps.box[b].quat, Rb[b]);
-    for (int k = 0; k < 6; k++) PGS(PG_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0;
-    if (fabs(ps.box[b].pos[0] - pc.slab_c[0][0]) > pc.slab_h[0][0] - 0.06 || fabs(ps.box[b].pos[1] - pc.slab_c[0][1]) > pc.slab_h[0][1] - 0.06) st.flags |= PF_OFF_TABLE;
-  }
-  // ---- collision -> contact records
-  int ncon = 0; bool has_bb = false, has_rod[2] = {false, false};
-  {
-    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    double rec[8][7];
-    for (int b = 0; b < PUSH_NB; b++) for (int s = 0; s < 2; s++) {
-      int n = box_box(pc.slab_c[s], I3, pc.slab_h[s], ps.box[b].pos, Rb[b], pc.box_half, 0.0, rec, 8);
-      for (int i = 0; i < n; i++) {
-        if (ncon >= PUSH_MAXCON) { st.flags |= PF_CON_OVERFLOW; break; }
-        int base = PG_CON + ncon * PREC;
-        for (int k = 0; k < 3; k++) { PGS(base + k) = rec[i][1 + k]; PGS(base + 3 + k) = rec[i][4 + k]; }
-        PGS(base + 12) = rec[i][0]; PGS(base + 13) = CK_SLAB; PGS(base + 14) = b;
-        ncon++;
-      }
-    }
-    {
-      int n = box_box(ps.box[0].pos, Rb[0], pc.box_half, ps.box[1].pos, Rb[1], pc.box_half, 0.0, rec, 8);
-      for (int i = 0; i < n; i++) {
-        if (ncon >= PUSH_MAXCON) { st.flags |= PF_CON_OVERFLOW; break; }
-        int base = PG_CON + ncon * PREC;
-        for (int k = 0; k < 3; k++) { PGS(base + k) = rec[i][1 + k]; PGS(base + 3 + k) = rec[i][4 + k]; }
-        PGS(base + 12) = rec[i][0]; PGS(base + 13) = CK_BOXBOX; PGS(base + 14) = 0;
-        ncon++; has_bb = true;
-      }
-    }
-    for (int b = 0; b < PUSH_NB; b++) {
-      double r1[7];
-      if (cyl_box(rodc, rodu, c.rod_r, c.rod_h, ps.box[b].pos, Rb[b], pc.box_half, 0.0, r1)) {
-        if (ncon >= PUSH_MAXCON) { st.flags |= PF_CON_OVERFLOW; continue; }
-        int base = PG_CON + ncon * PREC;
-        for (int k = 0; k < 3; k++) { PGS(base + k) = r1[1 + k]; PGS(base + 3 + k) = r1[4 + k]; }
-        PGS(base + 12) = r1[0]; PGS(base + 13) = CK_ROD; PGS(base + 14) = b;
-        ncon++; has_rod[b] = true;
-      }
-    }
-  }
-  // arm Jacobian rows of the rod contacts (world joint axes / origins from the arm chain)
-  if (has_rod[0] || has_rod[1]) {
-    double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3];
-    for (int k = 0; k < NARM; k++) { sn[k] = sin(st.q[k]); cs[k] = cos(st.q[k]); }
-    world_chain(c0, sn, cs, R7, p7, ax, og);
-    for (int ci = 0; ci < ncon; ci++) {
-      int base = PG_CON + ci * PREC;
-      if ((int)PGS(base + 13) != CK_ROD) continue;
-      int b = (int)PGS(base + 14);
-      double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)}, n[3] = {PGS(base + 3), PGS(base + 4), PGS(base + 5)}, t1[3], t2[3];
-      make_frame(n, t1, t2);
-      for (int k = 0; k < NARM; k++) {
-        double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
-        cross3(ax[k], dd, col);
-        PGS(PG_JA + b * 21 + k) = dot3(n, col); PGS(PG_JA + b * 21 + 7 + k) = dot3(t1, col); PGS(PG_JA + b * 21 + 14 + k) = dot3(t2, col);
-      }
-    }
-  }
-  // ---- per-contact frame, reference acceleration and regularisation
-  double vel21[PUSH_NV];
-  for (int b = 0; b < PUSH_NB; b++) for (int k = 0; k < 6; k++) vel21[6 * b + k] = ps.box[b].vel[k];
-  for (int k = 0; k < NDOF; k++) vel21[PUSH_ARM0 + k] = st.v[k];
+// returns false if the solver did not converge
+D3IL_NOINLINE inline bool push_general_solve(const PushConsts& pc, const PushScratch& sc, int ncon, bool env_bb, bool env_r1, bool env_r2) {
+  const double impr = pc.impratio;
+  // per-contact frame, reference acceleration, regularisation
   for (int ci = 0; ci < ncon; ci++) {
     int base = PG_CON + ci * PREC;
     double n[3] = {PGS(base + 3), PGS(base + 4), PGS(base + 5)}, t1[3], t2[3];
@@ -464,180 +582,1019 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
     int kind = (int)PGS(base + 13), set = kind == CK_SLAB ? 0 : 1;
     double dist = PGS(base + 12);
     double imp = impedance(pc.ct_solimp[set], dist);
-    double invw = kind == CK_SLAB ? pc.box_invw_t : (kind == CK_BOXBOX ? 2 * pc.box_invw_t : pc.box_invw_t + c.rod_invweight0);
+    double invw = kind == CK_SLAB ? pc.box_invw_t : (kind == CK_BOXBOX ? 2 * pc.box_invw_t : pc.box_invw_t + PGS(PG_AUX_LIM + 27));
     double Rn = fmax(1e-15, (1 - imp) / imp * invw);
     SRow rows[3];
-    contact_rows(sc, ci, Rb, ps.box, rows);
-    double v0 = srow_dot(rows[0], vel21), v1 = srow_dot(rows[1], vel21), v2 = srow_dot(rows[2], vel21);
+    contact_rows(sc, ci, rows);
+    double v0 = srow_dot_g(sc, rows[0], PG_AUX_VEL), v1 = srow_dot_g(sc, rows[1], PG_AUX_VEL), v2 = srow_dot_g(sc, rows[2], PG_AUX_VEL);
     PGS(base + 15) = -pc.ct_B[set] * v0 - pc.ct_K[set] * imp * dist;
     PGS(base + 16) = -pc.ct_B[set] * v1; PGS(base + 17) = -pc.ct_B[set] * v2;
     PGS(base + 18) = 1 / Rn;
-    PGS(base + 19) = pc.ct_fric[set] * sqrt(1 / fmax(1e-15, pc.impratio));
+    PGS(base + 19) = pc.ct_fric[set] * sqrt(1 / fmax(1e-15, impr));
   }
-  // joint-limit rows of the arm (mj_instantiateLimit): at most one side per joint can be inside its margin
-  LimitRow lim[NDOF];
-  for (int k = 0; k < NDOF; k++) {
-    double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
-    double sign = 0, dist = 0;
-    if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
-    else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
-    lim[k].sign = sign; lim[k].D = 0; lim[k].aref = 0;
-    if (sign != 0) {
-      double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
-      lim[k].D = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
-      lim[k].aref = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
+  bool converged = false;
+  for (int it = 0; it < PUSH_MAXIT && !converged; it++) {
+    // gradient (into PG_GRAD) and Hessian (h area) at x
+    for (int i = 0; i < PUSH_NV; i++) {
+      double s = 0;
+      if (i < PUSH_ARM0) s = gM(pc, sc, i, i) * (PGS(PG_X + i) - PGS(PG_A0 + i));
+      else for (int k = PUSH_ARM0; k < PUSH_NV; k++) s += gM(pc, sc, i, k) * (PGS(PG_X + k) - PGS(PG_A0 + k));
+      PGS(PG_GRAD + i) = s;
     }
-  }
-  bool any_lim = false;
-  for (int k = 0; k < NDOF; k++) any_lim = any_lim || lim[k].sign != 0;
-  // ---- Newton
-  const bool env_bb = wave_any(has_bb), env_r1 = wave_any(has_rod[0]), env_r2 = wave_any(has_rod[1]);
-  const double impr = pc.impratio;
-  double x[PUSH_NV];
-  if (ncon == 0 && !any_lim) {
-    for (int k = 0; k < PUSH_NV; k++) x[k] = PGS(PG_A0 + k);
-  } else {
-    if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) x[k] = ps.warm[k];
-    else for (int k = 0; k < PUSH_NV; k++) x[k] = PGS(PG_A0 + k);
-    bool converged = false;
-    for (int it = 0; it < PUSH_MAXIT && !converged; it++) {
-      // gradient and Hessian at x
-      double grad[PUSH_NV];
-      {
-        double dx[PUSH_NV];
-        for (int k = 0; k < PUSH_NV; k++) dx[k] = x[k] - PGS(PG_A0 + k);
-        for (int b = 0; b < PUSH_NB; b++) for (int k = 0; k < 6; k++) grad[6 * b + k] = (k < 3 ? pc.box_mass : pc.box_inertia) * dx[6 * b + k];
-        for (int i = 0; i < NDOF; i++) {
-          double s = 0;
-          for (int k = 0; k < NDOF; k++) s += PGS(PG_M + (i >= k ? tri(i, k) : tri(k, i))) * dx[PUSH_ARM0 + k];
-          grad[PUSH_ARM0 + i] = s;
-        }
+    for (int i = 0; i < PUSH_NH; i++) PHS(i) = 0;
+    for (int i = 0; i < PUSH_ARM0; i++) PHS(tri(i, i)) = gM(pc, sc, i, i);
+    for (int i = 0; i < NDOF; i++) for (int k = 0; k <= i; k++) PHS(tri(PUSH_ARM0 + i, PUSH_ARM0 + k)) = PGS(PG_M + tri(i, k));
+    for (int k = 0; k < NDOF; k++) {
+      double sign = PGS(PG_AUX_LIM + 3 * k), D = PGS(PG_AUX_LIM + 3 * k + 1), aref = PGS(PG_AUX_LIM + 3 * k + 2);
+      if (sign != 0) {
+        double jar = sign * PGS(PG_X + PUSH_ARM0 + k) - aref;
+        if (jar < 0) { PGS(PG_GRAD + PUSH_ARM0 + k) += sign * D * jar; PHS(tri(PUSH_ARM0 + k, PUSH_ARM0 + k)) += D; }
       }
-      for (int i = 0; i < PUSH_NH; i++) PHS(i) = 0;
-      for (int b = 0; b < PUSH_NB; b++) for (int k = 0; k < 6; k++) PHS(tri(6 * b + k, 6 * b + k)) = k < 3 ? pc.box_mass : pc.box_inertia;
-      for (int i = 0; i < NDOF; i++) for (int k = 0; k <= i; k++) PHS(tri(PUSH_ARM0 + i, PUSH_ARM0 + k)) = PGS(PG_M + tri(i, k));
-      for (int k = 0; k < NDOF; k++) if (lim[k].sign != 0) {
-        double jar = lim[k].sign * x[PUSH_ARM0 + k] - lim[k].aref;
-        if (jar < 0) { grad[PUSH_ARM0 + k] += lim[k].sign * lim[k].D * jar; PHS(tri(PUSH_ARM0 + k, PUSH_ARM0 + k)) += lim[k].D; }
+    }
+    for (int ci = 0; ci < ncon; ci++) {
+      int base = PG_CON + ci * PREC;
+      SRow rows[3];
+      contact_rows(sc, ci, rows);
+      double jar[3], force[3], Hc[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++) { jar[r] = srow_dot_g(sc, rows[r], PG_X) - PGS(base + 15 + r); PGS(base + 20 + r) = jar[r]; }
+      double Dn = PGS(base + 18), mu = PGS(base + 19), fric = pc.ct_fric[(int)PGS(base + 13) == CK_SLAB ? 0 : 1];
+      cone_eval(jar, Dn, Dn * impr, mu, fric, force, Hc);
+      if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
+      const int o1 = rows[0].o1, o2 = rows[0].o2, n2 = rows[0].n2;
+#pragma unroll
+      for (int k = 0; k < 6; k++) PGS(PG_GRAD + o1 + k) -= rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2];
+#pragma unroll
+      for (int k = 0; k < 7; k++) if (k < n2) PGS(PG_GRAD + o2 + k) -= rows[0].v2[k] * force[0] + rows[1].v2[k] * force[1] + rows[2].v2[k] * force[2];
+      // H += J' Hc J : block (1,1), then (2,1) and (2,2)
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+        double ta[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v1[a] + Hc[3 * r + 1] * rows[1].v1[a] + Hc[3 * r + 2] * rows[2].v1[a];
+#pragma unroll
+        for (int b = 0; b <= a; b++) PHS(tri(o1 + a, o1 + b)) += ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b];
+      }
+#pragma unroll
+      for (int a = 0; a < 7; a++) if (a < n2) {
+        double ta[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v2[a] + Hc[3 * r + 1] * rows[1].v2[a] + Hc[3 * r + 2] * rows[2].v2[a];
+#pragma unroll
+        for (int b = 0; b < 6; b++) PHS(tri(o2 + a, o1 + b)) += ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b];
+#pragma unroll
+        for (int b = 0; b < 7; b++) if (b <= a) PHS(tri(o2 + a, o2 + b)) += ta[0] * rows[0].v2[b] + ta[1] * rows[1].v2[b] + ta[2] * rows[2].v2[b];
+      }
+    }
+    if (!sky_chol(sc, env_bb, env_r1, env_r2)) return false;
+    // direction p = -H^-1 grad, in place
+    for (int k = 0; k < PUSH_NV; k++) PGS(PG_GRAD + k) = -PGS(PG_GRAD + k);
+    sky_solve_g(sc, env_bb, env_r1, env_r2, PG_GRAD);
+    double pMp = 0, pMa = 0;
+    for (int i = 0; i < PUSH_NV; i++) {
+      double s = 0, sa = 0;
+      if (i < PUSH_ARM0) { double mm = gM(pc, sc, i, i); s = mm * PGS(PG_GRAD + i); sa = mm * (PGS(PG_X + i) - PGS(PG_A0 + i)); }
+      else for (int k = PUSH_ARM0; k < PUSH_NV; k++) { double mm = gM(pc, sc, i, k); s += mm * PGS(PG_GRAD + k); sa += mm * (PGS(PG_X + k) - PGS(PG_A0 + k)); }
+      pMp += PGS(PG_GRAD + i) * s; pMa += PGS(PG_GRAD + i) * sa;
+    }
+    for (int ci = 0; ci < ncon; ci++) {
+      int base = PG_CON + ci * PREC;
+      SRow rows[3];
+      contact_rows(sc, ci, rows);
+#pragma unroll
+      for (int r = 0; r < 3; r++) PGS(base + 23 + r) = srow_dot_g(sc, rows[r], PG_GRAD);
+    }
+    double alpha = 1, lo = 0, hi = -1, best = 1;
+    for (int ls = 0; ls < 40; ls++) {
+      double d1 = pMa + alpha * pMp, d2 = pMp;
+      for (int k = 0; k < NDOF; k++) {
+        double sign = PGS(PG_AUX_LIM + 3 * k), D = PGS(PG_AUX_LIM + 3 * k + 1), aref = PGS(PG_AUX_LIM + 3 * k + 2);
+        if (sign != 0) {
+          double jp = sign * PGS(PG_GRAD + PUSH_ARM0 + k), jar = sign * PGS(PG_X + PUSH_ARM0 + k) - aref + alpha * jp;
+          if (jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
+        }
       }
       for (int ci = 0; ci < ncon; ci++) {
         int base = PG_CON + ci * PREC;
-        SRow rows[3];
-        contact_rows(sc, ci, Rb, ps.box, rows);
-        double jar[3], force[3], Hc[9];
-        for (int r = 0; r < 3; r++) { jar[r] = srow_dot(rows[r], x) - PGS(base + 15 + r); PGS(base + 20 + r) = jar[r]; }
+        double jp[3] = {PGS(base + 23), PGS(base + 24), PGS(base + 25)};
+        double jt[3] = {PGS(base + 20) + alpha * jp[0], PGS(base + 21) + alpha * jp[1], PGS(base + 22) + alpha * jp[2]}, ft[3], Hc[9];
         double Dn = PGS(base + 18), mu = PGS(base + 19), fric = pc.ct_fric[(int)PGS(base + 13) == CK_SLAB ? 0 : 1];
-        cone_eval(jar, Dn, Dn * impr, mu, fric, force, Hc);
-        for (int r = 0; r < 3; r++) {
-          if (force[r] == 0) continue;
-          for (int k = 0; k < rows[r].n1; k++) grad[rows[r].o1 + k] -= rows[r].v1[k] * force[r];
-          for (int k = 0; k < rows[r].n2; k++) grad[rows[r].o2 + k] -= rows[r].v2[k] * force[r];
+        cone_eval(jt, Dn, Dn * impr, mu, fric, ft, Hc);
+#pragma unroll
+        for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r];
+#pragma unroll
+          for (int q = 0; q < 3; q++) d2 += jp[r] * Hc[3 * r + q] * jp[q]; }
+      }
+      best = alpha;
+      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 / d2;
+      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+    double smax = 0, xmax = 0;
+    for (int k = 0; k < PUSH_NV; k++) {
+      double dxk = best * PGS(PG_GRAD + k), xn = PGS(PG_X + k) + dxk;
+      PGS(PG_X + k) = xn; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(xn));
+    }
+    // Newton converges quadratically once the full step is accepted: a step below 1e-6 (relative) leaves an error of the
+    // order of its square, so the confirming iteration is skipped
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
+  }
+  return converged;
+}
+
+// ------------------------------------------------------------------------------------------------ coupled path (registers + LDS)
+// Rod on one cube and / or cube <-> cube contacts: Newton over arm + both cubes with the arm eliminated first.  The rod
+// contact row is r = A a_arm + Jb a_cube - aref (A: 3 x 7 arm Jacobian, Jb: minus the cube rows), so with Hc the 3 x 3 cone
+// Hessian:  H_aa = M_a + limits + A' Hc A,  C = A' Hc Jb,  and the arm drops out of the Newton system as
+//   (H_cc - Jb' K Jb) p_c = -g_c + Jb' Hc (A z),   K = Hc (A Z) Hc,   Z = H_aa^-1 A',  z = H_aa^-1 g_a,
+//   p_a = -z - Z Hc (Jb p_c).
+// H_cc is the 12 x 12 cube block (cube-cube contacts fill its off-diagonal 6 x 6), factorised unrolled in registers; the
+// 9 x 9 arm factorisation reuses ldl9.  Per-contact data (aref, D, row residuals jar, directional derivatives jp) sits
+// in the lane-strided LDS table.  Layout of the table (fields per lane):
+constexpr int PT_X = 0, PT_P = 21, PT_A0 = 42, PT_M = 63, PT_LIM = 108, PT_R = 135, PT_POS = 153, PT_VEL = 159, PT_JA = 180, PT_Z = 201, PT_ZG = 228;
+constexpr int PT_SLAB = 237;            // 16 slots x (aref[3], Dn, jar[3], jp[3])
+constexpr int PT_CON = PT_SLAB + 160;   // 8 cube-cube + 1 rod: pos[3] n[3] dist aref[3] Dn jar[3] jp[3]
+constexpr int PT_ROD = PT_CON + 8 * 17;
+constexpr int PT_H = PT_CON + 9 * 17;      // 12 x 12 cube Hessian, packed lower (78)
+constexpr int PT_XR = PT_H + 78;           // rod-contact hand-over between the phases (42)
+constexpr int PT_SIZE = PT_XR + 42;        // 670
+
+template <int N> D3IL_HD bool ldl_n(double* A, double* d, double* id) {   // in place: strict lower part of A becomes L
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double s = A[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= A[tri(j, k)] * A[tri(j, k)] * d[k];
+    if (!(s > 1e-300)) { s = 1; ok = false; }
+    d[j] = s;
+    double inv = rcpd(s);
+    id[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < N; i++) {
+      double t = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= A[tri(i, k)] * A[tri(j, k)] * d[k];
+      A[tri(i, j)] = t * inv;
+    }
+  }
+  return ok;
+}
+template <int N> D3IL_HD void ldl_solve_n(const double* L, const double* id, double* x) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int k = 0; k < i; k++) x[i] -= L[tri(i, k)] * x[k];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] *= id[i];
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+#pragma unroll
+    for (int k = i + 1; k < N; k++) x[i] -= L[tri(k, i)] * x[k];
+  }
+}
+// accumulate J' Hc J into the packed lower-triangular 12 x 12 block: rows/cols at offsets oa >= ob (6 wide each)
+D3IL_HD void acc_block(double* H, int oa, int ob, const double (*Ja)[6], const double (*Jb)[6], const double* Hc, bool diag) {
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    double ta[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * Ja[0][a] + Hc[3 * r + 1] * Ja[1][a] + Hc[3 * r + 2] * Ja[2][a];
+#pragma unroll
+    for (int b = 0; b < 6; b++) if (!diag || b <= a) H[tri(oa + a, ob + b)] += ta[0] * Jb[0][b] + ta[1] * Jb[1][b] + ta[2] * Jb[2][b];
+  }
+}
+
+// nbb: cube-cube contacts in the table; rod_cube: cube touched by the rod (-1: none).  x: PT_X in / out.
+// The function is written as a sequence of phases that hand their results over through the LDS table, so that the live
+// register set of each phase stays small (the 12 x 12 Hessian is only in registers while it is factorised).
+D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch& sc, int nbb, int rod_cube, double rod_invw) {
+  const double impr = pc.impratio, isq = sqrt(1 / fmax(1e-15, impr));
+  const double fric0 = pc.ct_fric[0], mu0 = fric0 * isq, fric1 = pc.ct_fric[1], mu1 = fric1 * isq;
+  const bool rod = rod_cube >= 0;
+  const bool any_rod = wave_any(rod);
+  int nbb_max = nbb;
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(nbb_max, o); nbb_max = t > nbb_max ? t : nbb_max; }
+  nbb_max = nbb_max > 8 ? 8 : (nbb_max < nbb ? nbb : nbb_max);   // lanes outside the branch contribute stale registers
+#endif
+  // ---- per-contact reference acceleration and regularisation
+#pragma clang loop unroll(disable)
+  for (int b = 0; b < PUSH_NB; b++) {
+    double R[9], pos[3], vel[6];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 * b + k);
+#pragma unroll
+    for (int k = 0; k < 3; k++) pos[k] = PTS(PT_POS + 3 * b + k);
+#pragma unroll
+    for (int k = 0; k < 6; k++) vel[k] = PTS(PT_VEL + 6 * b + k);
+    CubeFace face;
+    cube_face(pc, R, face);
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < 8; i++) {
+      int base = PT_SLAB + 10 * (8 * b + i);
+      double r[3], dist;
+      slot_geom(pc, face, pos, i, r, &dist);
+      bool act = dist < 0;
+      double ar[3] = {0, 0, 0}, Dn = 0;
+      if (wave_any(act)) {
+        double J[3][6]; slab_rows(R, r, J);
+        double imp = impedance(pc.ct_solimp[0], dist);
+        double v3[3];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) { double a = 0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) a += J[rr][k] * vel[k]; v3[rr] = a; }
+        if (act) {
+          ar[0] = -pc.ct_B[0] * v3[0] - pc.ct_K[0] * imp * dist; ar[1] = -pc.ct_B[0] * v3[1]; ar[2] = -pc.ct_B[0] * v3[2];
+          Dn = 1 / fmax(1e-15, (1 - imp) / imp * pc.box_invw_t);
         }
-        if (Hc[0] == 0 && Hc[4] == 0) continue;
-        // H += J' Hc J over the (up to two) dof blocks of this contact
-        const int o1 = rows[0].o1, n1 = rows[0].n1, o2 = rows[0].o2, n2 = rows[0].n2;
-        for (int a = 0; a < n1 + n2; a++) {
-          int ia = a < n1 ? o1 + a : o2 + a - n1;
-          double ja[3], ta[3];
-          for (int r = 0; r < 3; r++) ja[r] = a < n1 ? rows[r].v1[a] : rows[r].v2[a - n1];
-          for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * ja[0] + Hc[3 * r + 1] * ja[1] + Hc[3 * r + 2] * ja[2];
-          for (int bq = 0; bq <= a; bq++) {
-            int ib = bq < n1 ? o1 + bq : o2 + bq - n1;
-            double s = 0;
-            for (int r = 0; r < 3; r++) s += ta[r] * (bq < n1 ? rows[r].v1[bq] : rows[r].v2[bq - n1]);
-            PHS(ia >= ib ? tri(ia, ib) : tri(ib, ia)) += s;
+      }
+      PTS(base) = ar[0]; PTS(base + 1) = ar[1]; PTS(base + 2) = ar[2]; PTS(base + 3) = Dn;
+    }
+  }
+  for (int ci = 0; ci < 9; ci++) {
+    bool isrod = ci == 8;
+    if (isrod ? !any_rod : ci >= nbb_max) continue;
+    bool act = isrod ? rod : ci < nbb;
+    int base = PT_CON + 17 * ci;
+    double ar[3] = {0, 0, 0}, Dn = 0;
+    if (act) {
+      double p[3] = {PTS(base), PTS(base + 1), PTS(base + 2)}, n[3] = {PTS(base + 3), PTS(base + 4), PTS(base + 5)}, t1[3], t2[3], dist = PTS(base + 6);
+      make_frame(n, t1, t2);
+      double v3[3] = {0, 0, 0};
+      for (int b = 0; b < PUSH_NB; b++) {
+        if (isrod && b != rod_cube) continue;
+        double R[9], r[3], vel[6], J[3][6];
+        for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 * b + k);
+        for (int k = 0; k < 3; k++) r[k] = p[k] - PTS(PT_POS + 3 * b + k);
+        for (int k = 0; k < 6; k++) vel[k] = PTS(PT_VEL + 6 * b + k);
+        box_row_r(R, r, n, J[0]); box_row_r(R, r, t1, J[1]); box_row_r(R, r, t2, J[2]);
+        double sg = (isrod || b == 0) ? -1.0 : 1.0;
+        for (int r3 = 0; r3 < 3; r3++) for (int k = 0; k < 6; k++) v3[r3] += sg * J[r3][k] * vel[k];
+      }
+      if (isrod) for (int r3 = 0; r3 < 3; r3++) for (int k = 0; k < NARM; k++) v3[r3] += PTS(PT_JA + 7 * r3 + k) * PTS(PT_VEL + PUSH_ARM0 + k);
+      double imp = impedance(pc.ct_solimp[1], dist);
+      double invw = isrod ? pc.box_invw_t + rod_invw : 2 * pc.box_invw_t;
+      ar[0] = -pc.ct_B[1] * v3[0] - pc.ct_K[1] * imp * dist; ar[1] = -pc.ct_B[1] * v3[1]; ar[2] = -pc.ct_B[1] * v3[2];
+      Dn = 1 / fmax(1e-15, (1 - imp) / imp * invw);
+    }
+    PTS(base + 7) = ar[0]; PTS(base + 8) = ar[1]; PTS(base + 9) = ar[2]; PTS(base + 10) = Dn;
+  }
+  bool converged = false;
+  D3IL_STAT(g_stats.contact_calls++);
+  for (int it = 0; it < PUSH_MAXIT && !converged; it++) {
+    D3IL_STAT(g_stats.newton_iters++);
+    // ================= phase A: arm gradient, H_aa, elimination quantities -> PT_ZG, PT_Z, PT_XR
+    // PT_XR: W[9] (Hc - K) | hcAz[3] | frod[3] | HcR[9] | JbR[18] (cube rows of the rod contact, negated)
+    {
+      double xa[NDOF], ga[NDOF], Haa[45];
+#pragma unroll
+      for (int i = 0; i < 45; i++) Haa[i] = PTS(PT_M + i);
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) xa[k] = PTS(PT_X + PUSH_ARM0 + k);
+      {
+        double dx[NDOF];
+#pragma unroll
+        for (int k = 0; k < NDOF; k++) dx[k] = xa[k] - PTS(PT_A0 + PUSH_ARM0 + k);
+        symv9(Haa, dx, ga);
+      }
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) {
+        double sign = PTS(PT_LIM + 3 * k), D = PTS(PT_LIM + 3 * k + 1), aref = PTS(PT_LIM + 3 * k + 2);
+        double jar = sign * xa[k] - aref;
+        if (sign != 0 && jar < 0) { ga[k] += sign * D * jar; Haa[tri(k, k)] += D; }
+      }
+      double A[3][NARM], HcR[9], frod[3] = {0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 9; i++) HcR[i] = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < NARM; k++) A[r][k] = 0;
+      if (any_rod) {
+        double JbR[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int k = 0; k < 6; k++) JbR[r][k] = 0;
+        if (rod) {
+          int base = PT_ROD;
+          double p[3] = {PTS(base), PTS(base + 1), PTS(base + 2)}, n[3] = {PTS(base + 3), PTS(base + 4), PTS(base + 5)}, t1[3], t2[3];
+          make_frame(n, t1, t2);
+          double R[9], r[3];
+          int b = rod_cube;
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 * b + k);
+#pragma unroll
+          for (int k = 0; k < 3; k++) r[k] = p[k] - PTS(PT_POS + 3 * b + k);
+          box_row_r(R, r, n, JbR[0]); box_row_r(R, r, t1, JbR[1]); box_row_r(R, r, t2, JbR[2]);
+#pragma unroll
+          for (int r3 = 0; r3 < 3; r3++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) JbR[r3][k] = -JbR[r3][k];
+#pragma unroll
+          for (int r3 = 0; r3 < 3; r3++)
+#pragma unroll
+            for (int k = 0; k < NARM; k++) A[r3][k] = PTS(PT_JA + 7 * r3 + k);
+          double jar[3];
+#pragma unroll
+          for (int r3 = 0; r3 < 3; r3++) {
+            double a = -PTS(base + 7 + r3);
+#pragma unroll
+            for (int k = 0; k < NARM; k++) a += A[r3][k] * xa[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) a += JbR[r3][k] * PTS(PT_X + 6 * b + k);
+            jar[r3] = a; PTS(base + 11 + r3) = a;
+          }
+          double Dn = PTS(base + 10);
+          cone_eval(jar, Dn, Dn * impr, mu1, fric1, frod, HcR);
+#pragma unroll
+          for (int k = 0; k < NARM; k++) {
+            ga[k] -= A[0][k] * frod[0] + A[1][k] * frod[1] + A[2][k] * frod[2];
+            double ta[3];
+#pragma unroll
+            for (int r3 = 0; r3 < 3; r3++) ta[r3] = HcR[3 * r3] * A[0][k] + HcR[3 * r3 + 1] * A[1][k] + HcR[3 * r3 + 2] * A[2][k];
+#pragma unroll
+            for (int q = 0; q <= k; q++) Haa[tri(k, q)] += ta[0] * A[0][q] + ta[1] * A[1][q] + ta[2] * A[2][q];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) PTS(PT_XR + 15 + i) = HcR[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) PTS(PT_XR + 12 + i) = frod[i];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int k = 0; k < 6; k++) PTS(PT_XR + 24 + 6 * r + k) = JbR[r][k];
+      }
+      double da[NDOF], ida[NDOF];
+      if (!ldl_n<NDOF>(Haa, da, ida)) return false;
+      double z[NDOF];
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) z[k] = ga[k];
+      ldl_solve_n<NDOF>(Haa, ida, z);
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) PTS(PT_ZG + k) = z[k];
+      if (any_rod) {
+        double AZ[9], Az[3];
+#pragma unroll
+        for (int r3 = 0; r3 < 3; r3++) {
+          double col[NDOF];
+#pragma unroll
+          for (int k = 0; k < NDOF; k++) col[k] = k < NARM ? A[r3][k] : 0.0;
+          ldl_solve_n<NDOF>(Haa, ida, col);
+#pragma unroll
+          for (int k = 0; k < NDOF; k++) PTS(PT_Z + 9 * r3 + k) = col[k];
+#pragma unroll
+          for (int q = 0; q < 3; q++) { double a = 0;
+#pragma unroll
+            for (int k = 0; k < NARM; k++) a += A[q][k] * col[k]; AZ[3 * q + r3] = a; }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) { double a = 0;
+#pragma unroll
+          for (int k = 0; k < NARM; k++) a += A[q][k] * z[k]; Az[q] = a; }
+        double T[9];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) T[3 * a + b] = HcR[3 * a] * AZ[b] + HcR[3 * a + 1] * AZ[3 + b] + HcR[3 * a + 2] * AZ[6 + b];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) PTS(PT_XR + 3 * a + b) = HcR[3 * a + b] - (T[3 * a] * HcR[b] + T[3 * a + 1] * HcR[3 + b] + T[3 * a + 2] * HcR[6 + b]);
+#pragma unroll
+        for (int a = 0; a < 3; a++) PTS(PT_XR + 9 + a) = HcR[3 * a] * Az[0] + HcR[3 * a + 1] * Az[1] + HcR[3 * a + 2] * Az[2];
+      }
+    }
+    // ================= phase B: cube gradients and diagonal Hessian blocks (registers) -> PT_H, PT_P (right-hand side)
+    for (int i = 0; i < 36; i++) PTS(PT_H + tri(6 + i / 6, i % 6)) = 0;      // off-diagonal 6 x 6 block
+#pragma clang loop unroll(disable)
+    for (int b = 0; b < PUSH_NB; b++) {
+      const double Mc[6] = {pc.box_mass, pc.box_mass, pc.box_mass, pc.box_inertia, pc.box_inertia, pc.box_inertia};
+      double R[9], pos[3], xb[6], Hb[21], gb[6];
+#pragma unroll
+      for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 * b + k);
+#pragma unroll
+      for (int k = 0; k < 3; k++) pos[k] = PTS(PT_POS + 3 * b + k);
+#pragma unroll
+      for (int k = 0; k < 6; k++) xb[k] = PTS(PT_X + 6 * b + k);
+#pragma unroll
+      for (int i = 0; i < 21; i++) Hb[i] = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { gb[k] = Mc[k] * (xb[k] - PTS(PT_A0 + 6 * b + k)); Hb[tri(k, k)] = Mc[k]; }
+      CubeFace face;
+      cube_face(pc, R, face);
+#pragma clang loop unroll(disable)
+      for (int i = 0; i < 8; i++) {
+        int base = PT_SLAB + 10 * (8 * b + i);
+        double Dn = PTS(base + 3);
+        if (wave_any(Dn != 0)) {
+          double r[3], dist;
+          slot_geom(pc, face, pos, i, r, &dist);
+          double J[3][6]; slab_rows(R, r, J);
+          double jar[3], f[3], Hc[9];
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++) { double a = -PTS(base + rr);
+#pragma unroll
+            for (int k = 0; k < 6; k++) a += J[rr][k] * xb[k]; jar[rr] = a; PTS(base + 4 + rr) = a; }
+          cone_eval(jar, Dn, Dn * impr, mu0, fric0, f, Hc);
+#pragma unroll
+          for (int k = 0; k < 6; k++) gb[k] -= J[0][k] * f[0] + J[1][k] * f[1] + J[2][k] * f[2];
+          acc_block(Hb, 0, 0, J, J, Hc, true);
+        }
+      }
+      if (any_rod) {
+        if (rod_cube == b) {   // rod contact seen from the cube: gradient, reduced Hessian J' W J, reduced right-hand side J' Hc (A z)
+          double JbR[3][6], W[9], hf[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) JbR[r][k] = PTS(PT_XR + 24 + 6 * r + k);
+#pragma unroll
+          for (int i = 0; i < 9; i++) W[i] = PTS(PT_XR + i);
+#pragma unroll
+          for (int i = 0; i < 3; i++) hf[i] = PTS(PT_XR + 9 + i) + PTS(PT_XR + 12 + i);
+#pragma unroll
+          for (int k = 0; k < 6; k++) gb[k] -= JbR[0][k] * hf[0] + JbR[1][k] * hf[1] + JbR[2][k] * hf[2];
+          acc_block(Hb, 0, 0, JbR, JbR, W, true);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int q = 0; q <= a; q++) PTS(PT_H + tri(6 * b + a, 6 * b + q)) = Hb[tri(a, q)];
+#pragma unroll
+      for (int k = 0; k < 6; k++) PTS(PT_P + 6 * b + k) = -gb[k];
+    }
+    // cube <-> cube contacts: read-modify-write on the LDS copy of the Hessian
+    for (int ci = 0; ci < nbb_max; ci++) {
+      if (ci < nbb) {
+        int base = PT_CON + 17 * ci;
+        double p[3] = {PTS(base), PTS(base + 1), PTS(base + 2)}, n[3] = {PTS(base + 3), PTS(base + 4), PTS(base + 5)}, t1[3], t2[3];
+        make_frame(n, t1, t2);
+        double J1[3][6], J2[3][6];
+        {
+          double R[9], r[3];
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + k);
+#pragma unroll
+          for (int k = 0; k < 3; k++) r[k] = p[k] - PTS(PT_POS + k);
+          box_row_r(R, r, n, J1[0]); box_row_r(R, r, t1, J1[1]); box_row_r(R, r, t2, J1[2]);
+#pragma unroll
+          for (int r3 = 0; r3 < 3; r3++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) J1[r3][k] = -J1[r3][k];
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 + k);
+#pragma unroll
+          for (int k = 0; k < 3; k++) r[k] = p[k] - PTS(PT_POS + 3 + k);
+          box_row_r(R, r, n, J2[0]); box_row_r(R, r, t1, J2[1]); box_row_r(R, r, t2, J2[2]);
+        }
+        double jar[3], f[3], Hc[9], Dn = PTS(base + 10);
+#pragma unroll
+        for (int r3 = 0; r3 < 3; r3++) {
+          double a = -PTS(base + 7 + r3);
+#pragma unroll
+          for (int k = 0; k < 6; k++) a += J1[r3][k] * PTS(PT_X + k) + J2[r3][k] * PTS(PT_X + 6 + k);
+          jar[r3] = a; PTS(base + 11 + r3) = a;
+        }
+        cone_eval(jar, Dn, Dn * impr, mu1, fric1, f, Hc);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          PTS(PT_P + k) += J1[0][k] * f[0] + J1[1][k] * f[1] + J1[2][k] * f[2];
+          PTS(PT_P + 6 + k) += J2[0][k] * f[0] + J2[1][k] * f[1] + J2[2][k] * f[2];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          double t1a[3], t2a[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            t1a[r] = Hc[3 * r] * J1[0][a] + Hc[3 * r + 1] * J1[1][a] + Hc[3 * r + 2] * J1[2][a];
+            t2a[r] = Hc[3 * r] * J2[0][a] + Hc[3 * r + 1] * J2[1][a] + Hc[3 * r + 2] * J2[2][a];
+          }
+#pragma unroll
+          for (int q = 0; q < 6; q++) {
+            if (q <= a) {
+              PTS(PT_H + tri(a, q)) += t1a[0] * J1[0][q] + t1a[1] * J1[1][q] + t1a[2] * J1[2][q];
+              PTS(PT_H + tri(6 + a, 6 + q)) += t2a[0] * J2[0][q] + t2a[1] * J2[1][q] + t2a[2] * J2[2][q];
+            }
+            PTS(PT_H + tri(6 + a, q)) += t2a[0] * J1[0][q] + t2a[1] * J1[1][q] + t2a[2] * J1[2][q];
           }
         }
       }
-      // direction p = -H^-1 grad (kept in grad[])
-      double gmax = 0;
-      for (int k = 0; k < PUSH_NV; k++) gmax = fmax(gmax, fabs(grad[k]));
-      if (!sky_chol(sc, env_bb, env_r1, env_r2)) { st.flags |= F_SOLVER_FAIL; break; }
-      double p[PUSH_NV];
-      for (int k = 0; k < PUSH_NV; k++) p[k] = -grad[k];
-      sky_solve(sc, env_bb, env_r1, env_r2, p);
-      // quadratic part along p
-      double pMp = 0, pMa = 0;
-      for (int b = 0; b < PUSH_NB; b++) for (int k = 0; k < 6; k++) {
-        double mm = k < 3 ? pc.box_mass : pc.box_inertia, pk = p[6 * b + k];
-        pMp += mm * pk * pk; pMa += mm * pk * (x[6 * b + k] - PGS(PG_A0 + 6 * b + k));
-      }
-      for (int i = 0; i < NDOF; i++) {
-        double s = 0, sa = 0;
-        for (int k = 0; k < NDOF; k++) { double m_ik = PGS(PG_M + (i >= k ? tri(i, k) : tri(k, i))); s += m_ik * p[PUSH_ARM0 + k]; sa += m_ik * (x[PUSH_ARM0 + k] - PGS(PG_A0 + PUSH_ARM0 + k)); }
-        pMp += p[PUSH_ARM0 + i] * s; pMa += p[PUSH_ARM0 + i] * sa;
-      }
-      for (int ci = 0; ci < ncon; ci++) {
-        int base = PG_CON + ci * PREC;
-        SRow rows[3];
-        contact_rows(sc, ci, Rb, ps.box, rows);
-        for (int r = 0; r < 3; r++) PGS(base + 23 + r) = srow_dot(rows[r], p);
-      }
-      // exact line search: root of phi'(alpha) by safeguarded Newton (phi is convex, C1)
-      double alpha = 1, lo = 0, hi = -1, best = 1;
-      for (int ls = 0; ls < 40; ls++) {
-        double d1 = pMa + alpha * pMp, d2 = pMp;
-        for (int k = 0; k < NDOF; k++) if (lim[k].sign != 0) {
-          double jp = lim[k].sign * p[PUSH_ARM0 + k], jar = lim[k].sign * x[PUSH_ARM0 + k] - lim[k].aref + alpha * jp;
-          if (jar < 0) { d1 += lim[k].D * jar * jp; d2 += lim[k].D * jp * jp; }
-        }
-        for (int ci = 0; ci < ncon; ci++) {
-          int base = PG_CON + ci * PREC;
-          double jp[3] = {PGS(base + 23), PGS(base + 24), PGS(base + 25)};
-          double jt[3] = {PGS(base + 20) + alpha * jp[0], PGS(base + 21) + alpha * jp[1], PGS(base + 22) + alpha * jp[2]}, ft[3], Hc[9];
-          double Dn = PGS(base + 18), mu = PGS(base + 19), fric = pc.ct_fric[(int)PGS(base + 13) == CK_SLAB ? 0 : 1];
-          cone_eval(jt, Dn, Dn * impr, mu, fric, ft, Hc);
-          for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r]; for (int q = 0; q < 3; q++) d2 += jp[r] * Hc[3 * r + q] * jp[q]; }
-        }
-        best = alpha;
-        if (fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
-        if (d1 < 0) lo = alpha; else hi = alpha;
-        double na = alpha - d1 / d2;
-        if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
-        if (hi < 0 && na <= lo) na = 2 * lo + 1;
-        if (na == alpha) break;
-        alpha = na;
-      }
-      double smax = 0, xmax = 0;
-      for (int k = 0; k < PUSH_NV; k++) { double dxk = best * p[k]; x[k] += dxk; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(x[k])); }
-      if (smax <= 1e-12 * (1 + xmax)) converged = true;
-      (void)gmax;
     }
-    if (!converged) st.flags |= F_SOLVER_FAIL;
-    for (int k = 0; k < PUSH_NV; k++) ps.warm[k] = x[k];
-    st.flags |= PF_WARM_VALID;
+    // ================= phase C: factorise the 12 x 12 cube system, directions
+    {
+      double H[78], dc[12], idc[12], pcv[12];
+#pragma unroll
+      for (int i = 0; i < 78; i++) H[i] = PTS(PT_H + i);
+#pragma unroll
+      for (int k = 0; k < 12; k++) pcv[k] = PTS(PT_P + k);
+      if (!ldl_n<12>(H, dc, idc)) return false;
+      ldl_solve_n<12>(H, idc, pcv);
+#pragma unroll
+      for (int k = 0; k < 12; k++) PTS(PT_P + k) = pcv[k];
+    }
+    {
+      double pa[NDOF];
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) pa[k] = -PTS(PT_ZG + k);
+      if (any_rod) {
+        if (rod) {
+          double jp3[3], hj[3];
+#pragma unroll
+          for (int r3 = 0; r3 < 3; r3++) { double a = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) a += PTS(PT_XR + 24 + 6 * r3 + k) * PTS(PT_P + 6 * rod_cube + k); jp3[r3] = a; }
+#pragma unroll
+          for (int a = 0; a < 3; a++) hj[a] = PTS(PT_XR + 15 + 3 * a) * jp3[0] + PTS(PT_XR + 16 + 3 * a) * jp3[1] + PTS(PT_XR + 17 + 3 * a) * jp3[2];
+#pragma unroll
+          for (int k = 0; k < NDOF; k++) pa[k] -= PTS(PT_Z + k) * hj[0] + PTS(PT_Z + 9 + k) * hj[1] + PTS(PT_Z + 18 + k) * hj[2];
+          // directional derivative of the rod rows
+          int base = PT_ROD;
+#pragma unroll
+          for (int r3 = 0; r3 < 3; r3++) {
+            double a = jp3[r3];
+#pragma unroll
+            for (int k = 0; k < NARM; k++) a += PTS(PT_JA + 7 * r3 + k) * pa[k];
+            PTS(base + 14 + r3) = a;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) PTS(PT_P + PUSH_ARM0 + k) = pa[k];
+    }
+    // ================= phase D: line search quantities
+    double pMp = 0, pMa = 0;
+    {
+      const double Mc[6] = {pc.box_mass, pc.box_mass, pc.box_mass, pc.box_inertia, pc.box_inertia, pc.box_inertia};
+#pragma unroll
+      for (int k = 0; k < 12; k++) { double pk = PTS(PT_P + k); pMp += Mc[k % 6] * pk * pk; pMa += Mc[k % 6] * pk * (PTS(PT_X + k) - PTS(PT_A0 + k)); }
+      double Mm[45], pa[NDOF], dx[NDOF], t1[NDOF], t2[NDOF];
+#pragma unroll
+      for (int i = 0; i < 45; i++) Mm[i] = PTS(PT_M + i);
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) { pa[k] = PTS(PT_P + PUSH_ARM0 + k); dx[k] = PTS(PT_X + PUSH_ARM0 + k) - PTS(PT_A0 + PUSH_ARM0 + k); }
+      symv9(Mm, pa, t1); symv9(Mm, dx, t2);
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) { pMp += pa[k] * t1[k]; pMa += pa[k] * t2[k]; }
+    }
+#pragma clang loop unroll(disable)
+    for (int b = 0; b < PUSH_NB; b++) {
+      double R[9], pos[3], pb[6];
+#pragma unroll
+      for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 * b + k);
+#pragma unroll
+      for (int k = 0; k < 3; k++) pos[k] = PTS(PT_POS + 3 * b + k);
+#pragma unroll
+      for (int k = 0; k < 6; k++) pb[k] = PTS(PT_P + 6 * b + k);
+      CubeFace face;
+      cube_face(pc, R, face);
+#pragma clang loop unroll(disable)
+      for (int i = 0; i < 8; i++) {
+        int base = PT_SLAB + 10 * (8 * b + i);
+        if (wave_any(PTS(base + 3) != 0)) {
+          double r[3], dist;
+          slot_geom(pc, face, pos, i, r, &dist);
+          double J[3][6]; slab_rows(R, r, J);
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++) { double a = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) a += J[rr][k] * pb[k]; PTS(base + 7 + rr) = a; }
+        }
+      }
+    }
+    for (int ci = 0; ci < nbb_max; ci++) {
+      if (ci < nbb) {
+        int base = PT_CON + 17 * ci;
+        double p[3] = {PTS(base), PTS(base + 1), PTS(base + 2)}, n[3] = {PTS(base + 3), PTS(base + 4), PTS(base + 5)}, t1[3], t2[3];
+        make_frame(n, t1, t2);
+        double jp3[3] = {0, 0, 0};
+        for (int b = 0; b < PUSH_NB; b++) {
+          double R[9], r[3], J[3][6];
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 * b + k);
+#pragma unroll
+          for (int k = 0; k < 3; k++) r[k] = p[k] - PTS(PT_POS + 3 * b + k);
+          box_row_r(R, r, n, J[0]); box_row_r(R, r, t1, J[1]); box_row_r(R, r, t2, J[2]);
+          double sg = b == 0 ? -1.0 : 1.0;
+#pragma unroll
+          for (int r3 = 0; r3 < 3; r3++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) jp3[r3] += sg * J[r3][k] * PTS(PT_P + 6 * b + k);
+        }
+        PTS(base + 14) = jp3[0]; PTS(base + 15) = jp3[1]; PTS(base + 16) = jp3[2];
+      }
+    }
+    // ================= phase E: exact line search
+    double alpha = 1, lo = 0, hi = -1, best = 1;
+    for (int ls = 0; ls < 40; ls++) {
+      D3IL_STAT(g_stats.ls_iters++);
+      double d1 = pMa + alpha * pMp, d2 = pMp;
+#pragma unroll
+      for (int k = NARM; k < NDOF; k++) {   // finger limit rows (arm joints are inside their limits on this path)
+        double sign = PTS(PT_LIM + 3 * k), D = PTS(PT_LIM + 3 * k + 1), aref = PTS(PT_LIM + 3 * k + 2);
+        double jp = sign * PTS(PT_P + PUSH_ARM0 + k), jar = sign * PTS(PT_X + PUSH_ARM0 + k) - aref + alpha * jp;
+        if (sign != 0 && jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
+      }
+#pragma clang loop unroll(disable)
+      for (int i = 0; i < 16; i++) {
+        int base = PT_SLAB + 10 * i;
+        double Dn = PTS(base + 3);
+        if (wave_any(Dn != 0)) {
+          double jp[3] = {PTS(base + 7), PTS(base + 8), PTS(base + 9)};
+          double jt[3] = {PTS(base + 4) + alpha * jp[0], PTS(base + 5) + alpha * jp[1], PTS(base + 6) + alpha * jp[2]}, ft[3], Hc[9];
+          cone_eval(jt, Dn, Dn * impr, mu0, fric0, ft, Hc);
+#pragma unroll
+          for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r];
+#pragma unroll
+            for (int q = 0; q < 3; q++) d2 += jp[r] * Hc[3 * r + q] * jp[q]; }
+        }
+      }
+      for (int ci = 0; ci < 9; ci++) {
+        if (ci == 8 ? !any_rod : ci >= nbb_max) continue;
+        if (ci == 8 ? rod : ci < nbb) {
+          int base = PT_CON + 17 * ci;
+          double Dn = PTS(base + 10);
+          double jp[3] = {PTS(base + 14), PTS(base + 15), PTS(base + 16)};
+          double jt[3] = {PTS(base + 11) + alpha * jp[0], PTS(base + 12) + alpha * jp[1], PTS(base + 13) + alpha * jp[2]}, ft[3], Hc[9];
+          cone_eval(jt, Dn, Dn * impr, mu1, fric1, ft, Hc);
+#pragma unroll
+          for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r];
+#pragma unroll
+            for (int q = 0; q < 3; q++) d2 += jp[r] * Hc[3 * r + q] * jp[q]; }
+        }
+      }
+      best = alpha;
+      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 / d2;
+      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+    double smax = 0, xmax = 0;
+    for (int k = 0; k < PUSH_NV; k++) {
+      double dxk = best * PTS(PT_P + k), xn = PTS(PT_X + k) + dxk;
+      PTS(PT_X + k) = xn; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(xn));
+    }
+    // Newton converges quadratically once the full step is accepted: a step below 1e-6 (relative) leaves an error of the
+    // order of its square, so the confirming iteration is skipped
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
   }
-  // ---- semi-implicit Euler.  Arm: (M + h B) qacc = M x (= qfrc_smooth + qfrc_constraint at the optimum), B on the fingers
-  {
-    double Md[45], rhs[NDOF];
-    for (int i = 0; i < 45; i++) Md[i] = PGS(PG_M + i);
-    for (int i = 0; i < NDOF; i++) {
-      double s = 0;
-      for (int k = 0; k < NDOF; k++) s += Md[i >= k ? tri(i, k) : tri(k, i)] * x[PUSH_ARM0 + k];
-      rhs[i] = s;
+  return converged;
+}
+
+// general-path collision: slab contacts from the specialised routine, cube <-> cube and rod <-> cube from the general
+// ones; writes the contact records; returns the contact count
+D3IL_NOINLINE inline int push_collect_contacts(const PushConsts& pc, const PushScratch& sc, const CubeSlab* cs, const double* rodc, const double* rodu,
+                                               double rod_r, double rod_h, bool near_bb, const bool* near_rod, unsigned* flags_out, int* has) {
+  int ncon = 0;
+  unsigned fl = 0;
+  has[0] = has[1] = has[2] = 0;
+  for (int b = 0; b < PUSH_NB; b++) for (int i = 0; i < 8; i++) {
+    if (!(cs[b].dist[i] < 0)) continue;
+    if (ncon >= PUSH_MAXCON) { fl |= PF_CON_OVERFLOW; break; }
+    int base = PG_CON + ncon * PREC;
+    for (int k = 0; k < 3; k++) { PGS(base + k) = cs[b].r[i][k] + PGS(PG_AUX_POS + 3 * b + k); PGS(base + 3 + k) = k == 2 ? 1.0 : 0.0; }
+    PGS(base + 12) = cs[b].dist[i]; PGS(base + 13) = CK_SLAB; PGS(base + 14) = b;
+    ncon++;
+  }
+  double p0[3], p1[3], R0[9], R1[9];
+  for (int k = 0; k < 3; k++) { p0[k] = PGS(PG_AUX_POS + k); p1[k] = PGS(PG_AUX_POS + 3 + k); }
+  for (int k = 0; k < 9; k++) { R0[k] = PGS(PG_AUX_R + k); R1[k] = PGS(PG_AUX_R + 9 + k); }
+  if (near_bb) {
+    double rec[8][7];
+    int n = box_box(p0, R0, pc.box_half, p1, R1, pc.box_half, 0.0, rec, 8);
+    for (int i = 0; i < n; i++) {
+      if (ncon >= PUSH_MAXCON) { fl |= PF_CON_OVERFLOW; break; }
+      int base = PG_CON + ncon * PREC;
+      for (int k = 0; k < 3; k++) { PGS(base + k) = rec[i][1 + k]; PGS(base + 3 + k) = rec[i][4 + k]; }
+      PGS(base + 12) = rec[i][0]; PGS(base + 13) = CK_BOXBOX; PGS(base + 14) = 0;
+      ncon++; has[0] += 1;
     }
-    Md[tri(7, 7)] += h * c.f_damping[0]; Md[tri(8, 8)] += h * c.f_damping[1];
-    double L[45], d[NDOF], id[NDOF];
-    if (!ldl9(Md, L, d, id)) st.flags |= F_SOLVER_FAIL;
-    ldl9_solve(L, id, rhs);
-    for (int k = 0; k < NDOF; k++) { st.v[k] += h * rhs[k]; st.q[k] += h * st.v[k]; }
   }
   for (int b = 0; b < PUSH_NB; b++) {
-    BoxState& bx = ps.box[b];
-    for (int k = 0; k < 6; k++) bx.vel[k] += h * x[6 * b + k];
-    for (int k = 0; k < 3; k++) bx.pos[k] += h * bx.vel[k];
-    double w[3] = {bx.vel[3], bx.vel[4], bx.vel[5]}, ang = sqrt(dot3(w, w)) * h;
-    if (ang >= 1e-15) {   // mju_quatIntegrate
-      double sa = sin(0.5 * ang), ca = cos(0.5 * ang), sc_ = h / ang;
-      double dq[4] = {ca, w[0] * sc_ * sa, w[1] * sc_ * sa, w[2] * sc_ * sa}, q[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]}, r[4];
-      r[0] = q[0] * dq[0] - q[1] * dq[1] - q[2] * dq[2] - q[3] * dq[3];
-      r[1] = q[0] * dq[1] + q[1] * dq[0] + q[2] * dq[3] - q[3] * dq[2];
-      r[2] = q[0] * dq[2] - q[1] * dq[3] + q[2] * dq[0] + q[3] * dq[1];
-      r[3] = q[0] * dq[3] + q[1] * dq[2] - q[2] * dq[1] + q[3] * dq[0];
-      double nn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
-      for (int k = 0; k < 4; k++) bx.quat[k] = r[k] / nn;
+    if (!near_rod[b]) continue;
+    double r1[7];
+    if (cyl_box(rodc, rodu, rod_r, rod_h, b ? p1 : p0, b ? R1 : R0, pc.box_half, 0.0, r1)) {
+      if (ncon >= PUSH_MAXCON) { fl |= PF_CON_OVERFLOW; continue; }
+      int base = PG_CON + ncon * PREC;
+      for (int k = 0; k < 3; k++) { PGS(base + k) = r1[1 + k]; PGS(base + 3 + k) = r1[4 + k]; }
+      PGS(base + 12) = r1[0]; PGS(base + 13) = CK_ROD; PGS(base + 14) = b;
+      ncon++; has[1 + b] = 1;
     }
   }
+  *flags_out = fl;
+  return ncon;
+}
+
+// ------------------------------------------------------------------------------------------------ the physics sub-step
+D3IL_HD void cube_integrate(BoxState& bx, const double* acc, double h) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) bx.vel[k] += h * acc[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) bx.pos[k] += h * bx.vel[k];
+  double w[3] = {bx.vel[3], bx.vel[4], bx.vel[5]}, ang = sqrt(dot3(w, w)) * h;
+  if (ang >= 1e-15) {   // mju_quatIntegrate
+    double sa = sin(0.5 * ang), ca = cos(0.5 * ang), sc_ = h / ang;
+    double dq[4] = {ca, w[0] * sc_ * sa, w[1] * sc_ * sa, w[2] * sc_ * sa}, q[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]}, r[4];
+    r[0] = q[0] * dq[0] - q[1] * dq[1] - q[2] * dq[2] - q[3] * dq[3];
+    r[1] = q[0] * dq[1] + q[1] * dq[0] + q[2] * dq[3] - q[3] * dq[2];
+    r[2] = q[0] * dq[2] - q[1] * dq[3] + q[2] * dq[0] + q[3] * dq[1];
+    r[3] = q[0] * dq[3] + q[1] * dq[2] - q[2] * dq[1] + q[3] * dq[0];
+    double nn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) bx.quat[k] = r[k] / nn;
+  }
+}
+
+template <class C>
+D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* tau, const double* ffing) {
+  EnvState& st = ps.arm;
+  D3IL_REFRESH(c0, c);
+  const double h = c.timestep;
+  // ---- arm forward pass (panda_step.h physics_substep): dynamics, smooth force, read-backs, factorisation of M
+  DynOut dyn;
+  dynamics(c0, st.q, st.v, dyn);
+  double fs[NDOF];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) fs[k] = clampd(tau[k] + st.bias[k], c.force_lo[k], c.force_hi[k]) - dyn.bias[k];
+#pragma unroll
+  for (int k = 0; k < NFING; k++) fs[NARM + k] = clampd(ffing[k], c.force_lo[NARM + k], c.force_hi[NARM + k]) - dyn.bias[NARM + k] - c.f_damping[k] * st.v[NARM + k];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
+  double rodc[3], rodu[3];
+  {
+    double t[3]; mulE(dyn.R7, c.tcp7, t);
+    st.tcp[0] = dyn.p7[0] + t[0]; st.tcp[1] = dyn.p7[1] + t[1]; st.tcp[2] = dyn.p7[2] + t[2];
+    mulE(dyn.R7, c.rod_c7, rodc); rodc[0] += dyn.p7[0]; rodc[1] += dyn.p7[1]; rodc[2] += dyn.p7[2];
+    mulE(dyn.R7, c.rod_u7, rodu);
+  }
+  double L[45], d[NDOF], id[NDOF];
+  if (!ldl9(dyn.M, L, d, id)) st.flags |= F_SOLVER_FAIL;
+  bool arm_rows = false;
+#pragma unroll
+  for (int k = 0; k < NARM; k++) arm_rows = arm_rows || (st.q[k] - c.jnt_range[k][0] < c.lim_margin[k]) || (c.jnt_range[k][1] - st.q[k] < c.lim_margin[k]);
+  // ---- cheap proximity tests decide whether anything can couple the cubes with each other or with the arm
+  const double rcirc = sqrt(pc.box_half[0] * pc.box_half[0] + pc.box_half[1] * pc.box_half[1] + pc.box_half[2] * pc.box_half[2]);
+  bool near_rod[PUSH_NB], near_bb;
+#pragma unroll
+  for (int b = 0; b < PUSH_NB; b++) {
+    if (fabs(ps.box[b].pos[0] - pc.slab_c[0][0]) > pc.slab_h[0][0] - 0.06 || fabs(ps.box[b].pos[1] - pc.slab_c[0][1]) > pc.slab_h[0][1] - 0.06) st.flags |= PF_OFF_TABLE;
+    double w[3] = {ps.box[b].pos[0] - rodc[0], ps.box[b].pos[1] - rodc[1], ps.box[b].pos[2] - rodc[2]};
+    double t = clampd(dot3(w, rodu), -c.rod_h, c.rod_h);
+    double e[3] = {w[0] - t * rodu[0], w[1] - t * rodu[1], w[2] - t * rodu[2]};
+    near_rod[b] = dot3(e, e) < (rcirc + c.rod_r) * (rcirc + c.rod_r);
+  }
+  {
+    double dd[3] = {ps.box[1].pos[0] - ps.box[0].pos[0], ps.box[1].pos[1] - ps.box[0].pos[1], ps.box[1].pos[2] - ps.box[0].pos[2]};
+    near_bb = dot3(dd, dd) < 4 * rcirc * rcirc;
+  }
+  double fc[NDOF];
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) fc[k] = 0;
+  const bool general = arm_rows || near_bb || near_rod[0] || near_rod[1];
+  bool solved = false;
+  if (wave_any(general)) {
+    if (general) {
+      // ---- general path: publish the inputs to the scratch area, collect contacts, solve if anything couples
+      unsigned cfl = 0; int has[3], ncon;
+      {
+        double Rb[PUSH_NB][9];
+        CubeSlab cs[PUSH_NB];
+#pragma unroll
+        for (int b = 0; b < PUSH_NB; b++) {
+          quat2mat(ps.box[b].quat, Rb[b]);
+          cube_slab_contacts(pc, ps.box[b].pos, Rb[b], cs[b]);
+#pragma unroll
+          for (int k = 0; k < 9; k++) PGS(PG_AUX_R + 9 * b + k) = Rb[b][k];
+#pragma unroll
+          for (int k = 0; k < 3; k++) PGS(PG_AUX_POS + 3 * b + k) = ps.box[b].pos[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) PGS(PG_AUX_VEL + 6 * b + k) = ps.box[b].vel[k];
+        }
+        ncon = push_collect_contacts(pc, sc, cs, rodc, rodu, c.rod_r, c.rod_h, near_bb, near_rod, &cfl, has);
+      }
+      st.flags |= cfl;
+      if (has[0] || has[1] || has[2] || arm_rows) {
+        solved = true;
+        const bool slow = arm_rows || (has[1] && has[2]);   // arm joint at a limit, or the rod on both cubes: memory-resident solver
+        double a0[NDOF];
+#pragma unroll
+        for (int k = 0; k < NDOF; k++) a0[k] = fs[k];
+        ldl9_solve(L, id, a0);
+        if (wave_any(!slow)) {
+          if (!slow) {
+            // ---- coupled path: fill the LDS table
+#pragma unroll
+            for (int b = 0; b < PUSH_NB; b++) {
+#pragma unroll
+              for (int k = 0; k < 9; k++) PTS(PT_R + 9 * b + k) = PGS(PG_AUX_R + 9 * b + k);
+#pragma unroll
+              for (int k = 0; k < 3; k++) PTS(PT_POS + 3 * b + k) = ps.box[b].pos[k];
+#pragma unroll
+              for (int k = 0; k < 6; k++) { PTS(PT_VEL + 6 * b + k) = ps.box[b].vel[k]; PTS(PT_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0; }
+            }
+#pragma unroll
+            for (int k = 0; k < NDOF; k++) { PTS(PT_VEL + PUSH_ARM0 + k) = st.v[k]; PTS(PT_A0 + PUSH_ARM0 + k) = a0[k]; }
+#pragma unroll
+            for (int i = 0; i < 45; i++) PTS(PT_M + i) = dyn.M[i];
+#pragma unroll
+            for (int k = 0; k < NDOF; k++) {
+              double sign = 0, D = 0, aref = 0;
+              if (k >= NARM) {   // arm joints are inside their limits on this path
+                double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k], dist = 0;
+                if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
+                else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
+                if (sign != 0) {
+                  double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
+                  D = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
+                  aref = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
+                }
+              }
+              PTS(PT_LIM + 3 * k) = sign; PTS(PT_LIM + 3 * k + 1) = D; PTS(PT_LIM + 3 * k + 2) = aref;
+            }
+            int nbb = 0, rod_cube = -1;
+            for (int ci = 0; ci < ncon; ci++) {
+              int base = PG_CON + ci * PREC, kind = (int)PGS(base + 13);
+              if (kind == CK_SLAB) continue;
+              int dst = kind == CK_BOXBOX ? PT_CON + 17 * nbb : PT_ROD;
+              for (int k = 0; k < 6; k++) PTS(dst + k) = PGS(base + k);
+              PTS(dst + 6) = PGS(base + 12);
+              if (kind == CK_BOXBOX) nbb++;
+              else {
+                rod_cube = (int)PGS(base + 14);
+                double R7[9], p7[3], ax[NARM][3], og[NARM][3];
+                world_chain(c0, dyn.sn, dyn.cs, R7, p7, ax, og);
+                double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)}, n[3] = {PGS(base + 3), PGS(base + 4), PGS(base + 5)}, t1[3], t2[3];
+                make_frame(n, t1, t2);
+#pragma unroll
+                for (int k = 0; k < NARM; k++) {
+                  double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
+                  cross3(ax[k], dd, col);
+                  PTS(PT_JA + k) = dot3(n, col); PTS(PT_JA + 7 + k) = dot3(t1, col); PTS(PT_JA + 14 + k) = dot3(t2, col);
+                }
+              }
+            }
+            if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PTS(PT_X + k) = PWS(k);
+            else for (int k = 0; k < PUSH_NV; k++) PTS(PT_X + k) = PTS(PT_A0 + k);
+            if (!coupled_newton(pc, sc, nbb, rod_cube, c.rod_invweight0)) st.flags |= F_SOLVER_FAIL;
+            for (int k = 0; k < PUSH_NV; k++) PWS(k) = PTS(PT_X + k);
+          }
+        }
+        if (slow) {
+#pragma unroll
+          for (int k = 0; k < NDOF; k++) PGS(PG_AUX_VEL + PUSH_ARM0 + k) = st.v[k];
+#pragma unroll
+          for (int i = 0; i < 45; i++) PGS(PG_M + i) = dyn.M[i];
+#pragma unroll
+          for (int k = 0; k < NDOF; k++) PGS(PG_A0 + PUSH_ARM0 + k) = a0[k];
+#pragma unroll
+          for (int b = 0; b < PUSH_NB; b++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) PGS(PG_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0;
+#pragma unroll
+          for (int k = 0; k < NDOF; k++) {   // limit rows of all nine joints
+            double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
+            double sign = 0, dist = 0, D = 0, aref = 0;
+            if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
+            else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
+            if (sign != 0) {
+              double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
+              D = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
+              aref = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
+            }
+            PGS(PG_AUX_LIM + 3 * k) = sign; PGS(PG_AUX_LIM + 3 * k + 1) = D; PGS(PG_AUX_LIM + 3 * k + 2) = aref;
+          }
+          PGS(PG_AUX_LIM + 27) = c.rod_invweight0;
+          if (has[1] || has[2]) {   // arm Jacobian rows of the rod contacts
+            double R7[9], p7[3], ax[NARM][3], og[NARM][3];
+            world_chain(c0, dyn.sn, dyn.cs, R7, p7, ax, og);
+            for (int ci = 0; ci < ncon; ci++) {
+              int base = PG_CON + ci * PREC;
+              if ((int)PGS(base + 13) != CK_ROD) continue;
+              int b = (int)PGS(base + 14);
+              double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)}, n[3] = {PGS(base + 3), PGS(base + 4), PGS(base + 5)}, t1[3], t2[3];
+              make_frame(n, t1, t2);
+#pragma unroll
+              for (int k = 0; k < NARM; k++) {
+                double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
+                cross3(ax[k], dd, col);
+                PGS(PG_JA + b * 21 + k) = dot3(n, col); PGS(PG_JA + b * 21 + 7 + k) = dot3(t1, col); PGS(PG_JA + b * 21 + 14 + k) = dot3(t2, col);
+              }
+            }
+          }
+          if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PGS(PG_X + k) = PWS(k);
+          else for (int k = 0; k < PUSH_NV; k++) PGS(PG_X + k) = PGS(PG_A0 + k);
+          if (!push_general_solve(pc, sc, ncon, has[0] != 0, has[1] != 0, has[2] != 0)) st.flags |= F_SOLVER_FAIL;
+          for (int k = 0; k < PUSH_NV; k++) PWS(k) = PGS(PG_X + k);
+        }
+        {   // constraint force on the arm from the optimality condition M (x - a0) = J' f
+          double xa[NDOF], Mx[NDOF];
+#pragma unroll
+          for (int k = 0; k < NDOF; k++) xa[k] = PWS(PUSH_ARM0 + k);
+          symv9(dyn.M, xa, Mx);
+#pragma unroll
+          for (int k = 0; k < NDOF; k++) fc[k] = Mx[k] - fs[k];
+        }
+      }
+    }
+  }
+  if (!solved) {
+    // ---- decoupled path, arm: finger-limit rows by the exact active-set solution (panda_step.h)
+    double fsign[NFING], fD[NFING], faref[NFING];
+#pragma unroll
+    for (int k = 0; k < NFING; k++) {
+      int j = NARM + k;
+      double dlo = st.q[j] - c.jnt_range[j][0], dhi = c.jnt_range[j][1] - st.q[j];
+      double sign = 0, dist = 0;
+      if (dlo < c.lim_margin[j]) { sign = 1; dist = dlo; }
+      else if (dhi < c.lim_margin[j]) { sign = -1; dist = dhi; }
+      fsign[k] = sign; fD[k] = 0; faref[k] = 0;
+      if (sign != 0) {
+        double imp = impedance(c.lim_solimp[j], dist - c.lim_margin[j]);
+        fD[k] = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[j]);
+        faref[k] = -c.lim_B[j] * (sign * st.v[j]) - c.lim_K[j] * imp * (dist - c.lim_margin[j]);
+      }
+    }
+    if (fsign[0] != 0 || fsign[1] != 0) {
+      double l87 = L[tri(8, 7)];
+      double W00 = id[7] + l87 * l87 * id[8], W01 = -l87 * id[8], W11 = id[8];
+      double a0[NDOF];
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) a0[k] = fs[k];
+      ldl9_solve(L, id, a0);
+      double s0 = fsign[0], s1 = fsign[1];
+      double r0 = s0 * a0[7] - faref[0], r1 = s1 * a0[8] - faref[1];
+      double G00 = W00 * s0 * s0, G01 = W01 * s0 * s1, G11 = W11 * s1 * s1;
+      double f0 = 0, f1 = 0;
+      bool have0 = s0 != 0, have1 = s1 != 0, done = false;
+      if (have0 && have1) {
+        double a = 1 + fD[0] * G00, b = fD[0] * G01, cc = fD[1] * G01, dd = 1 + fD[1] * G11;
+        double det = a * dd - b * cc, y0 = -fD[0] * r0, y1 = -fD[1] * r1;
+        double g0 = (dd * y0 - b * y1) / det, g1 = (a * y1 - cc * y0) / det;
+        if (g0 > 0 && g1 > 0) { f0 = g0; f1 = g1; done = true; }
+      }
+      if (!done && have0) {
+        double g0 = -fD[0] * r0 / (1 + fD[0] * G00);
+        if (g0 > 0 && (!have1 || r1 + G01 * g0 >= 0)) { f0 = g0; f1 = 0; done = true; }
+      }
+      if (!done && have1) {
+        double g1 = -fD[1] * r1 / (1 + fD[1] * G11);
+        if (g1 > 0 && (!have0 || r0 + G01 * g1 >= 0)) { f1 = g1; f0 = 0; done = true; }
+      }
+      fc[7] = s0 * f0; fc[8] = s1 * f1;
+    }
+  }
+  // ---- arm: semi-implicit Euler, (M + h B) qacc = qfrc_smooth + qfrc_constraint with B on the fingers (last two pivots)
+  {
+    double hb0 = h * c.f_damping[0], hb1 = h * c.f_damping[1];
+    double l87 = L[tri(8, 7)];
+    double S11 = d[8] + l87 * l87 * d[7];
+    double d7n = d[7] + hb0, i7 = rcpd(d7n);
+    double l87n = l87 * d[7] * i7;
+    double d8n = S11 + hb1 - l87n * l87n * d7n;
+    d[7] = d7n; d[8] = d8n; id[7] = i7; id[8] = rcpd(d8n); L[tri(8, 7)] = l87n;
+    double qacc[NDOF];
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) qacc[k] = fs[k] + fc[k];
+    ldl9_solve(L, id, qacc);
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) { st.v[k] += h * qacc[k]; st.q[k] += h * st.v[k]; }
+    if (!solved)
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) PWS(PUSH_ARM0 + k) = qacc[k];
+  }
+  // ---- cubes: decoupled 6-dof solves (arm state is dead by now), then integration
+#pragma unroll
+  for (int b = 0; b < PUSH_NB; b++) {
+    double xb[6];
+    if (!solved) {
+      double Rb[9], a0b[6] = {c.gravity[0], c.gravity[1], c.gravity[2], 0, 0, 0}, vb[6];
+      CubeSlab cs;
+      quat2mat(ps.box[b].quat, Rb);
+      cube_slab_contacts(pc, ps.box[b].pos, Rb, cs);
+#pragma unroll
+      for (int k = 0; k < 6; k++) { xb[k] = (st.flags & PF_WARM_VALID) ? PWS(6 * b + k) : a0b[k]; vb[k] = ps.box[b].vel[k]; }
+      if (!cube_newton(pc, Rb, vb, cs, a0b, xb)) st.flags |= F_SOLVER_FAIL;
+#pragma unroll
+      for (int k = 0; k < 6; k++) PWS(6 * b + k) = xb[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; k++) xb[k] = PWS(6 * b + k);
+    }
+    cube_integrate(ps.box[b], xb, h);
+  }
+  st.flags |= PF_WARM_VALID;
 }
 
 // ------------------------------------------------------------------------------------------------ task logic (pushing.py)
@@ -740,7 +1697,7 @@ D3IL_HD void push_env_reset(const C& c, const PushConsts& pc, PushState& ps, con
     for (int k = 0; k < 4; k++) ps.box[b].quat[k] = ctx[7 * b + 3 + k];
     for (int k = 0; k < 6; k++) ps.box[b].vel[k] = 0;
   }
-  for (int k = 0; k < PUSH_NV; k++) ps.warm[k] = 0;
+  for (int k = 0; k < PUSH_NV; k++) PWS(k) = 0;
   {
     DynOut dyn;
     dynamics(c, st.q, st.v, dyn);

@@ -11,11 +11,16 @@
 #include <string>
 #include "../../include/d3il_rollout.h"
 #include "panda_step.h"
+#include "push_step.h"
 #include "gen/avoiding_consts.inc"
 
 namespace d3il {
-
 constexpr int WAVE = 64;
+}
+#include "push_kernels.h"
+
+namespace d3il {
+
 // The constant block is read through the constant address space so that every access is a scalar (SGPR) load.
 typedef const __attribute__((address_space(4))) PandaConsts CPanda4;
 __device__ __forceinline__ CPanda4* to_const_as(const PandaConsts* p) { return (CPanda4*)(unsigned long long)p; }
@@ -285,6 +290,9 @@ struct d3il_handle_s {
   int task_id, n, stride, device;
   PandaConsts hc;          // host copy
   PandaConsts* dc;         // device copy
+  PushConsts pc;           // Pushing: cubes, table slabs, contact parameter sets, targets
+  double* d_scratch;       // Pushing: per-lane solver scratch [PG_SIZE][stride]
+  int state_rows;          // f64 state fields per environment (42 Avoiding, 89 Pushing)
   double* d_init_qpos;
   bool started;
   d3il_buffers buf;
@@ -312,7 +320,8 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (blob_len != sizeof(d3il_model_blob)) return fail(D3IL_EBLOB, "d3il_create: blob size mismatch");
   if (n_envs <= 0) return fail(D3IL_EINVAL, "d3il_create: n_envs must be positive");
   const d3il_model_blob& m = *(const d3il_model_blob*)model_blob;
-  if (task_id != D3IL_TASK_AVOIDING || m.task_id != D3IL_TASK_AVOIDING) return fail(D3IL_EUNSUPPORTED, "d3il_create: only the Avoiding task is implemented in this build");
+  if (task_id != m.task_id) return fail(D3IL_EINVAL, "d3il_create: task_id does not match the model blob");
+  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING) return fail(D3IL_EUNSUPPORTED, "d3il_create: only the Avoiding and Pushing tasks are implemented in this build");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(D3IL_ENODEVICE, "d3il_create: no HIP device available (there is no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(D3IL_ENODEVICE, "d3il_create: device_id out of range");
@@ -323,9 +332,16 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   int rc = build_panda_consts(m, h->hc, &err);
   if (rc) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   finish_invweights(h->hc);
-  {  // the kernels are specialised at build time to the task model (csrc/gen/avoiding_consts.inc): the runtime blob
-     // must describe the same model.  n_substeps / max_steps stay run-time parameters.
+  if (task_id == D3IL_TASK_PUSHING && build_push_consts(m, h->pc, &err)) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  {  // the kernels are specialised at build time to the robot model (csrc/gen/avoiding_consts.inc): the runtime blob
+     // must describe the same arm, controller and (Avoiding) obstacles.  n_substeps / max_steps stay run-time parameters.
     PandaConsts a = h->hc, b = kAvoidingConsts;
+    if (task_id == D3IL_TASK_PUSHING) {   // no obstacles, other task constants: only the arm / controller part is compared
+      a.n_obst = b.n_obst;
+      std::memcpy(a.ob_c, b.ob_c, sizeof a.ob_c); std::memcpy(a.ob_u, b.ob_u, sizeof a.ob_u); std::memcpy(a.ob_r, b.ob_r, sizeof a.ob_r); std::memcpy(a.ob_h, b.ob_h, sizeof a.ob_h);
+      std::memcpy(a.ct_K, b.ct_K, sizeof a.ct_K); std::memcpy(a.ct_B, b.ct_B, sizeof a.ct_B); std::memcpy(a.ct_solimp, b.ct_solimp, sizeof a.ct_solimp);
+      std::memcpy(a.ct_margin, b.ct_margin, sizeof a.ct_margin); std::memcpy(a.ct_fric, b.ct_fric, sizeof a.ct_fric); std::memcpy(a.task_f, b.task_f, sizeof a.task_f);
+    }
     bool same = a.n_obst == b.n_obst && a.ik_iters == b.ik_iters;
     a.n_obst = b.n_obst = 0; a.ik_iters = b.ik_iters = 0; a.n_substeps = b.n_substeps = 0; a.max_steps = b.max_steps = 0; a.pad_i = b.pad_i = 0; a.pad_j = b.pad_j = 0;
     const double* pa = (const double*)&a; const double* pb = (const double*)&b;
@@ -337,24 +353,34 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
                                                            "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
   h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
-  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr;
+  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr;
+  const bool pushing = task_id == D3IL_TASK_PUSHING;
+  h->state_rows = pushing ? PUSH_STATE_F64 : D3IL_STATE_F64;
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
-  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = 2; b.action_dim = 7;
+  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : 2; b.action_dim = 7; b.state_rows = h->state_rows; b.n_info_f64 = pushing ? 2 : 0;
   HIPCHK(hipMalloc(&h->dc, sizeof(PandaConsts)));
   HIPCHK(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
-  HIPCHK(hipMalloc(&b.obs, S * 2 * sizeof(float)));
+  HIPCHK(hipMalloc(&b.obs, S * b.obs_dim * sizeof(float)));
   HIPCHK(hipMalloc(&b.done, S)); HIPCHK(hipMalloc(&b.success, S));
   HIPCHK(hipMalloc(&b.mode, S * sizeof(uint16_t)));
-  HIPCHK(hipMalloc(&b.state, S * D3IL_STATE_F64 * sizeof(double)));
+  HIPCHK(hipMalloc(&b.state, S * h->state_rows * sizeof(double)));
   HIPCHK(hipMalloc(&b.flags, S * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&b.step_count, S * sizeof(int32_t)));
   HIPCHK(hipMalloc(&b.policy_des, S * 3 * sizeof(double)));
-  HIPCHK(hipMemset(b.obs, 0, S * 2 * sizeof(float))); HIPCHK(hipMemset(b.done, 0, S)); HIPCHK(hipMemset(b.success, 0, S));
-  HIPCHK(hipMemset(b.mode, 0, S * sizeof(uint16_t))); HIPCHK(hipMemset(b.state, 0, S * D3IL_STATE_F64 * sizeof(double)));
+  HIPCHK(hipMemset(b.obs, 0, S * b.obs_dim * sizeof(float))); HIPCHK(hipMemset(b.done, 0, S)); HIPCHK(hipMemset(b.success, 0, S));
+  HIPCHK(hipMemset(b.mode, 0, S * sizeof(uint16_t))); HIPCHK(hipMemset(b.state, 0, S * h->state_rows * sizeof(double)));
   HIPCHK(hipMemset(b.flags, 0, S * sizeof(uint32_t))); HIPCHK(hipMemset(b.step_count, 0, S * sizeof(int32_t)));
   HIPCHK(hipMemset(b.policy_des, 0, S * 3 * sizeof(double)));
+  if (pushing) {
+    HIPCHK(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_scratch, S * PG_SIZE * sizeof(double))); HIPCHK(hipMemset(h->d_scratch, 0, S * PG_SIZE * sizeof(double)));
+    // the physics wave keeps the coupled solver's tables in LDS: 137.5 KiB + the set-point exchange, above the 64 KiB default cap
+    HIPCHK(hipFuncSetAttribute((const void*)k_pushing_step_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
+    HIPCHK(hipFuncSetAttribute((const void*)k_pushing_step_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
+    HIPCHK(hipFuncSetAttribute((const void*)k_pushing_reset, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_H));
+  }
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
   *out = h;
   return D3IL_OK;
@@ -363,7 +389,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
 int d3il_destroy(d3il_handle h) {
   if (!h) return fail(D3IL_EINVAL, "d3il_destroy: null handle");
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des};
+  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des, h->buf.info_f64, h->d_scratch};
   for (void* p : ptrs) (void)hipFree(p);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
   delete h;
@@ -379,12 +405,19 @@ int d3il_start(d3il_handle h, const double* init_qpos7) {
   return D3IL_OK;
 }
 
-int d3il_reset(d3il_handle h, const uint8_t* env_mask, const float* contexts, void* stream) {
+int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, void* stream) {
   if (!h) return fail(D3IL_EINVAL, "d3il_reset: null handle");
   if (!h->started) return fail(D3IL_ESTATE, "d3il_reset: d3il_start() has not been called (env.start() before env.reset())");
-  if (contexts) return fail(D3IL_EUNSUPPORTED, "d3il_reset: the Avoiding task takes no contexts");
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
+  if (h->task_id == D3IL_TASK_PUSHING) {
+    if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Pushing task needs contexts (device f64 [n_envs][14])");
+    hipLaunchKernelGGL(k_pushing_reset, dim3((h->n + PUSH_LANES - 1) / PUSH_LANES), dim3(WAVE), PUSH_LDS_H, (hipStream_t)stream, h->pc, h->d_init_qpos, env_mask, contexts, b.state,
+                       b.flags, b.step_count, b.obs, b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride);
+    HIPCHK(hipGetLastError());
+    return D3IL_OK;
+  }
+  if (contexts) return fail(D3IL_EUNSUPPORTED, "d3il_reset: the Avoiding task takes no contexts");
   hipLaunchKernelGGL(k_avoiding_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->dc, h->d_init_qpos, env_mask, b.state, b.flags,
                      b.step_count, b.obs, b.done, b.success, b.mode, h->n, h->stride);
   HIPCHK(hipGetLastError());
@@ -397,6 +430,19 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
   hipStream_t s = (hipStream_t)stream;
+  if (h->task_id == D3IL_TASK_PUSHING) {
+    int nwgp = (h->n + PUSH_LANES - 1) / PUSH_LANES;
+    if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+    if (h->fast)
+      hipLaunchKernelGGL((k_pushing_step_split<true>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, h->pc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                         b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    else
+      hipLaunchKernelGGL((k_pushing_step_split<false>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, h->pc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                         b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    HIPCHK(hipGetLastError());
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    return D3IL_OK;
+  }
   // Workgroup placement: a workgroup is one wave; the dispatcher packs several of them onto one CU (and SIMD) before
   // moving on, which halves the per-wave issue rate when only a few hundred waves exist.  Requesting LDS that is not
   // otherwise needed caps the workgroups per CU so that the waves spread over all 256 CUs / 1024 SIMDs.
@@ -434,7 +480,7 @@ int d3il_get_state(d3il_handle h, double* state, uint32_t* flags, int32_t* steps
   if (!h) return fail(D3IL_EINVAL, "d3il_get_state: null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
-  if (state) HIPCHK(hipMemcpy2D(state, (size_t)h->n * 8, h->buf.state, (size_t)h->stride * 8, (size_t)h->n * 8, D3IL_STATE_F64, hipMemcpyDeviceToHost));
+  if (state) HIPCHK(hipMemcpy2D(state, (size_t)h->n * 8, h->buf.state, (size_t)h->stride * 8, (size_t)h->n * 8, h->state_rows, hipMemcpyDeviceToHost));
   if (flags) HIPCHK(hipMemcpy(flags, h->buf.flags, (size_t)h->n * 4, hipMemcpyDeviceToHost));
   if (steps) HIPCHK(hipMemcpy(steps, h->buf.step_count, (size_t)h->n * 4, hipMemcpyDeviceToHost));
   return D3IL_OK;
@@ -443,7 +489,7 @@ int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, co
   if (!h) return fail(D3IL_EINVAL, "d3il_set_state: null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
-  if (state) HIPCHK(hipMemcpy2D(h->buf.state, (size_t)h->stride * 8, state, (size_t)h->n * 8, (size_t)h->n * 8, D3IL_STATE_F64, hipMemcpyHostToDevice));
+  if (state) HIPCHK(hipMemcpy2D(h->buf.state, (size_t)h->stride * 8, state, (size_t)h->n * 8, (size_t)h->n * 8, h->state_rows, hipMemcpyHostToDevice));
   if (flags) HIPCHK(hipMemcpy(h->buf.flags, flags, (size_t)h->n * 4, hipMemcpyHostToDevice));
   if (steps) HIPCHK(hipMemcpy(h->buf.step_count, steps, (size_t)h->n * 4, hipMemcpyHostToDevice));
   return D3IL_OK;
@@ -467,6 +513,7 @@ int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32
 int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream) {
   if (!h || !episode_counts_device) return fail(D3IL_EINVAL, "d3il_auto_reset: null argument");
   if (!h->started) return fail(D3IL_ESTATE, "d3il_auto_reset: d3il_start() has not been called");
+  if (h->task_id != D3IL_TASK_AVOIDING) return fail(D3IL_EUNSUPPORTED, "d3il_auto_reset: Avoiding only (Pushing episodes are reset with their contexts through d3il_reset)");
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
   hipLaunchKernelGGL(k_avoiding_auto_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->dc, h->d_init_qpos, b.state, b.flags, b.step_count,
@@ -477,6 +524,7 @@ int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream)
 
 int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream) {
   if (!h || !out_counts_device) return fail(D3IL_EINVAL, "d3il_count_metrics: null argument");
+  if (h->task_id != D3IL_TASK_AVOIDING) return fail(D3IL_EUNSUPPORTED, "d3il_count_metrics: Avoiding only");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemsetAsync(out_counts_device, 0, (2 + 512) * sizeof(int64_t), (hipStream_t)stream));
   hipLaunchKernelGGL(k_count_metrics, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->buf.done, h->buf.flags, (long long*)out_counts_device, h->n);

@@ -36,17 +36,21 @@ class ObstacleAvoidanceVecEnv:
     action_dim = 7
     obs_dim = 2
 
+    default_max_steps = 250
+
     def __init__(self, n_envs: int, device: int | str | torch.device = 0, render: bool = False,
-                 n_substeps: int = 35, max_steps_per_episode: int = 250):
+                 n_substeps: int = 35, max_steps_per_episode: int | None = None):
+        if max_steps_per_episode is None:
+            max_steps_per_episode = self.default_max_steps
         if render:
             raise NotImplementedError("rendering is outside the batched rollout path")
         dev = torch.device(device if not isinstance(device, int) else "cuda:%d" % device)
         if dev.type != "cuda":
-            raise capi.D3ilError("ObstacleAvoidanceVecEnv needs a HIP device (got %s); there is no CPU fallback" % dev)
+            raise capi.D3ilError("%s needs a HIP device (got %s); there is no CPU fallback" % (type(self).__name__, dev))
         self.device = dev
         self.n_envs = int(n_envs)
         self.L = capi.load()
-        self.js = blob_mod.load_json("avoiding")
+        self.js = blob_mod.load_json(self.task)
         self.js["task_const"]["n_substeps"] = int(n_substeps)
         self.js["task_const"]["max_steps"] = int(max_steps_per_episode)
         self.blob = blob_mod.pack(self.js)
@@ -58,11 +62,13 @@ class ObstacleAvoidanceVecEnv:
         capi.check(self.L.d3il_get_buffers(self.h, C.byref(b)))
         self.stride = b.stride
         n, s = self.n_envs, b.stride
-        self.obs = _view(b.obs, (n, 2), "<f4", dev, self)
+        self.obs = _view(b.obs, (n, b.obs_dim), "<f4", dev, self)
         self.done = _view(b.done, (n,), "|u1", dev, self)
         self.success = _view(b.success, (n,), "|u1", dev, self)
         self.mode = _view(b.mode, (n,), "<i2", dev, self)            # 9-bit code, fits int16
-        self.state = _view(b.state, (capi.STATE_F64, s), "<f8", dev, self)
+        self.state_rows = b.state_rows
+        self.state = _view(b.state, (b.state_rows, s), "<f8", dev, self)
+        self.info_f64 = _view(b.info_f64, (b.n_info_f64, s), "<f8", dev, self) if b.n_info_f64 else None
         self.flags = _view(b.flags, (s,), "<i4", dev, self)
         self.step_count = _view(b.step_count, (s,), "<i4", dev, self)
         self.policy_des = _view(b.policy_des, (3, s), "<f8", dev, self)
@@ -121,7 +127,7 @@ class ObstacleAvoidanceVecEnv:
 
     # ------------------------------------------------------------------ extras
     def get_state(self):
-        st = np.zeros((capi.STATE_F64, self.n_envs))
+        st = np.zeros((self.state_rows, self.n_envs))
         fl = np.zeros(self.n_envs, dtype=np.uint32)
         sc = np.zeros(self.n_envs, dtype=np.int32)
         capi.check(self.L.d3il_get_state(self.h, st.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
@@ -129,7 +135,7 @@ class ObstacleAvoidanceVecEnv:
 
     def set_state(self, st, fl, sc):
         st = np.ascontiguousarray(st, np.float64); fl = np.ascontiguousarray(fl, np.uint32); sc = np.ascontiguousarray(sc, np.int32)
-        assert st.shape == (capi.STATE_F64, self.n_envs)
+        assert st.shape == (self.state_rows, self.n_envs)
         capi.check(self.L.d3il_set_state(self.h, st.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
 
     def policy_begin(self, mask: torch.Tensor | None = None):

@@ -44,26 +44,37 @@ enum {
   D3IL_STATE_TCP = 25,    /* 3: TCP xpos of the last forward pass (what MjRobot.receiveState reads) */
   D3IL_STATE_IK_Q = 28,   /* 7: CartPosQuatImpedenceController.old_q */
   D3IL_STATE_IK_QD = 35,  /* 7: CartPosQuatImpedenceController.old_des_joint_vel */
-  D3IL_STATE_F64 = 42
+  D3IL_STATE_F64 = 42,
+  /* Pushing appends: per cube pos[3] quat[4] vel[6] (qpos/qvel of its free joint: linear velocity in world axes, angular
+   * velocity in body axes), then the constraint solver's warm start qacc[21] (cube1, cube2, arm) */
+  D3IL_PUSH_STATE_BOX = 42, D3IL_PUSH_STATE_WARM = 68, D3IL_PUSH_STATE_F64 = 89
 };
 /* bits of the per-environment u32 flag word */
 enum {
   D3IL_FLAG_MODE_MASK = 0x1FF,       /* 9 sticky mode bits, avoiding.py:173-202 */
   D3IL_FLAG_L1 = 1 << 9, D3IL_FLAG_L2 = 1 << 10, D3IL_FLAG_L3 = 1 << 11,
   D3IL_FLAG_TERMINATED = 1 << 12, D3IL_FLAG_SUCCESS = 1 << 13, D3IL_FLAG_ROD_CONTACT = 1 << 14,
-  D3IL_FLAG_IK_VALID = 1 << 15, D3IL_FLAG_SOLVER_FAIL = 1 << 16, D3IL_FLAG_MULTI_CONTACT = 1 << 17
+  D3IL_FLAG_IK_VALID = 1 << 15, D3IL_FLAG_SOLVER_FAIL = 1 << 16, D3IL_FLAG_MULTI_CONTACT = 1 << 17,
+  /* Pushing reuses TERMINATED / SUCCESS / IK_VALID / SOLVER_FAIL and replaces the low bits: */
+  D3IL_PFLAG_FIRST_MASK = 0x7,       /* first_visit + 1 (pushing.py:341-377) */
+  D3IL_PFLAG_MODE_MASK = 0x38,       /* (mode + 1) << 3 */
+  D3IL_PFLAG_WARM_VALID = 1 << 6,
+  D3IL_PFLAG_CON_OVERFLOW = 1 << 18, /* more contacts than the solver holds (24) in some sub-step */
+  D3IL_PFLAG_OFF_TABLE = 1 << 19     /* a cube left the modelled part of the table */
 };
 
 typedef struct d3il_buffers {
   int32_t n_envs, stride, obs_dim, action_dim;
-  float* obs;            /* [n_envs][obs_dim] f32, what get_observation() returns (avoiding.py:117-119) */
+  float* obs;            /* [n_envs][obs_dim] f32, what get_observation() returns (avoiding.py:117-119, pushing.py:255-280) */
   uint8_t* done;         /* [n_envs] result of is_finished() of the last step (gym_env_wrapper.py:124-137) */
   uint8_t* success;      /* [n_envs] info[1] (avoiding.py:171) */
-  uint16_t* mode;        /* [n_envs] 9-bit mode encoding, bit i = mode_encoding[i] (info[0]) */
-  double* state;         /* [D3IL_STATE_F64][stride] */
+  uint16_t* mode;        /* [n_envs] Avoiding: 9-bit mode encoding, bit i = mode_encoding[i] (info[0]); Pushing: info['mode'] as int16 (-1..3) */
+  double* state;         /* [state_rows][stride] */
   uint32_t* flags;       /* [stride] */
   int32_t* step_count;   /* [stride] env_step_counter */
   double* policy_des;    /* [3][stride] random-policy harness state: desired x, y and fixed z */
+  double* info_f64;      /* [n_info_f64][stride] extra f64 step outputs; Pushing: info['mean_distance'], reward (pushing.py:335-407) */
+  int32_t n_info_f64, state_rows;   /* state_rows: f64 state fields per environment (42 Avoiding, 89 Pushing) */
 } d3il_buffers;
 
 /* Replaces: env construction + scene.start() (avoiding.py:52-92, core/Scene.py:95-108,
@@ -76,8 +87,9 @@ int d3il_destroy(d3il_handle h);
 int d3il_start(d3il_handle h, const double* init_qpos7);
 
 /* Replaces env.reset() (avoiding.py:248-262).  env_mask: device u8[n_envs] (non-zero = reset that env) or
- * NULL for all.  contexts: unused for Avoiding (NULL). */
-int d3il_reset(d3il_handle h, const uint8_t* env_mask, const float* contexts, void* stream);
+ * NULL for all.  contexts: NULL for Avoiding; Pushing (pushing.py:461-483 with random=False): device f64 [n_envs][14] =
+ * per env 2 x (x, y, z, qw, qx, qy, qz) written into the cubes' qpos as BlockContextManager.set_context does (z = 0). */
+int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, void* stream);
 
 /* Replaces env.step(action) (avoiding.py:168-171 over gym_env_wrapper.py:45-100): n_substeps fused physics
  * sub-steps.  actions: device f64[n_envs][7] = desired TCP (x, y, z, qw, qx, qy, qz), the array the harness
@@ -87,7 +99,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream);
 int d3il_get_buffers(d3il_handle h, d3il_buffers* out);
 
 /* Golden replay / checkpointing: copies the SoA state + flags + step counters to/from host memory
- * (state: f64[D3IL_STATE_F64][n_envs] packed with stride n_envs; flags u32[n_envs]; steps i32[n_envs]). */
+ * (state: f64[state_rows][n_envs] packed with stride n_envs; flags u32[n_envs]; steps i32[n_envs]). */
 int d3il_get_state(d3il_handle h, double* state, uint32_t* flags, int32_t* steps);
 int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, const int32_t* steps);
 

@@ -250,3 +250,7 @@ class Oracle:
         f = np.zeros(8, dtype=np.int32)
         self.L.orc_push_get_flags(self.h, _p(f))
         return s, f
+
+    def push_set_state(self, s68, step=0, terminated=False, first_visit=-1, ik_valid=True):
+        s68 = np.ascontiguousarray(s68, float)
+        self.L.orc_push_set_state(self.h, _p(s68), int(step), int(terminated), int(first_visit), int(ik_valid))
