@@ -56,8 +56,127 @@ def cpu_baseline(blob, init_qpos, budget_s=12.0):
                       "env-steps/s/core (BASELINE.md section 2)" % (n, dt, os.cpu_count() or 0)}
 
 
+# Pushing: cube state adds 26 f64 (+ 2 flag/counter words as above); action 56 B; obs 32 B; done/success/mode 4 B; info 16 B
+PUSH_ALG_BYTES_PER_ENV_STEP = 2 * (68 * 8 + 4 + 4) + 56 + 32 + 4 + 16
+
+
+def cpu_baseline_pushing(blob, init_qpos, contexts, budget_s=12.0):
+    """Scalar C oracle on one host core, one environment, same stand-in policy (run on the CPU), bounded sample."""
+    import numpy as np
+    import torch
+    from d3il_amd.agents import RandomResidualMLPPolicy
+    from oracle.oracle import Oracle
+    o = Oracle(blob)
+    o.env_start(init_qpos)
+    pol = RandomResidualMLPPolicy(device="cpu")
+    n, ep = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        obs = o.push_reset(contexts[ep % len(contexts)])
+        s, _ = o.push_state()
+        des, z = s[25:27].copy(), s[27]
+        for t in range(400):
+            x = torch.as_tensor(np.concatenate([des, obs.astype(np.float64)])[None], dtype=torch.float64)
+            des = des + pol.predict_batch(x)[0].numpy().astype(np.float64)
+            obs, _, done, _ = o.push_step(np.array([des[0], des[1], z, 0, 1, 0, 0]))
+            n += 1
+            if done or time.perf_counter() - t0 >= budget_s:
+                break
+        ep += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "1 env, ResidualMLP stand-in policy on the CPU, %d env steps (35 sub-steps each) in %.1f s on one host core of %d; "
+                      "scalar C oracle (oracle/d3il_oracle.c)" % (n, dt, os.cpu_count() or 0)}
+
+
+def bench_pushing(args):
+    """BASELINE config 3: Pushing, 4096 envs per GPU, the 60 reference test contexts tiled, ResidualMLP 10 -> 128 x 6 -> 2 (Mish)
+    stand-in policy with fixed random weights, 400-step episode cap; a step = policy forward + d3il_step."""
+    import numpy as np
+    import torch
+    from d3il_amd import distributed as D
+    from d3il_amd.agents import RandomResidualMLPPolicy
+    from d3il_amd.envs.pushing import BlockPushVecEnv
+    from d3il_amd.simulation.pushing_sim import load_test_contexts
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    rank, world = D.init_from_env("nccl")
+    dev = torch.device("cuda:%d" % local_rank)
+    n = args.envs
+    env = BlockPushVecEnv(n, device=dev)
+    q, iters, err = env.start()
+    ctx60 = load_test_contexts()
+    ctx = torch.as_tensor(ctx60[(rank * n + np.arange(n)) % len(ctx60)], dtype=torch.float64, device=dev)
+    pol = RandomResidualMLPPolicy(device=dev)
+    quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
+    state = {}
+
+    def begin_episode():
+        env.reset(context=ctx)
+        rs = env.robot_state()
+        state["des"], state["z"] = rs[:, :2].clone(), rs[:, 2:3].clone()
+
+    def one_step(t):
+        if t % env.max_steps_per_episode == 0:
+            begin_episode()
+        obs10 = torch.cat((state["des"], env.obs.to(torch.float64)), dim=1)
+        state["des"] = state["des"] + pol.predict_batch(obs10).to(torch.float64)
+        env.step(torch.cat((state["des"], state["z"], quat), dim=1).contiguous())
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        one_step(t)
+    env.set_timing(True)
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        one_step(args.warmup + t)
+        if t % 16 == 15:
+            kernel_ms.append(env.last_step_ms())
+    barrier()
+    dt = time.perf_counter() - t0
+    env.set_timing(False)
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t_max.item())
+    st, fl, sc = env.get_state()
+    bad = int(((fl >> 16) & 1).sum()), int(((fl >> 18) & 1).sum()), int(((fl >> 19) & 1).sum())
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        achieved = PUSH_ALG_BYTES_PER_ENV_STEP * n / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/s", "value": world * n * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Pushing task, %d envs per GPU, the 60 reference test contexts tiled, ResidualMLP 10->128x6->2 (Mish) "
+                                   "stand-in policy with fixed random weights (torch, f32), 35 fused physics sub-steps per env step, "
+                                   "400-step episodes" % n,
+                       "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world,
+                       "finite": bool(np.isfinite(st[:68]).all()), "flagged_envs_solver_overflow_offtable": bad},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_pushing_step_split<true>", "kernel_ms": k_ms,
+                         "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
+                         "algorithmic_bytes_per_launch": PUSH_ALG_BYTES_PER_ENV_STEP * n,
+                         "note": "FP64 latency bound like the Avoiding step (DESIGN.md section 4); first correct version of this kernel"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline_pushing(env.blob, q, ctx60)
+        print(json.dumps(line))
+    env.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing"], help="avoiding = the headline configuration (BASELINE configs[1])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
@@ -77,6 +196,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a HIP device (there is no CPU fallback for the rollout path)", file=sys.stderr)
         sys.exit(2)
+    if args.task == "pushing":
+        return bench_pushing(args)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     rank, world = D.init_from_env("nccl")

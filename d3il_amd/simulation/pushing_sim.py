@@ -1,0 +1,108 @@
+"""Batched counterpart of ``Pushing_Sim`` (simulation/pushing_sim.py:27-178).
+
+The reference evaluates ``n_contexts`` test contexts x ``n_trajectories_per_context`` rollouts sequentially in
+``n_cores`` processes; here every rollout is one lane of the GPU environment batch (context-major order, rollout
+``c * n_trajectories + i``).  Kept from the reference: the rollout loop (obs := desired xy || env obs, action := policy
+delta + desired xy, frozen z and quaternion, pushing_sim.py:61-79), what is recorded (``info`` of the step that returned
+``done``, :81-83) and the metric tail (:140-167, ``metrics.pushing_metrics``).
+
+Multi-GPU: one process per GPU, contiguous shards of the rollout index range; the integer tables (mode counts per
+context, success count) and the f64 distance sum are combined with one all-reduce each.
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import numpy as np
+import torch
+
+from ..distributed import shard_range, world_info
+from ..envs.pushing import BlockPushVecEnv, contexts_from_reference
+from .base_sim import BaseSim
+from .metrics import pushing_metrics
+
+log = logging.getLogger(__name__)
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "pushing_test_contexts.npy")
+
+
+def load_test_contexts(path: str | None = None) -> np.ndarray:
+    """The reference's evaluation contexts as f64 [60, 14].  ``path`` may point at the reference's own
+    ``environments/dataset/data/pushing/test_contexts.pkl``; by default the copy shipped as data with this package is used."""
+    if path is None:
+        return np.load(_DATA)
+    return contexts_from_reference(np.load(path, allow_pickle=True))
+
+
+class Pushing_Sim(BaseSim):
+    def __init__(self, seed: int, device: str, render: bool, n_cores: int = 1, n_contexts: int = 30,
+                 n_trajectories_per_context: int = 1, max_steps_per_episode: int = 400, contexts: np.ndarray | None = None):
+        super().__init__(seed, device, render, n_cores)
+        self.n_contexts = n_contexts
+        self.n_trajectories_per_context = n_trajectories_per_context
+        self.max_steps_per_episode = max_steps_per_episode
+        self.contexts = load_test_contexts() if contexts is None else np.asarray(contexts, dtype=np.float64)
+        self.last_rollout = None
+
+    def _predict(self, agent, obs10: torch.Tensor) -> torch.Tensor:
+        if hasattr(agent, "predict_batch"):
+            return agent.predict_batch(obs10).to(device=obs10.device, dtype=torch.float64).reshape(obs10.shape[0], 2)
+        rows = obs10.detach().cpu().numpy()
+        acts = np.stack([np.asarray(agent.predict(r)).reshape(-1)[:2] for r in rows])
+        return torch.as_tensor(acts, dtype=torch.float64, device=obs10.device)
+
+    def test_agent(self, agent):
+        log.info("Starting trained model evaluation")
+        rank, world = world_info()
+        total = self.n_contexts * self.n_trajectories_per_context
+        lo, hi = shard_range(total, rank, world)
+        n = hi - lo
+        dev = torch.device(self.device)
+        ctx_of = torch.arange(lo, hi, device=dev) // self.n_trajectories_per_context          # context index of each rollout
+        env = BlockPushVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
+        env.start()
+        if hasattr(agent, "reset"):
+            agent.reset()
+        obs = env.reset(random=False, context=self.contexts[ctx_of.cpu().numpy()])
+        pred_action = env.robot_state().clone()                        # pushing_sim.py:69-70
+        fixed_z = pred_action[:, 2:3].clone()
+        des_xy = pred_action[:, :2].clone()
+        quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
+        finished = torch.zeros(n, dtype=torch.bool, device=dev)
+        mode = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        success = torch.zeros(n, dtype=torch.bool, device=dev)
+        mean_distance = torch.zeros(n, dtype=torch.float64, device=dev)
+        for t in range(self.max_steps_per_episode):
+            obs10 = torch.cat((des_xy, obs.to(torch.float64)), dim=1)   # np.concatenate((pred_action[:2], obs)), pushing_sim.py:75
+            delta = self._predict(agent, obs10)
+            des_new = delta + obs10[:, :2]                              # pushing_sim.py:78
+            des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
+            action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
+            obs, _, done, info = env.step(action)
+            newly = ~finished & done.bool()
+            mode = torch.where(newly, info["mode"].to(torch.int64), mode)
+            success = torch.where(newly, info["success"].bool(), success)
+            mean_distance = torch.where(newly, info["mean_distance"], mean_distance)
+            finished |= done.bool()
+            if t % 16 == 15 and bool(finished.all()):
+                break
+        # integer tables: mode counts of the successful rollouts per context, number of successes; f64 distance sum
+        counts = torch.zeros(self.n_contexts * 4 + 1, dtype=torch.int64, device=dev)
+        ok = success & (mode >= 0)
+        counts[:-1] = torch.bincount((ctx_of * 4 + mode.clamp_min(0))[ok], minlength=self.n_contexts * 4)
+        counts[-1] = success.sum()
+        dist_sum = mean_distance.sum().reshape(1)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(counts)
+            dist.all_reduce(dist_sum)
+        c = counts.cpu().numpy()
+        success_rate, entropy, mode_probs = pushing_metrics(c[:-1].reshape(self.n_contexts, 4), int(c[-1]), total, self.n_trajectories_per_context)
+        self.last_rollout = dict(mode=mode, success=success, mean_distance=mean_distance, counts=c, shard=(lo, hi),
+                                 success_rate=success_rate, entropy=entropy, mode_probs=mode_probs,
+                                 mean_distance_all=float(dist_sum.item()) / total, flags=env.flags[:n].clone())
+        log.info("Successrate %s entropy %s mean distance %s", success_rate, entropy, float(dist_sum.item()) / total)
+        env.close()
+        shape = (-1, self.n_trajectories_per_context)
+        return success.to(torch.float32).reshape(shape), mode.to(torch.float32).reshape(shape), mean_distance.to(torch.float32).reshape(shape)
