@@ -12,7 +12,6 @@
 
 namespace d3il {
 
-constexpr int PUSH_LANES = 24;                                   // environments per workgroup
 constexpr int PUSH_LDS_H = PT_SIZE * PUSH_LANES * 8;             // coupled-solver table
 constexpr int PUSH_LDS_X = 2 * 2 * NARM * PUSH_LANES * 8;        // set-point exchange (double buffered)
 constexpr int PUSH_LDS_STEP = PUSH_LDS_H + PUSH_LDS_X;
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(PushConsts pc, 
   } else {
     PushState ps;
     float o[PUSH_OBS]; unsigned char dn = 0; double reward = 0, mean_distance = 0;
-    PushScratch sc{tbl + lane, PUSH_LANES, scratch + (live ? e : 0), stride, state + (size_t)PUSH_STATE_WARM * stride + (live ? e : 0), stride};
+    PushScratch sc{(push_lds_double*)(tbl + lane), (push_glb_double*)(scratch + (live ? e : 0)), stride, (push_glb_double*)(state + (size_t)PUSH_STATE_WARM * stride + (live ? e : 0)), stride};
     if (live) {
       push_load(state, flags, steps, stride, e, ps, false);
       push_step_begin(pc, ps, o, &reward, &dn, max_steps);
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(WAVE) void k_pushing_reset(PushConsts pc, const dou
 #pragma unroll
   for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
   for (int k = 0; k < 14; k++) ctx[k] = contexts[(size_t)e * 14 + k];
-  PushScratch sc{smem + lane, PUSH_LANES, scratch + e, stride, state + (size_t)PUSH_STATE_WARM * stride + e, stride};
+  PushScratch sc{(push_lds_double*)(smem + lane), (push_glb_double*)(scratch + e), stride, (push_glb_double*)(state + (size_t)PUSH_STATE_WARM * stride + e), stride};
   float o[PUSH_OBS];
   ps.arm.flags = 0; ps.arm.step = 0;
   push_env_reset(kAvoidingConsts, pc, ps, sc, iq, ctx, o);

@@ -20,6 +20,16 @@
 #pragma once
 #include "panda_step.h"
 
+#if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define PUSH_TIC unsigned long long t_tic_ = wall_clock64()
+#define PUSH_TOC(slot) do { unsigned long long t_now_ = wall_clock64(); \
+    if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && blockIdx.x < 4096) \
+      atomicAdd(&d3il::g_dev_wave[blockIdx.x][slot], t_now_ - t_tic_); t_tic_ = t_now_; } while (0)
+#else
+#define PUSH_TIC ((void)0)
+#define PUSH_TOC(slot) ((void)0)
+#endif
+
 namespace d3il {
 
 constexpr int PUSH_NB = 2;              // free cubes
@@ -28,6 +38,7 @@ constexpr int PUSH_ARM0 = 12;
 constexpr int PUSH_MAXCON = 24;
 constexpr int PUSH_NH = PUSH_NV * (PUSH_NV + 1) / 2;   // 231
 constexpr int PUSH_MAXIT = 40;
+constexpr double PUSH_GRAD_TOL = 1e-10;   // gradient (generalised force) below which an iterate is accepted without a further Newton step
 
 // f64 state fields per environment in the SoA state buffer: the 42 arm fields of Avoiding (D3IL_STATE_*), then per cube
 // pos[3] quat[4] vel[6] (linear world, angular body axes = MuJoCo free-joint qvel), then the solver warm start qacc[21]
@@ -61,11 +72,23 @@ struct PushState {
   BoxState box[PUSH_NB];
 };
 
-// per-lane views of the two scratch areas: h = Hessian (LDS on the device), g = everything else (HBM)
+// per-lane views of the scratch areas: h = coupled-solver table (LDS on the device), g = memory-resident solver (HBM), w =
+// warm start.  On the device the pointers carry their address space so that accesses compile to ds_* / global_*
+// instructions instead of flat ones, and the LDS lane stride is a compile-time constant.
+constexpr int PUSH_LANES = 24;          // environments per workgroup (push_kernels.h)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) double push_lds_double;
+typedef __attribute__((address_space(1))) double push_glb_double;
+#define PUSH_HS PUSH_LANES
+#else
+typedef double push_lds_double;
+typedef double push_glb_double;
+#define PUSH_HS 1
+#endif
 struct PushScratch {
-  double* h; int hs;
-  double* g; int gs;
-  double* w; int ws;     // warm start qacc[21] of the constraint solver: rows PUSH_STATE_WARM.. of the state buffer
+  push_lds_double* h;
+  push_glb_double* g; int gs;
+  push_glb_double* w; int ws;     // warm start qacc[21] of the constraint solver: rows PUSH_STATE_WARM.. of the state buffer
 };
 // layout of the g area (doubles per lane)
 constexpr int PG_M = 0;                                 // arm mass matrix, packed lower 9x9
@@ -81,7 +104,7 @@ constexpr int PG_SIZE = PG_H + PUSH_NH;
 
 #define PGS(i) sc.g[(long)(i) * sc.gs]
 #define PHS(i) PGS(PG_H + (i))
-#define PTS(i) sc.h[(long)(i) * sc.hs]
+#define PTS(i) sc.h[(i) * PUSH_HS]
 #define PWS(i) sc.w[(long)(i) * sc.ws]
 
 enum { CK_SLAB = 0, CK_BOXBOX = 1, CK_ROD = 2 };
@@ -254,9 +277,21 @@ D3IL_HD void box_row_r(const double* R, const double* r, const double* f, double
 
 // elliptic cone (condim 3, friction mu_geom on both tangents): force and Hessian block at row residuals jar.
 // Returns the cost.  Zones: top (free), bottom (quadratic), middle.
+D3IL_HD double rsqrtd(double x) {   // 1 / sqrt(x), x > 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
 D3IL_HD double cone_eval(const double* jar, double Dn, double Dt, double mu, double fric, double* force, double* Hc /* 3x3 */) {
   double U0 = jar[0] * mu, U1 = jar[1] * fric, U2 = jar[2] * fric;
-  double N = U0, T = sqrt(U1 * U1 + U2 * U2);
+  double T2 = U1 * U1 + U2 * U2;
+  double iT = T2 > 0 ? rsqrtd(T2) : 0.0;
+  double N = U0, T = T2 * iT;
 #pragma unroll
   for (int i = 0; i < 9; i++) Hc[i] = 0;
   if (N >= mu * T || (T <= 0 && N >= 0)) { force[0] = force[1] = force[2] = 0; return 0; }
@@ -265,8 +300,8 @@ D3IL_HD double cone_eval(const double* jar, double Dn, double Dt, double mu, dou
     Hc[0] = Dn; Hc[4] = Dt; Hc[8] = Dt;
     return 0.5 * (Dn * jar[0] * jar[0] + Dt * jar[1] * jar[1] + Dt * jar[2] * jar[2]);
   }
-  double Dm = Dn / fmax(1e-15, mu * mu * (1 + mu * mu)), NmT = N - mu * T;
-  double iT = 1 / T, iT3 = iT * iT * iT;
+  double Dm = Dn * rcpd(fmax(1e-15, mu * mu * (1 + mu * mu))), NmT = N - mu * T;
+  double iT3 = iT * iT * iT;
   double g[3] = {mu, -mu * fric * U1 * iT, -mu * fric * U2 * iT}, U[3] = {0, U1, U2};
 #pragma unroll
   for (int j = 0; j < 3; j++) force[j] = -Dm * NmT * g[j];
@@ -411,6 +446,12 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, con
         }
       }
     }
+    {   // MuJoCo's Newton stops on a scaled gradient below `tolerance` (1e-10); here: absolute, in N and N m
+      double gm = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) gm = fmax(gm, fabs(g[k]));
+      if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
+    }
     double L[21], d[6], id[6], p[6], ng[6]; int nneg;
 #pragma unroll
     for (int i = 0; i < 21; i++) L[i] = 0;
@@ -432,6 +473,9 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, con
           for (int k = 0; k < 6; k++) a += J[r][k] * p[k]; jp[i][r] = a; }
       }
     }
+    double gTp = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) gTp += g[k] * p[k];
     double alpha = 1, lo = 0, hi = -1, best = 1;
     for (int ls = 0; ls < 40; ls++) {
       D3IL_STAT(g_stats.ik_calls++);
@@ -450,9 +494,11 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, con
         }
       }
       best = alpha;
+      // full Newton step: accepted on the curvature condition phi'(1) <= 0.1 |phi'(0)| (still descending, or just past the minimum)
+      if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
       if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
-      double na = alpha - d1 / d2;
+      double na = alpha - d1 * rcpd(d2);
       if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
       if (hi < 0 && na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
@@ -688,7 +734,7 @@ D3IL_NOINLINE inline bool push_general_solve(const PushConsts& pc, const PushScr
       best = alpha;
       if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
-      double na = alpha - d1 / d2;
+      double na = alpha - d1 * rcpd(d2);
       if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
       if (hi < 0 && na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
@@ -719,6 +765,7 @@ constexpr int PT_X = 0, PT_P = 21, PT_A0 = 42, PT_M = 63, PT_LIM = 108, PT_R = 1
 constexpr int PT_SLAB = 237;            // 16 slots x (aref[3], Dn, jar[3], jp[3])
 constexpr int PT_CON = PT_SLAB + 160;   // 8 cube-cube + 1 rod: pos[3] n[3] dist aref[3] Dn jar[3] jp[3]
 constexpr int PT_ROD = PT_CON + 8 * 17;
+constexpr int PT_G = PT_VEL;                // gradient of the current iterate (the velocities are only needed by the set-up pass)
 constexpr int PT_H = PT_CON + 9 * 17;      // 12 x 12 cube Hessian, packed lower (78)
 constexpr int PT_XR = PT_H + 78;           // rod-contact hand-over between the phases (42)
 constexpr int PT_SIZE = PT_XR + 42;        // 670
@@ -783,6 +830,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(nbb_max, o); nbb_max = t > nbb_max ? t : nbb_max; }
   nbb_max = nbb_max > 8 ? 8 : (nbb_max < nbb ? nbb : nbb_max);   // lanes outside the branch contribute stale registers
 #endif
+  PUSH_TIC;
   // ---- per-contact reference acceleration and regularisation
 #pragma clang loop unroll(disable)
   for (int b = 0; b < PUSH_NB; b++) {
@@ -847,9 +895,11 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
     PTS(base + 7) = ar[0]; PTS(base + 8) = ar[1]; PTS(base + 9) = ar[2]; PTS(base + 10) = Dn;
   }
   bool converged = false;
+  PUSH_TOC(0);
   D3IL_STAT(g_stats.contact_calls++);
   for (int it = 0; it < PUSH_MAXIT && !converged; it++) {
     D3IL_STAT(g_stats.newton_iters++);
+    double gmax_arm = 0;
     // ================= phase A: arm gradient, H_aa, elimination quantities -> PT_ZG, PT_Z, PT_XR
     // PT_XR: W[9] (Hc - K) | hcAz[3] | frod[3] | HcR[9] | JbR[18] (cube rows of the rod contact, negated)
     {
@@ -933,6 +983,12 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
 #pragma unroll
           for (int k = 0; k < 6; k++) PTS(PT_XR + 24 + 6 * r + k) = JbR[r][k];
       }
+      {
+        double gm = 0;
+#pragma unroll
+        for (int k = 0; k < NDOF; k++) { gm = fmax(gm, fabs(ga[k])); PTS(PT_G + PUSH_ARM0 + k) = ga[k]; }
+        gmax_arm = gm;
+      }
       double da[NDOF], ida[NDOF];
       if (!ldl_n<NDOF>(Haa, da, ida)) return false;
       double z[NDOF];
@@ -973,6 +1029,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
         for (int a = 0; a < 3; a++) PTS(PT_XR + 9 + a) = HcR[3 * a] * Az[0] + HcR[3 * a + 1] * Az[1] + HcR[3 * a + 2] * Az[2];
       }
     }
+    PUSH_TOC(1);
     // ================= phase B: cube gradients and diagonal Hessian blocks (registers) -> PT_H, PT_P (right-hand side)
     for (int i = 0; i < 36; i++) PTS(PT_H + tri(6 + i / 6, i % 6)) = 0;      // off-diagonal 6 x 6 block
 #pragma clang loop unroll(disable)
@@ -1010,6 +1067,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
           acc_block(Hb, 0, 0, J, J, Hc, true);
         }
       }
+      bool rod_here = false;
       if (any_rod) {
         if (rod_cube == b) {   // rod contact seen from the cube: gradient, reduced Hessian J' W J, reduced right-hand side J' Hc (A z)
           double JbR[3][6], W[9], hf[3];
@@ -1020,11 +1078,22 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
 #pragma unroll
           for (int i = 0; i < 9; i++) W[i] = PTS(PT_XR + i);
 #pragma unroll
-          for (int i = 0; i < 3; i++) hf[i] = PTS(PT_XR + 9 + i) + PTS(PT_XR + 12 + i);
+          for (int i = 0; i < 3; i++) hf[i] = PTS(PT_XR + 12 + i);
 #pragma unroll
-          for (int k = 0; k < 6; k++) gb[k] -= JbR[0][k] * hf[0] + JbR[1][k] * hf[1] + JbR[2][k] * hf[2];
+          for (int k = 0; k < 6; k++) gb[k] -= JbR[0][k] * hf[0] + JbR[1][k] * hf[1] + JbR[2][k] * hf[2];      // gradient
+#pragma unroll
+          for (int k = 0; k < 6; k++) PTS(PT_G + 6 * b + k) = gb[k];
+#pragma unroll
+          for (int i = 0; i < 3; i++) hf[i] = PTS(PT_XR + 9 + i);
+#pragma unroll
+          for (int k = 0; k < 6; k++) gb[k] -= JbR[0][k] * hf[0] + JbR[1][k] * hf[1] + JbR[2][k] * hf[2];      // reduced right-hand side
           acc_block(Hb, 0, 0, JbR, JbR, W, true);
+          rod_here = true;
         }
+      }
+      if (!rod_here) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) PTS(PT_G + 6 * b + k) = gb[k];
       }
 #pragma unroll
       for (int a = 0; a < 6; a++)
@@ -1068,8 +1137,9 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
         cone_eval(jar, Dn, Dn * impr, mu1, fric1, f, Hc);
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-          PTS(PT_P + k) += J1[0][k] * f[0] + J1[1][k] * f[1] + J1[2][k] * f[2];
-          PTS(PT_P + 6 + k) += J2[0][k] * f[0] + J2[1][k] * f[1] + J2[2][k] * f[2];
+          double c1 = J1[0][k] * f[0] + J1[1][k] * f[1] + J1[2][k] * f[2], c2 = J2[0][k] * f[0] + J2[1][k] * f[1] + J2[2][k] * f[2];
+          PTS(PT_P + k) += c1; PTS(PT_P + 6 + k) += c2;
+          PTS(PT_G + k) -= c1; PTS(PT_G + 6 + k) -= c2;
         }
 #pragma unroll
         for (int a = 0; a < 6; a++) {
@@ -1089,6 +1159,12 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
           }
         }
       }
+    }
+    PUSH_TOC(2);
+    {   // gradient at round-off / tolerance level: accept the iterate (MuJoCo's scaled-gradient stop)
+      double gm = gmax_arm;
+      for (int k = 0; k < 12; k++) gm = fmax(gm, fabs(PTS(PT_P + k)));
+      if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
     }
     // ================= phase C: factorise the 12 x 12 cube system, directions
     {
@@ -1131,8 +1207,10 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
 #pragma unroll
       for (int k = 0; k < NDOF; k++) PTS(PT_P + PUSH_ARM0 + k) = pa[k];
     }
+    PUSH_TOC(3);
     // ================= phase D: line search quantities
-    double pMp = 0, pMa = 0;
+    double pMp = 0, pMa = 0, gTp = 0;
+    for (int k = 0; k < PUSH_NV; k++) gTp += PTS(PT_G + k) * PTS(PT_P + k);
     {
       const double Mc[6] = {pc.box_mass, pc.box_mass, pc.box_mass, pc.box_inertia, pc.box_inertia, pc.box_inertia};
 #pragma unroll
@@ -1193,6 +1271,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
         PTS(base + 14) = jp3[0]; PTS(base + 15) = jp3[1]; PTS(base + 16) = jp3[2];
       }
     }
+    PUSH_TOC(4);
     // ================= phase E: exact line search
     double alpha = 1, lo = 0, hi = -1, best = 1;
     for (int ls = 0; ls < 40; ls++) {
@@ -1233,14 +1312,17 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
         }
       }
       best = alpha;
+      // full Newton step: accepted on the curvature condition phi'(1) <= 0.1 |phi'(0)| (still descending, or just past the minimum)
+      if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
       if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
-      double na = alpha - d1 / d2;
+      double na = alpha - d1 * rcpd(d2);
       if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
       if (hi < 0 && na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
       alpha = na;
     }
+    PUSH_TOC(5);
     double smax = 0, xmax = 0;
     for (int k = 0; k < PUSH_NV; k++) {
       double dxk = best * PTS(PT_P + k), xn = PTS(PT_X + k) + dxk;
@@ -1322,6 +1404,7 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
   EnvState& st = ps.arm;
   D3IL_REFRESH(c0, c);
   const double h = c.timestep;
+  PUSH_TIC;
   // ---- arm forward pass (panda_step.h physics_substep): dynamics, smooth force, read-backs, factorisation of M
   DynOut dyn;
   dynamics(c0, st.q, st.v, dyn);
@@ -1358,12 +1441,32 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
   {
     double dd[3] = {ps.box[1].pos[0] - ps.box[0].pos[0], ps.box[1].pos[1] - ps.box[0].pos[1], ps.box[1].pos[2] - ps.box[0].pos[2]};
     near_bb = dot3(dd, dd) < 4 * rcirc * rcirc;
+    if (wave_any(near_bb)) {
+      // inside the circumscribed spheres: the six face axes of the separating-axis test (the first part of box_box) decide
+      // most cases without the general routine; a positive separation on any of them means no contact (margin 0)
+      double R0[9], R1[9];
+      quat2mat(ps.box[0].quat, R0); quat2mat(ps.box[1].quat, R1);
+      bool sep = false;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        double a0[3] = {R0[i], R0[3 + i], R0[6 + i]}, a1[3] = {R1[i], R1[3 + i], R1[6 + i]};
+        double e0 = 0, e1 = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          double b1[3] = {R1[j], R1[3 + j], R1[6 + j]}, b0[3] = {R0[j], R0[3 + j], R0[6 + j]};
+          e0 += pc.box_half[j] * fabs(dot3(a0, b1)); e1 += pc.box_half[j] * fabs(dot3(a1, b0));
+        }
+        sep = sep || fabs(dot3(dd, a0)) - (pc.box_half[i] + e0) > 0 || fabs(dot3(dd, a1)) - (pc.box_half[i] + e1) > 0;
+      }
+      near_bb = near_bb && !sep;
+    }
   }
   double fc[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; k++) fc[k] = 0;
   const bool general = arm_rows || near_bb || near_rod[0] || near_rod[1];
   bool solved = false;
+  PUSH_TOC(6);
   if (wave_any(general)) {
     if (general) {
       // ---- general path: publish the inputs to the scratch area, collect contacts, solve if anything couples
@@ -1509,6 +1612,7 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
       }
     }
   }
+  PUSH_TOC(7);
   if (!solved) {
     // ---- decoupled path, arm: finger-limit rows by the exact active-set solution (panda_step.h)
     double fsign[NFING], fD[NFING], faref[NFING];
@@ -1574,6 +1678,7 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
 #pragma unroll
       for (int k = 0; k < NDOF; k++) PWS(PUSH_ARM0 + k) = qacc[k];
   }
+  PUSH_TOC(8);
   // ---- cubes: decoupled 6-dof solves (arm state is dead by now), then integration
 #pragma unroll
   for (int b = 0; b < PUSH_NB; b++) {
@@ -1595,6 +1700,7 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
     cube_integrate(ps.box[b], xb, h);
   }
   st.flags |= PF_WARM_VALID;
+  PUSH_TOC(9);
 }
 
 // ------------------------------------------------------------------------------------------------ task logic (pushing.py)

@@ -109,19 +109,19 @@ static void push_pack(const PushState& ps, double* s, int* f) {
 int hc_push_state_size() { return PUSH_STATE_F64; }
 void hc_push_reset(void* h, const double* init_qpos, const double* ctx, double* s, int* f, float* obs) {
   PushHost* p = (PushHost*)h; PushState ps; std::memset(&ps, 0, sizeof ps);
-  PushScratch sc{p->h, 1, p->g, 1, p->w, 1};
+  PushScratch sc{p->h, p->g, 1, p->w, 1};
   push_env_reset(p->c, p->pc, ps, sc, init_qpos, ctx, obs); push_pack(ps, s, f); std::memcpy(s + PUSH_STATE_WARM, p->w, sizeof p->w);
 }
 void hc_push_step(void* h, double* s, int* f, const double* action, float* obs, double* reward, unsigned char* done, double* mean_distance, int fast) {
   PushHost* p = (PushHost*)h; PushState ps; push_unpack(s, f, ps); std::memcpy(p->w, s + PUSH_STATE_WARM, sizeof p->w);
-  PushScratch sc{p->h, 1, p->g, 1, p->w, 1};
+  PushScratch sc{p->h, p->g, 1, p->w, 1};
   if (fast) push_env_step<true>(p->c, p->pc, ps, sc, action, obs, reward, done, mean_distance, p->c.n_substeps, p->c.max_steps);
   else push_env_step<false>(p->c, p->pc, ps, sc, action, obs, reward, done, mean_distance, p->c.n_substeps, p->c.max_steps);
   push_pack(ps, s, f); std::memcpy(s + PUSH_STATE_WARM, p->w, sizeof p->w);
 }
 void hc_push_substep(void* h, double* s, int* f, const double* tau, const double* ffing, int* ncon_out) {
   PushHost* p = (PushHost*)h; PushState ps; push_unpack(s, f, ps); std::memcpy(p->w, s + PUSH_STATE_WARM, sizeof p->w);
-  PushScratch sc{p->h, 1, p->g, 1, p->w, 1};
+  PushScratch sc{p->h, p->g, 1, p->w, 1};
   push_physics_substep(p->c, p->pc, ps, sc, tau, ffing); push_pack(ps, s, f);
   (void)ncon_out;
 }
