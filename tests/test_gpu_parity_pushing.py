@@ -206,3 +206,42 @@ def test_ragged_sizes_masks_and_errors(ctx60, init_qpos):
         with pytest.raises(capi.D3ilError):
             env.auto_reset(torch.zeros(2, dtype=torch.int64, device=env.device))
         env.close()
+
+
+def test_rare_solver_paths_one_step(ctx60, init_qpos, pushing_blob):
+    """Arm joint beyond its limit / rod squeezed between both cubes (memory-resident solver) and rod + cube-cube contact
+    (coupled solver with every coupling): states written with set_state, one step against the oracle."""
+    from oracle.oracle import Oracle
+    from tests.test_push_kernel_host import _special_states
+    o = Oracle(pushing_blob)
+    o.env_start(init_qpos)
+    obs = o.push_reset(ctx60[0])
+    a = np.concatenate([obs[:2].astype(float), [0.12235931], [0, 1, 0, 0]])
+    for t in range(12):
+        o.push_step(a)
+    s0, _ = o.push_state()
+    cases = _special_states(s0)
+    names = list(cases)
+    n = 48
+    env = _env(n)
+    env.set_init_qpos(init_qpos)
+    env.reset(context=ctx60[np.zeros(n, dtype=int)])
+    st, fl, sc = env.get_state()
+    for e in range(n):
+        st[:68, e] = cases[names[e % 3]]
+        st[68:, e] = 0
+    fl[:] = 1 << 15
+    sc[:] = 12
+    env.set_state(st, fl, sc)
+    act = torch.as_tensor(np.tile(a, (n, 1)), dtype=torch.float64, device=env.device).contiguous()
+    env.step(act)
+    torch.cuda.synchronize()
+    st1, fl1, sc1 = env.get_state()
+    for k, name in enumerate(names):
+        o.push_set_state(cases[name], step=12, terminated=False, first_visit=-1, ik_valid=True)
+        o.push_step(a)
+        so, fo = o.push_state()
+        for e in range(k, n, 3):
+            assert not (fl1[e] & BAD), (name, hex(fl1[e]))
+            np.testing.assert_allclose(st1[:68, e], so, atol=1e-6, rtol=0, err_msg=name)
+    env.close()

@@ -77,3 +77,40 @@ def test_slow_ik_path_gives_the_same_rollout(push_hc, pushing_blob, init_qpos, p
         o1 = push_hc.step(a, fast=True)[0]
         o2 = other.step(a, fast=False)[0]
     np.testing.assert_allclose(push_hc.s[:68], other.s[:68], atol=1e-8)
+
+
+def _special_states(s0):
+    """mid-episode states that force the rarely taken solver paths"""
+    tcp = s0[25:28]
+    out = {}
+    s = s0.copy(); s[3] = -0.06                                       # joint 4 beyond its upper limit (-0.0698): memory-resident path
+    out["arm_limit"] = s
+    s = s0.copy()                                                     # rod squeezed between the cubes: memory-resident path
+    s[42:45] = [tcp[0] - 0.0395, tcp[1], 0.011]; s[45:49] = [1, 0, 0, 0]; s[49:55] = 0
+    s[55:58] = [tcp[0] + 0.0395, tcp[1], 0.011]; s[58:62] = [1, 0, 0, 0]; s[62:68] = 0
+    out["rod_on_both"] = s
+    s = s0.copy()                                                     # rod on cube 1, cube 1 pressed against cube 2: coupled path, all couplings
+    s[42:45] = [tcp[0] + 0.0395, tcp[1], 0.011]; s[45:49] = [1, 0, 0, 0]; s[49:55] = 0
+    s[55:58] = [tcp[0] + 0.0395 + 0.0598, tcp[1] + 0.004, 0.011]; s[58:62] = [np.cos(0.1), 0, 0, np.sin(0.1)]; s[62:68] = 0
+    out["rod_and_cube_cube"] = s
+    return out
+
+
+def test_rare_solver_paths_match_oracle(push_oracle, push_hc, init_qpos, push_contexts):
+    o, hc = push_oracle, push_hc
+    o.env_start(init_qpos)
+    obs = o.push_reset(push_contexts[0])
+    hc.reset(init_qpos, push_contexts[0])
+    a = np.concatenate([obs[:2].astype(float), [0.12235931], [0, 1, 0, 0]])
+    for t in range(12):
+        o.push_step(a)
+    s0, _ = o.push_state()
+    for name, s in _special_states(s0).items():
+        o.push_set_state(s, step=12, terminated=False, first_visit=-1, ik_valid=True)
+        hc.s[:68] = s; hc.s[68:] = 0; hc.f[0] = 1 << 15; hc.f[1] = 12
+        o.push_step(a)
+        so, fo = o.push_state()
+        _, _, _, ih = hc.step(a)
+        assert not (ih["flags"] & ((1 << 16) | (1 << 18))), name
+        assert fo[6] >= 4, name
+        np.testing.assert_allclose(hc.s[:68], so, atol=1e-6, rtol=0, err_msg=name)
