@@ -344,9 +344,71 @@ def gen_pushing_task():
         logged["Metrics/successes"], logged["Metrics/entropy"], np.unique(mode), succ.sum()))
 
 
+def gen_sorting_stacking_metrics():
+    """Metric tails of Sorting_Sim.test_agent (sorting_sim.py:191-221) and Stacking_Sim.test_agent / cal_KL
+    (stacking_sim.py:143-167,226-257) with stubbed rollouts.  Sorting's context / mode-prior files are not part of the
+    reference checkout, so its sim object is built without __init__ and given a synthetic prior."""
+    import simulation.sorting_sim as SS
+    import simulation.stacking_sim as ST
+    import torch
+
+    rng = np.random.default_rng(11)
+    out = {}
+    # ---- sorting: 4 boxes -> modes are np.packbits of 4 bits (decode_mode), keys arbitrary ints
+    nc, nt = 20, 12
+    keys = np.array([48, 80, 96, 144, 160, 192])            # the six orders of two red / two blue boxes, packed
+    prior = rng.dirichlet(np.ones(len(keys))).astype(np.float64)
+    me = rng.choice(np.concatenate([keys, [112, 240]]), size=(nc, nt)).astype(np.float32)
+    su = (rng.uniform(size=(nc, nt)) < 0.65).astype(np.float32)
+    su[5] = 0
+    sim = object.__new__(SS.Sorting_Sim)
+    sim.n_contexts, sim.n_trajectories_per_context, sim.n_cores = nc, nt, 1
+    sim.mode_keys, sim.n_mode, sim.mode_encoding = keys, len(keys), torch.tensor(prior)
+
+    def fake_eval(self, agent, contexts, n_trajectories, mode_encoding, successes, mean_distance, pid, cpu_set):
+        mode_encoding[:] = torch.tensor(me)
+        successes[:] = torch.tensor(su)
+
+    logged = {}
+    SS.Sorting_Sim.eval_agent = fake_eval
+    SS.wandb.log = lambda d, *a, **k: logged.update(d)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim.test_agent(agent=None)
+    out.update(sort_keys=keys, sort_prior=prior, sort_mode=me, sort_succ=su, sort_success_rate=float(logged["Metrics/successes"]),
+               sort_entropy=float(logged["Metrics/entropy"]), sort_KL=float(logged["Metrics/KL"]), sort_score=float(logged["score"]))
+    # ---- stacking: real constructor (test_contexts.pkl and mode_prob.pkl are in the checkout)
+    nc, nt = 15, 10
+    m3 = rng.integers(0, 6, size=(nc, nt)).astype(np.float32)
+    m2 = rng.integers(0, 6, size=(nc, nt)).astype(np.float32)
+    m1 = rng.integers(0, 3, size=(nc, nt)).astype(np.float32)
+    s1 = (rng.uniform(size=(nc, nt)) < 0.8).astype(np.float32)
+    s2 = s1 * (rng.uniform(size=(nc, nt)) < 0.7)
+    s3 = s2 * (rng.uniform(size=(nc, nt)) < 0.5)
+    s3[2] = 0
+
+    def fake_eval2(self, agent, contexts, n_trajectories, mode_encoding, mode_encoding_1_box, mode_encoding_2_box, successes, successes_1,
+                   successes_2, pid, cpu_set):
+        mode_encoding[:] = torch.tensor(m3); mode_encoding_2_box[:] = torch.tensor(m2); mode_encoding_1_box[:] = torch.tensor(m1)
+        successes[:] = torch.tensor(s3.astype(np.float32)); successes_1[:] = torch.tensor(s1); successes_2[:] = torch.tensor(s2.astype(np.float32))
+
+    logged2 = {}
+    ST.Stacking_Sim.eval_agent = fake_eval2
+    ST.wandb.log = lambda d, *a, **k: logged2.update(d)
+    sim2 = ST.Stacking_Sim(seed=0, device="cpu", render=False, n_cores=1, n_contexts=nc, n_trajectories_per_context=nt)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim2.test_agent(agent=None)
+    out.update(stack_m1=m1, stack_m2=m2, stack_m3=m3, stack_s1=s1, stack_s2=s2.astype(np.float32), stack_s3=s3.astype(np.float32),
+               stack_prior3=sim2.mode_encoding_3.numpy(), stack_prior2=sim2.mode_encoding_2.numpy(), stack_prior1=sim2.mode_encoding_1.numpy(),
+               **{"stack_" + k.split("/")[-1]: float(v) for k, v in logged2.items()})
+    np.savez_compressed(os.path.join(HERE, "ref_sorting_stacking_metrics.npz"), **out)
+    print("sorting: success %.4f entropy %.6f KL %.6f | stacking:" % (out["sort_success_rate"], out["sort_entropy"], out["sort_KL"]),
+          {k: round(v, 5) for k, v in out.items() if k.startswith("stack_") and np.ndim(v) == 0})
+
+
 if __name__ == "__main__":
     gen_ik()
     gen_pd_finger()
     gen_offline_ik()
     gen_avoiding_task()
     gen_pushing_task()
+    gen_sorting_stacking_metrics()
