@@ -151,6 +151,14 @@ def bench_pushing(args):
     if rank == 0:
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = PUSH_ALG_BYTES_PER_ENV_STEP * n / (k_ms * 1e-3) / 1e9
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc runs)
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_pushing.json")) as f:
+                pm = json.load(f)
+            if n == 4096:
+                traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+        except Exception:
+            pass
         line = {
             "metric": "env-steps/s", "value": world * n * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -160,11 +168,12 @@ def bench_pushing(args):
                                    "400-step episodes" % n,
                        "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world,
                        "finite": bool(np.isfinite(st[:68]).all()), "flagged_envs_solver_overflow_offtable": bad},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_pushing_step_split<true>", "kernel_ms": k_ms,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
                          "algorithmic_bytes_per_launch": PUSH_ALG_BYTES_PER_ENV_STEP * n,
-                         "note": "FP64 latency bound like the Avoiding step (DESIGN.md section 4); first correct version of this kernel"},
+                         "note": "FP64 latency bound like the Avoiding step (DESIGN.md sections 4, 12.3).  Measured HBM traffic is ~25x the algorithmic bytes: "
+                                 "register spills of the solver functions (private scratch) and the solver warm start / scratch rows, not state traffic"},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_pushing(env.blob, q, ctx60)
