@@ -56,6 +56,14 @@ def cpu_baseline(blob, init_qpos, budget_s=12.0):
                       "env-steps/s/core (BASELINE.md section 2)" % (n, dt, os.cpu_count() or 0)}
 
 
+def _local_device() -> int:
+    """GPU of this rank: LOCAL_RANK (one process per GPU).  D3IL_BENCH_FORCE_DEVICE pins every rank to one GPU - only for
+    exercising the multi-process code path on a single-GPU box (with D3IL_DIST_BACKEND=gloo; RCCL needs distinct GPUs)."""
+    if os.environ.get("D3IL_BENCH_FORCE_DEVICE") is not None:
+        return int(os.environ["D3IL_BENCH_FORCE_DEVICE"])
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
 # Pushing: cube state adds 26 f64 (+ 2 flag/counter words as above); action 56 B; obs 32 B; done/success/mode 4 B; info 16 B
 PUSH_ALG_BYTES_PER_ENV_STEP = 2 * (68 * 8 + 4 + 4) + 56 + 32 + 4 + 16
 
@@ -99,9 +107,9 @@ def bench_pushing(args):
     from d3il_amd.envs.pushing import BlockPushVecEnv
     from d3il_amd.simulation.pushing_sim import load_test_contexts
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = _local_device()
     torch.cuda.set_device(local_rank)
-    rank, world = D.init_from_env("nccl")
+    rank, world = D.init_from_env(os.environ.get("D3IL_DIST_BACKEND", "nccl"))
     dev = torch.device("cuda:%d" % local_rank)
     n = args.envs
     env = BlockPushVecEnv(n, device=dev)
@@ -207,9 +215,9 @@ def main():
         sys.exit(2)
     if args.task == "pushing":
         return bench_pushing(args)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = _local_device()
     torch.cuda.set_device(local_rank)
-    rank, world = D.init_from_env("nccl")
+    rank, world = D.init_from_env(os.environ.get("D3IL_DIST_BACKEND", "nccl"))
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda:%d" % local_rank)
