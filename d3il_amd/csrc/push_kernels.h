@@ -4,8 +4,8 @@
 // controller wave runs the open-loop IK chain, the physics wave runs dynamics + collision + constraint solve +
 // integration, one workgroup barrier per sub-step, set-points handed over through an LDS slot).  A workgroup owns
 // PUSH_LANES = 24 environments: the coupled constraint solver keeps its per-contact table, the arm mass matrix, the cube
-// Hessian and the elimination matrices of each environment in LDS (670 doubles per environment, lane-strided =>
-// conflict-free ds_read/write_b64), 125.6 KiB per workgroup, i.e. one workgroup per CU; 4096 environments are 171
+// Hessian and the elimination matrices of each environment in LDS (710 doubles per environment, lane-strided =>
+// conflict-free ds_read/write_b64), 133 KiB per workgroup, i.e. one workgroup per CU; 4096 environments are 171
 // workgroups on 171 of the 256 CUs.  The rarely used memory-resident solver (arm joint at a limit, rod on both cubes) works in an HBM scratch area.
 #pragma once
 #include "push_step.h"
@@ -114,29 +114,100 @@ __global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(PushConsts pc, 
       for (int i = 0; i < NARM; i++) { so[(D3IL_STATE_IK_Q + i) * (size_t)stride] = ikq[i]; so[(D3IL_STATE_IK_QD + i) * (size_t)stride] = ikqd[i]; }
     }
   } else {
-    PushState ps;
+    // physics wave.  Lanes [0, PUSH_LANES): arm + cube 0 of environment e; lanes [PUSH_LANES, 2 PUSH_LANES): cube 1 of the
+    // same environments (same table column), so the two decoupled cube solves of a sub-step run side by side.  The pair
+    // exchanges cube states, warm starts, the "jointly solved" decision and its result through the LDS table; both
+    // lanes are in the same wave, so program order + a wavefront fence is all the synchronisation needed.
+    const int col = lane < PUSH_LANES ? lane : lane - PUSH_LANES;
+    const int cube_id = lane < PUSH_LANES ? 0 : 1;
+    const int ee = blockIdx.x * PUSH_LANES + col;
+    const bool plive = lane < 2 * PUSH_LANES && ee < n;
+    const bool arm_lane = plive && cube_id == 0;
+    const size_t ei = plive ? ee : 0;
+    PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + ei), stride, (push_glb_double*)(state + (size_t)PUSH_STATE_WARM * stride + ei), stride};
+    EnvState st;
+    BoxState own, other;
+    double warm6[6], owarm[6];
     float o[PUSH_OBS]; unsigned char dn = 0; double reward = 0, mean_distance = 0;
-    PushScratch sc{(push_lds_double*)(tbl + lane), (push_glb_double*)(scratch + (live ? e : 0)), stride, (push_glb_double*)(state + (size_t)PUSH_STATE_WARM * stride + (live ? e : 0)), stride};
-    if (live) {
-      push_load(state, flags, steps, stride, e, ps, false);
+    unsigned pflags = 0;
+    bool warm_valid = false;
+    const int crow = PUSH_STATE_BOX + 13 * cube_id, pub = PT_PAIR + 19 * cube_id, opub = PT_PAIR + 19;
+    auto publish = [&]() {
+      for (int k = 0; k < 3; k++) PTS(pub + k) = own.pos[k];
+      for (int k = 0; k < 4; k++) PTS(pub + 3 + k) = own.quat[k];
+      for (int k = 0; k < 6; k++) { PTS(pub + 7 + k) = own.vel[k]; PTS(pub + 13 + k) = warm6[k]; }
+    };
+    auto read_other = [&]() {
+      for (int k = 0; k < 3; k++) other.pos[k] = PTS(opub + k);
+      for (int k = 0; k < 4; k++) other.quat[k] = PTS(opub + 3 + k);
+      for (int k = 0; k < 6; k++) { other.vel[k] = PTS(opub + 7 + k); owarm[k] = PTS(opub + 13 + k); }
+    };
+    auto pair_sync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    if (plive) {
+      const double* s = state + ee;
+      for (int i = 0; i < 3; i++) own.pos[i] = s[(size_t)(crow + i) * stride];
+      for (int i = 0; i < 4; i++) own.quat[i] = s[(size_t)(crow + 3 + i) * stride];
+      for (int i = 0; i < 6; i++) own.vel[i] = s[(size_t)(crow + 7 + i) * stride];
+      for (int i = 0; i < 6; i++) warm6[i] = s[(size_t)(PUSH_STATE_WARM + 6 * cube_id + i) * stride];
+      warm_valid = (flags[ee] & PF_WARM_VALID) != 0;
+      publish();
+    }
+    pair_sync();
+    if (arm_lane) {
+      PushState ps;
+      push_load(state, flags, steps, stride, ee, ps, false);
+      read_other();
+      ps.box[0] = own; ps.box[1] = other;
       push_step_begin(pc, ps, o, &reward, &dn, max_steps);
+      st = ps.arm;
     }
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
       __syncthreads();
-      if (live) {
+      if (arm_lane) {
         const int b = s & 1;
-        double qd[NARM], qdd[NARM];
+        double qd[NARM], qdd[NARM], tau[NARM], ff[NFING], cw[12];
+        BoxState box[2];
 #pragma unroll
-        for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][lane]; qdd[k] = xch[b][NARM + k][lane]; }
-        push_control_and_physics(c, pc, ps, sc, qd, qdd, 0.04, false);
+        for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][col]; qdd[k] = xch[b][NARM + k][col]; }
+        read_other();
+        box[0] = own; box[1] = other;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cw[k] = warm6[k]; cw[6 + k] = owarm[k]; }
+        push_control(c, st, qd, qdd, 0.04, false, tau, ff);
+        const bool solved = push_substep_arm(c, pc, st, box, cw, sc, tau, ff);
+        PTS(PT_SOLVED) = solved ? 1.0 : 0.0;
       }
+      pair_sync();
+      if (plive) {
+        const bool solved = PTS(PT_SOLVED) != 0.0;
+        const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
+        push_substep_cube(pc, grav, c.timestep, own, warm6, cube_id, solved, warm_valid, pflags, sc);
+        warm_valid = true;
+        publish();
+      }
+      pair_sync();
     }
-    if (live) {
-      ps.arm.flags |= F_IK_VALID;
+    if (plive && cube_id == 1) PTS(PT_PFLAG) = (double)pflags;
+    pair_sync();
+    if (arm_lane) {
+      read_other();
+      PushState ps;
+      ps.arm = st; ps.box[0] = own; ps.box[1] = other;
+      ps.arm.flags |= F_IK_VALID | PF_WARM_VALID | pflags | (unsigned)PTS(PT_PFLAG);
       push_step_end(pc, ps, &mean_distance);
-      push_store(state, flags, steps, stride, e, ps, false);
-      push_store_outputs(ps, e, stride, o, dn, reward, mean_distance, obs, done, success, mode, info);
+      push_store(state, flags, steps, stride, ee, ps, false);
+      push_store_outputs(ps, ee, stride, o, dn, reward, mean_distance, obs, done, success, mode, info);
+    }
+    if (plive && cube_id == 1) {      // cube 1 rows and warm start are written by their owner (cube 0 went through push_store)
+      double* so = state + ee;
+      for (int i = 0; i < 3; i++) so[(size_t)(crow + i) * stride] = own.pos[i];
+      for (int i = 0; i < 4; i++) so[(size_t)(crow + 3 + i) * stride] = own.quat[i];
+      for (int i = 0; i < 6; i++) so[(size_t)(crow + 7 + i) * stride] = own.vel[i];
+    }
+    if (plive) {
+      double* so = state + ee;
+      for (int i = 0; i < 6; i++) so[(size_t)(PUSH_STATE_WARM + 6 * cube_id + i) * stride] = warm6[i];
     }
   }
 }

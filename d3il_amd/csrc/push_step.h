@@ -768,7 +768,9 @@ constexpr int PT_ROD = PT_CON + 8 * 17;
 constexpr int PT_G = PT_VEL;                // gradient of the current iterate (the velocities are only needed by the set-up pass)
 constexpr int PT_H = PT_CON + 9 * 17;      // 12 x 12 cube Hessian, packed lower (78)
 constexpr int PT_XR = PT_H + 78;           // rod-contact hand-over between the phases (42)
-constexpr int PT_SIZE = PT_XR + 42;        // 670
+constexpr int PT_PAIR = PT_XR + 42;        // lane-pair hand-over: per cube pos[3] quat[4] vel[6] warm[6] (2 x 19), then SOLVED, PFLAG
+constexpr int PT_SOLVED = PT_PAIR + 38, PT_PFLAG = PT_PAIR + 39;
+constexpr int PT_SIZE = PT_PAIR + 40;      // 710
 
 template <int N> D3IL_HD bool ldl_n(double* A, double* d, double* id) {   // in place: strict lower part of A becomes L
   bool ok = true;
@@ -1399,9 +1401,12 @@ D3IL_HD void cube_integrate(BoxState& bx, const double* acc, double h) {
   }
 }
 
+// Arm half of one physics sub-step: forward pass, contact-candidate search, the coupled / memory-resident solve when
+// something couples, the decoupled arm solve otherwise, arm integration.  box[2]: current cube states; cwarm[12]: the cubes'
+// warm start.  Returns true when a joint solve was made - the cube accelerations are then in the table at PT_X[0..11].
 template <class C>
-D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* tau, const double* ffing) {
-  EnvState& st = ps.arm;
+D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, const BoxState* box, const double* cwarm, const PushScratch& sc,
+                              const double* tau, const double* ffing) {
   D3IL_REFRESH(c0, c);
   const double h = c.timestep;
   PUSH_TIC;
@@ -1432,20 +1437,20 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
   bool near_rod[PUSH_NB], near_bb;
 #pragma unroll
   for (int b = 0; b < PUSH_NB; b++) {
-    if (fabs(ps.box[b].pos[0] - pc.slab_c[0][0]) > pc.slab_h[0][0] - 0.06 || fabs(ps.box[b].pos[1] - pc.slab_c[0][1]) > pc.slab_h[0][1] - 0.06) st.flags |= PF_OFF_TABLE;
-    double w[3] = {ps.box[b].pos[0] - rodc[0], ps.box[b].pos[1] - rodc[1], ps.box[b].pos[2] - rodc[2]};
+    if (fabs(box[b].pos[0] - pc.slab_c[0][0]) > pc.slab_h[0][0] - 0.06 || fabs(box[b].pos[1] - pc.slab_c[0][1]) > pc.slab_h[0][1] - 0.06) st.flags |= PF_OFF_TABLE;
+    double w[3] = {box[b].pos[0] - rodc[0], box[b].pos[1] - rodc[1], box[b].pos[2] - rodc[2]};
     double t = clampd(dot3(w, rodu), -c.rod_h, c.rod_h);
     double e[3] = {w[0] - t * rodu[0], w[1] - t * rodu[1], w[2] - t * rodu[2]};
     near_rod[b] = dot3(e, e) < (rcirc + c.rod_r) * (rcirc + c.rod_r);
   }
   {
-    double dd[3] = {ps.box[1].pos[0] - ps.box[0].pos[0], ps.box[1].pos[1] - ps.box[0].pos[1], ps.box[1].pos[2] - ps.box[0].pos[2]};
+    double dd[3] = {box[1].pos[0] - box[0].pos[0], box[1].pos[1] - box[0].pos[1], box[1].pos[2] - box[0].pos[2]};
     near_bb = dot3(dd, dd) < 4 * rcirc * rcirc;
     if (wave_any(near_bb)) {
       // inside the circumscribed spheres: the six face axes of the separating-axis test (the first part of box_box) decide
       // most cases without the general routine; a positive separation on any of them means no contact (margin 0)
       double R0[9], R1[9];
-      quat2mat(ps.box[0].quat, R0); quat2mat(ps.box[1].quat, R1);
+      quat2mat(box[0].quat, R0); quat2mat(box[1].quat, R1);
       bool sep = false;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
@@ -1476,14 +1481,14 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
         CubeSlab cs[PUSH_NB];
 #pragma unroll
         for (int b = 0; b < PUSH_NB; b++) {
-          quat2mat(ps.box[b].quat, Rb[b]);
-          cube_slab_contacts(pc, ps.box[b].pos, Rb[b], cs[b]);
+          quat2mat(box[b].quat, Rb[b]);
+          cube_slab_contacts(pc, box[b].pos, Rb[b], cs[b]);
 #pragma unroll
           for (int k = 0; k < 9; k++) PGS(PG_AUX_R + 9 * b + k) = Rb[b][k];
 #pragma unroll
-          for (int k = 0; k < 3; k++) PGS(PG_AUX_POS + 3 * b + k) = ps.box[b].pos[k];
+          for (int k = 0; k < 3; k++) PGS(PG_AUX_POS + 3 * b + k) = box[b].pos[k];
 #pragma unroll
-          for (int k = 0; k < 6; k++) PGS(PG_AUX_VEL + 6 * b + k) = ps.box[b].vel[k];
+          for (int k = 0; k < 6; k++) PGS(PG_AUX_VEL + 6 * b + k) = box[b].vel[k];
         }
         ncon = push_collect_contacts(pc, sc, cs, rodc, rodu, c.rod_r, c.rod_h, near_bb, near_rod, &cfl, has);
       }
@@ -1503,9 +1508,9 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
 #pragma unroll
               for (int k = 0; k < 9; k++) PTS(PT_R + 9 * b + k) = PGS(PG_AUX_R + 9 * b + k);
 #pragma unroll
-              for (int k = 0; k < 3; k++) PTS(PT_POS + 3 * b + k) = ps.box[b].pos[k];
+              for (int k = 0; k < 3; k++) PTS(PT_POS + 3 * b + k) = box[b].pos[k];
 #pragma unroll
-              for (int k = 0; k < 6; k++) { PTS(PT_VEL + 6 * b + k) = ps.box[b].vel[k]; PTS(PT_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0; }
+              for (int k = 0; k < 6; k++) { PTS(PT_VEL + 6 * b + k) = box[b].vel[k]; PTS(PT_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0; }
             }
 #pragma unroll
             for (int k = 0; k < NDOF; k++) { PTS(PT_VEL + PUSH_ARM0 + k) = st.v[k]; PTS(PT_A0 + PUSH_ARM0 + k) = a0[k]; }
@@ -1548,10 +1553,10 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
                 }
               }
             }
-            if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PTS(PT_X + k) = PWS(k);
+            if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PTS(PT_X + k) = k < PUSH_ARM0 ? cwarm[k] : PWS(k);
             else for (int k = 0; k < PUSH_NV; k++) PTS(PT_X + k) = PTS(PT_A0 + k);
             if (!coupled_newton(pc, sc, nbb, rod_cube, c.rod_invweight0)) st.flags |= F_SOLVER_FAIL;
-            for (int k = 0; k < PUSH_NV; k++) PWS(k) = PTS(PT_X + k);
+            for (int k = PUSH_ARM0; k < PUSH_NV; k++) PWS(k) = PTS(PT_X + k);
           }
         }
         if (slow) {
@@ -1596,10 +1601,10 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
               }
             }
           }
-          if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PGS(PG_X + k) = PWS(k);
+          if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PGS(PG_X + k) = k < PUSH_ARM0 ? cwarm[k] : PWS(k);
           else for (int k = 0; k < PUSH_NV; k++) PGS(PG_X + k) = PGS(PG_A0 + k);
           if (!push_general_solve(pc, sc, ncon, has[0] != 0, has[1] != 0, has[2] != 0)) st.flags |= F_SOLVER_FAIL;
-          for (int k = 0; k < PUSH_NV; k++) PWS(k) = PGS(PG_X + k);
+          for (int k = 0; k < PUSH_NV; k++) { double xk = PGS(PG_X + k); PTS(PT_X + k) = xk; if (k >= PUSH_ARM0) PWS(k) = xk; }
         }
         {   // constraint force on the arm from the optimality condition M (x - a0) = J' f
           double xa[NDOF], Mx[NDOF];
@@ -1679,28 +1684,53 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
       for (int k = 0; k < NDOF; k++) PWS(PUSH_ARM0 + k) = qacc[k];
   }
   PUSH_TOC(8);
-  // ---- cubes: decoupled 6-dof solves (arm state is dead by now), then integration
+  return solved;
+}
+
+// Cube half: one free cube integrates either with its share of the joint solution (table, PT_X) or with its own
+// decoupled 6-dof solve over the slab contacts.  warm[6]: this cube's warm start in / solution out.
+D3IL_HD void push_substep_cube(const PushConsts& pc, const double* gravity, double h, BoxState& bx, double* warm, int b, bool solved, bool warm_valid,
+                               unsigned& flags, const PushScratch& sc) {
+  PUSH_TIC;
+  double xb[6];
+  if (!solved) {
+    double Rb[9], a0b[6] = {gravity[0], gravity[1], gravity[2], 0, 0, 0}, vb[6];
+    CubeSlab cs;
+    quat2mat(bx.quat, Rb);
+    cube_slab_contacts(pc, bx.pos, Rb, cs);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { xb[k] = warm_valid ? warm[k] : a0b[k]; vb[k] = bx.vel[k]; }
+    if (!cube_newton(pc, Rb, vb, cs, a0b, xb)) flags |= F_SOLVER_FAIL;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) xb[k] = PTS(PT_X + 6 * b + k);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) warm[k] = xb[k];
+  cube_integrate(bx, xb, h);
+  PUSH_TOC(9);
+}
+
+// One physics sub-step on a single lane (host build, reset kernel): arm half, then both cubes in turn.  The step kernel
+// runs the two cube halves on two lanes instead (push_kernels.h).
+template <class C>
+D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* tau, const double* ffing) {
+  double cw[12];
+  for (int k = 0; k < 12; k++) cw[k] = PWS(k);
+  const bool warm_valid = (ps.arm.flags & PF_WARM_VALID) != 0;
+  const bool solved = push_substep_arm(c0, pc, ps.arm, ps.box, cw, sc, tau, ffing);
+  D3IL_REFRESH(c0, c);
+  const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
 #pragma unroll
   for (int b = 0; b < PUSH_NB; b++) {
-    double xb[6];
-    if (!solved) {
-      double Rb[9], a0b[6] = {c.gravity[0], c.gravity[1], c.gravity[2], 0, 0, 0}, vb[6];
-      CubeSlab cs;
-      quat2mat(ps.box[b].quat, Rb);
-      cube_slab_contacts(pc, ps.box[b].pos, Rb, cs);
+    double w6[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) { xb[k] = (st.flags & PF_WARM_VALID) ? PWS(6 * b + k) : a0b[k]; vb[k] = ps.box[b].vel[k]; }
-      if (!cube_newton(pc, Rb, vb, cs, a0b, xb)) st.flags |= F_SOLVER_FAIL;
+    for (int k = 0; k < 6; k++) w6[k] = cw[6 * b + k];
+    push_substep_cube(pc, grav, c.timestep, ps.box[b], w6, b, solved, warm_valid, ps.arm.flags, sc);
 #pragma unroll
-      for (int k = 0; k < 6; k++) PWS(6 * b + k) = xb[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 6; k++) xb[k] = PWS(6 * b + k);
-    }
-    cube_integrate(ps.box[b], xb, h);
+    for (int k = 0; k < 6; k++) PWS(6 * b + k) = w6[k];
   }
-  st.flags |= PF_WARM_VALID;
-  PUSH_TOC(9);
+  ps.arm.flags |= PF_WARM_VALID;
 }
 
 // ------------------------------------------------------------------------------------------------ task logic (pushing.py)
@@ -1767,12 +1797,9 @@ D3IL_HD void push_step_end(const PushConsts& pc, PushState& ps, double* mean_dis
 }
 
 // ------------------------------------------------------------------------------------------------ env level
-// joint PD on the set-point + finger PD + one physics sub-step (Scene.next_step after the IK update)
+// joint PD on the set-point + finger PD (Scene.next_step after the IK update): arm torque without gravity compensation, raw finger force
 template <class C>
-D3IL_HD void push_control_and_physics(const C& c, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* q_des, const double* qd_des,
-                                      double set_width, bool grasp) {
-  EnvState& st = ps.arm;
-  double tau[NARM], ff[NFING];
+D3IL_HD void push_control(const C& c, const EnvState& st, const double* q_des, const double* qd_des, double set_width, bool grasp, double* tau, double* ff) {
 #pragma unroll
   for (int k = 0; k < NARM; k++) tau[k] = c.pd_p[k] * (q_des[k] - st.q[k]) + c.pd_d[k] * (qd_des[k] - st.v[k]);
   double mean = 0.5 * (st.q[NARM] + st.q[NARM + 1]);   // RobotBase.fing_ctrl_step (Robots.py:441-476)
@@ -1784,6 +1811,12 @@ D3IL_HD void push_control_and_physics(const C& c, const PushConsts& pc, PushStat
     else f2 = clampd(500 * (set_width - w) - 10 * wv, -5, 5);
     ff[k] = f1 + f2;
   }
+}
+template <class C>
+D3IL_HD void push_control_and_physics(const C& c, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* q_des, const double* qd_des,
+                                      double set_width, bool grasp) {
+  double tau[NARM], ff[NFING];
+  push_control(c, ps.arm, q_des, qd_des, set_width, grasp, tau, ff);
   push_physics_substep(c, pc, ps, sc, tau, ff);
 }
 
