@@ -391,19 +391,6 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, con
     act[i] = cs.dist[i] < 0;
     any = any || act[i];
     aref[i][0] = aref[i][1] = aref[i][2] = 0; Dn[i] = 0;
-    if (wave_any(act[i])) {
-      double J[3][6]; slab_rows(R, cs.r[i], J);
-      double imp = impedance(pc.ct_solimp[0], cs.dist[i]);
-      double Rn = fmax(1e-15, (1 - imp) / imp * pc.box_invw_t);
-      double v3[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) { double a = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) a += J[r][k] * vel[k]; v3[r] = a; }
-      aref[i][0] = -pc.ct_B[0] * v3[0] - pc.ct_K[0] * imp * cs.dist[i];
-      aref[i][1] = -pc.ct_B[0] * v3[1]; aref[i][2] = -pc.ct_B[0] * v3[2];
-      Dn[i] = 1 / Rn;
-    }
   }
   if (!any) {
 #pragma unroll
@@ -426,6 +413,17 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, con
       jar[i][0] = jar[i][1] = jar[i][2] = 0;
       if (wave_any(act[i])) {
         double J[3][6]; slab_rows(R, cs.r[i], J);
+        if (it == 0 && act[i]) {   // reference acceleration and regularisation of the contact, with the rows that are needed anyway
+          double imp = impedance(pc.ct_solimp[0], cs.dist[i]);
+          double v3[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) { double a = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) a += J[r][k] * vel[k]; v3[r] = a; }
+          aref[i][0] = -pc.ct_B[0] * v3[0] - pc.ct_K[0] * imp * cs.dist[i];
+          aref[i][1] = -pc.ct_B[0] * v3[1]; aref[i][2] = -pc.ct_B[0] * v3[2];
+          Dn[i] = 1 / fmax(1e-15, (1 - imp) / imp * pc.box_invw_t);
+        }
         double f[3], Hc[9], jr[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) { double a = -aref[i][r];
