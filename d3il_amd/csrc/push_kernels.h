@@ -175,12 +175,12 @@ __global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(PushConsts pc, 
 #pragma unroll
         for (int k = 0; k < 6; k++) { cw[k] = warm6[k]; cw[6 + k] = owarm[k]; }
         push_control(c, st, qd, qdd, 0.04, false, tau, ff);
-        const bool solved = push_substep_arm(c, pc, st, box, cw, sc, tau, ff);
-        PTS(PT_SOLVED) = solved ? 1.0 : 0.0;
+        const int solved_mask = push_substep_arm(c, pc, st, box, cw, sc, tau, ff);
+        PTS(PT_SOLVED) = (double)solved_mask;
       }
       pair_sync();
       if (plive) {
-        const bool solved = PTS(PT_SOLVED) != 0.0;
+        const bool solved = (((int)PTS(PT_SOLVED) >> cube_id) & 1) != 0;
         const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
         push_substep_cube(pc, grav, c.timestep, own, warm6, cube_id, solved, warm_valid, pflags, sc);
         warm_valid = true;

@@ -288,6 +288,12 @@ D3IL_HD double rsqrtd(double x) {   // 1 / sqrt(x), x > 0
 #endif
 }
 D3IL_HD double cone_eval(const double* jar, double Dn, double Dt, double mu, double fric, double* force, double* Hc /* 3x3 */) {
+  if (Dn == 0) {   // inert row (inactive contact slot of this lane inside a wave-uniform loop)
+#pragma unroll
+    for (int i = 0; i < 9; i++) Hc[i] = 0;
+    force[0] = force[1] = force[2] = 0;
+    return 0;
+  }
   double U0 = jar[0] * mu, U1 = jar[1] * fric, U2 = jar[2] * fric;
   double T2 = U1 * U1 + U2 * U2;
   double iT = T2 > 0 ? rsqrtd(T2) : 0.0;
@@ -817,10 +823,18 @@ D3IL_HD void acc_block(double* H, int oa, int ob, const double (*Ja)[6], const d
   }
 }
 
-// nbb: cube-cube contacts in the table; rod_cube: cube touched by the rod (-1: none).  x: PT_X in / out.
+// nbb: cube-cube contacts in the table; rod_cube: cube group touched by the rod (-1: none).  x: PT_X in / out.
+// two (wave-uniform): both cube groups are in the system.  When no lane of the wave has a cube-cube contact the caller puts
+// the cube under the rod into group 0 and only that group is processed (6 x 6 cube system, half the slab slots); the other
+// cube then goes through its decoupled solve.
 // The function is written as a sequence of phases that hand their results over through the LDS table, so that the live
 // register set of each phase stays small (the 12 x 12 Hessian is only in registers while it is factorised).
-D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch& sc, int nbb, int rod_cube, double rod_invw) {
+D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch& sc, int nbb, int rod_cube, double rod_invw, bool two) {
+  const int nb = two ? PUSH_NB : 1, ncd = 6 * nb;
+  // This lane's own system holds group 1 only with a cube-cube contact.  In a wave that processes both groups for the sake of
+  // another lane, group 1 of this lane is inert (no contacts, x = a0 => zero gradient, zero step) and is left out of the
+  // convergence measures, so the result does not depend on which environments share a wave.
+  const bool lane_two = nbb > 0;
   const double impr = pc.impratio, isq = sqrt(1 / fmax(1e-15, impr));
   const double fric0 = pc.ct_fric[0], mu0 = fric0 * isq, fric1 = pc.ct_fric[1], mu1 = fric1 * isq;
   const bool rod = rod_cube >= 0;
@@ -833,7 +847,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
   PUSH_TIC;
   // ---- per-contact reference acceleration and regularisation
 #pragma clang loop unroll(disable)
-  for (int b = 0; b < PUSH_NB; b++) {
+  for (int b = 0; b < nb; b++) {
     double R[9], pos[3], vel[6];
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 * b + k);
@@ -848,7 +862,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
       int base = PT_SLAB + 10 * (8 * b + i);
       double r[3], dist;
       slot_geom(pc, face, pos, i, r, &dist);
-      bool act = dist < 0;
+      bool act = dist < 0 && (b == 0 || lane_two);
       double ar[3] = {0, 0, 0}, Dn = 0;
       if (wave_any(act)) {
         double J[3][6]; slab_rows(R, r, J);
@@ -1031,9 +1045,9 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
     }
     PUSH_TOC(1);
     // ================= phase B: cube gradients and diagonal Hessian blocks (registers) -> PT_H, PT_P (right-hand side)
-    for (int i = 0; i < 36; i++) PTS(PT_H + tri(6 + i / 6, i % 6)) = 0;      // off-diagonal 6 x 6 block
+    if (two) for (int i = 0; i < 36; i++) PTS(PT_H + tri(6 + i / 6, i % 6)) = 0;      // off-diagonal 6 x 6 block
 #pragma clang loop unroll(disable)
-    for (int b = 0; b < PUSH_NB; b++) {
+    for (int b = 0; b < nb; b++) {
       const double Mc[6] = {pc.box_mass, pc.box_mass, pc.box_mass, pc.box_inertia, pc.box_inertia, pc.box_inertia};
       double R[9], pos[3], xb[6], Hb[21], gb[6];
 #pragma unroll
@@ -1163,11 +1177,11 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
     PUSH_TOC(2);
     {   // gradient at round-off / tolerance level: accept the iterate (MuJoCo's scaled-gradient stop)
       double gm = gmax_arm;
-      for (int k = 0; k < 12; k++) gm = fmax(gm, fabs(PTS(PT_P + k)));
+      for (int k = 0; k < ncd; k++) gm = fmax(gm, fabs(PTS(PT_P + k)));
       if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
     }
     // ================= phase C: factorise the 12 x 12 cube system, directions
-    {
+    if (two) {
       double H[78], dc[12], idc[12], pcv[12];
 #pragma unroll
       for (int i = 0; i < 78; i++) H[i] = PTS(PT_H + i);
@@ -1177,6 +1191,16 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
       ldl_solve_n<12>(H, idc, pcv);
 #pragma unroll
       for (int k = 0; k < 12; k++) PTS(PT_P + k) = pcv[k];
+    } else {
+      double H[21], dc[6], idc[6], pcv[6];
+#pragma unroll
+      for (int i = 0; i < 21; i++) H[i] = PTS(PT_H + i);
+#pragma unroll
+      for (int k = 0; k < 6; k++) pcv[k] = PTS(PT_P + k);
+      if (!ldl_n<6>(H, dc, idc)) return false;
+      ldl_solve_n<6>(H, idc, pcv);
+#pragma unroll
+      for (int k = 0; k < 6; k++) PTS(PT_P + k) = pcv[k];
     }
     {
       double pa[NDOF];
@@ -1210,11 +1234,10 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
     PUSH_TOC(3);
     // ================= phase D: line search quantities
     double pMp = 0, pMa = 0, gTp = 0;
-    for (int k = 0; k < PUSH_NV; k++) gTp += PTS(PT_G + k) * PTS(PT_P + k);
+    for (int k = 0; k < PUSH_NV; k++) if (k < ncd || k >= PUSH_ARM0) gTp += PTS(PT_G + k) * PTS(PT_P + k);
     {
       const double Mc[6] = {pc.box_mass, pc.box_mass, pc.box_mass, pc.box_inertia, pc.box_inertia, pc.box_inertia};
-#pragma unroll
-      for (int k = 0; k < 12; k++) { double pk = PTS(PT_P + k); pMp += Mc[k % 6] * pk * pk; pMa += Mc[k % 6] * pk * (PTS(PT_X + k) - PTS(PT_A0 + k)); }
+      for (int k = 0; k < ncd; k++) { double pk = PTS(PT_P + k); pMp += Mc[k % 6] * pk * pk; pMa += Mc[k % 6] * pk * (PTS(PT_X + k) - PTS(PT_A0 + k)); }
       double Mm[45], pa[NDOF], dx[NDOF], t1[NDOF], t2[NDOF];
 #pragma unroll
       for (int i = 0; i < 45; i++) Mm[i] = PTS(PT_M + i);
@@ -1225,7 +1248,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
       for (int k = 0; k < NDOF; k++) { pMp += pa[k] * t1[k]; pMa += pa[k] * t2[k]; }
     }
 #pragma clang loop unroll(disable)
-    for (int b = 0; b < PUSH_NB; b++) {
+    for (int b = 0; b < nb; b++) {
       double R[9], pos[3], pb[6];
 #pragma unroll
       for (int k = 0; k < 9; k++) R[k] = PTS(PT_R + 9 * b + k);
@@ -1284,7 +1307,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
         if (sign != 0 && jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
       }
 #pragma clang loop unroll(disable)
-      for (int i = 0; i < 16; i++) {
+      for (int i = 0; i < 8 * nb; i++) {
         int base = PT_SLAB + 10 * i;
         double Dn = PTS(base + 3);
         if (wave_any(Dn != 0)) {
@@ -1325,6 +1348,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
     PUSH_TOC(5);
     double smax = 0, xmax = 0;
     for (int k = 0; k < PUSH_NV; k++) {
+      if (k >= (lane_two ? 12 : 6) && k < PUSH_ARM0) continue;
       double dxk = best * PTS(PT_P + k), xn = PTS(PT_X + k) + dxk;
       PTS(PT_X + k) = xn; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(xn));
     }
@@ -1401,9 +1425,9 @@ D3IL_HD void cube_integrate(BoxState& bx, const double* acc, double h) {
 
 // Arm half of one physics sub-step: forward pass, contact-candidate search, the coupled / memory-resident solve when
 // something couples, the decoupled arm solve otherwise, arm integration.  box[2]: current cube states; cwarm[12]: the cubes'
-// warm start.  Returns true when a joint solve was made - the cube accelerations are then in the table at PT_X[0..11].
+// warm start.  Returns a mask: bit b set = cube b took part in a joint solve and its acceleration is in the table at PT_P[6 b ..].
 template <class C>
-D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, const BoxState* box, const double* cwarm, const PushScratch& sc,
+D3IL_HD int push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, const BoxState* box, const double* cwarm, const PushScratch& sc,
                               const double* tau, const double* ffing) {
   D3IL_REFRESH(c0, c);
   const double h = c.timestep;
@@ -1469,6 +1493,7 @@ D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, c
   for (int k = 0; k < NDOF; k++) fc[k] = 0;
   const bool general = arm_rows || near_bb || near_rod[0] || near_rod[1];
   bool solved = false;
+  int solved_mask = 0;      // bit b: cube b's acceleration comes from the joint solve (table, PT_P)
   PUSH_TOC(6);
   if (wave_any(general)) {
     if (general) {
@@ -1492,7 +1517,7 @@ D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, c
       }
       st.flags |= cfl;
       if (has[0] || has[1] || has[2] || arm_rows) {
-        solved = true;
+        solved = true;   // the arm takes part in a joint solve
         const bool slow = arm_rows || (has[1] && has[2]);   // arm joint at a limit, or the rod on both cubes: memory-resident solver
         double a0[NDOF];
 #pragma unroll
@@ -1500,15 +1525,19 @@ D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, c
         ldl9_solve(L, id, a0);
         if (wave_any(!slow)) {
           if (!slow) {
-            // ---- coupled path: fill the LDS table
+            // ---- coupled path: fill the LDS table.  Cube groups: group g holds cube g ^ perm; without a cube-cube contact the
+            // cube under the rod becomes group 0 so that a wave without any cube-cube contact processes one group only
+            const int perm = (has[0] == 0 && has[2]) ? 1 : 0;
+            const bool two = wave_any(has[0] > 0);
 #pragma unroll
-            for (int b = 0; b < PUSH_NB; b++) {
+            for (int g = 0; g < PUSH_NB; g++) {
+              const BoxState& bg = (g ^ perm) ? box[1] : box[0];
 #pragma unroll
-              for (int k = 0; k < 9; k++) PTS(PT_R + 9 * b + k) = PGS(PG_AUX_R + 9 * b + k);
+              for (int k = 0; k < 9; k++) PTS(PT_R + 9 * g + k) = PGS(PG_AUX_R + 9 * (g ^ perm) + k);
 #pragma unroll
-              for (int k = 0; k < 3; k++) PTS(PT_POS + 3 * b + k) = box[b].pos[k];
+              for (int k = 0; k < 3; k++) PTS(PT_POS + 3 * g + k) = bg.pos[k];
 #pragma unroll
-              for (int k = 0; k < 6; k++) { PTS(PT_VEL + 6 * b + k) = box[b].vel[k]; PTS(PT_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0; }
+              for (int k = 0; k < 6; k++) { PTS(PT_VEL + 6 * g + k) = bg.vel[k]; PTS(PT_A0 + 6 * g + k) = k < 3 ? c.gravity[k] : 0.0; }
             }
 #pragma unroll
             for (int k = 0; k < NDOF; k++) { PTS(PT_VEL + PUSH_ARM0 + k) = st.v[k]; PTS(PT_A0 + PUSH_ARM0 + k) = a0[k]; }
@@ -1538,7 +1567,7 @@ D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, c
               PTS(dst + 6) = PGS(base + 12);
               if (kind == CK_BOXBOX) nbb++;
               else {
-                rod_cube = (int)PGS(base + 14);
+                rod_cube = (int)PGS(base + 14) ^ perm;
                 double R7[9], p7[3], ax[NARM][3], og[NARM][3];
                 world_chain(c0, dyn.sn, dyn.cs, R7, p7, ax, og);
                 double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)}, n[3] = {PGS(base + 3), PGS(base + 4), PGS(base + 5)}, t1[3], t2[3];
@@ -1551,10 +1580,16 @@ D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, c
                 }
               }
             }
-            if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PTS(PT_X + k) = k < PUSH_ARM0 ? cwarm[k] : PWS(k);
+            if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PTS(PT_X + k) = k < PUSH_ARM0 ? cwarm[6 * ((k / 6) ^ perm) + k % 6] : PWS(k);
             else for (int k = 0; k < PUSH_NV; k++) PTS(PT_X + k) = PTS(PT_A0 + k);
-            if (!coupled_newton(pc, sc, nbb, rod_cube, c.rod_invweight0)) st.flags |= F_SOLVER_FAIL;
+            if (has[0] == 0) for (int k = 6; k < 12; k++) PTS(PT_X + k) = PTS(PT_A0 + k);   // group 1 is not part of this lane's system
+            if (!coupled_newton(pc, sc, nbb, rod_cube, c.rod_invweight0, two)) st.flags |= F_SOLVER_FAIL;
             for (int k = PUSH_ARM0; k < PUSH_NV; k++) PWS(k) = PTS(PT_X + k);
+            // hand the cube accelerations over in physical cube order (PT_P is free again)
+            for (int b = 0; b < PUSH_NB; b++) {
+              const int g = b ^ perm;
+              if (g == 0 || has[0] > 0) { solved_mask |= 1 << b; for (int k = 0; k < 6; k++) PTS(PT_P + 6 * b + k) = PTS(PT_X + 6 * g + k); }
+            }
           }
         }
         if (slow) {
@@ -1602,7 +1637,8 @@ D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, c
           if (st.flags & PF_WARM_VALID) for (int k = 0; k < PUSH_NV; k++) PGS(PG_X + k) = k < PUSH_ARM0 ? cwarm[k] : PWS(k);
           else for (int k = 0; k < PUSH_NV; k++) PGS(PG_X + k) = PGS(PG_A0 + k);
           if (!push_general_solve(pc, sc, ncon, has[0] != 0, has[1] != 0, has[2] != 0)) st.flags |= F_SOLVER_FAIL;
-          for (int k = 0; k < PUSH_NV; k++) { double xk = PGS(PG_X + k); PTS(PT_X + k) = xk; if (k >= PUSH_ARM0) PWS(k) = xk; }
+          for (int k = 0; k < PUSH_NV; k++) { double xk = PGS(PG_X + k); if (k < PUSH_ARM0) PTS(PT_P + k) = xk; else { PTS(PT_X + k) = xk; PWS(k) = xk; } }
+          solved_mask = 3;
         }
         {   // constraint force on the arm from the optimality condition M (x - a0) = J' f
           double xa[NDOF], Mx[NDOF];
@@ -1682,7 +1718,7 @@ D3IL_HD bool push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, c
       for (int k = 0; k < NDOF; k++) PWS(PUSH_ARM0 + k) = qacc[k];
   }
   PUSH_TOC(8);
-  return solved;
+  return solved_mask;
 }
 
 // Cube half: one free cube integrates either with its share of the joint solution (table, PT_X) or with its own
@@ -1701,7 +1737,7 @@ D3IL_HD void push_substep_cube(const PushConsts& pc, const double* gravity, doub
     if (!cube_newton(pc, Rb, vb, cs, a0b, xb)) flags |= F_SOLVER_FAIL;
   } else {
 #pragma unroll
-    for (int k = 0; k < 6; k++) xb[k] = PTS(PT_X + 6 * b + k);
+    for (int k = 0; k < 6; k++) xb[k] = PTS(PT_P + 6 * b + k);
   }
 #pragma unroll
   for (int k = 0; k < 6; k++) warm[k] = xb[k];
@@ -1716,7 +1752,7 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
   double cw[12];
   for (int k = 0; k < 12; k++) cw[k] = PWS(k);
   const bool warm_valid = (ps.arm.flags & PF_WARM_VALID) != 0;
-  const bool solved = push_substep_arm(c0, pc, ps.arm, ps.box, cw, sc, tau, ffing);
+  const int solved_mask = push_substep_arm(c0, pc, ps.arm, ps.box, cw, sc, tau, ffing);
   D3IL_REFRESH(c0, c);
   const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
 #pragma unroll
@@ -1724,7 +1760,7 @@ D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& 
     double w6[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) w6[k] = cw[6 * b + k];
-    push_substep_cube(pc, grav, c.timestep, ps.box[b], w6, b, solved, warm_valid, ps.arm.flags, sc);
+    push_substep_cube(pc, grav, c.timestep, ps.box[b], w6, b, ((solved_mask >> b) & 1) != 0, warm_valid, ps.arm.flags, sc);
 #pragma unroll
     for (int k = 0; k < 6; k++) PWS(6 * b + k) = w6[k];
   }

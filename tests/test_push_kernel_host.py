@@ -114,3 +114,27 @@ def test_rare_solver_paths_match_oracle(push_oracle, push_hc, init_qpos, push_co
         assert not (ih["flags"] & ((1 << 16) | (1 << 18))), name
         assert fo[6] >= 4, name
         np.testing.assert_allclose(hc.s[:68], so, atol=1e-6, rtol=0, err_msg=name)
+
+
+def test_pushing_the_green_cube_matches_oracle(push_oracle, push_hc, init_qpos, push_contexts):
+    """The rod on cube 1 exercises the cube-group permutation of the coupled solver (the cube under the rod becomes group 0)."""
+    o, hc = push_oracle, push_hc
+    ctx = push_contexts[5]
+    o.env_start(init_qpos)
+    obs = o.push_reset(ctx)
+    hc.reset(init_qpos, ctx)
+    des = obs[:2].astype(float)
+    moved = False
+    pos_idx = list(range(0, 9)) + list(range(25, 28)) + list(range(42, 49)) + list(range(55, 62))
+    for t in range(45):
+        d = obs[5:7].astype(float) - des
+        n = np.linalg.norm(d)
+        des = des + d / max(n, 1e-9) * min(0.006, n)
+        a = np.concatenate([des, [0.12235931], [0, 1, 0, 0]])
+        obs, _, _, io = o.push_step(a)
+        _, _, _, ih = hc.step(a)
+        so, fo = o.push_state()
+        assert not (ih["flags"] & ((1 << 16) | (1 << 18) | (1 << 19)))
+        np.testing.assert_allclose(hc.s[:68][pos_idx], so[pos_idx], atol=1e-7, rtol=0)
+        moved = moved or abs(so[56] - ctx[8]) > 0.02
+    assert moved
