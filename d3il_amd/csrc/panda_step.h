@@ -138,6 +138,16 @@ D3IL_HD double rcpd(double x) {
   return 1.0 / x;
 #endif
 }
+D3IL_HD double rsqrtd(double x) {   // 1 / sqrt(x), x > 0: v_rsq_f64 + two Newton steps on the device
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
 D3IL_HD int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // packed lower-triangular index, r >= c
 
 // ------------------------------------------------------------------ controller kinematics (URDF chain, core/Model.py:37-66)
@@ -1001,7 +1011,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
 #pragma unroll
     for (int k = 0; k < j; k++) t -= LA[tri(j, k)] * LA[tri(j, k)] * dA[k];
     dA[j] = t; ok = ok && t > 0;
-    double inv = 1.0 / t;
+    double inv = rcpd(t);
     idA[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 5; i++) {
@@ -1032,7 +1042,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
   // s(y), -grad (force) and Hessian blocks: cone on rows 0-2, unilateral quadratics on rows 3-4
   auto eval = [&](const double* y, double* f, double* Hc /*6*/, double* hl /*2*/, bool want_h) {
     double cst = 0;
-    double U0 = y[0] * mu, U1 = y[1] * fr0, U2 = y[2] * fr1, T = sqrt(U1 * U1 + U2 * U2), Nn = U0;
+    double U0 = y[0] * mu, U1 = y[1] * fr0, U2 = y[2] * fr1, T2 = U1 * U1 + U2 * U2, iT = T2 > 0 ? rsqrtd(T2) : 0.0, T = T2 * iT, Nn = U0;
     f[0] = f[1] = f[2] = 0;
     if (want_h) { Hc[0] = Hc[1] = Hc[2] = Hc[3] = Hc[4] = Hc[5] = 0; }
     if (Nn >= mu * T || (T <= 0 && Nn >= 0)) {}
@@ -1041,7 +1051,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
       f[0] = -Dr[0] * y[0]; f[1] = -Dr[1] * y[1]; f[2] = -Dr[2] * y[2];
       if (want_h) { Hc[0] = Dr[0]; Hc[1] = Dr[1]; Hc[2] = Dr[2]; }
     } else {
-      double NmT = Nn - mu * T, iT = 1.0 / T;
+      double NmT = Nn - mu * T;
       double g0 = mu, g1 = -mu * fr0 * U1 * iT, g2 = -mu * fr1 * U2 * iT;
       cst += 0.5 * Dm * NmT * NmT;
       f[0] = -Dm * NmT * g0; f[1] = -Dm * NmT * g1; f[2] = -Dm * NmT * g2;
@@ -1124,7 +1134,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
 #pragma unroll
       for (int k = 0; k < j; k++) t -= LH[tri(j, k)] * LH[tri(j, k)] * dH[k];
       dH[j] = t; ok = ok && t > 0;
-      double inv = 1.0 / t;
+      double inv = rcpd(t);
       idH[j] = inv;
 #pragma unroll
       for (int i = j + 1; i < 5; i++) {
@@ -1166,9 +1176,11 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
       best = alpha;
       // inexact line search: with the exact Hessian the full step passes this test near the optimum, so the outer
       // iteration keeps its quadratic rate; far from it a 1e-3 reduction of the directional derivative is plenty
+      // the full Newton step is taken when phi is still descending there or just past its minimum (curvature condition)
+      if (ls == 0 && d1 <= 0.1 * fabs(gp0)) break;
       if (fabs(d1) <= 1e-3 * fabs(gp0)) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
-      double na = alpha - d1 / d2;
+      double na = alpha - d1 * rcpd(d2);
       if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
       if (hi < 0 && na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
@@ -1177,7 +1189,8 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
     double stepmax = 0, ymax = 0;
 #pragma unroll
     for (int i = 0; i < 5; i++) { y[i] += best * p[i]; stepmax = fmax(stepmax, fabs(best * p[i])); ymax = fmax(ymax, fabs(y[i])); }
-    if (stepmax <= 1e-13 * (1.0 + ymax)) break;
+    // a full step below 1e-6 (relative) leaves an error of the order of its square: the confirming iteration is skipped
+    if (stepmax <= 1e-13 * (1.0 + ymax) || (best == 1.0 && stepmax <= 1e-6 * (1.0 + ymax))) break;
   }
   eval(y, f, nullptr, nullptr, false);
 #pragma unroll

@@ -277,16 +277,6 @@ D3IL_HD void box_row_r(const double* R, const double* r, const double* f, double
 
 // elliptic cone (condim 3, friction mu_geom on both tangents): force and Hessian block at row residuals jar.
 // Returns the cost.  Zones: top (free), bottom (quadratic), middle.
-D3IL_HD double rsqrtd(double x) {   // 1 / sqrt(x), x > 0
-#if defined(__HIP_DEVICE_COMPILE__)
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
-  return y;
-#else
-  return 1.0 / sqrt(x);
-#endif
-}
 D3IL_HD double cone_eval(const double* jar, double Dn, double Dt, double mu, double fric, double* force, double* Hc /* 3x3 */) {
   if (Dn == 0) {   // inert row (inactive contact slot of this lane inside a wave-uniform loop)
 #pragma unroll
