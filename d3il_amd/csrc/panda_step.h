@@ -882,7 +882,7 @@ D3IL_NOINLINE inline bool solve_constraints(const double* __restrict__ M_in, con
 #pragma unroll
         for (int k = 0; k < NARM; k++) s += rc.J[r][k] * p[k]; Jp[r] = s; }
     }
-    double alpha = 0, lo = 0, hi = -1, best = 1;
+    double alpha = 0, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 40; ls++) {
       D3IL_STAT(g_stats.ls_iters++);
       D3IL_DSTAT(6);
@@ -903,8 +903,12 @@ D3IL_NOINLINE inline bool solve_constraints(const double* __restrict__ M_in, con
       if (fabs(d1) <= 1e-14 * fmax(1.0, fabs(pMa))) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 / d2;
-      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
-      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
+        double wbr = hi - lo;
+        bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
       alpha = na;
     }
@@ -1162,7 +1166,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
     double gp0 = 0;
 #pragma unroll
     for (int i = 0; i < 5; i++) gp0 += g[i] * p[i];
-    double alpha = 1, lo = 0, hi = -1, best = 1;   // phi'(0) = g.p < 0 is known: start at the full Newton step
+    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;   // phi'(0) = g.p < 0 is known: start at the full Newton step
     for (int ls = 0; ls < 40; ls++) {
       D3IL_DSTAT(6); D3IL_STAT(g_stats.ls_iters++);
       double yt[5], ft[5], Ht[6], ht[2];
@@ -1181,8 +1185,12 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
       if (fabs(d1) <= 1e-3 * fabs(gp0)) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
-      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
-      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
+        double wbr = hi - lo;
+        bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
       alpha = na;
     }

@@ -470,7 +470,7 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, con
     double gTp = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) gTp += g[k] * p[k];
-    double alpha = 1, lo = 0, hi = -1, best = 1;
+    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 40; ls++) {
       D3IL_STAT(g_stats.ik_calls++);
       double d1 = pMa + alpha * pMp, d2 = pMp;
@@ -493,8 +493,12 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, con
       if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
-      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
-      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
+        double wbr = hi - lo;
+        bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
       alpha = na;
     }
@@ -704,7 +708,7 @@ D3IL_NOINLINE inline bool push_general_solve(const PushConsts& pc, const PushScr
 #pragma unroll
       for (int r = 0; r < 3; r++) PGS(base + 23 + r) = srow_dot_g(sc, rows[r], PG_GRAD);
     }
-    double alpha = 1, lo = 0, hi = -1, best = 1;
+    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 40; ls++) {
       double d1 = pMa + alpha * pMp, d2 = pMp;
       for (int k = 0; k < NDOF; k++) {
@@ -729,8 +733,12 @@ D3IL_NOINLINE inline bool push_general_solve(const PushConsts& pc, const PushScr
       if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
-      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
-      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
+        double wbr = hi - lo;
+        bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
       alpha = na;
     }
@@ -1286,7 +1294,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
     }
     PUSH_TOC(4);
     // ================= phase E: exact line search
-    double alpha = 1, lo = 0, hi = -1, best = 1;
+    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 40; ls++) {
       D3IL_STAT(g_stats.ls_iters++);
       double d1 = pMa + alpha * pMp, d2 = pMp;
@@ -1330,8 +1338,12 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
       if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
-      if (hi >= 0 && !(na > lo && na < hi)) na = 0.5 * (lo + hi);
-      if (hi < 0 && na <= lo) na = 2 * lo + 1;
+      if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
+        double wbr = hi - lo;
+        bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
       if (na == alpha) break;
       alpha = na;
     }

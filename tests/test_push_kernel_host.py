@@ -138,3 +138,21 @@ def test_pushing_the_green_cube_matches_oracle(push_oracle, push_hc, init_qpos, 
         np.testing.assert_allclose(hc.s[:68][pos_idx], so[pos_idx], atol=1e-7, rtol=0)
         moved = moved or abs(so[56] - ctx[8]) > 0.02
     assert moved
+
+
+def test_line_search_regression_state(push_oracle, push_hc, init_qpos):
+    """A mid-push state (recorded from a GPU rollout) where phi'(alpha) of the coupled solve is sigmoid-like: Newton on alpha
+    alone jumps between the two flat sides for ever; the bracket-halving safeguard must converge (no solver-fail flag)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "push_hard_state.npz"))
+    s, fl, step, a = g["state"], int(g["flags"]), int(g["step"]), g["action"]
+    push_hc.s[:68] = s; push_hc.s[68:] = 0
+    push_hc.f[0] = fl & ~(1 << 6)                # no warm start: the recorded one is not part of the fixture
+    push_hc.f[1] = step
+    _, _, _, info = push_hc.step(a)
+    assert not (info["flags"] & (1 << 16))
+    push_oracle.env_start(init_qpos)
+    push_oracle.push_set_state(s, step=step, terminated=False, first_visit=(fl & 7) - 1, ik_valid=True)
+    push_oracle.push_step(a)
+    so, fo = push_oracle.push_state()
+    np.testing.assert_allclose(push_hc.s[:68], so, atol=1e-7, rtol=0)
