@@ -245,3 +245,57 @@ def test_rare_solver_paths_one_step(ctx60, init_qpos, pushing_blob):
             assert not (fl1[e] & BAD), (name, hex(fl1[e]))
             np.testing.assert_allclose(st1[:68, e], so, atol=1e-6, rtol=0, err_msg=name)
     env.close()
+
+
+def test_success_and_first_visit_mode_logic_on_device(ctx60, init_qpos, pushing_blob):
+    """Cubes are placed into the target zones with set_state: first-visit bookkeeping, mode, success, done and mean distance
+    of the device path against the oracle for all four visiting orders."""
+    from oracle.oracle import Oracle
+    o = Oracle(pushing_blob)
+    o.env_start(init_qpos)
+    obs = o.push_reset(ctx60[0])
+    a = np.concatenate([obs[:2].astype(float), [0.12235931], [0, 1, 0, 0]])
+    for t in range(8):
+        o.push_step(a)
+    s0, _ = o.push_state()
+    t1, t2 = np.array([0.42, 0.3]), np.array([0.63, 0.3])
+    # (first cube, its zone, second cube, its zone): rr->gg, gg->rr, rg->gr, gr->rg  => modes 0, 1, 2, 3
+    orders = [((0, t1), (1, t2)), ((1, t2), (0, t1)), ((0, t2), (1, t1)), ((1, t1), (0, t2))]
+    n = len(orders)
+    env = _env(n)
+    env.set_init_qpos(init_qpos)
+    env.reset(context=ctx60[np.zeros(n, dtype=int)])
+    st, fl, sc = env.get_state()
+    oracles = []
+    for e, ((c1, z1), _) in enumerate(orders):
+        s = s0.copy()
+        s[42 + 13 * c1:44 + 13 * c1] = z1 + [0.01, -0.015]; s[44 + 13 * c1] = 0.011
+        st[:68, e] = s; st[68:, e] = 0
+        oo = Oracle(pushing_blob); oo.env_start(init_qpos)
+        oo.push_set_state(s, step=8, terminated=False, first_visit=-1, ik_valid=True)
+        oracles.append(oo)
+    fl[:] = 1 << 15; sc[:] = 8
+    env.set_state(st, fl, sc)
+    act = torch.as_tensor(np.tile(a, (n, 1)), dtype=torch.float64, device=env.device).contiguous()
+    expected_first = [0, 3, 1, 2]
+    for phase in range(3):
+        obs, rew, done, info = env.step(act)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        for e in range(n):
+            oo, ro, do, io = oracles[e].push_step(a)
+            so, fo = oracles[e].push_state()
+            assert bool(done[e]) == do and int(info["mode"][e]) == io["mode"] and bool(info["success"][e]) == io["success"], (phase, e)
+            assert int(fl[e] & 7) - 1 == fo[3] == expected_first[e]
+            assert abs(float(info["mean_distance"][e]) - io["mean_distance"]) < 1e-6
+        if phase == 0:       # now bring the second cube into its zone, in both implementations
+            for e, (_, (c2, z2)) in enumerate(orders):
+                st[42 + 13 * c2:44 + 13 * c2, e] = z2 + [-0.012, 0.01]; st[44 + 13 * c2, e] = 0.011
+                st[49 + 13 * c2:55 + 13 * c2, e] = 0
+                first = int(fl[e] & 7) - 1
+                oracles[e].push_set_state(st[:68, e], step=sc[e], terminated=False, first_visit=first, ik_valid=True)
+            env.set_state(st, fl, sc)
+        if phase == 1:
+            # both cubes are in their zones when the step starts, so is_finished (evaluated before the physics) already reports done
+            assert [int(m) for m in info["mode"].cpu()] == [0, 1, 2, 3] and bool(info["success"].all()) and bool(done.all())
+    env.close()
