@@ -41,6 +41,8 @@ for t in range(400):
     tang = torch.stack((-away[:, 1], away[:, 0]), dim=1)
     tang = tang * torch.sign((tang * (behind - des)).sum(1, keepdim=True) + 1e-12)
     step = torch.where(near, 0.006 * (0.6 * tang + 0.4 * away), step)
+    if os.environ.get("PUSH_POLICY") == "random":     # random walk with a drift towards the current cube: frequent glancing contacts
+        step = 0.5 * step + (torch.rand(n, 2, dtype=torch.float64, device=dev) * 0.02 - 0.01)
     des = des + step
     act = torch.cat([des, z, quat], dim=1).contiguous()
     if os.environ.get("PUSH_TRACE_FAIL"):
