@@ -91,6 +91,11 @@ class Avoiding_Sim(BaseSim):
         success_rate, entropy = avoiding_metrics(int(c[0]), int(c[1]), c[2:])
         self.last_rollout = dict(success=success, mode_code=mode_code, c_pos=c_pos, n_pos=n_pos, counts=c, shard=(lo, hi))
         log.info("Successrate %s entropy %s", success_rate, entropy)
-        successes = success.to(torch.float32)
+        # the reference returns the success flags of all trajectories (avoiding_sim.py:144): shards are put together
+        successes = torch.zeros(self.n_trajectories, dtype=torch.float32, device=dev)
+        successes[lo:hi] = success.to(torch.float32)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(successes)
         env.close()
         return successes, entropy

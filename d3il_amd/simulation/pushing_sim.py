@@ -104,5 +104,12 @@ class Pushing_Sim(BaseSim):
                                  mean_distance_all=float(dist_sum.item()) / total, flags=env.flags[:n].clone())
         log.info("Successrate %s entropy %s mean distance %s", success_rate, entropy, float(dist_sum.item()) / total)
         env.close()
-        shape = (-1, self.n_trajectories_per_context)
-        return success.to(torch.float32).reshape(shape), mode.to(torch.float32).reshape(shape), mean_distance.to(torch.float32).reshape(shape)
+        # the reference returns the full [n_contexts, n_trajectories] tables (pushing_sim.py:178): every rank fills its slice of a
+        # zero table and the slices are summed (one more small all-reduce, outside the rollout)
+        full = torch.zeros(3, total, dtype=torch.float64, device=dev)
+        full[0, lo:hi], full[1, lo:hi], full[2, lo:hi] = success.to(torch.float64), mode.to(torch.float64), mean_distance
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(full)
+        shape = (self.n_contexts, self.n_trajectories_per_context)
+        return full[0].to(torch.float32).reshape(shape), full[1].to(torch.float32).reshape(shape), full[2].to(torch.float32).reshape(shape)

@@ -1,0 +1,60 @@
+"""Worker for the multi-process GPU test: one rank of a torch.distributed job running the batched Sim classes.
+
+Launched by tests/test_gpu_multiprocess.py through `python -m torch.distributed.run`; every rank uses cuda:0 (the GPU box has
+one GPU) with the gloo backend, which exercises the same sharding / all-reduce code path as one-rank-per-GPU with RCCL."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from d3il_amd import distributed as D  # noqa: E402
+from d3il_amd.simulation.avoiding_sim import Avoiding_Sim  # noqa: E402
+from d3il_amd.simulation.pushing_sim import Pushing_Sim  # noqa: E402
+
+
+class ChaseAgent:
+    """deterministic batched policy for Pushing: walk towards the red cube"""
+
+    def reset(self):
+        pass
+
+    def predict_batch(self, obs10):
+        d = obs10[:, 4:6] - obs10[:, 0:2]
+        n = d.norm(dim=1, keepdim=True).clamp_min(1e-9)
+        return d / n * torch.minimum(n, torch.full_like(n, 0.006))
+
+
+class WiggleAgent:
+    """deterministic batched policy for Avoiding: forward drift with an obs-dependent lateral wiggle"""
+
+    def reset(self):
+        pass
+
+    def predict_batch(self, obs4):
+        x, y = obs4[:, 2], obs4[:, 3]
+        return torch.stack((0.006 * torch.sin(40.0 * y), torch.full_like(y, 0.004)), dim=1)
+
+
+def main():
+    rank, world = D.init_from_env("gloo")
+    out = {}
+    sim = Pushing_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=9, n_trajectories_per_context=2, max_steps_per_episode=40)
+    succ, mode, dist = sim.test_agent(ChaseAgent())
+    r = sim.last_rollout
+    out["pushing"] = dict(counts=[int(v) for v in r["counts"]], success_rate=r["success_rate"], entropy=r["entropy"],
+                          mean_distance=r["mean_distance_all"], shard=list(r["shard"]))
+    sim2 = Avoiding_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_trajectories=37, max_steps_per_episode=60)
+    successes, entropy = sim2.test_agent(WiggleAgent())
+    r2 = sim2.last_rollout
+    out["avoiding"] = dict(counts=[int(v) for v in r2["counts"]], entropy=float(entropy), shard=list(r2["shard"]))
+    if rank == 0:
+        print("RESULT " + json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
