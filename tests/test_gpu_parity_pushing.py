@@ -299,3 +299,27 @@ def test_success_and_first_visit_mode_logic_on_device(ctx60, init_qpos, pushing_
             # both cubes are in their zones when the step starts, so is_finished (evaluated before the physics) already reports done
             assert [int(m) for m in info["mode"].cpu()] == [0, 1, 2, 3] and bool(info["success"].all()) and bool(done.all())
     env.close()
+
+
+def test_random_contexts_and_large_batch(init_qpos):
+    """reset(random=True) draws contexts from the spaces of BlockContextManager.sample; a 16384-env batch steps cleanly."""
+    from d3il_amd.envs.pushing import sample_contexts
+    c = sample_contexts(500, seed=3)
+    assert np.all((c[:, 0] >= 0.4) & (c[:, 0] <= 0.5) & (c[:, 7] >= 0.55) & (c[:, 7] <= 0.65))
+    assert np.all((c[:, [1, 8]] >= -0.15) & (c[:, [1, 8]] <= 0.0)) and np.all(c[:, [2, 9]] == 0)
+    np.testing.assert_allclose(np.linalg.norm(c[:, 3:7], axis=1), 1, atol=1e-12)
+    n = 16384
+    env = _env(n)
+    env.set_init_qpos(init_qpos)
+    obs = env.reset(random=True)
+    torch.cuda.synchronize()
+    assert obs.shape == (n, 8) and bool(torch.isfinite(obs).all())
+    des = env.robot_state()[:, :2].clone()
+    z = env.robot_state()[:, 2:3].clone()
+    for t in range(3):
+        des = _chase(env, des)
+        obs, rew, done, info = env.step(_action(des, z))
+    torch.cuda.synchronize()
+    st, fl, sc = env.get_state()
+    assert np.isfinite(st).all() and not np.any(fl & BAD) and np.all(sc == 3)
+    env.close()
