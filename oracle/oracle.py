@@ -254,3 +254,43 @@ class Oracle:
     def push_set_state(self, s68, step=0, terminated=False, first_visit=-1, ik_valid=True):
         s68 = np.ascontiguousarray(s68, float)
         self.L.orc_push_set_state(self.h, _p(s68), int(step), int(terminated), int(first_visit), int(ik_valid))
+
+
+class SortLogic:
+    """Sorting task logic with injected poses (oracle/d3il_oracle.c orc_sort_logic)."""
+
+    def __init__(self, num_boxes):
+        self.L = lib()
+        self.st = (C.c_int * 14)()
+        self.num_boxes = num_boxes
+        self.reset()
+
+    def reset(self):
+        self.L.orc_sort_reset(self.st)
+
+    def step(self, box42, tcp):
+        box42, tcp = np.ascontiguousarray(box42, float).reshape(42), np.ascontiguousarray(tcp, float)
+        obs = np.zeros(2 + 3 * self.num_boxes, dtype=np.float32)
+        succ, code = C.c_int(0), C.c_int(0)
+        self.L.orc_sort_logic(self.st, _p(box42), _p(tcp), self.num_boxes, _p(obs), C.byref(succ), C.byref(code))
+        return obs, bool(succ.value), code.value
+
+
+class StackLogic:
+    """Stacking task logic with injected poses (orc_stack_logic)."""
+
+    def __init__(self):
+        self.L = lib()
+        self.st = (C.c_int * 5)()
+        self.reset()
+
+    def reset(self):
+        self.L.orc_stack_reset(self.st)
+
+    def step(self, box21, target):
+        box21, target = np.ascontiguousarray(box21, float).reshape(21), np.ascontiguousarray(target, float)
+        obs = np.zeros(12, dtype=np.float32)
+        succ, md = C.c_int(0), C.c_double(0)
+        mode = C.create_string_buffer(4)
+        self.L.orc_stack_logic(self.st, _p(box21), _p(target), _p(obs), C.byref(succ), C.byref(md), mode)
+        return obs, bool(succ.value), md.value, mode.value.decode()

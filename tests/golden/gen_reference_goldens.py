@@ -405,6 +405,94 @@ def gen_sorting_stacking_metrics():
           {k: round(v, 5) for k, v in out.items() if k.startswith("stack_") and np.ndim(v) == 0})
 
 
+def gen_sort_stack_task():
+    """Sorting_Env / Stacking env task logic (sorting.py:308-390,444-543; stacking.py:228-277,395-447) driven with synthetic box
+    poses through a fake scene.  Boxes that are not in the model get one constant pose, as MjScene does for body id -1."""
+    from envs.gym_sorting_env.gym_sorting.envs.sorting import Sorting_Env
+    from envs.gym_stacking_env.gym_stacking.envs.stacking import CubeStacking_Env
+
+    rng = np.random.default_rng(21)
+    out = {}
+    names = ["r1", "r2", "r3", "b1", "b2", "b3"]
+    bogus = (np.array([0.0088, -0.0001, 0.0584]), np.array([1.0, 0, 0, 0]))
+    for nb in (2, 4, 6):
+        env = object.__new__(Sorting_Env)
+        env.num_boxes, env.if_vision = nb, False
+        env.red_box_1, env.red_box_2, env.red_box_3, env.blue_box_1, env.blue_box_2, env.blue_box_3 = names
+        env.red_target_pos, env.blue_target_pos = np.array([0.4, 0.32]), np.array([0.625, 0.32])
+        poses = {}
+        scene = type("S", (), {})()
+        scene.get_obj_pos = lambda o: poses[o][0].copy()
+        scene.get_obj_quat = lambda o: poses[o][1].copy()
+        env.scene = scene
+        tcp = np.zeros(3)
+        env.robot_state = lambda: tcp.copy()
+        E, T = 18, 56
+        present = names[:nb // 2] + names[3:3 + nb // 2]
+        box = np.zeros((E, T, 6, 7)); rob = np.zeros((E, T, 3))
+        obs = np.zeros((E, T, 2 + 3 * nb), dtype=np.float32); succ = np.zeros((E, T), dtype=bool); code = np.zeros((E, T), dtype=np.int64)
+        for e in range(E):
+            env.mode = np.array([-1, -1, -1, -1, -1, -1]); env.mode_step = 0; env.min_inds = []; env.terminated = False
+            p = {k: np.array([rng.uniform(0.4, 0.65), rng.uniform(-0.15, 0.1), 0.13]) for k in present}
+            yaw = {k: rng.uniform(-np.pi, np.pi) for k in present}
+            order = list(rng.permutation(present))
+            wrong = e % 5 == 0                      # sometimes a cube goes into the other colour's bin
+            for t in range(T):
+                mover = order[min(len(order) - 1, t * len(order) // T)]
+                red = mover.startswith("r")
+                goal = np.array([0.4 if (red != wrong) else 0.625, 0.315, -0.008]) + 0.0
+                p[mover] = p[mover] + 0.12 * (goal - p[mover]) + rng.normal(scale=0.004, size=3) * (e % 3 != 1)
+                for k in names:
+                    if k in present:
+                        yaw[k] += rng.normal(scale=0.05)
+                        poses[k] = (p[k].copy(), np.array([np.cos(yaw[k] / 2), 0.01 * (e % 2), 0, np.sin(yaw[k] / 2)]))
+                    else:
+                        poses[k] = (bogus[0].copy(), bogus[1].copy())
+                    box[e, t, names.index(k), :3], box[e, t, names.index(k), 3:] = poses[k]
+                tcp[:] = rng.uniform([0.3, -0.4, 0.2], [0.8, 0.45, 0.3]); rob[e, t] = tcp
+                obs[e, t] = env.get_observation()
+                succ[e, t] = env._check_early_termination()
+                mode, min_inds = env.check_mode()
+                code[e, t] = env.decode_mode(mode[:nb])
+        out.update({"sort%d_box" % nb: box, "sort%d_rob" % nb: rob, "sort%d_obs" % nb: obs, "sort%d_succ" % nb: succ, "sort%d_code" % nb: code})
+        print("sorting-%d: codes %s successes %d" % (nb, np.unique(code)[:12], succ.sum()))
+    # ---- stacking
+    env = object.__new__(CubeStacking_Env)
+    env.if_vision = False
+    env.red_box, env.green_box, env.blue_box, env.target_box = "r", "g", "b", "t"
+    env.pos_min_dist = 0.06
+    poses = {"t": (np.array([0.55, 0.2, 0.0]), np.array([1.0, 0, 0, 0]))}
+    scene = type("S", (), {})()
+    scene.get_obj_pos = lambda o: poses[o][0].copy()
+    scene.get_obj_quat = lambda o: poses[o][1].copy()
+    env.scene = scene
+    env.robot_state = lambda: (np.zeros(8), np.zeros(7), np.array([0.0, 1, 0, 0]))
+    E, T = 24, 60
+    box = np.zeros((E, T, 3, 7)); obs = np.zeros((E, T, 12), dtype=np.float32); succ = np.zeros((E, T), dtype=bool)
+    md = np.zeros((E, T)); modes = np.zeros((E, T), dtype="U3")
+    for e in range(E):
+        env.min_inds = []; env.mode_encoding = []; env.terminated = False
+        p = {k: np.array([rng.uniform(0.35, 0.65), rng.uniform(-0.2, 0.0), 0.03]) for k in "rgb"}
+        yaw = {k: rng.uniform(-np.pi, np.pi) for k in "rgb"}
+        order = list(rng.permutation(list("rgb")))
+        for t in range(T):
+            lvl = min(2, t * 3 // T)
+            mover = order[lvl]
+            goal = np.array([0.55, 0.2, 0.03 + 0.06 * lvl * (e % 4 != 3)]) + rng.normal(scale=0.01, size=3) * (e % 6 == 5)
+            p[mover] = p[mover] + 0.15 * (goal - p[mover]) + rng.normal(scale=0.003, size=3)
+            for i, k in enumerate("rgb"):
+                yaw[k] += rng.normal(scale=0.04)
+                poses[k] = (p[k].copy(), np.array([np.cos(yaw[k] / 2), 0, 0.01 * (e % 2), np.sin(yaw[k] / 2)]))
+                box[e, t, i, :3], box[e, t, i, 3:] = poses[k]
+            obs[e, t] = env.get_observation()
+            succ[e, t] = env._check_early_termination()
+            m, md[e, t] = env.check_mode()
+            modes[e, t] = "".join(m)
+    out.update(stack_box=box, stack_obs=obs, stack_succ=succ, stack_md=md, stack_mode=modes, stack_target=poses["t"][0])
+    print("stacking: modes %s successes %d" % (np.unique(modes[:, -1]), succ.sum()))
+    np.savez_compressed(os.path.join(HERE, "ref_sort_stack_task.npz"), **out)
+
+
 if __name__ == "__main__":
     gen_ik()
     gen_pd_finger()
@@ -412,3 +500,4 @@ if __name__ == "__main__":
     gen_avoiding_task()
     gen_pushing_task()
     gen_sorting_stacking_metrics()
+    gen_sort_stack_task()
