@@ -238,6 +238,8 @@ def pack(js: dict) -> ModelBlob:
     b.n_obj = len(objs)
     for i, o in enumerate(objs):
         b.obj_body[i] = bname[o]
+    if js["task"] == "sorting":
+        b.task_f[0] = tc["num_boxes"]
     if js["task"] == "pushing":
         for k in range(3):
             b.task_f[k], b.task_f[3 + k] = tc["target_pos1"][k], tc["target_pos2"][k]

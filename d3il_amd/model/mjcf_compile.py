@@ -469,6 +469,39 @@ def build_pushing():
     return to_blob(m, "pushing", tc)
 
 
+def sorting_objects(num_boxes=4):
+    """sorting_objects.py:5-228 restated as data, in the order Sorting_Env builds its object list (sorting.py:208-215):
+    red boxes, blue boxes, the eight bin walls, the platform (models/mj/common-objects/sorting/platform.xml with the pose
+    SortingObject.mj_load overrides: pos 0.5 -0.1 0, quat 1 0 0 0)."""
+    n = num_boxes // 2
+    objs = []
+    for colour in ("red", "blue"):
+        for i in range(n):
+            objs.append(prim_body("%s_%d" % (colour, i + 1), "box", [0.5, -0.1, 0.0], [0, 1, 0, 0], [0.03, 0.03, 0.03], mass=0.05))
+    walls = [([0.4, 0.41, 0.0], [0.1, 0.01, 0.1]), ([0.3, 0.32, 0.0], [0.005, 0.1, 0.1]), ([0.5, 0.32, 0.0], [0.005, 0.1, 0.1]),
+             ([0.4, 0.22, 0.0], [0.1, 0.005, 0.1]), ([0.625, 0.41, 0.0], [0.1, 0.01, 0.1]), ([0.525, 0.32, 0.0], [0.005, 0.1, 0.1]),
+             ([0.725, 0.32, 0.0], [0.005, 0.1, 0.1]), ([0.625, 0.22, 0.0], [0.1, 0.005, 0.1])]
+    for i, (pos, size) in enumerate(walls):
+        objs.append(prim_body("target_box_%d" % (i + 1), "box", pos, [0, 1, 0, 0], size, mass=0.05, static=True))
+    platform = ET.Element("body", name="platform", pos="0.5 -0.1 0.0", quat="1 0 0 0")
+    ET.SubElement(platform, "geom", pos="0 0 0", size="0.3 0.3 0.1", type="box", mass="10", friction="0.3 0.001 0.0001", priority="1")
+    objs.append(platform)
+    return objs
+
+
+def build_sorting(num_boxes=4):
+    m = build_scene("panda_rod_invisible.xml", sorting_objects(num_boxes), "sorting")
+    n = num_boxes // 2
+    tc = dict(
+        n_substeps=35, max_steps=700,                        # sorting.py:195, configs/sorting_4_config.yaml:80
+        init_end_eff_pos=[0.525, -0.3, 0.25], init_end_eff_quat=[0, 1, 0, 0],   # sorting_objects.py:11
+        rod_geom="rod:geom_rb0", tcp_body="tcp_rb0",
+        objects=["red_%d" % (i + 1) for i in range(n)] + ["blue_%d" % (i + 1) for i in range(n)],
+        num_boxes=num_boxes,
+    )
+    return to_blob(m, "sorting", tc)
+
+
 def main():
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "blobs")
     os.makedirs(out_dir, exist_ok=True)
@@ -480,6 +513,10 @@ def main():
     with open(os.path.join(out_dir, "pushing.json"), "w") as f:
         json.dump(blob, f, indent=1)
     print("pushing: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
+    blob = build_sorting(4)
+    with open(os.path.join(out_dir, "sorting.json"), "w") as f:
+        json.dump(blob, f, indent=1)
+    print("sorting-4: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
 
 
 if __name__ == "__main__":

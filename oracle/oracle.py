@@ -115,12 +115,12 @@ class Oracle:
         return xpos, xquat, invw
 
     def contacts(self):
-        out = np.zeros((40, 10))
+        out = np.zeros((96, 10))
         n = self.L.orc_get_contacts(self.h, _p(out))
         return out[:n]
 
     def efc(self):
-        f, a, d = np.zeros(160), np.zeros(160), np.zeros(160)
+        f, a, d = np.zeros(320), np.zeros(320), np.zeros(320)
         n = self.L.orc_get_efc(self.h, _p(f), _p(a), _p(d))
         return f[:n], a[:n], d[:n]
 
@@ -243,6 +243,20 @@ class Oracle:
         self.L.orc_push_logic(self.h, _p(box14), _p(tcp), int(reset), _p(obs), C.byref(succ), C.byref(mode), C.byref(first),
                               C.byref(md), C.byref(rew))
         return obs, bool(succ.value), mode.value, first.value, md.value, rew.value
+
+    # ---- env level (Sorting; oracle only so far)
+    def sort_reset(self, ctx):
+        ctx = np.ascontiguousarray(ctx, float).reshape(-1)
+        obs = np.zeros(2 + 3 * (len(ctx) // 7), dtype=np.float32)
+        self.L.orc_sortenv_reset(self.h, _p(ctx), _p(obs))
+        return obs
+
+    def sort_step(self, action):
+        action = np.ascontiguousarray(action, float)
+        obs = np.zeros(2 + 3 * self.blob.n_obj, dtype=np.float32)
+        done, code, succ = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.L.orc_sortenv_step(self.h, _p(action), _p(obs), C.byref(done), C.byref(code), C.byref(succ))
+        return obs, bool(done.value), dict(mode=code.value, success=bool(succ.value))
 
     def push_state(self):
         s = np.zeros(42 + 13 * 2)
