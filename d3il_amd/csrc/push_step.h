@@ -225,24 +225,50 @@ D3IL_HD bool cyl_box(const double* pc, const double* axis, double rad, double ha
                      double margin, double* out) {
   double c[3], u[3], rel[3] = {pc[0] - pb[0], pc[1] - pb[1], pc[2] - pb[2]};
   for (int i = 0; i < 3; i++) { double col[3] = {Rb[i], Rb[3 + i], Rb[6 + i]}; c[i] = dot3(rel, col); u[i] = dot3(axis, col); }
-  double T[8]; int nt = 0;
-  T[nt++] = -half; T[nt++] = half;
-  for (int i = 0; i < 3; i++) if (fabs(u[i]) > 1e-14) for (int sg = -1; sg <= 1; sg += 2) { double t = (sg * sb[i] - c[i]) / u[i]; if (t > -half && t < half) T[nt++] = t; }
-  for (int a = 1; a < nt; a++) { double v = T[a]; int b = a - 1; while (b >= 0 && T[b] > v) { T[b + 1] = T[b]; b--; } T[b + 1] = v; }
+  // candidate parameters: the two ends and the (up to six) crossings of the box's face planes; invalid ones collapse onto +half.
+  // Sorted with a fixed 19-comparator network and scanned with unrolled loops: everything stays in registers.
+  double T[8];
+  T[0] = -half; T[7] = half;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    bool okc = fabs(u[i]) > 1e-14;
+    double iu = okc ? 1.0 / u[i] : 0.0;
+    double ta = (sb[i] - c[i]) * iu, tb = (-sb[i] - c[i]) * iu;
+    T[1 + 2 * i] = (okc && ta > -half && ta < half) ? ta : half;
+    T[2 + 2 * i] = (okc && tb > -half && tb < half) ? tb : half;
+  }
+#define PUSH_CE(a, b) { double lo_ = fmin(T[a], T[b]), hi_ = fmax(T[a], T[b]); T[a] = lo_; T[b] = hi_; }
+  PUSH_CE(0, 1) PUSH_CE(2, 3) PUSH_CE(4, 5) PUSH_CE(6, 7) PUSH_CE(0, 2) PUSH_CE(1, 3) PUSH_CE(4, 6) PUSH_CE(5, 7) PUSH_CE(1, 2) PUSH_CE(5, 6)
+  PUSH_CE(0, 4) PUSH_CE(3, 7) PUSH_CE(1, 5) PUSH_CE(2, 6) PUSH_CE(1, 4) PUSH_CE(3, 6) PUSH_CE(2, 4) PUSH_CE(3, 5) PUSH_CE(3, 4)
+#undef PUSH_CE
   double G[8];
-  for (int k = 0; k < nt; k++) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
     double g = 0;
+#pragma unroll
     for (int i = 0; i < 3; i++) { double x = c[i] + T[k] * u[i], cl = x > sb[i] ? sb[i] : (x < -sb[i] ? -sb[i] : x); g += u[i] * (x - cl); }
     G[k] = g;
   }
   const double tol = 1e-13;
-  double tm, tp;
-  { int k = 0; while (k < nt && G[k] < -tol) k++;
-    if (k == 0) tm = T[0]; else if (k == nt) tm = T[nt - 1];
-    else tm = G[k] > tol ? T[k - 1] + (T[k] - T[k - 1]) * (-G[k - 1]) / (G[k] - G[k - 1]) : T[k]; }
-  { int k = nt - 1; while (k >= 0 && G[k] > tol) k--;
-    if (k == nt - 1) tp = T[nt - 1]; else if (k < 0) tp = T[0];
-    else tp = G[k] < -tol ? T[k] + (T[k + 1] - T[k]) * (-G[k]) / (G[k + 1] - G[k]) : T[k]; }
+  double tm = T[7], tp = T[0];
+  {   // smallest t with g(t) >= 0: first candidate with G >= -tol, interpolated from its predecessor when it is beyond the root
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      bool hit = !found && !(G[k] < -tol);
+      if (hit) tm = (k == 0 || !(G[k] > tol)) ? T[k] : T[k > 0 ? k - 1 : 0] + (T[k] - T[k > 0 ? k - 1 : 0]) * (-G[k > 0 ? k - 1 : 0]) / (G[k] - G[k > 0 ? k - 1 : 0]);
+      found = found || hit;
+    }
+  }
+  {   // largest t with g(t) <= 0, scanning from the upper end
+    bool found = false;
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+      bool hit = !found && !(G[k] > tol);
+      if (hit) tp = (k == 7 || !(G[k] < -tol)) ? T[k] : T[k] + (T[k < 7 ? k + 1 : 7] - T[k]) * (-G[k]) / (G[k < 7 ? k + 1 : 7] - G[k]);
+      found = found || hit;
+    }
+  }
   double ts = 0.5 * (tm + tp), x[3], q[3], df[3], len = 0;
   for (int i = 0; i < 3; i++) { x[i] = c[i] + ts * u[i]; q[i] = x[i] > sb[i] ? sb[i] : (x[i] < -sb[i] ? -sb[i] : x[i]); df[i] = x[i] - q[i]; len += df[i] * df[i]; }
   len = sqrt(len);

@@ -125,4 +125,16 @@ void hc_push_substep(void* h, double* s, int* f, const double* tau, const double
   push_physics_substep(p->c, p->pc, ps, sc, tau, ffing); push_pack(ps, s, f);
   (void)ncon_out;
 }
+// collision routines of push_step.h on their own (quaternions in, same record layout as the oracle's test hooks)
+int hc_cyl_box(const double* pc, const double* qc, double rad, double half, const double* pb, const double* qb, const double* sb, double margin, double* out) {
+  double Rc[9], Rb[9]; quat2mat(qc, Rc); quat2mat(qb, Rb);
+  double axis[3] = {Rc[2], Rc[5], Rc[8]};
+  return cyl_box(pc, axis, rad, half, pb, Rb, sb, margin, out) ? 1 : 0;
+}
+int hc_box_box(const double* p1, const double* q1, const double* s1, const double* p2, const double* q2, const double* s2, double margin, double* out) {
+  double R1[9], R2[9], rec[16][7]; quat2mat(q1, R1); quat2mat(q2, R2);
+  int n = box_box(p1, R1, s1, p2, R2, s2, margin, rec, 16);
+  std::memcpy(out, rec, n * 7 * sizeof(double));
+  return n;
+}
 }

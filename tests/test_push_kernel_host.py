@@ -156,3 +156,47 @@ def test_line_search_regression_state(push_oracle, push_hc, init_qpos):
     push_oracle.push_step(a)
     so, fo = push_oracle.push_state()
     np.testing.assert_allclose(push_hc.s[:68], so, atol=1e-7, rtol=0)
+
+
+def test_device_collision_routines_equal_the_oracle_ones():
+    """box_box / cyl_box of push_step.h (register-only variants: sorting network, unrolled scans) against the oracle's."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from tests.hostcheck.hostcheck import lib, _p
+    L = lib()
+    rng = np.random.default_rng(9)
+
+    def rq():
+        q = rng.standard_normal(4)
+        return q / np.linalg.norm(q)
+
+    n_c = n_b = 0
+    for it in range(600):
+        sb = rng.uniform(0.02, 0.05, 3)
+        qb, qc = rq(), rq()
+        if it % 3 == 0:                     # upright rod next to an upright yawed cube: the regime of the task (parallel axes)
+            yaw = rng.uniform(-np.pi, np.pi)
+            qb, qc = np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]), np.array([0.0, 1, 0, 0])
+        pb = rng.uniform(-0.1, 0.1, 3)
+        pc = pb + rng.uniform(-0.08, 0.08, 3) + np.array([0, 0, 0.12]) * (it % 3 == 0)
+        a = [np.ascontiguousarray(v, float) for v in (pc, qc, pb, qb, sb)]
+        out = np.zeros(7)
+        hit = L.hc_cyl_box(_p(a[0]), _p(a[1]), C.c_double(0.01), C.c_double(0.15), _p(a[2]), _p(a[3]), _p(a[4]), C.c_double(0.02), _p(out))
+        ref = orc.cyl_box(pc, qc, 0.01, 0.15, pb, qb, sb, margin=0.02)
+        assert bool(hit) == (ref is not None)
+        if hit:
+            n_c += 1
+            np.testing.assert_allclose(out, ref, atol=1e-12)
+        s1, s2 = rng.uniform(0.02, 0.06, 3), rng.uniform(0.02, 0.06, 3)
+        q1, q2 = rq(), rq()
+        p1 = rng.uniform(-0.1, 0.1, 3)
+        p2 = p1 + rng.uniform(-0.07, 0.07, 3)
+        b = [np.ascontiguousarray(v, float) for v in (p1, q1, s1, p2, q2, s2)]
+        out2 = np.zeros((16, 7))
+        n = L.hc_box_box(*[_p(v) for v in b], C.c_double(0.0), _p(out2))
+        ref2 = orc.box_box(p1, q1, s1, p2, q2, s2)
+        assert n == len(ref2)
+        if n:
+            n_b += 1
+            np.testing.assert_allclose(out2[:n], ref2, atol=1e-12)
+    assert n_c > 100 and n_b > 100
