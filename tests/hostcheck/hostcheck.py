@@ -11,7 +11,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libd3il_hostcheck.so")
-    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "push_step.h")]
+    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "push_step.h", "gen_step.h")]
     srcs.append(os.path.join(_HERE, "..", "..", "include", "d3il_model_blob.h"))
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
@@ -109,3 +109,44 @@ class PushHostCheck:
         fl = int(self.f[0]) & 0xFFFFFFFF
         info = dict(mode=((fl >> 3) & 7) - 1, success=bool(fl & (1 << 13)), mean_distance=md.value, first_visit=(fl & 7) - 1, flags=fl)
         return obs, rew.value, bool(done.value), info
+
+
+class GenHostCheck:
+    """Host build of the generic engine (d3il_amd/csrc/gen_step.h) running the Sorting task, one environment."""
+
+    def __init__(self, blob):
+        self.L = lib()
+        self.L.hc_gen_create.restype = C.c_void_p
+        err = C.c_char_p()
+        self.h = C.c_void_p(self.L.hc_gen_create(C.byref(blob), C.byref(err)))
+        if not self.h:
+            raise RuntimeError("hc_gen_create: %s" % (err.value.decode() if err.value else "?"))
+        nb, ns = C.c_int(0), C.c_int(0)
+        st = np.zeros((16, 7))
+        self.n = self.L.hc_gen_info(self.h, C.byref(nb), C.byref(ns), _p(st))
+        self.nb, self.ns, self.statics = nb.value, ns.value, st[: ns.value].copy()
+        self.n_obs = 2 + 3 * self.nb
+        self.s = np.zeros(self.n)
+        self.f = np.zeros(4, dtype=np.int32)
+
+    def reset(self, init_qpos, ctx):
+        init_qpos, ctx = np.ascontiguousarray(init_qpos, float), np.ascontiguousarray(ctx, float).reshape(7 * self.nb)
+        obs = np.zeros(20, dtype=np.float32)
+        self.L.hc_gen_reset(self.h, _p(init_qpos), _p(ctx), _p(self.s), _p(self.f), _p(obs))
+        return obs[: self.n_obs]
+
+    def step(self, action, fast=True):
+        action = np.ascontiguousarray(action, float)
+        obs = np.zeros(20, dtype=np.float32)
+        done, code = C.c_ubyte(0), C.c_int(0)
+        self.L.hc_gen_step(self.h, _p(self.s), _p(self.f), _p(action), _p(obs), C.byref(done), C.byref(code), int(fast))
+        fl = int(self.f[0]) & 0xFFFFFFFF
+        return obs[: self.n_obs], bool(done.value), dict(mode=code.value, success=bool(fl & (1 << 13)), flags=fl)
+
+    def substep(self, tau, ff):
+        tau, ff = np.ascontiguousarray(tau, float), np.ascontiguousarray(ff, float)
+        self.L.hc_gen_substep(self.h, _p(self.s), _p(self.f), _p(tau), _p(ff))
+
+    def box(self, b):
+        o = 42 + 13 * b
+        return self.s[o:o + 3], self.s[o + 3:o + 7], self.s[o + 7:o + 13]

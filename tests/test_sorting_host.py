@@ -1,0 +1,77 @@
+"""Generic engine of the Sorting kernel (d3il_amd/csrc/gen_step.h) built for the host, against the oracle: scene constants,
+the reset transient, and a scripted push that takes a cube over the platform edge into its bin (same trajectory, same
+observation, same completion-order mode code)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from tests.hostcheck.hostcheck import GenHostCheck
+from tests.test_sorting_oracle import CTX, sort_blob, sort_init_qpos  # noqa: F401  (fixtures)
+
+
+def _state_err(h, o):
+    qp, qv = o.state()
+    e = 0.0
+    for b in range(h.nb):
+        p, q, v = h.box(b)
+        e = max(e, np.abs(p - qp[7 * b:7 * b + 3]).max(), np.abs(q - qp[7 * b + 3:7 * b + 7]).max(), 1e-2 * np.abs(v - qv[6 * b:6 * b + 6]).max())
+    return max(e, np.abs(h.s[:9] - qp[7 * h.nb:7 * h.nb + 9]).max())
+
+
+def test_scene_constants(sort_blob):
+    h = GenHostCheck(sort_blob)
+    assert (h.nb, h.ns) == (4, 11)
+    st = h.statics
+    # table_plane and support_body precede the cubes in the model (geom 1 of a pair), walls and platform follow them
+    assert st[:, 6].tolist() == [1, 1] + [0] * 9
+    np.testing.assert_allclose(st[0, :6], [0.4, 0, -0.02, 0.49, 0.98, 0.001], atol=1e-12)
+    np.testing.assert_allclose(st[10, :6], [0.5, -0.1, 0.0, 0.3, 0.3, 0.1], atol=1e-12)
+    assert sorted(np.round(st[2:10, 3:5].min(axis=1), 3).tolist()) == [0.005] * 6 + [0.01] * 2
+
+
+def test_reset_and_hop(sort_blob, sort_init_qpos):
+    o = Oracle(sort_blob)
+    o.env_start(sort_init_qpos)
+    h = GenHostCheck(sort_blob)
+    obs_o = o.sort_reset(CTX)
+    obs_h = h.reset(sort_init_qpos, CTX)
+    assert obs_h.shape == (14,) and np.array_equal(obs_o, obs_h)
+    z = float(o.body(sort_blob.tcp_body)[0][2])
+    a = np.concatenate([obs_o[:2].astype(float), [z], [0, 1, 0, 0]])
+    for t in range(14):                               # cubes leave the platform box through its top, fly ~5 cm, land
+        oo, do, io = o.sort_step(a)
+        oh, dh, ih = h.step(a, fast=bool(t % 2))
+        assert _state_err(h, o) < 1e-12 and np.array_equal(oo, oh) and do == dh and io["mode"] == ih["mode"] == 240
+        assert not (ih["flags"] & 0x1F0000)           # no solver failure, overflow or off-table flag
+
+
+def test_scripted_push_into_the_bin(sort_blob, sort_init_qpos):
+    o = Oracle(sort_blob)
+    o.env_start(sort_init_qpos)
+    h = GenHostCheck(sort_blob)
+    obs = o.sort_reset(CTX)
+    h.reset(sort_init_qpos, CTX)
+    z = float(o.body(sort_blob.tcp_body)[0][2])
+    des = obs[:2].astype(float)
+    code = 240
+    for t in range(170):
+        box = obs[2:4].astype(float)
+        if t < 12:
+            target = des.copy()
+        else:
+            aligned = abs(des[0] - box[0]) < 0.008 and des[1] < box[1] - 0.02
+            target = np.array([box[0], 0.36]) if aligned else box + np.array([0.0, -0.06])
+        d = target - des
+        n = np.linalg.norm(d)
+        des = des + d / max(n, 1e-9) * min(0.006, n)
+        a = np.concatenate([des, [z], [0, 1, 0, 0]])
+        obs, done, info = o.sort_step(a)
+        oh, dh, ih = h.step(a)
+        # rod on cube, cube sliding over the platform edge and dropping between the bin walls: two f64 formulations of the
+        # same solve drift apart slowly (cf. Pushing); the bound is generous against the observed 2e-8
+        assert _state_err(h, o) < 1e-6 and np.abs(obs - oh).max() < 1e-6 and done == dh and info["mode"] == ih["mode"]
+        assert not (ih["flags"] & 0x1F0000)
+        code = info["mode"]
+        if code != 240:
+            break
+    assert code == 0b01110000 and ih["success"] is False
