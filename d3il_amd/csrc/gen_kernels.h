@@ -1,0 +1,151 @@
+// gen_kernels.h - HIP kernels of the Sorting task on the generic engine (included by rollout.hip).
+//
+// Execution shape as for Pushing: one environment per lane, a controller wave (open-loop IK chain) and a physics wave per
+// workgroup, one workgroup barrier per sub-step.  A workgroup owns GEN_LANES = 32 environments; the physics wave keeps the
+// dense (6 nb + 9)^2 Newton Hessian of every environment in LDS (561 doubles per environment, lane strided: 140 KiB), the
+// contact records and solver vectors in the HBM scratch area, and the cubes in the state buffer itself.
+#pragma once
+#include "gen_step.h"
+
+namespace d3il {
+
+constexpr int GEN_LDS_H = GEN_NH * GEN_LANES * 8;
+constexpr int GEN_LDS_X = 2 * 2 * NARM * GEN_LANES * 8;
+constexpr int GEN_LDS_STEP = GEN_LDS_H + GEN_LDS_X;
+
+__device__ __forceinline__ void gen_load_arm(const double* __restrict__ state, const unsigned* __restrict__ flags, const int* __restrict__ steps, int stride, int e,
+                                             EnvState& st, bool with_ik) {
+  const double* s = state + e;
+  for (int i = 0; i < NDOF; i++) st.q[i] = s[(D3IL_STATE_QPOS + i) * (size_t)stride];
+  for (int i = 0; i < NDOF; i++) st.v[i] = s[(D3IL_STATE_QVEL + i) * (size_t)stride];
+  for (int i = 0; i < NARM; i++) st.bias[i] = s[(D3IL_STATE_BIAS + i) * (size_t)stride];
+  for (int i = 0; i < 3; i++) st.tcp[i] = s[(D3IL_STATE_TCP + i) * (size_t)stride];
+  if (with_ik) {
+    for (int i = 0; i < NARM; i++) st.ikq[i] = s[(D3IL_STATE_IK_Q + i) * (size_t)stride];
+    for (int i = 0; i < NARM; i++) st.ikqd[i] = s[(D3IL_STATE_IK_QD + i) * (size_t)stride];
+  }
+  st.flags = flags[e]; st.step = steps[e];
+}
+__device__ __forceinline__ void gen_store_arm(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps, int stride, int e, const EnvState& st,
+                                              bool with_ik) {
+  double* s = state + e;
+  for (int i = 0; i < NDOF; i++) s[(D3IL_STATE_QPOS + i) * (size_t)stride] = st.q[i];
+  for (int i = 0; i < NDOF; i++) s[(D3IL_STATE_QVEL + i) * (size_t)stride] = st.v[i];
+  for (int i = 0; i < NARM; i++) s[(D3IL_STATE_BIAS + i) * (size_t)stride] = st.bias[i];
+  for (int i = 0; i < 3; i++) s[(D3IL_STATE_TCP + i) * (size_t)stride] = st.tcp[i];
+  if (with_ik) {
+    for (int i = 0; i < NARM; i++) s[(D3IL_STATE_IK_Q + i) * (size_t)stride] = st.ikq[i];
+    for (int i = 0; i < NARM; i++) s[(D3IL_STATE_IK_QD + i) * (size_t)stride] = st.ikqd[i];
+  }
+  flags[e] = st.flags; steps[e] = st.step;
+}
+
+// env.step() for the Sorting task
+template <bool FAST>
+__global__ __launch_bounds__(2 * WAVE) void k_sorting_step(const GenConsts* __restrict__ gcp, double* __restrict__ state, unsigned* __restrict__ flags,
+                                                           int* __restrict__ steps, const double* __restrict__ actions, float* __restrict__ obs,
+                                                           unsigned char* __restrict__ done, unsigned char* __restrict__ success, unsigned short* __restrict__ mode,
+                                                           double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
+  extern __shared__ double smem[];
+  double* tbl = smem;                                    // [GEN_NH][GEN_LANES]
+  double (*xch)[2 * NARM][GEN_LANES] = (double (*)[2 * NARM][GEN_LANES])(smem + GEN_NH * GEN_LANES);
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int role = threadIdx.x / WAVE;
+  const int e = blockIdx.x * GEN_LANES + lane;
+  const bool live = lane < GEN_LANES && e < n;           // the other lanes only take part in the barriers
+  const PandaConsts& c = kAvoidingConsts;                // the arm is the Avoiding arm (same robot XML / gin / URDF)
+  const GenConsts& gc = *gcp;
+  if (role == 0) {
+    double ikq[NARM], ikqd[NARM], q0[NARM], des[7];
+    unsigned fl = 0;
+    double vwarm[7];
+    vwarm[6] = 0.0;
+    if (live) {
+      const double* sp = state + e;
+      double act[7];
+#pragma unroll
+      for (int i = 0; i < NARM; i++) {
+        ikq[i] = sp[(D3IL_STATE_IK_Q + i) * (size_t)stride]; ikqd[i] = sp[(D3IL_STATE_IK_QD + i) * (size_t)stride];
+        q0[i] = sp[(D3IL_STATE_QPOS + i) * (size_t)stride];
+      }
+#pragma unroll
+      for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
+      fl = flags[e];
+      make_setpoint(act, des);
+    }
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < n_substeps; s++) {
+      if (live) {
+        ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd, vwarm);
+        const int b = s & 1;
+#pragma unroll
+        for (int k = 0; k < NARM; k++) { xch[b][k][lane] = ikq[k]; xch[b][NARM + k][lane] = ikqd[k]; }
+      }
+      __syncthreads();
+    }
+    if (live) {
+      double* so = state + e;
+#pragma unroll
+      for (int i = 0; i < NARM; i++) { so[(D3IL_STATE_IK_Q + i) * (size_t)stride] = ikq[i]; so[(D3IL_STATE_IK_QD + i) * (size_t)stride] = ikqd[i]; }
+    }
+  } else {
+    const size_t ei = live ? e : 0;
+    PushScratch sc{(push_lds_double*)(tbl + (lane < GEN_LANES ? lane : 0)), (push_glb_double*)(scratch + ei), stride, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
+    EnvState st;
+    float o[GEN_SORT_OBS]; unsigned char dn = 0;
+    if (live) {
+      gen_load_arm(state, flags, steps, stride, e, st, false);
+      sort_step_begin(gc, st, sc, o, &dn, max_steps);
+    }
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < n_substeps; s++) {
+      __syncthreads();
+      if (live) {
+        const int b = s & 1;
+        double qd[NARM], qdd[NARM], tau[NARM], ff[NFING];
+#pragma unroll
+        for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][lane]; qdd[k] = xch[b][NARM + k][lane]; }
+        push_control(c, st, qd, qdd, 0.04, false, tau, ff);
+        gen_physics_substep(c, gc, st, sc, tau, ff);
+      }
+    }
+    if (live) {
+      int code = 0;
+      st.flags |= F_IK_VALID;
+      sort_step_end(gc, st, sc, &code);
+      gen_store_arm(state, flags, steps, stride, e, st, false);
+      const int od = 2 + 3 * gc.nb;
+      for (int k = 0; k < od; k++) obs[(size_t)od * e + k] = o[k];
+      done[e] = dn; success[e] = (st.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)code;
+    }
+  }
+}
+
+// env.reset(random=False, context) for masked environments; contexts: f64 [n][7 nb] = nb x (pos3, quat4), red boxes first
+__global__ __launch_bounds__(WAVE) void k_sorting_reset(const GenConsts* __restrict__ gcp, const double* __restrict__ init_qpos, const unsigned char* __restrict__ mask,
+                                                        const double* __restrict__ contexts, double* __restrict__ state, unsigned* __restrict__ flags,
+                                                        int* __restrict__ steps, float* __restrict__ obs, unsigned char* __restrict__ done,
+                                                        unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ scratch, int n, int stride) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x * GEN_LANES + lane;
+  if (lane >= GEN_LANES || e >= n) return;
+  if (mask && !mask[e]) return;
+  const GenConsts& gc = *gcp;
+  EnvState st;
+  double iq[NARM];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
+  PushScratch sc{(push_lds_double*)(smem + lane), (push_glb_double*)(scratch + e), stride, (push_glb_double*)(state + (size_t)42 * stride + e), stride};
+  float o[GEN_SORT_OBS];
+  st.flags = 0; st.step = 0;
+  gen_env_reset(kAvoidingConsts, gc, st, sc, iq, contexts + (size_t)e * 7 * gc.nb, o);
+  gen_store_arm(state, flags, steps, stride, e, st, true);
+  const int od = 2 + 3 * gc.nb;
+  for (int k = 0; k < od; k++) obs[(size_t)od * e + k] = o[k];
+  int code = 0;
+  for (int i = 0; i < gc.nb; i++) code |= 1 << (7 - i);        // np.packbits of the all -1 mode vector
+  done[e] = 0; success[e] = 0; mode[e] = (unsigned short)code;
+}
+
+}  // namespace d3il

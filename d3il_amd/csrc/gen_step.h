@@ -18,6 +18,7 @@ namespace d3il {
 constexpr int GEN_MAXNB = 4, GEN_MAXNS = 12, GEN_MAXCON = 72, GEN_MAXSET = GEN_MAXNS + 2;
 constexpr int GEN_MAXNV = 6 * GEN_MAXNB + NDOF;     // 33
 constexpr int GEN_NH = GEN_MAXNV * (GEN_MAXNV + 1) / 2;   // 561
+constexpr int GEN_LANES = 32;           // environments per workgroup: 32 x 561 doubles of LDS for the Hessians
 
 struct GenConsts {
   int nb, ns, set_bb, set_rod;
@@ -30,7 +31,13 @@ struct GenConsts {
   double absent[7];               // pose reported for boxes the model does not have (body id -1)
 };
 
-struct GenState { EnvState arm; BoxState box[GEN_MAXNB]; unsigned task[2]; };
+// The w area of the scratch views is the environment's object block of the state buffer (rows 42 ..): the cubes' pos[3] quat[4]
+// vel[6], then the solver's warm start [nv], then the two task words (stored as doubles).  The cubes stay there for the
+// whole step - only the arm lives in registers.
+#define GBX(b, k) PWS(13 * (b) + (k))
+#define GWARM(k) PWS(13 * gc.nb + (k))
+#define GTASK(k) PWS(13 * gc.nb + 6 * gc.nb + NDOF + (k))
+D3IL_HD constexpr int gen_state_rows(int nb) { return 42 + 13 * nb + 6 * nb + NDOF + 2; }
 
 // g-area layout (doubles per lane)
 constexpr int GG_M = 0, GG_A0 = 45, GG_X = GG_A0 + GEN_MAXNV, GG_P = GG_X + GEN_MAXNV, GG_G = GG_P + GEN_MAXNV, GG_VEL = GG_G + GEN_MAXNV;
@@ -88,7 +95,12 @@ D3IL_HD double gen_M(const GenConsts& gc, const PushScratch& sc, int i, int k) {
   return PGS(GG_M + (a >= b ? tri(a, b) : tri(b, a)));
 }
 // H (h area, packed lower, order nv) -> L L^T in place; solve in place on the g vector at `vec`
-#define GHS(i) sc.h[(i) * PUSH_HS]
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GEN_HS GEN_LANES
+#else
+#define GEN_HS 1
+#endif
+#define GHS(i) sc.h[(i) * GEN_HS]
 D3IL_HD bool gen_chol(const PushScratch& sc, int nv) {
   bool ok = true;
   for (int i = 0; i < nv; i++)
@@ -291,8 +303,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc, const PushScratch& sc, 
 
 // one physics sub-step (mj_step) of arm + cubes; warm start / result of the solver at sc.w[0 .. nv)
 template <class C>
-D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, GenState& gs, const PushScratch& sc, const double* tau, const double* ffing) {
-  EnvState& st = gs.arm;
+D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, EnvState& st, const PushScratch& sc, const double* tau, const double* ffing) {
   D3IL_REFRESH(c0, c);
   const double h = c.timestep;
   const int arm0 = 6 * gc.nb, nv = arm0 + NDOF;
@@ -316,10 +327,12 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, GenState& gs,
   // publish the system to the scratch area
   for (int i = 0; i < 45; i++) PGS(GG_M + i) = dyn.M[i];
   for (int b = 0; b < gc.nb; b++) {
-    double R[9]; quat2mat(gs.box[b].quat, R);
+    double R[9], q[4] = {GBX(b, 3), GBX(b, 4), GBX(b, 5), GBX(b, 6)};
+    quat2mat(q, R);
     for (int k = 0; k < 9; k++) PGS(GG_R + 9 * b + k) = R[k];
-    for (int k = 0; k < 3; k++) PGS(GG_POS + 3 * b + k) = gs.box[b].pos[k];
-    for (int k = 0; k < 6; k++) { PGS(GG_VEL + 6 * b + k) = gs.box[b].vel[k]; PGS(GG_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0; }
+    for (int k = 0; k < 3; k++) PGS(GG_POS + 3 * b + k) = GBX(b, k);
+    for (int k = 0; k < 6; k++) { PGS(GG_VEL + 6 * b + k) = GBX(b, 7 + k); PGS(GG_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0; }
+    if (GBX(b, 0) < gc.ws_lo[0] || GBX(b, 0) > gc.ws_hi[0] || GBX(b, 1) < gc.ws_lo[1] || GBX(b, 1) > gc.ws_hi[1]) st.flags |= PF_OFF_TABLE;
   }
   for (int k = 0; k < NDOF; k++) { PGS(GG_VEL + arm0 + k) = st.v[k]; PGS(GG_A0 + arm0 + k) = a0[k]; }
   bool any_lim = false;
@@ -361,11 +374,11 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, GenState& gs,
   if (ncon == 0 && !any_lim) {
     for (int k = 0; k < nv; k++) PGS(GG_X + k) = PGS(GG_A0 + k);
   } else {
-    if (st.flags & PF_WARM_VALID) for (int k = 0; k < nv; k++) PGS(GG_X + k) = PWS(k);
+    if (st.flags & PF_WARM_VALID) for (int k = 0; k < nv; k++) PGS(GG_X + k) = GWARM(k);
     else for (int k = 0; k < nv; k++) PGS(GG_X + k) = PGS(GG_A0 + k);
     if (!gen_solve(gc, sc, ncon)) st.flags |= F_SOLVER_FAIL;
   }
-  for (int k = 0; k < nv; k++) PWS(k) = PGS(GG_X + k);
+  for (int k = 0; k < nv; k++) GWARM(k) = PGS(GG_X + k);
   st.flags |= PF_WARM_VALID;
   // arm: (M + h B) qacc = M x, B on the fingers
   {
@@ -384,8 +397,15 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, GenState& gs,
   }
   for (int b = 0; b < gc.nb; b++) {
     double xb[6];
+    BoxState bx;
     for (int k = 0; k < 6; k++) xb[k] = PGS(GG_X + 6 * b + k);
-    cube_integrate(gs.box[b], xb, h);
+    for (int k = 0; k < 3; k++) bx.pos[k] = GBX(b, k);
+    for (int k = 0; k < 4; k++) bx.quat[k] = GBX(b, 3 + k);
+    for (int k = 0; k < 6; k++) bx.vel[k] = GBX(b, 7 + k);
+    cube_integrate(bx, xb, h);
+    for (int k = 0; k < 3; k++) GBX(b, k) = bx.pos[k];
+    for (int k = 0; k < 4; k++) GBX(b, 3 + k) = bx.quat[k];
+    for (int k = 0; k < 6; k++) GBX(b, 7 + k) = bx.vel[k];
   }
 }
 
@@ -394,14 +414,12 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, GenState& gs,
 // (3 bits each).  sorting.py:405-411 (reset), :460-507 (check_mode)
 constexpr int GEN_SORT_OBS = 20;      // 2 + 3 * 6 at most (num_boxes = 6); Sorting-4 uses 14
 D3IL_HD unsigned sort_word0_reset() { return 0; }
-D3IL_HD void sort_collect(const GenConsts& gc, const GenState& gs, double (*box)[7]) {
+D3IL_HD void sort_collect(const GenConsts& gc, const PushScratch& sc, double (*box)[7]) {
   const int nr = gc.nb / 2;
   for (int i = 0; i < 6; i++) {
     const int cidx = i / 3, k = i % 3;
     if (k < nr) {
-      const BoxState& b = gs.box[cidx * nr + k];
-      for (int j = 0; j < 3; j++) box[i][j] = b.pos[j];
-      for (int j = 0; j < 4; j++) box[i][3 + j] = b.quat[j];
+      for (int j = 0; j < 7; j++) box[i][j] = GBX(cidx * nr + k, j);
     } else for (int j = 0; j < 7; j++) box[i][j] = gc.absent[j];   // body id -1: the model's last body (MjScene.py:233-247)
   }
 }
@@ -447,72 +465,72 @@ D3IL_HD int sort_check_mode(const GenConsts& gc, unsigned* task, const double (*
 
 // ------------------------------------------------------------------------------------------------ env level
 template <class C>
-D3IL_HD void gen_control_and_physics(const C& c, const GenConsts& gc, GenState& gs, const PushScratch& sc, const double* q_des, const double* qd_des,
+D3IL_HD void gen_control_and_physics(const C& c, const GenConsts& gc, EnvState& st, const PushScratch& sc, const double* q_des, const double* qd_des,
                                      double set_width, bool grasp) {
   double tau[NARM], ff[NFING];
-  push_control(c, gs.arm, q_des, qd_des, set_width, grasp, tau, ff);
-  gen_physics_substep(c, gc, gs, sc, tau, ff);
+  push_control(c, st, q_des, qd_des, set_width, grasp, tau, ff);
+  gen_physics_substep(c, gc, st, sc, tau, ff);
 }
 // Sorting_Env.reset(random=False, context) (sorting.py:545-575): ctx = nb x (pos3, quat4) in the order red_1.., blue_1..
 template <class C>
-D3IL_HD void gen_env_reset(const C& c, const GenConsts& gc, GenState& gs, const PushScratch& sc, const double* init_qpos, const double* ctx, float* obs) {
-  EnvState& st = gs.arm;
+D3IL_HD void gen_env_reset(const C& c, const GenConsts& gc, EnvState& st, const PushScratch& sc, const double* init_qpos, const double* ctx, float* obs) {
   for (int k = 0; k < NARM; k++) { st.q[k] = init_qpos[k]; st.ikq[k] = 0; st.ikqd[k] = 0; }
   st.q[NARM] = 0; st.q[NARM + 1] = 0;
   for (int k = 0; k < NDOF; k++) st.v[k] = 0;
   st.flags = 0; st.step = 0;
-  gs.task[0] = 0; gs.task[1] = 0;
+  GTASK(0) = 0; GTASK(1) = 0;
   for (int b = 0; b < gc.nb; b++) {
-    for (int k = 0; k < 3; k++) gs.box[b].pos[k] = ctx[7 * b + k];
-    for (int k = 0; k < 4; k++) gs.box[b].quat[k] = ctx[7 * b + 3 + k];
-    for (int k = 0; k < 6; k++) gs.box[b].vel[k] = 0;
+    for (int k = 0; k < 7; k++) GBX(b, k) = ctx[7 * b + k];
+    for (int k = 0; k < 6; k++) GBX(b, 7 + k) = 0;
   }
-  for (int k = 0; k < 6 * gc.nb + NDOF; k++) PWS(k) = 0;
+  for (int k = 0; k < 6 * gc.nb + NDOF; k++) GWARM(k) = 0;
   {
     DynOut dyn;
     dynamics(c, st.q, st.v, dyn);
     for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
   }
   double zero[NARM] = {0, 0, 0, 0, 0, 0, 0};
-  gen_control_and_physics(c, gc, gs, sc, init_qpos, zero, 0.001, false);
+  gen_control_and_physics(c, gc, st, sc, init_qpos, zero, 0.001, false);
   double box[6][7];
-  sort_collect(gc, gs, box);
+  sort_collect(gc, sc, box);
   sort_obs_success(gc, box, st.tcp, obs);
 }
 // before the physics of a step: observation and done (gym_env_wrapper.py:88-90,124-137)
-D3IL_HD void sort_step_begin(const GenConsts& gc, GenState& gs, float* obs, unsigned char* done, int max_steps) {
+D3IL_HD void sort_step_begin(const GenConsts& gc, EnvState& st, const PushScratch& sc, float* obs, unsigned char* done, int max_steps) {
   double box[6][7];
-  sort_collect(gc, gs, box);
-  bool succ = sort_obs_success(gc, box, gs.arm.tcp, obs);
-  bool fin = (gs.arm.flags & F_TERMINATED) != 0;
-  if (!fin && succ) { gs.arm.flags |= F_TERMINATED; fin = true; }
-  if (!fin && gs.arm.step >= max_steps - 1) fin = true;
+  sort_collect(gc, sc, box);
+  bool succ = sort_obs_success(gc, box, st.tcp, obs);
+  bool fin = (st.flags & F_TERMINATED) != 0;
+  if (!fin && succ) { st.flags |= F_TERMINATED; fin = true; }
+  if (!fin && st.step >= max_steps - 1) fin = true;
   *done = fin ? 1 : 0;
 }
 // after the physics: success and the completion-order mode code (sorting.py:444-458)
-D3IL_HD void sort_step_end(const GenConsts& gc, GenState& gs, int* mode_code) {
-  gs.arm.step++;
+D3IL_HD void sort_step_end(const GenConsts& gc, EnvState& st, const PushScratch& sc, int* mode_code) {
+  st.step++;
   double box[6][7]; float dummy[GEN_SORT_OBS];
-  sort_collect(gc, gs, box);
-  bool succ = sort_obs_success(gc, box, gs.arm.tcp, dummy);
-  gs.arm.flags &= ~F_SUCCESS;
-  if (succ) gs.arm.flags |= F_SUCCESS | F_TERMINATED;
-  *mode_code = sort_check_mode(gc, gs.task, box);
+  sort_collect(gc, sc, box);
+  bool succ = sort_obs_success(gc, box, st.tcp, dummy);
+  st.flags &= ~F_SUCCESS;
+  if (succ) st.flags |= F_SUCCESS | F_TERMINATED;
+  unsigned task[2] = {(unsigned)GTASK(0), (unsigned)GTASK(1)};
+  *mode_code = sort_check_mode(gc, task, box);
+  GTASK(0) = (double)task[0]; GTASK(1) = (double)task[1];
 }
 template <bool FAST, class C>
-D3IL_HD void gen_env_step(const C& c, const GenConsts& gc, GenState& gs, const PushScratch& sc, const double* action, float* obs, unsigned char* done,
+D3IL_HD void gen_env_step(const C& c, const GenConsts& gc, EnvState& st, const PushScratch& sc, const double* action, float* obs, unsigned char* done,
                           int* mode_code, int n_substeps, int max_steps) {
-  sort_step_begin(gc, gs, obs, done, max_steps);
+  sort_step_begin(gc, st, sc, obs, done, max_steps);
   double des[7];
   make_setpoint(action, des);
   double vwarm[7]; vwarm[6] = 0.0;
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
     D3IL_REFRESH(c, cs);
-    ik_update<FAST>(cs, des, des + 3, gs.arm.q, gs.arm.flags, gs.arm.ikq, gs.arm.ikqd, vwarm);
-    gen_control_and_physics(cs, gc, gs, sc, gs.arm.ikq, gs.arm.ikqd, 0.04, false);
+    ik_update<FAST>(cs, des, des + 3, st.q, st.flags, st.ikq, st.ikqd, vwarm);
+    gen_control_and_physics(cs, gc, st, sc, st.ikq, st.ikqd, 0.04, false);
   }
-  sort_step_end(gc, gs, mode_code);
+  sort_step_end(gc, st, sc, mode_code);
 }
 
 // ------------------------------------------------------------------------------------------------ constants from the blob

@@ -18,6 +18,7 @@ namespace d3il {
 constexpr int WAVE = 64;
 }
 #include "push_kernels.h"
+#include "gen_kernels.h"
 
 namespace d3il {
 
@@ -291,6 +292,8 @@ struct d3il_handle_s {
   PandaConsts hc;          // host copy
   PandaConsts* dc;         // device copy
   PushConsts pc;           // Pushing: cubes, table slabs, contact parameter sets, targets
+  GenConsts gc;            // Sorting: cubes, static boxes, contact parameter sets (host copy)
+  GenConsts* d_gc;         // device copy
   double* d_scratch;       // Pushing: per-lane solver scratch [PG_SIZE][stride]
   int state_rows;          // f64 state fields per environment (42 Avoiding, 89 Pushing)
   double* d_init_qpos;
@@ -321,7 +324,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (n_envs <= 0) return fail(D3IL_EINVAL, "d3il_create: n_envs must be positive");
   const d3il_model_blob& m = *(const d3il_model_blob*)model_blob;
   if (task_id != m.task_id) return fail(D3IL_EINVAL, "d3il_create: task_id does not match the model blob");
-  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING) return fail(D3IL_EUNSUPPORTED, "d3il_create: only the Avoiding and Pushing tasks are implemented in this build");
+  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING) return fail(D3IL_EUNSUPPORTED, "d3il_create: only the Avoiding, Pushing and Sorting tasks are implemented in this build");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(D3IL_ENODEVICE, "d3il_create: no HIP device available (there is no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(D3IL_ENODEVICE, "d3il_create: device_id out of range");
@@ -333,10 +336,11 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (rc) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   finish_invweights(h->hc);
   if (task_id == D3IL_TASK_PUSHING && build_push_consts(m, h->pc, &err)) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  if (task_id == D3IL_TASK_SORTING && build_gen_consts(m, h->hc, h->gc, &err)) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   {  // the kernels are specialised at build time to the robot model (csrc/gen/avoiding_consts.inc): the runtime blob
      // must describe the same arm, controller and (Avoiding) obstacles.  n_substeps / max_steps stay run-time parameters.
     PandaConsts a = h->hc, b = kAvoidingConsts;
-    if (task_id == D3IL_TASK_PUSHING) {   // no obstacles, other task constants: only the arm / controller part is compared
+    if (task_id != D3IL_TASK_AVOIDING) {   // no obstacles, other task constants: only the arm / controller part is compared
       a.n_obst = b.n_obst;
       std::memcpy(a.ob_c, b.ob_c, sizeof a.ob_c); std::memcpy(a.ob_u, b.ob_u, sizeof a.ob_u); std::memcpy(a.ob_r, b.ob_r, sizeof a.ob_r); std::memcpy(a.ob_h, b.ob_h, sizeof a.ob_h);
       std::memcpy(a.ct_K, b.ct_K, sizeof a.ct_K); std::memcpy(a.ct_B, b.ct_B, sizeof a.ct_B); std::memcpy(a.ct_solimp, b.ct_solimp, sizeof a.ct_solimp);
@@ -353,12 +357,13 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
                                                            "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
   h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
-  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr;
+  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr; h->d_gc = nullptr;
   const bool pushing = task_id == D3IL_TASK_PUSHING;
-  h->state_rows = pushing ? PUSH_STATE_F64 : D3IL_STATE_F64;
+  const bool sorting = task_id == D3IL_TASK_SORTING;
+  h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : D3IL_STATE_F64);
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
-  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : 2; b.action_dim = 7; b.state_rows = h->state_rows; b.n_info_f64 = pushing ? 2 : 0;
+  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : 2); b.action_dim = 7; b.state_rows = h->state_rows; b.n_info_f64 = pushing ? 2 : 0;
   HIPCHK(hipMalloc(&h->dc, sizeof(PandaConsts)));
   HIPCHK(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
@@ -381,6 +386,13 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     HIPCHK(hipFuncSetAttribute((const void*)k_pushing_step_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
     HIPCHK(hipFuncSetAttribute((const void*)k_pushing_reset, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_H));
   }
+  if (sorting) {
+    HIPCHK(hipMalloc(&h->d_gc, sizeof(GenConsts))); HIPCHK(hipMemcpy(h->d_gc, &h->gc, sizeof(GenConsts), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->d_scratch, S * GG_SIZE * sizeof(double))); HIPCHK(hipMemset(h->d_scratch, 0, S * GG_SIZE * sizeof(double)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sorting_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sorting_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sorting_reset, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_H));
+  }
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
   *out = h;
   return D3IL_OK;
@@ -389,7 +401,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
 int d3il_destroy(d3il_handle h) {
   if (!h) return fail(D3IL_EINVAL, "d3il_destroy: null handle");
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des, h->buf.info_f64, h->d_scratch};
+  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des, h->buf.info_f64, h->d_scratch, h->d_gc};
   for (void* p : ptrs) (void)hipFree(p);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
   delete h;
@@ -417,6 +429,13 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
     HIPCHK(hipGetLastError());
     return D3IL_OK;
   }
+  if (h->task_id == D3IL_TASK_SORTING) {
+    if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Sorting task needs contexts (device f64 [n_envs][7 * n_boxes])");
+    hipLaunchKernelGGL(k_sorting_reset, dim3((h->n + GEN_LANES - 1) / GEN_LANES), dim3(WAVE), GEN_LDS_H, (hipStream_t)stream, h->d_gc, h->d_init_qpos, env_mask, contexts, b.state,
+                       b.flags, b.step_count, b.obs, b.done, b.success, b.mode, h->d_scratch, h->n, h->stride);
+    HIPCHK(hipGetLastError());
+    return D3IL_OK;
+  }
   if (contexts) return fail(D3IL_EUNSUPPORTED, "d3il_reset: the Avoiding task takes no contexts");
   hipLaunchKernelGGL(k_avoiding_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->dc, h->d_init_qpos, env_mask, b.state, b.flags,
                      b.step_count, b.obs, b.done, b.success, b.mode, h->n, h->stride);
@@ -439,6 +458,19 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     else
       hipLaunchKernelGGL((k_pushing_step_split<false>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, h->pc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                          b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    HIPCHK(hipGetLastError());
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    return D3IL_OK;
+  }
+  if (h->task_id == D3IL_TASK_SORTING) {
+    int nwgs = (h->n + GEN_LANES - 1) / GEN_LANES;
+    if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+    if (h->fast)
+      hipLaunchKernelGGL((k_sorting_step<true>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, h->d_gc, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
+                         h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    else
+      hipLaunchKernelGGL((k_sorting_step<false>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, h->d_gc, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
+                         h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
     return D3IL_OK;

@@ -258,6 +258,11 @@ class Oracle:
         self.L.orc_sortenv_step(self.h, _p(action), _p(obs), C.byref(done), C.byref(code), C.byref(succ))
         return obs, bool(done.value), dict(mode=code.value, success=bool(succ.value))
 
+    def sort_set_state(self, state_col, flags, step):
+        """Load one environment's column of the HIP path's Sorting state buffer (+ flags word, step counter)."""
+        state_col = np.ascontiguousarray(state_col, float)
+        self.L.orc_sort_set_state(self.h, _p(state_col), C.c_uint(int(flags) & 0xFFFFFFFF), int(step))
+
     def push_state(self):
         s = np.zeros(42 + 13 * 2)
         self.L.orc_push_get_state(self.h, _p(s))

@@ -126,7 +126,7 @@ void hc_push_substep(void* h, double* s, int* f, const double* tau, const double
   (void)ncon_out;
 }
 // ---------------------------------------------------------------- generic engine / Sorting (gen_step.h)
-struct GenHost { PandaConsts c; GenConsts gc; double h[GEN_NH]; double g[GG_SIZE]; double w[GEN_MAXNV]; };
+struct GenHost { PandaConsts c; GenConsts gc; double h[GEN_NH]; double g[GG_SIZE]; };
 void* hc_gen_create(const d3il_model_blob* blob, const char** err) {
   GenHost* p = (GenHost*)std::calloc(1, sizeof(GenHost));
   static const char* e = "";
@@ -138,37 +138,25 @@ void* hc_gen_create(const d3il_model_blob* blob, const char** err) {
 int hc_gen_info(void* h, int* nb, int* ns, double* statics /* ns x (c3, h3, first) */) {
   GenHost* p = (GenHost*)h; *nb = p->gc.nb; *ns = p->gc.ns;
   for (int s = 0; s < p->gc.ns; s++) { for (int k = 0; k < 3; k++) { statics[7 * s + k] = p->gc.st_c[s][k]; statics[7 * s + 3 + k] = p->gc.st_h[s][k]; } statics[7 * s + 6] = p->gc.st_first[s]; }
-  return 42 + 13 * p->gc.nb + 6 * p->gc.nb + NDOF;
+  return gen_state_rows(p->gc.nb);
 }
-static void gen_unpack(const GenHost* p, const double* s, const int* f, GenState& gs) {
-  unpack(s, f, gs.arm);
-  int k = 42;
-  for (int b = 0; b < p->gc.nb; b++) { for (int i = 0; i < 3; i++) gs.box[b].pos[i] = s[k++]; for (int i = 0; i < 4; i++) gs.box[b].quat[i] = s[k++]; for (int i = 0; i < 6; i++) gs.box[b].vel[i] = s[k++]; }
-  gs.task[0] = (unsigned)f[2]; gs.task[1] = (unsigned)f[3];
-}
-static void gen_pack(GenHost* p, const GenState& gs, double* s, int* f) {
-  pack(gs.arm, s, f);
-  int k = 42;
-  for (int b = 0; b < p->gc.nb; b++) { for (int i = 0; i < 3; i++) s[k++] = gs.box[b].pos[i]; for (int i = 0; i < 4; i++) s[k++] = gs.box[b].quat[i]; for (int i = 0; i < 6; i++) s[k++] = gs.box[b].vel[i]; }
-  for (int i = 0; i < 6 * p->gc.nb + NDOF; i++) s[k++] = p->w[i];
-  f[2] = (int)gs.task[0]; f[3] = (int)gs.task[1];
-}
+// s: the environment's state column (arm[42] | cubes | warm start | task words), f: flags, step
 void hc_gen_reset(void* h, const double* init_qpos, const double* ctx, double* s, int* f, float* obs) {
-  GenHost* p = (GenHost*)h; GenState gs; std::memset(&gs, 0, sizeof gs);
-  PushScratch sc{p->h, p->g, 1, p->w, 1};
-  gen_env_reset(p->c, p->gc, gs, sc, init_qpos, ctx, obs); gen_pack(p, gs, s, f);
+  GenHost* p = (GenHost*)h; EnvState st; std::memset(&st, 0, sizeof st);
+  PushScratch sc{p->h, p->g, 1, s + 42, 1};
+  gen_env_reset(p->c, p->gc, st, sc, init_qpos, ctx, obs); pack(st, s, f);
 }
 void hc_gen_step(void* h, double* s, int* f, const double* action, float* obs, unsigned char* done, int* mode_code, int fast) {
-  GenHost* p = (GenHost*)h; GenState gs; gen_unpack(p, s, f, gs); std::memcpy(p->w, s + 42 + 13 * p->gc.nb, sizeof(double) * (6 * p->gc.nb + NDOF));
-  PushScratch sc{p->h, p->g, 1, p->w, 1};
-  if (fast) gen_env_step<true>(p->c, p->gc, gs, sc, action, obs, done, mode_code, p->c.n_substeps, p->c.max_steps);
-  else gen_env_step<false>(p->c, p->gc, gs, sc, action, obs, done, mode_code, p->c.n_substeps, p->c.max_steps);
-  gen_pack(p, gs, s, f);
+  GenHost* p = (GenHost*)h; EnvState st; unpack(s, f, st);
+  PushScratch sc{p->h, p->g, 1, s + 42, 1};
+  if (fast) gen_env_step<true>(p->c, p->gc, st, sc, action, obs, done, mode_code, p->c.n_substeps, p->c.max_steps);
+  else gen_env_step<false>(p->c, p->gc, st, sc, action, obs, done, mode_code, p->c.n_substeps, p->c.max_steps);
+  pack(st, s, f);
 }
 void hc_gen_substep(void* h, double* s, int* f, const double* tau, const double* ffing) {
-  GenHost* p = (GenHost*)h; GenState gs; gen_unpack(p, s, f, gs); std::memcpy(p->w, s + 42 + 13 * p->gc.nb, sizeof(double) * (6 * p->gc.nb + NDOF));
-  PushScratch sc{p->h, p->g, 1, p->w, 1};
-  gen_physics_substep(p->c, p->gc, gs, sc, tau, ffing); gen_pack(p, gs, s, f);
+  GenHost* p = (GenHost*)h; EnvState st; unpack(s, f, st);
+  PushScratch sc{p->h, p->g, 1, s + 42, 1};
+  gen_physics_substep(p->c, p->gc, st, sc, tau, ffing); pack(st, s, f);
 }
 // collision routines of push_step.h on their own (quaternions in, same record layout as the oracle's test hooks)
 int hc_cyl_box(const double* pc, const double* qc, double rad, double half, const double* pb, const double* qb, const double* sb, double margin, double* out) {

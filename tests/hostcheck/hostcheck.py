@@ -127,7 +127,7 @@ class GenHostCheck:
         self.nb, self.ns, self.statics = nb.value, ns.value, st[: ns.value].copy()
         self.n_obs = 2 + 3 * self.nb
         self.s = np.zeros(self.n)
-        self.f = np.zeros(4, dtype=np.int32)
+        self.f = np.zeros(2, dtype=np.int32)
 
     def reset(self, init_qpos, ctx):
         init_qpos, ctx = np.ascontiguousarray(init_qpos, float), np.ascontiguousarray(ctx, float).reshape(7 * self.nb)
