@@ -1,15 +1,17 @@
 // gen_kernels.h - HIP kernels of the Sorting task on the generic engine (included by rollout.hip).
 //
-// Execution shape as for Pushing: one environment per lane, a controller wave (open-loop IK chain) and a physics wave per
-// workgroup, one workgroup barrier per sub-step.  A workgroup owns GEN_LANES = 32 environments; the physics wave keeps the
-// dense (6 nb + 9)^2 Newton Hessian of every environment in LDS (561 doubles per environment, lane strided: 140 KiB), the
-// contact records and solver vectors in the HBM scratch area, and the cubes in the state buffer itself.
+// A workgroup owns GEN_LANES = 16 environments and runs two waves: the controller wave (open-loop IK chain, one lane per
+// environment) and the physics wave, in which every environment has a group of four lanes - lane l of the group owns cube l,
+// lane 0 also the arm (gen_step.h).  Lane = 16 l + column, so the 16 lanes that do the same job sit next to each other:
+// coalesced HBM rows, conflict-free LDS columns.  The physics wave keeps each environment's vectors, matrices and the dense
+// Newton Hessian in LDS (944 doubles per environment, 125 KiB per workgroup), the contact records in the HBM scratch area
+// and the cubes in the state buffer itself.  4096 environments are 256 workgroups: one per CU.
 #pragma once
 #include "gen_step.h"
 
 namespace d3il {
 
-constexpr int GEN_LDS_H = GEN_NH * GEN_LANES * 8;
+constexpr int GEN_LDS_H = GL_SIZE * (GEN_LANES + 1) * 8;
 constexpr int GEN_LDS_X = 2 * 2 * NARM * GEN_LANES * 8;
 constexpr int GEN_LDS_STEP = GEN_LDS_H + GEN_LDS_X;
 
@@ -42,20 +44,20 @@ __device__ __forceinline__ void gen_store_arm(double* __restrict__ state, unsign
 
 // env.step() for the Sorting task
 template <bool FAST>
-__global__ __launch_bounds__(2 * WAVE) void k_sorting_step(const GenConsts* __restrict__ gcp, double* __restrict__ state, unsigned* __restrict__ flags,
+__global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ state, unsigned* __restrict__ flags,
                                                            int* __restrict__ steps, const double* __restrict__ actions, float* __restrict__ obs,
                                                            unsigned char* __restrict__ done, unsigned char* __restrict__ success, unsigned short* __restrict__ mode,
                                                            double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
   extern __shared__ double smem[];
-  double* tbl = smem;                                    // [GEN_NH][GEN_LANES]
-  double (*xch)[2 * NARM][GEN_LANES] = (double (*)[2 * NARM][GEN_LANES])(smem + GEN_NH * GEN_LANES);
+  double* tbl = smem;                                    // [GL_SIZE][GEN_LANES + 1]
+  double (*xch)[2 * NARM][GEN_LANES] = (double (*)[2 * NARM][GEN_LANES])(smem + GL_SIZE * (GEN_LANES + 1));
   const int lane = threadIdx.x & (WAVE - 1);
   const int role = threadIdx.x / WAVE;
-  const int e = blockIdx.x * GEN_LANES + lane;
-  const bool live = lane < GEN_LANES && e < n;           // the other lanes only take part in the barriers
   const PandaConsts& c = kAvoidingConsts;                // the arm is the Avoiding arm (same robot XML / gin / URDF)
-  const GenConsts& gc = *gcp;
+  const GenConsts& gc = g_gen_consts;
   if (role == 0) {
+    const int e = blockIdx.x * GEN_LANES + lane;
+    const bool live = lane < GEN_LANES && e < n;         // the other lanes only take part in the barriers
     double ikq[NARM], ikqd[NARM], q0[NARM], des[7];
     unsigned fl = 0;
     double vwarm[7];
@@ -89,29 +91,53 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(const GenConsts* __re
       for (int i = 0; i < NARM; i++) { so[(D3IL_STATE_IK_Q + i) * (size_t)stride] = ikq[i]; so[(D3IL_STATE_IK_QD + i) * (size_t)stride] = ikqd[i]; }
     }
   } else {
-    const size_t ei = live ? e : 0;
-    PushScratch sc{(push_lds_double*)(tbl + (lane < GEN_LANES ? lane : 0)), (push_glb_double*)(scratch + ei), stride, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
+    const int col = lane & (GEN_LANES - 1), l = lane / GEN_LANES;   // group lane l of environment column col
+    const int e = blockIdx.x * GEN_LANES + col;
+    const bool plive = e < n && l < gc.nb;
+    const bool arm_lane = plive && l == 0;
+    const size_t ei = e < n ? e : 0;
+    PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + ei), stride, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
     EnvState st;
     float o[GEN_SORT_OBS]; unsigned char dn = 0;
-    if (live) {
+    unsigned lfl = 0;
+    bool warm_valid = false;
+    const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
+    if (plive) warm_valid = (flags[e] & PF_WARM_VALID) != 0;
+    if (arm_lane) {
       gen_load_arm(state, flags, steps, stride, e, st, false);
       sort_step_begin(gc, st, sc, o, &dn, max_steps);
     }
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
       __syncthreads();
-      if (live) {
+      if (arm_lane) {
         const int b = s & 1;
         double qd[NARM], qdd[NARM], tau[NARM], ff[NFING];
 #pragma unroll
-        for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][lane]; qdd[k] = xch[b][NARM + k][lane]; }
+        for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][col]; qdd[k] = xch[b][NARM + k][col]; }
         push_control(c, st, qd, qdd, 0.04, false, tau, ff);
-        gen_physics_substep(c, gc, st, sc, tau, ff);
+        gen_phase1(c, gc, st, sc, tau, ff);
       }
+      int cnt = 0;
+      if (plive) cnt = gen_phase2(gc, sc, l, grav, lfl);
+      gen_sync();
+      if (plive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl);
+      gen_sync();
+      if (arm_lane) gen_phase3b(c, gc, st, sc);
+      gen_sync();
+      if (plive) gen_phase4(gc, sc, l, warm_valid, lfl);
+      gen_sync();
+      if (arm_lane) gen_phase5_arm(c, gc, st, sc);
+      if (plive) gen_phase5_cube(gc, sc, l, c.timestep);
+      gen_sync();
+      warm_valid = true;
     }
-    if (live) {
+    if (plive && l > 0) GLS(GL_INFO + 4 + l) = (double)lfl;
+    gen_sync();
+    if (arm_lane) {
       int code = 0;
-      st.flags |= F_IK_VALID;
+      for (int k = 1; k < gc.nb; k++) lfl |= (unsigned)GLS(GL_INFO + 4 + k);
+      st.flags |= F_IK_VALID | PF_WARM_VALID | lfl;
       sort_step_end(gc, st, sc, &code);
       gen_store_arm(state, flags, steps, stride, e, st, false);
       const int od = 2 + 3 * gc.nb;
@@ -122,7 +148,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(const GenConsts* __re
 }
 
 // env.reset(random=False, context) for masked environments; contexts: f64 [n][7 nb] = nb x (pos3, quat4), red boxes first
-__global__ __launch_bounds__(WAVE) void k_sorting_reset(const GenConsts* __restrict__ gcp, const double* __restrict__ init_qpos, const unsigned char* __restrict__ mask,
+__global__ __launch_bounds__(WAVE) void k_sorting_reset(const double* __restrict__ init_qpos, const unsigned char* __restrict__ mask,
                                                         const double* __restrict__ contexts, double* __restrict__ state, unsigned* __restrict__ flags,
                                                         int* __restrict__ steps, float* __restrict__ obs, unsigned char* __restrict__ done,
                                                         unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ scratch, int n, int stride) {
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(WAVE) void k_sorting_reset(const GenConsts* __restr
   const int e = blockIdx.x * GEN_LANES + lane;
   if (lane >= GEN_LANES || e >= n) return;
   if (mask && !mask[e]) return;
-  const GenConsts& gc = *gcp;
+  const GenConsts& gc = g_gen_consts;
   EnvState st;
   double iq[NARM];
 #pragma unroll

@@ -1,24 +1,34 @@
-// gen_step.h - generic (memory-resident) sub-step for "Panda arm + rod + NB free cubes + NS static boxes": the engine the
-// Sorting task (4 cubes, 2 table slabs, 8 bin walls, platform) runs on until it gets specialised fast paths like Pushing's.
+// gen_step.h - generic sub-step for "Panda arm + rod + NB free cubes + NS static boxes": the engine of the Sorting task
+// (4 cubes, 2 table slabs, 8 bin walls, platform).
 //
-// Everything that varies in size lives in the per-lane scratch areas (contact records, vectors in HBM; the dense
-// (6 NB + 9)^2 Hessian in the LDS area), so the code is loop based and register-light:
-//   collision   every cube against every static box (sphere pre-test, then box_box in the oracle's geom order), cube
-//               pairs, rod against every cube;
-//   constraints 9 joint-limit rows + condim-3 elliptic cones, contact parameters mixed per pair (priority: the platform's
-//               own solref / solimp / friction, sorting platform.xml);
-//   solve       primal Newton with safeguarded exact line search on the full system, dense LDL^T in the h area;
-//   integrate   semi-implicit Euler (arm with implicit finger damping, cubes with quaternion integration).
-// Same numerics as the oracle's generic engine up to solver tolerance; compared with it in tests/test_sorting_host.py.
+// An environment is worked on by a group of NB lanes, lane l owning cube l (lane 0 also owns the arm):
+//   phase 1  lane 0    arm forward dynamics, smooth acceleration, limit rows, rod pose; the arm-alone solution (finger limit
+//                      rows in closed form) as the default arm result
+//   phase 2  lane l    cube l: rotation matrix, collision against the static boxes (sphere pre-test, then box_box in the
+//                      model's geom order)
+//   phase 3  lane l    cube l against the cubes after it and against the rod; lane 0 then adds the arm Jacobian rows of
+//                      the rod contacts
+//   phase 4  lane l    the constraint system is split into islands (connected components of cubes and arm under cube-cube
+//                      and rod contacts); the lane of an island's first cube solves it: primal Newton with safeguarded exact
+//                      line search, elliptic cones (condim 3), contact parameters mixed per pair (priority: the platform's
+//                      own solref / solimp / friction), dense Cholesky over the island's dofs.  A cube resting on the
+//                      platform or the table is a 6-dof island with 4 .. 8 contacts; the arm joins an island only through a
+//                      rod contact
+//   phase 5  lane l    semi-implicit Euler: arm with implicit finger damping (lane 0), cube l with quaternion integration
+// The group's lanes are lanes of one wavefront on the device (wave-level fences between the phases, gen_kernels.h); the host
+// build runs the lanes one after the other.  Per-environment working set: vectors, rotation matrices, arm mass matrix,
+// limit rows and the dense (6 NB + 9)^2 Hessian in LDS (t area); contact records in HBM (g area); the cubes' state in the
+// state buffer itself (w area).  Same numerics as the oracle's generic engine up to solver tolerance
+// (tests/test_sorting_host.py, tests/test_gpu_parity_sorting.py).
 #pragma once
 #include "push_step.h"
 
 namespace d3il {
 
-constexpr int GEN_MAXNB = 4, GEN_MAXNS = 12, GEN_MAXCON = 72, GEN_MAXSET = GEN_MAXNS + 2;
+constexpr int GEN_MAXNB = 4, GEN_MAXNS = 12, GEN_SEG = 24, GEN_MAXCON = GEN_MAXNB * GEN_SEG, GEN_MAXSET = GEN_MAXNS + 2;
 constexpr int GEN_MAXNV = 6 * GEN_MAXNB + NDOF;     // 33
 constexpr int GEN_NH = GEN_MAXNV * (GEN_MAXNV + 1) / 2;   // 561
-constexpr int GEN_LANES = 32;           // environments per workgroup: 32 x 561 doubles of LDS for the Hessians
+constexpr int GEN_LANES = 16;           // environments per workgroup (x GEN_MAXNB lanes each = one wavefront)
 
 struct GenConsts {
   int nb, ns, set_bb, set_rod;
@@ -31,6 +41,17 @@ struct GenConsts {
   double absent[7];               // pose reported for boxes the model does not have (body id -1)
 };
 
+// On the device the constants sit in constant memory (uniform reads become scalar loads); every function re-binds its `gc`
+// to that object so that no generic pointer to it survives a call boundary.  One Sorting model per process.
+#if defined(__HIPCC__)
+__constant__ GenConsts g_gen_consts;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define D3IL_GEN_CONSTS(in, name) const GenConsts& name = g_gen_consts; (void)in
+#else
+#define D3IL_GEN_CONSTS(in, name) const GenConsts& name = in
+#endif
+
 // The w area of the scratch views is the environment's object block of the state buffer (rows 42 ..): the cubes' pos[3] quat[4]
 // vel[6], then the solver's warm start [nv], then the two task words (stored as doubles).  The cubes stay there for the
 // whole step - only the arm lives in registers.
@@ -39,243 +60,500 @@ struct GenConsts {
 #define GTASK(k) PWS(13 * gc.nb + 6 * gc.nb + NDOF + (k))
 D3IL_HD constexpr int gen_state_rows(int nb) { return 42 + 13 * nb + 6 * nb + NDOF + 2; }
 
-// g-area layout (doubles per lane)
-constexpr int GG_M = 0, GG_A0 = 45, GG_X = GG_A0 + GEN_MAXNV, GG_P = GG_X + GEN_MAXNV, GG_G = GG_P + GEN_MAXNV, GG_VEL = GG_G + GEN_MAXNV;
-constexpr int GG_R = GG_VEL + GEN_MAXNV, GG_POS = GG_R + 9 * GEN_MAXNB, GG_LIM = GG_POS + 3 * GEN_MAXNB, GG_JA = GG_LIM + 27;
-constexpr int GG_CON = GG_JA + 21 * GEN_MAXNB;
-constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn mu fric | jar[3] jp[3]
-constexpr int GG_SIZE = GG_CON + GEN_MAXCON * GREC;
-enum { GK_STATIC = 0, GK_BOXBOX = 1, GK_ROD = 2 };
-
-struct GRow { int o1, o2, n2; double v1[6], v2[7]; };
-
-// rows of contact ci over the solver dofs [cube0 .. cube(nb-1) | arm]; the contact normal points from geom 1 to geom 2 and
-// the row is J(body 2) - J(body 1)
-D3IL_HD void gen_rows(const GenConsts& gc, const PushScratch& sc, int ci, GRow* rows) {
-  const int base = GG_CON + ci * GREC, arm0 = 6 * gc.nb;
-  double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
-  const int kind = (int)PGS(base + 13), a = (int)PGS(base + 14), b = (int)PGS(base + 15);
-  const int c1 = kind == GK_STATIC ? b : a;        // first cube of the row (static: b = cube, a = static index)
-  double R[9], r[3];
-  for (int k = 0; k < 9; k++) R[k] = PGS(GG_R + 9 * c1 + k);
-  for (int k = 0; k < 3; k++) r[k] = p[k] - PGS(GG_POS + 3 * c1 + k);
-  for (int rr = 0; rr < 3; rr++) {
-    double f[3] = {PGS(base + 3 + 3 * rr), PGS(base + 4 + 3 * rr), PGS(base + 5 + 3 * rr)};
-    GRow& s = rows[rr];
-    box_row_r(R, r, f, s.v1);
-    for (int k = 0; k < 7; k++) s.v2[k] = 0;
-    s.o1 = 6 * c1; s.o2 = 0; s.n2 = 0;
-    if (kind == GK_STATIC) {
-      if (!gc.st_first[a]) for (int k = 0; k < 6; k++) s.v1[k] = -s.v1[k];       // cube is geom 1
-    } else if (kind == GK_BOXBOX) {
-      for (int k = 0; k < 6; k++) s.v1[k] = -s.v1[k];
-      double R2[9], r2[3], t[6];
-      for (int k = 0; k < 9; k++) R2[k] = PGS(GG_R + 9 * b + k);
-      for (int k = 0; k < 3; k++) r2[k] = p[k] - PGS(GG_POS + 3 * b + k);
-      box_row_r(R2, r2, f, t);
-      s.o2 = 6 * b; s.n2 = 6;
-      for (int k = 0; k < 6; k++) s.v2[k] = t[k];
-    } else {
-      for (int k = 0; k < 6; k++) s.v1[k] = -s.v1[k];
-      s.o2 = arm0; s.n2 = 7;
-      for (int k = 0; k < 7; k++) s.v2[k] = PGS(GG_JA + 21 * a + 7 * rr + k);
-    }
-  }
-}
-D3IL_HD double grow_dot(const PushScratch& sc, const GRow& s, int vec) {
-  double acc = 0;
-  for (int k = 0; k < 6; k++) acc += s.v1[k] * PGS(vec + s.o1 + k);
-  for (int k = 0; k < s.n2; k++) acc += s.v2[k] * PGS(vec + s.o2 + k);
-  return acc;
-}
-D3IL_HD double gen_M(const GenConsts& gc, const PushScratch& sc, int i, int k) {
-  const int arm0 = 6 * gc.nb;
-  if (i < arm0 || k < arm0) return i == k ? ((i % 6) < 3 ? gc.box_mass : gc.box_inertia) : 0.0;
-  int a = i - arm0, b = k - arm0;
-  return PGS(GG_M + (a >= b ? tri(a, b) : tri(b, a)));
-}
-// H (h area, packed lower, order nv) -> L L^T in place; solve in place on the g vector at `vec`
+// t area (LDS, doubles per environment; the lane stride is odd so that the lanes of a group do not pile up on a bank)
 #if defined(__HIP_DEVICE_COMPILE__)
-#define GEN_HS GEN_LANES
+#define GEN_HS (GEN_LANES + 1)
 #else
 #define GEN_HS 1
 #endif
-#define GHS(i) sc.h[(i) * GEN_HS]
-D3IL_HD bool gen_chol(const PushScratch& sc, int nv) {
-  bool ok = true;
-  for (int i = 0; i < nv; i++)
-    for (int j = 0; j <= i; j++) {
-      double s = GHS(tri(i, j));
-      for (int k = 0; k < j; k++) s -= GHS(tri(i, k)) * GHS(tri(j, k));
-      if (i == j) { if (!(s > 0)) { ok = false; s = 1; } GHS(tri(i, i)) = sqrt(s); }
-      else GHS(tri(i, j)) = s / GHS(tri(j, j));
+#define GLS(i) sc.h[(i) * GEN_HS]
+constexpr int GL_H = 0, GL_X = GEN_NH, GL_P = GL_X + GEN_MAXNV, GL_G = GL_P + GEN_MAXNV, GL_A0 = GL_G + GEN_MAXNV, GL_VEL = GL_A0 + GEN_MAXNV;
+constexpr int GL_R = GL_VEL + GEN_MAXNV, GL_POS = GL_R + 9 * GEN_MAXNB, GL_M = GL_POS + 3 * GEN_MAXNB, GL_LIM = GL_M + 45, GL_JA = GL_LIM + 27;
+constexpr int GL_ROD = GL_JA + 21 * GEN_MAXNB;      // rod centre[3], axis[3]
+constexpr int GL_INFO = GL_ROD + 6;                 // [0..3] per cube: contact count | partner cubes << 5 | rod contact << 9;  [4] arm joint at a limit;  [5..7] flags of lanes 1..3
+constexpr int GL_SIZE = GL_INFO + 8;                // 944
+// g area (HBM): contact records, GEN_SEG per cube
+constexpr int GG_CON = 0;
+constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn fric set | jar[3] jp[3]
+constexpr int GG_SIZE = GG_CON + GEN_MAXCON * GREC;
+enum { GK_STATIC = 0, GK_BOXBOX = 1, GK_ROD = 2 };
+
+D3IL_HD void gen_sync() {     // orders the LDS / HBM traffic of the lanes of a group between two phases
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+// ---- islands.  mask: bit b = cube b, bit nb = arm.  An island's blocks sit in a packed list (4 bits per entry, ascending:
+// cubes, then the arm), and its Newton system is stored compactly: block k of the list owns the compact dofs 6 k .. (the arm,
+// always last, 9 of them).  The gradient / direction vectors (voff) and the packed lower Hessian (hoff) of the islands of an
+// environment are laid out one after the other in the t area, so the lanes of a group can solve their islands side by side.
+struct Isl { unsigned list; int n, m, hoff, voff; bool arm; };
+D3IL_HD Isl gen_island(unsigned mask, int nb) {
+  Isl s{0u, 0, 0, 0, 0, false};
+  for (int b = 0; b <= nb; b++) if ((mask >> b) & 1) { s.list |= (unsigned)b << (4 * s.n); s.n++; s.m += b < nb ? 6 : NDOF; }
+  s.arm = ((mask >> nb) & 1) != 0;
+  return s;
+}
+#define ISL_BLK(k) ((int)((isl.list >> (4 * (k))) & 15u))
+#define GEN_FOR_BLOCKS(b) for (int k_##b = 0, b = ISL_BLK(0); k_##b < isl.n; k_##b++, b = ISL_BLK(k_##b))
+// (ci, gi): compact and global index of every dof of the island
+#define GEN_FOR_DOFS(ci, gi) GEN_FOR_BLOCKS(b_) for (int ci = 6 * k_b_, gi = 6 * b_, e_ = gi + (b_ < gc.nb ? 6 : NDOF); gi < e_; ci++, gi++)
+#define GEN_FOR_CONTACTS(ci) GEN_FOR_BLOCKS(c_) if (c_ < gc.nb) \
+    for (int q_ = 0, n_ = (int)GLS(GL_INFO + c_) & 31, ci = c_ * GEN_SEG; q_ < n_; q_++, ci++)
+D3IL_HD int isl_rank(const Isl isl, int b) {   // position of block b in the island's list
+  int r = 0;
+  for (int k = 0; k < isl.n; k++) if (ISL_BLK(k) == b) r = k;
+  return r;
+}
+
+// rows of a contact over the solver dofs; the contact normal points from geom 1 to geom 2 and the row is J(body 2) - J(body 1).
+// Block 1: the first cube (6 dofs, global offset o1, compact c1); block 2: the second cube or the arm (n2 = 0, 6 or 7 dofs)
+struct GRow { int o1, o2, n2, c1, c2; double v1[6], v2[7]; };
+// rec: the first 16 fields of the contact's record (pos[3] frame[9] dist kind a b), fetched by the caller in one batch
+D3IL_HD void gen_rows(const GenConsts& gc_, const PushScratch sc, const Isl isl, const double* rec, GRow* rows) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  const int arm0 = 6 * gc.nb;
+  const int kind = (int)rec[13], a = (int)rec[14], b = (int)rec[15];
+  const int cb1 = kind == GK_STATIC ? b : a;        // first cube of the row (static: b = cube, a = static index)
+  double R[9], r[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = GLS(GL_R + 9 * cb1 + k);
+#pragma unroll
+  for (int k = 0; k < 3; k++) r[k] = rec[k] - GLS(GL_POS + 3 * cb1 + k);
+  const int c1 = 6 * isl_rank(isl, cb1);
+  int o2 = 0, n2 = 0, c2 = 0;
+  double sign1 = -1.0;
+  if (kind == GK_STATIC) sign1 = gc.st_first[a] ? 1.0 : -1.0;      // cube is geom 2 / geom 1
+  else if (kind == GK_BOXBOX) { o2 = 6 * b; n2 = 6; c2 = 6 * isl_rank(isl, b); }
+  else { o2 = arm0; n2 = 7; c2 = isl.m - NDOF; }
+#pragma unroll
+  for (int rr = 0; rr < 3; rr++) {
+    GRow& s = rows[rr];
+    box_row_r(R, r, rec + 3 + 3 * rr, s.v1);
+#pragma unroll
+    for (int k = 0; k < 6; k++) s.v1[k] *= sign1;
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v2[k] = 0;
+    s.o1 = 6 * cb1; s.c1 = c1; s.o2 = o2; s.n2 = n2; s.c2 = c2;
+  }
+  if (kind == GK_BOXBOX) {
+    double R2[9], r2[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R2[k] = GLS(GL_R + 9 * b + k);
+#pragma unroll
+    for (int k = 0; k < 3; k++) r2[k] = rec[k] - GLS(GL_POS + 3 * b + k);
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+      double t[6];
+      box_row_r(R2, r2, rec + 3 + 3 * rr, t);
+#pragma unroll
+      for (int k = 0; k < 6; k++) rows[rr].v2[k] = t[k];
     }
+  } else if (kind == GK_ROD) {
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+      for (int k = 0; k < 7; k++) rows[rr].v2[k] = GLS(GL_JA + 21 * a + 7 * rr + k);
+  }
+}
+// row . vector of the t area: globally indexed (x, velocities) or the island's compact vector at vec
+D3IL_HD double grow_dot_g(const PushScratch sc, const GRow& s, int vec) {
+  double acc = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc += s.v1[k] * GLS(vec + s.o1 + k);
+#pragma unroll
+  for (int k = 0; k < 7; k++) if (k < s.n2) acc += s.v2[k] * GLS(vec + s.o2 + k);
+  return acc;
+}
+D3IL_HD double grow_dot_c(const PushScratch sc, const GRow& s, int vec) {
+  double acc = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc += s.v1[k] * GLS(vec + s.c1 + k);
+#pragma unroll
+  for (int k = 0; k < 7; k++) if (k < s.n2) acc += s.v2[k] * GLS(vec + s.c2 + k);
+  return acc;
+}
+// sum_k M(a, k) v(k) over the arm dofs; v at t-area offset va (minus the vector at vb if vb >= 0)
+D3IL_HD double gen_arm_Mv(const PushScratch sc, int a, int va, int vb) {
+  double s = 0;
+  for (int k = 0; k < NDOF; k++) {
+    double m = GLS(GL_M + (a >= k ? tri(a, k) : tri(k, a)));
+    s += m * (vb >= 0 ? GLS(va + k) - GLS(vb + k) : GLS(va + k));
+  }
+  return s;
+}
+// Dense Cholesky of the island's compact Hessian (packed lower at hb, order m), right-looking so that the updates of a
+// column are independent of each other; then the two triangular solves on the compact vector at vec
+D3IL_HD bool gen_chol(const PushScratch sc, int hb, int m) {
+  bool ok = true;
+  for (int j = 0; j < m; j++) {
+    const int rj = hb + tri(j, 0);
+    double d = GLS(rj + j);
+    if (!(d > 0)) { ok = false; d = 1; }
+    d = sqrt(d);
+    GLS(rj + j) = d;
+    const double inv = 1.0 / d;
+    for (int i = j + 1; i < m; i++) GLS(hb + tri(i, j)) *= inv;
+    for (int i = j + 1; i < m; i++) {
+      const int ri = hb + tri(i, 0);
+      const double lij = GLS(ri + j);
+      int k = j + 1;
+      for (; k + 3 <= i; k += 4) {   // four independent updates: all eight loads are issued before the first store
+        double t0 = GLS(ri + k), t1 = GLS(ri + k + 1), t2 = GLS(ri + k + 2), t3 = GLS(ri + k + 3);
+        double m0 = GLS(hb + tri(k, j)), m1 = GLS(hb + tri(k + 1, j)), m2 = GLS(hb + tri(k + 2, j)), m3 = GLS(hb + tri(k + 3, j));
+        GLS(ri + k) = t0 - lij * m0; GLS(ri + k + 1) = t1 - lij * m1; GLS(ri + k + 2) = t2 - lij * m2; GLS(ri + k + 3) = t3 - lij * m3;
+      }
+      for (; k <= i; k++) GLS(ri + k) -= lij * GLS(hb + tri(k, j));
+    }
+  }
   return ok;
 }
-D3IL_HD void gen_chol_solve(const PushScratch& sc, int nv, int vec) {
-  for (int i = 0; i < nv; i++) {
-    double s = PGS(vec + i);
-    for (int k = 0; k < i; k++) s -= GHS(tri(i, k)) * PGS(vec + k);
-    PGS(vec + i) = s / GHS(tri(i, i));
+D3IL_HD void gen_chol_solve(const PushScratch sc, int hb, int m, int vec) {
+  for (int i = 0; i < m; i++) {
+    const int ri = hb + tri(i, 0);
+    double s = GLS(vec + i);
+#pragma unroll 4
+    for (int k = 0; k < i; k++) s -= GLS(ri + k) * GLS(vec + k);
+    GLS(vec + i) = s / GLS(ri + i);
   }
-  for (int i = nv - 1; i >= 0; i--) {
-    double xi = PGS(vec + i) / GHS(tri(i, i));
-    PGS(vec + i) = xi;
-    for (int k = 0; k < i; k++) PGS(vec + k) -= GHS(tri(i, k)) * xi;
-  }
-}
-
-// contact collection; returns the count (contacts beyond GEN_MAXCON are dropped and flagged)
-D3IL_NOINLINE inline int gen_collect(const GenConsts& gc, const PushScratch& sc, const double* rodc, const double* rodu, double rod_r, double rod_h, unsigned* flags) {
-  int ncon = 0;
-  const double rcirc = sqrt(gc.box_half[0] * gc.box_half[0] + gc.box_half[1] * gc.box_half[1] + gc.box_half[2] * gc.box_half[2]);
-  auto put = [&](const double* rec, double nsign, int kind, int a, int b, int set) {
-    if (ncon >= GEN_MAXCON) { *flags |= PF_CON_OVERFLOW; return; }
-    int base = GG_CON + ncon * GREC;
-    double n[3] = {nsign * rec[4], nsign * rec[5], nsign * rec[6]}, t1[3], t2[3];
-    make_frame(n, t1, t2);
-    for (int k = 0; k < 3; k++) { PGS(base + k) = rec[1 + k]; PGS(base + 3 + k) = n[k]; PGS(base + 6 + k) = t1[k]; PGS(base + 9 + k) = t2[k]; }
-    PGS(base + 12) = rec[0]; PGS(base + 13) = kind; PGS(base + 14) = a; PGS(base + 15) = b; PGS(base + 21) = set;
-    ncon++;
-  };
-  double rec[8][7];
-  for (int c = 0; c < gc.nb; c++) {
-    double pc[3], Rc[9];
-    for (int k = 0; k < 3; k++) pc[k] = PGS(GG_POS + 3 * c + k);
-    for (int k = 0; k < 9; k++) Rc[k] = PGS(GG_R + 9 * c + k);
-    for (int s = 0; s < gc.ns; s++) {
-      // sphere against the static box (in its frame): cheap exact rejection
-      double d2 = 0;
-      for (int i = 0; i < 3; i++) {
-        double x = (pc[0] - gc.st_c[s][0]) * gc.st_R[s][i] + (pc[1] - gc.st_c[s][1]) * gc.st_R[s][3 + i] + (pc[2] - gc.st_c[s][2]) * gc.st_R[s][6 + i];
-        double e = fabs(x) - gc.st_h[s][i];
-        if (e > 0) d2 += e * e;
-      }
-      if (d2 > rcirc * rcirc) continue;
-      int n = gc.st_first[s] ? box_box(gc.st_c[s], gc.st_R[s], gc.st_h[s], pc, Rc, gc.box_half, 0.0, rec, 8)
-                             : box_box(pc, Rc, gc.box_half, gc.st_c[s], gc.st_R[s], gc.st_h[s], 0.0, rec, 8);
-      for (int i = 0; i < n; i++) put(rec[i], 1.0, GK_STATIC, s, c, s);
+  for (int i = m - 1; i >= 0; i--) {
+    const int ri = hb + tri(i, 0);
+    const double xi = GLS(vec + i) / GLS(ri + i);
+    GLS(vec + i) = xi;
+    int k = 0;
+    for (; k + 3 < i; k += 4) {
+      double t0 = GLS(vec + k), t1 = GLS(vec + k + 1), t2 = GLS(vec + k + 2), t3 = GLS(vec + k + 3);
+      double m0 = GLS(ri + k), m1 = GLS(ri + k + 1), m2 = GLS(ri + k + 2), m3 = GLS(ri + k + 3);
+      GLS(vec + k) = t0 - m0 * xi; GLS(vec + k + 1) = t1 - m1 * xi; GLS(vec + k + 2) = t2 - m2 * xi; GLS(vec + k + 3) = t3 - m3 * xi;
     }
+    for (; k < i; k++) GLS(vec + k) -= GLS(ri + k) * xi;
   }
-  for (int c = 0; c < gc.nb; c++) for (int d = c + 1; d < gc.nb; d++) {
-    double pc[3], pd[3], Rc[9], Rd[9], dd = 0;
-    for (int k = 0; k < 3; k++) { pc[k] = PGS(GG_POS + 3 * c + k); pd[k] = PGS(GG_POS + 3 * d + k); dd += (pc[k] - pd[k]) * (pc[k] - pd[k]); }
-    if (dd > 4 * rcirc * rcirc) continue;
-    for (int k = 0; k < 9; k++) { Rc[k] = PGS(GG_R + 9 * c + k); Rd[k] = PGS(GG_R + 9 * d + k); }
-    int n = box_box(pc, Rc, gc.box_half, pd, Rd, gc.box_half, 0.0, rec, 8);
-    for (int i = 0; i < n; i++) put(rec[i], 1.0, GK_BOXBOX, c, d, gc.set_bb);
-  }
-  for (int c = 0; c < gc.nb; c++) {
-    double pc[3], Rc[9], r1[7];
-    for (int k = 0; k < 3; k++) pc[k] = PGS(GG_POS + 3 * c + k);
-    for (int k = 0; k < 9; k++) Rc[k] = PGS(GG_R + 9 * c + k);
-    double w[3] = {pc[0] - rodc[0], pc[1] - rodc[1], pc[2] - rodc[2]};
-    double t = clampd(dot3(w, rodu), -rod_h, rod_h);
-    double e[3] = {w[0] - t * rodu[0], w[1] - t * rodu[1], w[2] - t * rodu[2]};
-    if (dot3(e, e) >= (rcirc + rod_r) * (rcirc + rod_r)) continue;
-    if (cyl_box(rodc, rodu, rod_r, rod_h, pc, Rc, gc.box_half, 0.0, r1)) put(r1, 1.0, GK_ROD, c, 0, gc.set_rod);   // cube is geom 1: normal cube -> rod
-  }
-  return ncon;
 }
 
-// Newton solve on the collected system; x in / out at GG_X.  Returns false when it did not converge.
-D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc, const PushScratch& sc, int ncon) {
-  const int arm0 = 6 * gc.nb, nv = arm0 + NDOF;
-  const double impr = gc.impratio;
-  for (int ci = 0; ci < ncon; ci++) {   // reference acceleration and regularisation
-    int base = GG_CON + ci * GREC, kind = (int)PGS(base + 13), set = (int)PGS(base + 21);
-    double dist = PGS(base + 12);
+// Newton solve of one island; x in / out at GL_X (island dofs).  Returns false when it did not converge.
+D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, const Isl isl) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  const int arm0 = 6 * gc.nb, ca = isl.m - NDOF;       // global / compact offset of the arm block (when isl.arm)
+  const int hb = GL_H + isl.hoff, vg = GL_G + isl.voff, vp = GL_P + isl.voff;
+  const double impr = gc.impratio, mu_scale = sqrt(1 / fmax(1e-15, impr));
+  PUSH_TIC;
+  GEN_FOR_CONTACTS(ci) {   // reference acceleration and regularisation
+    const int base = GG_CON + ci * GREC;
+    double rec[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
+    const int kind = (int)rec[13], set = kind == GK_STATIC ? (int)rec[14] : (kind == GK_BOXBOX ? gc.set_bb : gc.set_rod);
+    const double dist = rec[12];
     double imp = impedance(gc.ct_solimp[set], dist);
     double invw = kind == GK_STATIC ? gc.box_invw_t : (kind == GK_BOXBOX ? 2 * gc.box_invw_t : gc.box_invw_t + gc.rod_invw);
     GRow rows[3];
-    gen_rows(gc, sc, ci, rows);
-    double v0 = grow_dot(sc, rows[0], GG_VEL), v1 = grow_dot(sc, rows[1], GG_VEL), v2 = grow_dot(sc, rows[2], GG_VEL);
+    gen_rows(gc, sc, isl, rec, rows);
+    double v0 = grow_dot_g(sc, rows[0], GL_VEL), v1 = grow_dot_g(sc, rows[1], GL_VEL), v2 = grow_dot_g(sc, rows[2], GL_VEL);
     PGS(base + 16) = -gc.ct_B[set] * v0 - gc.ct_K[set] * imp * dist;
     PGS(base + 17) = -gc.ct_B[set] * v1; PGS(base + 18) = -gc.ct_B[set] * v2;
     PGS(base + 19) = 1 / fmax(1e-15, (1 - imp) / imp * invw);
-    PGS(base + 20) = gc.ct_fric[set] * sqrt(1 / fmax(1e-15, impr));
+    PGS(base + 20) = gc.ct_fric[set];
   }
   bool converged = false;
+  PUSH_TOC(3);
+  D3IL_STAT(g_stats.newton_calls++);
+  D3IL_STAT(g_stats.eig_calls += isl.m);
   for (int it = 0; it < 60 && !converged; it++) {
-    for (int i = 0; i < nv; i++) {
-      double s = 0;
-      if (i < arm0) s = gen_M(gc, sc, i, i) * (PGS(GG_X + i) - PGS(GG_A0 + i));
-      else for (int k = arm0; k < nv; k++) s += gen_M(gc, sc, i, k) * (PGS(GG_X + k) - PGS(GG_A0 + k));
-      PGS(GG_G + i) = s;
-    }
-    for (int i = 0; i < nv * (nv + 1) / 2; i++) GHS(i) = 0;
-    for (int i = 0; i < arm0; i++) GHS(tri(i, i)) = gen_M(gc, sc, i, i);
-    for (int i = 0; i < NDOF; i++) for (int k = 0; k <= i; k++) GHS(tri(arm0 + i, arm0 + k)) = PGS(GG_M + tri(i, k));
-    for (int k = 0; k < NDOF; k++) {
-      double sign = PGS(GG_LIM + 3 * k), D = PGS(GG_LIM + 3 * k + 1), aref = PGS(GG_LIM + 3 * k + 2);
-      if (sign != 0) {
-        double jar = sign * PGS(GG_X + arm0 + k) - aref;
-        if (jar < 0) { PGS(GG_G + arm0 + k) += sign * D * jar; GHS(tri(arm0 + k, arm0 + k)) += D; }
+    D3IL_STAT(g_stats.newton_iters++);
+    D3IL_STAT(g_stats.ik_calls += isl.m * isl.m * isl.m / 6);
+    // gradient (compact, at vg) and Hessian (compact, at hb) at x
+    for (int i = 0, nh = isl.m * (isl.m + 1) / 2; i < nh; i++) GLS(hb + i) = 0;
+    GEN_FOR_DOFS(ci, gi) {
+      if (gi < arm0) { const double mm = (gi % 6) < 3 ? gc.box_mass : gc.box_inertia; GLS(vg + ci) = mm * (GLS(GL_X + gi) - GLS(GL_A0 + gi)); GLS(hb + tri(ci, ci)) = mm; }
+      else {
+        GLS(vg + ci) = gen_arm_Mv(sc, gi - arm0, GL_X + arm0, GL_A0 + arm0);
+        for (int k = 0; k <= gi - arm0; k++) GLS(hb + tri(ci, ca + k)) = GLS(GL_M + tri(gi - arm0, k));
       }
     }
-    for (int ci = 0; ci < ncon; ci++) {
-      int base = GG_CON + ci * GREC;
+    if (isl.arm)
+      for (int k = 0; k < NDOF; k++) {
+        double sign = GLS(GL_LIM + 3 * k), D = GLS(GL_LIM + 3 * k + 1), aref = GLS(GL_LIM + 3 * k + 2);
+        if (sign != 0) {
+          double jar = sign * GLS(GL_X + arm0 + k) - aref;
+          if (jar < 0) { GLS(vg + ca + k) += sign * D * jar; GLS(hb + tri(ca + k, ca + k)) += D; }
+        }
+      }
+    GEN_FOR_CONTACTS(ci) {
+      const int base = GG_CON + ci * GREC;
+      double rec[21];
+#pragma unroll
+      for (int k = 0; k < 21; k++) rec[k] = PGS(base + k);
       GRow rows[3];
-      gen_rows(gc, sc, ci, rows);
+      gen_rows(gc, sc, isl, rec, rows);
       double jar[3], force[3], Hc[9];
-      for (int r = 0; r < 3; r++) { jar[r] = grow_dot(sc, rows[r], GG_X) - PGS(base + 16 + r); PGS(base + 22 + r) = jar[r]; }
-      double Dn = PGS(base + 19), mu = PGS(base + 20), fric = gc.ct_fric[(int)PGS(base + 21)];
-      cone_eval(jar, Dn, Dn * impr, mu, fric, force, Hc);
+#pragma unroll
+      for (int r = 0; r < 3; r++) { jar[r] = grow_dot_g(sc, rows[r], GL_X) - rec[16 + r]; PGS(base + 22 + r) = jar[r]; }
+      const double Dn = rec[19], fric = rec[20];
+      cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
       if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
-      const int o1 = rows[0].o1, o2 = rows[0].o2, n2 = rows[0].n2;
-      for (int k = 0; k < 6; k++) PGS(GG_G + o1 + k) -= rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2];
-      for (int k = 0; k < n2; k++) PGS(GG_G + o2 + k) -= rows[0].v2[k] * force[0] + rows[1].v2[k] * force[1] + rows[2].v2[k] * force[2];
-      for (int a = 0; a < 6; a++) {
-        double ta[3];
-        for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v1[a] + Hc[3 * r + 1] * rows[1].v1[a] + Hc[3 * r + 2] * rows[2].v1[a];
-        for (int b = 0; b <= a; b++) GHS(tri(o1 + a, o1 + b)) += ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b];
+      const int c1 = rows[0].c1, c2 = rows[0].c2, n2 = rows[0].n2;
+#pragma unroll
+      for (int k = 0; k < 6; k++) GLS(vg + c1 + k) -= rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2];
+#pragma unroll
+      for (int k = 0; k < 7; k++) if (k < n2) GLS(vg + c2 + k) -= rows[0].v2[k] * force[0] + rows[1].v2[k] * force[1] + rows[2].v2[k] * force[2];
+      // H += J' Hc J block by block; each block is read in one batch, updated in registers and written back
+      {
+        double blk[21];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = 0; b <= a; b++) blk[tri(a, b)] = GLS(hb + tri(c1 + a, c1 + b));
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          double ta[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v1[a] + Hc[3 * r + 1] * rows[1].v1[a] + Hc[3 * r + 2] * rows[2].v1[a];
+#pragma unroll
+          for (int b = 0; b <= a; b++) blk[tri(a, b)] += ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = 0; b <= a; b++) GLS(hb + tri(c1 + a, c1 + b)) = blk[tri(a, b)];
       }
-      for (int a = 0; a < n2; a++) {
-        double ta[3];
-        for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v2[a] + Hc[3 * r + 1] * rows[1].v2[a] + Hc[3 * r + 2] * rows[2].v2[a];
-        // o2 > o1 for every contact kind (second cube index > first, arm after the cubes)
-        for (int b = 0; b < 6; b++) GHS(tri(o2 + a, o1 + b)) += ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b];
-        for (int b = 0; b <= a; b++) GHS(tri(o2 + a, o2 + b)) += ta[0] * rows[0].v2[b] + ta[1] * rows[1].v2[b] + ta[2] * rows[2].v2[b];
+      if (n2 > 0) {   // c2 > c1 for every contact kind (second cube after the first, arm after the cubes)
+        double blk[7][6];
+#pragma unroll
+        for (int a = 0; a < 7; a++)
+#pragma unroll
+          for (int b = 0; b < 6; b++) blk[a][b] = a < n2 ? GLS(hb + tri(c2 + a, c1 + b)) : 0.0;
+        double ta[7][3];
+#pragma unroll
+        for (int a = 0; a < 7; a++)
+#pragma unroll
+          for (int r = 0; r < 3; r++) ta[a][r] = Hc[3 * r] * rows[0].v2[a] + Hc[3 * r + 1] * rows[1].v2[a] + Hc[3 * r + 2] * rows[2].v2[a];
+#pragma unroll
+        for (int a = 0; a < 7; a++)
+#pragma unroll
+          for (int b = 0; b < 6; b++) blk[a][b] += ta[a][0] * rows[0].v1[b] + ta[a][1] * rows[1].v1[b] + ta[a][2] * rows[2].v1[b];
+#pragma unroll
+        for (int a = 0; a < 7; a++) if (a < n2)
+#pragma unroll
+          for (int b = 0; b < 6; b++) GLS(hb + tri(c2 + a, c1 + b)) = blk[a][b];
+        double b22[28];
+#pragma unroll
+        for (int a = 0; a < 7; a++)
+#pragma unroll
+          for (int b = 0; b <= a; b++) b22[tri(a, b)] = a < n2 ? GLS(hb + tri(c2 + a, c2 + b)) : 0.0;
+#pragma unroll
+        for (int a = 0; a < 7; a++)
+#pragma unroll
+          for (int b = 0; b <= a; b++) b22[tri(a, b)] += ta[a][0] * rows[0].v2[b] + ta[a][1] * rows[1].v2[b] + ta[a][2] * rows[2].v2[b];
+#pragma unroll
+        for (int a = 0; a < 7; a++) if (a < n2)
+#pragma unroll
+          for (int b = 0; b <= a; b++) GLS(hb + tri(c2 + a, c2 + b)) = b22[tri(a, b)];
       }
     }
     {
       double gm = 0;
-      for (int k = 0; k < nv; k++) gm = fmax(gm, fabs(PGS(GG_G + k)));
+      for (int k = 0; k < isl.m; k++) gm = fmax(gm, fabs(GLS(vg + k)));
       if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
     }
-    if (!gen_chol(sc, nv)) return false;
-    for (int k = 0; k < nv; k++) PGS(GG_P + k) = -PGS(GG_G + k);
-    gen_chol_solve(sc, nv, GG_P);
+    PUSH_TOC(4);
+    if (!gen_chol(sc, hb, isl.m)) return false;
+    for (int k = 0; k < isl.m; k++) GLS(vp + k) = -GLS(vg + k);
+    gen_chol_solve(sc, hb, isl.m, vp);
+    PUSH_TOC(5);
     double pMp = 0, pMa = 0, gTp = 0;
-    for (int i = 0; i < nv; i++) {
-      double s = 0, sa = 0;
-      if (i < arm0) { double mm = gen_M(gc, sc, i, i); s = mm * PGS(GG_P + i); sa = mm * (PGS(GG_X + i) - PGS(GG_A0 + i)); }
-      else for (int k = arm0; k < nv; k++) { double mm = gen_M(gc, sc, i, k); s += mm * PGS(GG_P + k); sa += mm * (PGS(GG_X + k) - PGS(GG_A0 + k)); }
-      pMp += PGS(GG_P + i) * s; pMa += PGS(GG_P + i) * sa; gTp += PGS(GG_G + i) * PGS(GG_P + i);
+    GEN_FOR_DOFS(ci, gi) {
+      double s, sa, pi = GLS(vp + ci);
+      if (gi < arm0) { const double mm = (gi % 6) < 3 ? gc.box_mass : gc.box_inertia; s = mm * pi; sa = mm * (GLS(GL_X + gi) - GLS(GL_A0 + gi)); }
+      else { s = gen_arm_Mv(sc, gi - arm0, vp + ca, -1); sa = gen_arm_Mv(sc, gi - arm0, GL_X + arm0, GL_A0 + arm0); }
+      pMp += pi * s; pMa += pi * sa; gTp += GLS(vg + ci) * pi;
     }
-    for (int ci = 0; ci < ncon; ci++) {
-      int base = GG_CON + ci * GREC;
+    GEN_FOR_CONTACTS(ci) {
+      const int base = GG_CON + ci * GREC;
+      double rec[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
       GRow rows[3];
-      gen_rows(gc, sc, ci, rows);
-      for (int r = 0; r < 3; r++) PGS(base + 25 + r) = grow_dot(sc, rows[r], GG_P);
+      gen_rows(gc, sc, isl, rec, rows);
+#pragma unroll
+      for (int r = 0; r < 3; r++) PGS(base + 25 + r) = grow_dot_c(sc, rows[r], vp);
     }
+    PUSH_TOC(6);
     double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 50; ls++) {
+      D3IL_STAT(g_stats.ls_iters++);
       double d1 = pMa + alpha * pMp, d2 = pMp;
-      for (int k = 0; k < NDOF; k++) {
-        double sign = PGS(GG_LIM + 3 * k), D = PGS(GG_LIM + 3 * k + 1), aref = PGS(GG_LIM + 3 * k + 2);
-        if (sign != 0) {
-          double jp = sign * PGS(GG_P + arm0 + k), jar = sign * PGS(GG_X + arm0 + k) - aref + alpha * jp;
-          if (jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
+      if (isl.arm)
+        for (int k = 0; k < NDOF; k++) {
+          double sign = GLS(GL_LIM + 3 * k), D = GLS(GL_LIM + 3 * k + 1), aref = GLS(GL_LIM + 3 * k + 2);
+          if (sign != 0) {
+            double jp = sign * GLS(vp + ca + k), jar = sign * GLS(GL_X + arm0 + k) - aref + alpha * jp;
+            if (jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
+          }
         }
+      GEN_FOR_CONTACTS(ci) {
+        const int base = GG_CON + ci * GREC;
+        double rec[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) rec[k] = PGS(base + 19 + k);     // Dn fric set jar[3] jp[3]
+        double jp[3] = {rec[6], rec[7], rec[8]};
+        double jt[3] = {rec[3] + alpha * jp[0], rec[4] + alpha * jp[1], rec[5] + alpha * jp[2]}, ft[3], Hc[9];
+        const double Dn = rec[0], fric = rec[1];
+        cone_eval(jt, Dn, Dn * impr, fric * mu_scale, fric, ft, Hc);
+#pragma unroll
+        for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r];
+#pragma unroll
+          for (int q = 0; q < 3; q++) d2 += jp[r] * Hc[3 * r + q] * jp[q]; }
       }
-      for (int ci = 0; ci < ncon; ci++) {
-        int base = GG_CON + ci * GREC;
-        double jp[3] = {PGS(base + 25), PGS(base + 26), PGS(base + 27)};
-        double jt[3] = {PGS(base + 22) + alpha * jp[0], PGS(base + 23) + alpha * jp[1], PGS(base + 24) + alpha * jp[2]}, ft[3], Hc[9];
-        double Dn = PGS(base + 19), mu = PGS(base + 20), fric = gc.ct_fric[(int)PGS(base + 21)];
-        cone_eval(jt, Dn, Dn * impr, mu, fric, ft, Hc);
-        for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r]; for (int q = 0; q < 3; q++) d2 += jp[r] * Hc[3 * r + q] * jp[q]; }
+      best = alpha;
+      if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
+      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 * rcpd(d2);
+      if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
+        double wbr = hi - lo;
+        bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+    PUSH_TOC(7);
+    double smax = 0, xmax = 0;
+    GEN_FOR_DOFS(ci, gi) {
+      double dxk = best * GLS(vp + ci), xn = GLS(GL_X + gi) + dxk;
+      GLS(GL_X + gi) = xn; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(xn));
+    }
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
+  }
+  return converged;
+}
+// Newton solve of a single-cube island (the cube touches static boxes only): the 6-dof system lives in registers, every
+// contact record is fetched from the g area in one batch of loads per pass.  Same iteration and stopping rules as gen_solve.
+D3IL_NOINLINE inline bool gen_solve_cube(const GenConsts& gc_, const PushScratch sc, int c, int cnt, bool warm_valid) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  const double impr = gc.impratio, mt = gc.box_mass, mr = gc.box_inertia;
+  double R[9], pos[3], vel[6], a0[6], x[6];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = GLS(GL_R + 9 * c + k);
+#pragma unroll
+  for (int k = 0; k < 3; k++) pos[k] = GLS(GL_POS + 3 * c + k);
+#pragma unroll
+  for (int k = 0; k < 6; k++) { vel[k] = GLS(GL_VEL + 6 * c + k); a0[k] = GLS(GL_A0 + 6 * c + k); }
+#pragma unroll
+  for (int k = 0; k < 6; k++) x[k] = warm_valid ? GWARM(6 * c + k) : a0[k];
+  const int seg = GG_CON + c * GEN_SEG * GREC;
+  // rows of the contact whose record (pos[3] frame[9]) is in rc; sign: J(body 2) - J(body 1) with the static as body 1 or 2
+  auto rows_of = [&](const double* rc, double sign, double (*J)[6]) {
+    double r[3] = {rc[0] - pos[0], rc[1] - pos[1], rc[2] - pos[2]};
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+      box_row_r(R, r, rc + 3 + 3 * rr, J[rr]);
+#pragma unroll
+      for (int k = 0; k < 6; k++) J[rr][k] *= sign;
+    }
+  };
+#pragma clang loop unroll(disable)
+  for (int q = 0; q < cnt; q++) {   // reference acceleration and regularisation
+    const int base = seg + q * GREC;
+    double rc[15];
+#pragma unroll
+    for (int k = 0; k < 15; k++) rc[k] = PGS(base + k);
+    const int set = (int)rc[14];
+    double J[3][6];
+    rows_of(rc, gc.st_first[set] ? 1.0 : -1.0, J);
+    double v[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) { v[rr] = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[rr] += J[rr][k] * vel[k]; }
+    const double dist = rc[12], imp = impedance(gc.ct_solimp[set], dist);
+    PGS(base + 16) = -gc.ct_B[set] * v[0] - gc.ct_K[set] * imp * dist;
+    PGS(base + 17) = -gc.ct_B[set] * v[1]; PGS(base + 18) = -gc.ct_B[set] * v[2];
+    PGS(base + 19) = 1 / fmax(1e-15, (1 - imp) / imp * gc.box_invw_t);
+  }
+  const double mu_scale = sqrt(1 / fmax(1e-15, impr));
+  bool converged = false;
+  D3IL_STAT(g_stats.newton_calls++);
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < 60 && !converged; it++) {
+    D3IL_STAT(g_stats.newton_iters++);
+    double g[6], H[21];
+#pragma unroll
+    for (int i = 0; i < 21; i++) H[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { double mm = k < 3 ? mt : mr; g[k] = mm * (x[k] - a0[k]); H[tri(k, k)] = mm; }
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < cnt; q++) {
+      const int base = seg + q * GREC;
+      double rc[20];
+#pragma unroll
+      for (int k = 0; k < 20; k++) rc[k] = PGS(base + k);
+      const int set = (int)rc[14];
+      double J[3][6], jar[3], force[3], Hc[9];
+      rows_of(rc, gc.st_first[set] ? 1.0 : -1.0, J);
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) { double a = -rc[16 + rr];
+#pragma unroll
+        for (int k = 0; k < 6; k++) a += J[rr][k] * x[k];
+        jar[rr] = a; PGS(base + 22 + rr) = a; }
+      const double Dn = rc[19], fric = gc.ct_fric[set];
+      cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
+      if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
+#pragma unroll
+      for (int k = 0; k < 6; k++) g[k] -= J[0][k] * force[0] + J[1][k] * force[1] + J[2][k] * force[2];
+      acc_block(H, 0, 0, J, J, Hc, true);
+    }
+    {
+      double gm = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) gm = fmax(gm, fabs(g[k]));
+      if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
+    }
+    double d[6], id[6], p[6];
+    if (!ldl_n<6>(H, d, id)) return false;
+#pragma unroll
+    for (int k = 0; k < 6; k++) p[k] = -g[k];
+    ldl_solve_n<6>(H, id, p);
+    double pMp = 0, pMa = 0, gTp = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { double mm = k < 3 ? mt : mr; pMp += mm * p[k] * p[k]; pMa += mm * p[k] * (x[k] - a0[k]); gTp += g[k] * p[k]; }
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < cnt; q++) {
+      const int base = seg + q * GREC;
+      double rc[15];
+#pragma unroll
+      for (int k = 0; k < 15; k++) rc[k] = PGS(base + k);
+      double J[3][6];
+      rows_of(rc, gc.st_first[(int)rc[14]] ? 1.0 : -1.0, J);
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) { double a = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) a += J[rr][k] * p[k];
+        PGS(base + 25 + rr) = a; }
+    }
+    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
+#pragma clang loop unroll(disable)
+    for (int ls = 0; ls < 50; ls++) {
+      D3IL_STAT(g_stats.ls_iters++);
+      double d1 = pMa + alpha * pMp, d2 = pMp;
+#pragma clang loop unroll(disable)
+      for (int q = 0; q < cnt; q++) {
+        const int base = seg + q * GREC;
+        double rc[9];     // Dn | - | set? no: 19 Dn, 22..24 jar, 25..27 jp (set is field 14)
+        rc[0] = PGS(base + 19); rc[1] = PGS(base + 14);
+#pragma unroll
+        for (int k = 0; k < 6; k++) rc[2 + k] = PGS(base + 22 + k);
+        double jp[3] = {rc[5], rc[6], rc[7]};
+        double jt[3] = {rc[2] + alpha * jp[0], rc[3] + alpha * jp[1], rc[4] + alpha * jp[2]}, ft[3], Hc[9];
+        const double Dn = rc[0], fric = gc.ct_fric[(int)rc[1]];
+        cone_eval(jt, Dn, Dn * impr, fric * mu_scale, fric, ft, Hc);
+#pragma unroll
+        for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r];
+#pragma unroll
+          for (int qq = 0; qq < 3; qq++) d2 += jp[r] * Hc[3 * r + qq] * jp[qq]; }
       }
       best = alpha;
       if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
@@ -292,51 +570,54 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc, const PushScratch& sc, 
       alpha = na;
     }
     double smax = 0, xmax = 0;
-    for (int k = 0; k < nv; k++) {
-      double dxk = best * PGS(GG_P + k), xn = PGS(GG_X + k) + dxk;
-      PGS(GG_X + k) = xn; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(xn));
-    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { double dxk = best * p[k]; x[k] += dxk; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(x[k])); }
     if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
   }
+#pragma unroll
+  for (int k = 0; k < 6; k++) GLS(GL_X + 6 * c + k) = x[k];
   return converged;
 }
 
-// one physics sub-step (mj_step) of arm + cubes; warm start / result of the solver at sc.w[0 .. nv)
+// ---- phase 1 (lane 0): arm forward pass.  Publishes M, qacc_smooth, velocities, limit rows, rod pose; leaves the arm-alone
+// solution (finger limit rows by the exact active-set solution, as in panda_step.h) at GL_X
 template <class C>
-D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, EnvState& st, const PushScratch& sc, const double* tau, const double* ffing) {
+D3IL_HD void gen_phase1(const C& c0, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* tau, const double* ffing) {
+  D3IL_GEN_CONSTS(gc_, gc);
   D3IL_REFRESH(c0, c);
-  const double h = c.timestep;
-  const int arm0 = 6 * gc.nb, nv = arm0 + NDOF;
+  const int arm0 = 6 * gc.nb;
   DynOut dyn;
   dynamics(c0, st.q, st.v, dyn);
   double fs[NDOF];
+#pragma unroll
   for (int k = 0; k < NARM; k++) fs[k] = clampd(tau[k] + st.bias[k], c.force_lo[k], c.force_hi[k]) - dyn.bias[k];
+#pragma unroll
   for (int k = 0; k < NFING; k++) fs[NARM + k] = clampd(ffing[k], c.force_lo[NARM + k], c.force_hi[NARM + k]) - dyn.bias[NARM + k] - c.f_damping[k] * st.v[NARM + k];
+#pragma unroll
   for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
-  double rodc[3], rodu[3];
   {
-    double t[3]; mulE(dyn.R7, c.tcp7, t);
+    double t[3], rodc[3], rodu[3];
+    mulE(dyn.R7, c.tcp7, t);
     st.tcp[0] = dyn.p7[0] + t[0]; st.tcp[1] = dyn.p7[1] + t[1]; st.tcp[2] = dyn.p7[2] + t[2];
-    mulE(dyn.R7, c.rod_c7, rodc); rodc[0] += dyn.p7[0]; rodc[1] += dyn.p7[1]; rodc[2] += dyn.p7[2];
+    mulE(dyn.R7, c.rod_c7, rodc);
     mulE(dyn.R7, c.rod_u7, rodu);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { GLS(GL_ROD + k) = rodc[k] + dyn.p7[k]; GLS(GL_ROD + 3 + k) = rodu[k]; }
   }
   double L[45], d[NDOF], id[NDOF], a0[NDOF];
   if (!ldl9(dyn.M, L, d, id)) st.flags |= F_SOLVER_FAIL;
+#pragma unroll
   for (int k = 0; k < NDOF; k++) a0[k] = fs[k];
   ldl9_solve(L, id, a0);
-  // publish the system to the scratch area
-  for (int i = 0; i < 45; i++) PGS(GG_M + i) = dyn.M[i];
-  for (int b = 0; b < gc.nb; b++) {
-    double R[9], q[4] = {GBX(b, 3), GBX(b, 4), GBX(b, 5), GBX(b, 6)};
-    quat2mat(q, R);
-    for (int k = 0; k < 9; k++) PGS(GG_R + 9 * b + k) = R[k];
-    for (int k = 0; k < 3; k++) PGS(GG_POS + 3 * b + k) = GBX(b, k);
-    for (int k = 0; k < 6; k++) { PGS(GG_VEL + 6 * b + k) = GBX(b, 7 + k); PGS(GG_A0 + 6 * b + k) = k < 3 ? c.gravity[k] : 0.0; }
-    if (GBX(b, 0) < gc.ws_lo[0] || GBX(b, 0) > gc.ws_hi[0] || GBX(b, 1) < gc.ws_lo[1] || GBX(b, 1) > gc.ws_hi[1]) st.flags |= PF_OFF_TABLE;
-  }
-  for (int k = 0; k < NDOF; k++) { PGS(GG_VEL + arm0 + k) = st.v[k]; PGS(GG_A0 + arm0 + k) = a0[k]; }
-  bool any_lim = false;
+#pragma unroll
+  for (int i = 0; i < 45; i++) GLS(GL_M + i) = dyn.M[i];
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) { GLS(GL_VEL + arm0 + k) = st.v[k]; GLS(GL_A0 + arm0 + k) = a0[k]; }
+  bool arm_lim = false;
+  double fc[NDOF];
+#pragma unroll
   for (int k = 0; k < NDOF; k++) {
+    fc[k] = 0;
     double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
     double sign = 0, dist = 0, D = 0, aref = 0;
     if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
@@ -345,68 +626,270 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, EnvState& st,
       double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
       D = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
       aref = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
-      any_lim = true;
+      if (k < NARM) arm_lim = true;
     }
-    PGS(GG_LIM + 3 * k) = sign; PGS(GG_LIM + 3 * k + 1) = D; PGS(GG_LIM + 3 * k + 2) = aref;
+    GLS(GL_LIM + 3 * k) = sign; GLS(GL_LIM + 3 * k + 1) = D; GLS(GL_LIM + 3 * k + 2) = aref;
   }
-  unsigned cfl = 0;
-  int ncon = gen_collect(gc, sc, rodc, rodu, c.rod_r, c.rod_h, &cfl);
-  st.flags |= cfl;
-  {   // arm Jacobian rows of the rod contacts
-    bool any_rod = false;
-    for (int ci = 0; ci < ncon; ci++) any_rod = any_rod || (int)PGS(GG_CON + ci * GREC + 13) == GK_ROD;
-    if (any_rod) {
-      double R7[9], p7[3], ax[NARM][3], og[NARM][3];
-      world_chain(c0, dyn.sn, dyn.cs, R7, p7, ax, og);
-      for (int ci = 0; ci < ncon; ci++) {
-        int base = GG_CON + ci * GREC;
-        if ((int)PGS(base + 13) != GK_ROD) continue;
-        int b = (int)PGS(base + 14);
-        double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
-        for (int k = 0; k < NARM; k++) {
-          double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
-          cross3(ax[k], dd, col);
-          for (int r = 0; r < 3; r++) PGS(GG_JA + 21 * b + 7 * r + k) = col[0] * PGS(base + 3 + 3 * r) + col[1] * PGS(base + 4 + 3 * r) + col[2] * PGS(base + 5 + 3 * r);
-        }
+  GLS(GL_INFO + 4) = arm_lim ? 1.0 : 0.0;
+  {   // finger rows alone: 2 x 2 active-set solution in force space
+    double s0 = GLS(GL_LIM + 3 * 7), s1 = GLS(GL_LIM + 3 * 8);
+    if (s0 != 0 || s1 != 0) {
+      double D0 = GLS(GL_LIM + 3 * 7 + 1), D1 = GLS(GL_LIM + 3 * 8 + 1), ar0 = GLS(GL_LIM + 3 * 7 + 2), ar1 = GLS(GL_LIM + 3 * 8 + 2);
+      double l87 = L[tri(8, 7)];
+      double W00 = id[7] + l87 * l87 * id[8], W01 = -l87 * id[8], W11 = id[8];
+      double r0 = s0 * a0[7] - ar0, r1 = s1 * a0[8] - ar1;
+      double G00 = W00 * s0 * s0, G01 = W01 * s0 * s1, G11 = W11 * s1 * s1;
+      double f0 = 0, f1 = 0;
+      bool have0 = s0 != 0, have1 = s1 != 0, done = false;
+      if (have0 && have1) {
+        double a = 1 + D0 * G00, b = D0 * G01, cc = D1 * G01, dd = 1 + D1 * G11;
+        double det = a * dd - b * cc, y0 = -D0 * r0, y1 = -D1 * r1;
+        double g0 = (dd * y0 - b * y1) / det, g1 = (a * y1 - cc * y0) / det;
+        if (g0 > 0 && g1 > 0) { f0 = g0; f1 = g1; done = true; }
       }
+      if (!done && have0) {
+        double g0 = -D0 * r0 / (1 + D0 * G00);
+        if (g0 > 0 && (!have1 || r1 + G01 * g0 >= 0)) { f0 = g0; f1 = 0; done = true; }
+      }
+      if (!done && have1) {
+        double g1 = -D1 * r1 / (1 + D1 * G11);
+        if (g1 > 0 && (!have0 || r0 + G01 * g1 >= 0)) { f1 = g1; f0 = 0; done = true; }
+      }
+      fc[7] = s0 * f0; fc[8] = s1 * f1;
     }
   }
-  if (ncon == 0 && !any_lim) {
-    for (int k = 0; k < nv; k++) PGS(GG_X + k) = PGS(GG_A0 + k);
-  } else {
-    if (st.flags & PF_WARM_VALID) for (int k = 0; k < nv; k++) PGS(GG_X + k) = GWARM(k);
-    else for (int k = 0; k < nv; k++) PGS(GG_X + k) = PGS(GG_A0 + k);
-    if (!gen_solve(gc, sc, ncon)) st.flags |= F_SOLVER_FAIL;
-  }
-  for (int k = 0; k < nv; k++) GWARM(k) = PGS(GG_X + k);
-  st.flags |= PF_WARM_VALID;
-  // arm: (M + h B) qacc = M x, B on the fingers
+  double xa[NDOF];
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) xa[k] = fs[k] + fc[k];
+  ldl9_solve(L, id, xa);
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) GLS(GL_X + arm0 + k) = xa[k];
+}
+
+D3IL_HD void gen_put(const GenConsts& gc_, const PushScratch sc, int cube, int& cnt, unsigned& fl, const double* rec, int kind, int a, int b, int set) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  if (cnt >= GEN_SEG) { fl |= PF_CON_OVERFLOW; return; }
+  const int base = GG_CON + (cube * GEN_SEG + cnt) * GREC;
+  double n[3] = {rec[4], rec[5], rec[6]}, t1[3], t2[3];
+  make_frame(n, t1, t2);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { PGS(base + k) = rec[1 + k]; PGS(base + 3 + k) = n[k]; PGS(base + 6 + k) = t1[k]; PGS(base + 9 + k) = t2[k]; }
+  PGS(base + 12) = rec[0]; PGS(base + 13) = kind; PGS(base + 14) = a; PGS(base + 15) = b; PGS(base + 21) = set;
+  cnt++;
+}
+// ---- phase 2 (lane c): cube c's pose into the t area, collision against the static boxes.  Returns the contact count.
+D3IL_NOINLINE inline int gen_phase2(const GenConsts& gc_, const PushScratch sc, int c, const double* gravity, unsigned& fl) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  double pc[3], Rc[9];
   {
-    double xa[NDOF], rhs[NDOF];
-    for (int k = 0; k < NDOF; k++) xa[k] = PGS(GG_X + arm0 + k);
-    symv9(dyn.M, xa, rhs);
-    double hb0 = h * c.f_damping[0], hb1 = h * c.f_damping[1];
-    double l87 = L[tri(8, 7)];
-    double S11 = d[8] + l87 * l87 * d[7];
-    double d7n = d[7] + hb0, i7 = rcpd(d7n);
-    double l87n = l87 * d[7] * i7;
-    double d8n = S11 + hb1 - l87n * l87n * d7n;
-    d[7] = d7n; d[8] = d8n; id[7] = i7; id[8] = rcpd(d8n); L[tri(8, 7)] = l87n;
-    ldl9_solve(L, id, rhs);
-    for (int k = 0; k < NDOF; k++) { st.v[k] += h * rhs[k]; st.q[k] += h * st.v[k]; }
+    double q[4] = {GBX(c, 3), GBX(c, 4), GBX(c, 5), GBX(c, 6)};
+    quat2mat(q, Rc);
+#pragma unroll
+    for (int k = 0; k < 9; k++) GLS(GL_R + 9 * c + k) = Rc[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pc[k] = GBX(c, k); GLS(GL_POS + 3 * c + k) = pc[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { GLS(GL_VEL + 6 * c + k) = GBX(c, 7 + k); GLS(GL_A0 + 6 * c + k) = k < 3 ? gravity[k] : 0.0; }
+    if (pc[0] < gc.ws_lo[0] || pc[0] > gc.ws_hi[0] || pc[1] < gc.ws_lo[1] || pc[1] > gc.ws_hi[1]) fl |= PF_OFF_TABLE;
   }
+  const double rcirc2 = gc.box_half[0] * gc.box_half[0] + gc.box_half[1] * gc.box_half[1] + gc.box_half[2] * gc.box_half[2];
+  int cnt = 0;
+  double rec[8][7];
+  for (int s = 0; s < gc.ns; s++) {
+    double d2 = 0;   // sphere against the static box (in its frame): cheap exact rejection
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      double x = (pc[0] - gc.st_c[s][0]) * gc.st_R[s][i] + (pc[1] - gc.st_c[s][1]) * gc.st_R[s][3 + i] + (pc[2] - gc.st_c[s][2]) * gc.st_R[s][6 + i];
+      double e = fabs(x) - gc.st_h[s][i];
+      if (e > 0) d2 += e * e;
+    }
+    if (d2 > rcirc2) continue;
+    int n = gc.st_first[s] ? box_box(gc.st_c[s], gc.st_R[s], gc.st_h[s], pc, Rc, gc.box_half, 0.0, rec, 8)
+                           : box_box(pc, Rc, gc.box_half, gc.st_c[s], gc.st_R[s], gc.st_h[s], 0.0, rec, 8);
+    for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_STATIC, s, c, s);
+  }
+  return cnt;
+}
+// ---- phase 3 (lane c): cube c against the cubes after it and against the rod; publishes the cube's info word
+D3IL_NOINLINE inline void gen_phase3(const GenConsts& gc_, const PushScratch sc, int c, int cnt, double rod_r, double rod_h, unsigned& fl) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  const double rcirc2 = gc.box_half[0] * gc.box_half[0] + gc.box_half[1] * gc.box_half[1] + gc.box_half[2] * gc.box_half[2];
+  double pc[3], Rc[9];
+#pragma unroll
+  for (int k = 0; k < 3; k++) pc[k] = GLS(GL_POS + 3 * c + k);
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rc[k] = GLS(GL_R + 9 * c + k);
+  unsigned partners = 0, rod = 0;
+  for (int d = c + 1; d < gc.nb; d++) {
+    double pd[3], Rd[9], dd = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pd[k] = GLS(GL_POS + 3 * d + k); dd += (pc[k] - pd[k]) * (pc[k] - pd[k]); }
+    if (dd > 4 * rcirc2) continue;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rd[k] = GLS(GL_R + 9 * d + k);
+    double rec[8][7];
+    int n = box_box(pc, Rc, gc.box_half, pd, Rd, gc.box_half, 0.0, rec, 8);
+    for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_BOXBOX, c, d, gc.set_bb);
+    if (n > 0) partners |= 1u << d;
+  }
+  {
+    double rodc[3], rodu[3], r1[7];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rodc[k] = GLS(GL_ROD + k); rodu[k] = GLS(GL_ROD + 3 + k); }
+    double w[3] = {pc[0] - rodc[0], pc[1] - rodc[1], pc[2] - rodc[2]};
+    double t = clampd(dot3(w, rodu), -rod_h, rod_h);
+    double e[3] = {w[0] - t * rodu[0], w[1] - t * rodu[1], w[2] - t * rodu[2]};
+    double rr = sqrt(rcirc2) + rod_r;
+    if (dot3(e, e) < rr * rr && cyl_box(rodc, rodu, rod_r, rod_h, pc, Rc, gc.box_half, 0.0, r1)) {   // cube is geom 1: normal cube -> rod
+      const int before = cnt;
+      gen_put(gc, sc, c, cnt, fl, r1, GK_ROD, c, 0, gc.set_rod);
+      if (cnt > before) rod = 1;
+    }
+  }
+  GLS(GL_INFO + c) = (double)((unsigned)cnt | (partners << 5) | (rod << 9));
+}
+// ---- phase 3b (lane 0): arm Jacobian rows of the rod contacts (the last record of a cube's segment)
+template <class C>
+D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, const PushScratch sc) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  bool any = false;
+  for (int b = 0; b < gc.nb; b++) any = any || (((unsigned)GLS(GL_INFO + b) >> 9) & 1);
+  if (!any) return;
+  double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3];
+#pragma unroll
+  for (int i = 0; i < NARM; i++) sincos(st.q[i], &sn[i], &cs[i]);
+  world_chain(c0, sn, cs, R7, p7, ax, og);
   for (int b = 0; b < gc.nb; b++) {
-    double xb[6];
-    BoxState bx;
-    for (int k = 0; k < 6; k++) xb[k] = PGS(GG_X + 6 * b + k);
-    for (int k = 0; k < 3; k++) bx.pos[k] = GBX(b, k);
-    for (int k = 0; k < 4; k++) bx.quat[k] = GBX(b, 3 + k);
-    for (int k = 0; k < 6; k++) bx.vel[k] = GBX(b, 7 + k);
-    cube_integrate(bx, xb, h);
-    for (int k = 0; k < 3; k++) GBX(b, k) = bx.pos[k];
-    for (int k = 0; k < 4; k++) GBX(b, 3 + k) = bx.quat[k];
-    for (int k = 0; k < 6; k++) GBX(b, 7 + k) = bx.vel[k];
+    unsigned info = (unsigned)GLS(GL_INFO + b);
+    if (!((info >> 9) & 1)) continue;
+    const int base = GG_CON + (b * GEN_SEG + (int)(info & 31) - 1) * GREC;
+    double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
+    for (int k = 0; k < NARM; k++) {
+      double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
+      cross3(ax[k], dd, col);
+      for (int r = 0; r < 3; r++) GLS(GL_JA + 21 * b + 7 * r + k) = col[0] * PGS(base + 3 + 3 * r) + col[1] * PGS(base + 4 + 3 * r) + col[2] * PGS(base + 5 + 3 * r);
+    }
   }
+}
+// ---- phase 4 (lane l): island bookkeeping and solve.  The lane of an island's first cube solves it; the arm alone keeps
+// the phase-1 solution unless one of its seven joints is at a limit (then lane 0 solves the arm island)
+D3IL_HD void gen_phase4(const GenConsts& gc_, const PushScratch sc, int l, bool warm_valid, unsigned& fl) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  const int nb = gc.nb;
+  unsigned adj[GEN_MAXNB + 1], cnt_any = 0;
+#pragma unroll
+  for (int b = 0; b <= GEN_MAXNB; b++) adj[b] = 0;
+#pragma unroll
+  for (int b = 0; b < GEN_MAXNB; b++) if (b < nb) {
+    unsigned info = (unsigned)GLS(GL_INFO + b);
+    unsigned m = (info >> 5) & 15u;
+    if ((info >> 9) & 1) m |= 1u << nb;
+    if (info & 31) cnt_any |= 1u << b;
+    adj[b] |= m;
+#pragma unroll
+    for (int d = 0; d <= GEN_MAXNB; d++) if ((m >> d) & 1) adj[d] |= 1u << b;
+  }
+  // islands in the order of their first block; storage offsets accumulate along the way
+  Isl mine{0u, 0, 0, 0, 0, false}, armisl = mine;
+  bool root = false, arm_alone = false;
+  unsigned seen = 0;
+  int hoff = 0, voff = 0;
+#pragma unroll
+  for (int b = 0; b <= GEN_MAXNB; b++) if (b <= nb && !((seen >> b) & 1)) {
+    unsigned mask = 1u << b;
+#pragma unroll
+    for (int sweep = 0; sweep < GEN_MAXNB; sweep++)
+#pragma unroll
+      for (int d = 0; d <= GEN_MAXNB; d++) if ((mask >> d) & 1) mask |= adj[d];
+    seen |= mask;
+    Isl t = gen_island(mask, nb);
+    t.hoff = hoff; t.voff = voff;
+    if (b == l) { mine = t; root = true; }
+    if (b == nb) { armisl = t; arm_alone = true; }
+    hoff += t.m * (t.m + 1) / 2; voff += t.m;
+  }
+  if (root) {
+    if (mine.n == 1) {
+      // a cube on its own: register-resident 6-dof solve over its static contacts (no contact: x = a0)
+      const int cnt = (int)((unsigned)GLS(GL_INFO + l) & 31u);
+      if (cnt == 0) for (int k = 0; k < 6; k++) GLS(GL_X + 6 * l + k) = GLS(GL_A0 + 6 * l + k);
+      else if (!gen_solve_cube(gc, sc, l, cnt, warm_valid)) fl |= F_SOLVER_FAIL;
+    } else {
+      const Isl isl = mine;
+      GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);
+      if (!gen_solve(gc, sc, isl)) fl |= F_SOLVER_FAIL;
+    }
+  }
+  if (l == 0 && arm_alone && GLS(GL_INFO + 4) != 0) {   // the arm on its own with one of its seven joints at a limit
+    const Isl isl = armisl;
+    GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);
+    if (!gen_solve(gc, sc, isl)) fl |= F_SOLVER_FAIL;
+  }
+  (void)cnt_any;
+}
+// ---- phase 5: integration.  Arm (lane 0): (M + h B) qacc = M x with B on the fingers; cube l: mj_Euler with quaternion integration
+template <class C>
+D3IL_HD void gen_phase5_arm(const C& c0, const GenConsts& gc_, EnvState& st, const PushScratch sc) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  D3IL_REFRESH(c0, c);
+  const double h = c.timestep;
+  const int arm0 = 6 * gc.nb;
+  double M[45], xa[NDOF], rhs[NDOF], L[45], d[NDOF], id[NDOF];
+#pragma unroll
+  for (int i = 0; i < 45; i++) M[i] = GLS(GL_M + i);
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) { xa[k] = GLS(GL_X + arm0 + k); GWARM(arm0 + k) = xa[k]; }
+  symv9(M, xa, rhs);
+  if (!ldl9(M, L, d, id)) st.flags |= F_SOLVER_FAIL;
+  double hb0 = h * c.f_damping[0], hb1 = h * c.f_damping[1];
+  double l87 = L[tri(8, 7)];
+  double S11 = d[8] + l87 * l87 * d[7];
+  double d7n = d[7] + hb0, i7 = rcpd(d7n);
+  double l87n = l87 * d[7] * i7;
+  double d8n = S11 + hb1 - l87n * l87n * d7n;
+  d[7] = d7n; d[8] = d8n; id[7] = i7; id[8] = rcpd(d8n); L[tri(8, 7)] = l87n;
+  ldl9_solve(L, id, rhs);
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) { st.v[k] += h * rhs[k]; st.q[k] += h * st.v[k]; }
+}
+D3IL_HD void gen_phase5_cube(const GenConsts& gc_, const PushScratch sc, int b, double h) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  double xb[6];
+  BoxState bx;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { xb[k] = GLS(GL_X + 6 * b + k); GWARM(6 * b + k) = xb[k]; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) bx.pos[k] = GLS(GL_POS + 3 * b + k);
+#pragma unroll
+  for (int k = 0; k < 4; k++) bx.quat[k] = GBX(b, 3 + k);
+#pragma unroll
+  for (int k = 0; k < 6; k++) bx.vel[k] = GLS(GL_VEL + 6 * b + k);
+  cube_integrate(bx, xb, h);
+#pragma unroll
+  for (int k = 0; k < 3; k++) GBX(b, k) = bx.pos[k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) GBX(b, 3 + k) = bx.quat[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) GBX(b, 7 + k) = bx.vel[k];
+}
+
+// one physics sub-step (mj_step) of arm + cubes with the group's lanes run one after the other (host build, reset kernel)
+template <class C>
+D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* tau, const double* ffing) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  D3IL_REFRESH(c0, c);
+  const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
+  const bool warm_valid = (st.flags & PF_WARM_VALID) != 0;
+  unsigned fl = 0;
+  int cnt[GEN_MAXNB];
+  gen_phase1(c0, gc, st, sc, tau, ffing);
+  for (int l = 0; l < gc.nb; l++) cnt[l] = gen_phase2(gc, sc, l, grav, fl);
+  for (int l = 0; l < gc.nb; l++) gen_phase3(gc, sc, l, cnt[l], c.rod_r, c.rod_h, fl);
+  gen_phase3b(c0, gc, st, sc);
+  for (int l = 0; l < gc.nb; l++) gen_phase4(gc, sc, l, warm_valid, fl);
+  gen_phase5_arm(c0, gc, st, sc);
+  for (int l = 0; l < gc.nb; l++) gen_phase5_cube(gc, sc, l, c.timestep);
+  st.flags |= fl | PF_WARM_VALID;
 }
 
 // ------------------------------------------------------------------------------------------------ Sorting task (sorting.py)
@@ -414,7 +897,8 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc, EnvState& st,
 // (3 bits each).  sorting.py:405-411 (reset), :460-507 (check_mode)
 constexpr int GEN_SORT_OBS = 20;      // 2 + 3 * 6 at most (num_boxes = 6); Sorting-4 uses 14
 D3IL_HD unsigned sort_word0_reset() { return 0; }
-D3IL_HD void sort_collect(const GenConsts& gc, const PushScratch& sc, double (*box)[7]) {
+D3IL_HD void sort_collect(const GenConsts& gc_, const PushScratch sc, double (*box)[7]) {
+  D3IL_GEN_CONSTS(gc_, gc);
   const int nr = gc.nb / 2;
   for (int i = 0; i < 6; i++) {
     const int cidx = i / 3, k = i % 3;
@@ -427,7 +911,8 @@ D3IL_HD bool sort_in_bin(const double* b, bool red) {
   return red ? (b[0] > 0.3 && b[0] < 0.5 && b[1] > 0.22 && b[1] < 0.41) : (b[0] > 0.525 && b[0] < 0.725 && b[1] > 0.22 && b[1] < 0.41);
 }
 // Sorting_Env.get_observation (sorting.py:308-390) and _check_early_termination (:513-543)
-D3IL_HD bool sort_obs_success(const GenConsts& gc, const double (*box)[7], const double* tcp, float* obs) {
+D3IL_HD bool sort_obs_success(const GenConsts& gc_, const double (*box)[7], const double* tcp, float* obs) {
+  D3IL_GEN_CONSTS(gc_, gc);
   const int nr = gc.nb / 2;
   int k = 0;
   obs[k++] = (float)tcp[0]; obs[k++] = (float)tcp[1];
@@ -440,7 +925,8 @@ D3IL_HD bool sort_obs_success(const GenConsts& gc, const double (*box)[7], const
   return ok;
 }
 // check_mode + decode_mode: int(np.packbits(mode[:num_boxes])[0]) - every non-zero entry (also -1) is a set bit, MSB first
-D3IL_HD int sort_check_mode(const GenConsts& gc, unsigned* task, const double (*box)[7]) {
+D3IL_HD int sort_check_mode(const GenConsts& gc_, unsigned* task, const double (*box)[7]) {
+  D3IL_GEN_CONSTS(gc_, gc);
   int mode_step = (int)(task[0] >> 12) & 7;
   if (mode_step <= 5) {
     double dists[6];
@@ -465,15 +951,17 @@ D3IL_HD int sort_check_mode(const GenConsts& gc, unsigned* task, const double (*
 
 // ------------------------------------------------------------------------------------------------ env level
 template <class C>
-D3IL_HD void gen_control_and_physics(const C& c, const GenConsts& gc, EnvState& st, const PushScratch& sc, const double* q_des, const double* qd_des,
+D3IL_HD void gen_control_and_physics(const C& c, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* q_des, const double* qd_des,
                                      double set_width, bool grasp) {
+  D3IL_GEN_CONSTS(gc_, gc);
   double tau[NARM], ff[NFING];
   push_control(c, st, q_des, qd_des, set_width, grasp, tau, ff);
   gen_physics_substep(c, gc, st, sc, tau, ff);
 }
 // Sorting_Env.reset(random=False, context) (sorting.py:545-575): ctx = nb x (pos3, quat4) in the order red_1.., blue_1..
 template <class C>
-D3IL_HD void gen_env_reset(const C& c, const GenConsts& gc, EnvState& st, const PushScratch& sc, const double* init_qpos, const double* ctx, float* obs) {
+D3IL_HD void gen_env_reset(const C& c, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* init_qpos, const double* ctx, float* obs) {
+  D3IL_GEN_CONSTS(gc_, gc);
   for (int k = 0; k < NARM; k++) { st.q[k] = init_qpos[k]; st.ikq[k] = 0; st.ikqd[k] = 0; }
   st.q[NARM] = 0; st.q[NARM + 1] = 0;
   for (int k = 0; k < NDOF; k++) st.v[k] = 0;
@@ -496,7 +984,8 @@ D3IL_HD void gen_env_reset(const C& c, const GenConsts& gc, EnvState& st, const 
   sort_obs_success(gc, box, st.tcp, obs);
 }
 // before the physics of a step: observation and done (gym_env_wrapper.py:88-90,124-137)
-D3IL_HD void sort_step_begin(const GenConsts& gc, EnvState& st, const PushScratch& sc, float* obs, unsigned char* done, int max_steps) {
+D3IL_HD void sort_step_begin(const GenConsts& gc_, EnvState& st, const PushScratch sc, float* obs, unsigned char* done, int max_steps) {
+  D3IL_GEN_CONSTS(gc_, gc);
   double box[6][7];
   sort_collect(gc, sc, box);
   bool succ = sort_obs_success(gc, box, st.tcp, obs);
@@ -506,7 +995,8 @@ D3IL_HD void sort_step_begin(const GenConsts& gc, EnvState& st, const PushScratc
   *done = fin ? 1 : 0;
 }
 // after the physics: success and the completion-order mode code (sorting.py:444-458)
-D3IL_HD void sort_step_end(const GenConsts& gc, EnvState& st, const PushScratch& sc, int* mode_code) {
+D3IL_HD void sort_step_end(const GenConsts& gc_, EnvState& st, const PushScratch sc, int* mode_code) {
+  D3IL_GEN_CONSTS(gc_, gc);
   st.step++;
   double box[6][7]; float dummy[GEN_SORT_OBS];
   sort_collect(gc, sc, box);
@@ -518,8 +1008,9 @@ D3IL_HD void sort_step_end(const GenConsts& gc, EnvState& st, const PushScratch&
   GTASK(0) = (double)task[0]; GTASK(1) = (double)task[1];
 }
 template <bool FAST, class C>
-D3IL_HD void gen_env_step(const C& c, const GenConsts& gc, EnvState& st, const PushScratch& sc, const double* action, float* obs, unsigned char* done,
+D3IL_HD void gen_env_step(const C& c, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* action, float* obs, unsigned char* done,
                           int* mode_code, int n_substeps, int max_steps) {
+  D3IL_GEN_CONSTS(gc_, gc);
   sort_step_begin(gc, st, sc, obs, done, max_steps);
   double des[7];
   make_setpoint(action, des);

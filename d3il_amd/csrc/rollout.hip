@@ -387,7 +387,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     HIPCHK(hipFuncSetAttribute((const void*)k_pushing_reset, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_H));
   }
   if (sorting) {
-    HIPCHK(hipMalloc(&h->d_gc, sizeof(GenConsts))); HIPCHK(hipMemcpy(h->d_gc, &h->gc, sizeof(GenConsts), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_gen_consts), &h->gc, sizeof(GenConsts)));   // constant memory: one Sorting model per process
     HIPCHK(hipMalloc(&h->d_scratch, S * GG_SIZE * sizeof(double))); HIPCHK(hipMemset(h->d_scratch, 0, S * GG_SIZE * sizeof(double)));
     HIPCHK(hipFuncSetAttribute((const void*)k_sorting_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
     HIPCHK(hipFuncSetAttribute((const void*)k_sorting_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
@@ -431,7 +431,7 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   }
   if (h->task_id == D3IL_TASK_SORTING) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Sorting task needs contexts (device f64 [n_envs][7 * n_boxes])");
-    hipLaunchKernelGGL(k_sorting_reset, dim3((h->n + GEN_LANES - 1) / GEN_LANES), dim3(WAVE), GEN_LDS_H, (hipStream_t)stream, h->d_gc, h->d_init_qpos, env_mask, contexts, b.state,
+    hipLaunchKernelGGL(k_sorting_reset, dim3((h->n + GEN_LANES - 1) / GEN_LANES), dim3(WAVE), GEN_LDS_H, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
                        b.flags, b.step_count, b.obs, b.done, b.success, b.mode, h->d_scratch, h->n, h->stride);
     HIPCHK(hipGetLastError());
     return D3IL_OK;
@@ -466,10 +466,10 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     int nwgs = (h->n + GEN_LANES - 1) / GEN_LANES;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     if (h->fast)
-      hipLaunchKernelGGL((k_sorting_step<true>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, h->d_gc, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
+      hipLaunchKernelGGL((k_sorting_step<true>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                          h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
     else
-      hipLaunchKernelGGL((k_sorting_step<false>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, h->d_gc, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
+      hipLaunchKernelGGL((k_sorting_step<false>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                          h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }

@@ -126,7 +126,7 @@ void hc_push_substep(void* h, double* s, int* f, const double* tau, const double
   (void)ncon_out;
 }
 // ---------------------------------------------------------------- generic engine / Sorting (gen_step.h)
-struct GenHost { PandaConsts c; GenConsts gc; double h[GEN_NH]; double g[GG_SIZE]; };
+struct GenHost { PandaConsts c; GenConsts gc; double h[GL_SIZE]; double g[GG_SIZE]; };
 void* hc_gen_create(const d3il_model_blob* blob, const char** err) {
   GenHost* p = (GenHost*)std::calloc(1, sizeof(GenHost));
   static const char* e = "";

@@ -1,0 +1,32 @@
+"""Stats build: where the Sorting step spends its time (ticks of the 100 MHz wall clock, per workgroup)."""
+import ctypes as C, os, sys, numpy as np, torch
+os.environ["D3IL_STATS_LIB"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from d3il_amd import capi
+from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+iq = np.load(os.path.join(ROOT, "tests", "golden", "ref_offline_ik.npz"))["sorting__traj_last"]
+env = SortingVecEnv(n, device=0)
+L = capi.load()
+env.set_init_qpos(iq); env.reset(context=sample_contexts(n, 4, seed=1))
+des = env.robot_state()[:, :2].clone(); z = env.robot_state()[:, 2:3].clone()
+quat = torch.tensor([0.0, 1, 0, 0], dtype=torch.float64, device=env.device).expand(n, 4)
+NW = (n + 15) // 16
+W = np.zeros((NW, 10), dtype=np.uint64)
+names = ["dyn+publish", "collect", "rodjac", "s.setup", "s.grad+H", "s.chol", "s.jp", "s.linesearch", "solve+integ", "s.tail"]
+for t in range(40):
+    box = env.obs[:, 2:4].to(torch.float64)
+    if t >= 12:
+        aligned = ((des[:, 0] - box[:, 0]).abs() < 0.008) & (des[:, 1] < box[:, 1] - 0.02)
+        target = torch.where(aligned[:, None], torch.stack([box[:, 0], torch.full_like(box[:, 0], 0.36)], 1), box + torch.tensor([0.0, -0.06], dtype=torch.float64, device=box.device))
+        d = target - des; nn = d.norm(dim=1, keepdim=True)
+        des = des + d / nn.clamp_min(1e-9) * torch.minimum(nn, torch.full_like(nn, 0.006))
+    torch.cuda.synchronize()
+    L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), NW, 1)
+    env.step(torch.cat([des, z, quat], dim=1).contiguous())
+    torch.cuda.synchronize()
+    L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), NW, 1)
+    if t in (2, 3, 11, 20, 35, 39):
+        med = np.median(W.astype(np.float64), axis=0) / 100.0     # microseconds per env step
+        print("t %2d  median us per step per workgroup: " % t + "  ".join("%s %.0f" % (names[i], med[i]) for i in range(10)), flush=True)
