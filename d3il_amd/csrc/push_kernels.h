@@ -68,7 +68,7 @@ __device__ __forceinline__ void push_store_outputs(const PushState& ps, int e, i
 
 // env.step() for the Pushing task
 template <bool FAST>
-__global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(PushConsts pc, double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+__global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
                                                                  const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
                                                                  unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
                                                                  double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(PushConsts pc, 
   const int e = blockIdx.x * PUSH_LANES + lane;
   const bool live = lane < PUSH_LANES && e < n;          // the other lanes only take part in the barriers
   const PandaConsts& c = kAvoidingConsts;                // the arm is the Avoiding arm (same robot XML / gin / URDF)
+  const PushConsts& pc = g_push_consts;
   if (role == 0) {
     double ikq[NARM], ikqd[NARM], q0[NARM], des[7];
     unsigned fl = 0;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(PushConsts pc, 
 }
 
 // env.reset(random=False, context) for masked environments; contexts: f64 [n][14] = 2 x (pos3, quat4)
-__global__ __launch_bounds__(WAVE) void k_pushing_reset(PushConsts pc, const double* __restrict__ init_qpos, const unsigned char* __restrict__ mask,
+__global__ __launch_bounds__(WAVE) void k_pushing_reset(const double* __restrict__ init_qpos, const unsigned char* __restrict__ mask,
                                                         const double* __restrict__ contexts, double* __restrict__ state, unsigned* __restrict__ flags,
                                                         int* __restrict__ steps, float* __restrict__ obs, unsigned char* __restrict__ done,
                                                         unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(WAVE) void k_pushing_reset(PushConsts pc, const dou
   const int e = blockIdx.x * PUSH_LANES + lane;
   if (lane >= PUSH_LANES || e >= n) return;
   if (mask && !mask[e]) return;
+  const PushConsts& pc = g_push_consts;
   PushState ps;
   double iq[NARM], ctx[14];
 #pragma unroll

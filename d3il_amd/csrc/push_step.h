@@ -66,6 +66,17 @@ struct PushConsts {
   double impratio;
 };
 
+// On the device the constants sit in constant memory and every function re-binds its `pc` to that object, so that no generic
+// pointer to them survives a (non-inlined) call boundary.  One Pushing model per process.
+#if defined(__HIPCC__)
+__constant__ PushConsts g_push_consts;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define D3IL_PUSH_CONSTS(in, name) const PushConsts& name = g_push_consts; (void)in
+#else
+#define D3IL_PUSH_CONSTS(in, name) const PushConsts& name = in
+#endif
+
 struct BoxState { double pos[3], quat[4], vel[6]; };
 struct PushState {
   EnvState arm;
@@ -357,7 +368,8 @@ struct CubeSlab {
   double dist[8];     // signed distance (< 0: active)
 };
 struct CubeFace { double Bk[3], B1[3], B2[3], hk, h1, h2, sgi; };
-D3IL_HD void cube_face(const PushConsts& pc, const double* R, CubeFace& f) {   // incident face: the cube face most opposed to +z
+D3IL_HD void cube_face(const PushConsts& pc_, const double* R, CubeFace& f) {   // incident face: the cube face most opposed to +z
+  D3IL_PUSH_CONSTS(pc_, pc);
   double bz0 = fabs(R[6]), bz1 = fabs(R[7]), bz2 = fabs(R[8]);
   int kin = 0; double bestdot = bz0;
   if (bz1 > bestdot) { bestdot = bz1; kin = 1; }
@@ -375,7 +387,8 @@ D3IL_HD void cube_face(const PushConsts& pc, const double* R, CubeFace& f) {   /
   f.sgi = f.Bk[2] > 0 ? -1.0 : 1.0;
 }
 // slot i = 4 * slab + vertex: contact position relative to the cube centre and signed distance
-D3IL_HD void slot_geom(const PushConsts& pc, const CubeFace& f, const double* pos, int i, double* r, double* dist) {
+D3IL_HD void slot_geom(const PushConsts& pc_, const CubeFace& f, const double* pos, int i, double* r, double* dist) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   int s = i >> 2, v = i & 3;
   double c0 = (v == 0 || v == 3) ? 1.0 : -1.0, c1 = v < 2 ? 1.0 : -1.0, x[3];
   double sc0 = s ? pc.slab_c[1][0] : pc.slab_c[0][0], sc1 = s ? pc.slab_c[1][1] : pc.slab_c[0][1], sc2 = s ? pc.slab_c[1][2] : pc.slab_c[0][2];
@@ -389,7 +402,8 @@ D3IL_HD void slot_geom(const PushConsts& pc, const CubeFace& f, const double* po
   r[1] = sc1 + x[1] - pos[1];
   r[2] = sc2 + (sh2 + 0.5 * w) - pos[2];
 }
-D3IL_HD void cube_slab_contacts(const PushConsts& pc, const double* pos, const double* R, CubeSlab& cs) {
+D3IL_HD void cube_slab_contacts(const PushConsts& pc_, const double* pos, const double* R, CubeSlab& cs) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   CubeFace f;
   cube_face(pc, R, f);
 #pragma unroll
@@ -403,7 +417,8 @@ D3IL_HD void slab_rows(const double* R, const double* r, double (*J)[6]) {
 
 // One free cube resting / sliding on the slabs, no other contact: 6-dof primal Newton with exact line search, everything
 // in registers.  x: start point in, optimum out (acceleration: linear world, angular body axes).
-D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc, const double* R, const double* vel, const CubeSlab& cs, const double* a0, double* x) {
+D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc_, const double* R, const double* vel, const CubeSlab& cs, const double* a0, double* x) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   const double Mm[6] = {pc.box_mass, pc.box_mass, pc.box_mass, pc.box_inertia, pc.box_inertia, pc.box_inertia};
   const double fric = pc.ct_fric[0], mu = fric * sqrt(1 / fmax(1e-15, pc.impratio)), impr = pc.impratio;
   bool act[8]; double aref[8][3], Dn[8];
@@ -548,7 +563,7 @@ constexpr int PG_AUX_R = PG_AUX, PG_AUX_POS = PG_AUX + 18, PG_AUX_VEL = PG_AUX +
 
 struct SRow { int o1, o2, n2; double v1[6], v2[7]; };   // block 1: 6 cube dofs at o1; block 2: n2 (0, 6 or 7) dofs at o2
 
-D3IL_HD void contact_rows(const PushScratch& sc, int ci, SRow* rows) {
+D3IL_HD void contact_rows(const PushScratch sc, int ci, SRow* rows) {
   int base = PG_CON + ci * PREC;
   double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
   int kind = (int)PGS(base + 13), cube = (int)PGS(base + 14);
@@ -589,7 +604,7 @@ D3IL_HD void contact_rows(const PushScratch& sc, int ci, SRow* rows) {
   }
 }
 // row . vector stored in the g area at offset `vec`
-D3IL_HD double srow_dot_g(const PushScratch& sc, const SRow& s, int vec) {
+D3IL_HD double srow_dot_g(const PushScratch sc, const SRow& s, int vec) {
   double a = 0;
 #pragma unroll
   for (int k = 0; k < 6; k++) a += s.v1[k] * PGS(vec + s.o1 + k);
@@ -605,7 +620,7 @@ D3IL_HD int sky_first(int i, bool bb, bool rod1, bool rod2) {
   if (i < 12) return bb ? 0 : 6;
   return rod1 ? 0 : (rod2 ? 6 : 12);
 }
-D3IL_HD bool sky_chol(const PushScratch& sc, bool bb, bool rod1, bool rod2) {
+D3IL_HD bool sky_chol(const PushScratch sc, bool bb, bool rod1, bool rod2) {
   bool ok = true;
   for (int i = 0; i < PUSH_NV; i++) {
     int fi = sky_first(i, bb, rod1, rod2);
@@ -620,7 +635,7 @@ D3IL_HD bool sky_chol(const PushScratch& sc, bool bb, bool rod1, bool rod2) {
   return ok;
 }
 // solves in place on the vector at g offset `vec`
-D3IL_HD void sky_solve_g(const PushScratch& sc, bool bb, bool rod1, bool rod2, int vec) {
+D3IL_HD void sky_solve_g(const PushScratch sc, bool bb, bool rod1, bool rod2, int vec) {
   for (int i = 0; i < PUSH_NV; i++) {
     int fi = sky_first(i, bb, rod1, rod2);
     double s = PGS(vec + i);
@@ -634,14 +649,16 @@ D3IL_HD void sky_solve_g(const PushScratch& sc, bool bb, bool rod1, bool rod2, i
     for (int k = fi; k < i; k++) PGS(vec + k) -= PHS(tri(i, k)) * xi;
   }
 }
-D3IL_HD double gM(const PushConsts& pc, const PushScratch& sc, int i, int k) {   // entry (i, k) of the block-diagonal mass matrix
+D3IL_HD double gM(const PushConsts& pc_, const PushScratch sc, int i, int k) {   // entry (i, k) of the block-diagonal mass matrix
+  D3IL_PUSH_CONSTS(pc_, pc);
   if (i < PUSH_ARM0 || k < PUSH_ARM0) return i == k ? ((i % 6) < 3 ? pc.box_mass : pc.box_inertia) : 0.0;
   int a = i - PUSH_ARM0, b = k - PUSH_ARM0;
   return PGS(PG_M + (a >= b ? tri(a, b) : tri(b, a)));
 }
 
 // returns false if the solver did not converge
-D3IL_NOINLINE inline bool push_general_solve(const PushConsts& pc, const PushScratch& sc, int ncon, bool env_bb, bool env_r1, bool env_r2) {
+D3IL_NOINLINE inline bool push_general_solve(const PushConsts& pc_, const PushScratch sc, int ncon, bool env_bb, bool env_r1, bool env_r2) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   const double impr = pc.impratio;
   // per-contact frame, reference acceleration, regularisation
   for (int ci = 0; ci < ncon; ci++) {
@@ -853,7 +870,8 @@ D3IL_HD void acc_block(double* H, int oa, int ob, const double (*Ja)[6], const d
 // cube then goes through its decoupled solve.
 // The function is written as a sequence of phases that hand their results over through the LDS table, so that the live
 // register set of each phase stays small (the 12 x 12 Hessian is only in registers while it is factorised).
-D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch& sc, int nbb, int rod_cube, double rod_invw, bool two) {
+D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc_, const PushScratch sc, int nbb, int rod_cube, double rod_invw, bool two) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   const int nb = two ? PUSH_NB : 1, ncd = 6 * nb;
   // This lane's own system holds group 1 only with a cube-cube contact.  In a wave that processes both groups for the sake of
   // another lane, group 1 of this lane is inert (no contacts, x = a0 => zero gradient, zero step) and is left out of the
@@ -1389,8 +1407,9 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc, const PushScratch
 
 // general-path collision: slab contacts from the specialised routine, cube <-> cube and rod <-> cube from the general
 // ones; writes the contact records; returns the contact count
-D3IL_NOINLINE inline int push_collect_contacts(const PushConsts& pc, const PushScratch& sc, const CubeSlab* cs, const double* rodc, const double* rodu,
+D3IL_NOINLINE inline int push_collect_contacts(const PushConsts& pc_, const PushScratch sc, const CubeSlab* cs, const double* rodc, const double* rodu,
                                                double rod_r, double rod_h, bool near_bb, const bool* near_rod, unsigned* flags_out, int* has) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   int ncon = 0;
   unsigned fl = 0;
   has[0] = has[1] = has[2] = 0;
@@ -1455,8 +1474,9 @@ D3IL_HD void cube_integrate(BoxState& bx, const double* acc, double h) {
 // something couples, the decoupled arm solve otherwise, arm integration.  box[2]: current cube states; cwarm[12]: the cubes'
 // warm start.  Returns a mask: bit b set = cube b took part in a joint solve and its acceleration is in the table at PT_P[6 b ..].
 template <class C>
-D3IL_HD int push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, const BoxState* box, const double* cwarm, const PushScratch& sc,
+D3IL_HD int push_substep_arm(const C& c0, const PushConsts& pc_, EnvState& st, const BoxState* box, const double* cwarm, const PushScratch sc,
                               const double* tau, const double* ffing) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   D3IL_REFRESH(c0, c);
   const double h = c.timestep;
   PUSH_TIC;
@@ -1751,8 +1771,9 @@ D3IL_HD int push_substep_arm(const C& c0, const PushConsts& pc, EnvState& st, co
 
 // Cube half: one free cube integrates either with its share of the joint solution (table, PT_X) or with its own
 // decoupled 6-dof solve over the slab contacts.  warm[6]: this cube's warm start in / solution out.
-D3IL_HD void push_substep_cube(const PushConsts& pc, const double* gravity, double h, BoxState& bx, double* warm, int b, bool solved, bool warm_valid,
-                               unsigned& flags, const PushScratch& sc) {
+D3IL_HD void push_substep_cube(const PushConsts& pc_, const double* gravity, double h, BoxState& bx, double* warm, int b, bool solved, bool warm_valid,
+                               unsigned& flags, const PushScratch sc) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   PUSH_TIC;
   double xb[6];
   if (!solved) {
@@ -1776,7 +1797,8 @@ D3IL_HD void push_substep_cube(const PushConsts& pc, const double* gravity, doub
 // One physics sub-step on a single lane (host build, reset kernel): arm half, then both cubes in turn.  The step kernel
 // runs the two cube halves on two lanes instead (push_kernels.h).
 template <class C>
-D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* tau, const double* ffing) {
+D3IL_HD void push_physics_substep(const C& c0, const PushConsts& pc_, PushState& ps, const PushScratch sc, const double* tau, const double* ffing) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   double cw[12];
   for (int k = 0; k < 12; k++) cw[k] = PWS(k);
   const bool warm_valid = (ps.arm.flags & PF_WARM_VALID) != 0;
@@ -1809,13 +1831,15 @@ D3IL_HD double push_tan_yaw(const double* q) {   // np.tan(quat2euler(q)[-1]); g
   double yaw = cy > 4 * FEPS ? -atan2(m01, m00) : -atan2(-m10, m11);
   return tan(yaw);
 }
-D3IL_HD void push_dists(const PushConsts& pc, const PushState& ps, double* d) {   // rr rg gr gg
+D3IL_HD void push_dists(const PushConsts& pc_, const PushState& ps, double* d) {   // rr rg gr gg
+  D3IL_PUSH_CONSTS(pc_, pc);
   for (int b = 0; b < 2; b++) for (int t = 0; t < 2; t++) {
     double dx = ps.box[b].pos[0] - pc.target[t][0], dy = ps.box[b].pos[1] - pc.target[t][1], dz = ps.box[b].pos[2] - pc.target[t][2];
     d[2 * b + t] = sqrt(dx * dx + dy * dy + dz * dz);
   }
 }
-D3IL_HD bool push_success(const PushConsts& pc, const PushState& ps) {   // pushing.py:440-459
+D3IL_HD bool push_success(const PushConsts& pc_, const PushState& ps) {   // pushing.py:440-459
+  D3IL_PUSH_CONSTS(pc_, pc);
   double d[4]; push_dists(pc, ps, d);
   return (d[0] <= pc.min_dist && d[3] <= pc.min_dist) || (d[1] <= pc.min_dist && d[2] <= pc.min_dist);
 }
@@ -1824,7 +1848,8 @@ D3IL_HD void push_obs(const PushState& ps, float* obs) {   // pushing.py:255-280
   for (int b = 0; b < 2; b++) { obs[2 + 3 * b] = (float)ps.box[b].pos[0]; obs[3 + 3 * b] = (float)ps.box[b].pos[1]; obs[4 + 3 * b] = (float)push_tan_yaw(ps.box[b].quat); }
 }
 // before the physics of a step: obs, reward, done (gym_env_wrapper.py:88-90,124-137)
-D3IL_HD void push_step_begin(const PushConsts& pc, PushState& ps, float* obs, double* reward, unsigned char* done, int max_steps) {
+D3IL_HD void push_step_begin(const PushConsts& pc_, PushState& ps, float* obs, double* reward, unsigned char* done, int max_steps) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   push_obs(ps, obs);
   double d[4]; push_dists(pc, ps, d);
   double dx = ps.arm.tcp[0] - ps.box[0].pos[0], dy = ps.arm.tcp[1] - ps.box[0].pos[1];
@@ -1835,7 +1860,8 @@ D3IL_HD void push_step_begin(const PushConsts& pc, PushState& ps, float* obs, do
   *done = fin ? 1 : 0;
 }
 // after the physics: success, first-visit mode logic (pushing.py:335-377)
-D3IL_HD void push_step_end(const PushConsts& pc, PushState& ps, double* mean_distance) {
+D3IL_HD void push_step_end(const PushConsts& pc_, PushState& ps, double* mean_distance) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   ps.arm.step++;
   double d[4]; push_dists(pc, ps, d);
   double md = pc.min_dist;
@@ -1875,8 +1901,9 @@ D3IL_HD void push_control(const C& c, const EnvState& st, const double* q_des, c
   }
 }
 template <class C>
-D3IL_HD void push_control_and_physics(const C& c, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* q_des, const double* qd_des,
+D3IL_HD void push_control_and_physics(const C& c, const PushConsts& pc_, PushState& ps, const PushScratch sc, const double* q_des, const double* qd_des,
                                       double set_width, bool grasp) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   double tau[NARM], ff[NFING];
   push_control(c, ps.arm, q_des, qd_des, set_width, grasp, tau, ff);
   push_physics_substep(c, pc, ps, sc, tau, ff);
@@ -1885,7 +1912,8 @@ D3IL_HD void push_control_and_physics(const C& c, const PushConsts& pc, PushStat
 // Block_Push_Env.reset(random=False, context) (pushing.py:461-483): scene.reset, beam to init_qpos, context written into
 // the cubes' qpos (z = 0, pushing.py:99-113), one PD-hold sub-step.  ctx = 2 x (pos3, quat4).
 template <class C>
-D3IL_HD void push_env_reset(const C& c, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* init_qpos, const double* ctx, float* obs) {
+D3IL_HD void push_env_reset(const C& c, const PushConsts& pc_, PushState& ps, const PushScratch sc, const double* init_qpos, const double* ctx, float* obs) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   EnvState& st = ps.arm;
 #pragma unroll
   for (int k = 0; k < NARM; k++) { st.q[k] = init_qpos[k]; st.ikq[k] = 0; st.ikqd[k] = 0; }
@@ -1913,8 +1941,9 @@ D3IL_HD void push_env_reset(const C& c, const PushConsts& pc, PushState& ps, con
 // Block_Push_Env.step (pushing.py:335-339) over GymEnvWrapper.step (gym_env_wrapper.py:45-100), one lane doing both the
 // controller and the physics (the split-wave kernel in rollout.hip runs the same pieces on two waves)
 template <bool FAST, class C>
-D3IL_HD void push_env_step(const C& c, const PushConsts& pc, PushState& ps, const PushScratch& sc, const double* action, float* obs, double* reward,
+D3IL_HD void push_env_step(const C& c, const PushConsts& pc_, PushState& ps, const PushScratch sc, const double* action, float* obs, double* reward,
                            unsigned char* done, double* mean_distance, int n_substeps, int max_steps) {
+  D3IL_PUSH_CONSTS(pc_, pc);
   push_step_begin(pc, ps, obs, reward, done, max_steps);
   double des[7];
   make_setpoint(action, des);

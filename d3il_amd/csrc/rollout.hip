@@ -379,6 +379,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   HIPCHK(hipMemset(b.flags, 0, S * sizeof(uint32_t))); HIPCHK(hipMemset(b.step_count, 0, S * sizeof(int32_t)));
   HIPCHK(hipMemset(b.policy_des, 0, S * 3 * sizeof(double)));
   if (pushing) {
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_push_consts), &h->pc, sizeof(PushConsts)));   // constant memory: one Pushing model per process
     HIPCHK(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
     HIPCHK(hipMalloc(&h->d_scratch, S * PG_SIZE * sizeof(double))); HIPCHK(hipMemset(h->d_scratch, 0, S * PG_SIZE * sizeof(double)));
     // the physics wave keeps the coupled solver's tables in LDS: 137.5 KiB + the set-point exchange, above the 64 KiB default cap
@@ -424,7 +425,7 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   d3il_buffers& b = h->buf;
   if (h->task_id == D3IL_TASK_PUSHING) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Pushing task needs contexts (device f64 [n_envs][14])");
-    hipLaunchKernelGGL(k_pushing_reset, dim3((h->n + PUSH_LANES - 1) / PUSH_LANES), dim3(WAVE), PUSH_LDS_H, (hipStream_t)stream, h->pc, h->d_init_qpos, env_mask, contexts, b.state,
+    hipLaunchKernelGGL(k_pushing_reset, dim3((h->n + PUSH_LANES - 1) / PUSH_LANES), dim3(WAVE), PUSH_LDS_H, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
                        b.flags, b.step_count, b.obs, b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride);
     HIPCHK(hipGetLastError());
     return D3IL_OK;
@@ -453,10 +454,10 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     int nwgp = (h->n + PUSH_LANES - 1) / PUSH_LANES;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     if (h->fast)
-      hipLaunchKernelGGL((k_pushing_step_split<true>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, h->pc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+      hipLaunchKernelGGL((k_pushing_step_split<true>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                          b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
     else
-      hipLaunchKernelGGL((k_pushing_step_split<false>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, h->pc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+      hipLaunchKernelGGL((k_pushing_step_split<false>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                          b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
