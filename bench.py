@@ -97,6 +97,39 @@ def cpu_baseline_pushing(blob, init_qpos, contexts, budget_s=12.0):
                       "scalar C oracle (oracle/d3il_oracle.c)" % (n, dt, os.cpu_count() or 0)}
 
 
+def cpu_baseline_sorting(blob, init_qpos, contexts, budget_s=15.0):
+    """Scalar C oracle on one host core, one environment, same stand-in policy (run on the CPU), bounded sample."""
+    import numpy as np
+    import torch
+    from d3il_amd.agents import RandomResidualMLPPolicy
+    from oracle.oracle import Oracle
+    o = Oracle(blob)
+    o.env_start(init_qpos)
+    pol = RandomResidualMLPPolicy(input_dim=16, device="cpu")
+    n, ep = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        obs = o.sort_reset(contexts[ep % len(contexts)].reshape(-1, 7))
+        des, z = obs[:2].astype(np.float64), float(o.body(blob.tcp_body)[0][2])
+        for t in range(500):
+            x = torch.as_tensor(np.concatenate([des, obs.astype(np.float64)])[None], dtype=torch.float64)
+            des = des + pol.predict_batch(x)[0].numpy().astype(np.float64)
+            obs, done, _ = o.sort_step(np.array([des[0], des[1], z, 0, 1, 0, 0]))
+            n += 1
+            if done or time.perf_counter() - t0 >= budget_s:
+                break
+        ep += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "1 env, ResidualMLP stand-in policy on the CPU, %d env steps (35 sub-steps each) in %.1f s on one host core of %d; "
+                      "scalar C oracle (oracle/d3il_oracle.c)" % (n, dt, os.cpu_count() or 0)}
+
+
+# algorithmic HBM bytes per env step, Sorting-4: state column read + written once (129 f64 rows + flags + step counter), action 56 B,
+# obs 14 x 4 B, done/success/mode 4 B
+SORT_ALG_BYTES_PER_ENV_STEP = 2 * (129 * 8 + 4 + 4) + 56 + 56 + 4
+
+
 def bench_pushing(args):
     """BASELINE config 3: Pushing, 4096 envs per GPU, the 60 reference test contexts tiled, ResidualMLP 10 -> 128 x 6 -> 2 (Mish)
     stand-in policy with fixed random weights, 400-step episode cap; a step = policy forward + d3il_step."""
@@ -106,17 +139,21 @@ def bench_pushing(args):
     from d3il_amd.agents import RandomResidualMLPPolicy
     from d3il_amd.envs.pushing import BlockPushVecEnv
     from d3il_amd.simulation.pushing_sim import load_test_contexts
+    sorting = args.task == "sorting"
+    if sorting:
+        from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
 
     local_rank = _local_device()
     torch.cuda.set_device(local_rank)
     rank, world = D.init_from_env(os.environ.get("D3IL_DIST_BACKEND", "nccl"))
     dev = torch.device("cuda:%d" % local_rank)
     n = args.envs
-    env = BlockPushVecEnv(n, device=dev)
+    env = SortingVecEnv(n, device=dev) if sorting else BlockPushVecEnv(n, device=dev)
     q, iters, err = env.start()
-    ctx60 = load_test_contexts()
+    # Sorting: the reference's 4_test_contexts.pkl is not part of its tree; contexts are drawn like BlockContextManager.sample
+    ctx60 = sample_contexts(60, 4, seed=0) if sorting else load_test_contexts()
     ctx = torch.as_tensor(ctx60[(rank * n + np.arange(n)) % len(ctx60)], dtype=torch.float64, device=dev)
-    pol = RandomResidualMLPPolicy(device=dev)
+    pol = RandomResidualMLPPolicy(input_dim=2 + env.obs.shape[1], device=dev)
     quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
     state = {}
 
@@ -158,10 +195,11 @@ def bench_pushing(args):
     bad = int(((fl >> 16) & 1).sum()), int(((fl >> 18) & 1).sum()), int(((fl >> 19) & 1).sum())
     if rank == 0:
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        achieved = PUSH_ALG_BYTES_PER_ENV_STEP * n / (k_ms * 1e-3) / 1e9
+        alg_bytes = SORT_ALG_BYTES_PER_ENV_STEP if sorting else PUSH_ALG_BYTES_PER_ENV_STEP
+        achieved = alg_bytes * n / (k_ms * 1e-3) / 1e9
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc runs)
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_pushing.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_%s.json" % args.task)) as f:
                 pm = json.load(f)
             if n == 4096:
                 traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
@@ -171,20 +209,24 @@ def bench_pushing(args):
             "metric": "env-steps/s", "value": world * n * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Pushing task, %d envs per GPU, the 60 reference test contexts tiled, ResidualMLP 10->128x6->2 (Mish) "
-                                   "stand-in policy with fixed random weights (torch, f32), 35 fused physics sub-steps per env step, "
-                                   "400-step episodes" % n,
+            "config": {"workload": ("Sorting-4 task, %d envs per GPU, 60 contexts sampled like BlockContextManager.sample tiled, ResidualMLP 16->128x6->2 (Mish) "
+                                    "stand-in policy with fixed random weights (torch, f32), 35 fused physics sub-steps per env step, 500-step episodes" % n) if sorting else
+                                   ("Pushing task, %d envs per GPU, the 60 reference test contexts tiled, ResidualMLP 10->128x6->2 (Mish) "
+                                    "stand-in policy with fixed random weights (torch, f32), 35 fused physics sub-steps per env step, "
+                                    "400-step episodes" % n),
                        "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world,
-                       "finite": bool(np.isfinite(st[:68]).all()), "flagged_envs_solver_overflow_offtable": bad},
+                       "finite": bool(np.isfinite(st[:env.state_rows - 2]).all()), "flagged_envs_solver_overflow_offtable": bad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_pushing_step_split<true>", "kernel_ms": k_ms,
+                         "kernel": "k_sorting_step<true>" if sorting else "k_pushing_step_split<true>", "kernel_ms": k_ms,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
-                         "algorithmic_bytes_per_launch": PUSH_ALG_BYTES_PER_ENV_STEP * n,
-                         "note": "FP64 latency bound like the Avoiding step (DESIGN.md sections 4, 12.3).  Measured HBM traffic is ~25x the algorithmic bytes: "
-                                 "register spills of the solver functions (private scratch) and the solver warm start / scratch rows, not state traffic"},
+                         "algorithmic_bytes_per_launch": alg_bytes * n,
+                         "note": ("FP64 instruction-issue bound (DESIGN.md section 13): one wave per SIMD, solver loops over LDS-resident systems; HBM traffic beyond the "
+                                  "state column is the contact records of the constraint solver") if sorting else
+                                 ("FP64 latency bound like the Avoiding step (DESIGN.md sections 4, 12.3).  Measured HBM traffic is ~25x the algorithmic bytes: "
+                                  "register spills of the solver functions (private scratch) and the solver warm start / scratch rows, not state traffic")},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline_pushing(env.blob, q, ctx60)
+            line["cpu_baseline"] = cpu_baseline_sorting(env.blob, q, ctx60) if sorting else cpu_baseline_pushing(env.blob, q, ctx60)
         print(json.dumps(line))
     env.close()
     if world > 1:
@@ -193,7 +235,7 @@ def bench_pushing(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing"], help="avoiding = the headline configuration (BASELINE configs[1])")
+    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting"], help="avoiding = the headline configuration (BASELINE configs[1])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
@@ -213,7 +255,7 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a HIP device (there is no CPU fallback for the rollout path)", file=sys.stderr)
         sys.exit(2)
-    if args.task == "pushing":
+    if args.task in ("pushing", "sorting"):
         return bench_pushing(args)
     local_rank = _local_device()
     torch.cuda.set_device(local_rank)

@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 from d3il_amd import distributed as D  # noqa: E402
 from d3il_amd.simulation.avoiding_sim import Avoiding_Sim  # noqa: E402
 from d3il_amd.simulation.pushing_sim import Pushing_Sim  # noqa: E402
+from d3il_amd.simulation.sorting_sim import Sorting_Sim  # noqa: E402
 
 
 class ChaseAgent:
@@ -25,6 +26,21 @@ class ChaseAgent:
         d = obs10[:, 4:6] - obs10[:, 0:2]
         n = d.norm(dim=1, keepdim=True).clamp_min(1e-9)
         return d / n * torch.minimum(n, torch.full_like(n, 0.006))
+
+
+class PushToBinAgent:
+    """deterministic batched policy for Sorting: get behind red_1, then push it towards the red bin"""
+
+    def reset(self):
+        self.t = 0
+
+    def predict_batch(self, obs16):
+        des, box = obs16[:, 0:2], obs16[:, 4:6]
+        aligned = ((des[:, 0] - box[:, 0]).abs() < 0.008) & (des[:, 1] < box[:, 1] - 0.02)
+        target = torch.where(aligned[:, None], torch.stack([box[:, 0], torch.full_like(box[:, 0], 0.36)], 1), box + torch.tensor([0.0, -0.06], dtype=des.dtype, device=des.device))
+        d = target - des
+        n = d.norm(dim=1, keepdim=True)
+        return d / n.clamp_min(1e-9) * torch.minimum(n, torch.full_like(n, 0.006))
 
 
 class WiggleAgent:
@@ -50,6 +66,11 @@ def main():
     successes, entropy = sim2.test_agent(WiggleAgent())
     r2 = sim2.last_rollout
     out["avoiding"] = dict(counts=[int(v) for v in r2["counts"]], entropy=float(entropy), shard=list(r2["shard"]))
+    sim3 = Sorting_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=11, n_trajectories_per_context=2, max_steps_per_episode=130)
+    res3 = sim3.test_agent(PushToBinAgent())
+    r3 = sim3.last_rollout
+    out["sorting"] = dict(counts=[int(v) for v in r3["counts"]], mode_hist=[int(v) for v in r3["mode_hist"]], shard=list(r3["shard"]),
+                          successes=res3["Metrics/successes"], entropy=res3["Metrics/entropy"])
     if rank == 0:
         print("RESULT " + json.dumps(out), flush=True)
     if world > 1:

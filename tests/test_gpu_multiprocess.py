@@ -28,12 +28,14 @@ def _run(world, port):
 
 def test_sim_metrics_do_not_depend_on_the_number_of_ranks():
     one = _run(1, 0)
-    assert one["pushing"]["shard"] == [0, 18] and one["avoiding"]["shard"] == [0, 37]
+    assert one["pushing"]["shard"] == [0, 18] and one["avoiding"]["shard"] == [0, 37] and one["sorting"]["shard"] == [0, 22]
+    assert one["sorting"]["mode_hist"][112] > 0 and sum(one["sorting"]["mode_hist"]) == 22      # some scripted pushes deliver the red cube
     for world, port in ((2, 29531), (3, 29532)):
         many = _run(world, port)
         assert many["pushing"]["shard"][0] == 0 and many["pushing"]["shard"][1] < 18      # rank 0 owns a proper shard
         assert many["pushing"]["counts"] == one["pushing"]["counts"]
         assert many["avoiding"]["counts"] == one["avoiding"]["counts"]
+        assert many["sorting"]["counts"] == one["sorting"]["counts"] and many["sorting"]["mode_hist"] == one["sorting"]["mode_hist"]
         assert many["pushing"]["success_rate"] == one["pushing"]["success_rate"] and many["pushing"]["entropy"] == one["pushing"]["entropy"]
         assert many["avoiding"]["entropy"] == one["avoiding"]["entropy"]
         assert abs(many["pushing"]["mean_distance"] - one["pushing"]["mean_distance"]) < 1e-12

@@ -230,8 +230,10 @@ def test_api_errors(lib_loaded):
     assert L.d3il_create(0, 0, 0, C.byref(b), C.sizeof(b), C.byref(h)) == -1          # n_envs <= 0
     assert L.d3il_create(0, 8, 0, C.byref(b), 17, C.byref(h)) == -2                     # blob size
     assert L.d3il_create(1, 8, 0, C.byref(b), C.sizeof(b), C.byref(h)) == -1           # task id does not match the blob
-    b3 = blob.load("avoiding"); b3.task_id = 2
-    assert L.d3il_create(2, 8, 0, C.byref(b3), C.sizeof(b3), C.byref(h)) == -5          # task not implemented (sorting)
+    b3 = blob.load("avoiding"); b3.task_id = 3
+    assert L.d3il_create(3, 8, 0, C.byref(b3), C.sizeof(b3), C.byref(h)) == -5          # task not implemented (stacking)
+    b4 = blob.load("avoiding"); b4.task_id = 2
+    assert L.d3il_create(2, 8, 0, C.byref(b4), C.sizeof(b4), C.byref(h)) == -2 and b"task objects" in L.d3il_last_error()   # a Sorting blob without cubes
     b2 = blob.load("avoiding"); b2.body_mass[35] *= 1.01
     assert L.d3il_create(0, 8, 0, C.byref(b2), C.sizeof(b2), C.byref(h)) == -5 and b"specialised" in L.d3il_last_error()
     assert L.d3il_create(0, 8, 0, C.byref(b), C.sizeof(b), C.byref(h)) == 0
