@@ -47,7 +47,11 @@ enum {
   D3IL_STATE_F64 = 42,
   /* Pushing appends: per cube pos[3] quat[4] vel[6] (qpos/qvel of its free joint: linear velocity in world axes, angular
    * velocity in body axes), then the constraint solver's warm start qacc[21] (cube1, cube2, arm) */
-  D3IL_PUSH_STATE_BOX = 42, D3IL_PUSH_STATE_WARM = 68, D3IL_PUSH_STATE_F64 = 89
+  D3IL_PUSH_STATE_BOX = 42, D3IL_PUSH_STATE_WARM = 68, D3IL_PUSH_STATE_F64 = 89,
+  /* Sorting-4 (sorting.py): per cube pos[3] quat[4] vel[6] in the order red_1, red_2, blue_1, blue_2, the solver's warm start
+   * qacc[33] (cubes, arm), then the task state of Sorting_Env as two words stored as doubles: word 0 = mode[6], two bits each
+   * (value + 1), | mode_step << 12;  word 1 = min_inds[6], three bits each (sorting.py:405-411, 460-507) */
+  D3IL_SORT_STATE_BOX = 42, D3IL_SORT_STATE_WARM = 94, D3IL_SORT_STATE_TASK = 127, D3IL_SORT_STATE_F64 = 129
 };
 /* bits of the per-environment u32 flag word */
 enum {
@@ -88,7 +92,9 @@ int d3il_start(d3il_handle h, const double* init_qpos7);
 
 /* Replaces env.reset() (avoiding.py:248-262).  env_mask: device u8[n_envs] (non-zero = reset that env) or
  * NULL for all.  contexts: NULL for Avoiding; Pushing (pushing.py:461-483 with random=False): device f64 [n_envs][14] =
- * per env 2 x (x, y, z, qw, qx, qy, qz) written into the cubes' qpos as BlockContextManager.set_context does (z = 0). */
+ * per env 2 x (x, y, z, qw, qx, qy, qz) written into the cubes' qpos as BlockContextManager.set_context does (z = 0);
+ * Sorting-4 (sorting.py:545-575): device f64 [n_envs][28] = 4 x (x, y, z = 0.05, quat), red boxes first (sorting.py:121-187).
+ * Sorting outputs: obs f32 [n_envs][14] (TCP xy, then x, y, tan(yaw) per box), mode = int(np.packbits(mode[:4])[0]). */
 int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, void* stream);
 
 /* Replaces env.step(action) (avoiding.py:168-171 over gym_env_wrapper.py:45-100): n_substeps fused physics
