@@ -89,6 +89,12 @@ D3IL_HD void gen_sync() {     // orders the LDS / HBM traffic of the lanes of a 
 // cubes, then the arm), and its Newton system is stored compactly: block k of the list owns the compact dofs 6 k .. (the arm,
 // always last, 9 of them).  The gradient / direction vectors (voff) and the packed lower Hessian (hoff) of the islands of an
 // environment are laid out one after the other in the t area, so the lanes of a group can solve their islands side by side.
+#if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define GEN_COUNT(slot, v) do { if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && blockIdx.x < 4096) \
+    atomicAdd(&d3il::g_dev_wave[blockIdx.x][slot], (unsigned long long)(v)); } while (0)
+#else
+#define GEN_COUNT(slot, v) ((void)0)
+#endif
 struct Isl { unsigned list; int n, m, hoff, voff; bool arm; };
 D3IL_HD Isl gen_island(unsigned mask, int nb) {
   Isl s{0u, 0, 0, 0, 0, false};
@@ -184,51 +190,107 @@ D3IL_HD double gen_arm_Mv(const PushScratch sc, int a, int va, int vb) {
   }
   return s;
 }
-// Dense Cholesky of the island's compact Hessian (packed lower at hb, order m), right-looking so that the updates of a
-// column are independent of each other; then the two triangular solves on the compact vector at vec
+// Dense Cholesky of the island's compact Hessian (packed lower at hb, order m - always a multiple of 3), right-looking over
+// 3 x 3 blocks: a block update fetches its 27 operands in one batch of LDS reads and does 27 multiply-adds in registers, so
+// the LDS latency is paid once per block instead of once per element.  Then the two triangular solves on the compact
+// vector at vec.
 D3IL_HD bool gen_chol(const PushScratch sc, int hb, int m) {
   bool ok = true;
-  for (int j = 0; j < m; j++) {
-    const int rj = hb + tri(j, 0);
-    double d = GLS(rj + j);
-    if (!(d > 0)) { ok = false; d = 1; }
-    d = sqrt(d);
-    GLS(rj + j) = d;
-    const double inv = 1.0 / d;
-    for (int i = j + 1; i < m; i++) GLS(hb + tri(i, j)) *= inv;
-    for (int i = j + 1; i < m; i++) {
-      const int ri = hb + tri(i, 0);
-      const double lij = GLS(ri + j);
-      int k = j + 1;
-      for (; k + 3 <= i; k += 4) {   // four independent updates: all eight loads are issued before the first store
-        double t0 = GLS(ri + k), t1 = GLS(ri + k + 1), t2 = GLS(ri + k + 2), t3 = GLS(ri + k + 3);
-        double m0 = GLS(hb + tri(k, j)), m1 = GLS(hb + tri(k + 1, j)), m2 = GLS(hb + tri(k + 2, j)), m3 = GLS(hb + tri(k + 3, j));
-        GLS(ri + k) = t0 - lij * m0; GLS(ri + k + 1) = t1 - lij * m1; GLS(ri + k + 2) = t2 - lij * m2; GLS(ri + k + 3) = t3 - lij * m3;
+  const int nbk = m / 3;
+  for (int jb = 0; jb < nbk; jb++) {
+    const int j0 = 3 * jb;
+    // diagonal block: 3 x 3 Cholesky in registers
+    double d00 = GLS(hb + tri(j0, j0)), d10 = GLS(hb + tri(j0 + 1, j0)), d11 = GLS(hb + tri(j0 + 1, j0 + 1));
+    double d20 = GLS(hb + tri(j0 + 2, j0)), d21 = GLS(hb + tri(j0 + 2, j0 + 1)), d22 = GLS(hb + tri(j0 + 2, j0 + 2));
+    if (!(d00 > 0)) { ok = false; d00 = 1; }
+    const double l00 = sqrt(d00), i00 = 1.0 / l00;
+    const double l10 = d10 * i00, l20 = d20 * i00;
+    double t11 = d11 - l10 * l10;
+    if (!(t11 > 0)) { ok = false; t11 = 1; }
+    const double l11 = sqrt(t11), i11 = 1.0 / l11;
+    const double l21 = (d21 - l20 * l10) * i11;
+    double t22 = d22 - l20 * l20 - l21 * l21;
+    if (!(t22 > 0)) { ok = false; t22 = 1; }
+    const double l22 = sqrt(t22), i22 = 1.0 / l22;
+    GLS(hb + tri(j0, j0)) = l00; GLS(hb + tri(j0 + 1, j0)) = l10; GLS(hb + tri(j0 + 1, j0 + 1)) = l11;
+    GLS(hb + tri(j0 + 2, j0)) = l20; GLS(hb + tri(j0 + 2, j0 + 1)) = l21; GLS(hb + tri(j0 + 2, j0 + 2)) = l22;
+    // panel: L(ib, jb) = H(ib, jb) L(jb, jb)^-T
+    for (int ib = jb + 1; ib < nbk; ib++) {
+      double a[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) a[r][c] = GLS(hb + tri(3 * ib + r, j0 + c));
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const double x0 = a[r][0] * i00;
+        const double x1 = (a[r][1] - x0 * l10) * i11;
+        const double x2 = (a[r][2] - x0 * l20 - x1 * l21) * i22;
+        GLS(hb + tri(3 * ib + r, j0)) = x0; GLS(hb + tri(3 * ib + r, j0 + 1)) = x1; GLS(hb + tri(3 * ib + r, j0 + 2)) = x2;
       }
-      for (; k <= i; k++) GLS(ri + k) -= lij * GLS(hb + tri(k, j));
+    }
+    // trailing update: H(ib, kb) -= L(ib, jb) L(kb, jb)^T for jb < kb <= ib
+    for (int ib = jb + 1; ib < nbk; ib++) {
+      double li[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) li[r][c] = GLS(hb + tri(3 * ib + r, j0 + c));
+      for (int kb = jb + 1; kb <= ib; kb++) {
+        double lk[3][3], h[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            lk[r][c] = GLS(hb + tri(3 * kb + r, j0 + c));
+            h[r][c] = (kb < ib || c <= r) ? GLS(hb + tri(3 * ib + r, 3 * kb + c)) : 0.0;
+          }
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) h[r][c] -= li[r][0] * lk[c][0] + li[r][1] * lk[c][1] + li[r][2] * lk[c][2];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) if (kb < ib || c <= r) GLS(hb + tri(3 * ib + r, 3 * kb + c)) = h[r][c];
+      }
     }
   }
   return ok;
 }
 D3IL_HD void gen_chol_solve(const PushScratch sc, int hb, int m, int vec) {
-  for (int i = 0; i < m; i++) {
-    const int ri = hb + tri(i, 0);
-    double s = GLS(vec + i);
-#pragma unroll 4
-    for (int k = 0; k < i; k++) s -= GLS(ri + k) * GLS(vec + k);
-    GLS(vec + i) = s / GLS(ri + i);
-  }
-  for (int i = m - 1; i >= 0; i--) {
-    const int ri = hb + tri(i, 0);
-    const double xi = GLS(vec + i) / GLS(ri + i);
-    GLS(vec + i) = xi;
-    int k = 0;
-    for (; k + 3 < i; k += 4) {
-      double t0 = GLS(vec + k), t1 = GLS(vec + k + 1), t2 = GLS(vec + k + 2), t3 = GLS(vec + k + 3);
-      double m0 = GLS(ri + k), m1 = GLS(ri + k + 1), m2 = GLS(ri + k + 2), m3 = GLS(ri + k + 3);
-      GLS(vec + k) = t0 - m0 * xi; GLS(vec + k + 1) = t1 - m1 * xi; GLS(vec + k + 2) = t2 - m2 * xi; GLS(vec + k + 3) = t3 - m3 * xi;
+  const int nbk = m / 3;
+  for (int ib = 0; ib < nbk; ib++) {          // L y = b, block row by block row; the sums accumulate in registers
+    const int i0 = 3 * ib;
+    double y0 = GLS(vec + i0), y1 = GLS(vec + i0 + 1), y2 = GLS(vec + i0 + 2);
+#pragma unroll 2
+    for (int kb = 0; kb < ib; kb++) {
+      const double v0 = GLS(vec + 3 * kb), v1 = GLS(vec + 3 * kb + 1), v2 = GLS(vec + 3 * kb + 2);
+      const int r0 = hb + tri(i0, 3 * kb), r1 = hb + tri(i0 + 1, 3 * kb), r2 = hb + tri(i0 + 2, 3 * kb);
+      y0 -= GLS(r0) * v0 + GLS(r0 + 1) * v1 + GLS(r0 + 2) * v2;
+      y1 -= GLS(r1) * v0 + GLS(r1 + 1) * v1 + GLS(r1 + 2) * v2;
+      y2 -= GLS(r2) * v0 + GLS(r2 + 1) * v1 + GLS(r2 + 2) * v2;
     }
-    for (; k < i; k++) GLS(vec + k) -= GLS(ri + k) * xi;
+    const double l00 = GLS(hb + tri(i0, i0)), l10 = GLS(hb + tri(i0 + 1, i0)), l11 = GLS(hb + tri(i0 + 1, i0 + 1));
+    const double l20 = GLS(hb + tri(i0 + 2, i0)), l21 = GLS(hb + tri(i0 + 2, i0 + 1)), l22 = GLS(hb + tri(i0 + 2, i0 + 2));
+    y0 = y0 / l00; y1 = (y1 - l10 * y0) / l11; y2 = (y2 - l20 * y0 - l21 * y1) / l22;
+    GLS(vec + i0) = y0; GLS(vec + i0 + 1) = y1; GLS(vec + i0 + 2) = y2;
+  }
+  for (int ib = nbk - 1; ib >= 0; ib--) {      // L' x = y
+    const int i0 = 3 * ib;
+    double x0 = GLS(vec + i0), x1 = GLS(vec + i0 + 1), x2 = GLS(vec + i0 + 2);
+#pragma unroll 2
+    for (int kb = ib + 1; kb < nbk; kb++) {
+      const double v0 = GLS(vec + 3 * kb), v1 = GLS(vec + 3 * kb + 1), v2 = GLS(vec + 3 * kb + 2);
+      const int r0 = hb + tri(3 * kb, i0), r1 = hb + tri(3 * kb + 1, i0), r2 = hb + tri(3 * kb + 2, i0);
+      x0 -= GLS(r0) * v0 + GLS(r1) * v1 + GLS(r2) * v2;
+      x1 -= GLS(r0 + 1) * v0 + GLS(r1 + 1) * v1 + GLS(r2 + 1) * v2;
+      x2 -= GLS(r0 + 2) * v0 + GLS(r1 + 2) * v1 + GLS(r2 + 2) * v2;
+    }
+    const double l00 = GLS(hb + tri(i0, i0)), l10 = GLS(hb + tri(i0 + 1, i0)), l11 = GLS(hb + tri(i0 + 1, i0 + 1));
+    const double l20 = GLS(hb + tri(i0 + 2, i0)), l21 = GLS(hb + tri(i0 + 2, i0 + 1)), l22 = GLS(hb + tri(i0 + 2, i0 + 2));
+    x2 = x2 / l22; x1 = (x1 - l21 * x2) / l11; x0 = (x0 - l10 * x1 - l20 * x2) / l00;
+    GLS(vec + i0) = x0; GLS(vec + i0 + 1) = x1; GLS(vec + i0 + 2) = x2;
   }
 }
 
@@ -260,9 +322,11 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
   PUSH_TOC(3);
   D3IL_STAT(g_stats.newton_calls++);
   D3IL_STAT(g_stats.eig_calls += isl.m);
+  GEN_COUNT(1, 1); GEN_COUNT(8, isl.m);
   for (int it = 0; it < 60 && !converged; it++) {
     D3IL_STAT(g_stats.newton_iters++);
     D3IL_STAT(g_stats.ik_calls += isl.m * isl.m * isl.m / 6);
+    GEN_COUNT(9, 1);
     // gradient (compact, at vg) and Hessian (compact, at hb) at x
     for (int i = 0, nh = isl.m * (isl.m + 1) / 2; i < nh; i++) GLS(hb + i) = 0;
     GEN_FOR_DOFS(ci, gi) {
@@ -383,6 +447,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 50; ls++) {
       D3IL_STAT(g_stats.ls_iters++);
+      GEN_COUNT(2, 1);
       double d1 = pMa + alpha * pMp, d2 = pMp;
       if (isl.arm)
         for (int k = 0; k < NDOF; k++) {

@@ -14,8 +14,8 @@ des = env.robot_state()[:, :2].clone(); z = env.robot_state()[:, 2:3].clone()
 quat = torch.tensor([0.0, 1, 0, 0], dtype=torch.float64, device=env.device).expand(n, 4)
 NW = (n + 15) // 16
 W = np.zeros((NW, 10), dtype=np.uint64)
-names = ["dyn+publish", "collect", "rodjac", "s.setup", "s.grad+H", "s.chol", "s.jp", "s.linesearch", "solve+integ", "s.tail"]
-for t in range(40):
+names = ["-", "calls", "ls_evals", "s.setup", "s.grad+H", "s.chol", "s.jp", "s.linesearch", "sum_m", "newton_its"]
+for t in range(60):
     box = env.obs[:, 2:4].to(torch.float64)
     if t >= 12:
         aligned = ((des[:, 0] - box[:, 0]).abs() < 0.008) & (des[:, 1] < box[:, 1] - 0.02)
@@ -27,6 +27,8 @@ for t in range(40):
     env.step(torch.cat([des, z, quat], dim=1).contiguous())
     torch.cuda.synchronize()
     L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), NW, 1)
-    if t in (2, 3, 11, 20, 35, 39):
-        med = np.median(W.astype(np.float64), axis=0) / 100.0     # microseconds per env step
-        print("t %2d  median us per step per workgroup: " % t + "  ".join("%s %.0f" % (names[i], med[i]) for i in range(10)), flush=True)
+    if t in (20, 39, 55):
+        Wf = W.astype(np.float64)
+        Wf[:, 3:8] /= 100.0                                       # ticks -> microseconds per env step; the other slots are counts (first active lane of the wave)
+        for lab, v in (("median", np.median(Wf, axis=0)), ("p90", np.percentile(Wf, 90, axis=0)), ("max", Wf.max(axis=0))):
+            print("t %2d %6s per workgroup: " % (t, lab) + "  ".join("%s %.0f" % (names[i], v[i]) for i in range(1, 10)), flush=True)
