@@ -841,7 +841,7 @@ D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, 
 D3IL_HD void gen_phase4(const GenConsts& gc_, const PushScratch sc, int l, bool warm_valid, unsigned& fl) {
   D3IL_GEN_CONSTS(gc_, gc);
   const int nb = gc.nb;
-  unsigned adj[GEN_MAXNB + 1], cnt_any = 0;
+  unsigned adj[GEN_MAXNB + 1];
 #pragma unroll
   for (int b = 0; b <= GEN_MAXNB; b++) adj[b] = 0;
 #pragma unroll
@@ -849,7 +849,6 @@ D3IL_HD void gen_phase4(const GenConsts& gc_, const PushScratch sc, int l, bool 
     unsigned info = (unsigned)GLS(GL_INFO + b);
     unsigned m = (info >> 5) & 15u;
     if ((info >> 9) & 1) m |= 1u << nb;
-    if (info & 31) cnt_any |= 1u << b;
     adj[b] |= m;
 #pragma unroll
     for (int d = 0; d <= GEN_MAXNB; d++) if ((m >> d) & 1) adj[d] |= 1u << b;
@@ -890,7 +889,6 @@ D3IL_HD void gen_phase4(const GenConsts& gc_, const PushScratch sc, int l, bool 
     GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);
     if (!gen_solve(gc, sc, isl)) fl |= F_SOLVER_FAIL;
   }
-  (void)cnt_any;
 }
 // ---- phase 5: integration.  Arm (lane 0): (M + h B) qacc = M x with B on the fingers; cube l: mj_Euler with quaternion integration
 template <class C>
@@ -961,7 +959,6 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc_, EnvState& st
 // Task state of Sorting_Env in two words: word 0 = mode[6] (2 bits each: value + 1) | mode_step << 12;  word 1 = min_inds[6]
 // (3 bits each).  sorting.py:405-411 (reset), :460-507 (check_mode)
 constexpr int GEN_SORT_OBS = 20;      // 2 + 3 * 6 at most (num_boxes = 6); Sorting-4 uses 14
-D3IL_HD unsigned sort_word0_reset() { return 0; }
 D3IL_HD void sort_collect(const GenConsts& gc_, const PushScratch sc, double (*box)[7]) {
   D3IL_GEN_CONSTS(gc_, gc);
   const int nr = gc.nb / 2;

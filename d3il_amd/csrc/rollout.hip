@@ -292,8 +292,7 @@ struct d3il_handle_s {
   PandaConsts hc;          // host copy
   PandaConsts* dc;         // device copy
   PushConsts pc;           // Pushing: cubes, table slabs, contact parameter sets, targets
-  GenConsts gc;            // Sorting: cubes, static boxes, contact parameter sets (host copy)
-  GenConsts* d_gc;         // device copy
+  GenConsts gc;            // Sorting: cubes, static boxes, contact parameter sets (host copy; the device copy is the __constant__ object)
   double* d_scratch;       // Pushing: per-lane solver scratch [PG_SIZE][stride]
   int state_rows;          // f64 state fields per environment (42 Avoiding, 89 Pushing)
   double* d_init_qpos;
@@ -357,7 +356,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
                                                            "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
   h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
-  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr; h->d_gc = nullptr;
+  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr;
   const bool pushing = task_id == D3IL_TASK_PUSHING;
   const bool sorting = task_id == D3IL_TASK_SORTING;
   h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : D3IL_STATE_F64);
@@ -402,7 +401,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
 int d3il_destroy(d3il_handle h) {
   if (!h) return fail(D3IL_EINVAL, "d3il_destroy: null handle");
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des, h->buf.info_f64, h->d_scratch, h->d_gc};
+  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des, h->buf.info_f64, h->d_scratch};
   for (void* p : ptrs) (void)hipFree(p);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
   delete h;
