@@ -11,7 +11,7 @@
 
 namespace d3il {
 
-constexpr int GEN_LDS_H = GL_SIZE * (GEN_LANES + 1) * 8;
+constexpr int GEN_LDS_H = GL_SIZE * (GEN_LANES + 1) * 8;   // 960 x 17 doubles = 127.5 KiB
 constexpr int GEN_LDS_X = 2 * 2 * NARM * GEN_LANES * 8;
 constexpr int GEN_LDS_STEP = GEN_LDS_H + GEN_LDS_X;
 
@@ -125,7 +125,9 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
       gen_sync();
       if (arm_lane) gen_phase3b(c, gc, st, sc);
       gen_sync();
-      if (plive) gen_phase4(gc, sc, l, warm_valid, lfl);
+      if (plive) gen_phase4_single(gc, sc, l, warm_valid, lfl);
+      gen_sync();
+      if (plive) gen_phase4_multi(gc, sc, l, gc.nb, warm_valid, lfl);
       gen_sync();
       if (arm_lane) gen_phase5_arm(c, gc, st, sc);
       if (plive) gen_phase5_cube(gc, sc, l, c.timestep);

@@ -71,7 +71,8 @@ constexpr int GL_H = 0, GL_X = GEN_NH, GL_P = GL_X + GEN_MAXNV, GL_G = GL_P + GE
 constexpr int GL_R = GL_VEL + GEN_MAXNV, GL_POS = GL_R + 9 * GEN_MAXNB, GL_M = GL_POS + 3 * GEN_MAXNB, GL_LIM = GL_M + 45, GL_JA = GL_LIM + 27;
 constexpr int GL_ROD = GL_JA + 21 * GEN_MAXNB;      // rod centre[3], axis[3]
 constexpr int GL_INFO = GL_ROD + 6;                 // [0..3] per cube: contact count | partner cubes << 5 | rod contact << 9;  [4] arm joint at a limit;  [5..7] flags of lanes 1..3
-constexpr int GL_SIZE = GL_INFO + 8;                // 944
+constexpr int GL_RED = GL_INFO + 8;                  // line-search partial sums of the group's lanes, double buffered: 2 x 4 x (d1, d2)
+constexpr int GL_SIZE = GL_RED + 16;                // 960
 // g area (HBM): contact records, GEN_SEG per cube
 constexpr int GG_CON = 0;
 constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn fric set | jar[3] jp[3]
@@ -192,14 +193,14 @@ D3IL_HD double gen_arm_Mv(const PushScratch sc, int a, int va, int vb) {
 }
 // Dense Cholesky of the island's compact Hessian (packed lower at hb, order m - always a multiple of 3), right-looking over
 // 3 x 3 blocks: a block update fetches its 27 operands in one batch of LDS reads and does 27 multiply-adds in registers, so
-// the LDS latency is paid once per block instead of once per element.  Then the two triangular solves on the compact
-// vector at vec.
-D3IL_HD bool gen_chol(const PushScratch sc, int hb, int m) {
+// the LDS latency is paid once per block instead of once per element.  The nl lanes of the group share the work: every lane
+// factors the diagonal block (in registers; lane 0 stores it), block rows of the panel and of the trailing update are dealt
+// out round robin (a block row is only ever touched by its own lane between two syncs).
+D3IL_HD bool gen_chol(const PushScratch sc, int hb, int m, int l, int nl) {
   bool ok = true;
   const int nbk = m / 3;
   for (int jb = 0; jb < nbk; jb++) {
     const int j0 = 3 * jb;
-    // diagonal block: 3 x 3 Cholesky in registers
     double d00 = GLS(hb + tri(j0, j0)), d10 = GLS(hb + tri(j0 + 1, j0)), d11 = GLS(hb + tri(j0 + 1, j0 + 1));
     double d20 = GLS(hb + tri(j0 + 2, j0)), d21 = GLS(hb + tri(j0 + 2, j0 + 1)), d22 = GLS(hb + tri(j0 + 2, j0 + 2));
     if (!(d00 > 0)) { ok = false; d00 = 1; }
@@ -212,10 +213,13 @@ D3IL_HD bool gen_chol(const PushScratch sc, int hb, int m) {
     double t22 = d22 - l20 * l20 - l21 * l21;
     if (!(t22 > 0)) { ok = false; t22 = 1; }
     const double l22 = sqrt(t22), i22 = 1.0 / l22;
-    GLS(hb + tri(j0, j0)) = l00; GLS(hb + tri(j0 + 1, j0)) = l10; GLS(hb + tri(j0 + 1, j0 + 1)) = l11;
-    GLS(hb + tri(j0 + 2, j0)) = l20; GLS(hb + tri(j0 + 2, j0 + 1)) = l21; GLS(hb + tri(j0 + 2, j0 + 2)) = l22;
+    gen_sync();        // every lane has read the diagonal block
+    if (l == 0) {
+      GLS(hb + tri(j0, j0)) = l00; GLS(hb + tri(j0 + 1, j0)) = l10; GLS(hb + tri(j0 + 1, j0 + 1)) = l11;
+      GLS(hb + tri(j0 + 2, j0)) = l20; GLS(hb + tri(j0 + 2, j0 + 1)) = l21; GLS(hb + tri(j0 + 2, j0 + 2)) = l22;
+    }
     // panel: L(ib, jb) = H(ib, jb) L(jb, jb)^-T
-    for (int ib = jb + 1; ib < nbk; ib++) {
+    for (int ib = jb + 1 + l; ib < nbk; ib += nl) {
       double a[3][3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
@@ -229,8 +233,9 @@ D3IL_HD bool gen_chol(const PushScratch sc, int hb, int m) {
         GLS(hb + tri(3 * ib + r, j0)) = x0; GLS(hb + tri(3 * ib + r, j0 + 1)) = x1; GLS(hb + tri(3 * ib + r, j0 + 2)) = x2;
       }
     }
+    gen_sync();        // panel complete
     // trailing update: H(ib, kb) -= L(ib, jb) L(kb, jb)^T for jb < kb <= ib
-    for (int ib = jb + 1; ib < nbk; ib++) {
+    for (int ib = jb + 1 + l; ib < nbk; ib += nl) {
       double li[3][3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
@@ -255,9 +260,12 @@ D3IL_HD bool gen_chol(const PushScratch sc, int hb, int m) {
           for (int c = 0; c < 3; c++) if (kb < ib || c <= r) GLS(hb + tri(3 * ib + r, 3 * kb + c)) = h[r][c];
       }
     }
+    gen_sync();        // trailing update complete
   }
   return ok;
 }
+// the two triangular solves on the compact vector at vec; executed by every lane of the group with identical operands
+// (identical stores), so that no hand-over is needed
 D3IL_HD void gen_chol_solve(const PushScratch sc, int hb, int m, int vec) {
   const int nbk = m / 3;
   for (int ib = 0; ib < nbk; ib++) {          // L y = b, block row by block row; the sums accumulate in registers
@@ -294,15 +302,42 @@ D3IL_HD void gen_chol_solve(const PushScratch sc, int hb, int m, int vec) {
   }
 }
 
-// Newton solve of one island; x in / out at GL_X (island dofs).  Returns false when it did not converge.
-D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, const Isl isl) {
+
+// accumulation into the t area by several lanes of a group at once (LDS atomic add; the conflicting lanes of one instruction
+// are served in lane order, so the sum is reproducible); the host build runs the lanes one after the other
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GLS_ADD(i, v) ((void)__hip_atomic_fetch_add(&GLS(i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT))
+#else
+#define GLS_ADD(i, v) (GLS(i) += (v))
+#endif
+
+// Newton solve of one island by the nl lanes of the group together (lane l); x in / out at GL_X (island dofs).  cpk: contact
+// counts of the island's blocks, 5 bits each in list order.  Work is dealt out by contact (lane l takes contacts l, l + nl, ..
+// of the island's concatenated segments) and by block row (Cholesky); everything else is computed by every lane from the same
+// LDS data, so all lanes take the same decisions.  Returns false when it did not converge.
+D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, const Isl isl, unsigned cpk, int l, int nl) {
   D3IL_GEN_CONSTS(gc_, gc);
   const int arm0 = 6 * gc.nb, ca = isl.m - NDOF;       // global / compact offset of the arm block (when isl.arm)
   const int hb = GL_H + isl.hoff, vg = GL_G + isl.voff, vp = GL_P + isl.voff;
   const double impr = gc.impratio, mu_scale = sqrt(1 / fmax(1e-15, impr));
+  int ntot = 0;
+  for (int k = 0; k < isl.n; k++) ntot += (int)((cpk >> (5 * k)) & 31u);
+  auto locate = [&](int t) {      // record index of the island's t-th contact
+    int ci = 0;
+    bool found = false;
+    for (int k = 0; k < isl.n; k++) {
+      const int n = (int)((cpk >> (5 * k)) & 31u);
+      if (!found && t < n) { ci = ISL_BLK(k) * GEN_SEG + t; found = true; }
+      t -= n;
+    }
+    return ci;
+  };
+  auto dof_of = [&](int ci) {     // global dof of compact dof ci
+    return (isl.arm && ci >= ca) ? arm0 + ci - ca : 6 * ISL_BLK(ci / 6) + ci % 6;
+  };
   PUSH_TIC;
-  GEN_FOR_CONTACTS(ci) {   // reference acceleration and regularisation
-    const int base = GG_CON + ci * GREC;
+  for (int t = l; t < ntot; t += nl) {   // reference acceleration and regularisation
+    const int base = GG_CON + locate(t) * GREC;
     double rec[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
@@ -318,7 +353,9 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     PGS(base + 19) = 1 / fmax(1e-15, (1 - imp) / imp * invw);
     PGS(base + 20) = gc.ct_fric[set];
   }
+  gen_sync();
   bool converged = false;
+  int buf = 0;
   PUSH_TOC(3);
   D3IL_STAT(g_stats.newton_calls++);
   D3IL_STAT(g_stats.eig_calls += isl.m);
@@ -327,16 +364,20 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     D3IL_STAT(g_stats.newton_iters++);
     D3IL_STAT(g_stats.ik_calls += isl.m * isl.m * isl.m / 6);
     GEN_COUNT(9, 1);
-    // gradient (compact, at vg) and Hessian (compact, at hb) at x
-    for (int i = 0, nh = isl.m * (isl.m + 1) / 2; i < nh; i++) GLS(hb + i) = 0;
-    GEN_FOR_DOFS(ci, gi) {
+    // gradient (compact, at vg) and Hessian (compact, at hb) at x: smooth part entry by entry, then the limit rows (lane 0),
+    // then the contacts (accumulated by all lanes)
+    for (int i = l, nh = isl.m * (isl.m + 1) / 2; i < nh; i += nl) GLS(hb + i) = 0;
+    gen_sync();
+    for (int ci = l; ci < isl.m; ci += nl) {
+      const int gi = dof_of(ci);
       if (gi < arm0) { const double mm = (gi % 6) < 3 ? gc.box_mass : gc.box_inertia; GLS(vg + ci) = mm * (GLS(GL_X + gi) - GLS(GL_A0 + gi)); GLS(hb + tri(ci, ci)) = mm; }
       else {
         GLS(vg + ci) = gen_arm_Mv(sc, gi - arm0, GL_X + arm0, GL_A0 + arm0);
         for (int k = 0; k <= gi - arm0; k++) GLS(hb + tri(ci, ca + k)) = GLS(GL_M + tri(gi - arm0, k));
       }
     }
-    if (isl.arm)
+    gen_sync();
+    if (isl.arm && l == 0)
       for (int k = 0; k < NDOF; k++) {
         double sign = GLS(GL_LIM + 3 * k), D = GLS(GL_LIM + 3 * k + 1), aref = GLS(GL_LIM + 3 * k + 2);
         if (sign != 0) {
@@ -344,8 +385,9 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
           if (jar < 0) { GLS(vg + ca + k) += sign * D * jar; GLS(hb + tri(ca + k, ca + k)) += D; }
         }
       }
-    GEN_FOR_CONTACTS(ci) {
-      const int base = GG_CON + ci * GREC;
+    gen_sync();
+    for (int t = l; t < ntot; t += nl) {
+      const int base = GG_CON + locate(t) * GREC;
       double rec[21];
 #pragma unroll
       for (int k = 0; k < 21; k++) rec[k] = PGS(base + k);
@@ -359,82 +401,51 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
       if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
       const int c1 = rows[0].c1, c2 = rows[0].c2, n2 = rows[0].n2;
 #pragma unroll
-      for (int k = 0; k < 6; k++) GLS(vg + c1 + k) -= rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2];
+      for (int k = 0; k < 6; k++) GLS_ADD(vg + c1 + k, -(rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2]));
 #pragma unroll
-      for (int k = 0; k < 7; k++) if (k < n2) GLS(vg + c2 + k) -= rows[0].v2[k] * force[0] + rows[1].v2[k] * force[1] + rows[2].v2[k] * force[2];
-      // H += J' Hc J block by block; each block is read in one batch, updated in registers and written back
-      {
-        double blk[21];
+      for (int k = 0; k < 7; k++) if (k < n2) GLS_ADD(vg + c2 + k, -(rows[0].v2[k] * force[0] + rows[1].v2[k] * force[1] + rows[2].v2[k] * force[2]));
+      // H += J' Hc J, block (1,1), then (2,1) and (2,2); c2 > c1 for every contact kind (second cube after the first, arm last)
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+      for (int a = 0; a < 6; a++) {
+        double ta[3];
 #pragma unroll
-          for (int b = 0; b <= a; b++) blk[tri(a, b)] = GLS(hb + tri(c1 + a, c1 + b));
+        for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v1[a] + Hc[3 * r + 1] * rows[1].v1[a] + Hc[3 * r + 2] * rows[2].v1[a];
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-          double ta[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v1[a] + Hc[3 * r + 1] * rows[1].v1[a] + Hc[3 * r + 2] * rows[2].v1[a];
-#pragma unroll
-          for (int b = 0; b <= a; b++) blk[tri(a, b)] += ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b];
-        }
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-          for (int b = 0; b <= a; b++) GLS(hb + tri(c1 + a, c1 + b)) = blk[tri(a, b)];
+        for (int b = 0; b <= a; b++) GLS_ADD(hb + tri(c1 + a, c1 + b), ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b]);
       }
-      if (n2 > 0) {   // c2 > c1 for every contact kind (second cube after the first, arm after the cubes)
-        double blk[7][6];
 #pragma unroll
-        for (int a = 0; a < 7; a++)
+      for (int a = 0; a < 7; a++) if (a < n2) {
+        double ta[3];
 #pragma unroll
-          for (int b = 0; b < 6; b++) blk[a][b] = a < n2 ? GLS(hb + tri(c2 + a, c1 + b)) : 0.0;
-        double ta[7][3];
+        for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v2[a] + Hc[3 * r + 1] * rows[1].v2[a] + Hc[3 * r + 2] * rows[2].v2[a];
 #pragma unroll
-        for (int a = 0; a < 7; a++)
+        for (int b = 0; b < 6; b++) GLS_ADD(hb + tri(c2 + a, c1 + b), ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b]);
 #pragma unroll
-          for (int r = 0; r < 3; r++) ta[a][r] = Hc[3 * r] * rows[0].v2[a] + Hc[3 * r + 1] * rows[1].v2[a] + Hc[3 * r + 2] * rows[2].v2[a];
-#pragma unroll
-        for (int a = 0; a < 7; a++)
-#pragma unroll
-          for (int b = 0; b < 6; b++) blk[a][b] += ta[a][0] * rows[0].v1[b] + ta[a][1] * rows[1].v1[b] + ta[a][2] * rows[2].v1[b];
-#pragma unroll
-        for (int a = 0; a < 7; a++) if (a < n2)
-#pragma unroll
-          for (int b = 0; b < 6; b++) GLS(hb + tri(c2 + a, c1 + b)) = blk[a][b];
-        double b22[28];
-#pragma unroll
-        for (int a = 0; a < 7; a++)
-#pragma unroll
-          for (int b = 0; b <= a; b++) b22[tri(a, b)] = a < n2 ? GLS(hb + tri(c2 + a, c2 + b)) : 0.0;
-#pragma unroll
-        for (int a = 0; a < 7; a++)
-#pragma unroll
-          for (int b = 0; b <= a; b++) b22[tri(a, b)] += ta[a][0] * rows[0].v2[b] + ta[a][1] * rows[1].v2[b] + ta[a][2] * rows[2].v2[b];
-#pragma unroll
-        for (int a = 0; a < 7; a++) if (a < n2)
-#pragma unroll
-          for (int b = 0; b <= a; b++) GLS(hb + tri(c2 + a, c2 + b)) = b22[tri(a, b)];
+        for (int b = 0; b < 7; b++) if (b <= a) GLS_ADD(hb + tri(c2 + a, c2 + b), ta[0] * rows[0].v2[b] + ta[1] * rows[1].v2[b] + ta[2] * rows[2].v2[b]);
       }
     }
+    gen_sync();
     {
       double gm = 0;
       for (int k = 0; k < isl.m; k++) gm = fmax(gm, fabs(GLS(vg + k)));
       if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
     }
     PUSH_TOC(4);
-    if (!gen_chol(sc, hb, isl.m)) return false;
+    if (!gen_chol(sc, hb, isl.m, l, nl)) return false;
     for (int k = 0; k < isl.m; k++) GLS(vp + k) = -GLS(vg + k);
     gen_chol_solve(sc, hb, isl.m, vp);
+    gen_sync();
     PUSH_TOC(5);
     double pMp = 0, pMa = 0, gTp = 0;
-    GEN_FOR_DOFS(ci, gi) {
+    for (int ci = 0; ci < isl.m; ci++) {
+      const int gi = dof_of(ci);
       double s, sa, pi = GLS(vp + ci);
       if (gi < arm0) { const double mm = (gi % 6) < 3 ? gc.box_mass : gc.box_inertia; s = mm * pi; sa = mm * (GLS(GL_X + gi) - GLS(GL_A0 + gi)); }
       else { s = gen_arm_Mv(sc, gi - arm0, vp + ca, -1); sa = gen_arm_Mv(sc, gi - arm0, GL_X + arm0, GL_A0 + arm0); }
       pMp += pi * s; pMa += pi * sa; gTp += GLS(vg + ci) * pi;
     }
-    GEN_FOR_CONTACTS(ci) {
-      const int base = GG_CON + ci * GREC;
+    for (int t = l; t < ntot; t += nl) {
+      const int base = GG_CON + locate(t) * GREC;
       double rec[16];
 #pragma unroll
       for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
@@ -443,22 +454,15 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
 #pragma unroll
       for (int r = 0; r < 3; r++) PGS(base + 25 + r) = grow_dot_c(sc, rows[r], vp);
     }
+    gen_sync();
     PUSH_TOC(6);
     double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 50; ls++) {
       D3IL_STAT(g_stats.ls_iters++);
       GEN_COUNT(2, 1);
-      double d1 = pMa + alpha * pMp, d2 = pMp;
-      if (isl.arm)
-        for (int k = 0; k < NDOF; k++) {
-          double sign = GLS(GL_LIM + 3 * k), D = GLS(GL_LIM + 3 * k + 1), aref = GLS(GL_LIM + 3 * k + 2);
-          if (sign != 0) {
-            double jp = sign * GLS(vp + ca + k), jar = sign * GLS(GL_X + arm0 + k) - aref + alpha * jp;
-            if (jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
-          }
-        }
-      GEN_FOR_CONTACTS(ci) {
-        const int base = GG_CON + ci * GREC;
+      double p1 = 0, p2 = 0;      // this lane's share of the contact terms of phi'(alpha), phi''(alpha)
+      for (int t = l; t < ntot; t += nl) {
+        const int base = GG_CON + locate(t) * GREC;
         double rec[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) rec[k] = PGS(base + 19 + k);     // Dn fric set jar[3] jp[3]
@@ -467,10 +471,23 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
         const double Dn = rec[0], fric = rec[1];
         cone_eval(jt, Dn, Dn * impr, fric * mu_scale, fric, ft, Hc);
 #pragma unroll
-        for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r];
+        for (int r = 0; r < 3; r++) { p1 -= ft[r] * jp[r];
 #pragma unroll
-          for (int q = 0; q < 3; q++) d2 += jp[r] * Hc[3 * r + q] * jp[q]; }
+          for (int q = 0; q < 3; q++) p2 += jp[r] * Hc[3 * r + q] * jp[q]; }
       }
+      GLS(GL_RED + 8 * buf + 2 * l) = p1; GLS(GL_RED + 8 * buf + 2 * l + 1) = p2;
+      gen_sync();
+      double d1 = pMa + alpha * pMp, d2 = pMp;
+      for (int j = 0; j < nl; j++) { d1 += GLS(GL_RED + 8 * buf + 2 * j); d2 += GLS(GL_RED + 8 * buf + 2 * j + 1); }
+      buf ^= 1;
+      if (isl.arm)
+        for (int k = 0; k < NDOF; k++) {
+          double sign = GLS(GL_LIM + 3 * k), D = GLS(GL_LIM + 3 * k + 1), aref = GLS(GL_LIM + 3 * k + 2);
+          if (sign != 0) {
+            double jp = sign * GLS(vp + ca + k), jar = sign * GLS(GL_X + arm0 + k) - aref + alpha * jp;
+            if (jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
+          }
+        }
       best = alpha;
       if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
       if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
@@ -487,10 +504,14 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     }
     PUSH_TOC(7);
     double smax = 0, xmax = 0;
-    GEN_FOR_DOFS(ci, gi) {
-      double dxk = best * GLS(vp + ci), xn = GLS(GL_X + gi) + dxk;
-      GLS(GL_X + gi) = xn; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(xn));
+    for (int ci = 0; ci < isl.m; ci++) {
+      const int gi = dof_of(ci);
+      const double dxk = best * GLS(vp + ci), xo = GLS(GL_X + gi);
+      smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(xo + dxk));
     }
+    gen_sync();        // every lane has read the old iterate
+    for (int ci = l; ci < isl.m; ci += nl) { const int gi = dof_of(ci); GLS(GL_X + gi) += best * GLS(vp + ci); }
+    gen_sync();
     if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
   }
   return converged;
@@ -836,28 +857,28 @@ D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, 
     }
   }
 }
-// ---- phase 4 (lane l): island bookkeeping and solve.  The lane of an island's first cube solves it; the arm alone keeps
-// the phase-1 solution unless one of its seven joints is at a limit (then lane 0 solves the arm island)
-D3IL_HD void gen_phase4(const GenConsts& gc_, const PushScratch sc, int l, bool warm_valid, unsigned& fl) {
+// ---- phase 4: islands.  Every lane derives the connected components of {cubes, arm} under cube-cube and rod contacts from the
+// per-cube info words (identical result in all lanes), in the order of their first block, with their storage offsets.
+struct IslSet { Isl isl[GEN_MAXNB + 1]; unsigned cpk[GEN_MAXNB + 1]; int first[GEN_MAXNB + 1]; int n; };
+D3IL_HD void gen_islands(const GenConsts& gc_, const PushScratch sc, IslSet& out) {
   D3IL_GEN_CONSTS(gc_, gc);
   const int nb = gc.nb;
-  unsigned adj[GEN_MAXNB + 1];
+  unsigned adj[GEN_MAXNB + 1], cnt[GEN_MAXNB + 1];
 #pragma unroll
-  for (int b = 0; b <= GEN_MAXNB; b++) adj[b] = 0;
+  for (int b = 0; b <= GEN_MAXNB; b++) { adj[b] = 0; cnt[b] = 0; }
 #pragma unroll
   for (int b = 0; b < GEN_MAXNB; b++) if (b < nb) {
     unsigned info = (unsigned)GLS(GL_INFO + b);
     unsigned m = (info >> 5) & 15u;
     if ((info >> 9) & 1) m |= 1u << nb;
+    cnt[b] = info & 31u;
     adj[b] |= m;
 #pragma unroll
     for (int d = 0; d <= GEN_MAXNB; d++) if ((m >> d) & 1) adj[d] |= 1u << b;
   }
-  // islands in the order of their first block; storage offsets accumulate along the way
-  Isl mine{0u, 0, 0, 0, 0, false}, armisl = mine;
-  bool root = false, arm_alone = false;
   unsigned seen = 0;
   int hoff = 0, voff = 0;
+  out.n = 0;
 #pragma unroll
   for (int b = 0; b <= GEN_MAXNB; b++) if (b <= nb && !((seen >> b) & 1)) {
     unsigned mask = 1u << b;
@@ -868,26 +889,69 @@ D3IL_HD void gen_phase4(const GenConsts& gc_, const PushScratch sc, int l, bool 
     seen |= mask;
     Isl t = gen_island(mask, nb);
     t.hoff = hoff; t.voff = voff;
-    if (b == l) { mine = t; root = true; }
-    if (b == nb) { armisl = t; arm_alone = true; }
+    unsigned cpk = 0;
+    int k = 0;
+#pragma unroll
+    for (int d = 0; d <= GEN_MAXNB; d++) if ((mask >> d) & 1) { cpk |= cnt[d] << (5 * k); k++; }
+    out.isl[out.n] = t; out.cpk[out.n] = cpk; out.first[out.n] = b; out.n++;
     hoff += t.m * (t.m + 1) / 2; voff += t.m;
   }
-  if (root) {
-    if (mine.n == 1) {
-      // a cube on its own: register-resident 6-dof solve over its static contacts (no contact: x = a0)
-      const int cnt = (int)((unsigned)GLS(GL_INFO + l) & 31u);
-      if (cnt == 0) for (int k = 0; k < 6; k++) GLS(GL_X + 6 * l + k) = GLS(GL_A0 + 6 * l + k);
-      else if (!gen_solve_cube(gc, sc, l, cnt, warm_valid)) fl |= F_SOLVER_FAIL;
-    } else {
-      const Isl isl = mine;
-      GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);
-      if (!gen_solve(gc, sc, isl)) fl |= F_SOLVER_FAIL;
-    }
+}
+// phase 4a (lane l): a cube that forms an island on its own is solved by its lane - register-resident 6-dof Newton over its
+// static contacts (no contact: x = a0)
+D3IL_HD bool gen_uncoupled(const GenConsts& gc_, const PushScratch sc) {   // no cube-cube and no rod contact in this environment
+  D3IL_GEN_CONSTS(gc_, gc);
+  unsigned c = 0;
+#pragma unroll
+  for (int b = 0; b < GEN_MAXNB; b++) if (b < gc.nb) c |= (unsigned)GLS(GL_INFO + b) >> 5;
+  return c == 0;
+}
+D3IL_HD void gen_phase4_single(const GenConsts& gc_, const PushScratch sc, int l, bool warm_valid, unsigned& fl) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  int cnt = -1;                                   // contact count of cube l when it is an island on its own
+  if (gen_uncoupled(gc, sc)) cnt = (int)((unsigned)GLS(GL_INFO + l) & 31u);      // the usual case: no island bookkeeping needed
+  else {
+    IslSet is;
+    gen_islands(gc, sc, is);
+#pragma unroll
+    for (int k = 0; k <= GEN_MAXNB; k++) if (k < is.n && is.first[k] == l && is.isl[k].n == 1 && l < gc.nb) cnt = (int)(is.cpk[k] & 31u);
   }
-  if (l == 0 && arm_alone && GLS(GL_INFO + 4) != 0) {   // the arm on its own with one of its seven joints at a limit
-    const Isl isl = armisl;
+  if (cnt == 0) for (int j = 0; j < 6; j++) GLS(GL_X + 6 * l + j) = GLS(GL_A0 + 6 * l + j);
+  else if (cnt > 0 && !gen_solve_cube(gc, sc, l, cnt, warm_valid)) fl |= F_SOLVER_FAIL;
+}
+// phase 4b (all nl lanes of the group together, lane l): the islands with more than one block, one after the other, and the arm
+// on its own when one of its seven joints is at a limit (otherwise it keeps the phase-1 solution)
+D3IL_HD void gen_phase4_multi(const GenConsts& gc_, const PushScratch sc, int l, int nl, bool warm_valid, unsigned& fl) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  if (gen_uncoupled(gc, sc)) {
+    if (GLS(GL_INFO + 4) == 0) return;                         // the usual case: nothing to do
+    Isl isl = gen_island(1u << gc.nb, gc.nb);                   // only the arm, with a joint at its limit
     GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);
-    if (!gen_solve(gc, sc, isl)) fl |= F_SOLVER_FAIL;
+    gen_sync();
+    if (!gen_solve(gc, sc, isl, 0u, l, nl)) fl |= F_SOLVER_FAIL;
+    gen_sync();
+    return;
+  }
+  IslSet is;
+  gen_islands(gc, sc, is);
+  // the k-th island that needs the joint solver: packed so that the groups of a wave run their k-th solves side by side
+  unsigned todo = 0;
+  int ntodo = 0;
+#pragma unroll
+  for (int k = 0; k <= GEN_MAXNB; k++) if (k < is.n) {
+    const bool arm_alone = is.isl[k].n == 1 && is.isl[k].arm;
+    if (is.isl[k].n > 1 || (arm_alone && GLS(GL_INFO + 4) != 0)) { todo |= (unsigned)k << (4 * ntodo); ntodo++; }
+  }
+  for (int j = 0; j < ntodo; j++) {
+    const int k = (int)((todo >> (4 * j)) & 15u);
+    Isl isl = is.isl[0];
+    unsigned cpk = is.cpk[0];
+#pragma unroll
+    for (int q = 1; q <= GEN_MAXNB; q++) if (q == k) { isl = is.isl[q]; cpk = is.cpk[q]; }
+    GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);      // identical stores from every lane
+    gen_sync();
+    if (!gen_solve(gc, sc, isl, cpk, l, nl)) fl |= F_SOLVER_FAIL;
+    gen_sync();
   }
 }
 // ---- phase 5: integration.  Arm (lane 0): (M + h B) qacc = M x with B on the fingers; cube l: mj_Euler with quaternion integration
@@ -949,7 +1013,8 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc_, EnvState& st
   for (int l = 0; l < gc.nb; l++) cnt[l] = gen_phase2(gc, sc, l, grav, fl);
   for (int l = 0; l < gc.nb; l++) gen_phase3(gc, sc, l, cnt[l], c.rod_r, c.rod_h, fl);
   gen_phase3b(c0, gc, st, sc);
-  for (int l = 0; l < gc.nb; l++) gen_phase4(gc, sc, l, warm_valid, fl);
+  for (int l = 0; l < gc.nb; l++) gen_phase4_single(gc, sc, l, warm_valid, fl);
+  gen_phase4_multi(gc, sc, 0, 1, warm_valid, fl);
   gen_phase5_arm(c0, gc, st, sc);
   for (int l = 0; l < gc.nb; l++) gen_phase5_cube(gc, sc, l, c.timestep);
   st.flags |= fl | PF_WARM_VALID;
