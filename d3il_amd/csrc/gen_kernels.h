@@ -110,6 +110,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
       __syncthreads();
+      PUSH_TIC;
       if (arm_lane) {
         const int b = s & 1;
         double qd[NARM], qdd[NARM], tau[NARM], ff[NFING];
@@ -118,17 +119,22 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
         push_control(c, st, qd, qdd, 0.04, false, tau, ff);
         gen_phase1(c, gc, st, sc, tau, ff);
       }
+      PUSH_TOC(0);
       int cnt = 0;
       if (plive) cnt = gen_phase2(gc, sc, l, grav, lfl);
       gen_sync();
+      PUSH_TOC(1);
       if (plive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl);
       gen_sync();
       if (arm_lane) gen_phase3b(c, gc, st, sc);
       gen_sync();
+      PUSH_TOC(2);
       if (plive) gen_phase4_single(gc, sc, l, warm_valid, lfl);
       gen_sync();
+      PUSH_TOC(8);
       if (plive) gen_phase4_multi(gc, sc, l, gc.nb, warm_valid, lfl);
       gen_sync();
+      PUSH_TOC(9);
       if (arm_lane) gen_phase5_arm(c, gc, st, sc);
       if (plive) gen_phase5_cube(gc, sc, l, c.timestep);
       gen_sync();

@@ -90,12 +90,6 @@ D3IL_HD void gen_sync() {     // orders the LDS / HBM traffic of the lanes of a 
 // cubes, then the arm), and its Newton system is stored compactly: block k of the list owns the compact dofs 6 k .. (the arm,
 // always last, 9 of them).  The gradient / direction vectors (voff) and the packed lower Hessian (hoff) of the islands of an
 // environment are laid out one after the other in the t area, so the lanes of a group can solve their islands side by side.
-#if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
-#define GEN_COUNT(slot, v) do { if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && blockIdx.x < 4096) \
-    atomicAdd(&d3il::g_dev_wave[blockIdx.x][slot], (unsigned long long)(v)); } while (0)
-#else
-#define GEN_COUNT(slot, v) ((void)0)
-#endif
 struct Isl { unsigned list; int n, m, hoff, voff; bool arm; };
 D3IL_HD Isl gen_island(unsigned mask, int nb) {
   Isl s{0u, 0, 0, 0, 0, false};
@@ -204,15 +198,15 @@ D3IL_HD bool gen_chol(const PushScratch sc, int hb, int m, int l, int nl) {
     double d00 = GLS(hb + tri(j0, j0)), d10 = GLS(hb + tri(j0 + 1, j0)), d11 = GLS(hb + tri(j0 + 1, j0 + 1));
     double d20 = GLS(hb + tri(j0 + 2, j0)), d21 = GLS(hb + tri(j0 + 2, j0 + 1)), d22 = GLS(hb + tri(j0 + 2, j0 + 2));
     if (!(d00 > 0)) { ok = false; d00 = 1; }
-    const double l00 = sqrt(d00), i00 = 1.0 / l00;
+    const double i00 = rsqrtd(d00), l00 = d00 * i00;
     const double l10 = d10 * i00, l20 = d20 * i00;
     double t11 = d11 - l10 * l10;
     if (!(t11 > 0)) { ok = false; t11 = 1; }
-    const double l11 = sqrt(t11), i11 = 1.0 / l11;
+    const double i11 = rsqrtd(t11), l11 = t11 * i11;
     const double l21 = (d21 - l20 * l10) * i11;
     double t22 = d22 - l20 * l20 - l21 * l21;
     if (!(t22 > 0)) { ok = false; t22 = 1; }
-    const double l22 = sqrt(t22), i22 = 1.0 / l22;
+    const double i22 = rsqrtd(t22), l22 = t22 * i22;
     gen_sync();        // every lane has read the diagonal block
     if (l == 0) {
       GLS(hb + tri(j0, j0)) = l00; GLS(hb + tri(j0 + 1, j0)) = l10; GLS(hb + tri(j0 + 1, j0 + 1)) = l11;
@@ -281,7 +275,7 @@ D3IL_HD void gen_chol_solve(const PushScratch sc, int hb, int m, int vec) {
     }
     const double l00 = GLS(hb + tri(i0, i0)), l10 = GLS(hb + tri(i0 + 1, i0)), l11 = GLS(hb + tri(i0 + 1, i0 + 1));
     const double l20 = GLS(hb + tri(i0 + 2, i0)), l21 = GLS(hb + tri(i0 + 2, i0 + 1)), l22 = GLS(hb + tri(i0 + 2, i0 + 2));
-    y0 = y0 / l00; y1 = (y1 - l10 * y0) / l11; y2 = (y2 - l20 * y0 - l21 * y1) / l22;
+    y0 = y0 * rcpd(l00); y1 = (y1 - l10 * y0) * rcpd(l11); y2 = (y2 - l20 * y0 - l21 * y1) * rcpd(l22);
     GLS(vec + i0) = y0; GLS(vec + i0 + 1) = y1; GLS(vec + i0 + 2) = y2;
   }
   for (int ib = nbk - 1; ib >= 0; ib--) {      // L' x = y
@@ -297,7 +291,7 @@ D3IL_HD void gen_chol_solve(const PushScratch sc, int hb, int m, int vec) {
     }
     const double l00 = GLS(hb + tri(i0, i0)), l10 = GLS(hb + tri(i0 + 1, i0)), l11 = GLS(hb + tri(i0 + 1, i0 + 1));
     const double l20 = GLS(hb + tri(i0 + 2, i0)), l21 = GLS(hb + tri(i0 + 2, i0 + 1)), l22 = GLS(hb + tri(i0 + 2, i0 + 2));
-    x2 = x2 / l22; x1 = (x1 - l21 * x2) / l11; x0 = (x0 - l10 * x1 - l20 * x2) / l00;
+    x2 = x2 * rcpd(l22); x1 = (x1 - l21 * x2) * rcpd(l11); x0 = (x0 - l10 * x1 - l20 * x2) * rcpd(l00);
     GLS(vec + i0) = x0; GLS(vec + i0 + 1) = x1; GLS(vec + i0 + 2) = x2;
   }
 }
@@ -359,11 +353,9 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
   PUSH_TOC(3);
   D3IL_STAT(g_stats.newton_calls++);
   D3IL_STAT(g_stats.eig_calls += isl.m);
-  GEN_COUNT(1, 1); GEN_COUNT(8, isl.m);
   for (int it = 0; it < 60 && !converged; it++) {
     D3IL_STAT(g_stats.newton_iters++);
     D3IL_STAT(g_stats.ik_calls += isl.m * isl.m * isl.m / 6);
-    GEN_COUNT(9, 1);
     // gradient (compact, at vg) and Hessian (compact, at hb) at x: smooth part entry by entry, then the limit rows (lane 0),
     // then the contacts (accumulated by all lanes)
     for (int i = l, nh = isl.m * (isl.m + 1) / 2; i < nh; i += nl) GLS(hb + i) = 0;
@@ -459,7 +451,6 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 50; ls++) {
       D3IL_STAT(g_stats.ls_iters++);
-      GEN_COUNT(2, 1);
       double p1 = 0, p2 = 0;      // this lane's share of the contact terms of phi'(alpha), phi''(alpha)
       for (int t = l; t < ntot; t += nl) {
         const int base = GG_CON + locate(t) * GREC;

@@ -1,4 +1,5 @@
-"""Stats build: where the Sorting step spends its time (ticks of the 100 MHz wall clock, per workgroup)."""
+"""Stats build: where the Sorting step spends its time (ticks of the 100 MHz wall clock, per workgroup): the phases of
+the physics wave (gen_kernels.h) and, inside the joint island solves, the solver passes (gen_step.h)."""
 import ctypes as C, os, sys, numpy as np, torch
 os.environ["D3IL_STATS_LIB"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,7 @@ des = env.robot_state()[:, :2].clone(); z = env.robot_state()[:, 2:3].clone()
 quat = torch.tensor([0.0, 1, 0, 0], dtype=torch.float64, device=env.device).expand(n, 4)
 NW = (n + 15) // 16
 W = np.zeros((NW, 10), dtype=np.uint64)
-names = ["-", "calls", "ls_evals", "s.setup", "s.grad+H", "s.chol", "s.jp", "s.linesearch", "sum_m", "newton_its"]
+names = ["p1.arm", "p2.statics", "p3.bb+rod", "s.setup", "s.grad+H", "s.chol", "s.jp", "s.linesearch", "p4.single", "p4.multi"]
 for t in range(60):
     box = env.obs[:, 2:4].to(torch.float64)
     if t >= 12:
@@ -29,6 +30,6 @@ for t in range(60):
     L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), NW, 1)
     if t in (20, 39, 55):
         Wf = W.astype(np.float64)
-        Wf[:, 3:8] /= 100.0                                       # ticks -> microseconds per env step; the other slots are counts (first active lane of the wave)
+        Wf /= 100.0                                       # ticks -> microseconds per env step; the other slots are counts (first active lane of the wave)
         for lab, v in (("median", np.median(Wf, axis=0)), ("p90", np.percentile(Wf, 90, axis=0)), ("max", Wf.max(axis=0))):
-            print("t %2d %6s per workgroup: " % (t, lab) + "  ".join("%s %.0f" % (names[i], v[i]) for i in range(1, 10)), flush=True)
+            print("t %2d %6s per workgroup: " % (t, lab) + "  ".join("%s %.0f" % (names[i], v[i]) for i in range(0, 10)), flush=True)
