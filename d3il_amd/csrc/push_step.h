@@ -151,7 +151,11 @@ D3IL_HD int box_box(const double* p1, const double* R1, const double* s1, const 
   for (int j = 0; j < 3; j++) {
     double sep = fabs(dB[j]) - (s2[j] + s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j]);
     if (sep > margin) return 0;
-    if (sep > best + 1e-10) { best = sep; code = 3 + j; nsign = dB[j] < 0 ? -1 : 1; }
+    // a face axis of box 2 must beat box 1's by more than 1e-10 - unless the two tie within that band and box 2 offers the larger
+    // face: a small box lying flat on a big one is then clipped against the big face (reference) whichever geom comes first
+    bool wins = sep > best + 1e-10;
+    if (!wins && code >= 0 && code < 3 && sep >= best - 1e-10 && s2[(j + 1) % 3] * s2[(j + 2) % 3] > s1[(code + 1) % 3] * s1[(code + 2) % 3]) wins = true;
+    if (wins) { best = sep; code = 3 + j; nsign = dB[j] < 0 ? -1 : 1; }
   }
   double en[3] = {0, 0, 0};
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
@@ -194,12 +198,33 @@ D3IL_HD int box_box(const double* p1, const double* R1, const double* s1, const 
   for (int k = 0; k < 3; k++) { double t = fabs(dot3(n, Ai[k])); if (t > bestdot) { bestdot = t; kin = k; } }
   double sgi = dot3(n, Ai[kin]) > 0 ? -1 : 1;
   int k1 = (kin + 1) % 3, k2 = (kin + 2) % 3, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
-  double poly[16][3], tmp[16][3]; int np = 4;
+  double p4[4][3];
+  bool inside = true;      // the incident face lies within the side planes of the reference face: nothing to clip
+#pragma unroll
   for (int v = 0; v < 4; v++) {
     double c0 = (v == 0 || v == 3) ? 1.0 : -1.0, c1 = v < 2 ? 1.0 : -1.0, x[3];
     for (int k = 0; k < 3; k++) x[k] = pi[k] + sgi * si[kin] * Ai[kin][k] + c0 * si[k1] * Ai[k1][k] + c1 * si[k2] * Ai[k2][k] - pr[k];
-    poly[v][0] = dot3(x, Ar[a1]); poly[v][1] = dot3(x, Ar[a2]); poly[v][2] = dot3(x, n) - sr[ax];
+    p4[v][0] = dot3(x, Ar[a1]); p4[v][1] = dot3(x, Ar[a2]); p4[v][2] = dot3(x, n) - sr[ax];
+    inside = inside && p4[v][0] - sr[a1] <= 0 && -p4[v][0] - sr[a1] <= 0 && p4[v][1] - sr[a2] <= 0 && -p4[v][1] - sr[a2] <= 0;
   }
+  if (inside) {
+    // the clipping below would return the four vertices unchanged and in order; they are distinct, so no duplicate test either
+    int cnt = 0;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const double w = p4[v][2];
+      if (w >= margin || cnt >= cap) continue;
+      out[cnt][0] = w;
+      for (int k = 0; k < 3; k++) {
+        out[cnt][1 + k] = pr[k] + p4[v][0] * Ar[a1][k] + p4[v][1] * Ar[a2][k] + (sr[ax] + 0.5 * w) * n[k];
+        out[cnt][4 + k] = ref2 ? -n[k] : n[k];
+      }
+      cnt++;
+    }
+    return cnt;
+  }
+  double poly[16][3], tmp[16][3]; int np = 4;
+  for (int v = 0; v < 4; v++) for (int k = 0; k < 3; k++) poly[v][k] = p4[v][k];
   for (int side = 0; side < 4; side++) {
     int cdim = side >> 1; double sg = (side & 1) ? -1 : 1, lim = sr[cdim ? a2 : a1];
     int nn = 0;
