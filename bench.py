@@ -167,7 +167,13 @@ def bench_pushing(args):
             begin_episode()
         obs10 = torch.cat((state["des"], env.obs.to(torch.float64)), dim=1)
         state["des"] = state["des"] + pol.predict_batch(obs10).to(torch.float64)
-        env.step(torch.cat((state["des"], state["z"], quat), dim=1).contiguous())
+        act = torch.cat((state["des"], state["z"], quat), dim=1).contiguous()
+        if state.get("ev") is not None:      # events on the stream the kernel is launched on (torch's current stream), one pair per step
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); env.step(act); e1.record()
+            state["ev"].append((e0, e1))
+        else:
+            env.step(act)
 
     def barrier():
         if world > 1:
@@ -177,16 +183,18 @@ def bench_pushing(args):
     for t in range(args.warmup):
         one_step(t)
     env.set_timing(True)
-    kernel_ms = []
+    kernel_ms_lib = []
+    state["ev"] = []
     barrier()
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(args.warmup + t)
-        if t % 16 == 15:
-            kernel_ms.append(env.last_step_ms())
+        if t % 16 == 15:      # cross-check: the library's own HIP event pair around the launch, read every 16th step
+            kernel_ms_lib.append(env.last_step_ms())
     barrier()
     dt = time.perf_counter() - t0
     env.set_timing(False)
+    kernel_ms = [a.elapsed_time(b) for a, b in state["ev"]]      # every launch of the timed region
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
@@ -219,6 +227,7 @@ def bench_pushing(args):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_sorting_step<true>" if sorting else "k_pushing_step_split<true>", "kernel_ms": k_ms,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
+                         "kernel_ms_library_events_every_16th": float(np.mean(kernel_ms_lib)) if kernel_ms_lib else None,
                          "algorithmic_bytes_per_launch": alg_bytes * n,
                          "note": ("FP64 instruction-issue bound (DESIGN.md section 13): one wave per SIMD, solver loops over LDS-resident systems; HBM traffic beyond the "
                                   "state column is the contact records of the constraint solver") if sorting else
@@ -277,9 +286,16 @@ def main():
     counts = torch.zeros(514, dtype=torch.int64, device=dev)
     episodes = torch.zeros(2, dtype=torch.int64, device=dev)   # finished, successful
 
+    evs = None
+
     def one_step(t):
         env.policy_action(42, env_offset, t, actions)
-        env.step(actions)
+        if evs is not None:      # events on the stream the kernel is launched on (torch's current stream), one pair per step
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); env.step(actions); e1.record()
+            evs.append((e0, e1))
+        else:
+            env.step(actions)
         if not args.no_auto_reset:
             env.auto_reset(episodes)
 
@@ -293,20 +309,22 @@ def main():
         one_step(t)
     episodes.zero_()
     env.set_timing(True)
-    kernel_ms = []
+    kernel_ms_lib = []
+    evs = []
     barrier()
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(args.warmup + t)
-        # HIP events are recorded by the library around the step kernel on the launch stream; reading the
+        # cross-check: HIP events recorded by the library around the step kernel on the launch stream; reading the
         # previous pair costs one event sync on an already finished kernel every 16 steps
         if t % 16 == 15:
-            kernel_ms.append(env.last_step_ms())
+            kernel_ms_lib.append(env.last_step_ms())
     env.count_metrics(counts)
     D.reduce_counts(counts)
     barrier()
     dt = time.perf_counter() - t0
     env.set_timing(False)
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]      # every launch of the timed region
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
@@ -343,6 +361,7 @@ def main():
                        "episodes_finished_rank0": int(episodes[0].item()), "episodes_success_rank0": int(episodes[1].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_avoiding_step_split<true>", "kernel_ms": k_ms,
+                         "kernel_ms_library_events_every_16th": float(np.mean(kernel_ms_lib)) if kernel_ms_lib else None,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n,
                          "note": "path is FP64-VALU issue/latency bound, not HBM bound: 756 B of HBM per env step with all 35 "
