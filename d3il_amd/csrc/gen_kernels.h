@@ -4,7 +4,7 @@
 // environment) and the physics wave, in which every environment has a group of four lanes - lane l of the group owns cube l,
 // lane 0 also the arm (gen_step.h).  Lane = 16 l + column, so the 16 lanes that do the same job sit next to each other:
 // coalesced HBM rows, conflict-free LDS columns.  The physics wave keeps each environment's vectors, matrices and the dense
-// Newton Hessian in LDS (944 doubles per environment, 125 KiB per workgroup), the contact records in the HBM scratch area
+// Newton Hessian in LDS (960 doubles per environment, 127.5 KiB per workgroup), the contact records in the HBM scratch area
 // and the cubes in the state buffer itself.  4096 environments are 256 workgroups: one per CU.
 #pragma once
 #include "gen_step.h"

@@ -8,12 +8,13 @@
 //                      model's geom order)
 //   phase 3  lane l    cube l against the cubes after it and against the rod; lane 0 then adds the arm Jacobian rows of
 //                      the rod contacts
-//   phase 4  lane l    the constraint system is split into islands (connected components of cubes and arm under cube-cube
-//                      and rod contacts); the lane of an island's first cube solves it: primal Newton with safeguarded exact
-//                      line search, elliptic cones (condim 3), contact parameters mixed per pair (priority: the platform's
-//                      own solref / solimp / friction), dense Cholesky over the island's dofs.  A cube resting on the
-//                      platform or the table is a 6-dof island with 4 .. 8 contacts; the arm joins an island only through a
-//                      rod contact
+//   phase 4            the constraint system is split into islands (connected components of cubes and arm under cube-cube
+//                      and rod contacts); primal Newton with safeguarded exact line search, elliptic cones (condim 3), contact
+//                      parameters mixed per pair (priority: the platform's own solref / solimp / friction):
+//            lane l    a cube on its own - resting on the platform or the table: 6 dofs, 4 .. 8 contacts - is solved by its
+//                      lane in registers (gen_solve_cube);
+//            all lanes a larger island (the arm joins one only through a rod contact) is solved by the lanes of the group
+//                      together (gen_solve): contacts dealt out per lane, compact dense system in LDS, blocked Cholesky
 //   phase 5  lane l    semi-implicit Euler: arm with implicit finger damping (lane 0), cube l with quaternion integration
 // The group's lanes are lanes of one wavefront on the device (wave-level fences between the phases, gen_kernels.h); the host
 // build runs the lanes one after the other.  Per-environment working set: vectors, rotation matrices, arm mass matrix,
