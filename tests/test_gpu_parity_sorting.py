@@ -200,3 +200,45 @@ def test_one_step_parity_from_mid_episode_states(sort_blob, sort_init_qpos):
                 assert int(env.mode[e]) == io["mode"] and bool(env.success[e]) == io["success"]
         assert not (env.flags[:n].cpu().numpy() & ((1 << 16) | (1 << 18))).any()
     env.close()
+
+
+def test_batch_size_and_lane_position_do_not_change_results(sort_init_qpos):
+    """The same contexts in batches of 1, 17 (ragged last workgroup) and 80 environments evolve bit-identically, wherever they
+    sit in a wave; a 8192-environment batch stays finite and unflagged."""
+    from d3il_amd.envs.sorting import sample_contexts
+    ctx = sample_contexts(80, NB, seed=21)
+    finals = {}
+    for n in (1, 17, 80):
+        env = _env(n)
+        env.set_init_qpos(sort_init_qpos)
+        env.reset(context=ctx[:n])
+        z = env.robot_state()[:, 2:3].clone()
+        des = env.obs[:, :2].to(torch.float64).clone()
+        for t in range(60):
+            box = env.obs[:, 2:4].to(torch.float64)
+            if t >= 12:
+                aligned = ((des[:, 0] - box[:, 0]).abs() < 0.008) & (des[:, 1] < box[:, 1] - 0.02)
+                target = torch.where(aligned[:, None], torch.stack([box[:, 0], torch.full_like(box[:, 0], 0.36)], 1), box + torch.tensor([0.0, -0.06], dtype=torch.float64, device=box.device))
+                d = target - des
+                nn = d.norm(dim=1, keepdim=True)
+                des = des + d / nn.clamp_min(1e-9) * torch.minimum(nn, torch.full_like(nn, 0.006))
+            env.step(_action(des, z))
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        finals[n] = st
+        assert not (fl & BAD).any()
+        env.close()
+    assert np.array_equal(finals[1][:, 0], finals[80][:, 0]) and np.array_equal(finals[17], finals[80][:, :17])
+    big = _env(8192)
+    big.set_init_qpos(sort_init_qpos)
+    big.reset(context=np.tile(ctx, (103, 1))[:8192])
+    z = big.robot_state()[:, 2:3].clone()
+    des = big.obs[:, :2].to(torch.float64).clone()
+    for t in range(20):
+        big.step(_action(des, z))
+    torch.cuda.synchronize()
+    st, fl, sc = big.get_state()
+    assert np.isfinite(st).all() and not (fl & BAD).any() and (sc == 20).all()
+    # tiles of the 80 contexts are bit-identical across the batch
+    assert np.array_equal(st[:, :80], st[:, 80:160]) and np.array_equal(st[:, :80], st[:, 8000:8080])
+    big.close()
