@@ -482,7 +482,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
         }
       best = alpha;
       if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
-      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (fabs(d1) <= D3IL_LS_C2 * fabs(gTp) || fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
@@ -635,7 +635,7 @@ D3IL_NOINLINE inline bool gen_solve_cube(const GenConsts& gc_, const PushScratch
       }
       best = alpha;
       if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
-      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (fabs(d1) <= D3IL_LS_C2 * fabs(gTp) || fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {

@@ -939,6 +939,9 @@ D3IL_NOINLINE inline bool solve_constraints(const double* __restrict__ M_in, con
   return ok;
 }
 
+#ifndef D3IL_LS_C2
+#define D3IL_LS_C2 0.5     // curvature condition of the contact line search: |phi'(alpha)| <= c2 |phi'(0)|
+#endif
 // mju_makeFrame: tangents for a given normal [ext]
 D3IL_HD void make_frame(const double* n, double* t1, double* t2) {
   double y[3] = {0, 0, 0};
@@ -1182,7 +1185,7 @@ D3IL_RARE bool solve_contact5(const double* __restrict__ L_in, const double* __r
       // iteration keeps its quadratic rate; far from it a 1e-3 reduction of the directional derivative is plenty
       // the full Newton step is taken when phi is still descending there or just past its minimum (curvature condition)
       if (ls == 0 && d1 <= 0.1 * fabs(gp0)) break;
-      if (fabs(d1) <= 1e-3 * fabs(gp0)) break;
+      if (fabs(d1) <= D3IL_LS_C2 * fabs(gp0)) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)

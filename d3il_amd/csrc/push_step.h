@@ -556,7 +556,7 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc_, const double* R, co
       best = alpha;
       // full Newton step: accepted on the curvature condition phi'(1) <= 0.1 |phi'(0)| (still descending, or just past the minimum)
       if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
-      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
+      if (fabs(d1) <= D3IL_LS_C2 * fabs(gTp) || fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
@@ -1404,7 +1404,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc_, const PushScratc
       best = alpha;
       // full Newton step: accepted on the curvature condition phi'(1) <= 0.1 |phi'(0)| (still descending, or just past the minimum)
       if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
-      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
+      if (fabs(d1) <= D3IL_LS_C2 * fabs(gTp) || fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
