@@ -149,6 +149,16 @@ D3IL_HD double rsqrtd(double x) {   // 1 / sqrt(x), x > 0: v_rsq_f64 + two Newto
 #endif
 }
 D3IL_HD int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // packed lower-triangular index, r >= c
+// sin / cos of an angle that moved by a small dl (|dl| <= 0.01): angle addition with a Taylor series of the increment
+// (truncation < 1e-25 relative); used to carry the joints' sin / cos from sub-step to sub-step instead of re-evaluating them
+D3IL_HD void trig_advance(double dl, double& sn, double& cs) {
+  const double d2 = dl * dl;
+  const double sd = dl * (1.0 - d2 * (1.0 / 6.0) * (1.0 - d2 * (1.0 / 20.0) * (1.0 - d2 * (1.0 / 42.0))));
+  const double cd = 1.0 - d2 * 0.5 * (1.0 - d2 * (1.0 / 12.0) * (1.0 - d2 * (1.0 / 30.0) * (1.0 - d2 * (1.0 / 56.0))));
+  const double s2 = sn * cd + cs * sd, c2 = cs * cd - sn * sd;
+  sn = s2; cs = c2;
+}
+
 
 // ------------------------------------------------------------------ controller kinematics (URDF chain, core/Model.py:37-66)
 // pos/R of the grasp-target frame, world joint axes and origins
@@ -372,13 +382,15 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
 // One call of CartPosQuatImpedenceController.getControl up to (and including) the set-point handed to the
 // joint PD law: advances the virtual joint target ikq by ik_iters damped-least-squares iterations.
 template <bool FAST, class C>
+// trig (optional, 15 doubles): sin[7] cos[7] of ikq carried between calls, [14] != 0 when valid
 D3IL_HD void ik_update(const C& c0, const double* des_pos, const double* des_quat_in, const double* cur_q,
-                       unsigned& flags, double* ikq, double* ikqd, double* vwarm = nullptr) {
+                       unsigned& flags, double* ikq, double* ikqd, double* vwarm = nullptr, double* trig = nullptr) {
   double q[NARM], old_q[NARM];
   if (!(flags & F_IK_VALID)) {
 #pragma unroll
     for (int k = 0; k < NARM; k++) ikq[k] = cur_q[k];
     flags |= F_IK_VALID;
+    if (trig) trig[2 * NARM] = 0.0;
   }
 #pragma unroll
   for (int k = 0; k < NARM; k++) { old_q[k] = ikq[k]; q[k] = ikq[k]; }
@@ -386,9 +398,15 @@ D3IL_HD void ik_update(const C& c0, const double* des_pos, const double* des_qua
   // sin/cos of the virtual joint angles: exact once per call, then advanced by the angle-addition formulas with a
   // short Taylor series of the (tiny) increment: |dq| <= ik_lr * 3 (norm clip) - truncation error < 1e-25 relative.
   double sq[NARM], cq[NARM];
-#pragma unroll
-  for (int k = 0; k < NARM; k++) sincos(q[k], &sq[k], &cq[k]);
   const bool small_step = c0.ik_lr * 3.0 <= 0.01;
+  const bool carry = trig != nullptr && small_step;
+  if (carry && trig[2 * NARM] != 0.0) {
+#pragma unroll
+    for (int k = 0; k < NARM; k++) { sq[k] = trig[k]; cq[k] = trig[NARM + k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NARM; k++) sincos(q[k], &sq[k], &cq[k]);
+  }
   const int n_it = c0.ik_iters;
 #pragma clang loop unroll(disable)
   for (int it = 0; it < n_it; it++) {
@@ -445,17 +463,17 @@ D3IL_HD void ik_update(const C& c0, const double* des_pos, const double* des_qua
 #pragma unroll
     for (int k = 0; k < NARM; k++) {
       double qn2 = clampd(q[k] + c.ik_lr * qd[k], c.q_min[k], c.q_max[k]);
-      if (it + 1 < n_it) {
-        if (small_step) {
-          double dl = qn2 - q[k], d2 = dl * dl;
-          double sd = dl * (1.0 - d2 * (1.0 / 6.0) * (1.0 - d2 * (1.0 / 20.0) * (1.0 - d2 * (1.0 / 42.0))));
-          double cd = 1.0 - d2 * 0.5 * (1.0 - d2 * (1.0 / 12.0) * (1.0 - d2 * (1.0 / 30.0) * (1.0 - d2 * (1.0 / 56.0))));
-          double s2 = sq[k] * cd + cq[k] * sd, c2 = cq[k] * cd - sq[k] * sd;
-          sq[k] = s2; cq[k] = c2;
-        } else sincos(qn2, &sq[k], &cq[k]);
+      if (it + 1 < n_it || carry) {
+        if (small_step) trig_advance(qn2 - q[k], sq[k], cq[k]);
+        else sincos(qn2, &sq[k], &cq[k]);
       }
       q[k] = qn2;
     }
+  }
+  if (carry) {
+#pragma unroll
+    for (int k = 0; k < NARM; k++) { trig[k] = sq[k]; trig[NARM + k] = cq[k]; }
+    trig[2 * NARM] = 1.0;
   }
 #pragma unroll
   for (int k = 0; k < NARM; k++) { ikqd[k] = (q[k] - old_q[k]) / c0.timestep; ikq[k] = q[k]; }
@@ -492,10 +510,14 @@ template <class C> D3IL_HD void world_chain(const C& c0, const double* sn, const
   p7[0] = p[0]; p7[1] = p[1]; p7[2] = p[2];
 }
 
-template <class C> D3IL_HD void dynamics(const C& c0, const double* q, const double* v, DynOut& o) {
+// trig (optional): sin[7] cos[7] of the arm joints carried by the caller (physics_substep keeps them current)
+template <class C> D3IL_HD void dynamics(const C& c0, const double* q, const double* v, DynOut& o, const double* trig = nullptr) {
   double sn[NARM], cs[NARM];
 #pragma unroll
-  for (int i = 0; i < NARM; i++) { sincos(q[i], &sn[i], &cs[i]); o.sn[i] = sn[i]; o.cs[i] = cs[i]; }
+  for (int i = 0; i < NARM; i++) {
+    if (trig) { sn[i] = trig[i]; cs[i] = trig[NARM + i]; } else sincos(q[i], &sn[i], &cs[i]);
+    o.sn[i] = sn[i]; o.cs[i] = cs[i];
+  }
   world_chain(c0, sn, cs, o.R7, o.p7, nullptr, nullptr);
 
   // ---- RNEA forward pass (velocities, accelerations with qacc = 0, base acceleration = -gravity)
@@ -1250,10 +1272,10 @@ D3IL_RARE void make_rod_contact(const C& c, const double* sn, const double* cs, 
 // active sets - no iteration.  The same factors, with the last two pivots updated for the implicit damping term h B,
 // give the integration solve: one 9x9 factorisation per sub-step.  Arm limit rows or a rod contact (rare) take the
 // general out-of-line Newton path.
-template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const double* tau, const double* ffing, double* warm) {
+template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const double* tau, const double* ffing, double* warm, double* trig = nullptr) {
   D3IL_DSTAT(7);
   DynOut dyn;
-  dynamics(c0, st.q, st.v, dyn);
+  dynamics(c0, st.q, st.v, dyn, trig);
   D3IL_REFRESH(c0, c);
   // actuation: ctrl = tau + (stale) qfrc_bias for the arm, raw for fingers; motors clamp to forcerange
   double fs[NDOF];
@@ -1399,11 +1421,14 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
   ldl9_solve(L, id, qacc);
 #pragma unroll
   for (int k = 0; k < NDOF; k++) { st.v[k] += ce.timestep * qacc[k]; st.q[k] += ce.timestep * st.v[k]; }
+  if (trig)      // |dq| = h |v| <= 1e-3 x a few rad/s
+#pragma unroll
+    for (int k = 0; k < NARM; k++) trig_advance(ce.timestep * st.v[k], trig[k], trig[NARM + k]);
 }
 
 // joint PD on the IK set-point + finger PD + one physics sub-step (the part of Scene.next_step after the IK update)
 template <class C>
-D3IL_HD void control_and_physics(const C& c, EnvState& st, const double* q_des, const double* qd_des, double set_width, bool grasp, double* warm) {
+D3IL_HD void control_and_physics(const C& c, EnvState& st, const double* q_des, const double* qd_des, double set_width, bool grasp, double* warm, double* trig = nullptr) {
   double tau[NARM], ff[NFING];
 #pragma unroll
   for (int k = 0; k < NARM; k++) tau[k] = c.pd_p[k] * (q_des[k] - st.q[k]) + c.pd_d[k] * (qd_des[k] - st.v[k]);
@@ -1417,7 +1442,7 @@ D3IL_HD void control_and_physics(const C& c, EnvState& st, const double* q_des, 
     else f2 = clampd(500 * (set_width - w) - 10 * wv, -5, 5);
     ff[k] = f1 + f2;
   }
-  physics_substep(c, st, tau, ff, warm);
+  physics_substep(c, st, tau, ff, warm, trig);
 }
 
 // controllers feeding one physics sub-step (Scene.next_step, core/Scene.py:121-138)

@@ -132,11 +132,11 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
     for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
     unsigned fl = flags[e];
     make_setpoint(act, des);
-    double vwarm[7];
-    vwarm[6] = 0.0;
+    double vwarm[7], trig[2 * NARM + 1];       // sin / cos of ikq carried across the sub-steps (exact once per step)
+    vwarm[6] = 0.0; trig[2 * NARM] = 0.0;
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
-      ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd, vwarm);
+      ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd, vwarm, trig);
       const int b = s & 1;
 #pragma unroll
       for (int k = 0; k < NARM; k++) { xch[b][k][lane] = ikq[k]; xch[b][NARM + k][lane] = ikqd[k]; }
@@ -161,8 +161,10 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
     load_state(state, flags, steps, stride, e, st);
     float o[2]; unsigned char dn;
     step_begin(c, st, o, &dn, max_steps);
-    double warm[6];
+    double warm[6], trig[2 * NARM];            // sin / cos of the arm joints carried across the sub-steps (exact once per step)
     warm[5] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NARM; k++) sincos(st.q[k], &trig[k], &trig[NARM + k]);
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
 #if defined(D3IL_DEVICE_STATS)
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
       double qd[NARM], qdd[NARM];
 #pragma unroll
       for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][lane]; qdd[k] = xch[b][NARM + k][lane]; }
-      control_and_physics(c, st, qd, qdd, 0.04, false, warm);
+      control_and_physics(c, st, qd, qdd, 0.04, false, warm, trig);
     }
 #if defined(D3IL_DEVICE_STATS)
     if (lane == 0 && blockIdx.x < 4096) { g_dev_wave[blockIdx.x][9] = wall_clock64() - t0 - tw; }
