@@ -1,5 +1,5 @@
 """Batched counterpart of ``Sorting_Env`` (environments/d3il/envs/gym_sorting_env/gym_sorting/envs/sorting.py:244-575,
-num_boxes = 4) over libd3il_rollout.
+num_boxes = 2 or 4) over libd3il_rollout.
 
 Protocol of the reference env - ``start()``, ``reset(random=False, context=...)``, ``step(action)`` returning
 ``(obs, reward, done, info)`` with ``info = {'mode', 'success'}``, ``robot_state()`` - for ``n_envs`` environments at once,
@@ -61,17 +61,20 @@ class SortingVecEnv(ObstacleAvoidanceVecEnv):
     default_max_steps = 500          # sorting_sim.py:33
 
     def __init__(self, n_envs, device=0, render=False, n_substeps: int = 35, max_steps_per_episode: int | None = None, num_boxes: int = 4):
-        if num_boxes != 4:
-            raise NotImplementedError("this build carries the Sorting-4 scene (4_test_contexts / 4_mode_prob of sorting_sim.py:44-47)")
+        if num_boxes not in (2, 4):
+            raise NotImplementedError("this build carries the Sorting-2 and Sorting-4 scenes (the engine has one lane per cube, at most four)")
+        self.num_boxes = int(num_boxes)
+        self.obs_dim = 2 + 3 * self.num_boxes
+        self.task = "sorting" if num_boxes == 4 else "sorting_%d" % num_boxes          # scene blob (d3il_amd/model/blobs)
         super().__init__(n_envs, device=device, render=render, n_substeps=n_substeps, max_steps_per_episode=max_steps_per_episode)
         self._contexts = None
         self.reward = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)   # get_reward is the constant 0 (sorting.py:509-511)
         self.box_row = 42
-        self.warm_row = 42 + 13 * num_boxes
-        self.task_row = self.warm_row + 6 * num_boxes + 9
+        self.warm_row = 42 + 13 * self.num_boxes
+        self.task_row = self.warm_row + 6 * self.num_boxes + 9
 
     def reset(self, mask: torch.Tensor | None = None, random: bool = False, context=None):
-        """env.reset(random=False, context=...): ``context`` is f64[n_envs, 28] (numpy or tensor; see module docstring).
+        """env.reset(random=False, context=...): ``context`` is f64[n_envs, 7 * num_boxes] (numpy or tensor; see module docstring).
         With ``random=True`` contexts are sampled like BlockContextManager.sample.  A mask resets a subset."""
         if context is None:
             if not random and self._contexts is None:

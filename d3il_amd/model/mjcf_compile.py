@@ -517,6 +517,10 @@ def main():
     with open(os.path.join(out_dir, "sorting.json"), "w") as f:
         json.dump(blob, f, indent=1)
     print("sorting-4: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
+    blob = build_sorting(2)
+    with open(os.path.join(out_dir, "sorting_2.json"), "w") as f:
+        json.dump(blob, f, indent=1)
+    print("sorting-2: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
 
 
 if __name__ == "__main__":

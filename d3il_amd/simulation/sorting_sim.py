@@ -1,4 +1,4 @@
-"""Batched counterpart of ``Sorting_Sim`` (simulation/sorting_sim.py:24-213), num_box = 4.
+"""Batched counterpart of ``Sorting_Sim`` (simulation/sorting_sim.py:24-213), num_box = 2 or 4.
 
 The reference evaluates ``n_contexts`` test contexts x ``n_trajectories_per_context`` rollouts sequentially in ``n_cores``
 processes; here every rollout is one group of lanes of the GPU environment batch (context-major order, rollout
@@ -50,8 +50,8 @@ class Sorting_Sim(BaseSim):
                  num_box: int = 4, if_vision: bool = False, max_steps_per_episode: int = 500, contexts: np.ndarray | None = None,
                  mode_prob: dict | None = None):
         super().__init__(seed, device, render, n_cores, if_vision)
-        if num_box != 4:
-            raise NotImplementedError("this build carries the Sorting-4 scene")
+        if num_box not in (2, 4):
+            raise NotImplementedError("this build carries the Sorting-2 and Sorting-4 scenes")
         self.n_contexts, self.n_trajectories_per_context = n_contexts, n_trajectories_per_context
         self.max_steps_per_episode, self.num_box = max_steps_per_episode, num_box
         self.test_contexts = sample_contexts(max(n_contexts, 60), num_box, seed=seed) if contexts is None else np.asarray(contexts, dtype=np.float64)

@@ -242,3 +242,49 @@ def test_batch_size_and_lane_position_do_not_change_results(sort_init_qpos):
     # tiles of the 80 contexts are bit-identical across the batch
     assert np.array_equal(st[:, :80], st[:, 80:160]) and np.array_equal(st[:, :80], st[:, 8000:8080])
     big.close()
+
+
+def test_sorting_2_reset_landing_and_push_match_oracle(sort_init_qpos):
+    """The two-box scene through the same kernels (two live lanes per group): oracle parity through reset, landing, approach and
+    the first pushes; protocol shapes of the num_boxes = 2 env."""
+    from oracle.oracle import Oracle
+    from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
+    from d3il_amd.model import blob
+    n = 24
+    ctx = sample_contexts(n, 2, seed=8)
+    env = SortingVecEnv(n, device=0, num_boxes=2)
+    assert env.obs.shape == (n, 8) and env.state_rows == 42 + 26 + 21 + 2
+    env.set_init_qpos(sort_init_qpos)
+    env.reset(context=ctx)
+    assert (env.mode.cpu().numpy() == 0b11000000).all()
+    m2 = blob.load("sorting_2")
+    check = [0, 7, 16, 23]
+    oracles = {}
+    for e in check:
+        o = Oracle(m2); o.env_start(sort_init_qpos); o.sort_reset(ctx[e].reshape(2, 7)); oracles[e] = o
+    z = env.robot_state()[:, 2:3].clone()
+    des = env.obs[:, :2].to(torch.float64).clone()
+    for t in range(45):
+        box = env.obs[:, 2:4].to(torch.float64)
+        if t >= 12:
+            aligned = ((des[:, 0] - box[:, 0]).abs() < 0.008) & (des[:, 1] < box[:, 1] - 0.02)
+            target = torch.where(aligned[:, None], torch.stack([box[:, 0], torch.full_like(box[:, 0], 0.36)], 1), box + torch.tensor([0.0, -0.06], dtype=torch.float64, device=box.device))
+            d = target - des
+            nn = d.norm(dim=1, keepdim=True)
+            des = des + d / nn.clamp_min(1e-9) * torch.minimum(nn, torch.full_like(nn, 0.006))
+        a = _action(des, z)
+        obs, rew, done, info = env.step(a)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        assert not (fl & BAD).any()
+        an = a.cpu().numpy()
+        for e in check:
+            oo, do, io = oracles[e].sort_step(an[e])
+            qp, qv = oracles[e].state()
+            cubes = np.concatenate([np.concatenate([qp[7 * b:7 * b + 7], qv[6 * b:6 * b + 6]]) for b in range(2)])
+            d = st[42:68, e] - cubes
+            pos = np.array([k % 13 < 7 for k in range(26)])
+            assert np.abs(d[pos]).max() < 1e-6 and np.abs(st[:9, e] - qp[14:23]).max() < 1e-6, (t, e)
+            np.testing.assert_allclose(obs[e].cpu().numpy(), oo, rtol=1e-4, atol=1e-5)
+            assert bool(done[e]) == do and int(info["mode"][e]) == io["mode"]
+    env.close()

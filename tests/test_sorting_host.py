@@ -75,3 +75,32 @@ def test_scripted_push_into_the_bin(sort_blob, sort_init_qpos):
         if code != 240:
             break
     assert code == 0b01110000 and ih["success"] is False
+
+
+def test_sorting_2_scene_tracks_the_oracle(sort_init_qpos):
+    """The two-box variant of the scene (sorting.py:121-138) on the same engine: reset, landing and the first pushes."""
+    from d3il_amd.model import blob
+    m2 = blob.load("sorting_2")
+    assert m2.n_obj == 2
+    o = Oracle(m2)
+    o.env_start(sort_init_qpos)
+    h = GenHostCheck(m2)
+    assert (h.nb, h.ns, h.n) == (2, 11, 42 + 26 + 21 + 2)
+    ctx = CTX[[0, 2]]
+    obs_o, obs_h = o.sort_reset(ctx), h.reset(sort_init_qpos, ctx)
+    assert obs_h.shape == (8,) and np.array_equal(obs_o, obs_h)
+    z = float(o.body(m2.tcp_body)[0][2])
+    des = obs_o[:2].astype(float)
+    for t in range(60):
+        box = obs_o[2:4].astype(float)
+        if t >= 12:
+            aligned = abs(des[0] - box[0]) < 0.008 and des[1] < box[1] - 0.02
+            target = np.array([box[0], 0.36]) if aligned else box + np.array([0.0, -0.06])
+            d = target - des
+            n = np.linalg.norm(d)
+            des = des + d / max(n, 1e-9) * min(0.006, n)
+        a = np.concatenate([des, [z], [0, 1, 0, 0]])
+        obs_o, do, io = o.sort_step(a)
+        oh, dh, ih = h.step(a)
+        assert _state_err(h, o) < 1e-7 and np.abs(obs_o - oh).max() < 1e-6 and do == dh
+        assert io["mode"] == ih["mode"] == 0b11000000 and not (ih["flags"] & 0x1F0000)      # two unset entries
