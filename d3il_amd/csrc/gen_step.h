@@ -533,25 +533,6 @@ D3IL_NOINLINE inline bool gen_solve_cube(const GenConsts& gc_, const PushScratch
       for (int k = 0; k < 6; k++) J[rr][k] *= sign;
     }
   };
-#pragma clang loop unroll(disable)
-  for (int q = 0; q < cnt; q++) {   // reference acceleration and regularisation
-    const int base = seg + q * GREC;
-    double rc[15];
-#pragma unroll
-    for (int k = 0; k < 15; k++) rc[k] = PGS(base + k);
-    const int set = (int)rc[14];
-    double J[3][6];
-    rows_of(rc, gc.st_first[set] ? 1.0 : -1.0, J);
-    double v[3];
-#pragma unroll
-    for (int rr = 0; rr < 3; rr++) { v[rr] = 0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) v[rr] += J[rr][k] * vel[k]; }
-    const double dist = rc[12], imp = impedance(gc.ct_solimp[set], dist);
-    PGS(base + 16) = -gc.ct_B[set] * v[0] - gc.ct_K[set] * imp * dist;
-    PGS(base + 17) = -gc.ct_B[set] * v[1]; PGS(base + 18) = -gc.ct_B[set] * v[2];
-    PGS(base + 19) = 1 / fmax(1e-15, (1 - imp) / imp * gc.box_invw_t);
-  }
   const double mu_scale = sqrt(1 / fmax(1e-15, impr));
   bool converged = false;
   D3IL_STAT(g_stats.newton_calls++);
@@ -572,6 +553,18 @@ D3IL_NOINLINE inline bool gen_solve_cube(const GenConsts& gc_, const PushScratch
       const int set = (int)rc[14];
       double J[3][6], jar[3], force[3], Hc[9];
       rows_of(rc, gc.st_first[set] ? 1.0 : -1.0, J);
+      if (it == 0) {   // reference acceleration and regularisation of the contact, with the rows that are needed anyway
+        double v[3];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) { v[rr] = 0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) v[rr] += J[rr][k] * vel[k]; }
+        const double dist = rc[12], imp = impedance(gc.ct_solimp[set], dist);
+        rc[16] = -gc.ct_B[set] * v[0] - gc.ct_K[set] * imp * dist;
+        rc[17] = -gc.ct_B[set] * v[1]; rc[18] = -gc.ct_B[set] * v[2];
+        rc[19] = 1 / fmax(1e-15, (1 - imp) / imp * gc.box_invw_t);
+        PGS(base + 16) = rc[16]; PGS(base + 17) = rc[17]; PGS(base + 18) = rc[18]; PGS(base + 19) = rc[19];
+      }
 #pragma unroll
       for (int rr = 0; rr < 3; rr++) { double a = -rc[16 + rr];
 #pragma unroll
