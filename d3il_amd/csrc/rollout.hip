@@ -110,6 +110,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
                                                                   unsigned char* __restrict__ done, unsigned char* __restrict__ success,
                                                                   unsigned short* __restrict__ mode, int n, int stride, int n_substeps, int max_steps) {
   __shared__ double xch[2][2 * NARM][WAVE];
+  __shared__ double trg[2][2 * NARM + 1][WAVE];     // sin / cos of ikq (controller) and of the arm joints (physics) carried across the sub-steps: parked in LDS between them
   const int lane = threadIdx.x & (WAVE - 1);
   const int role = threadIdx.x / WAVE;          // wave-uniform: 0 controller, 1 physics
   int e = blockIdx.x * WAVE + lane;
@@ -132,11 +133,18 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
     for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
     unsigned fl = flags[e];
     make_setpoint(act, des);
-    double vwarm[7], trig[2 * NARM + 1];       // sin / cos of ikq carried across the sub-steps (exact once per step)
-    vwarm[6] = 0.0; trig[2 * NARM] = 0.0;
+    double vwarm[7];
+    vwarm[6] = 0.0; trg[0][2 * NARM][lane] = 0.0;
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
-      ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd, vwarm, trig);
+      {
+        double trig[2 * NARM + 1];                 // exact once per step, then carried
+#pragma unroll
+        for (int k = 0; k <= 2 * NARM; k++) trig[k] = trg[0][k][lane];
+        ik_update<FAST>(c, des, des + 3, q0, fl, ikq, ikqd, vwarm, trig);
+#pragma unroll
+        for (int k = 0; k <= 2 * NARM; k++) trg[0][k][lane] = trig[k];
+      }
       const int b = s & 1;
 #pragma unroll
       for (int k = 0; k < NARM; k++) { xch[b][k][lane] = ikq[k]; xch[b][NARM + k][lane] = ikqd[k]; }
@@ -161,10 +169,10 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
     load_state(state, flags, steps, stride, e, st);
     float o[2]; unsigned char dn;
     step_begin(c, st, o, &dn, max_steps);
-    double warm[6], trig[2 * NARM];            // sin / cos of the arm joints carried across the sub-steps (exact once per step)
+    double warm[6];
     warm[5] = 0.0;
 #pragma unroll
-    for (int k = 0; k < NARM; k++) sincos(st.q[k], &trig[k], &trig[NARM + k]);
+    for (int k = 0; k < NARM; k++) { double sk, ck; sincos(st.q[k], &sk, &ck); trg[1][k][lane] = sk; trg[1][NARM + k][lane] = ck; }
 #pragma clang loop unroll(disable)
     for (int s = 0; s < n_substeps; s++) {
 #if defined(D3IL_DEVICE_STATS)
@@ -178,7 +186,12 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
       double qd[NARM], qdd[NARM];
 #pragma unroll
       for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][lane]; qdd[k] = xch[b][NARM + k][lane]; }
+      double trig[2 * NARM];
+#pragma unroll
+      for (int k = 0; k < 2 * NARM; k++) trig[k] = trg[1][k][lane];
       control_and_physics(c, st, qd, qdd, 0.04, false, warm, trig);
+#pragma unroll
+      for (int k = 0; k < 2 * NARM; k++) trg[1][k][lane] = trig[k];
     }
 #if defined(D3IL_DEVICE_STATS)
     if (lane == 0 && blockIdx.x < 4096) { g_dev_wave[blockIdx.x][9] = wall_clock64() - t0 - tw; }
