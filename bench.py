@@ -1,20 +1,31 @@
 #!/usr/bin/env python
-"""bench.py - env-steps/s of the fused Avoiding step() on MI355X (BASELINE.json configs[1]).
+"""bench.py - env-steps/s of the fused D3IL step() on MI355X (headline: BASELINE.json configs[1], Avoiding, 4096 envs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--task avoiding|pushing|sorting] [--envs 4096]
+                    [--policy random|mlp|scripted_push] [--no-cpu-baseline] [--no-preroll]
 
-A "step" is one pass of the hot path over one batch: for every one of the 4096 environments per GPU the
-device-side random policy writes the action (Philox, seed 42, counter = global env index x t), d3il_step runs
-the 35 fused physics sub-steps, and finished environments are auto-reset (d3il_auto_reset), everything enqueued on one HIP stream with the state resident in HBM.  N > 1: one process
-per GPU (torch.distributed / RCCL), env shards are independent (weak scaling, 4096 envs per GPU), the only
-collective is the final int64 count all-reduce, outside the per-step path but inside the timed region.
-Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch: for every one of the 4096 environments per GPU the policy writes the
+action (Avoiding: device-side Philox random policy, seed 42, counter = global env index x t; Pushing / Sorting: torch policy on
+the resident observations), d3il_step runs the 35 fused physics sub-steps and finished environments start their next
+trajectory (d3il_auto_reset) - everything enqueued on one HIP stream with the state resident in HBM, no host synchronisation
+inside the loop.
+
+Steady state.  Before the warm-up the batch is brought to the steady-state mix of episode phases (untimed "pre-roll"): the
+episode counters are staggered over [0, max_steps) and max_steps env steps are run with auto-reset, so every lane has been
+re-started at its own time and a K-step window measures the phase mix of a long evaluation run - not the first, contact-free
+steps of a freshly reset batch.
+
+N > 1: one process per GPU (torch.distributed / RCCL); env shards are independent (weak scaling, 4096 envs per GPU), the only
+collective is the final int64 tally all-reduce, outside the per-step path but inside the timed region.  When started as plain
+`python bench.py --gpus N` (no WORLD_SIZE in the environment) the script re-launches itself under torch.distributed.run with
+N ranks.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,39 +34,117 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
-# algorithmic HBM bytes per env step: state read + written once (42 f64 + flags + step
-# counter = 344 B each way), action 56 B read, obs 8 B + done/success/mode 4 B written
-ALG_BYTES_PER_ENV_STEP = 2 * (42 * 8 + 4 + 4) + 56 + 8 + 4
+PROFILE_DIRS = ("r02", "r01")  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
+
+# algorithmic HBM bytes per env step (DESIGN.md sections 3, 12.3, 13.3): the state column read + written once (f64 rows + flags +
+# step counter), the action read (56 B), observation + done/success/mode written
+ALG_BYTES = {
+    "avoiding": 2 * (42 * 8 + 4 + 4) + 56 + 8 + 4,
+    "pushing": 2 * (68 * 8 + 4 + 4) + 56 + 32 + 4 + 16,
+    "sorting": 2 * (129 * 8 + 4 + 4) + 56 + 56 + 4,
+}
+KERNEL = {"avoiding": "k_avoiding_step_split<true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>"}
+PMC_FILE = {"avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json"}
 
 
-def cpu_baseline(blob, init_qpos, budget_s=12.0):
-    """Oracle (scalar C port of the reference path) timed on one host core on a bounded sample of the same
-    workload: one environment, random policy, as many env steps as fit in ~budget_s."""
+# ---------------------------------------------------------------------------------------------------- CPU baseline (oracle)
+def _cpu_worker(task, blob_bytes, init_qpos, contexts, budget_s, seed):
+    """One oracle environment on one host core for ~budget_s seconds; returns (env steps, seconds).  Test infrastructure timed as
+    the CPU baseline only (oracle/d3il_oracle.c is the scalar C restatement of the reference path)."""
     import numpy as np
+    from d3il_amd.model import blob as blob_mod
     from oracle.oracle import Oracle
+    blob = blob_mod.ModelBlob.from_buffer_copy(blob_bytes)
     o = Oracle(blob)
     o.env_start(init_qpos)
-    o.env_reset()
-    s, _ = o.env_state()
-    des = s[25:28].copy()
-    rng = np.random.default_rng(42)
-    n = 0
+    rng = np.random.default_rng(seed)
+    n, ep = 0, seed
+    t0 = time.perf_counter()
+    if task == "avoiding":
+        o.env_reset()
+        s, _ = o.env_state()
+        des = s[25:28].copy()
+        while time.perf_counter() - t0 < budget_s:
+            des[:2] += rng.uniform(-0.01, 0.01, 2)
+            _, done, _, _ = o.env_step(np.array([des[0], des[1], des[2], 0, 1, 0, 0]))
+            n += 1
+            if done:
+                o.env_reset()
+                s, _ = o.env_state()
+                des = s[25:28].copy()
+        return n, time.perf_counter() - t0
+    import torch
+    from d3il_amd.agents import RandomResidualMLPPolicy
+    torch.set_num_threads(1)
+    pol = RandomResidualMLPPolicy(input_dim=10 if task == "pushing" else 16, device="cpu")
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        des[:2] += rng.uniform(-0.01, 0.01, 2)
-        _, done, _, _ = o.env_step(np.array([des[0], des[1], des[2], 0, 1, 0, 0]))
-        n += 1
-        if done:
-            o.env_reset()
-            s, _ = o.env_state()
-            des = s[25:28].copy()
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "1 env, random policy, %d env steps (35 sub-steps each) in %.1f s on one host core of %d; "
-                      "scalar C oracle (oracle/d3il_oracle.c); the Python reference is bounded above by 146 "
-                      "env-steps/s/core (BASELINE.md section 2)" % (n, dt, os.cpu_count() or 0)}
+        if task == "pushing":
+            obs = o.push_reset(contexts[ep % len(contexts)])
+            s, _ = o.push_state()
+            des, z = s[25:27].copy(), s[27]
+        else:
+            obs = o.sort_reset(contexts[ep % len(contexts)].reshape(-1, 7))
+            des, z = obs[:2].astype(np.float64), float(o.body(blob.tcp_body)[0][2])
+        for t in range(400 if task == "pushing" else 500):
+            x = torch.as_tensor(np.concatenate([des, obs.astype(np.float64)])[None], dtype=torch.float64)
+            des = des + pol.predict_batch(x)[0].numpy().astype(np.float64)
+            a = np.array([des[0], des[1], z, 0, 1, 0, 0])
+            if task == "pushing":
+                obs, _, done, _ = o.push_step(a)
+            else:
+                obs, done, _ = o.sort_step(a)
+            n += 1
+            if done or time.perf_counter() - t0 >= budget_s:
+                break
+        ep += 1
+    return n, time.perf_counter() - t0
 
 
+def cpu_baseline(task, blob, init_qpos, contexts, budget_s=10.0):
+    """The oracle timed on the GPU box's host cores on a bounded sample of the same workload: first one environment on one core,
+    then one environment per core on all cores (independent OS processes, like the reference's n_cores workers; plain
+    subprocesses of this script - the parent holds an initialised HIP runtime, so nothing is forked)."""
+    import tempfile
+    import numpy as np
+    n1, t1 = _cpu_worker(task, bytes(blob), init_qpos, contexts, budget_s * 0.5, 0)
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    with tempfile.TemporaryDirectory() as td:
+        arg = os.path.join(td, "args.npz")
+        np.savez(arg, blob=np.frombuffer(bytes(blob), dtype=np.uint8), init_qpos=np.asarray(init_qpos, dtype=np.float64),
+                 contexts=np.zeros((0, 0)) if contexts is None else np.asarray(contexts, dtype=np.float64))
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", task, arg, str(budget_s), str(1 + i)],
+                                  stdout=subprocess.PIPE, env=env) for i in range(cores)]
+        outs = [p.communicate()[0] for p in procs]
+        wall = time.perf_counter() - t0
+    res = [tuple(float(x) for x in o.decode().split()[-2:]) for o in outs if o.strip()]
+    total = sum(r[0] for r in res)
+    busy = max(r[1] for r in res) if res else float("nan")
+    pol = "random policy" if task == "avoiding" else "ResidualMLP stand-in policy on the CPU"
+    return {"value": total / busy, "unit": "env-steps/s", "cores": len(res), "kind": "port",
+            "single_core_value": n1 / t1,
+            "sample": "one oracle environment per core on all %d host cores (%s, %d env steps of 35 sub-steps in %.1f s of stepping per worker, %.1f s wall "
+                      "including interpreter start-up), after one environment on one core (%d env steps in %.1f s); scalar C oracle (oracle/d3il_oracle.c, the CPU "
+                      "restatement of the reference path - the Python reference itself is bounded above by 146 env-steps/s/core, BASELINE.md section 2)"
+                      % (len(res), pol, total, busy, wall, n1, t1)}
+
+
+def _cpu_worker_main(argv):
+    import numpy as np
+    task, arg, budget, seed = argv[0], argv[1], float(argv[2]), int(argv[3])
+    z = np.load(arg)
+    ctx = z["contexts"] if z["contexts"].size else None
+    n, t = _cpu_worker(task, z["blob"].tobytes(), z["init_qpos"], ctx, budget, seed)
+    print(n, t)
+
+
+# ---------------------------------------------------------------------------------------------------- helpers
 def _local_device() -> int:
     """GPU of this rank: LOCAL_RANK (one process per GPU).  D3IL_BENCH_FORCE_DEVICE pins every rank to one GPU - only for
     exercising the multi-process code path on a single-GPU box (with D3IL_DIST_BACKEND=gloo; RCCL needs distinct GPUs)."""
@@ -64,216 +153,65 @@ def _local_device() -> int:
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
-# Pushing: cube state adds 26 f64 (+ 2 flag/counter words as above); action 56 B; obs 32 B; done/success/mode 4 B; info 16 B
-PUSH_ALG_BYTES_PER_ENV_STEP = 2 * (68 * 8 + 4 + 4) + 56 + 32 + 4 + 16
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def cpu_baseline_pushing(blob, init_qpos, contexts, budget_s=12.0):
-    """Scalar C oracle on one host core, one environment, same stand-in policy (run on the CPU), bounded sample."""
-    import numpy as np
-    import torch
-    from d3il_amd.agents import RandomResidualMLPPolicy
-    from oracle.oracle import Oracle
-    o = Oracle(blob)
-    o.env_start(init_qpos)
-    pol = RandomResidualMLPPolicy(device="cpu")
-    n, ep = 0, 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        obs = o.push_reset(contexts[ep % len(contexts)])
-        s, _ = o.push_state()
-        des, z = s[25:27].copy(), s[27]
-        for t in range(400):
-            x = torch.as_tensor(np.concatenate([des, obs.astype(np.float64)])[None], dtype=torch.float64)
-            des = des + pol.predict_batch(x)[0].numpy().astype(np.float64)
-            obs, _, done, _ = o.push_step(np.array([des[0], des[1], z, 0, 1, 0, 0]))
-            n += 1
-            if done or time.perf_counter() - t0 >= budget_s:
-                break
-        ep += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "1 env, ResidualMLP stand-in policy on the CPU, %d env steps (35 sub-steps each) in %.1f s on one host core of %d; "
-                      "scalar C oracle (oracle/d3il_oracle.c)" % (n, dt, os.cpu_count() or 0)}
+def _self_spawn(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks (one per GPU) under torch.distributed.run and pass its output on."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline_sorting(blob, init_qpos, contexts, budget_s=15.0):
-    """Scalar C oracle on one host core, one environment, same stand-in policy (run on the CPU), bounded sample."""
-    import numpy as np
-    import torch
-    from d3il_amd.agents import RandomResidualMLPPolicy
-    from oracle.oracle import Oracle
-    o = Oracle(blob)
-    o.env_start(init_qpos)
-    pol = RandomResidualMLPPolicy(input_dim=16, device="cpu")
-    n, ep = 0, 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        obs = o.sort_reset(contexts[ep % len(contexts)].reshape(-1, 7))
-        des, z = obs[:2].astype(np.float64), float(o.body(blob.tcp_body)[0][2])
-        for t in range(500):
-            x = torch.as_tensor(np.concatenate([des, obs.astype(np.float64)])[None], dtype=torch.float64)
-            des = des + pol.predict_batch(x)[0].numpy().astype(np.float64)
-            obs, done, _ = o.sort_step(np.array([des[0], des[1], z, 0, 1, 0, 0]))
-            n += 1
-            if done or time.perf_counter() - t0 >= budget_s:
-                break
-        ep += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "1 env, ResidualMLP stand-in policy on the CPU, %d env steps (35 sub-steps each) in %.1f s on one host core of %d; "
-                      "scalar C oracle (oracle/d3il_oracle.c)" % (n, dt, os.cpu_count() or 0)}
-
-
-# algorithmic HBM bytes per env step, Sorting-4: state column read + written once (129 f64 rows + flags + step counter), action 56 B,
-# obs 14 x 4 B, done/success/mode 4 B
-SORT_ALG_BYTES_PER_ENV_STEP = 2 * (129 * 8 + 4 + 4) + 56 + 56 + 4
-
-
-def bench_pushing(args):
-    """BASELINE config 3: Pushing, 4096 envs per GPU, the 60 reference test contexts tiled, ResidualMLP 10 -> 128 x 6 -> 2 (Mish)
-    stand-in policy with fixed random weights, 400-step episode cap; a step = policy forward + d3il_step."""
-    import numpy as np
-    import torch
-    from d3il_amd import distributed as D
-    from d3il_amd.agents import RandomResidualMLPPolicy
-    from d3il_amd.envs.pushing import BlockPushVecEnv
-    from d3il_amd.simulation.pushing_sim import load_test_contexts
-    sorting = args.task == "sorting"
-    if sorting:
-        from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
-
-    local_rank = _local_device()
-    torch.cuda.set_device(local_rank)
-    rank, world = D.init_from_env(os.environ.get("D3IL_DIST_BACKEND", "nccl"))
-    dev = torch.device("cuda:%d" % local_rank)
-    n = args.envs
-    env = SortingVecEnv(n, device=dev) if sorting else BlockPushVecEnv(n, device=dev)
-    q, iters, err = env.start()
-    # Sorting: the reference's 4_test_contexts.pkl is not part of its tree; contexts are drawn like BlockContextManager.sample
-    ctx60 = sample_contexts(60, 4, seed=0) if sorting else load_test_contexts()
-    ctx = torch.as_tensor(ctx60[(rank * n + np.arange(n)) % len(ctx60)], dtype=torch.float64, device=dev)
-    pol = RandomResidualMLPPolicy(input_dim=2 + env.obs.shape[1], device=dev)
-    quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
-    state = {}
-
-    def begin_episode():
-        env.reset(context=ctx)
-        rs = env.robot_state()
-        state["des"], state["z"] = rs[:, :2].clone(), rs[:, 2:3].clone()
-
-    def one_step(t):
-        if t % env.max_steps_per_episode == 0:
-            begin_episode()
-        obs10 = torch.cat((state["des"], env.obs.to(torch.float64)), dim=1)
-        state["des"] = state["des"] + pol.predict_batch(obs10).to(torch.float64)
-        act = torch.cat((state["des"], state["z"], quat), dim=1).contiguous()
-        if state.get("ev") is not None:      # events on the stream the kernel is launched on (torch's current stream), one pair per step
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); env.step(act); e1.record()
-            state["ev"].append((e0, e1))
-        else:
-            env.step(act)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for t in range(args.warmup):
-        one_step(t)
-    env.set_timing(True)
-    kernel_ms_lib = []
-    state["ev"] = []
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(args.steps):
-        one_step(args.warmup + t)
-        if t % 16 == 15:      # cross-check: the library's own HIP event pair around the launch, read every 16th step
-            kernel_ms_lib.append(env.last_step_ms())
-    barrier()
-    dt = time.perf_counter() - t0
-    env.set_timing(False)
-    kernel_ms = [a.elapsed_time(b) for a, b in state["ev"]]      # every launch of the timed region
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t_max.item())
-    st, fl, sc = env.get_state()
-    bad = int(((fl >> 16) & 1).sum()), int(((fl >> 18) & 1).sum()), int(((fl >> 19) & 1).sum())
-    if rank == 0:
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        alg_bytes = SORT_ALG_BYTES_PER_ENV_STEP if sorting else PUSH_ALG_BYTES_PER_ENV_STEP
-        achieved = alg_bytes * n / (k_ms * 1e-3) / 1e9
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc runs)
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_%s.json" % args.task)) as f:
-                pm = json.load(f)
-            if n == 4096:
-                traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+def _pmc(task, n):
+    """HBM traffic / VALU counters per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
+    (the PMC passes are separate runs by construction: counters cannot be collected inside the timed run)."""
+    if n != 4096:
+        return None, None
+    for d in PROFILE_DIRS:
+        path = os.path.join(ROOT, "profiles", d, PMC_FILE[task])
+        try:
+            with open(path) as f:
+                return json.load(f), os.path.relpath(path, ROOT)
         except Exception:
-            pass
-        line = {
-            "metric": "env-steps/s", "value": world * n * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("Sorting-4 task, %d envs per GPU, 60 contexts sampled like BlockContextManager.sample tiled, ResidualMLP 16->128x6->2 (Mish) "
-                                    "stand-in policy with fixed random weights (torch, f32), 35 fused physics sub-steps per env step, 500-step episodes" % n) if sorting else
-                                   ("Pushing task, %d envs per GPU, the 60 reference test contexts tiled, ResidualMLP 10->128x6->2 (Mish) "
-                                    "stand-in policy with fixed random weights (torch, f32), 35 fused physics sub-steps per env step, "
-                                    "400-step episodes" % n),
-                       "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world,
-                       "finite": bool(np.isfinite(st[:env.state_rows - 2]).all()), "flagged_envs_solver_overflow_offtable": bad},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_sorting_step<true>" if sorting else "k_pushing_step_split<true>", "kernel_ms": k_ms,
-                         "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
-                         "kernel_ms_library_events_every_16th": float(np.mean(kernel_ms_lib)) if kernel_ms_lib else None,
-                         "algorithmic_bytes_per_launch": alg_bytes * n,
-                         "note": ("FP64 instruction-issue bound (DESIGN.md section 13): one wave per SIMD, solver loops over LDS-resident systems; HBM traffic beyond the "
-                                  "state column is the contact records of the constraint solver") if sorting else
-                                 ("FP64 latency bound like the Avoiding step (DESIGN.md sections 4, 12.3).  Measured HBM traffic is ~25x the algorithmic bytes: "
-                                  "register spills of the solver functions (private scratch) and the solver warm start / scratch rows, not state traffic")},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline_sorting(env.blob, q, ctx60) if sorting else cpu_baseline_pushing(env.blob, q, ctx60)
-        print(json.dumps(line))
-    env.close()
-    if world > 1:
-        torch.distributed.destroy_process_group()
+            continue
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting"], help="avoiding = the headline configuration (BASELINE configs[1])")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-auto-reset", action="store_true")
-    ap.add_argument("--lanes", type=int, default=None, help="environments per wave (default 64)")
-    ap.add_argument("--split", type=int, default=None, help="1: two-wave controller||physics kernel, 0: fused kernel, default auto")
-    ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
-    args = ap.parse_args()
-
+# ---------------------------------------------------------------------------------------------------- the benchmark
+def run(args):
     import numpy as np
     import torch
     from d3il_amd import distributed as D
-    from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
 
-    if not torch.cuda.is_available():
-        print("bench.py needs a HIP device (there is no CPU fallback for the rollout path)", file=sys.stderr)
-        sys.exit(2)
-    if args.task in ("pushing", "sorting"):
-        return bench_pushing(args)
+    task = args.task
     local_rank = _local_device()
     torch.cuda.set_device(local_rank)
     rank, world = D.init_from_env(os.environ.get("D3IL_DIST_BACKEND", "nccl"))
     if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        print("warning: --gpus %d but WORLD_SIZE %d (the line reports n_gpus = WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda:%d" % local_rank)
     n = args.envs
-    env = ObstacleAvoidanceVecEnv(n, device=dev)
+    env_offset = rank * n
+    ctx60 = None
+    if task == "avoiding":
+        from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
+        env = ObstacleAvoidanceVecEnv(n, device=dev)
+    elif task == "pushing":
+        from d3il_amd.envs.pushing import BlockPushVecEnv
+        from d3il_amd.simulation.pushing_sim import load_test_contexts
+        env = BlockPushVecEnv(n, device=dev)
+        ctx60 = load_test_contexts()
+    else:
+        from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
+        env = SortingVecEnv(n, device=dev)
+        ctx60 = sample_contexts(60, 4, seed=0)     # the reference's 4_test_contexts.pkl is not part of its tree
     q, iters, err = env.start()
     if args.lanes is not None:
         env.set_option("lanes_per_wave", args.lanes)
@@ -281,15 +219,45 @@ def main():
         env.set_option("split_waves", args.split)
     if args.lds_pad is not None:
         env.set_option("lds_pad_bytes", args.lds_pad)
-    env_offset = rank * n
-    actions = torch.zeros(n, 7, dtype=torch.float64, device=dev)
-    counts = torch.zeros(514, dtype=torch.int64, device=dev)
+    if args.solver_strict:
+        env.set_option("solver_strict", 1)
+    max_steps = env.max_steps_per_episode
+    ctx_id = None
+    if ctx60 is not None:
+        ids = (env_offset + np.arange(n)) % len(ctx60)
+        ctx_id = torch.as_tensor(ids, dtype=torch.int32, device=dev)
+        env.reset(context=ctx60[ids])
+    else:
+        env.reset()
+    env.policy_begin()
+    table = env.set_tally(len(ctx60) if ctx60 is not None else 1, ctx_id)
     episodes = torch.zeros(2, dtype=torch.int64, device=dev)   # finished, successful
-
+    actions = torch.zeros(n, 7, dtype=torch.float64, device=dev)
+    policy = args.policy or ("random" if task == "avoiding" else "mlp")
+    pol = None
+    if task != "avoiding" or policy != "random":
+        from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedPushPolicy
+        if policy == "mlp":
+            pol = RandomResidualMLPPolicy(input_dim=2 + env.obs.shape[1], device=dev)
+        elif policy == "scripted_push":
+            pol = ScriptedPushPolicy(task, device=dev)
+        else:
+            raise SystemExit("--policy %s is not available for task %s" % (policy, task))
+        actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
+    des_xy = env.policy_des[:2, :n]                              # [2, n] view: the harness set-point the library re-latches on auto-reset
+    des_z = env.policy_des[2, :n]
     evs = None
 
     def one_step(t):
-        env.policy_action(42, env_offset, t, actions)
+        if pol is None:
+            env.policy_action(42, env_offset, t, actions)
+        else:
+            if hasattr(pol, "begin_episodes"):
+                pol.begin_episodes(env.last_reset)
+            obs_in = torch.cat((des_xy.t(), env.obs.to(torch.float64)), dim=1)      # np.concatenate((pred_action[:2], obs)), pushing_sim.py:75
+            des_xy.add_(pol.predict_batch(obs_in).to(torch.float64).t())            # pushing_sim.py:78
+            actions[:, 0:2] = des_xy.t()
+            actions[:, 2] = des_z
         if evs is not None:      # events on the stream the kernel is launched on (torch's current stream), one pair per step
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); env.step(actions); e1.record()
@@ -304,23 +272,31 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    env.reset(); env.policy_begin()
+    t_run = 0
+    preroll = 0
+    if not args.no_preroll and not args.no_auto_reset:
+        # steady-state phase mix: lane i pretends to be (i * 977) % max_steps steps into its episode, then one full episode length of
+        # untimed steps: every lane is re-started at its own time
+        stagger = (torch.arange(n, device=dev, dtype=torch.int64) + env_offset) * 977 % max_steps
+        env.step_count[:n] = stagger.to(torch.int32)
+        preroll = max_steps if args.preroll is None else args.preroll
+        for t in range(preroll):
+            one_step(t_run); t_run += 1
     for t in range(args.warmup):
-        one_step(t)
-    episodes.zero_()
+        one_step(t_run); t_run += 1
+    episodes.zero_(); table.zero_()
     env.set_timing(True)
     kernel_ms_lib = []
     evs = []
     barrier()
     t0 = time.perf_counter()
     for t in range(args.steps):
-        one_step(args.warmup + t)
+        one_step(t_run); t_run += 1
         # cross-check: HIP events recorded by the library around the step kernel on the launch stream; reading the
         # previous pair costs one event sync on an already finished kernel every 16 steps
         if t % 16 == 15:
             kernel_ms_lib.append(env.last_step_ms())
-    env.count_metrics(counts)
-    D.reduce_counts(counts)
+    D.reduce_counts(table)          # the one collective of the path: int64 episode tally
     barrier()
     dt = time.perf_counter() - t0
     env.set_timing(False)
@@ -330,51 +306,97 @@ def main():
         torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
     dt = float(t_max.item())
     st, fl, sc = env.get_state()
-    ok = bool(np.isfinite(st).all()) and not bool((fl & (1 << 16)).any())
+    n_state = env.state_rows - (2 if task == "sorting" else 0)
+    finite = bool(np.isfinite(st[:n_state]).all())
+    flagged = {"solver_fail": int(((fl >> 16) & 1).sum())}
+    if task != "avoiding":
+        flagged.update(contact_overflow=int(((fl >> 18) & 1).sum()), off_table=int(((fl >> 19) & 1).sum()))
     if rank == 0:
         value = world * n * args.steps / dt
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        alg = ALG_BYTES[task]
+        achieved = alg * n / (k_ms * 1e-3) / 1e9
+        pm, pm_path = _pmc(task, n)
         traffic, valu = None, None
-        try:  # HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc runs)
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_bench300.json")) as f:
-                pm = json.load(f)
-            if n == 4096:
-                traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+        if pm is not None:
+            traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+            if task == "avoiding":
                 # binding resource: FP64 VALU issue.  Instruction count from the PMC pass, ~2/3 of the VALU stream is FP64
                 # arithmetic (static mix), an FMA counts 2 flop; peak = 78.6 TFLOP/s vector FP64 (whole chip, 1024 SIMDs)
                 insts = pm["SQ_INSTS_VALU"]["mean_per_dispatch"]
                 tflops = insts * 0.66 * 1.6 * 64 / (k_ms * 1e-3) / 1e12
-                valu = {"bound": "fp64_valu", "valu_insts_per_launch": insts, "achieved_tflops_est": tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                        "frac_est": tflops / FP64_VALU_PEAK_TFLOPS, "simds_used": 128, "simds_total": 1024,
+                valu = {"bound": "fp64_valu", "source": pm_path, "valu_insts_per_launch": insts, "achieved_tflops_est": tflops,
+                        "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac_est": tflops / FP64_VALU_PEAK_TFLOPS,
                         "valu_active_frac_of_wave_cycles": pm["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / pm["SQ_WAVE_CYCLES"]["mean_per_dispatch"]}
-        except Exception:
-            pass
-        achieved = ALG_BYTES_PER_ENV_STEP * n / (k_ms * 1e-3) / 1e9
+        tb = table.cpu().numpy()
+        workload = {
+            "avoiding": "Avoiding task, %d envs per GPU, random policy (Philox seed 42), state obs, 35 fused physics sub-steps per env step, "
+                        "250-step episodes with auto-reset" % n,
+            "pushing": "Pushing task, %d envs per GPU, the 60 reference test contexts tiled, %s, 35 fused physics sub-steps per env step, "
+                       "400-step episodes with auto-reset" % (n, "ResidualMLP 10->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)"
+                                                              if policy == "mlp" else "scripted pushing policy (every rod drives its cube to the target: contact regime)"),
+            "sorting": "Sorting-4 task, %d envs per GPU, 60 contexts sampled like BlockContextManager.sample tiled, %s, 35 fused physics sub-steps per "
+                       "env step, 500-step episodes with auto-reset" % (n, "ResidualMLP 16->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)"
+                                                                        if policy == "mlp" else "scripted pushing policy (every rod pushes a cube towards its bin: contact regime)"),
+        }[task]
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Avoiding task, %d envs per GPU, random policy (Philox seed 42), state obs, "
-                                   "35 fused physics sub-steps per env step, auto-reset" % n,
-                       "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world,
-                       "auto_reset": not args.no_auto_reset, "finite_and_solver_ok": ok,
-                       "episodes_finished_rank0": int(episodes[0].item()), "episodes_success_rank0": int(episodes[1].item())},
+            "config": {"workload": workload, "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world, "policy": policy,
+                       "preroll_steps_untimed": preroll, "phase_mix": "steady state (staggered episode phases)" if preroll else "fresh reset",
+                       "auto_reset": not args.no_auto_reset, "finite": finite, "flagged_envs": flagged,
+                       "episodes_finished_all_ranks": int(tb[:, 0].sum()), "episodes_success_all_ranks": int(tb[:, 1].sum()),
+                       "episodes_finished_rank0": int(episodes[0].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_avoiding_step_split<true>", "kernel_ms": k_ms,
+                         "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run)" % pm_path) if pm_path else None,
+                         "kernel": KERNEL[task], "kernel_ms": k_ms,
                          "kernel_ms_library_events_every_16th": float(np.mean(kernel_ms_lib)) if kernel_ms_lib else None,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n,
-                         "note": "path is FP64-VALU issue/latency bound, not HBM bound: 756 B of HBM per env step with all 35 "
-                                 "sub-steps fused in registers (DESIGN.md section 4); see the valu object and profiles/r01",
+                         "algorithmic_bytes_per_launch": alg * n,
+                         "note": "the path is FP64-VALU issue/latency bound, not HBM bound: < 2.2 KB of HBM per env step with all 35 sub-steps "
+                                 "fused in registers / LDS (DESIGN.md sections 4, 12.3, 13.3); `frac` is the (structurally tiny) HBM fraction the contract asks for, "
+                                 "`valu` the binding resource",
                          "valu": valu},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(env.blob, q)
+            line["cpu_baseline"] = cpu_baseline(task, env.blob, q, ctx60)
         print(json.dumps(line))
     env.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 
 
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting"], help="avoiding = the headline configuration (BASELINE configs[1])")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--policy", default=None, choices=["random", "mlp", "scripted_push"], help="default: random (Avoiding), mlp (Pushing / Sorting)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auto-reset", action="store_true")
+    ap.add_argument("--no-preroll", action="store_true", help="measure from a freshly reset batch (round-1 behaviour)")
+    ap.add_argument("--preroll", type=int, default=None, help="untimed steady-state pre-roll steps (default: one episode length)")
+    ap.add_argument("--solver-strict", action="store_true", help="contact solvers iterate to round-off like the oracle (parity A/B)")
+    ap.add_argument("--lanes", type=int, default=None, help="environments per wave (default 64)")
+    ap.add_argument("--split", type=int, default=None, help="1: two-wave controller||physics kernel, 0: fused kernel, default auto")
+    ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_spawn(args.gpus))
+
+    import torch
+    if not torch.cuda.is_available():
+        print("bench.py needs a HIP device (there is no CPU fallback for the rollout path)", file=sys.stderr)
+        sys.exit(2)
+    run(args)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        _cpu_worker_main(sys.argv[2:])
+    else:
+        main()

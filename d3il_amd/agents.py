@@ -39,21 +39,70 @@ class BatchedBCAgent:
         return self.agent.predict(state, *args, **kwargs)
 
 
-class RowwiseAgent:
-    """Fallback adapter for any reference agent: calls ``predict`` row by row (host round trip per env, slow)."""
+def _is_lane_state(v) -> bool:
+    """Attributes of a reference agent that hold per-episode state: history deques (ddpm_agent.py:61, beso_agent.py:86-87,
+    bet_agent.py:131), action-chunk buffers, plain containers and non-parameter tensors / arrays."""
+    import collections
+    import numpy as np
+    if isinstance(v, (collections.deque, list, dict, set, bytearray, np.ndarray)):
+        return True
+    return isinstance(v, torch.Tensor) and not isinstance(v, torch.nn.Parameter)
 
-    def __init__(self, agent):
+
+class RowwiseAgent:
+    """Fallback adapter for any reference agent without ``predict_batch``: calls ``predict`` row by row (host round trip per
+    environment, slow), with ONE AGENT STATE PER LANE.  Most reference agents keep per-episode state inside ``predict`` - BeT,
+    BESO, DDPM and ACT hold an observation deque and action-chunk counters (e.g. ddpm_agent.py:223-227, beso_agent.py:354-355) -
+    so a single instance stepped through N lock-stepped environments would mix the histories of different environments.  Every
+    lane therefore gets a shallow clone of the agent that shares the network, scaler and everything immutable, and owns copies
+    of the per-episode containers."""
+
+    def __init__(self, agent, n_envs: int | None = None):
         self.agent = agent
+        self.lanes = []
+        if n_envs:
+            self._grow(n_envs)
+
+    def _clone(self):
+        import copy
+        c = copy.copy(self.agent)
+        for k, v in vars(self.agent).items():
+            if _is_lane_state(v):
+                setattr(c, k, copy.deepcopy(v))
+        return c
+
+    def _grow(self, n):
+        while len(self.lanes) < n:
+            self.lanes.append(self._clone())
 
     def reset(self):
         if hasattr(self.agent, "reset"):
             self.agent.reset()
+            for a in self.lanes:
+                a.reset()
+
+    def begin_episodes(self, mask: torch.Tensor):
+        """Lanes that start their next trajectory (env.last_reset) get a fresh history."""
+        for i in torch.nonzero(mask.reshape(-1)).reshape(-1).tolist():
+            if i < len(self.lanes) and hasattr(self.lanes[i], "reset"):
+                self.lanes[i].reset()
 
     def predict_batch(self, obs: torch.Tensor) -> torch.Tensor:
         import numpy as np
         rows = obs.detach().cpu().numpy()
-        acts = np.stack([np.asarray(self.agent.predict(r)).reshape(-1) for r in rows])
+        self._grow(len(rows))
+        acts = np.stack([np.asarray(self.lanes[i].predict(r)).reshape(-1) for i, r in enumerate(rows)])
         return torch.as_tensor(acts, dtype=torch.float64, device=obs.device)
+
+
+def as_batched(agent, n_envs: int | None = None):
+    """What the batched sims call: agents that provide ``predict_batch`` (the adapters of this module, or any policy written
+    for the batch) are used as they are; everything else is wrapped row by row with per-lane state."""
+    if hasattr(agent, "predict_batch"):
+        if not hasattr(agent, "reset"):
+            agent.reset = lambda: None
+        return agent
+    return RowwiseAgent(agent, n_envs)
 
 
 class RandomResidualMLPPolicy(torch.nn.Module):
@@ -94,3 +143,70 @@ class RandomResidualMLPPolicy(torch.nn.Module):
         for l1, l2 in self.blocks:
             x = x + l2(self.act(l1(self.act(x))))
         return self.out(x).clamp_(-self.bound, self.bound)
+
+
+class ScriptedPushPolicy:
+    """Scripted contact-regime policy for the measurement harness (bench.py --policy scripted_push, tools/): every rod walks
+    behind a cube and pushes it - Pushing: the red cube to the red target, then the green cube to the green target (two-phase
+    script); Sorting: the first cube still on the platform over the platform edge into the bins.  Input / output like the
+    rollout loops of the sims: ``predict_batch([des_xy, obs]) -> delta_xy`` with |delta| <= 6 mm (the env's action box is +-1 cm).
+    Per-lane phase state is re-latched by ``begin_episodes(mask)`` when a lane starts its next trajectory."""
+
+    STEP = 0.006
+
+    def __init__(self, task: str, device="cuda"):
+        assert task in ("pushing", "sorting")
+        self.task, self.device = task, torch.device(device)
+        self.goals = torch.tensor([[0.42, 0.3], [0.63, 0.3]], dtype=torch.float64, device=self.device)   # pushing_objects.py:11-15 (x, y of the two targets)
+        self.phase = None
+
+    def reset(self):
+        self.phase = None
+
+    def begin_episodes(self, mask: torch.Tensor):
+        if self.phase is not None:
+            self.phase = torch.where(mask.bool(), torch.zeros_like(self.phase), self.phase)
+
+    @torch.no_grad()
+    def predict_batch(self, obs_in: torch.Tensor) -> torch.Tensor:
+        o = obs_in.to(torch.float64)
+        n = o.shape[0]
+        des, obs = o[:, :2], o[:, 2:]
+        if self.phase is None:
+            self.phase = torch.zeros(n, dtype=torch.long, device=o.device)
+        if self.task == "pushing":
+            box = torch.where(self.phase.unsqueeze(1) == 0, obs[:, 2:4], obs[:, 5:7])
+            goal = self.goals[self.phase]
+            togo = goal - box
+            dist = togo.norm(dim=1, keepdim=True)
+            self.phase = torch.where((dist.squeeze(1) < 0.03) & (self.phase == 0), torch.ones_like(self.phase), self.phase)
+            dirn = togo / dist.clamp_min(1e-9)
+        else:
+            nb = (obs.shape[1] - 2) // 3
+            xy = obs[:, 2:].reshape(n, nb, 3)[:, :, :2]
+            on_platform = xy[:, :, 1] < 0.19
+            first = torch.argmax(on_platform.to(torch.int64), dim=1)                 # first cube still on the platform (0 when none is)
+            box = xy[torch.arange(n, device=o.device), first]
+            dirn = torch.tensor([0.0, 1.0], dtype=torch.float64, device=o.device).expand(n, 2)
+            dist = torch.where(on_platform.any(dim=1, keepdim=True), torch.ones(n, 1, dtype=torch.float64, device=o.device),
+                               torch.zeros(n, 1, dtype=torch.float64, device=o.device))
+        behind = box - dirn * 0.055                                # stand-off point behind the cube, on the line to its goal
+        off = des - behind
+        along = (off * dirn).sum(1, keepdim=True)
+        lateral = off - along * dirn
+        aligned = (lateral.norm(dim=1, keepdim=True) < 0.012) & (along < 0.02)
+        target = torch.where(aligned, box, behind)
+        d = target - des
+        dn = d.norm(dim=1, keepdim=True)
+        step = d / dn.clamp_min(1e-9) * torch.minimum(dn, torch.full_like(dn, self.STEP))
+        # go around the cube when the straight line to the stand-off point crosses it
+        rel = des - box
+        rn = rel.norm(dim=1, keepdim=True)
+        near = (rn < 0.06) & ~aligned
+        away = rel / rn.clamp_min(1e-9)
+        tang = torch.stack((-away[:, 1], away[:, 0]), dim=1)
+        tang = tang * torch.sign((tang * (behind - des)).sum(1, keepdim=True) + 1e-12)
+        step = torch.where(near, self.STEP * (0.6 * tang + 0.4 * away), step)
+        if self.task == "sorting":
+            step = step * dist                                        # nothing left on the platform: hold
+        return step

@@ -17,7 +17,7 @@ class Buffers(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("stride", C.c_int32), ("obs_dim", C.c_int32), ("action_dim", C.c_int32),
                 ("obs", C.c_void_p), ("done", C.c_void_p), ("success", C.c_void_p), ("mode", C.c_void_p),
                 ("state", C.c_void_p), ("flags", C.c_void_p), ("step_count", C.c_void_p), ("policy_des", C.c_void_p),
-                ("info_f64", C.c_void_p), ("n_info_f64", C.c_int32), ("state_rows", C.c_int32)]
+                ("info_f64", C.c_void_p), ("n_info_f64", C.c_int32), ("state_rows", C.c_int32), ("last_reset", C.c_void_p)]
 
 
 STATE_F64 = 42
@@ -28,10 +28,11 @@ FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
 PUSH_STATE_BOX, PUSH_STATE_WARM, PUSH_STATE_F64 = 42, 68, 89
 PFLAG_FIRST_MASK, PFLAG_MODE_MASK, PFLAG_WARM_VALID, PFLAG_CON_OVERFLOW, PFLAG_OFF_TABLE = 0x7, 0x38, 1 << 6, 1 << 18, 1 << 19
 TASK_AVOIDING, TASK_PUSHING, TASK_SORTING = 0, 1, 2
+TALLY_ROW = 514
 SORT_STATE_BOX, SORT_STATE_WARM, SORT_STATE_TASK, SORT_STATE_F64 = 42, 94, 127, 129
 
 EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
-           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_auto_reset", "d3il_count_metrics", "d3il_set_timing",
+           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_auto_reset", "d3il_set_tally", "d3il_count_metrics", "d3il_set_timing",
            "d3il_last_step_ms", "d3il_set_option", "d3il_debug_stats", "d3il_debug_wave_stats", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
 
 
@@ -68,6 +69,7 @@ def load():
         L.d3il_policy_action.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.d3il_count_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.d3il_auto_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_set_tally.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.d3il_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.d3il_last_step_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.d3il_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]

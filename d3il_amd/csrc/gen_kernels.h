@@ -73,6 +73,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
       fl = flags[e];
+      sanitize_action(act);
       make_setpoint(act, des);
     }
 #pragma clang loop unroll(disable)
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
       int code = 0;
       for (int k = 1; k < gc.nb; k++) lfl |= (unsigned)GLS(GL_INFO + 4 + k);
       st.flags |= F_IK_VALID | PF_WARM_VALID | lfl;
+      if (action_is_bad(actions + (size_t)e * 7)) st.flags |= F_SOLVER_FAIL | F_TERMINATED;
       sort_step_end(gc, st, sc, &code);
       gen_store_arm(state, flags, steps, stride, e, st, false);
       const int od = 2 + 3 * gc.nb;

@@ -481,8 +481,8 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
           }
         }
       best = alpha;
-      if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
-      if (fabs(d1) <= D3IL_LS_C2 * fabs(gTp) || fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (ls == 0 && d1 <= D3IL_TOL.ls_full * fabs(gTp)) break;
+      if (fabs(d1) <= D3IL_TOL.ls_c2 * fabs(gTp) || fabs(d1) <= D3IL_TOL.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
@@ -504,7 +504,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     gen_sync();        // every lane has read the old iterate
     for (int ci = l; ci < isl.m; ci += nl) { const int gi = dof_of(ci); GLS(GL_X + gi) += best * GLS(vp + ci); }
     gen_sync();
-    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
   }
   return converged;
 }
@@ -627,8 +627,8 @@ D3IL_NOINLINE inline bool gen_solve_cube(const GenConsts& gc_, const PushScratch
           for (int qq = 0; qq < 3; qq++) d2 += jp[r] * Hc[3 * r + qq] * jp[qq]; }
       }
       best = alpha;
-      if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
-      if (fabs(d1) <= D3IL_LS_C2 * fabs(gTp) || fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (ls == 0 && d1 <= D3IL_TOL.ls_full * fabs(gTp)) break;
+      if (fabs(d1) <= D3IL_TOL.ls_c2 * fabs(gTp) || fabs(d1) <= D3IL_TOL.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {
@@ -643,7 +643,7 @@ D3IL_NOINLINE inline bool gen_solve_cube(const GenConsts& gc_, const PushScratch
     double smax = 0, xmax = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) { double dxk = best * p[k]; x[k] += dxk; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(x[k])); }
-    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
   }
 #pragma unroll
   for (int k = 0; k < 6; k++) GLS(GL_X + 6 * c + k) = x[k];

@@ -1489,6 +1489,22 @@ template <class C> D3IL_HD void step_begin(const C& c, EnvState& st, float* obs,
   *done = fin ? 1 : 0;
 }
 // controller.setSetPoint(action) (IKControllers.py:346-362): position + normalised quaternion
+// A NaN / Inf action (a diverged policy) must not reach the dynamics: integer test of the exponent field, which
+// -ffinite-math-only cannot fold away.  A bad action is replaced by a fixed reachable set-point; the caller flags the lane
+// (F_SOLVER_FAIL | F_TERMINATED).  The reference has no such check (MuJoCo would warn and reset its data on the NaN qacc).
+D3IL_HD bool sanitize_action(double* act) {
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 7; k++) { unsigned long long b; __builtin_memcpy(&b, &act[k], 8); bad = bad || ((b >> 52) & 0x7ffull) == 0x7ffull; }
+  if (bad) { act[0] = 0.5; act[1] = 0.0; act[2] = 0.3; act[3] = 0.0; act[4] = 1.0; act[5] = 0.0; act[6] = 0.0; }
+  return bad;
+}
+D3IL_HD bool action_is_bad(const double* __restrict__ a) {
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 7; k++) { unsigned long long b; __builtin_memcpy(&b, &a[k], 8); bad = bad || ((b >> 52) & 0x7ffull) == 0x7ffull; }
+  return bad;
+}
 D3IL_HD void make_setpoint(const double* action, double* des) {
   double n = sqrt(action[3] * action[3] + action[4] * action[4] + action[5] * action[5] + action[6] * action[6]);
   des[0] = action[0]; des[1] = action[1]; des[2] = action[2];

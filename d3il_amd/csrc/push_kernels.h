@@ -97,6 +97,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(double* __restr
 #pragma unroll
       for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
       fl = flags[e];
+      sanitize_action(act);
       make_setpoint(act, des);
     }
 #pragma clang loop unroll(disable)
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(double* __restr
       PushState ps;
       ps.arm = st; ps.box[0] = own; ps.box[1] = other;
       ps.arm.flags |= F_IK_VALID | PF_WARM_VALID | pflags | (unsigned)PTS(PT_PFLAG);
+      if (action_is_bad(actions + (size_t)ee * 7)) ps.arm.flags |= F_SOLVER_FAIL | F_TERMINATED;
       push_step_end(pc, ps, &mean_distance);
       push_store(state, flags, steps, stride, ee, ps, false);
       push_store_outputs(ps, ee, stride, o, dn, reward, mean_distance, obs, done, success, mode, info);

@@ -38,7 +38,27 @@ constexpr int PUSH_ARM0 = 12;
 constexpr int PUSH_MAXCON = 24;
 constexpr int PUSH_NH = PUSH_NV * (PUSH_NV + 1) / 2;   // 231
 constexpr int PUSH_MAXIT = 40;
-constexpr double PUSH_GRAD_TOL = 1e-10;   // gradient (generalised force) below which an iterate is accepted without a further Newton step
+// Stopping rule of the contact Newton solvers (Pushing and the generic engine), a run-time setting so that the device path can be
+// run with the oracle's rule for parity A/B tests (d3il_set_option "solver_strict"; tests/test_gpu_parity_*).
+//   grad_tol : gradient (generalised force, N / N m) below which an iterate is accepted without a further Newton step
+//              (MuJoCo: scaled gradient below `tolerance` = 1e-10)
+//   step_rel : an accepted full Newton step below step_rel (relative) ends the iteration (quadratic convergence leaves its square)
+//   ls_c2    : curvature condition of the line search |phi'(alpha)| <= ls_c2 |phi'(0)|
+//   ls_full  : the full step is taken when phi'(1) <= ls_full |phi'(0)|
+//   ls_rel   : or when the minimiser of phi is within ls_rel (relative) of alpha
+struct SolverTol { double grad_tol, step_rel, ls_c2, ls_full, ls_rel; };
+constexpr SolverTol SOLVER_TOL_PRODUCTION = {1e-10, 1e-6, D3IL_LS_C2, 0.1, 1e-3};
+constexpr SolverTol SOLVER_TOL_STRICT = {1e-13, 1e-10, 1e-6, 1e-6, 1e-9};     // the oracle iterates to round-off (scaled gradient 1e-15, exact line search)
+#if defined(__HIPCC__)
+__constant__ SolverTol g_solver_tol = {1e-10, 1e-6, D3IL_LS_C2, 0.1, 1e-3};
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define D3IL_TOL g_solver_tol
+#else
+inline SolverTol& host_solver_tol() { static SolverTol t = SOLVER_TOL_PRODUCTION; return t; }
+#define D3IL_TOL host_solver_tol()
+#endif
+#define PUSH_GRAD_TOL (D3IL_TOL.grad_tol)
 
 // f64 state fields per environment in the SoA state buffer: the 42 arm fields of Avoiding (D3IL_STATE_*), then per cube
 // pos[3] quat[4] vel[6] (linear world, angular body axes = MuJoCo free-joint qvel), then the solver warm start qacc[21]
@@ -555,8 +575,8 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc_, const double* R, co
       }
       best = alpha;
       // full Newton step: accepted on the curvature condition phi'(1) <= 0.1 |phi'(0)| (still descending, or just past the minimum)
-      if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
-      if (fabs(d1) <= D3IL_LS_C2 * fabs(gTp) || fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
+      if (ls == 0 && d1 <= D3IL_TOL.ls_full * fabs(gTp)) break;
+      if (fabs(d1) <= D3IL_TOL.ls_c2 * fabs(gTp) || fabs(d1) <= D3IL_TOL.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
@@ -573,7 +593,7 @@ D3IL_NOINLINE inline bool cube_newton(const PushConsts& pc_, const double* R, co
     for (int k = 0; k < 6; k++) { double dxk = best * p[k]; x[k] += dxk; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(x[k])); }
     // Newton converges quadratically once the full step is accepted: a step below 1e-6 (relative) leaves an error of the
     // order of its square, so the confirming iteration is skipped
-    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
   }
   return converged;
 }
@@ -798,7 +818,7 @@ D3IL_NOINLINE inline bool push_general_solve(const PushConsts& pc_, const PushSc
           for (int q = 0; q < 3; q++) d2 += jp[r] * Hc[3 * r + q] * jp[q]; }
       }
       best = alpha;
-      if (fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
+      if (fabs(d1) <= D3IL_TOL.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
@@ -817,7 +837,7 @@ D3IL_NOINLINE inline bool push_general_solve(const PushConsts& pc_, const PushSc
     }
     // Newton converges quadratically once the full step is accepted: a step below 1e-6 (relative) leaves an error of the
     // order of its square, so the confirming iteration is skipped
-    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
   }
   return converged;
 }
@@ -1403,8 +1423,8 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc_, const PushScratc
       }
       best = alpha;
       // full Newton step: accepted on the curvature condition phi'(1) <= 0.1 |phi'(0)| (still descending, or just past the minimum)
-      if (ls == 0 && d1 <= 0.1 * fabs(gTp)) break;
-      if (fabs(d1) <= D3IL_LS_C2 * fabs(gTp) || fabs(d1) <= 1e-3 * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
+      if (ls == 0 && d1 <= D3IL_TOL.ls_full * fabs(gTp)) break;
+      if (fabs(d1) <= D3IL_TOL.ls_c2 * fabs(gTp) || fabs(d1) <= D3IL_TOL.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;   // minimiser of phi within 0.1 % of alpha (any such step keeps Newton's rate), or slope at round-off level
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 * rcpd(d2);
       if (hi >= 0) {   // bracketed: Newton on alpha, bisection whenever the bracket failed to halve (phi' can be sigmoid-like)
@@ -1425,7 +1445,7 @@ D3IL_NOINLINE inline bool coupled_newton(const PushConsts& pc_, const PushScratc
     }
     // Newton converges quadratically once the full step is accepted: a step below 1e-6 (relative) leaves an error of the
     // order of its square, so the confirming iteration is skipped
-    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= 1e-6 * (1 + xmax))) converged = true;
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
   }
   return converged;
 }

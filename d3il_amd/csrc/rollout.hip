@@ -80,6 +80,7 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_step(const PandaConsts* __res
   double act[7];
 #pragma unroll
   for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
+  const bool bad_action = sanitize_action(act);
   float o[2]; unsigned char dn;
 #if defined(D3IL_DEVICE_STATS)
   unsigned long long t0 = wall_clock64();
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_step(const PandaConsts* __res
 #if defined(D3IL_DEVICE_STATS)
   if (threadIdx.x == 0 && blockIdx.x < 4096) g_dev_wave[blockIdx.x][9] = wall_clock64() - t0;
 #endif
+  if (bad_action) st.flags |= F_SOLVER_FAIL | F_TERMINATED;
   store_state(state, flags, steps, stride, e, st);
   store_outputs(st, e, o, dn, obs, done, success, mode);
 }
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
 #pragma unroll
     for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
     unsigned fl = flags[e];
+    sanitize_action(act);
     make_setpoint(act, des);
     double vwarm[7];
     vwarm[6] = 0.0; trg[0][2 * NARM][lane] = 0.0;
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
     if (lane == 0 && blockIdx.x < 4096) { g_dev_wave[blockIdx.x][9] = wall_clock64() - t0 - tw; }
 #endif
     st.flags |= F_IK_VALID;                     // set by the controller wave's first ik_update in the fused kernel
+    if (action_is_bad(actions + (size_t)e * 7)) st.flags |= F_SOLVER_FAIL | F_TERMINATED;
     step_end(c, st);
     if (live) {
       double* so = state + e;
@@ -297,6 +301,37 @@ __global__ void k_count_metrics(const unsigned char* __restrict__ done, const un
   }
 }
 
+// Episode tally of the rollout harnesses (avoiding_sim.py:45-54, pushing_sim.py:43-86, sorting_sim.py:100-133 loop over contexts and
+// trajectories and record success / mode of the step that returned done): every finished environment adds to row ctx_id[e] of an
+// int64 table [n_ctx][D3IL_TALLY_ROW]: [0] episodes, [1] successes, [2 + code] successes by mode code (Avoiding: 9-bit code,
+// Pushing: info['mode'] + 1, Sorting: np.packbits code).  Integer sums: bit-exact and order independent.
+__global__ void k_episode_tally(const unsigned char* __restrict__ done, const unsigned char* __restrict__ success, const unsigned short* __restrict__ mode,
+                                const int* __restrict__ ctx_id, long long* __restrict__ table, long long* __restrict__ episode_counts, int n, int n_ctx, int mode_bias) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n || !done[e]) return;
+  if (episode_counts) {
+    atomicAdd((unsigned long long*)&episode_counts[0], 1ull);
+    if (success[e]) atomicAdd((unsigned long long*)&episode_counts[1], 1ull);
+  }
+  if (!table) return;
+  int c = ctx_id ? ctx_id[e] : 0;
+  if (c < 0 || c >= n_ctx) return;
+  long long* row = table + (size_t)c * D3IL_TALLY_ROW;
+  atomicAdd((unsigned long long*)&row[0], 1ull);
+  if (success[e]) {
+    atomicAdd((unsigned long long*)&row[1], 1ull);
+    int code = (int)(short)mode[e] + mode_bias;
+    if (code >= 0 && code < D3IL_TALLY_ROW - 2) atomicAdd((unsigned long long*)&row[2 + code], 1ull);
+  }
+}
+// contexts of the last reset of every environment (what auto-reset starts the next trajectory of that lane from)
+__global__ void k_store_contexts(const unsigned char* __restrict__ mask, const double* __restrict__ src, double* __restrict__ dst, int n, int dim) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * dim) return;
+  if (mask && !mask[i / dim]) return;
+  dst[i] = src[i];
+}
+
 }  // namespace d3il
 
 // ====================================================================== C ABI
@@ -318,8 +353,20 @@ struct d3il_handle_s {
   int lanes;              // active lanes (environments) per wave: 64, or fewer to spread a small batch over more SIMDs
   int lds_pad;            // dynamic LDS bytes requested per workgroup: spreads the single-wave workgroups over CUs
   hipEvent_t ev0, ev1;
-  bool ev_valid;
+  bool ev_valid, ev_created;
+  int tol_mode;            // 0 production stopping rule of the contact solvers, 1 the oracle's (solver_strict)
+  double* d_ctx;           // [n][ctx_dim] context of the last reset of every environment (Pushing 14, Sorting 7 nb)
+  int ctx_dim;
+  uint8_t* d_mask;         // [stride] environments reset by the last d3il_auto_reset (buf.last_reset)
+  const int32_t* tally_ctx; int tally_nctx; int64_t* tally_table;   // caller-owned device memory (d3il_set_tally)
 };
+
+// The Pushing / Sorting kernels read their model from one __constant__ object per device (scalar loads, no pointer across call
+// boundaries: push_step.h).  Handles on one device therefore have to share the model: d3il_create refuses a different one while
+// another handle is alive (a second model would silently re-point the kernels of the first).
+struct ActiveModel { int refs; bool valid; PushConsts pc; GenConsts gc; };
+static ActiveModel g_active_push[16], g_active_gen[16];
+static int g_active_tol[16];   // solver tolerance set currently in the device's g_solver_tol (0 production)
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -331,6 +378,22 @@ const char* d3il_last_error(void) { return g_err.c_str(); }
 size_t d3il_blob_sizeof(void) { return sizeof(d3il_model_blob); }
 int d3il_version(void) { return 1; }
 
+static void free_handle(d3il_handle_s* h) {
+  if (!h) return;
+  int dev = h->device;
+  if (dev >= 0 && dev < 16) {
+    if (h->task_id == D3IL_TASK_PUSHING && g_active_push[dev].refs > 0) g_active_push[dev].refs--;
+    if (h->task_id == D3IL_TASK_SORTING && g_active_gen[dev].refs > 0) g_active_gen[dev].refs--;
+  }
+  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des,
+                  h->buf.info_f64, h->d_scratch, h->d_ctx, h->d_mask};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->ev_created) { (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); }
+  delete h;
+}
+// inside d3il_create: every failure releases what has been allocated so far
+#define HIPCHK_H(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { free_handle(h); return fail(D3IL_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+
 int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, size_t blob_len, d3il_handle* out) {
   if (!out || !model_blob) return fail(D3IL_EINVAL, "d3il_create: null argument");
   *out = nullptr;
@@ -341,16 +404,19 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING) return fail(D3IL_EUNSUPPORTED, "d3il_create: only the Avoiding, Pushing and Sorting tasks are implemented in this build");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(D3IL_ENODEVICE, "d3il_create: no HIP device available (there is no CPU fallback)");
-  if (device_id < 0 || device_id >= ndev) return fail(D3IL_ENODEVICE, "d3il_create: device_id out of range");
+  if (device_id < 0 || device_id >= ndev || device_id >= 16) return fail(D3IL_ENODEVICE, "d3il_create: device_id out of range");
   HIPCHK(hipSetDevice(device_id));
   d3il_handle_s* h = new d3il_handle_s();
   std::memset(&h->buf, 0, sizeof h->buf);
+  h->task_id = -1; h->device = device_id;      // task_id is set once the model reference is taken (free_handle)
+  h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr; h->d_ctx = nullptr; h->d_mask = nullptr; h->ev_created = false;
+  h->tally_ctx = nullptr; h->tally_nctx = 0; h->tally_table = nullptr; h->tol_mode = 0; h->ctx_dim = 0;
   const char* err = "";
   int rc = build_panda_consts(m, h->hc, &err);
-  if (rc) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  if (rc) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   finish_invweights(h->hc);
-  if (task_id == D3IL_TASK_PUSHING && build_push_consts(m, h->pc, &err)) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
-  if (task_id == D3IL_TASK_SORTING && build_gen_consts(m, h->hc, h->gc, &err)) { delete h; return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  if (task_id == D3IL_TASK_PUSHING && build_push_consts(m, h->pc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  if (task_id == D3IL_TASK_SORTING && build_gen_consts(m, h->hc, h->gc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   {  // the kernels are specialised at build time to the robot model (csrc/gen/avoiding_consts.inc): the runtime blob
      // must describe the same arm, controller and (Avoiding) obstacles.  n_substeps / max_steps stay run-time parameters.
     PandaConsts a = h->hc, b = kAvoidingConsts;
@@ -367,48 +433,81 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
       double d = pa[i] - pb[i], m = pa[i] < 0 ? -pa[i] : pa[i];
       if (!(d <= 1e-12 * (m > 1 ? m : 1) && -d <= 1e-12 * (m > 1 ? m : 1))) same = false;
     }
-    if (!same) { delete h; return fail(D3IL_EUNSUPPORTED, "d3il_create: the model blob differs from the model this library was specialised for at build time; "
-                                                           "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
+    if (!same) { free_handle(h); return fail(D3IL_EUNSUPPORTED, "d3il_create: the model blob differs from the model this library was specialised for at build time; "
+                                                                 "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
-  h->task_id = task_id; h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE; h->device = device_id;
-  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false; h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr;
   const bool pushing = task_id == D3IL_TASK_PUSHING;
   const bool sorting = task_id == D3IL_TASK_SORTING;
+  // one Pushing / Sorting model per device while handles are alive (constant memory)
+  if (pushing) {
+    ActiveModel& am = g_active_push[device_id];
+    if (am.refs > 0 && std::memcmp(&am.pc, &h->pc, sizeof(PushConsts)) != 0) {
+      free_handle(h);
+      return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Pushing handle on this device uses a different model (the kernels read one model per device from constant memory); destroy it first");
+    }
+  }
+  if (sorting) {
+    ActiveModel& am = g_active_gen[device_id];
+    if (am.refs > 0 && std::memcmp(&am.gc, &h->gc, sizeof(GenConsts)) != 0) {
+      free_handle(h);
+      return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Sorting handle on this device uses a different model, e.g. another num_boxes (the kernels read one model per device from constant memory); destroy it first");
+    }
+  }
+  h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE;
+  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false;
   h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : D3IL_STATE_F64);
+  h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : 0);
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
   b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : 2); b.action_dim = 7; b.state_rows = h->state_rows; b.n_info_f64 = pushing ? 2 : 0;
-  HIPCHK(hipMalloc(&h->dc, sizeof(PandaConsts)));
-  HIPCHK(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
-  HIPCHK(hipMalloc(&b.obs, S * b.obs_dim * sizeof(float)));
-  HIPCHK(hipMalloc(&b.done, S)); HIPCHK(hipMalloc(&b.success, S));
-  HIPCHK(hipMalloc(&b.mode, S * sizeof(uint16_t)));
-  HIPCHK(hipMalloc(&b.state, S * h->state_rows * sizeof(double)));
-  HIPCHK(hipMalloc(&b.flags, S * sizeof(uint32_t)));
-  HIPCHK(hipMalloc(&b.step_count, S * sizeof(int32_t)));
-  HIPCHK(hipMalloc(&b.policy_des, S * 3 * sizeof(double)));
-  HIPCHK(hipMemset(b.obs, 0, S * b.obs_dim * sizeof(float))); HIPCHK(hipMemset(b.done, 0, S)); HIPCHK(hipMemset(b.success, 0, S));
-  HIPCHK(hipMemset(b.mode, 0, S * sizeof(uint16_t))); HIPCHK(hipMemset(b.state, 0, S * h->state_rows * sizeof(double)));
-  HIPCHK(hipMemset(b.flags, 0, S * sizeof(uint32_t))); HIPCHK(hipMemset(b.step_count, 0, S * sizeof(int32_t)));
-  HIPCHK(hipMemset(b.policy_des, 0, S * 3 * sizeof(double)));
+  HIPCHK_H(hipMalloc(&h->dc, sizeof(PandaConsts)));
+  HIPCHK_H(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
+  HIPCHK_H(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
+  HIPCHK_H(hipMalloc(&b.obs, S * b.obs_dim * sizeof(float)));
+  HIPCHK_H(hipMalloc(&b.done, S)); HIPCHK_H(hipMalloc(&b.success, S));
+  HIPCHK_H(hipMalloc(&b.mode, S * sizeof(uint16_t)));
+  HIPCHK_H(hipMalloc(&b.state, S * h->state_rows * sizeof(double)));
+  HIPCHK_H(hipMalloc(&b.flags, S * sizeof(uint32_t)));
+  HIPCHK_H(hipMalloc(&b.step_count, S * sizeof(int32_t)));
+  HIPCHK_H(hipMalloc(&b.policy_des, S * 3 * sizeof(double)));
+  HIPCHK_H(hipMalloc(&h->d_mask, S)); HIPCHK_H(hipMemset(h->d_mask, 0, S));
+  b.last_reset = h->d_mask;
+  HIPCHK_H(hipMemset(b.obs, 0, S * b.obs_dim * sizeof(float))); HIPCHK_H(hipMemset(b.done, 0, S)); HIPCHK_H(hipMemset(b.success, 0, S));
+  HIPCHK_H(hipMemset(b.mode, 0, S * sizeof(uint16_t))); HIPCHK_H(hipMemset(b.state, 0, S * h->state_rows * sizeof(double)));
+  HIPCHK_H(hipMemset(b.flags, 0, S * sizeof(uint32_t))); HIPCHK_H(hipMemset(b.step_count, 0, S * sizeof(int32_t)));
+  HIPCHK_H(hipMemset(b.policy_des, 0, S * 3 * sizeof(double)));
+  if (h->ctx_dim) { HIPCHK_H(hipMalloc(&h->d_ctx, S * h->ctx_dim * sizeof(double))); HIPCHK_H(hipMemset(h->d_ctx, 0, S * h->ctx_dim * sizeof(double))); }
   if (pushing) {
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_push_consts), &h->pc, sizeof(PushConsts)));   // constant memory: one Pushing model per process
-    HIPCHK(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_scratch, S * PG_SIZE * sizeof(double))); HIPCHK(hipMemset(h->d_scratch, 0, S * PG_SIZE * sizeof(double)));
+    ActiveModel& am = g_active_push[device_id];
+    if (am.refs == 0) {
+      HIPCHK_H(hipDeviceSynchronize());
+      HIPCHK_H(hipMemcpyToSymbol(HIP_SYMBOL(g_push_consts), &h->pc, sizeof(PushConsts)));
+      am.pc = h->pc;
+    }
+    am.refs++; h->task_id = task_id;
+    HIPCHK_H(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
+    HIPCHK_H(hipMalloc(&h->d_scratch, S * PG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * PG_SIZE * sizeof(double)));
     // the physics wave keeps the coupled solver's tables in LDS: 137.5 KiB + the set-point exchange, above the 64 KiB default cap
-    HIPCHK(hipFuncSetAttribute((const void*)k_pushing_step_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
-    HIPCHK(hipFuncSetAttribute((const void*)k_pushing_step_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
-    HIPCHK(hipFuncSetAttribute((const void*)k_pushing_reset, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_H));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_reset, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_H));
   }
   if (sorting) {
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_gen_consts), &h->gc, sizeof(GenConsts)));   // constant memory: one Sorting model per process
-    HIPCHK(hipMalloc(&h->d_scratch, S * GG_SIZE * sizeof(double))); HIPCHK(hipMemset(h->d_scratch, 0, S * GG_SIZE * sizeof(double)));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sorting_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sorting_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sorting_reset, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_H));
+    ActiveModel& am = g_active_gen[device_id];
+    if (am.refs == 0) {
+      HIPCHK_H(hipDeviceSynchronize());
+      HIPCHK_H(hipMemcpyToSymbol(HIP_SYMBOL(g_gen_consts), &h->gc, sizeof(GenConsts)));
+      am.gc = h->gc;
+    }
+    am.refs++; h->task_id = task_id;
+    HIPCHK_H(hipMalloc(&h->d_scratch, S * GG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * GG_SIZE * sizeof(double)));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_reset, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_H));
   }
-  HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+  h->task_id = task_id;
+  HIPCHK_H(hipEventCreate(&h->ev0)); HIPCHK_H(hipEventCreate(&h->ev1));
+  h->ev_created = true;
   *out = h;
   return D3IL_OK;
 }
@@ -416,10 +515,8 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
 int d3il_destroy(d3il_handle h) {
   if (!h) return fail(D3IL_EINVAL, "d3il_destroy: null handle");
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des, h->buf.info_f64, h->d_scratch};
-  for (void* p : ptrs) (void)hipFree(p);
-  (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
-  delete h;
+  (void)hipDeviceSynchronize();
+  free_handle(h);
   return D3IL_OK;
 }
 
@@ -432,11 +529,27 @@ int d3il_start(d3il_handle h, const double* init_qpos7) {
   return D3IL_OK;
 }
 
+// the contact solvers' stopping rule lives in one __constant__ object per device; a handle whose setting differs from what is
+// loaded re-loads it on its stream before launching (handles with different settings must not run concurrently on one device)
+static int sync_solver_tol(d3il_handle_s* h, hipStream_t s) {
+  static const SolverTol k_tol[2] = {SOLVER_TOL_PRODUCTION, SOLVER_TOL_STRICT};
+  if (h->task_id == D3IL_TASK_AVOIDING || g_active_tol[h->device] == h->tol_mode) return D3IL_OK;
+  HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_solver_tol), &k_tol[h->tol_mode ? 1 : 0], sizeof(SolverTol), 0, hipMemcpyHostToDevice, s));
+  g_active_tol[h->device] = h->tol_mode;
+  return D3IL_OK;
+}
+
 int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, void* stream) {
   if (!h) return fail(D3IL_EINVAL, "d3il_reset: null handle");
   if (!h->started) return fail(D3IL_ESTATE, "d3il_reset: d3il_start() has not been called (env.start() before env.reset())");
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
+  if (int rc = sync_solver_tol(h, (hipStream_t)stream)) return rc;
+  if (h->ctx_dim && contexts && contexts != h->d_ctx) {
+    int tot = h->n * h->ctx_dim;
+    hipLaunchKernelGGL(k_store_contexts, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_mask, contexts, h->d_ctx, h->n, h->ctx_dim);
+    HIPCHK(hipGetLastError());
+  }
   if (h->task_id == D3IL_TASK_PUSHING) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Pushing task needs contexts (device f64 [n_envs][14])");
     hipLaunchKernelGGL(k_pushing_reset, dim3((h->n + PUSH_LANES - 1) / PUSH_LANES), dim3(WAVE), PUSH_LDS_H, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
@@ -464,6 +577,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = sync_solver_tol(h, s)) return rc;
   if (h->task_id == D3IL_TASK_PUSHING) {
     int nwgp = (h->n + PUSH_LANES - 1) / PUSH_LANES;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
@@ -557,16 +671,38 @@ int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }
+int d3il_set_tally(d3il_handle h, const int32_t* ctx_id_device, int n_ctx, int64_t* table_device) {
+  if (!h) return fail(D3IL_EINVAL, "d3il_set_tally: null handle");
+  if (table_device && n_ctx <= 0) return fail(D3IL_EINVAL, "d3il_set_tally: n_ctx must be positive");
+  h->tally_ctx = ctx_id_device; h->tally_nctx = n_ctx; h->tally_table = table_device;
+  return D3IL_OK;
+}
+
 int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream) {
-  if (!h || !episode_counts_device) return fail(D3IL_EINVAL, "d3il_auto_reset: null argument");
+  if (!h) return fail(D3IL_EINVAL, "d3il_auto_reset: null handle");
   if (!h->started) return fail(D3IL_ESTATE, "d3il_auto_reset: d3il_start() has not been called");
-  if (h->task_id != D3IL_TASK_AVOIDING) return fail(D3IL_EUNSUPPORTED, "d3il_auto_reset: Avoiding only (Pushing episodes are reset with their contexts through d3il_reset)");
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
-  hipLaunchKernelGGL(k_avoiding_auto_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->dc, h->d_init_qpos, b.state, b.flags, b.step_count,
-                     b.obs, b.done, b.success, b.mode, b.policy_des, (long long*)episode_counts_device, h->n, h->stride);
-  HIPCHK(hipGetLastError());
-  return D3IL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool avoiding = h->task_id == D3IL_TASK_AVOIDING;
+  // which environments this call resets (buf.last_reset): the harness re-latches its per-lane state (agent history) from it
+  HIPCHK(hipMemcpyAsync(h->d_mask, b.done, (size_t)h->n, hipMemcpyDeviceToDevice, s));
+  if (h->tally_table || (!avoiding && episode_counts_device)) {
+    // Avoiding counts its episodes in the fused reset kernel below
+    hipLaunchKernelGGL(k_episode_tally, dim3((h->n + 255) / 256), dim3(256), 0, s, b.done, b.success, b.mode, h->tally_ctx, (long long*)h->tally_table,
+                       avoiding ? (long long*)nullptr : (long long*)episode_counts_device, h->n, h->tally_nctx, h->task_id == D3IL_TASK_PUSHING ? 1 : 0);
+    HIPCHK(hipGetLastError());
+  }
+  if (avoiding) {
+    if (!episode_counts_device) return fail(D3IL_EINVAL, "d3il_auto_reset: null argument");
+    hipLaunchKernelGGL(k_avoiding_auto_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, h->d_init_qpos, b.state, b.flags, b.step_count,
+                       b.obs, b.done, b.success, b.mode, b.policy_des, (long long*)episode_counts_device, h->n, h->stride);
+    HIPCHK(hipGetLastError());
+    return D3IL_OK;
+  }
+  // Pushing / Sorting: the next trajectory of a lane starts from the context of its last reset (pushing_sim.py:63, sorting_sim.py:112)
+  if (int rc = d3il_reset(h, h->d_mask, h->d_ctx, stream)) return rc;
+  return d3il_policy_begin(h, h->d_mask, stream);
 }
 
 int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream) {
@@ -620,6 +756,7 @@ int d3il_debug_stats(uint64_t* out32, int reset) {
 int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
+  if (std::strcmp(name, "solver_strict") == 0) { h->tol_mode = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "split_waves") == 0) { h->split = value; return D3IL_OK; }
   if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }
   if (std::strcmp(name, "lanes_per_wave") == 0) { if (value < 1 || value > WAVE) return fail(D3IL_EINVAL, "lanes_per_wave must be in 1..64"); h->lanes = value; return D3IL_OK; }

@@ -72,6 +72,8 @@ class ObstacleAvoidanceVecEnv:
         self.flags = _view(b.flags, (s,), "<i4", dev, self)
         self.step_count = _view(b.step_count, (s,), "<i4", dev, self)
         self.policy_des = _view(b.policy_des, (3, s), "<f8", dev, self)
+        self.last_reset = _view(b.last_reset, (n,), "|u1", dev, self)   # environments reset by the last auto_reset()
+        self._tally = None
         self.init_qpos = None
         self._started = False
 
@@ -151,11 +153,36 @@ class ObstacleAvoidanceVecEnv:
             capi.check(self.L.d3il_policy_action(self.h, int(seed), int(env_offset), int(t), C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
-    def auto_reset(self, episode_counts: torch.Tensor):
-        """Reset every finished env, re-latch the random-policy set-point, episode_counts (int64[2]) += (finished, successes)."""
-        assert episode_counts.dtype == torch.int64 and episode_counts.numel() >= 2 and episode_counts.device == self.device
+    def auto_reset(self, episode_counts: torch.Tensor | None = None):
+        """Start the next trajectory in every finished lane: reset it (Pushing / Sorting: with the context of its last reset),
+        re-latch the harness set-point ``policy_des`` := TCP, episode_counts (int64[2]) += (finished, successes), add the
+        episode to the tally table when one is set; ``last_reset`` marks the lanes that were reset.  No host synchronisation."""
+        if episode_counts is None:
+            if self.task == "avoiding":
+                raise ValueError("the Avoiding auto-reset needs episode_counts (int64[2] on the env's device)")
+            ptr = None
+        else:
+            assert episode_counts.dtype == torch.int64 and episode_counts.numel() >= 2 and episode_counts.device == self.device
+            ptr = C.c_void_p(episode_counts.data_ptr())
         with torch.cuda.device(self.device):
-            capi.check(self.L.d3il_auto_reset(self.h, C.c_void_p(episode_counts.data_ptr()), self._stream()))
+            capi.check(self.L.d3il_auto_reset(self.h, ptr, self._stream()))
+
+    def set_tally(self, n_ctx: int = 1, ctx_id: torch.Tensor | None = None):
+        """Per-context episode tally filled by auto_reset(): returns the int64 [n_ctx, 514] table (episodes, successes, successes by
+        mode code; include/d3il_rollout.h).  ctx_id: int32[n_envs] context index of every lane (None: one context)."""
+        table = torch.zeros(int(n_ctx), capi.TALLY_ROW, dtype=torch.int64, device=self.device)
+        cp = None
+        if ctx_id is not None:
+            ctx_id = ctx_id.to(device=self.device, dtype=torch.int32).contiguous()
+            assert ctx_id.numel() == self.n_envs
+            cp = C.c_void_p(ctx_id.data_ptr())
+        capi.check(self.L.d3il_set_tally(self.h, cp, int(n_ctx), C.c_void_p(table.data_ptr())))
+        self._tally = (table, ctx_id)            # keeps the device memory alive while the library holds the pointers
+        return table
+
+    def clear_tally(self):
+        capi.check(self.L.d3il_set_tally(self.h, None, 0, None))
+        self._tally = None
 
     def count_metrics(self, out: torch.Tensor | None = None):
         if out is None:

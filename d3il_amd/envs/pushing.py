@@ -105,8 +105,5 @@ class BlockPushVecEnv(ObstacleAvoidanceVecEnv):
     def mode_encoding(self):
         return self.mode
 
-    def auto_reset(self, episode_counts):
-        raise capi.D3ilError("auto_reset is an Avoiding harness helper; Pushing episodes are reset with their contexts")
-
     def count_metrics(self, out=None):
         raise capi.D3ilError("count_metrics is Avoiding only; see simulation/pushing_sim.py for the Pushing metrics")

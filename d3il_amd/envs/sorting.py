@@ -111,8 +111,5 @@ class SortingVecEnv(ObstacleAvoidanceVecEnv):
     def mode_encoding(self):
         return self.mode
 
-    def auto_reset(self, episode_counts):
-        raise capi.D3ilError("auto_reset is an Avoiding harness helper; Sorting episodes are reset with their contexts")
-
     def count_metrics(self, out=None):
         raise capi.D3ilError("count_metrics is Avoiding only; see simulation/metrics.py:sorting_metrics for the Sorting metrics")

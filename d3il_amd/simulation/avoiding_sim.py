@@ -20,6 +20,7 @@ import torch
 
 from ..distributed import reduce_counts, shard_range, world_info
 from ..envs.avoiding import ObstacleAvoidanceVecEnv
+from ..agents import as_batched
 from .base_sim import BaseSim
 from .metrics import avoiding_metrics
 
@@ -35,12 +36,7 @@ class Avoiding_Sim(BaseSim):
         self.last_rollout = None
 
     def _predict(self, agent, obs4: torch.Tensor) -> torch.Tensor:
-        if hasattr(agent, "predict_batch"):
-            out = agent.predict_batch(obs4)
-            return out.to(device=obs4.device, dtype=torch.float64).reshape(obs4.shape[0], 2)
-        rows = obs4.detach().cpu().numpy()
-        acts = np.stack([np.asarray(agent.predict(r)).reshape(-1)[:2] for r in rows])
-        return torch.as_tensor(acts, dtype=torch.float64, device=obs4.device)
+        return agent.predict_batch(obs4).to(device=obs4.device, dtype=torch.float64).reshape(obs4.shape[0], 2)
 
     def test_agent(self, agent):
         log.info("Starting trained model evaluation")
@@ -48,14 +44,8 @@ class Avoiding_Sim(BaseSim):
         lo, hi = shard_range(self.n_trajectories, rank, world)
         n = hi - lo
         dev = torch.device(self.device)
-        env = ObstacleAvoidanceVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
-        env.start()
-        if hasattr(agent, "reset"):
-            agent.reset()
-        obs = env.reset()
-        pred_action = env.robot_state().clone()                       # TCP xyz, avoiding_sim.py:53
-        fixed_z = pred_action[:, 2:3].clone()
-        des_xy = pred_action[:, :2].clone()
+        agent = as_batched(agent, n)
+        agent.reset()
         quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
         finished = torch.zeros(n, dtype=torch.bool, device=dev)
         mode_code = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -63,25 +53,35 @@ class Avoiding_Sim(BaseSim):
         # the reference stores c_pos in a 150-row buffer and crashes on longer episodes (avoiding_sim.py:73,87);
         # this buffer is sized max_steps + 1 instead (documented divergence)
         c_pos = torch.zeros(n, self.max_steps_per_episode + 1, 2, dtype=torch.float64, device=dev)
-        c_pos[:, 0] = env.robot_state()[:, :2]
         n_pos = torch.ones(n, dtype=torch.int64, device=dev)
-        for t in range(self.max_steps_per_episode):
-            # avoiding_sim.py:61: np.concatenate((f64 desired xy, f32 obs)) -> f64[4]
-            obs4 = torch.cat((des_xy, obs.to(torch.float64)), dim=1)
-            delta = self._predict(agent, obs4)
-            des_new = delta + obs4[:, :2]                              # avoiding_sim.py:64
-            des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
-            action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
-            obs, _, done, (mode, succ) = env.step(action)
-            active = ~finished
-            c_pos[torch.arange(n, device=dev)[active], n_pos[active]] = env.robot_state()[active, :2]
-            n_pos += active.to(torch.int64)
-            newly = active & done.bool()
-            mode_code = torch.where(newly, mode.to(torch.int32), mode_code)
-            success = torch.where(newly, succ.bool(), success)
-            finished |= done.bool()
-            if bool(finished.all()):
-                break
+        env = None
+        if n > 0:      # a rank whose shard is empty (n_trajectories < world size) only takes part in the reductions below
+            env = ObstacleAvoidanceVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
+            env.start()
+            obs = env.reset()
+            pred_action = env.robot_state().clone()                       # TCP xyz, avoiding_sim.py:53
+            fixed_z = pred_action[:, 2:3].clone()
+            des_xy = pred_action[:, :2].clone()
+            c_pos[:, 0] = env.robot_state()[:, :2]
+            rows = torch.arange(n, device=dev)
+            for t in range(self.max_steps_per_episode):
+                # avoiding_sim.py:61: np.concatenate((f64 desired xy, f32 obs)) -> f64[4]
+                obs4 = torch.cat((des_xy, obs.to(torch.float64)), dim=1)
+                delta = self._predict(agent, obs4)
+                des_new = delta + obs4[:, :2]                              # avoiding_sim.py:64
+                des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
+                action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
+                obs, _, done, (mode, succ) = env.step(action)
+                active = ~finished
+                # no boolean-mask indexing (its size is a host sync): finished lanes rewrite their last row with itself
+                c_pos[rows, n_pos] = torch.where(active.unsqueeze(1), env.robot_state()[:, :2], c_pos[rows, n_pos])
+                n_pos += active.to(torch.int64)
+                newly = active & done.bool()
+                mode_code = torch.where(newly, mode.to(torch.int32), mode_code)
+                success = torch.where(newly, succ.bool(), success)
+                finished |= done.bool()
+                if t % 16 == 15 and bool(finished.all()):                  # the only host synchronisation of the loop
+                    break
         counts = torch.zeros(514, dtype=torch.int64, device=dev)
         counts[0] = n
         counts[1] = success.sum()
@@ -97,5 +97,6 @@ class Avoiding_Sim(BaseSim):
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(successes)
-        env.close()
+        if env is not None:
+            env.close()
         return successes, entropy

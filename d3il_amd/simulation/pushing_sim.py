@@ -19,6 +19,7 @@ import torch
 
 from ..distributed import shard_range, world_info
 from ..envs.pushing import BlockPushVecEnv, contexts_from_reference
+from ..agents import as_batched
 from .base_sim import BaseSim
 from .metrics import pushing_metrics
 
@@ -46,11 +47,7 @@ class Pushing_Sim(BaseSim):
         self.last_rollout = None
 
     def _predict(self, agent, obs10: torch.Tensor) -> torch.Tensor:
-        if hasattr(agent, "predict_batch"):
-            return agent.predict_batch(obs10).to(device=obs10.device, dtype=torch.float64).reshape(obs10.shape[0], 2)
-        rows = obs10.detach().cpu().numpy()
-        acts = np.stack([np.asarray(agent.predict(r)).reshape(-1)[:2] for r in rows])
-        return torch.as_tensor(acts, dtype=torch.float64, device=obs10.device)
+        return agent.predict_batch(obs10).to(device=obs10.device, dtype=torch.float64).reshape(obs10.shape[0], 2)
 
     def test_agent(self, agent):
         log.info("Starting trained model evaluation")
@@ -60,33 +57,36 @@ class Pushing_Sim(BaseSim):
         n = hi - lo
         dev = torch.device(self.device)
         ctx_of = torch.arange(lo, hi, device=dev) // self.n_trajectories_per_context          # context index of each rollout
-        env = BlockPushVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
-        env.start()
-        if hasattr(agent, "reset"):
-            agent.reset()
-        obs = env.reset(random=False, context=self.contexts[ctx_of.cpu().numpy()])
-        pred_action = env.robot_state().clone()                        # pushing_sim.py:69-70
-        fixed_z = pred_action[:, 2:3].clone()
-        des_xy = pred_action[:, :2].clone()
+        agent = as_batched(agent, n)
+        agent.reset()
         quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
         finished = torch.zeros(n, dtype=torch.bool, device=dev)
         mode = torch.full((n,), -1, dtype=torch.int64, device=dev)
         success = torch.zeros(n, dtype=torch.bool, device=dev)
         mean_distance = torch.zeros(n, dtype=torch.float64, device=dev)
-        for t in range(self.max_steps_per_episode):
-            obs10 = torch.cat((des_xy, obs.to(torch.float64)), dim=1)   # np.concatenate((pred_action[:2], obs)), pushing_sim.py:75
-            delta = self._predict(agent, obs10)
-            des_new = delta + obs10[:, :2]                              # pushing_sim.py:78
-            des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
-            action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
-            obs, _, done, info = env.step(action)
-            newly = ~finished & done.bool()
-            mode = torch.where(newly, info["mode"].to(torch.int64), mode)
-            success = torch.where(newly, info["success"].bool(), success)
-            mean_distance = torch.where(newly, info["mean_distance"], mean_distance)
-            finished |= done.bool()
-            if t % 16 == 15 and bool(finished.all()):
-                break
+        env, flags = None, torch.zeros(0, dtype=torch.int32, device=dev)
+        if n > 0:      # a rank whose shard is empty (fewer rollouts than ranks) only takes part in the reductions below
+            env = BlockPushVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
+            env.start()
+            obs = env.reset(random=False, context=self.contexts[ctx_of.cpu().numpy()])
+            pred_action = env.robot_state().clone()                        # pushing_sim.py:69-70
+            fixed_z = pred_action[:, 2:3].clone()
+            des_xy = pred_action[:, :2].clone()
+            for t in range(self.max_steps_per_episode):
+                obs10 = torch.cat((des_xy, obs.to(torch.float64)), dim=1)   # np.concatenate((pred_action[:2], obs)), pushing_sim.py:75
+                delta = self._predict(agent, obs10)
+                des_new = delta + obs10[:, :2]                              # pushing_sim.py:78
+                des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
+                action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
+                obs, _, done, info = env.step(action)
+                newly = ~finished & done.bool()
+                mode = torch.where(newly, info["mode"].to(torch.int64), mode)
+                success = torch.where(newly, info["success"].bool(), success)
+                mean_distance = torch.where(newly, info["mean_distance"], mean_distance)
+                finished |= done.bool()
+                if t % 16 == 15 and bool(finished.all()):                  # the only host synchronisation of the loop
+                    break
+            flags = env.flags[:n].clone()
         # integer tables: mode counts of the successful rollouts per context, number of successes; f64 distance sum
         counts = torch.zeros(self.n_contexts * 4 + 1, dtype=torch.int64, device=dev)
         ok = success & (mode >= 0)
@@ -101,9 +101,10 @@ class Pushing_Sim(BaseSim):
         success_rate, entropy, mode_probs = pushing_metrics(c[:-1].reshape(self.n_contexts, 4), int(c[-1]), total, self.n_trajectories_per_context)
         self.last_rollout = dict(mode=mode, success=success, mean_distance=mean_distance, counts=c, shard=(lo, hi),
                                  success_rate=success_rate, entropy=entropy, mode_probs=mode_probs,
-                                 mean_distance_all=float(dist_sum.item()) / total, flags=env.flags[:n].clone())
+                                 mean_distance_all=float(dist_sum.item()) / total, flags=flags)
         log.info("Successrate %s entropy %s mean distance %s", success_rate, entropy, float(dist_sum.item()) / total)
-        env.close()
+        if env is not None:
+            env.close()
         # the reference returns the full [n_contexts, n_trajectories] tables (pushing_sim.py:178): every rank fills its slice of a
         # zero table and the slices are summed (one more small all-reduce, outside the rollout)
         full = torch.zeros(3, total, dtype=torch.float64, device=dev)

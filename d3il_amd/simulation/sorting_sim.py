@@ -23,6 +23,7 @@ import torch
 
 from ..distributed import shard_range, world_info
 from ..envs.sorting import SortingVecEnv, contexts_from_reference, sample_contexts
+from ..agents import as_batched
 from .base_sim import BaseSim
 from .metrics import sorting_metrics
 
@@ -65,11 +66,7 @@ class Sorting_Sim(BaseSim):
         self.last_rollout = None
 
     def _predict(self, agent, obs_in: torch.Tensor) -> torch.Tensor:
-        if hasattr(agent, "predict_batch"):
-            return agent.predict_batch(obs_in).to(device=obs_in.device, dtype=torch.float64).reshape(obs_in.shape[0], 2)
-        rows = obs_in.detach().cpu().numpy()
-        acts = np.stack([np.asarray(agent.predict(r)).reshape(-1)[:2] for r in rows])
-        return torch.as_tensor(acts, dtype=torch.float64, device=obs_in.device)
+        return agent.predict_batch(obs_in).to(device=obs_in.device, dtype=torch.float64).reshape(obs_in.shape[0], 2)
 
     def test_agent(self, agent):
         log.info("Starting trained model evaluation")
@@ -79,36 +76,40 @@ class Sorting_Sim(BaseSim):
         n = hi - lo
         dev = torch.device(self.device)
         ctx_of = torch.arange(lo, hi, device=dev) // self.n_trajectories_per_context
-        env = SortingVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode, num_boxes=self.num_box)
-        env.start()
-        if hasattr(agent, "reset"):
-            agent.reset()
-        obs = env.reset(random=False, context=self.test_contexts[ctx_of.cpu().numpy()])
-        pred_action = env.robot_state().clone()                        # sorting_sim.py:120-121
-        fixed_z = pred_action[:, 2:3].clone()
-        des_xy = pred_action[:, :2].clone()
+        agent = as_batched(agent, n)
+        agent.reset()
         quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
         finished = torch.zeros(n, dtype=torch.bool, device=dev)
         mode = torch.zeros(n, dtype=torch.int64, device=dev)
         success = torch.zeros(n, dtype=torch.bool, device=dev)
-        for t in range(self.max_steps_per_episode):
-            obs_in = torch.cat((des_xy, obs.to(torch.float64)), dim=1)  # np.concatenate((pred_action[:2], obs)), sorting_sim.py:124
-            delta = self._predict(agent, obs_in)
-            des_new = delta + obs_in[:, :2]                             # sorting_sim.py:127
-            des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
-            action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
-            obs, _, done, info = env.step(action)
-            newly = ~finished & done.bool()
-            mode = torch.where(newly, info["mode"].to(torch.int64), mode)
-            success = torch.where(newly, info["success"].bool(), success)
-            finished |= done.bool()
-            if t % 16 == 15 and bool(finished.all()):
-                break
+        env, flags = None, torch.zeros(0, dtype=torch.int32, device=dev)
+        if n > 0:      # a rank whose shard is empty (fewer rollouts than ranks) only takes part in the reductions below
+            env = SortingVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode, num_boxes=self.num_box)
+            env.start()
+            obs = env.reset(random=False, context=self.test_contexts[ctx_of.cpu().numpy()])
+            pred_action = env.robot_state().clone()                        # sorting_sim.py:120-121
+            fixed_z = pred_action[:, 2:3].clone()
+            des_xy = pred_action[:, :2].clone()
+            for t in range(self.max_steps_per_episode):
+                obs_in = torch.cat((des_xy, obs.to(torch.float64)), dim=1)  # np.concatenate((pred_action[:2], obs)), sorting_sim.py:124
+                delta = self._predict(agent, obs_in)
+                des_new = delta + obs_in[:, :2]                             # sorting_sim.py:127
+                des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
+                action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
+                obs, _, done, info = env.step(action)
+                newly = ~finished & done.bool()
+                mode = torch.where(newly, info["mode"].to(torch.int64), mode)
+                success = torch.where(newly, info["success"].bool(), success)
+                finished |= done.bool()
+                if t % 16 == 15 and bool(finished.all()):                  # the only host synchronisation of the loop
+                    break
+            flags = env.flags[:n].clone()
         # integer table: per context, successful rollouts whose mode code is the k-th key of the prior; number of successes
         keys = torch.as_tensor(self.mode_keys, dtype=torch.int64, device=dev)
         hit = (mode.unsqueeze(1) == keys.unsqueeze(0)) & success.unsqueeze(1)                 # [n, n_mode]
         counts = torch.zeros(self.n_contexts * self.n_mode + 1, dtype=torch.int64, device=dev)
-        counts[:-1].index_add_(0, (ctx_of.unsqueeze(1) * self.n_mode + torch.arange(self.n_mode, device=dev).unsqueeze(0))[hit], torch.ones(int(hit.sum()), dtype=torch.int64, device=dev))
+        slot = (ctx_of.unsqueeze(1) * self.n_mode + torch.arange(self.n_mode, device=dev).unsqueeze(0)).reshape(-1)
+        counts[:-1].index_add_(0, slot, hit.reshape(-1).to(torch.int64))
         counts[-1] = success.sum()
         mode_hist = torch.bincount(mode.clamp(0, 255), minlength=256)       # all rollouts, by final mode code (diagnostics)
         if world > 1:
@@ -118,8 +119,9 @@ class Sorting_Sim(BaseSim):
         c = counts.cpu().numpy()
         success_rate, entropy, kl, score = sorting_metrics(c[:-1].reshape(self.n_contexts, self.n_mode), int(c[-1]), total, self.n_trajectories_per_context,
                                                            self.mode_encoding.numpy())
-        self.last_rollout = dict(mode=mode, success=success, counts=c, mode_hist=mode_hist.cpu().numpy(), shard=(lo, hi), flags=env.flags[:n].clone())
+        self.last_rollout = dict(mode=mode, success=success, counts=c, mode_hist=mode_hist.cpu().numpy(), shard=(lo, hi), flags=flags)
         log.info("Successrate %s entropy %s KL %s", success_rate, entropy, kl)
-        env.close()
+        if env is not None:
+            env.close()
         # the quantities the reference logs (sorting_sim.py:209-212)
         return {"score": score, "Metrics/successes": success_rate, "Metrics/KL": kl, "Metrics/entropy": entropy}

@@ -58,7 +58,9 @@ enum {
   D3IL_FLAG_MODE_MASK = 0x1FF,       /* 9 sticky mode bits, avoiding.py:173-202 */
   D3IL_FLAG_L1 = 1 << 9, D3IL_FLAG_L2 = 1 << 10, D3IL_FLAG_L3 = 1 << 11,
   D3IL_FLAG_TERMINATED = 1 << 12, D3IL_FLAG_SUCCESS = 1 << 13, D3IL_FLAG_ROD_CONTACT = 1 << 14,
-  D3IL_FLAG_IK_VALID = 1 << 15, D3IL_FLAG_SOLVER_FAIL = 1 << 16, D3IL_FLAG_MULTI_CONTACT = 1 << 17,
+  D3IL_FLAG_IK_VALID = 1 << 15,
+  D3IL_FLAG_SOLVER_FAIL = 1 << 16,   /* a solver did not converge, or the action held NaN / Inf (the step then ran on a fixed safe set-point and the episode is terminated) */
+  D3IL_FLAG_MULTI_CONTACT = 1 << 17,
   /* Pushing reuses TERMINATED / SUCCESS / IK_VALID / SOLVER_FAIL and replaces the low bits: */
   D3IL_PFLAG_FIRST_MASK = 0x7,       /* first_visit + 1 (pushing.py:341-377) */
   D3IL_PFLAG_MODE_MASK = 0x38,       /* (mode + 1) << 3 */
@@ -79,6 +81,7 @@ typedef struct d3il_buffers {
   double* policy_des;    /* [3][stride] random-policy harness state: desired x, y and fixed z */
   double* info_f64;      /* [n_info_f64][stride] extra f64 step outputs; Pushing: info['mean_distance'], reward (pushing.py:335-407) */
   int32_t n_info_f64, state_rows;   /* state_rows: f64 state fields per environment (42 Avoiding, 89 Pushing) */
+  uint8_t* last_reset;   /* [n_envs] environments reset by the last d3il_auto_reset (non-zero): per-lane harness / agent state re-latches from it */
 } d3il_buffers;
 
 /* Replaces: env construction + scene.start() (avoiding.py:52-92, core/Scene.py:95-108,
@@ -116,10 +119,20 @@ int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, co
 int d3il_policy_begin(d3il_handle h, const uint8_t* env_mask, void* stream);
 int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, void* stream);
 
-/* Vectorised-env auto-reset: every environment whose `done` flag is set is reset (as d3il_reset with mask = done), the
- * random-policy harness re-latches its desired pose, and episode_counts (device i64[2]) += {finished, successful}
- * episodes.  Counterpart of starting the next trajectory in the rollout loop (avoiding_sim.py:45-54). */
+/* Vectorised-env auto-reset: every environment whose `done` flag is set is reset (as d3il_reset with mask = done; Pushing /
+ * Sorting: with the context of that environment's last d3il_reset), the harness re-latches its desired pose (policy_des := TCP,
+ * avoiding_sim.py:53-54, pushing_sim.py:69-70, sorting_sim.py:120-121), episode_counts (device i64[2], may be NULL for
+ * Pushing / Sorting) += {finished, successful} episodes, and buf.last_reset marks the environments that were reset.
+ * Counterpart of starting the next trajectory in the rollout loops (avoiding_sim.py:45-54, pushing_sim.py:43-66). */
 int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream);
+
+/* Per-context episode tally, filled by d3il_auto_reset before it resets: table i64 [n_ctx][D3IL_TALLY_ROW] (caller-owned device
+ * memory, caller zeroes it), row ctx_id[env] (device i32[n_envs]; NULL = row 0) += {episodes, successes, successes by mode code}
+ * with the mode code = Avoiding: 9-bit mode encoding; Pushing: info['mode'] + 1; Sorting: np.packbits code.  These are the
+ * integer tables the metric tails work from (avoiding_sim.py:128-135, pushing_sim.py:140-167, sorting_sim.py:191-208) and the
+ * input of the single cross-GPU all-reduce.  table = NULL switches the tally off. */
+enum { D3IL_TALLY_ROW = 2 + 512 };
+int d3il_set_tally(d3il_handle h, const int32_t* ctx_id_device, int n_ctx, int64_t* table_device);
 
 /* Integer metric counts on device: out_counts i64[2 + 512] = {n_done, n_success, histogram of 9-bit mode codes
  * among successful envs}; input to the cross-GPU reduction (one RCCL all-reduce, done by the Python layer)
@@ -131,7 +144,9 @@ int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream);
 int d3il_set_timing(d3il_handle h, int enabled);
 int d3il_last_step_ms(d3il_handle h, float* ms);
 
-int d3il_set_option(d3il_handle h, const char* name, int value);  /* "ik_fast_path" (default 1), "split_waves" (-1 auto, 0, 1), "lanes_per_wave", "lds_pad_bytes" */
+/* "ik_fast_path" (default 1), "split_waves" (-1 auto, 0, 1), "lanes_per_wave", "lds_pad_bytes";
+ * "solver_strict" (default 0): 1 = the contact solvers of Pushing / Sorting iterate to round-off like the CPU oracle (parity A/B) */
+int d3il_set_option(d3il_handle h, const char* name, int value);
 /* Diagnostics builds only (-DD3IL_DEVICE_STATS): per-path lane/wave counters of the step kernel. */
 int d3il_debug_stats(uint64_t* out32, int reset);
 int d3il_debug_wave_stats(uint64_t* out_nwaves_x10, int nwaves, int reset);
