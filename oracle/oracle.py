@@ -127,6 +127,13 @@ class Oracle:
     def solver_iter(self):
         return self.L.orc_solver_iter(self.h)
 
+    def grad_at(self, x):
+        """Optimality residual (gradient of the constraint problem of the last forward pass) at acceleration x."""
+        x = np.ascontiguousarray(x, float)
+        g = np.zeros(self.nv)
+        self.L.orc_grad_at(self.h, _p(x), _p(g))
+        return g
+
     def pairs(self, supported=True):
         out = np.zeros((1024, 2), dtype=np.int32)
         fn = self.L.orc_supported_pairs if supported else self.L.orc_unsupported_pairs

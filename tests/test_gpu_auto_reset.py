@@ -1,0 +1,125 @@
+"""Device auto-reset with per-context episode tally (Pushing / Sorting), the guards added in round 2 (NaN actions, one model per
+device, empty handles) - through the C ABI on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "ref_offline_ik.npz"))
+
+
+def _action(des, z):
+    quat = torch.tensor([0.0, 1, 0, 0], dtype=torch.float64, device=des.device).expand(des.shape[0], 4)
+    return torch.cat([des, z, quat], dim=1).contiguous()
+
+
+def test_pushing_auto_reset_restarts_finished_lanes_from_their_context():
+    from d3il_amd import capi
+    from d3il_amd.envs.pushing import BlockPushVecEnv
+    ctx60 = np.load(os.path.join(ROOT, "d3il_amd", "data", "pushing_test_contexts.npy"))
+    n = 90
+    ids = np.arange(n) % 7
+    env = BlockPushVecEnv(n, device=0, max_steps_per_episode=6)
+    env.set_init_qpos(G["avoiding__traj_last"].copy())
+    env.reset(context=ctx60[ids])
+    torch.cuda.synchronize()
+    st_reset, fl_reset, _ = env.get_state()
+    table = env.set_tally(7, torch.as_tensor(ids, dtype=torch.int32))
+    # stagger: lane i is i % 6 steps into its episode
+    env.step_count[:n] = torch.as_tensor(np.arange(n) % 6, dtype=torch.int32, device=env.device)
+    env.policy_begin()
+    counts = torch.zeros(2, dtype=torch.int64, device=env.device)
+    finished_total = 0
+    for t in range(9):
+        des = env.policy_des[:2, :n].t().clone() + 0.001
+        env.policy_des[:2, :n] = des.t()
+        env.step(_action(des, env.policy_des[2:3, :n].t().clone()))
+        done = env.done.clone().cpu().numpy().astype(bool)
+        env.auto_reset(counts)
+        torch.cuda.synchronize()
+        finished_total += int(done.sum())
+        st, fl, sc = env.get_state()
+        np.testing.assert_array_equal(env.last_reset.cpu().numpy().astype(bool), done)
+        assert np.all(sc[done] == 0) and not env.done.any()
+        # a lane that was reset is bit-identical to the state d3il_reset produced for its context
+        np.testing.assert_array_equal(st[:68][:, done], st_reset[:68][:, done])
+        # and its harness set-point is re-latched to the TCP
+        np.testing.assert_array_equal(env.policy_des[:3, :n].cpu().numpy()[:, done], st[25:28][:, done])
+    tb = table.cpu().numpy()
+    assert int(counts[0]) == finished_total == int(tb[:, 0].sum()) and finished_total >= n
+    # every context row has counted its own lanes only
+    lanes_per_ctx = np.bincount(ids, minlength=7)
+    assert np.all(tb[:, 0] >= lanes_per_ctx) and tb[:, 1].sum() == int(counts[1]) == 0
+    assert not (fl & (capi.FLAG_SOLVER_FAIL | capi.PFLAG_CON_OVERFLOW)).any()
+    env.close()
+
+
+def test_sorting_auto_reset_and_tally_codes():
+    from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
+    n = 40
+    ctx = sample_contexts(n, 4, seed=2)
+    env = SortingVecEnv(n, device=0, max_steps_per_episode=4)
+    env.set_init_qpos(G["sorting__traj_last"].copy())
+    env.reset(context=ctx)
+    torch.cuda.synchronize()
+    st_reset, _, _ = env.get_state()
+    table = env.set_tally(1)
+    env.policy_begin()
+    z = env.robot_state()[:, 2:3].clone()
+    des = env.obs[:, :2].to(torch.float64).clone()
+    for t in range(4):
+        env.step(_action(des, z))
+    assert bool(env.done.all())
+    env.auto_reset()
+    torch.cuda.synchronize()
+    st, fl, sc = env.get_state()
+    np.testing.assert_array_equal(st[:94], st_reset[:94])
+    assert np.all(sc == 0) and (env.mode.cpu().numpy() == 240).all()
+    tb = table.cpu().numpy()
+    assert tb[0, 0] == n and tb[0, 1] == 0 and tb[0, 2:].sum() == 0
+    env.close()
+
+
+def test_nan_action_is_flagged_not_propagated():
+    from d3il_amd import capi
+    from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
+    from d3il_amd.envs.pushing import BlockPushVecEnv
+    ctx60 = np.load(os.path.join(ROOT, "d3il_amd", "data", "pushing_test_contexts.npy"))
+    for cls in (ObstacleAvoidanceVecEnv, BlockPushVecEnv):
+        n = 70
+        env = cls(n, device=0)
+        env.set_init_qpos(G["avoiding__traj_last"].copy())
+        if cls is BlockPushVecEnv:
+            env.reset(context=ctx60[np.arange(n) % 60])
+        else:
+            env.reset()
+        rs = env.robot_state().clone()
+        act = _action(rs[:, :2].clone(), rs[:, 2:3].clone())
+        act[3, 1] = float("nan"); act[64, 0] = float("inf")
+        env.step(act)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        assert np.isfinite(st[:42]).all()
+        bad = (fl & capi.FLAG_SOLVER_FAIL) != 0
+        assert bad[3] and bad[64] and bad.sum() == 2
+        assert (fl[[3, 64]] & capi.FLAG_TERMINATED).all()
+        env.step(_action(rs[:, :2].clone(), rs[:, 2:3].clone()))
+        torch.cuda.synchronize()
+        assert env.done.cpu().numpy()[[3, 64]].all() and env.done.sum() == 2
+        env.close()
+
+
+def test_second_sorting_model_on_a_device_is_refused_while_the_first_lives():
+    from d3il_amd import capi
+    from d3il_amd.envs.sorting import SortingVecEnv
+    a = SortingVecEnv(8, device=0, num_boxes=4)
+    with pytest.raises(capi.D3ilError, match="different model"):
+        SortingVecEnv(8, device=0, num_boxes=2)
+    b = SortingVecEnv(8, device=0, num_boxes=4)       # the same model is fine
+    a.close(); b.close()
+    c = SortingVecEnv(8, device=0, num_boxes=2)       # and a different one once no handle is alive
+    c.close()

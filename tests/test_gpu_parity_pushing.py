@@ -98,12 +98,59 @@ def test_bounded_horizon_rollout_matches_oracle(ctx60, init_qpos, pushing_blob, 
     env.close()
 
 
-def test_one_step_parity_from_mid_episode_states(ctx60, init_qpos, pushing_blob):
-    """States sampled along a GPU rollout (rest, rod contact, cube-cube contact) are loaded into the oracle; one env step
-    with the same action must agree."""
+def test_north_star_horizon_of_free_running_rollouts(ctx60, init_qpos, pushing_blob):
+    """Free-running rollouts (no state re-synchronisation) against the oracle, ALL state rows incl. velocities: the north star's
+    1e-4 must hold through reset transient, approach and the first pushes (>= 40 env steps = 1400 sub-steps in every followed
+    environment); the horizon at which each threshold is first exceeded is recorded.  Beyond it the two are different valid
+    rollouts of a chaotic contact system (a rocking cube amplifies 1e-16 by x1.5-2 per env step)."""
     from oracle.oracle import Oracle
     n = 120
     env = _env(n)
+    env.set_init_qpos(init_qpos)
+    ctx = ctx60[np.arange(n) % 60]
+    env.reset(context=ctx)
+    follow = {}
+    for e in (0, 7, 33, 61, 90, 119):
+        o = Oracle(pushing_blob); o.env_start(init_qpos); o.push_reset(ctx[e]); follow[e] = o
+    horizon = {e: {} for e in follow}
+    des = env.robot_state()[:, :2].clone()
+    z = env.robot_state()[:, 2:3].clone()
+    T = 80
+    for t in range(T):
+        des = _chase(env, des)
+        act = _action(des, z)
+        env.step(act)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        assert not (fl & BAD).any()
+        a = act.cpu().numpy()
+        for e, o in follow.items():
+            o.push_step(a[e])
+            so, _ = o.push_state()
+            err = float(np.abs(st[:68, e] - so).max())
+            for thr in (1e-8, 1e-6, 1e-4):
+                if err > thr and thr not in horizon[e]:
+                    horizon[e][thr] = t
+    h4 = [horizon[e].get(1e-4, T) for e in follow]
+    print("pushing horizons (1e-8 / 1e-6 / 1e-4): %s" % {e: tuple(horizon[e].get(k, T) for k in (1e-8, 1e-6, 1e-4)) for e in follow})
+    assert min(h4) >= 40, horizon
+    env.close()
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+def test_one_step_parity_from_mid_episode_states(ctx60, init_qpos, pushing_blob, strict):
+    """States sampled along a GPU rollout (rest, rod contact, cube-cube contact) are loaded into the oracle; one env step
+    (35 sub-steps) with the same action must agree on ALL state rows, velocities included, far inside the north star's 1e-4.
+
+    What bounds the agreement: not the device solvers' stopping rule - the run with the oracle's rule
+    (solver_strict = 1) gives the same numbers - but the conditioning of the soft-contact problem itself: contact rows carry
+    D ~ 1e6 .. 1e7 against a cube inertia of 3e-5 kg m^2, so a round-off level residual (1e-8 N, the size of the oracle's OWN
+    optimality residual at its solution, tests/test_parity_conditioning.py) moves the cube's angular acceleration by 1e-6 .. 1e-5
+    rad/s^2: 3.5e-8 rad/s per sub-step, 2 .. 4e-7 per env step between any two correct f64 implementations."""
+    from oracle.oracle import Oracle
+    n = 120
+    env = _env(n)
+    env.set_option("solver_strict", strict)
     env.set_init_qpos(init_qpos)
     ctx = ctx60[np.arange(n) % 60]
     env.reset(context=ctx)
@@ -138,8 +185,8 @@ def test_one_step_parity_from_mid_episode_states(ctx60, init_qpos, pushing_blob)
             ncon = len(o.contacts())
             geoms = o.contacts()[:, 8:10] if ncon else np.zeros((0, 2))
             assert not (fl1[e] & BAD), hex(fl1[e])
-            np.testing.assert_allclose(st1[POS, e], so[POS], atol=2e-7, rtol=0, err_msg="t %d env %d" % (t, e))
-            np.testing.assert_allclose(st1[VEL, e], so[VEL], atol=2e-4, rtol=0, err_msg="t %d env %d" % (t, e))
+            np.testing.assert_allclose(st1[POS, e], so[POS], atol=2e-8, rtol=0, err_msg="t %d env %d" % (t, e))
+            np.testing.assert_allclose(st1[VEL, e], so[VEL], atol=2e-6, rtol=0, err_msg="t %d env %d" % (t, e))
             assert bool(done[e]) == do and int(info["mode"][e]) == io["mode"] and bool(info["success"][e]) == io["success"]
             assert int(fl1[e] & 7) - 1 == fo[3]
             checked += 1
@@ -203,8 +250,6 @@ def test_ragged_sizes_masks_and_errors(ctx60, init_qpos):
         assert sc2[0] == 0 and np.all(sc2[1:] == 3)
         np.testing.assert_array_equal(st2[:68, 1:], st[:68, 1:])
         np.testing.assert_allclose(st2[42:44, 0], ctx[0, 0:2], atol=1e-3)
-        with pytest.raises(capi.D3ilError):
-            env.auto_reset(torch.zeros(2, dtype=torch.int64, device=env.device))
         env.close()
 
 

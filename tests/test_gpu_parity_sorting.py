@@ -133,10 +133,11 @@ def test_scripted_push_into_the_bin_matches_oracle(sort_blob, sort_init_qpos, fa
         for e in list(oracles):
             oo, do, io = oracles[e].sort_step(an[e])
             err = _dev_err(st, e, oracles[e])
-            if err > 1e-6:
-                # a contact event (cube tipping over the platform edge, cube meeting cube) has amplified the round-off level
-                # difference of the two implementations: from here on the trajectories are different valid rollouts.  One-step
-                # parity through such events is asserted in test_one_step_parity_from_mid_episode_states.
+            if err > 1e-4:
+                # the north star's bound (1e-4 on trajectory state) is the parity criterion.  A contact event (cube tipping over the
+                # platform edge, cube meeting cube) amplifies the conditioning-level difference of two correct implementations
+                # (tests/test_parity_conditioning.py): beyond this point the trajectories are different valid rollouts; the step at which
+                # it happens is asserted below.  One-step parity through such events: test_one_step_parity_from_mid_episode_states.
                 lost_at[e] = t
                 del oracles[e]
                 continue
@@ -149,21 +150,26 @@ def test_scripted_push_into_the_bin_matches_oracle(sort_blob, sort_init_qpos, fa
                 del oracles[e]          # parity shown up to the completion event; stop following this environment
     codes = env.mode.cpu().numpy()
     # every followed environment stays on the oracle's trajectory through reset transient, approach and the first pushes
-    assert all(t >= 45 for t in lost_at.values()), (lost_at, worst)
+    print("sorting scripted push: north-star (1e-4) horizon per followed env: %s (never exceeded: %s)" % (lost_at, sorted(set(check) - set(lost_at))))
+    assert all(t >= 50 for t in lost_at.values()), (lost_at, worst)
     # and at least one of them all the way to the completion event, with the reference's mode code
     assert len(first_code) >= 1 and all(c == 0b01110000 for c in first_code.values()), (first_code, lost_at, worst)
     assert (codes == 0b01110000).sum() >= n // 3      # the simple script delivers most of the (randomly turned) red cubes
     env.close()
 
 
-def test_one_step_parity_from_mid_episode_states(sort_blob, sort_init_qpos):
+@pytest.mark.parametrize("strict", [0, 1])
+def test_one_step_parity_from_mid_episode_states(sort_blob, sort_init_qpos, strict):
     """Random-walk set-points stir rod-cube, cube-cube and wall contacts; at several instants the oracle is loaded with the
-    device state of a few environments and both take the same step."""
+    device state of a few environments and both take the same step.  All state rows incl. velocities, production stopping rule
+    of the device solvers and the oracle's (solver_strict): the same bound holds - the difference is the conditioning of the
+    soft-contact problem, not the solver tolerance (tests/test_parity_conditioning.py)."""
     from oracle.oracle import Oracle
     from d3il_amd.envs.sorting import sample_contexts
     n = 96
     ctx = sample_contexts(n, NB, seed=5)
     env = _env(n)
+    env.set_option("solver_strict", strict)
     env.set_init_qpos(sort_init_qpos)
     env.reset(context=ctx)
     o = Oracle(sort_blob)
@@ -194,9 +200,9 @@ def test_one_step_parity_from_mid_episode_states(sort_blob, sort_init_qpos):
             for e in pick:
                 o.sort_set_state(st[:, e], int(fl[e]), int(sc[e]))
                 oo, do, io = o.sort_step(an[e])
-                err = _dev_err(st2, e, o)
+                err = _dev_err(st2, e, o)          # positions, and velocities weighted 1e-2: |dpos| < 2e-8, |dvel| < 2e-6 (north star 1e-4)
                 worst = max(worst, err)
-                assert err < 1e-7, (t, e, err)
+                assert err < 2e-8, (t, e, err)
                 assert int(env.mode[e]) == io["mode"] and bool(env.success[e]) == io["success"]
         assert not (env.flags[:n].cpu().numpy() & ((1 << 16) | (1 << 18))).any()
     env.close()

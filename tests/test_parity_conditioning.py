@@ -1,0 +1,55 @@
+"""What bounds the one-step agreement of two correct implementations of the soft-contact sub-step (CPU, no GPU needed).
+
+VERDICT r1 asked whether the device solvers' loose stopping rule explains the velocity differences seen in contact.  It does
+not: the host build of the kernel math (tests/hostcheck) and the oracle are advanced ONE physics sub-step from identical
+states along a scripted push.  Typical sub-steps agree to round-off (median 1e-14); in contact-rich sub-steps the cube's angular
+velocity differs by up to a few 1e-8 rad/s - and the oracle's OWN optimality residual at its solution (M (a - a0) - J' f) is
+of the size that explains it: contact rows carry D ~ 1e6..1e7 (stiff directions are resolved to round-off of a), so a residual of
+1e-8 N lands in the soft directions (cube inertia 3e-5 kg m^2).  That is the conditioning of the problem in f64, shared by every
+implementation (MuJoCo's Newton solver stops on a scaled gradient of 1e-10, i.e. earlier).
+"""
+import numpy as np
+
+from d3il_amd.model import blob as blob_mod
+from oracle.oracle import Oracle
+from tests.hostcheck.hostcheck import PushHostCheck
+
+P_VEL = list(range(9, 18)) + list(range(49, 55)) + list(range(62, 68))
+
+
+def test_one_substep_difference_is_conditioning_not_solver_tolerance(init_qpos, push_contexts):
+    js = blob_mod.load_json("pushing")
+    js["task_const"]["n_substeps"] = 1
+    js["task_const"]["max_steps"] = 100000
+    b1 = blob_mod.pack(js)
+    o = Oracle(b1)
+    o.env_start(init_qpos)
+    hc = PushHostCheck(b1)
+    hc.reset(init_qpos, push_contexts[7])
+    des, z = hc.s[25:27].copy(), float(hc.s[27])
+    dvel, resid = [], []
+    for t in range(35 * 52):
+        if t % 35 == 0 and t >= 35 * 12:
+            d = hc.s[42:44] - des
+            n = np.linalg.norm(d)
+            des = des + d / max(n, 1e-9) * min(0.006, n)
+        a = np.concatenate([des, [z], [0, 1, 0, 0]])
+        s0, f0 = hc.s.copy(), hc.f.copy()
+        hc.step(a)
+        if t < 35 * 30:          # approach: both agree to round-off, checked on a sample
+            if t % 7:
+                continue
+        fl = int(f0[0]) & 0xFFFFFFFF
+        o.push_set_state(s0[:68], step=int(f0[1]), terminated=bool(fl & (1 << 12)), first_visit=(fl & 7) - 1, ik_valid=bool(fl & (1 << 15)))
+        o.push_step(a)
+        so, _ = o.push_state()
+        dvel.append(np.abs(hc.s[:68][P_VEL] - so[P_VEL]).max())
+        resid.append(np.abs(o.grad_at(o.vec("qacc"))).max())
+    dvel, resid = np.array(dvel), np.array(resid)
+    assert np.median(dvel) < 1e-12                     # the two formulations are the same function
+    assert dvel.max() < 2e-7                           # worst contact-rich sub-step (measured 5e-8)
+    worst = np.argsort(dvel)[-10:]
+    # in those sub-steps the oracle's own solution carries an optimality residual far above round-off of the forces (1e-15 N):
+    assert resid[worst].min() > 1e-10 and resid.max() < 1e-5
+    # and a residual of that size in the cube's rotational dofs (inertia 3e-5 kg m^2) over dt = 1 ms covers the difference
+    assert np.all(dvel[worst] < 10 * resid[worst] / 3e-5 * 1e-3)

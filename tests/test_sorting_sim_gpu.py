@@ -57,6 +57,4 @@ def test_sorting_env_protocol():
     torch.cuda.synchronize()
     sc1 = env.step_count[:33]
     assert int(sc1[5]) == 0 and torch.equal(sc1[torch.arange(33) != 5], sc0[torch.arange(33) != 5])
-    with pytest.raises(Exception):
-        env.auto_reset(None)
     env.close()
