@@ -210,3 +210,36 @@ class ScriptedPushPolicy:
         if self.task == "sorting":
             step = step * dist                                        # nothing left on the platform: hold
         return step
+
+
+class ScriptedStackPolicy:
+    """Scripted pick-and-place policy of the Stacking measurement harness: a per-context table of joint-space actions
+    (controllers/scripted_stacking.py) replayed by episode step.  ``predict_batch([last command 8, obs 12]) -> [delta joints 7,
+    gripper command]`` - the interface of the Stacking rollout loop (stacking_sim.py:99-106: the policy output is added to the last
+    commanded joints).  ``ctx_id``: context index of every lane; the episode step of a lane restarts with ``begin_episodes(mask)``."""
+
+    def __init__(self, tables, ctx_id, device="cuda"):
+        self.device = torch.device(device)
+        T = max(len(t) for t in tables)
+        tab = torch.zeros(len(tables), T, 8, dtype=torch.float64)
+        for i, t in enumerate(tables):
+            tt = torch.as_tensor(t, dtype=torch.float64)
+            tab[i, :len(t)] = tt
+            tab[i, len(t):] = tt[-1]
+        self.table = tab.to(self.device)
+        self.ctx_id = torch.as_tensor(ctx_id, dtype=torch.int64, device=self.device)
+        self.t = torch.zeros(len(self.ctx_id), dtype=torch.int64, device=self.device)
+
+    def reset(self):
+        self.t.zero_()
+
+    def begin_episodes(self, mask: torch.Tensor):
+        self.t = torch.where(mask.bool(), torch.zeros_like(self.t), self.t)
+
+    @torch.no_grad()
+    def predict_batch(self, obs20: torch.Tensor) -> torch.Tensor:
+        a = self.table[self.ctx_id, self.t.clamp_max(self.table.shape[1] - 1)]
+        self.t += 1
+        out = a.clone()
+        out[:, :7] -= obs20[:, :7].to(torch.float64)
+        return out

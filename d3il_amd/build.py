@@ -15,6 +15,7 @@ LIB = os.path.join(PKG, "libd3il_rollout.so")
 SOURCES = [os.path.join(PKG, "csrc", "rollout.hip")]
 DEPS = SOURCES + [os.path.join(PKG, "csrc", "panda_step.h"), os.path.join(PKG, "csrc", "panda_consts.h"),
                   os.path.join(PKG, "csrc", "push_step.h"), os.path.join(PKG, "csrc", "gen_step.h"), os.path.join(PKG, "csrc", "gen_kernels.h"), os.path.join(PKG, "csrc", "push_kernels.h"),
+                  os.path.join(PKG, "csrc", "stack_step.h"), os.path.join(PKG, "csrc", "stack_kernels.h"), os.path.join(PKG, "model", "blobs", "stacking.json"),
                   os.path.join(PKG, "csrc", "gen_consts.cpp"), os.path.join(PKG, "model", "blobs", "avoiding.json"),
                   os.path.join(ROOT, "include", "d3il_rollout.h"), os.path.join(ROOT, "include", "d3il_model_blob.h")]
 # -disable-machine-licm / -disable-machine-sink: with the model constants baked in as literals, MachineLICM hoists
@@ -52,7 +53,7 @@ def generate_consts(verbose: bool = False):
     with tempfile.TemporaryDirectory() as td:
         exe = os.path.join(td, "gen_consts")
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", exe, GEN_SRC], cwd=ROOT)
-        for task, sym in (("avoiding", "kAvoidingConsts"),):
+        for task, sym in (("avoiding", "kAvoidingConsts"), ("stacking", "kStackingConsts")):
             bin_path = os.path.join(td, task + ".bin")
             with open(bin_path, "wb") as f:
                 f.write(bytes(blob_mod.load(task)))

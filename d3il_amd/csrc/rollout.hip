@@ -13,12 +13,14 @@
 #include "panda_step.h"
 #include "push_step.h"
 #include "gen/avoiding_consts.inc"
+#include "gen/stacking_consts.inc"
 
 namespace d3il {
 constexpr int WAVE = 64;
 }
 #include "push_kernels.h"
 #include "gen_kernels.h"
+#include "stack_kernels.h"
 
 namespace d3il {
 
@@ -343,6 +345,7 @@ struct d3il_handle_s {
   PandaConsts* dc;         // device copy
   PushConsts pc;           // Pushing: cubes, table slabs, contact parameter sets, targets
   GenConsts gc;            // Sorting: cubes, static boxes, contact parameter sets (host copy; the device copy is the __constant__ object)
+  StackConsts kc;          // Stacking: boxes, finger geoms, contact parameter sets (host copy; device: __constant__)
   double* d_scratch;       // Pushing: per-lane solver scratch [PG_SIZE][stride]
   int state_rows;          // f64 state fields per environment (42 Avoiding, 89 Pushing)
   double* d_init_qpos;
@@ -364,8 +367,8 @@ struct d3il_handle_s {
 // The Pushing / Sorting kernels read their model from one __constant__ object per device (scalar loads, no pointer across call
 // boundaries: push_step.h).  Handles on one device therefore have to share the model: d3il_create refuses a different one while
 // another handle is alive (a second model would silently re-point the kernels of the first).
-struct ActiveModel { int refs; bool valid; PushConsts pc; GenConsts gc; };
-static ActiveModel g_active_push[16], g_active_gen[16];
+struct ActiveModel { int refs; bool valid; PushConsts pc; GenConsts gc; StackConsts kc; };
+static ActiveModel g_active_push[16], g_active_gen[16], g_active_stack[16];
 static int g_active_tol[16];   // solver tolerance set currently in the device's g_solver_tol (0 production)
 
 static thread_local std::string g_err;
@@ -384,6 +387,7 @@ static void free_handle(d3il_handle_s* h) {
   if (dev >= 0 && dev < 16) {
     if (h->task_id == D3IL_TASK_PUSHING && g_active_push[dev].refs > 0) g_active_push[dev].refs--;
     if (h->task_id == D3IL_TASK_SORTING && g_active_gen[dev].refs > 0) g_active_gen[dev].refs--;
+    if (h->task_id == D3IL_TASK_STACKING && g_active_stack[dev].refs > 0) g_active_stack[dev].refs--;
   }
   void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des,
                   h->buf.info_f64, h->d_scratch, h->d_ctx, h->d_mask};
@@ -401,7 +405,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (n_envs <= 0) return fail(D3IL_EINVAL, "d3il_create: n_envs must be positive");
   const d3il_model_blob& m = *(const d3il_model_blob*)model_blob;
   if (task_id != m.task_id) return fail(D3IL_EINVAL, "d3il_create: task_id does not match the model blob");
-  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING) return fail(D3IL_EUNSUPPORTED, "d3il_create: only the Avoiding, Pushing and Sorting tasks are implemented in this build");
+  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING && task_id != D3IL_TASK_STACKING) return fail(D3IL_EUNSUPPORTED, "d3il_create: unknown task id (Avoiding, Pushing, Sorting and Stacking are implemented)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(D3IL_ENODEVICE, "d3il_create: no HIP device available (there is no CPU fallback)");
   if (device_id < 0 || device_id >= ndev || device_id >= 16) return fail(D3IL_ENODEVICE, "d3il_create: device_id out of range");
@@ -417,9 +421,10 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   finish_invweights(h->hc);
   if (task_id == D3IL_TASK_PUSHING && build_push_consts(m, h->pc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_SORTING && build_gen_consts(m, h->hc, h->gc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  if (task_id == D3IL_TASK_STACKING && build_stack_consts(m, h->hc, h->kc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   {  // the kernels are specialised at build time to the robot model (csrc/gen/avoiding_consts.inc): the runtime blob
      // must describe the same arm, controller and (Avoiding) obstacles.  n_substeps / max_steps stay run-time parameters.
-    PandaConsts a = h->hc, b = kAvoidingConsts;
+    PandaConsts a = h->hc, b = task_id == D3IL_TASK_STACKING ? kStackingConsts : kAvoidingConsts;   // Stacking: the gripper robot without the rod
     if (task_id != D3IL_TASK_AVOIDING) {   // no obstacles, other task constants: only the arm / controller part is compared
       a.n_obst = b.n_obst;
       std::memcpy(a.ob_c, b.ob_c, sizeof a.ob_c); std::memcpy(a.ob_u, b.ob_u, sizeof a.ob_u); std::memcpy(a.ob_r, b.ob_r, sizeof a.ob_r); std::memcpy(a.ob_h, b.ob_h, sizeof a.ob_h);
@@ -453,13 +458,21 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
       return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Sorting handle on this device uses a different model, e.g. another num_boxes (the kernels read one model per device from constant memory); destroy it first");
     }
   }
+  const bool stacking = task_id == D3IL_TASK_STACKING;
+  if (stacking) {
+    ActiveModel& am = g_active_stack[device_id];
+    if (am.refs > 0 && std::memcmp(&am.kc, &h->kc, sizeof(StackConsts)) != 0) {
+      free_handle(h);
+      return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Stacking handle on this device uses a different model (the kernels read one model per device from constant memory); destroy it first");
+    }
+  }
   h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE;
   h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false;
-  h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : D3IL_STATE_F64);
-  h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : 0);
+  h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : (stacking ? SK_STATE_F64 : D3IL_STATE_F64));
+  h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : (stacking ? 21 : 0));
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
-  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : 2); b.action_dim = 7; b.state_rows = h->state_rows; b.n_info_f64 = pushing ? 2 : 0;
+  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : 2)); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = pushing ? 2 : (stacking ? 1 : 0);
   HIPCHK_H(hipMalloc(&h->dc, sizeof(PandaConsts)));
   HIPCHK_H(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
   HIPCHK_H(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
@@ -504,6 +517,19 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_reset, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_H));
+  }
+  if (stacking) {
+    ActiveModel& am = g_active_stack[device_id];
+    if (am.refs == 0) {
+      HIPCHK_H(hipDeviceSynchronize());
+      HIPCHK_H(hipMemcpyToSymbol(HIP_SYMBOL(g_stack_consts), &h->kc, sizeof(StackConsts)));
+      am.kc = h->kc;
+    }
+    am.refs++; h->task_id = task_id;
+    HIPCHK_H(hipMalloc(&b.info_f64, S * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * sizeof(double)));
+    HIPCHK_H(hipMalloc(&h->d_scratch, S * SG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * SG_SIZE * sizeof(double)));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_step, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_reset, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
   }
   h->task_id = task_id;
   HIPCHK_H(hipEventCreate(&h->ev0)); HIPCHK_H(hipEventCreate(&h->ev1));
@@ -564,6 +590,13 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
     HIPCHK(hipGetLastError());
     return D3IL_OK;
   }
+  if (h->task_id == D3IL_TASK_STACKING) {
+    if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Stacking task needs contexts (device f64 [n_envs][21])");
+    hipLaunchKernelGGL(k_stacking_reset, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
+                       b.flags, b.step_count, b.obs, b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride);
+    HIPCHK(hipGetLastError());
+    return D3IL_OK;
+  }
   if (contexts) return fail(D3IL_EUNSUPPORTED, "d3il_reset: the Avoiding task takes no contexts");
   hipLaunchKernelGGL(k_avoiding_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->dc, h->d_init_qpos, env_mask, b.state, b.flags,
                      b.step_count, b.obs, b.done, b.success, b.mode, h->n, h->stride);
@@ -600,6 +633,14 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     else
       hipLaunchKernelGGL((k_sorting_step<false>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                          h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    HIPCHK(hipGetLastError());
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    return D3IL_OK;
+  }
+  if (h->task_id == D3IL_TASK_STACKING) {
+    if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
+                       b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
     return D3IL_OK;

@@ -1,0 +1,987 @@
+// stack_step.h - sub-step of the Stacking task: Panda arm with a USED gripper + three free boxes of individual size + static boxes.
+//
+// Reference path: CubeStacking_Env.step (stacking.py:331-393) over mujoco.mj_step on the scene of stacking.py:150-156
+// (panda_invisible.xml: no rod; finger geoms of class panda:gripper - condim 4, friction 1 / .005 / .0001, margin 1 mm; finger-tip
+// boxes with friction 2 / .05 / .0001, solref .01 .5; stacking_objects.py: two 6 cm cubes and a 6 x 10 x 6 cm box, 50 g each).
+//
+// What is new against the Pushing / Sorting engines: (i) boxes of different size and non-isotropic inertia; (ii) contacts between
+// the boxes and geoms of the moving finger bodies - the finger-tip boxes (box-box) and the convex hulls of the finger meshes
+// (Minkowski Portal Refinement, one contact per pair like mjc_Convex) - whose Jacobians run over the 7 arm joints and the finger's own
+// slide joint; (iii) condim-4 contacts (a torsional row about the normal); (iv) finger <-> finger contacts (an empty gripper closes on
+// itself); (v) a joint-space PD law instead of the Cartesian IK controller, so there is no controller wave.
+//
+// Formulation: one primal Newton problem per sub-step over the 27 dofs [box0 | box1 | box2 | arm 9], as MuJoCo's Newton solver sees
+// it: 1/2 (x - a0)' M (x - a0) + sum_i s_i(J_i x - aref_i), elliptic cones, soft-constraint impedances.  M is block diagonal (box:
+// mass and body-frame principal inertia; arm: the 9 x 9 matrix of panda_step.h), so the Hessian M + J' Hc J is block sparse:
+// blocks are coupled only through contacts, and the Cholesky skips structurally empty blocks (resting boxes cost a 6 x 6 each).
+// Contact rows are never stored: a contact record holds position, frame, distance, the two bodies and its parameter set, the rows
+// are rebuilt from the record wherever they are needed (a box side: 6 columns from the contact arm; a finger side: z_k x (p - o_k)
+// from the joint axes / origins of this sub-step).
+//
+// Execution: ONE LANE PER ENVIRONMENT (first, correctness-first version): vectors, the packed 27 x 27 Hessian and the kinematic tables
+// of a lane's environment sit in LDS (lane-strided), contact records in an HBM scratch area.  Host build: tests/hostcheck.
+#pragma once
+#include "push_step.h"
+
+namespace d3il {
+
+constexpr int SK_NB = 3, SK_NV = 6 * SK_NB + NDOF, SK_ARM0 = 6 * SK_NB, SK_NH = SK_NV * (SK_NV + 1) / 2;   // 27 dofs, 378 packed
+constexpr int SK_MAXCON = 48, SK_MAXNS = 4, SK_MAXHV = 96;
+constexpr int SK_LANES = 24;            // environments per workgroup (one per lane; LDS bound)
+// contact parameter sets
+enum { SKS_STATIC = 0 /* + static index */, SKS_BOXBOX = SK_MAXNS, SKS_BOXHULL, SKS_BOXTIP, SKS_HULLHULL, SKS_HULLTIP, SKS_TIPTIP, SKS_N };
+// bodies of a contact: boxes 0..2, then
+enum { SKB_STATIC = 3, SKB_FINGER = 4 /* + finger: the finger body (hull geom) */, SKB_TIP = 6 /* + finger: the tip body (tip box) */ };
+
+struct StackSet { double K, B, solimp[5], fric[3], margin; int dim, pad; };
+struct StackConsts {
+  int nb, ns, hull_nv, pad;
+  double box_half[SK_NB][3], box_mass[SK_NB], box_inertia[SK_NB][3];
+  double st_c[SK_MAXNS][3], st_h[SK_MAXNS][3], st_R[SK_MAXNS][9];
+  // finger geoms in the link-7 frame at finger position 0: the frame moves by f_axis * q_finger
+  double tip_R[NFING][9], tip_p[NFING][3], tip_half[3];
+  double hull_R[NFING][9], hull_p[NFING][3], hull_center[3];
+  double hull_v[SK_MAXHV][3];
+  double invw_finger[NFING], invw_tip[NFING];     // translational body_invweight0 of the finger / finger-tip bodies
+  StackSet set[SKS_N];
+  double impratio;
+  double target[3], min_dist, grip_thresh;       // stacking_objects.py:17, stacking.py:193, :337
+  double ws_lo[2], ws_hi[2];                     // modelled workspace of the box centres (x, y): the table top without its rim
+  double hand_R[9], hand_p[3], hand_lo[3], hand_hi[3];   // bounding box of the hand mesh in the hand frame (pair not evaluated: flagged)
+};
+
+// flag bits of the Stacking task (EnvState::flags).  F_TERMINATED / F_SUCCESS / F_SOLVER_FAIL keep their positions.
+enum : unsigned {
+  SKF_NMODE_MASK = 0x3u,          // number of boxes that have reached the target so far (stacking.py:395-419)
+  SKF_IND_SHIFT = 2,              // min_inds[3], two bits each
+  SKF_CON_OVERFLOW = 1u << 18,    // more than SK_MAXCON contacts in one sub-step (extra contacts dropped)
+  SKF_OFF_TABLE = 1u << 19,       // a box left the modelled part of the table
+  SKF_HAND_NEAR = 1u << 20,       // a box reached the hand mesh (a pair this engine does not evaluate)
+};
+constexpr int SK_STATE_BOX = 28, SK_STATE_F64 = SK_STATE_BOX + 13 * SK_NB;     // arm q[9] v[9] bias[7] tcp[3] | boxes (pos3 quat4 vel6) x 3
+constexpr int SK_OBS = 12, SK_ACT = 8;
+
+#if defined(__HIPCC__)
+__constant__ StackConsts g_stack_consts;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define D3IL_STACK_CONSTS(in, name) const StackConsts& name = g_stack_consts; (void)in
+#else
+#define D3IL_STACK_CONSTS(in, name) const StackConsts& name = in
+#endif
+
+// scratch views of one environment: t area (LDS on the device) and g area (HBM)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) double sk_lds_double;
+typedef __attribute__((address_space(1))) double sk_glb_double;
+#define SK_TS SK_LANES
+#else
+typedef double sk_lds_double;
+typedef double sk_glb_double;
+#define SK_TS 1
+#endif
+struct StackScratch { sk_lds_double* t; sk_glb_double* g; int gs; };
+#define SL(i) sc.t[(i) * SK_TS]
+#define SG(i) sc.g[(long)(i) * sc.gs]
+// t area
+constexpr int ST_H = 0, ST_X = SK_NH, ST_A0 = ST_X + SK_NV, ST_G = ST_A0 + SK_NV, ST_P = ST_G + SK_NV, ST_VEL = ST_P + SK_NV;
+constexpr int ST_M = ST_VEL + SK_NV;            // arm mass matrix, packed lower 45
+constexpr int ST_BR = ST_M + 45;                // box rotation matrices 3 x 9
+constexpr int ST_BP = ST_BR + 27;               // box positions 3 x 3
+constexpr int ST_Z = ST_BP + 9;                 // world joint axes 7 x 3
+constexpr int ST_O = ST_Z + 21;                 // world joint origins 7 x 3
+constexpr int ST_FAX = ST_O + 21;               // world finger slide axes 2 x 3
+constexpr int ST_TIPR = ST_FAX + 6, ST_TIPP = ST_TIPR + 18, ST_HULR = ST_TIPP + 6, ST_HULP = ST_HULR + 18;
+constexpr int ST_LIM = ST_HULP + 6;             // per arm dof: sign, D, aref
+constexpr int ST_SIZE = ST_LIM + 27;            // 717
+// g area: contact records
+constexpr int SREC = 36;    // pos[3] frame[9] dist bodyA bodyB set | aref[4] D[4] mu | jar[4] jp[4] | pad
+constexpr int SG_SIZE = SK_MAXCON * SREC;
+
+// ------------------------------------------------------------------------------------------------ convex pairs: MPR
+// Same algorithm as the oracle's mpr_penetration (libccd's ccdMPRPenetration as MuJoCo 2.3.2 runs it for mesh geoms [ext]); the
+// tie rule of the support functions (lowest index within 1e-10, box components >= -1e-10 positive) makes the portal independent
+// of round-off in flat-on-flat configurations.  Written with exact divisions / square roots: the portal logic branches on signs.
+struct SkShape { const double* R; const double* p; const double* half; int hull; };   // hull != 0: the finger hull, else a box
+struct SkPt { double v[3], v1[3], v2[3]; };
+D3IL_HD void sk_support1(const StackConsts& kc_, const SkShape& s, const double* dir, double margin, double* out) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const double* R = s.R;
+  double dl[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2], R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
+  double loc[3];
+  if (s.hull) {
+    double bd = -1e300;
+    for (int i = 0; i < kc.hull_nv; i++) { double d = kc.hull_v[i][0] * dl[0] + kc.hull_v[i][1] * dl[1] + kc.hull_v[i][2] * dl[2]; if (d > bd) bd = d; }
+    int best = 0; bool found = false;
+    for (int i = 0; i < kc.hull_nv; i++) { double d = kc.hull_v[i][0] * dl[0] + kc.hull_v[i][1] * dl[1] + kc.hull_v[i][2] * dl[2]; if (!found && d >= bd - 1e-10) { best = i; found = true; } }
+    loc[0] = kc.hull_v[best][0]; loc[1] = kc.hull_v[best][1]; loc[2] = kc.hull_v[best][2];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) loc[k] = dl[k] >= -1e-10 ? s.half[k] : -s.half[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[k] = R[3 * k] * loc[0] + R[3 * k + 1] * loc[1] + R[3 * k + 2] * loc[2] + s.p[k] + 0.5 * margin * dir[k];
+}
+D3IL_HD void sk_support(const StackConsts& kc, const SkShape& a, const SkShape& b, const double* dir, double margin, SkPt& pt) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  sk_support1(kc, a, dir, margin, pt.v1); sk_support1(kc, b, nd, margin, pt.v2);
+#pragma unroll
+  for (int k = 0; k < 3; k++) pt.v[k] = pt.v1[k] - pt.v2[k];
+}
+D3IL_HD bool sk_zero(double x) { return fabs(x) < 2.220446049250313e-16; }
+D3IL_HD void sk_norm3(double* a) { double n = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); a[0] /= n; a[1] /= n; a[2] /= n; }
+D3IL_HD void sk_portal_dir(const SkPt* P, double* dir) {
+  double a[3] = {P[2].v[0] - P[1].v[0], P[2].v[1] - P[1].v[1], P[2].v[2] - P[1].v[2]}, b[3] = {P[3].v[0] - P[1].v[0], P[3].v[1] - P[1].v[1], P[3].v[2] - P[1].v[2]};
+  cross3(a, b, dir); sk_norm3(dir);
+}
+D3IL_HD void sk_expand(SkPt* P, const SkPt& v4) {
+  double w[3]; cross3(v4.v, P[0].v, w);
+  if (dot3(P[1].v, w) > 0) { if (dot3(P[2].v, w) > 0) P[1] = v4; else P[3] = v4; }
+  else { if (dot3(P[3].v, w) > 0) P[2] = v4; else P[1] = v4; }
+}
+D3IL_HD bool sk_reach_tol(const SkPt* P, const SkPt& v4, const double* dir) {
+  double dv4 = dot3(v4.v, dir);
+  double d = fmin(dv4 - dot3(P[1].v, dir), fmin(dv4 - dot3(P[2].v, dir), dv4 - dot3(P[3].v, dir)));
+  return d < 1e-6 || sk_zero(d - 1e-6);
+}
+D3IL_HD void sk_tri_closest_origin(const double* a, const double* b, const double* c, double* out) {   // Ericson, RTCD 5.1.5
+  double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, ap[3] = {-a[0], -a[1], -a[2]};
+  double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; return; }
+  double bp[3] = {-b[0], -b[1], -b[2]}, d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { out[0] = b[0]; out[1] = b[1]; out[2] = b[2]; return; }
+  double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); for (int k = 0; k < 3; k++) out[k] = a[k] + v * ab[k]; return; }
+  double cp[3] = {-c[0], -c[1], -c[2]}, d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; return; }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double w = d2 / (d2 - d6); for (int k = 0; k < 3; k++) out[k] = a[k] + w * ac[k]; return; }
+  double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); for (int k = 0; k < 3; k++) out[k] = b[k] + w * (c[k] - b[k]); return; }
+  double den = 1 / (va + vb + vc), v = vb * den, w = vc * den;
+  for (int k = 0; k < 3; k++) out[k] = a[k] + ab[k] * v + ac[k] * w;
+}
+// out = {dist, pos[3], normal[3]} (normal from shape a to shape b); false when the inflated shapes do not overlap
+D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const SkShape b, double margin, double* out) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  SkPt P[4], v4;
+  double dir[3], va[3], vb[3];
+  for (int s = 0; s < 2; s++) {
+    const SkShape& sh = s ? b : a;
+    double* c = s ? P[0].v2 : P[0].v1;
+    if (sh.hull) { for (int k = 0; k < 3; k++) c[k] = sh.R[3 * k] * kc.hull_center[0] + sh.R[3 * k + 1] * kc.hull_center[1] + sh.R[3 * k + 2] * kc.hull_center[2] + sh.p[k]; }
+    else { c[0] = sh.p[0]; c[1] = sh.p[1]; c[2] = sh.p[2]; }
+  }
+  for (int k = 0; k < 3; k++) P[0].v[k] = P[0].v1[k] - P[0].v2[k];
+  if (sk_zero(P[0].v[0]) && sk_zero(P[0].v[1]) && sk_zero(P[0].v[2])) P[0].v[0] += 10 * 2.220446049250313e-16;
+  for (int k = 0; k < 3; k++) dir[k] = -P[0].v[k];
+  sk_norm3(dir);
+  sk_support(kc, a, b, dir, margin, P[1]);
+  double dot = dot3(P[1].v, dir);
+  if (sk_zero(dot) || dot < 0) return false;
+  cross3(P[0].v, P[1].v, dir);
+  if (sk_zero(dot3(dir, dir))) {
+    if (sk_zero(P[1].v[0]) && sk_zero(P[1].v[1]) && sk_zero(P[1].v[2])) return false;
+    double depth = sqrt(dot3(P[1].v, P[1].v));
+    for (int k = 0; k < 3; k++) { out[1 + k] = 0.5 * (P[1].v1[k] + P[1].v2[k]); out[4 + k] = P[1].v[k] / depth; }
+    out[0] = margin - depth;
+    return true;
+  }
+  sk_norm3(dir);
+  sk_support(kc, a, b, dir, margin, P[2]);
+  dot = dot3(P[2].v, dir);
+  if (sk_zero(dot) || dot < 0) return false;
+  for (int k = 0; k < 3; k++) { va[k] = P[1].v[k] - P[0].v[k]; vb[k] = P[2].v[k] - P[0].v[k]; }
+  cross3(va, vb, dir); sk_norm3(dir);
+  if (dot3(dir, P[0].v) > 0) { SkPt t = P[1]; P[1] = P[2]; P[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+  for (int guard = 0; guard < 100; guard++) {
+    sk_support(kc, a, b, dir, margin, P[3]);
+    dot = dot3(P[3].v, dir);
+    if (sk_zero(dot) || dot < 0) return false;
+    bool cont = false;
+    cross3(P[1].v, P[3].v, va); dot = dot3(va, P[0].v);
+    if (dot < 0 && !sk_zero(dot)) { P[2] = P[3]; cont = true; }
+    if (!cont) { cross3(P[3].v, P[2].v, va); dot = dot3(va, P[0].v); if (dot < 0 && !sk_zero(dot)) { P[1] = P[3]; cont = true; } }
+    if (!cont) break;
+    for (int k = 0; k < 3; k++) { va[k] = P[1].v[k] - P[0].v[k]; vb[k] = P[2].v[k] - P[0].v[k]; }
+    cross3(va, vb, dir); sk_norm3(dir);
+  }
+  for (int guard = 0; ; guard++) {          // refine the portal until it encloses the origin
+    sk_portal_dir(P, dir);
+    dot = dot3(dir, P[1].v);
+    if (sk_zero(dot) || dot > 0) break;
+    sk_support(kc, a, b, dir, margin, v4);
+    dot = dot3(v4.v, dir);
+    if (!(sk_zero(dot) || dot > 0) || sk_reach_tol(P, v4, dir) || guard > 100) return false;
+    sk_expand(P, v4);
+  }
+  for (int it = 0; ; it++) {                // penetration
+    sk_portal_dir(P, dir);
+    sk_support(kc, a, b, dir, margin, v4);
+    if (sk_reach_tol(P, v4, dir) || it > 50) {
+      double w[3]; sk_tri_closest_origin(P[1].v, P[2].v, P[3].v, w);
+      double depth = sqrt(dot3(w, w));
+      if (sk_zero(w[0]) && sk_zero(w[1]) && sk_zero(w[2])) { w[0] = dir[0]; w[1] = dir[1]; w[2] = dir[2]; }
+      sk_norm3(w);
+      double bb[4], t[3], sum;
+      cross3(P[1].v, P[2].v, t); bb[0] = dot3(t, P[3].v);
+      cross3(P[3].v, P[2].v, t); bb[1] = dot3(t, P[0].v);
+      cross3(P[0].v, P[1].v, t); bb[2] = dot3(t, P[3].v);
+      cross3(P[2].v, P[1].v, t); bb[3] = dot3(t, P[0].v);
+      sum = bb[0] + bb[1] + bb[2] + bb[3];
+      if (sk_zero(sum) || sum < 0) {
+        bb[0] = 0;
+        cross3(P[2].v, P[3].v, t); bb[1] = dot3(t, dir);
+        cross3(P[3].v, P[1].v, t); bb[2] = dot3(t, dir);
+        cross3(P[1].v, P[2].v, t); bb[3] = dot3(t, dir);
+        sum = bb[1] + bb[2] + bb[3];
+      }
+      double inv = 1 / sum;
+      for (int k = 0; k < 3; k++) {
+        double p1 = bb[0] * P[0].v1[k] + bb[1] * P[1].v1[k] + bb[2] * P[2].v1[k] + bb[3] * P[3].v1[k];
+        double p2 = bb[0] * P[0].v2[k] + bb[1] * P[1].v2[k] + bb[2] * P[2].v2[k] + bb[3] * P[3].v2[k];
+        out[1 + k] = 0.5 * (p1 + p2) * inv; out[4 + k] = w[k];
+      }
+      out[0] = margin - depth;
+      return true;
+    }
+    sk_expand(P, v4);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ contact rows
+// elliptic cone of dimension dim (3 or 4): force and Hessian block at the row residuals jar; D[r] = 1 / R[r], fr[j] = friction
+// coefficient of row j + 1 (tangent, tangent, torsional).  Zones as in MuJoCo's PGS / Newton cone [ext]; mirrors cone_eval (dim 3).
+D3IL_HD void sk_cone(int dim, const double* jar, const double* D, double mu, const double* fr, double* force, double* Hc /* 4 x 4 */) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) Hc[i] = 0;
+  double U[4] = {jar[0] * mu, 0, 0, 0}, T2 = 0;
+  for (int j = 1; j < dim; j++) { U[j] = jar[j] * fr[j - 1]; T2 += U[j] * U[j]; }
+  const double N = U[0], T = sqrt(T2);
+  if (N >= mu * T || (T <= 0 && N >= 0)) { force[0] = force[1] = force[2] = force[3] = 0; return; }
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    for (int j = 0; j < 4; j++) { force[j] = j < dim ? -D[j] * jar[j] : 0.0; if (j < dim) Hc[5 * j] = D[j]; }
+    return;
+  }
+  const double Dm = D[0] / fmax(1e-15, mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+  double g[4] = {mu, 0, 0, 0};
+  for (int j = 1; j < dim; j++) g[j] = -mu * fr[j - 1] * U[j] / T;
+  for (int j = 0; j < 4; j++) force[j] = j < dim ? -Dm * NmT * g[j] : 0.0;
+  for (int a = 0; a < dim; a++)
+    for (int b = 0; b < dim; b++) {
+      double h = g[a] * g[b];
+      if (a > 0 && b > 0) h += NmT * (-mu) * fr[a - 1] * fr[b - 1] * ((a == b ? 1.0 / T : 0.0) - U[a] * U[b] / (T * T * T));
+      Hc[4 * a + b] = Dm * h;
+    }
+}
+// one side of a contact: the body's dofs and the dim x n block of the constraint Jacobian (J(body) as such; the caller applies the
+// sign - the contact's rows are J(body B) - J(body A)).  off = first solver dof, n = 0 (static), 6 (box) or 9 (arm).
+struct SkSide { int off, n; double J[4][NDOF]; };
+D3IL_HD void sk_side(const StackScratch sc, int body, const double* pos, const double* frame, int dim, SkSide& s) {
+  if (body == SKB_STATIC) { s.off = 0; s.n = 0; return; }
+  if (body < SK_NB) {
+    s.off = 6 * body; s.n = 6;
+    double R[9], r[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = SL(ST_BR + 9 * body + k);
+#pragma unroll
+    for (int k = 0; k < 3; k++) r[k] = pos[k] - SL(ST_BP + 3 * body + k);
+    for (int rr = 0; rr < 3; rr++) box_row_r(R, r, frame + 3 * rr, s.J[rr]);
+    if (dim > 3) {     // torsional row: relative angular velocity about the normal; box angular dofs are body axes
+      s.J[3][0] = s.J[3][1] = s.J[3][2] = 0;
+      s.J[3][3] = R[0] * frame[0] + R[3] * frame[1] + R[6] * frame[2];
+      s.J[3][4] = R[1] * frame[0] + R[4] * frame[1] + R[7] * frame[2];
+      s.J[3][5] = R[2] * frame[0] + R[5] * frame[1] + R[8] * frame[2];
+    }
+    return;
+  }
+  const int f = (body - SKB_FINGER) & 1;       // finger body or its tip: the same dofs
+  s.off = SK_ARM0; s.n = NDOF;
+  for (int k = 0; k < NARM; k++) {
+    double z[3] = {SL(ST_Z + 3 * k), SL(ST_Z + 3 * k + 1), SL(ST_Z + 3 * k + 2)};
+    double d[3] = {pos[0] - SL(ST_O + 3 * k), pos[1] - SL(ST_O + 3 * k + 1), pos[2] - SL(ST_O + 3 * k + 2)}, col[3];
+    cross3(z, d, col);
+    for (int rr = 0; rr < 3; rr++) s.J[rr][k] = dot3(frame + 3 * rr, col);
+    s.J[3][k] = dot3(frame, z);
+  }
+  for (int g = 0; g < NFING; g++) {
+    double ax[3] = {SL(ST_FAX + 3 * g), SL(ST_FAX + 3 * g + 1), SL(ST_FAX + 3 * g + 2)};
+    for (int rr = 0; rr < 3; rr++) s.J[rr][NARM + g] = g == f ? dot3(frame + 3 * rr, ax) : 0.0;
+    s.J[3][NARM + g] = 0;
+  }
+}
+// rows of contact record ci: A = body 1 (enters with -), B = body 2 (+)
+struct SkCon { int dim, set; SkSide A, B; };
+D3IL_HD void sk_rows(const StackConsts& kc_, const StackScratch sc, int ci, SkCon& c) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const int base = ci * SREC;
+  double rec[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) rec[k] = SG(base + k);
+  c.set = (int)rec[15]; c.dim = kc.set[c.set].dim;
+  sk_side(sc, (int)rec[13], rec, rec + 3, c.dim, c.A);
+  sk_side(sc, (int)rec[14], rec, rec + 3, c.dim, c.B);
+  if (c.A.n == NDOF && c.B.n == NDOF) {     // finger <-> finger: both sides are the arm block, one row set J(B) - J(A)
+    for (int r = 0; r < 4; r++) for (int k = 0; k < NDOF; k++) c.B.J[r][k] -= c.A.J[r][k];
+    c.A.n = 0;
+  }
+}
+// friction coefficients of the rows 1 .. 3 of a contact: tangent, tangent, torsional (mjContact.friction[0, 1, 2] of MuJoCo's
+// 5-vector (slide, slide, spin, roll, roll))
+D3IL_HD void sk_row_fric(const StackSet& ps, double* fr) { fr[0] = ps.fric[0]; fr[1] = ps.fric[0]; fr[2] = ps.fric[1]; }
+D3IL_HD double sk_row_dot(const StackScratch sc, const SkCon& c, int r, int vec) {   // row r of the contact times the t-area vector at vec
+  double s = 0;
+  for (int k = 0; k < c.B.n; k++) s += c.B.J[r][k] * SL(vec + c.B.off + k);
+  for (int k = 0; k < c.A.n; k++) s -= c.A.J[r][k] * SL(vec + c.A.off + k);
+  return s;
+}
+D3IL_HD int sk_blk(int dof) { return dof >= SK_ARM0 ? SK_NB : dof / 6; }
+D3IL_HD double sk_Mv(const StackConsts& kc_, const StackScratch sc, int i, int va, int vb) {   // (M (v_a - v_b))_i of the block-diagonal mass matrix
+  D3IL_STACK_CONSTS(kc_, kc);
+  if (i < SK_ARM0) {
+    const int b = i / 6, k = i % 6;
+    return (k < 3 ? kc.box_mass[b] : kc.box_inertia[b][k - 3]) * (SL(va + i) - SL(vb + i));
+  }
+  const int a = i - SK_ARM0;
+  double s = 0;
+  for (int k = 0; k < NDOF; k++) s += SL(ST_M + (a >= k ? tri(a, k) : tri(k, a))) * (SL(va + SK_ARM0 + k) - SL(vb + SK_ARM0 + k));
+  return s;
+}
+
+// Cholesky of the packed Hessian with block skipping: cm[i] = bit mask of the blocks coupled with block i (after fill closure)
+D3IL_HD int sk_blk0(int b) { return b < SK_NB ? 6 * b : SK_ARM0; }
+D3IL_HD int sk_blkn(int b) { return b < SK_NB ? 6 : NDOF; }
+D3IL_NOINLINE inline bool sk_chol(const StackScratch sc, const unsigned* cm) {
+  bool ok = true;
+  for (int i = 0; i < SK_NV; i++) {
+    const int bi = sk_blk(i);
+    for (int j = 0; j <= i; j++) {
+      const int bj = sk_blk(j);
+      if (bi != bj && !((cm[bi] >> bj) & 1u)) { SL(ST_H + tri(i, j)) = 0; continue; }
+      double s = SL(ST_H + tri(i, j));
+      for (int bk = 0; bk <= bj; bk++) {      // columns of the blocks coupled with both rows
+        if (!(bk == bj || ((cm[bj] >> bk) & 1u)) || !(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
+        const int k0 = sk_blk0(bk), k1 = k0 + sk_blkn(bk) < j ? k0 + sk_blkn(bk) : j;
+        for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(i, k)) * SL(ST_H + tri(j, k));
+      }
+      if (i == j) {
+        if (!(s > 0)) { ok = false; s = 1; }
+        SL(ST_H + tri(i, i)) = sqrt(s);
+      } else SL(ST_H + tri(i, j)) = s / SL(ST_H + tri(j, j));
+    }
+  }
+  return ok;
+}
+D3IL_NOINLINE inline void sk_chol_solve(const StackScratch sc, const unsigned* cm, int vec) {
+  for (int i = 0; i < SK_NV; i++) {
+    const int bi = sk_blk(i);
+    double s = SL(vec + i);
+    for (int bk = 0; bk <= bi; bk++) {
+      if (!(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
+      const int k0 = sk_blk0(bk), k1 = k0 + sk_blkn(bk) < i ? k0 + sk_blkn(bk) : i;
+      for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(i, k)) * SL(vec + k);
+    }
+    SL(vec + i) = s / SL(ST_H + tri(i, i));
+  }
+  for (int i = SK_NV - 1; i >= 0; i--) {
+    const int bi = sk_blk(i);
+    double s = SL(vec + i);
+    for (int bk = bi; bk <= SK_NB; bk++) {
+      if (!(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
+      const int k0 = sk_blk0(bk) > i + 1 ? sk_blk0(bk) : i + 1, k1 = sk_blk0(bk) + sk_blkn(bk);
+      for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(k, i)) * SL(vec + k);
+    }
+    SL(vec + i) = s / SL(ST_H + tri(i, i));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ the Newton solve
+// x (ST_X) in: start point, out: optimum.  ncon contact records in the g area with aref / D / mu filled in; limit rows in ST_LIM.
+D3IL_NOINLINE inline bool sk_solve(const StackConsts& kc_, const StackScratch sc, int ncon) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  // block coupling through the contacts, closed under fill (4 blocks)
+  unsigned cm[SK_NB + 1] = {0, 0, 0, 0};
+  for (int ci = 0; ci < ncon; ci++) {
+    const int a = (int)SG(ci * SREC + 13), b = (int)SG(ci * SREC + 14);
+    const int ba = a == SKB_STATIC ? -1 : (a < SK_NB ? a : SK_NB), bb = b == SKB_STATIC ? -1 : (b < SK_NB ? b : SK_NB);
+    if (ba >= 0 && bb >= 0 && ba != bb) { cm[ba] |= 1u << bb; cm[bb] |= 1u << ba; }
+  }
+  for (int k = 0; k <= SK_NB; k++)       // eliminating block k couples every pair of later blocks it touches
+    for (int i = k + 1; i <= SK_NB; i++) if ((cm[k] >> i) & 1u)
+      for (int j = k + 1; j <= SK_NB; j++) if (j != i && ((cm[k] >> j) & 1u)) cm[i] |= 1u << j;
+  bool converged = false;
+  for (int it = 0; it < 60 && !converged; it++) {
+    // gradient and Hessian at x
+    for (int i = 0; i < SK_NH; i++) SL(ST_H + i) = 0;
+    for (int i = 0; i < SK_NV; i++) SL(ST_G + i) = sk_Mv(kc, sc, i, ST_X, ST_A0);
+    for (int b = 0; b < SK_NB; b++) for (int k = 0; k < 6; k++) SL(ST_H + tri(6 * b + k, 6 * b + k)) = k < 3 ? kc.box_mass[b] : kc.box_inertia[b][k - 3];
+    for (int a = 0; a < NDOF; a++) for (int k = 0; k <= a; k++) SL(ST_H + tri(SK_ARM0 + a, SK_ARM0 + k)) = SL(ST_M + tri(a, k));
+    for (int a = 0; a < NDOF; a++) {     // joint-limit rows
+      const double sg = SL(ST_LIM + 3 * a), D = SL(ST_LIM + 3 * a + 1), ar = SL(ST_LIM + 3 * a + 2);
+      if (sg != 0) {
+        const double jar = sg * SL(ST_X + SK_ARM0 + a) - ar;
+        if (jar < 0) { SL(ST_G + SK_ARM0 + a) += sg * D * jar; SL(ST_H + tri(SK_ARM0 + a, SK_ARM0 + a)) += D; }
+      }
+    }
+    for (int ci = 0; ci < ncon; ci++) {
+      SkCon c; sk_rows(kc, sc, ci, c);
+      const int base = ci * SREC;
+      double jar[4] = {0, 0, 0, 0}, D[4], f[4], Hc[16];
+      for (int r = 0; r < c.dim; r++) jar[r] = sk_row_dot(sc, c, r, ST_X) - SG(base + 16 + r);
+      for (int r = 0; r < 4; r++) { D[r] = SG(base + 20 + r); SG(base + 25 + r) = jar[r]; }
+      double fr[3]; sk_row_fric(kc.set[c.set], fr);
+      sk_cone(c.dim, jar, D, SG(base + 24), fr, f, Hc);
+      // g -= J' f ; H += J' Hc J  (J = [ -A | +B ])
+      for (int side = 0; side < 2; side++) {
+        const SkSide& S = side ? c.B : c.A;
+        const double sg = side ? 1.0 : -1.0;
+        for (int k = 0; k < S.n; k++) {
+          double acc = 0;
+          for (int r = 0; r < c.dim; r++) acc += S.J[r][k] * f[r];
+          SL(ST_G + S.off + k) -= sg * acc;
+        }
+      }
+      bool any = false;
+      for (int i = 0; i < 16; i++) any = any || Hc[i] != 0;
+      if (!any) continue;
+      for (int s1 = 0; s1 < 2; s1++) {
+        const SkSide& S1 = s1 ? c.B : c.A;
+        for (int s2 = 0; s2 <= s1; s2++) {
+          const SkSide& S2 = s2 ? c.B : c.A;
+          if (S1.n == 0 || S2.n == 0) continue;
+          const double sg = (s1 == s2) ? 1.0 : -1.0;
+          // the block with the larger offset supplies the rows of the packed lower triangle
+          const bool swap = S1.off < S2.off;
+          const SkSide& Rw = swap ? S2 : S1; const SkSide& Cl = swap ? S1 : S2;
+          for (int i = 0; i < Rw.n; i++) {
+            double t[4] = {0, 0, 0, 0};     // (J_rw' Hc)_i over the rows
+            for (int r = 0; r < c.dim; r++) for (int q = 0; q < c.dim; q++) t[q] += Rw.J[r][i] * (swap ? Hc[4 * q + r] : Hc[4 * r + q]);
+            const int kmax = (s1 == s2) ? i + 1 : Cl.n;
+            for (int k = 0; k < kmax; k++) {
+              double acc = 0;
+              for (int q = 0; q < c.dim; q++) acc += t[q] * Cl.J[q][k];
+              SL(ST_H + tri(Rw.off + i, Cl.off + k)) += sg * acc;
+            }
+          }
+        }
+      }
+    }
+    double gm = 0, gn = 0;
+    for (int i = 0; i < SK_NV; i++) { gm = fmax(gm, fabs(SL(ST_G + i))); gn += SL(ST_G + i) * SL(ST_G + i); }
+    if (gm <= D3IL_TOL.grad_tol) { converged = true; break; }
+    if (!sk_chol(sc, cm)) return false;
+    for (int i = 0; i < SK_NV; i++) SL(ST_P + i) = -SL(ST_G + i);
+    sk_chol_solve(sc, cm, ST_P);
+    // line search: phi'(alpha) = p' M (x - a0) + alpha p' M p - sum f(jar + alpha Jp) . Jp, safeguarded Newton on alpha
+    double pMp = 0, pMa = 0, gTp = 0;
+    for (int i = 0; i < SK_NV; i++) {
+      const double p = SL(ST_P + i);
+      gTp += SL(ST_G + i) * p;
+    }
+    {   // p' M p and p' M (x - a0) with the block-diagonal M
+      for (int i = 0; i < SK_ARM0; i++) { const int b = i / 6, k = i % 6; const double m = k < 3 ? kc.box_mass[b] : kc.box_inertia[b][k - 3], p = SL(ST_P + i); pMp += m * p * p; pMa += m * p * (SL(ST_X + i) - SL(ST_A0 + i)); }
+      for (int a = 0; a < NDOF; a++) {
+        double mp = 0, ma = 0;
+        for (int k = 0; k < NDOF; k++) { const double m = SL(ST_M + (a >= k ? tri(a, k) : tri(k, a))); mp += m * SL(ST_P + SK_ARM0 + k); ma += m * (SL(ST_X + SK_ARM0 + k) - SL(ST_A0 + SK_ARM0 + k)); }
+        pMp += SL(ST_P + SK_ARM0 + a) * mp; pMa += SL(ST_P + SK_ARM0 + a) * ma;
+      }
+    }
+    for (int ci = 0; ci < ncon; ci++) {
+      SkCon c; sk_rows(kc, sc, ci, c);
+      for (int r = 0; r < 4; r++) SG(ci * SREC + 29 + r) = r < c.dim ? sk_row_dot(sc, c, r, ST_P) : 0.0;
+    }
+    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
+    for (int ls = 0; ls < 50; ls++) {
+      double d1 = pMa + alpha * pMp, d2 = pMp;
+      for (int a = 0; a < NDOF; a++) {
+        const double sg = SL(ST_LIM + 3 * a), D = SL(ST_LIM + 3 * a + 1), ar = SL(ST_LIM + 3 * a + 2);
+        if (sg != 0) {
+          const double jp = sg * SL(ST_P + SK_ARM0 + a), jar = sg * SL(ST_X + SK_ARM0 + a) - ar + alpha * jp;
+          if (jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
+        }
+      }
+      for (int ci = 0; ci < ncon; ci++) {
+        const int base = ci * SREC, set = (int)SG(base + 15), dim = kc.set[set].dim;
+        double jt[4], jp[4], D[4], f[4], Hc[16];
+        for (int r = 0; r < 4; r++) { jp[r] = SG(base + 29 + r); jt[r] = SG(base + 25 + r) + alpha * jp[r]; D[r] = SG(base + 20 + r); }
+        double fr[3]; sk_row_fric(kc.set[set], fr);
+        sk_cone(dim, jt, D, SG(base + 24), fr, f, Hc);
+        for (int r = 0; r < dim; r++) { d1 -= f[r] * jp[r]; for (int q = 0; q < dim; q++) d2 += jp[r] * Hc[4 * r + q] * jp[q]; }
+      }
+      best = alpha;
+      if (ls == 0 && d1 <= D3IL_TOL.ls_full * fabs(gTp)) break;
+      if (fabs(d1) <= D3IL_TOL.ls_c2 * fabs(gTp) || fabs(d1) <= D3IL_TOL.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 / d2;
+      if (hi >= 0) {
+        const double wbr = hi - lo;
+        const bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+    double smax = 0, xmax = 0;
+    for (int i = 0; i < SK_NV; i++) { const double dx = best * SL(ST_P + i); SL(ST_X + i) += dx; smax = fmax(smax, fabs(dx)); xmax = fmax(xmax, fabs(SL(ST_X + i))); }
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
+    (void)gn;
+  }
+  return converged;
+}
+
+// ------------------------------------------------------------------------------------------------ sub-step
+struct StackState { EnvState arm; BoxState box[SK_NB]; };
+
+D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& ncon, unsigned& flags, const double* rec7, double nsign, int bodyA, int bodyB, int set) {
+  if (ncon >= SK_MAXCON) { flags |= SKF_CON_OVERFLOW; return; }
+  const int base = ncon * SREC;
+  double n[3] = {nsign * rec7[4], nsign * rec7[5], nsign * rec7[6]}, t1[3], t2[3];
+  make_frame(n, t1, t2);
+  SG(base + 0) = rec7[1]; SG(base + 1) = rec7[2]; SG(base + 2) = rec7[3];
+  for (int k = 0; k < 3; k++) { SG(base + 3 + k) = n[k]; SG(base + 6 + k) = t1[k]; SG(base + 9 + k) = t2[k]; }
+  SG(base + 12) = rec7[0]; SG(base + 13) = (double)bodyA; SG(base + 14) = (double)bodyB; SG(base + 15) = (double)set;
+  ncon++;
+}
+D3IL_HD double sk_invw(const StackConsts& kc_, int body) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  if (body == SKB_STATIC) return 0.0;
+  if (body < SK_NB) return 1.0 / kc.box_mass[body];
+  const int f = (body - SKB_FINGER) & 1;
+  return body >= SKB_TIP ? kc.invw_tip[f] : kc.invw_finger[f];
+}
+
+// One physics sub-step (mj_step) with the torques of this sub-step's control law.
+template <class C>
+D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  D3IL_REFRESH(c0, c);
+  EnvState& st = ss.arm;
+  const double h = c.timestep;
+  // ---- arm forward pass
+  DynOut dyn;
+  dynamics(c0, st.q, st.v, dyn);
+  double fs[NDOF];
+  for (int k = 0; k < NARM; k++) fs[k] = clampd(tau[k] + st.bias[k], c.force_lo[k], c.force_hi[k]) - dyn.bias[k];
+  for (int k = 0; k < NFING; k++) fs[NARM + k] = clampd(ffing[k], c.force_lo[NARM + k], c.force_hi[NARM + k]) - dyn.bias[NARM + k] - c.f_damping[k] * st.v[NARM + k];
+  for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
+  {
+    double t[3]; mulE(dyn.R7, c.tcp7, t);
+    st.tcp[0] = dyn.p7[0] + t[0]; st.tcp[1] = dyn.p7[1] + t[1]; st.tcp[2] = dyn.p7[2] + t[2];
+  }
+  for (int k = 0; k < 45; k++) SL(ST_M + k) = dyn.M[k];
+  {   // smooth acceleration of the arm
+    double L[45], d[NDOF], id[NDOF], a0[NDOF];
+    if (!ldl9(dyn.M, L, d, id)) st.flags |= F_SOLVER_FAIL;
+    for (int k = 0; k < NDOF; k++) a0[k] = fs[k];
+    ldl9_solve(L, id, a0);
+    for (int k = 0; k < NDOF; k++) { SL(ST_A0 + SK_ARM0 + k) = a0[k]; SL(ST_VEL + SK_ARM0 + k) = st.v[k]; }
+  }
+  {   // world joint axes / origins, finger slide axes, finger geom poses
+    double R7[9], p7[3], ax[NARM][3], og[NARM][3];
+    world_chain(c0, dyn.sn, dyn.cs, R7, p7, ax, og);
+    for (int k = 0; k < NARM; k++) for (int i = 0; i < 3; i++) { SL(ST_Z + 3 * k + i) = ax[k][i]; SL(ST_O + 3 * k + i) = og[k][i]; }
+    for (int f = 0; f < NFING; f++) {
+      double axw[3]; mulE(R7, c.f_axis[f], axw);
+      for (int i = 0; i < 3; i++) SL(ST_FAX + 3 * f + i) = axw[i];
+      const double qf = st.q[NARM + f];
+      for (int g = 0; g < 2; g++) {
+        const double* Rl = g ? kc.hull_R[f] : kc.tip_R[f];
+        const double* pl = g ? kc.hull_p[f] : kc.tip_p[f];
+        const int oR = (g ? ST_HULR : ST_TIPR) + 9 * f, oP = (g ? ST_HULP : ST_TIPP) + 3 * f;
+        double pm[3] = {pl[0] + c.f_axis[f][0] * qf, pl[1] + c.f_axis[f][1] * qf, pl[2] + c.f_axis[f][2] * qf}, pw[3];
+        mulE(R7, pm, pw);
+        for (int i = 0; i < 3; i++) SL(oP + i) = p7[i] + pw[i];
+        for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) SL(oR + 3 * r + cc) = R7[3 * r] * Rl[cc] + R7[3 * r + 1] * Rl[3 + cc] + R7[3 * r + 2] * Rl[6 + cc];
+      }
+    }
+  }
+  // ---- boxes: rotation matrices, smooth acceleration (gravity, gyroscopic term of the body-frame angular dofs)
+  for (int b = 0; b < SK_NB; b++) {
+    double R[9], qn[4];     // mj_kinematics works on the normalised quaternion (a context may be off by float32 round-off)
+    { const double* q = ss.box[b].quat; const double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]); for (int k = 0; k < 4; k++) qn[k] = q[k] / nn; }
+    quat2mat(qn, R);
+    for (int k = 0; k < 9; k++) SL(ST_BR + 9 * b + k) = R[k];
+    for (int k = 0; k < 3; k++) SL(ST_BP + 3 * b + k) = ss.box[b].pos[k];
+    const double* I = kc.box_inertia[b];
+    const double* w = ss.box[b].vel + 3;
+    const double Iw[3] = {I[0] * w[0], I[1] * w[1], I[2] * w[2]};
+    double gy[3]; cross3(w, Iw, gy);
+    for (int k = 0; k < 3; k++) { SL(ST_A0 + 6 * b + k) = c.gravity[k]; SL(ST_A0 + 6 * b + 3 + k) = -gy[k] / I[k]; }
+    for (int k = 0; k < 6; k++) SL(ST_VEL + 6 * b + k) = ss.box[b].vel[k];
+    if (ss.box[b].pos[0] < kc.ws_lo[0] || ss.box[b].pos[0] > kc.ws_hi[0] || ss.box[b].pos[1] < kc.ws_lo[1] || ss.box[b].pos[1] > kc.ws_hi[1]) st.flags |= SKF_OFF_TABLE;
+  }
+  // ---- collision, in the model's geom order: static < boxes < left hull < left tip < right hull < right tip
+  int ncon = 0;
+  double rec[8][7];
+  auto boxR = [&](int b, double* R) { for (int k = 0; k < 9; k++) R[k] = SL(ST_BR + 9 * b + k); };
+  auto rcirc = [&](const double* hf) { return sqrt(hf[0] * hf[0] + hf[1] * hf[1] + hf[2] * hf[2]); };
+  for (int s = 0; s < kc.ns; s++)
+    for (int b = 0; b < SK_NB; b++) {
+      double R[9]; boxR(b, R);
+      // sphere against the static box (exact distance of the centre from the box)
+      double d[3] = {ss.box[b].pos[0] - kc.st_c[s][0], ss.box[b].pos[1] - kc.st_c[s][1], ss.box[b].pos[2] - kc.st_c[s][2]}, ex = 0;
+      for (int i = 0; i < 3; i++) { double loc = kc.st_R[s][i] * d[0] + kc.st_R[s][3 + i] * d[1] + kc.st_R[s][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[s][i]; if (o > 0) ex += o * o; }
+      const double rc = rcirc(kc.box_half[b]) + kc.set[SKS_STATIC + s].margin;
+      if (ex > rc * rc) continue;
+      const int n = box_box(kc.st_c[s], kc.st_R[s], kc.st_h[s], ss.box[b].pos, R, kc.box_half[b], kc.set[SKS_STATIC + s].margin, rec, 8);
+      for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, SKB_STATIC, b, SKS_STATIC + s);
+    }
+  for (int b1 = 0; b1 < SK_NB; b1++)
+    for (int b2 = b1 + 1; b2 < SK_NB; b2++) {
+      double d[3] = {ss.box[b2].pos[0] - ss.box[b1].pos[0], ss.box[b2].pos[1] - ss.box[b1].pos[1], ss.box[b2].pos[2] - ss.box[b1].pos[2]};
+      const double rc = rcirc(kc.box_half[b1]) + rcirc(kc.box_half[b2]) + kc.set[SKS_BOXBOX].margin;
+      if (dot3(d, d) > rc * rc) continue;
+      double R1[9], R2[9]; boxR(b1, R1); boxR(b2, R2);
+      const int n = box_box(ss.box[b1].pos, R1, kc.box_half[b1], ss.box[b2].pos, R2, kc.box_half[b2], kc.set[SKS_BOXBOX].margin, rec, 8);
+      for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, b1, b2, SKS_BOXBOX);
+    }
+  const double r_tip = rcirc(kc.tip_half);
+  double r_hull = 0;
+  for (int i = 0; i < kc.hull_nv; i++) { double d[3] = {kc.hull_v[i][0] - kc.hull_center[0], kc.hull_v[i][1] - kc.hull_center[1], kc.hull_v[i][2] - kc.hull_center[2]}; r_hull = fmax(r_hull, dot3(d, d)); }
+  r_hull = sqrt(r_hull);
+  double fR[NFING][2][9], fP[NFING][2][3], hullC[NFING][3];
+  for (int f = 0; f < NFING; f++) {
+    for (int k = 0; k < 9; k++) { fR[f][0][k] = SL(ST_HULR + 9 * f + k); fR[f][1][k] = SL(ST_TIPR + 9 * f + k); }
+    for (int k = 0; k < 3; k++) { fP[f][0][k] = SL(ST_HULP + 3 * f + k); fP[f][1][k] = SL(ST_TIPP + 3 * f + k); }
+    for (int k = 0; k < 3; k++) hullC[f][k] = fR[f][0][3 * k] * kc.hull_center[0] + fR[f][0][3 * k + 1] * kc.hull_center[1] + fR[f][0][3 * k + 2] * kc.hull_center[2] + fP[f][0][k];
+  }
+  for (int b = 0; b < SK_NB; b++) {
+    double R[9]; boxR(b, R);
+    const double rb = rcirc(kc.box_half[b]);
+    for (int f = 0; f < NFING; f++) {
+      {   // box <-> finger hull (geom order: box first)
+        double d[3] = {hullC[f][0] - ss.box[b].pos[0], hullC[f][1] - ss.box[b].pos[1], hullC[f][2] - ss.box[b].pos[2]};
+        const double rc = rb + r_hull + kc.set[SKS_BOXHULL].margin;
+        if (dot3(d, d) <= rc * rc) {
+          SkShape A{R, ss.box[b].pos, kc.box_half[b], 0}, B{fR[f][0], fP[f][0], nullptr, 1};
+          double r7[7];
+          if (sk_mpr(kc, A, B, kc.set[SKS_BOXHULL].margin, r7)) sk_add_contact(kc, sc, ncon, st.flags, r7, 1.0, b, SKB_FINGER + f, SKS_BOXHULL);
+        }
+      }
+      {   // box <-> finger-tip box
+        double d[3] = {fP[f][1][0] - ss.box[b].pos[0], fP[f][1][1] - ss.box[b].pos[1], fP[f][1][2] - ss.box[b].pos[2]};
+        const double rc = rb + r_tip + kc.set[SKS_BOXTIP].margin;
+        if (dot3(d, d) <= rc * rc) {
+          const int n = box_box(ss.box[b].pos, R, kc.box_half[b], fP[f][1], fR[f][1], kc.tip_half, kc.set[SKS_BOXTIP].margin, rec, 8);
+          for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, b, SKB_TIP + f, SKS_BOXTIP);
+        }
+      }
+    }
+    {   // hand mesh: not evaluated; flag a box that reaches its bounding box
+      double Rh[9], ph[3], pm[3];
+      for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) Rh[3 * r + cc] = dyn.R7[3 * r] * kc.hand_R[cc] + dyn.R7[3 * r + 1] * kc.hand_R[3 + cc] + dyn.R7[3 * r + 2] * kc.hand_R[6 + cc];
+      mulE(dyn.R7, kc.hand_p, pm);
+      for (int k = 0; k < 3; k++) ph[k] = dyn.p7[k] + pm[k];
+      double dw[3] = {ss.box[b].pos[0] - ph[0], ss.box[b].pos[1] - ph[1], ss.box[b].pos[2] - ph[2]};
+      bool inside = true;
+      for (int i = 0; i < 3; i++) {
+        double ci = Rh[i] * dw[0] + Rh[3 + i] * dw[1] + Rh[6 + i] * dw[2], ei = 0;
+        for (int j = 0; j < 3; j++) ei += fabs(Rh[i] * R[j] + Rh[3 + i] * R[3 + j] + Rh[6 + i] * R[6 + j]) * kc.box_half[b][j];
+        if (ci - ei > kc.hand_hi[i] || ci + ei < kc.hand_lo[i]) inside = false;
+      }
+      if (inside) st.flags |= SKF_HAND_NEAR;
+    }
+  }
+  if (st.q[NARM] + st.q[NARM + 1] < 0.004) {     // finger <-> finger: only a (nearly) closed gripper (the gaps are q1 + q2 - 1 mm or less)
+    double r7[7];
+    {
+      SkShape A{fR[0][0], fP[0][0], nullptr, 1}, B{fR[1][0], fP[1][0], nullptr, 1};
+      if (sk_mpr(kc, A, B, kc.set[SKS_HULLHULL].margin, r7)) sk_add_contact(kc, sc, ncon, st.flags, r7, 1.0, SKB_FINGER, SKB_FINGER + 1, SKS_HULLHULL);
+    }
+    {
+      SkShape A{fR[0][0], fP[0][0], nullptr, 1}, B{fR[1][1], fP[1][1], kc.tip_half, 0};
+      if (sk_mpr(kc, A, B, kc.set[SKS_HULLTIP].margin, r7)) sk_add_contact(kc, sc, ncon, st.flags, r7, 1.0, SKB_FINGER, SKB_TIP + 1, SKS_HULLTIP);
+    }
+    {
+      SkShape A{fR[0][1], fP[0][1], kc.tip_half, 0}, B{fR[1][0], fP[1][0], nullptr, 1};
+      if (sk_mpr(kc, A, B, kc.set[SKS_HULLTIP].margin, r7)) sk_add_contact(kc, sc, ncon, st.flags, r7, 1.0, SKB_TIP, SKB_FINGER + 1, SKS_HULLTIP);
+    }
+    const int n = box_box(fP[0][1], fR[0][1], kc.tip_half, fP[1][1], fR[1][1], kc.tip_half, kc.set[SKS_TIPTIP].margin, rec, 8);
+    for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, SKB_TIP, SKB_TIP + 1, SKS_TIPTIP);
+  }
+  // ---- joint-limit rows (mj_instantiateLimit) of the 9 arm dofs
+  bool any_lim = false;
+  for (int k = 0; k < NDOF; k++) {
+    const double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
+    double sign = 0, dist = 0;
+    if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; } else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
+    double D = 0, ar = 0;
+    if (sign != 0) {
+      const double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
+      D = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
+      ar = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
+      any_lim = true;
+    }
+    SL(ST_LIM + 3 * k) = sign; SL(ST_LIM + 3 * k + 1) = D; SL(ST_LIM + 3 * k + 2) = ar;
+  }
+  // ---- reference accelerations and regularisation of the contact rows (mj_makeImpedance, elliptic cones)
+  for (int ci = 0; ci < ncon; ci++) {
+    SkCon cn; sk_rows(kc, sc, ci, cn);
+    const int base = ci * SREC;
+    const StackSet& ps = kc.set[cn.set];
+    const double dist = SG(base + 12);
+    const double imp = impedance(ps.solimp, dist - ps.margin);
+    const double R0 = fmax(1e-15, (1 - imp) / imp * (sk_invw(kc, (int)SG(base + 13)) + sk_invw(kc, (int)SG(base + 14))));
+    const double R1 = R0 / fmax(1e-15, kc.impratio);
+    for (int r = 0; r < 4; r++) {
+      const double v = r < cn.dim ? sk_row_dot(sc, cn, r, ST_VEL) : 0.0;
+      SG(base + 16 + r) = r < cn.dim ? -ps.B * v - (r == 0 ? ps.K * imp * (dist - ps.margin) : 0.0) : 0.0;
+    }
+    SG(base + 20) = 1 / R0; SG(base + 21) = 1 / R1; SG(base + 22) = 1 / R1;
+    SG(base + 23) = 1 / (R1 * ps.fric[0] * ps.fric[0] / (ps.fric[1] * ps.fric[1]));
+    SG(base + 24) = ps.fric[0] * sqrt(R1 / R0);
+  }
+  // ---- solve
+  for (int i = 0; i < SK_NV; i++) SL(ST_X + i) = SL(ST_A0 + i);
+  if (ncon > 0 || any_lim) { if (!sk_solve(kc, sc, ncon)) st.flags |= F_SOLVER_FAIL; }
+  // ---- mj_Euler: implicit in the finger-joint damping (M + h B) qacc = M x on the arm block
+  {
+    double Mh[45], rhs[NDOF], L[45], d[NDOF], id[NDOF];
+    for (int k = 0; k < 45; k++) Mh[k] = dyn.M[k];
+    for (int a = 0; a < NDOF; a++) { double s = 0; for (int k = 0; k < NDOF; k++) s += dyn.M[a >= k ? tri(a, k) : tri(k, a)] * SL(ST_X + SK_ARM0 + k); rhs[a] = s; }
+    for (int k = 0; k < NFING; k++) Mh[tri(NARM + k, NARM + k)] += h * c.f_damping[k];
+    if (!ldl9(Mh, L, d, id)) st.flags |= F_SOLVER_FAIL;
+    ldl9_solve(L, id, rhs);
+    for (int k = 0; k < NDOF; k++) { st.v[k] += h * rhs[k]; st.q[k] += h * st.v[k]; }
+  }
+  for (int b = 0; b < SK_NB; b++) {
+    double acc[6];
+    for (int k = 0; k < 6; k++) acc[k] = SL(ST_X + 6 * b + k);
+    cube_integrate(ss.box[b], acc, h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ env level (stacking.py)
+D3IL_HD void stack_obs(const StackState& ss, float* obs) {     // stacking.py:228-277: (x, y, z, tan yaw) x 3
+  for (int b = 0; b < SK_NB; b++) {
+    obs[4 * b] = (float)ss.box[b].pos[0]; obs[4 * b + 1] = (float)ss.box[b].pos[1]; obs[4 * b + 2] = (float)ss.box[b].pos[2];
+    obs[4 * b + 3] = (float)push_tan_yaw(ss.box[b].quat);
+  }
+}
+D3IL_HD bool stack_success(const StackConsts& kc_, const StackState& ss) {    // _check_early_termination, stacking.py:425-447
+  D3IL_STACK_CONSTS(kc_, kc);
+  double dz = fmin(fabs(ss.box[0].pos[2] - ss.box[1].pos[2]), fmin(fabs(ss.box[0].pos[2] - ss.box[2].pos[2]), fabs(ss.box[1].pos[2] - ss.box[2].pos[2])));
+  bool ok = dz > 0.03;
+  for (int b = 0; b < SK_NB; b++) {
+    double dx = ss.box[b].pos[0] - kc.target[0], dy = ss.box[b].pos[1] - kc.target[1];
+    ok = ok && sqrt(dx * dx + dy * dy) <= kc.min_dist;
+  }
+  return ok;
+}
+D3IL_HD void stack_check_mode(const StackConsts& kc_, StackState& ss, double* mean_dist) {   // check_mode, stacking.py:395-419
+  D3IL_STACK_CONSTS(kc_, kc);
+  unsigned fl = ss.arm.flags;
+  int n = (int)(fl & SKF_NMODE_MASK);
+  double d[3], md = 0;
+  for (int b = 0; b < SK_NB; b++) { double dx = ss.box[b].pos[0] - kc.target[0], dy = ss.box[b].pos[1] - kc.target[1]; d[b] = sqrt(dx * dx + dy * dy); md += d[b]; }
+  *mean_dist = md / 3;
+  for (int i = 0; i < n; i++) d[(fl >> (SKF_IND_SHIFT + 2 * i)) & 3u] = 100000;
+  int mi = 0;
+  for (int b = 1; b < SK_NB; b++) if (d[b] < d[mi]) mi = b;
+  if (d[mi] <= kc.min_dist && n < 3) {
+    fl = (fl & ~SKF_NMODE_MASK) | (unsigned)(n + 1);
+    fl = (fl & ~(3u << (SKF_IND_SHIFT + 2 * n))) | ((unsigned)mi << (SKF_IND_SHIFT + 2 * n));
+  }
+  ss.arm.flags = fl;
+}
+D3IL_HD int stack_mode_code(unsigned flags) { return (int)(flags & 0xFFu); }   // n | letters << 2 (0 r, 1 g, 2 b): info['mode'] as an integer
+
+// joint PD with qd_des = 0 (module comment of the oracle's Stacking section) + finger control
+template <class C>
+D3IL_HD void stack_control(const C& c, const EnvState& st, const double* q_des, double set_width, bool grasp, double* tau, double* ff) {
+  double zero[NARM] = {0, 0, 0, 0, 0, 0, 0};
+  push_control(c, st, q_des, zero, set_width, grasp, tau, ff);
+}
+template <class C>
+D3IL_HD void stack_env_step(const C& c, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* action, float* obs, unsigned char* done,
+                            double* mean_dist, int n_substeps, int max_steps) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const bool open = action[7] > kc.grip_thresh;
+  const double width = open ? 0.04 : 0.0;
+  stack_obs(ss, obs);
+  bool fin = (ss.arm.flags & F_TERMINATED) != 0;
+  if (!fin && stack_success(kc, ss)) { ss.arm.flags |= F_TERMINATED; fin = true; }
+  if (!fin && ss.arm.step >= max_steps - 1) fin = true;
+  *done = fin ? 1 : 0;
+  for (int s = 0; s < n_substeps; s++) {
+    double tau[NARM], ff[NFING];
+    stack_control(c, ss.arm, action, width, !open, tau, ff);
+    stack_physics_substep(c, kc, ss, sc, tau, ff);
+  }
+  ss.arm.step += 1;
+  if (stack_success(kc, ss)) ss.arm.flags |= F_SUCCESS | F_TERMINATED; else ss.arm.flags &= ~F_SUCCESS;
+  stack_check_mode(kc, ss, mean_dist);
+}
+// reset(random=False, context): scene.reset + beam to init_qpos + open_fingers + contexts + one sub-step (stacking.py:449-481)
+template <class C>
+D3IL_HD void stack_env_reset(const C& c, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* init_qpos, const double* ctx, float* obs) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  EnvState& st = ss.arm;
+  for (int k = 0; k < NDOF; k++) { st.q[k] = k < NARM ? init_qpos[k] : 0.0; st.v[k] = 0; }
+  st.flags = 0; st.step = 0;
+  {   // mj_forward at the beamed pose: qfrc_bias and TCP of that pass are what the first controller call reads
+    DynOut dyn;
+    dynamics(c, st.q, st.v, dyn);
+    for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
+    double t[3]; mulE(dyn.R7, c.tcp7, t);
+    for (int k = 0; k < 3; k++) st.tcp[k] = dyn.p7[k] + t[k];
+  }
+  for (int b = 0; b < SK_NB; b++) {
+    for (int k = 0; k < 3; k++) ss.box[b].pos[k] = ctx[7 * b + k];
+    for (int k = 0; k < 4; k++) ss.box[b].quat[k] = ctx[7 * b + 3 + k];
+    for (int k = 0; k < 6; k++) ss.box[b].vel[k] = 0;
+  }
+  double tau[NARM], ff[NFING];
+  stack_control(c, st, init_qpos, 0.04, false, tau, ff);
+  stack_physics_substep(c, kc, ss, sc, tau, ff);
+  stack_obs(ss, obs);
+  (void)kc;
+}
+
+// ------------------------------------------------------------------------------------------------ constants from the blob (host)
+D3IL_HOSTFN inline int build_stack_consts(const d3il_model_blob& m, const PandaConsts& pcst, StackConsts& kc, const char** err) {
+  using hostmath::Xf; using hostmath::identity; using hostmath::compose; using hostmath::mv; using hostmath::solref_kb; using hostmath::clamp_solimp;
+  std::memset(&kc, 0, sizeof kc);
+  if (m.n_obj != SK_NB) { *err = "stacking needs three task objects"; return -1; }
+  if (m.nmesh < 1) { *err = "stacking needs the finger hull (blob meshes)"; return -1; }
+  kc.nb = SK_NB;
+  auto obj_geom = [&](int body) { for (int g = 0; g < m.ngeom; g++) if (m.geom_body[g] == body && m.geom_contype[g]) return g; return -1; };
+  int gb[SK_NB];
+  for (int b = 0; b < SK_NB; b++) {
+    int bd = m.obj_body[b]; gb[b] = obj_geom(bd);
+    if (gb[b] < 0 || m.geom_type[gb[b]] != D3IL_GEOM_BOX) { *err = "task objects must be boxes"; return -1; }
+    for (int k = 0; k < 3; k++) { kc.box_half[b][k] = m.geom_size[gb[b]][k]; kc.box_inertia[b][k] = m.body_inertia[bd][k]; if (m.geom_pos[gb[b]][k] != 0) { *err = "boxes must be centred on their bodies"; return -1; } }
+    if (m.body_iquat[bd][0] != 1.0) { *err = "box inertial frames must be the body frames"; return -1; }
+    kc.box_mass[b] = m.body_mass[bd];
+    if (b > 0 && gb[b] < gb[b - 1]) { *err = "unexpected geom order"; return -1; }
+  }
+  // world transforms of all bodies at q = 0
+  static thread_local Xf X0[D3IL_MAXBODY];
+  X0[0] = identity();
+  for (int b = 1; b < m.nbody; b++) { Xf l; quat2mat(m.body_quat[b], l.R); std::memcpy(l.p, m.body_pos[b], sizeof l.p); X0[b] = compose(X0[m.body_parent[b]], l); }
+  auto rel = [&](int a, int b) {
+    Xf inv; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inv.R[3 * i + j] = X0[a].R[3 * j + i];
+    double t[3]; mv(inv.R, X0[a].p, t); for (int k = 0; k < 3; k++) inv.p[k] = -t[k];
+    return compose(inv, X0[b]);
+  };
+  auto weld_root = [&](int b) { while (b > 0 && m.body_jntnum[b] == 0) b = m.body_parent[b]; return b; };
+  auto mix = [&](int g1, int g2, StackSet& s) {   // mj_contactParam: priority, else solmix average / max friction / max condim
+    int src = m.geom_priority[g1] > m.geom_priority[g2] ? g1 : (m.geom_priority[g2] > m.geom_priority[g1] ? g2 : -1);
+    double sr[2], si[5];
+    if (src >= 0) { for (int k = 0; k < 2; k++) sr[k] = m.geom_solref[src][k]; for (int k = 0; k < 5; k++) si[k] = m.geom_solimp[src][k]; for (int k = 0; k < 3; k++) s.fric[k] = m.geom_friction[src][k]; s.dim = m.geom_condim[src]; }
+    else {
+      double s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2], w = s1 / (s1 + s2);
+      for (int k = 0; k < 2; k++) sr[k] = w * m.geom_solref[g1][k] + (1 - w) * m.geom_solref[g2][k];
+      for (int k = 0; k < 5; k++) si[k] = w * m.geom_solimp[g1][k] + (1 - w) * m.geom_solimp[g2][k];
+      for (int k = 0; k < 3; k++) s.fric[k] = std::fmax(m.geom_friction[g1][k], m.geom_friction[g2][k]);
+      s.dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
+    }
+    solref_kb(sr, si, m.timestep, &s.K, &s.B);
+    clamp_solimp(si, s.solimp);
+    s.margin = std::fmax(m.geom_margin[g1], m.geom_margin[g2]) - std::fmax(m.geom_gap[g1], m.geom_gap[g2]);
+    return (s.dim == 3 || s.dim == 4) ? 0 : -1;
+  };
+  // static boxes under the workspace (as build_gen_consts: the table-top footprint without its rim is the modelled workspace)
+  double rmax = 0;
+  for (int b = 0; b < SK_NB; b++) rmax = std::fmax(rmax, std::sqrt(kc.box_half[b][0] * kc.box_half[b][0] + kc.box_half[b][1] * kc.box_half[b][1] + kc.box_half[b][2] * kc.box_half[b][2]));
+  int ns = 0, table = -1;
+  double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
+  for (int pass = 0; pass < 2; pass++)
+  for (int g = 0; g < m.ngeom; g++) {
+    if (m.geom_type[g] != D3IL_GEOM_BOX) continue;
+    if (!((m.geom_contype[g] & m.geom_conaffinity[gb[0]]) || (m.geom_contype[gb[0]] & m.geom_conaffinity[g]))) continue;
+    if (weld_root(m.geom_body[g]) != 0) continue;
+    Xf gl; quat2mat(m.geom_quat[g], gl.R); std::memcpy(gl.p, m.geom_pos[g], sizeof gl.p);
+    Xf xg = compose(X0[m.geom_body[g]], gl);
+    double ext[3];
+    for (int i = 0; i < 3; i++) ext[i] = std::fabs(xg.R[3 * i]) * m.geom_size[g][0] + std::fabs(xg.R[3 * i + 1]) * m.geom_size[g][1] + std::fabs(xg.R[3 * i + 2]) * m.geom_size[g][2];
+    if (pass == 0) {
+      if (std::fabs(m.geom_size[g][0] - 0.49) < 1e-12 && std::fabs(m.geom_size[g][1] - 0.98) < 1e-12 && std::fabs(m.geom_size[g][2] - 0.001) < 1e-12) {
+        table = g;
+        // the aluminium profiles around the table edge reach ~2.5 cm into the footprint: a box centre stays 3 cm + its circumradius inside
+        for (int i = 0; i < 2; i++) { wlo[i] = xg.p[i] - ext[i] + 0.03 + rmax; whi[i] = xg.p[i] + ext[i] - 0.03 - rmax; kc.ws_lo[i] = wlo[i]; kc.ws_hi[i] = whi[i]; wlo[i] -= rmax; whi[i] += rmax; }
+        wlo[2] = xg.p[2] + ext[2] - rmax;
+      }
+      continue;
+    }
+    if (table < 0) { *err = "table slab not found"; return -1; }
+    if (xg.p[0] + ext[0] < wlo[0] || xg.p[0] - ext[0] > whi[0] || xg.p[1] + ext[1] < wlo[1] || xg.p[1] - ext[1] > whi[1] || xg.p[2] + ext[2] < wlo[2]) continue;
+    if (ns >= SK_MAXNS) { *err = "too many static boxes"; return -1; }
+    if (g > gb[0]) { *err = "static geoms must precede the boxes"; return -1; }
+    for (int k = 0; k < 3; k++) { kc.st_c[ns][k] = xg.p[k]; kc.st_h[ns][k] = m.geom_size[g][k]; }
+    for (int k = 0; k < 9; k++) kc.st_R[ns][k] = xg.R[k];
+    if (mix(g, gb[0], kc.set[SKS_STATIC + ns])) { *err = "unsupported contact dimension"; return -1; }
+    ns++;
+  }
+  kc.ns = ns;
+  // finger geoms
+  int link7 = m.jnt_body[m.act_jnt[NARM - 1]];
+  int ghull[NFING] = {-1, -1}, gtip[NFING] = {-1, -1};
+  for (int f = 0; f < NFING; f++) {
+    int fb = m.jnt_body[m.act_jnt[NARM + f]];
+    for (int g = 0; g < m.ngeom; g++) {
+      if (weld_root(m.geom_body[g]) != fb || !m.geom_contype[g]) continue;
+      if (m.geom_type[g] == D3IL_GEOM_MESH && m.geom_mesh[g] >= 0) ghull[f] = g;
+      if (m.geom_type[g] == D3IL_GEOM_BOX) gtip[f] = g;
+    }
+    if (ghull[f] < 0 || gtip[f] < 0) { *err = "finger hull / tip geoms not found"; return -1; }
+    for (int g = 0; g < 2; g++) {
+      int gg = g ? ghull[f] : gtip[f];
+      Xf gl; quat2mat(m.geom_quat[gg], gl.R); std::memcpy(gl.p, m.geom_pos[gg], sizeof gl.p);
+      Xf xg = compose(rel(link7, m.geom_body[gg]), gl);
+      std::memcpy(g ? kc.hull_R[f] : kc.tip_R[f], xg.R, sizeof xg.R); std::memcpy(g ? kc.hull_p[f] : kc.tip_p[f], xg.p, sizeof xg.p);
+    }
+    for (int k = 0; k < 3; k++) if (m.geom_size[gtip[f]][k] != m.geom_size[gtip[0]][k]) { *err = "finger tips must be identical"; return -1; }
+  }
+  if (!(gb[SK_NB - 1] < ghull[0] && ghull[0] < gtip[0] && gtip[0] < ghull[1] && ghull[1] < gtip[1])) { *err = "unexpected finger geom order"; return -1; }
+  for (int k = 0; k < 3; k++) kc.tip_half[k] = m.geom_size[gtip[0]][k];
+  int mi = m.geom_mesh[ghull[0]];
+  if (m.geom_mesh[ghull[1]] != mi || m.mesh_nvert[mi] > SK_MAXHV) { *err = "finger hulls must share one mesh"; return -1; }
+  kc.hull_nv = m.mesh_nvert[mi];
+  for (int i = 0; i < kc.hull_nv; i++) for (int k = 0; k < 3; k++) kc.hull_v[i][k] = m.mesh_vert[mi][i][k];
+  for (int k = 0; k < 3; k++) kc.hull_center[k] = m.mesh_center[mi][k];
+  if (mix(gb[0], gb[1], kc.set[SKS_BOXBOX]) || mix(gb[0], ghull[0], kc.set[SKS_BOXHULL]) || mix(gb[0], gtip[0], kc.set[SKS_BOXTIP]) ||
+      mix(ghull[0], ghull[1], kc.set[SKS_HULLHULL]) || mix(ghull[0], gtip[1], kc.set[SKS_HULLTIP]) || mix(gtip[0], gtip[1], kc.set[SKS_TIPTIP])) { *err = "unsupported contact dimension"; return -1; }
+  // translational body_invweight0 of the finger and finger-tip bodies at qpos0: mean diagonal of Jp M^-1 Jp' at the body's COM
+  {
+    double q[NDOF] = {0}, v[NDOF] = {0};
+    DynOut dyn;
+    dynamics(pcst, q, v, dyn);
+    double L[45], d[NDOF], id[NDOF], Minv[NDOF][NDOF];
+    ldl9(dyn.M, L, d, id);
+    for (int col = 0; col < NDOF; col++) { double e[NDOF] = {0}; e[col] = 1; ldl9_solve(L, id, e); for (int r = 0; r < NDOF; r++) Minv[r][col] = e[r]; }
+    double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3];
+    for (int i = 0; i < NARM; i++) { sn[i] = 0; cs[i] = 1; }
+    world_chain(pcst, sn, cs, R7, p7, ax, og);
+    for (int f = 0; f < NFING; f++) {
+      int fb = m.jnt_body[m.act_jnt[NARM + f]];
+      for (int which = 0; which < 2; which++) {
+        int body = which ? m.geom_body[gtip[f]] : fb;
+        Xf xb = rel(link7, body);
+        double cl[3], cw[3];
+        mv(xb.R, m.body_ipos[body], cl); for (int k = 0; k < 3; k++) cl[k] += xb.p[k];
+        mulE(R7, cl, cw); for (int k = 0; k < 3; k++) cw[k] += p7[k];
+        double J[3][NDOF];
+        for (int k = 0; k < NARM; k++) { double dd[3] = {cw[0] - og[k][0], cw[1] - og[k][1], cw[2] - og[k][2]}, col[3]; cross3(ax[k], dd, col); for (int r = 0; r < 3; r++) J[r][k] = col[r]; }
+        double axw[3]; mulE(R7, pcst.f_axis[f], axw);
+        for (int g = 0; g < NFING; g++) for (int r = 0; r < 3; r++) J[r][NARM + g] = g == f ? axw[r] : 0.0;
+        double tr = 0;
+        for (int r = 0; r < 3; r++) for (int a = 0; a < NDOF; a++) for (int b = 0; b < NDOF; b++) tr += J[r][a] * Minv[a][b] * J[r][b];
+        (which ? kc.invw_tip[f] : kc.invw_finger[f]) = std::fmax(1e-15, tr / 3);
+      }
+    }
+  }
+  kc.impratio = m.impratio;
+  for (int k = 0; k < 3; k++) kc.target[k] = m.task_f[k];
+  kc.min_dist = m.task_f[3]; kc.grip_thresh = m.task_f[4];
+  {   // hand mesh: frame in the link-7 frame, bounding box from the blob's task constants (task_f[5..10])
+    int hand = m.body_parent[m.jnt_body[m.act_jnt[NARM]]];
+    Xf xh = rel(link7, hand);
+    std::memcpy(kc.hand_R, xh.R, sizeof xh.R); std::memcpy(kc.hand_p, xh.p, sizeof xh.p);
+    for (int k = 0; k < 3; k++) { kc.hand_lo[k] = m.task_f[5 + k]; kc.hand_hi[k] = m.task_f[8 + k]; }
+  }
+  return 0;
+}
+
+}  // namespace d3il

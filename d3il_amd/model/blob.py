@@ -14,9 +14,10 @@ import json
 import os
 
 MAGIC = 0x4C493344  # 'D3IL'
-VERSION = 3
+VERSION = 4
 
 MAXBODY, MAXJNT, MAXGEOM, MAXACT, MAXEXCL, MAXCHAIN, MAXOBST = 64, 16, 80, 12, 16, 16, 8
+MAXMESH, MAXMVERT = 2, 96
 
 TASK_IDS = {"avoiding": 0, "pushing": 1, "sorting": 2, "stacking": 3}
 JNT_TYPES = {"free": 0, "hinge": 2, "slide": 3}       # numeric values follow mjtJoint [ext]
@@ -87,6 +88,11 @@ FIELDS = [
     ("task_f", F64, (32,), ""),
     # free-joint task objects in observation order (pushing.py:255-280: push_box, push_box2)
     ("n_obj", I32, (), ""), ("obj_pad", I32, (), ""), ("obj_body", I32, (8,), "body ids"),
+    # convex hulls of the mesh geoms that take part in collision (Stacking: fingerv.stl of panda_invisible.xml:97-109); vertices in
+    # mesh-file coordinates, i.e. in the frame geom_pos / geom_quat place on the body; centre = centroid of the hull volume
+    ("nmesh", I32, (), ""), ("mesh_pad", I32, (), ""), ("mesh_nvert", I32, (MAXMESH,), ""),
+    ("geom_mesh", I32, (MAXGEOM,), "mesh id of a mesh geom whose hull is carried, -1 otherwise"),
+    ("mesh_center", F64, (MAXMESH, 3), ""), ("mesh_vert", F64, (MAXMESH, MAXMVERT, 3), ""),
 ]
 
 
@@ -112,7 +118,7 @@ def emit_header() -> str:
         "#define D3IL_MAXBODY %d" % MAXBODY, "#define D3IL_MAXJNT %d" % MAXJNT,
         "#define D3IL_MAXGEOM %d" % MAXGEOM, "#define D3IL_MAXACT %d" % MAXACT,
         "#define D3IL_MAXEXCL %d" % MAXEXCL, "#define D3IL_MAXCHAIN %d" % MAXCHAIN,
-        "#define D3IL_MAXOBST %d" % MAXOBST, "",
+        "#define D3IL_MAXOBST %d" % MAXOBST, "#define D3IL_MAXMESH %d" % MAXMESH, "#define D3IL_MAXMVERT %d" % MAXMVERT, "",
         "enum { D3IL_JNT_FREE = 0, D3IL_JNT_HINGE = 2, D3IL_JNT_SLIDE = 3 };",
         "enum { D3IL_GEOM_PLANE = 0, D3IL_GEOM_SPHERE = 2, D3IL_GEOM_CYLINDER = 5, D3IL_GEOM_BOX = 6, D3IL_GEOM_MESH = 7 };",
         "enum { D3IL_TASK_AVOIDING = 0, D3IL_TASK_PUSHING = 1, D3IL_TASK_SORTING = 2, D3IL_TASK_STACKING = 3 };",
@@ -224,7 +230,7 @@ def pack(js: dict) -> ModelBlob:
     b.n_substeps, b.max_steps = tc["n_substeps"], tc["max_steps"]
     bname = {bd["name"]: i for i, bd in enumerate(bodies)}
     b.tcp_body = bname[tc["tcp_body"]]
-    b.rod_geom = gname.get(tc.get("rod_geom", ""), -1)
+    b.rod_geom = gname[tc["rod_geom"]] if tc.get("rod_geom") else -1
     obst = tc.get("obstacles", [])
     b.n_obst = len(obst)
     for i, o in enumerate(obst):
@@ -238,6 +244,28 @@ def pack(js: dict) -> ModelBlob:
     b.n_obj = len(objs)
     for i, o in enumerate(objs):
         b.obj_body[i] = bname[o]
+    meshes = js.get("meshes", {})
+    mesh_id = {}
+    for name in tc.get("collision_meshes", []):
+        mv = meshes[name]
+        assert len(mesh_id) < MAXMESH and len(mv["vert"]) <= MAXMVERT
+        k = mesh_id[name] = len(mesh_id)
+        b.mesh_nvert[k] = len(mv["vert"])
+        for i, v in enumerate(mv["vert"]):
+            for c in range(3):
+                b.mesh_vert[k][i][c] = v[c]
+        for c in range(3):
+            b.mesh_center[k][c] = mv["center"][c]
+    b.nmesh = len(mesh_id)
+    for i, g in enumerate(geoms):
+        b.geom_mesh[i] = mesh_id.get(g.get("mesh"), -1) if g["type"] == "mesh" else -1
+    if js["task"] == "stacking":
+        # stacking_objects.py:17 target position, stacking.py:193 pos_min_dist, stacking.py:337 gripper threshold
+        for k in range(3):
+            b.task_f[k] = tc["target_pos"][k]
+        b.task_f[3], b.task_f[4] = tc["pos_min_dist"], tc["gripper_open_threshold"]
+        for k in range(3):
+            b.task_f[5 + k], b.task_f[8 + k] = tc["hand_bbox_min"][k], tc["hand_bbox_max"][k]
     if js["task"] == "sorting":
         b.task_f[0] = tc["num_boxes"]
     if js["task"] == "pushing":

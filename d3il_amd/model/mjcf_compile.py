@@ -502,6 +502,68 @@ def build_sorting(num_boxes=4):
     return to_blob(m, "sorting", tc)
 
 
+def load_stl_vertices(path):
+    """Unique vertices of a binary STL file (models/mj/robot/assets/*.stl)."""
+    import struct
+    d = open(path, "rb").read()
+    n = struct.unpack("<I", d[80:84])[0]
+    if 84 + n * 50 != len(d):
+        raise ValueError("%s is not a binary STL" % path)
+    a = np.frombuffer(d[84:], dtype=np.dtype([("n", "<3f4"), ("v", "<9f4"), ("a", "<u2")]), count=n)
+    return np.unique(a["v"].reshape(-1, 3).astype(np.float64), axis=0)
+
+
+def mesh_hull(path):
+    """Collision geometry of a mesh geom: MuJoCo collides the CONVEX HULL of the mesh vertices (qhull at compile time [ext]).
+    Returns the hull vertices (mesh file coordinates) and the centroid of the hull volume, which stands in for the geom centre
+    MuJoCo derives from the mesh's inertial frame (the centre only seeds the MPR portal search)."""
+    from scipy.spatial import ConvexHull
+    v = load_stl_vertices(path)
+    h = ConvexHull(v)
+    hv = v[h.vertices]
+    c0 = hv.mean(0)
+    vol, cen = 0.0, np.zeros(3)
+    for tri in h.simplices:
+        a, b, c = v[tri[0]] - c0, v[tri[1]] - c0, v[tri[2]] - c0
+        w = abs(np.dot(a, np.cross(b, c))) / 6.0
+        vol += w
+        cen += w * (a + b + c) / 4.0
+    return hv, c0 + cen / vol
+
+
+def stacking_objects():
+    """stacking_objects.py:11-61 restated as data, in the order get_obj_list returns them (red, green, blue, target)."""
+    return [
+        prim_body("red_box", "box", [0.5, -0.1, 0.0], [0, 1, 0, 0], [0.03, 0.03, 0.03], mass=0.05),
+        prim_body("green_box", "box", [0.5, 0.0, 0.0], [0, 1, 0, 0], [0.03, 0.03, 0.03], mass=0.05),
+        prim_body("blue_box", "box", [0.5, 0.0, 0.0], [0, 1, 0, 0], [0.03, 0.05, 0.03], mass=0.05),   # init_pos = box_pos2 (sic, stacking_objects.py:44)
+        prim_body("target_box", "box", [0.5, 0.2, 0.0], [0, 1, 0, 0], [0.05, 0.05, 0.04], static=True, visual_only=True),
+    ]
+
+
+def build_stacking():
+    """CubeStacking_Env (stacking.py:135-198): robot panda_invisible.xml (no rod; finger geoms of class panda:gripper: condim 4,
+    margin 1 mm; finger-tip boxes), three free boxes, joint-space PD controller, 30 sub-steps (stacking.py:138)."""
+    m = build_scene("panda_invisible.xml", stacking_objects(), "stacking")
+    tc = dict(
+        n_substeps=30, max_steps=1000,                       # stacking.py:138, configs/stacking_config.yaml:84
+        init_end_eff_pos=[0.525, 0.0, 0.3], init_end_eff_quat=[0, 1, 0, 0],     # stacking_objects.py:11, stacking.py:299-317
+        tcp_body="tcp_rb0",
+        objects=["red_box", "green_box", "blue_box"],
+        target_pos=[0.5, 0.2, 0.0], pos_min_dist=0.06,       # stacking_objects.py:17, stacking.py:193
+        gripper_open_threshold=0.075,                        # stacking.py:337
+        collision_meshes=["fingerv"],                    # mesh geoms whose hull is carried (finger <-> box grasp contacts)
+    )
+    blob = to_blob(m, "stacking", tc)
+    hv, cen = mesh_hull(os.path.join(D3IL, "models/mj/robot/assets/fingerv.stl"))
+    blob["meshes"] = {"fingerv": dict(vert=hv.tolist(), center=cen.tolist())}
+    # the hand mesh is not collided (773 hull vertices); its bounding box lets the engine flag a box that reaches it
+    hand = load_stl_vertices(os.path.join(D3IL, "models/mj/robot/assets/handv.stl"))
+    blob["task_const"]["hand_bbox_min"] = hand.min(0).tolist()
+    blob["task_const"]["hand_bbox_max"] = hand.max(0).tolist()
+    return blob
+
+
 def main():
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "blobs")
     os.makedirs(out_dir, exist_ok=True)
@@ -521,6 +583,11 @@ def main():
     with open(os.path.join(out_dir, "sorting_2.json"), "w") as f:
         json.dump(blob, f, indent=1)
     print("sorting-2: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
+    blob = build_stacking()
+    with open(os.path.join(out_dir, "stacking.json"), "w") as f:
+        json.dump(blob, f, indent=1)
+    print("stacking: %d bodies, %d geoms, %d actuators, hull vertices %s" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"]),
+                                                                             {k: len(v["vert"]) for k, v in blob["meshes"].items()}))
 
 
 if __name__ == "__main__":

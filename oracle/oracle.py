@@ -270,6 +270,39 @@ class Oracle:
         state_col = np.ascontiguousarray(state_col, float)
         self.L.orc_sort_set_state(self.h, _p(state_col), C.c_uint(int(flags) & 0xFFFFFFFF), int(step))
 
+    # ---- env level (Stacking)
+    def stack_reset(self, ctx):
+        """ctx: 3 x (x, y, z = 0, quat) red, green, blue (BlockContextManager.set_context, stacking.py:99-125)."""
+        ctx = np.ascontiguousarray(ctx, float).reshape(21)
+        obs = np.zeros(12, dtype=np.float32)
+        self.L.orc_stackenv_reset(self.h, _p(ctx), _p(obs))
+        return obs
+
+    def stack_step(self, action8):
+        action8 = np.ascontiguousarray(action8, float).reshape(8)
+        obs = np.zeros(12, dtype=np.float32)
+        done, succ = C.c_int(0), C.c_int(0)
+        md = C.c_double(0)
+        mode = C.create_string_buffer(4)
+        self.L.orc_stackenv_step(self.h, _p(action8), _p(obs), C.byref(done), mode, C.byref(succ), C.byref(md))
+        m = mode.value.decode()
+        return obs, bool(done.value), dict(mode=m, success=bool(succ.value), success_1=len(m) > 0, success_2=len(m) > 1, mean_distance=md.value)
+
+    def stack_robot_state(self):
+        out = np.zeros(8)
+        self.L.orc_stackenv_robot_state(self.h, _p(out))
+        return out
+
+    def stack_state(self):
+        s = np.zeros(28 + 13 * 3)
+        self.L.orc_stack_get_state(self.h, _p(s))
+        return s
+
+    def stack_set_state(self, s67, step=0, terminated=False, min_inds=()):
+        s67 = np.ascontiguousarray(s67, float)
+        mi = np.ascontiguousarray(list(min_inds) + [0] * (3 - len(min_inds)), dtype=np.int32)
+        self.L.orc_stack_set_state(self.h, _p(s67), int(step), int(terminated), len(min_inds), _p(mi))
+
     def push_state(self):
         s = np.zeros(42 + 13 * 2)
         self.L.orc_push_get_state(self.h, _p(s))

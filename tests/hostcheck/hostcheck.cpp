@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "../../d3il_amd/csrc/gen_step.h"
+#include "../../d3il_amd/csrc/stack_step.h"
 
 using namespace d3il;
 
@@ -157,6 +158,57 @@ void hc_gen_substep(void* h, double* s, int* f, const double* tau, const double*
   GenHost* p = (GenHost*)h; EnvState st; unpack(s, f, st);
   PushScratch sc{p->h, p->g, 1, s + 42, 1};
   gen_physics_substep(p->c, p->gc, st, sc, tau, ffing); pack(st, s, f);
+}
+// ---------------------------------------------------------------- Stacking (stack_step.h)
+struct StackHost { PandaConsts c; StackConsts kc; double t[ST_SIZE]; double g[SG_SIZE]; };
+static void stack_unpack(const double* s, const int* f, StackState& ss) {
+  int k = 0;
+  for (int i = 0; i < NDOF; i++) ss.arm.q[i] = s[k++];
+  for (int i = 0; i < NDOF; i++) ss.arm.v[i] = s[k++];
+  for (int i = 0; i < NARM; i++) ss.arm.bias[i] = s[k++];
+  for (int i = 0; i < 3; i++) ss.arm.tcp[i] = s[k++];
+  for (int b = 0; b < SK_NB; b++) { for (int i = 0; i < 3; i++) ss.box[b].pos[i] = s[k++]; for (int i = 0; i < 4; i++) ss.box[b].quat[i] = s[k++]; for (int i = 0; i < 6; i++) ss.box[b].vel[i] = s[k++]; }
+  ss.arm.flags = (unsigned)f[0]; ss.arm.step = f[1];
+}
+static void stack_pack(const StackState& ss, double* s, int* f) {
+  int k = 0;
+  for (int i = 0; i < NDOF; i++) s[k++] = ss.arm.q[i];
+  for (int i = 0; i < NDOF; i++) s[k++] = ss.arm.v[i];
+  for (int i = 0; i < NARM; i++) s[k++] = ss.arm.bias[i];
+  for (int i = 0; i < 3; i++) s[k++] = ss.arm.tcp[i];
+  for (int b = 0; b < SK_NB; b++) { for (int i = 0; i < 3; i++) s[k++] = ss.box[b].pos[i]; for (int i = 0; i < 4; i++) s[k++] = ss.box[b].quat[i]; for (int i = 0; i < 6; i++) s[k++] = ss.box[b].vel[i]; }
+  f[0] = (int)ss.arm.flags; f[1] = ss.arm.step;
+}
+void* hc_stack_create(const d3il_model_blob* blob, const char** err) {
+  StackHost* p = (StackHost*)std::calloc(1, sizeof(StackHost));
+  static const char* e = "";
+  if (build_panda_consts(*blob, p->c, &e)) { *err = e; std::free(p); return nullptr; }
+  finish_invweights(p->c);
+  if (build_stack_consts(*blob, p->c, p->kc, &e)) { *err = e; std::free(p); return nullptr; }
+  return p;
+}
+int hc_stack_state_size() { return SK_STATE_F64; }
+void hc_stack_reset(void* h, const double* init_qpos, const double* ctx, double* s, int* f, float* obs) {
+  StackHost* p = (StackHost*)h; StackState ss; std::memset(&ss, 0, sizeof ss);
+  StackScratch sc{p->t, p->g, 1};
+  stack_env_reset(p->c, p->kc, ss, sc, init_qpos, ctx, obs); stack_pack(ss, s, f);
+}
+void hc_stack_step(void* h, double* s, int* f, const double* action, float* obs, unsigned char* done, double* mean_dist) {
+  StackHost* p = (StackHost*)h; StackState ss; stack_unpack(s, f, ss);
+  StackScratch sc{p->t, p->g, 1};
+  stack_env_step(p->c, p->kc, ss, sc, action, obs, done, mean_dist, p->c.n_substeps, p->c.max_steps);
+  stack_pack(ss, s, f);
+}
+// contacts of the last sub-step: per contact dist, pos3, normal3, bodyA, bodyB, set
+int hc_stack_contacts(void* h, double* out) {
+  StackHost* p = (StackHost*)h; int n = 0;
+  for (int ci = 0; ci < SK_MAXCON; ci++) {
+    const double* r = p->g + ci * SREC;
+    if (r[3] == 0 && r[4] == 0 && r[5] == 0) break;
+    out[10 * n] = r[12]; for (int k = 0; k < 3; k++) { out[10 * n + 1 + k] = r[k]; out[10 * n + 4 + k] = r[3 + k]; }
+    out[10 * n + 7] = r[13]; out[10 * n + 8] = r[14]; out[10 * n + 9] = r[15]; n++;
+  }
+  return n;
 }
 // collision routines of push_step.h on their own (quaternions in, same record layout as the oracle's test hooks)
 int hc_cyl_box(const double* pc, const double* qc, double rad, double half, const double* pb, const double* qb, const double* sb, double margin, double* out) {

@@ -11,7 +11,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libd3il_hostcheck.so")
-    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "push_step.h", "gen_step.h")]
+    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "push_step.h", "gen_step.h", "stack_step.h")]
     srcs.append(os.path.join(_HERE, "..", "..", "include", "d3il_model_blob.h"))
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
@@ -150,3 +150,39 @@ class GenHostCheck:
     def box(self, b):
         o = 42 + 13 * b
         return self.s[o:o + 3], self.s[o + 3:o + 7], self.s[o + 7:o + 13]
+
+
+class StackHostCheck:
+    """Host build of the Stacking engine (d3il_amd/csrc/stack_step.h), one environment."""
+
+    def __init__(self, blob):
+        self.L = lib()
+        self.L.hc_stack_create.restype = C.c_void_p
+        err = C.c_char_p()
+        self.h = C.c_void_p(self.L.hc_stack_create(C.byref(blob), C.byref(err)))
+        if not self.h:
+            raise RuntimeError("hc_stack_create: %s" % (err.value.decode() if err.value else "?"))
+        self.n = self.L.hc_stack_state_size()
+        self.s = np.zeros(self.n)
+        self.f = np.zeros(2, dtype=np.int32)
+
+    def reset(self, init_qpos, ctx):
+        init_qpos, ctx = np.ascontiguousarray(init_qpos, float), np.ascontiguousarray(ctx, float).reshape(21)
+        obs = np.zeros(12, dtype=np.float32)
+        self.L.hc_stack_reset(self.h, _p(init_qpos), _p(ctx), _p(self.s), _p(self.f), _p(obs))
+        return obs
+
+    def step(self, action8):
+        action8 = np.ascontiguousarray(action8, float).reshape(8)
+        obs = np.zeros(12, dtype=np.float32)
+        done, md = C.c_ubyte(0), C.c_double(0)
+        self.L.hc_stack_step(self.h, _p(self.s), _p(self.f), _p(action8), _p(obs), C.byref(done), C.byref(md))
+        fl = int(self.f[0]) & 0xFFFFFFFF
+        n = fl & 3
+        mode = "".join("rgb"[(fl >> (2 + 2 * i)) & 3] for i in range(n))
+        return obs, bool(done.value), dict(mode=mode, success=bool(fl & (1 << 13)), mean_distance=md.value, flags=fl)
+
+    def contacts(self):
+        out = np.zeros((48, 10))
+        n = self.L.hc_stack_contacts(self.h, _p(out))
+        return out[:n]
