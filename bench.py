@@ -42,9 +42,10 @@ ALG_BYTES = {
     "avoiding": 2 * (42 * 8 + 4 + 4) + 56 + 8 + 4,
     "pushing": 2 * (68 * 8 + 4 + 4) + 56 + 32 + 4 + 16,
     "sorting": 2 * (129 * 8 + 4 + 4) + 56 + 56 + 4,
+    "stacking": 2 * (67 * 8 + 4 + 4) + 64 + 48 + 4 + 8,      # state column 67 f64, action 8 f64, obs 12 f32, done/success/mode, mean distance
 }
-KERNEL = {"avoiding": "k_avoiding_step_split<true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>"}
-PMC_FILE = {"avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json"}
+KERNEL = {"avoiding": "k_avoiding_step_split<true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step"}
+PMC_FILE = {"avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json"}
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline (oracle)
@@ -72,6 +73,20 @@ def _cpu_worker(task, blob_bytes, init_qpos, contexts, budget_s, seed):
                 o.env_reset()
                 s, _ = o.env_state()
                 des = s[25:28].copy()
+        return n, time.perf_counter() - t0
+    if task == "stacking":      # scripted pick-and-place of one context (the GPU workload's policy), repeated
+        from d3il_amd.controllers.scripted_stacking import build_trajectory
+        js = blob_mod.load_json("stacking")
+        ctx = contexts[seed % len(contexts)]
+        traj = build_trajectory(js, init_qpos, ctx, speed=0.5)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            o.stack_reset(ctx)
+            for a in traj:
+                _, done, _ = o.stack_step(a)
+                n += 1
+                if done or time.perf_counter() - t0 >= budget_s:
+                    break
         return n, time.perf_counter() - t0
     import torch
     from d3il_amd.agents import RandomResidualMLPPolicy
@@ -126,10 +141,10 @@ def cpu_baseline(task, blob, init_qpos, contexts, budget_s=10.0):
     res = [tuple(float(x) for x in o.decode().split()[-2:]) for o in outs if o.strip()]
     total = sum(r[0] for r in res)
     busy = max(r[1] for r in res) if res else float("nan")
-    pol = "random policy" if task == "avoiding" else "ResidualMLP stand-in policy on the CPU"
+    pol = {"avoiding": "random policy", "stacking": "scripted pick-and-place"}.get(task, "ResidualMLP stand-in policy on the CPU")
     return {"value": total / busy, "unit": "env-steps/s", "cores": len(res), "kind": "port",
             "single_core_value": n1 / t1,
-            "sample": "one oracle environment per core on all %d host cores (%s, %d env steps of 35 sub-steps in %.1f s of stepping per worker, %.1f s wall "
+            "sample": "one oracle environment per core on all %d host cores (%s, %d env steps of 35 (Stacking: 30) sub-steps in %.1f s of stepping per worker, %.1f s wall "
                       "including interpreter start-up), after one environment on one core (%d env steps in %.1f s); scalar C oracle (oracle/d3il_oracle.c, the CPU "
                       "restatement of the reference path - the Python reference itself is bounded above by 146 env-steps/s/core, BASELINE.md section 2)"
                       % (len(res), pol, total, busy, wall, n1, t1)}
@@ -208,10 +223,14 @@ def run(args):
         from d3il_amd.simulation.pushing_sim import load_test_contexts
         env = BlockPushVecEnv(n, device=dev)
         ctx60 = load_test_contexts()
-    else:
+    elif task == "sorting":
         from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
         env = SortingVecEnv(n, device=dev)
         ctx60 = sample_contexts(60, 4, seed=0)     # the reference's 4_test_contexts.pkl is not part of its tree
+    else:
+        from d3il_amd.envs.stacking import CubeStackingVecEnv, load_test_contexts as load_stack_contexts
+        env = CubeStackingVecEnv(n, device=dev)
+        ctx60 = load_stack_contexts()[:args.stack_contexts]     # the first contexts of the reference's 100 test contexts, tiled
     q, iters, err = env.start()
     if args.lanes is not None:
         env.set_option("lanes_per_wave", args.lanes)
@@ -232,10 +251,22 @@ def run(args):
     env.policy_begin()
     table = env.set_tally(len(ctx60) if ctx60 is not None else 1, ctx_id)
     episodes = torch.zeros(2, dtype=torch.int64, device=dev)   # finished, successful
-    actions = torch.zeros(n, 7, dtype=torch.float64, device=dev)
-    policy = args.policy or ("random" if task == "avoiding" else "mlp")
+    actions = torch.zeros(n, env.action_dim, dtype=torch.float64, device=dev)
+    policy = args.policy or {"avoiding": "random", "stacking": "scripted_stack"}.get(task, "mlp")
     pol = None
-    if task != "avoiding" or policy != "random":
+    last_cmd = None
+    if task == "stacking":
+        from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedStackPolicy
+        if policy == "scripted_stack":
+            from d3il_amd.controllers.scripted_stacking import build_trajectory
+            tables = [build_trajectory(env.js, q, c, speed=0.5) for c in ctx60]     # host IK once per context (untimed set-up)
+            pol = ScriptedStackPolicy(tables, ctx_id.to(torch.int64), device=dev)
+        elif policy == "mlp":
+            pol = RandomResidualMLPPolicy(input_dim=20, output_dim=8, device=dev, bound=0.01)
+        else:
+            raise SystemExit("--policy %s is not available for task %s" % (policy, task))
+        last_cmd = env.robot_state().to(torch.float32).clone()                      # stacking_sim.py:90-91
+    elif task != "avoiding" or policy != "random":
         from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedPushPolicy
         if policy == "mlp":
             pol = RandomResidualMLPPolicy(input_dim=2 + env.obs.shape[1], device=dev)
@@ -249,7 +280,16 @@ def run(args):
     evs = None
 
     def one_step(t):
-        if pol is None:
+        nonlocal last_cmd
+        if task == "stacking":
+            if hasattr(pol, "begin_episodes"):
+                pol.begin_episodes(env.last_reset)
+            last_cmd = torch.where(env.last_reset.bool().unsqueeze(1), env.robot_state().to(torch.float32), last_cmd)
+            obs20 = torch.cat((last_cmd, env.obs), dim=1)                           # np.concatenate((pred_action, obs)), stacking_sim.py:99
+            out = pol.predict_batch(obs20).to(torch.float32)
+            last_cmd = torch.cat((out[:, :7] + obs20[:, :7], out[:, 7:8]), dim=1)   # stacking_sim.py:104
+            actions.copy_(last_cmd)
+        elif pol is None:
             env.policy_action(42, env_offset, t, actions)
         else:
             if hasattr(pol, "begin_episodes"):
@@ -307,10 +347,13 @@ def run(args):
     dt = float(t_max.item())
     st, fl, sc = env.get_state()
     n_state = env.state_rows - (2 if task == "sorting" else 0)
+    n_sub = env.n_substeps
     finite = bool(np.isfinite(st[:n_state]).all())
     flagged = {"solver_fail": int(((fl >> 16) & 1).sum())}
     if task != "avoiding":
         flagged.update(contact_overflow=int(((fl >> 18) & 1).sum()), off_table=int(((fl >> 19) & 1).sum()))
+    if task == "stacking":
+        flagged.update(hand_near=int(((fl >> 20) & 1).sum()))
     if rank == 0:
         value = world * n * args.steps / dt
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
@@ -338,12 +381,16 @@ def run(args):
             "sorting": "Sorting-4 task, %d envs per GPU, 60 contexts sampled like BlockContextManager.sample tiled, %s, 35 fused physics sub-steps per "
                        "env step, 500-step episodes with auto-reset" % (n, "ResidualMLP 16->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)"
                                                                         if policy == "mlp" else "scripted pushing policy (every rod pushes a cube towards its bin: contact regime)"),
+            "stacking": "Stacking task, %d envs per GPU, the first %d of the reference's 100 test contexts tiled, %s, 30 fused physics sub-steps per env step, "
+                        "1000-step episodes with auto-reset" % (n, len(ctx60) if ctx60 is not None else 0,
+                                                                "scripted pick-and-place policy (joint-space table from host IK: grasp, carry, stack - the contact regime of the task)"
+                                                                if policy == "scripted_stack" else "ResidualMLP 20->128x6->8 (Mish) stand-in policy with fixed random weights (torch, f32)"),
         }[task]
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "envs_per_gpu": n, "n_substeps": 35, "parallelism": "env-shard x%d" % world, "policy": policy,
+            "config": {"workload": workload, "envs_per_gpu": n, "n_substeps": n_sub, "parallelism": "env-shard x%d" % world, "policy": policy,
                        "preroll_steps_untimed": preroll, "phase_mix": "steady state (staggered episode phases)" if preroll else "fresh reset",
                        "auto_reset": not args.no_auto_reset, "finite": finite, "flagged_envs": flagged,
                        "episodes_finished_all_ranks": int(tb[:, 0].sum()), "episodes_success_all_ranks": int(tb[:, 1].sum()),
@@ -369,13 +416,15 @@ def run(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting"], help="avoiding = the headline configuration (BASELINE configs[1])")
+    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting", "stacking"], help="avoiding = the headline configuration (BASELINE configs[1])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--policy", default=None, choices=["random", "mlp", "scripted_push"], help="default: random (Avoiding), mlp (Pushing / Sorting)")
+    ap.add_argument("--policy", default=None, choices=["random", "mlp", "scripted_push", "scripted_stack"],
+                    help="default: random (Avoiding), mlp (Pushing / Sorting), scripted_stack (Stacking: pick-and-place, the contact regime of the task)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stack-contexts", type=int, default=16, help="Stacking: number of reference test contexts in the tile (host IK of the scripted policy: ~1.3 s each)")
     ap.add_argument("--no-auto-reset", action="store_true")
     ap.add_argument("--no-preroll", action="store_true", help="measure from a freshly reset batch (round-1 behaviour)")
     ap.add_argument("--preroll", type=int, default=None, help="untimed steady-state pre-roll steps (default: one episode length)")

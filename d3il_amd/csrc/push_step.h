@@ -155,6 +155,7 @@ D3IL_HD void quat2mat(const double* q, double* R) {   // mju_quat2Mat [ext]
 D3IL_HD int box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
                     double margin, double (*out)[7], int cap) {
   const double FUDGE = 1.05;
+  const double ETOL = 1e-12;   // a vertex this close to a side plane of the reference face counts as inside (faces of equal extent lying on each other)
   double A[3][3], B[3][3], d[3], Cm[3][3], Q[3][3], dA[3], dB[3];
   for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = R1[3 * k + i]; B[i][k] = R2[3 * k + i]; }
   for (int k = 0; k < 3; k++) d[k] = p2[k] - p1[k];
@@ -187,7 +188,8 @@ D3IL_HD int box_box(const double* p1, const double* R1, const double* s1, const 
     double ra = s1[i1] * Q[i2][j] + s1[i2] * Q[i1][j], rb = s2[j1] * Q[i][j2] + s2[j2] * Q[i][j1];
     double sep = (fabs(proj) - (ra + rb)) / l;
     if (sep > margin) return 0;
-    if (sep * FUDGE > best + 1e-10 && sep > best) {
+    // 5 % better: a shallower penetration (sep < 0) or, for boxes apart but inside the margin (sep > 0), a larger gap
+    if (sep > 0 ? sep > best * FUDGE + 1e-10 : (sep * FUDGE > best + 1e-10 && sep > best)) {
       best = sep; code = 6 + 3 * i + j;
       double Lx[3]; cross3(A[i], B[j], Lx);
       double sg = proj < 0 ? -1 : 1;
@@ -225,7 +227,7 @@ D3IL_HD int box_box(const double* p1, const double* R1, const double* s1, const 
     double c0 = (v == 0 || v == 3) ? 1.0 : -1.0, c1 = v < 2 ? 1.0 : -1.0, x[3];
     for (int k = 0; k < 3; k++) x[k] = pi[k] + sgi * si[kin] * Ai[kin][k] + c0 * si[k1] * Ai[k1][k] + c1 * si[k2] * Ai[k2][k] - pr[k];
     p4[v][0] = dot3(x, Ar[a1]); p4[v][1] = dot3(x, Ar[a2]); p4[v][2] = dot3(x, n) - sr[ax];
-    inside = inside && p4[v][0] - sr[a1] <= 0 && -p4[v][0] - sr[a1] <= 0 && p4[v][1] - sr[a2] <= 0 && -p4[v][1] - sr[a2] <= 0;
+    inside = inside && p4[v][0] - sr[a1] <= ETOL && -p4[v][0] - sr[a1] <= ETOL && p4[v][1] - sr[a2] <= ETOL && -p4[v][1] - sr[a2] <= ETOL;
   }
   if (inside) {
     // the clipping below would return the four vertices unchanged and in order; they are distinct, so no duplicate test either
@@ -251,8 +253,8 @@ D3IL_HD int box_box(const double* p1, const double* R1, const double* s1, const 
     for (int v = 0; v < np; v++) {
       int vn = v + 1 == np ? 0 : v + 1;
       double fp = sg * poly[v][cdim] - lim, fq = sg * poly[vn][cdim] - lim;
-      if (fp <= 0) { for (int k = 0; k < 3; k++) tmp[nn][k] = poly[v][k]; nn++; }
-      if ((fp <= 0) != (fq <= 0)) { double t = fp / (fp - fq); for (int k = 0; k < 3; k++) tmp[nn][k] = poly[v][k] + t * (poly[vn][k] - poly[v][k]); nn++; }
+      if (fp <= ETOL) { for (int k = 0; k < 3; k++) tmp[nn][k] = poly[v][k]; nn++; }
+      if ((fp <= ETOL) != (fq <= ETOL)) { double t = fp / (fp - fq); for (int k = 0; k < 3; k++) tmp[nn][k] = poly[v][k] + t * (poly[vn][k] - poly[v][k]); nn++; }
     }
     np = nn;
     for (int v = 0; v < np; v++) for (int k = 0; k < 3; k++) poly[v][k] = tmp[v][k];

@@ -1,0 +1,155 @@
+"""Stacking: the HIP path through the C ABI against the CPU oracle (reset on reference contexts, scripted pick-and-place followed
+by the oracle, one-step parity from mid-episode device states incl. grasp contacts, batch invariance, auto-reset, Stacking_Sim)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BAD = (1 << 16) | (1 << 18) | (1 << 19)          # solver fail, contact overflow, off table
+
+
+@pytest.fixture(scope="module")
+def stack_js():
+    from d3il_amd.model import blob
+    return blob.load_json("stacking")
+
+
+@pytest.fixture(scope="module")
+def stack_blob(stack_js):
+    from d3il_amd.model import blob
+    return blob.pack(stack_js)
+
+
+@pytest.fixture(scope="module")
+def ctx100():
+    return np.load(os.path.join(ROOT, "d3il_amd", "data", "stacking_test_contexts.npy"))
+
+
+def _env(n, **kw):
+    from d3il_amd.envs.stacking import CubeStackingVecEnv
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return CubeStackingVecEnv(n, device=0, **kw)
+
+
+def test_reset_matches_oracle_on_reference_contexts(stack_blob, ctx100):
+    from oracle.oracle import Oracle
+    n = 100
+    env = _env(n)
+    q0, it, err = env.start()
+    assert it == 72
+    obs = env.reset(context=ctx100).cpu().numpy()
+    st, fl, sc = env.get_state()
+    assert env.obs.shape == (n, 12) and env.state_rows == 67 and env.robot_state().shape == (n, 8)
+    o = Oracle(stack_blob)
+    o.env_start(q0)
+    for e in range(0, n, 7):
+        oo = o.stack_reset(ctx100[e])
+        np.testing.assert_array_equal(obs[e], oo)
+        np.testing.assert_allclose(st[:, e], o.stack_state(), atol=1e-10, rtol=0)
+        np.testing.assert_allclose(env.robot_state()[e].cpu().numpy(), o.stack_robot_state(), atol=1e-10)
+        assert sc[e] == 0 and not (fl[e] & BAD)
+    env.close()
+
+
+def test_pick_and_place_followed_by_the_oracle(stack_js, stack_blob, ctx100):
+    """Every lane runs the scripted pick-and-place of its context's red box; four lanes are followed by the oracle through approach,
+    grasp (finger-tip + finger-hull contacts, condim 4), lift, carry and release: all state rows incl. velocities."""
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    from oracle.oracle import Oracle
+    ids = [0, 3, 11, 42]
+    n = 48
+    env = _env(n)
+    q0, _, _ = env.start()
+    ctx = ctx100[[ids[i % 4] for i in range(n)]]
+    env.reset(context=ctx)
+    trajs = [build_trajectory(stack_js, q0, ctx100[i], n_boxes=1, speed=0.8) for i in ids]
+    T = min(len(t) for t in trajs)
+    oracles = []
+    for i in ids:
+        o = Oracle(stack_blob); o.env_start(q0); o.stack_reset(ctx100[i]); oracles.append(o)
+    worst, lifted = 0.0, 0.0
+    for t in range(T):
+        act = torch.as_tensor(np.stack([trajs[i % 4][t] for i in range(n)]), dtype=torch.float64, device=env.device).contiguous()
+        obs, rew, done, info = env.step(act)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        assert not (fl & BAD).any(), "flags at step %d: %s" % (t, hex(int(np.bitwise_or.reduce(fl))))
+        for k in range(4):
+            oo, do, io = oracles[k].stack_step(trajs[k][t])
+            e = k + 4 * (t % 12)                      # a different lane of the same context every step: results do not depend on the lane
+            err = float(np.abs(st[:, e] - oracles[k].stack_state()).max())
+            worst = max(worst, err)
+            assert err < 1e-5, (t, k, err)
+            assert bool(done[e]) == do and bool(info["success"][e]) == io["success"]
+            from d3il_amd.envs.stacking import mode_string
+            assert mode_string(int(info["mode"][e])) == io["mode"]
+            lifted = max(lifted, float(oo[2]))
+    assert lifted > 0.08 and worst < 1e-5, (lifted, worst)
+    # lanes with the same context are bit-identical
+    for k in range(4):
+        ref = st[:, k]
+        for e in range(k + 4, n, 4):
+            assert np.array_equal(st[:, e], ref)
+    env.close()
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+def test_one_step_parity_from_mid_episode_states(stack_js, stack_blob, ctx100, strict):
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    from oracle.oracle import Oracle
+    ids = [1, 5, 17, 60, 77, 93]
+    n = len(ids)
+    env = _env(n)
+    env.set_option("solver_strict", strict)
+    q0, _, _ = env.start()
+    env.reset(context=ctx100[ids])
+    trajs = [build_trajectory(stack_js, q0, ctx100[i], n_boxes=2, speed=1.0) for i in ids]
+    T = min(len(t) for t in trajs)
+    o = Oracle(stack_blob); o.env_start(q0); o.stack_reset(ctx100[0])
+    worst_p = worst_v = 0.0
+    vel = list(range(9, 18)) + [28 + 13 * b + 7 + k for b in range(3) for k in range(6)]
+    pos = [r for r in range(67) if r not in vel and not (18 <= r < 25)]
+    checked = grasp = 0
+    for t in range(T):
+        act = torch.as_tensor(np.stack([trajs[k][t] for k in range(n)]), dtype=torch.float64, device=env.device).contiguous()
+        if t % 6 == 5:
+            torch.cuda.synchronize()
+            st0, fl0, sc0 = env.get_state()
+        env.step(act)
+        if t % 6 == 5:
+            torch.cuda.synchronize()
+            st1, fl1, sc1 = env.get_state()
+            for k in (t // 6 % n, (t // 6 + 3) % n):
+                nm = int(fl0[k] & 3)
+                o.stack_set_state(st0[:, k], step=int(sc0[k]), terminated=bool(fl0[k] & (1 << 12)), min_inds=[int((fl0[k] >> (2 + 2 * i)) & 3) for i in range(nm)])
+                o.stack_step(trajs[k][t])
+                so = o.stack_state()
+                worst_p = max(worst_p, float(np.abs(st1[pos, k] - so[pos]).max())); worst_v = max(worst_v, float(np.abs(st1[vel, k] - so[vel]).max()))
+                grasp += sum(1 for c in o.contacts() if c[9] > 40) >= 4
+                checked += 1
+    assert checked > 40 and grasp > 5
+    assert worst_p < 1e-7 and worst_v < 1e-5, (worst_p, worst_v)       # north star 1e-4
+    env.close()
+
+
+def test_auto_reset_tally_and_sim(stack_js, ctx100):
+    from d3il_amd.agents import ScriptedStackPolicy
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    from d3il_amd.simulation.stacking_sim import Stacking_Sim
+    # Stacking_Sim with the scripted policy on 4 contexts x 2 rollouts: the pick-and-place succeeds (slow script) and the metric tail runs
+    sim = Stacking_Sim(seed=0, device="cuda:0", render=False, n_contexts=4, n_trajectories_per_context=2, max_steps_per_episode=900)
+    from d3il_amd.envs.stacking import CubeStackingVecEnv
+    probe = CubeStackingVecEnv(1, device=0)
+    q0, _, _ = probe.start(); probe.close()
+    tables = [build_trajectory(stack_js, q0, sim.test_contexts[c], speed=0.5) for c in range(4)]
+    pol = ScriptedStackPolicy(tables, np.arange(8) // 2, device="cuda:0")
+    succ, modes = sim.test_agent(pol)
+    assert succ.shape == (4, 2) and modes.shape == (4, 2)
+    r = sim.last_rollout
+    assert not (r["flags"].cpu().numpy() & BAD).any()
+    assert float(succ.mean()) >= 0.75 and r["metrics"]["successes_1_box"] == 1.0
+    assert torch.equal(succ[:, 0], succ[:, 1]) and torch.equal(modes[:, 0], modes[:, 1])     # identical rollouts of one context agree bit for bit
