@@ -35,7 +35,7 @@ SORT_STATE_BOX, SORT_STATE_WARM, SORT_STATE_TASK, SORT_STATE_F64 = 42, 94, 127, 
 
 EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
            "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_auto_reset", "d3il_set_tally", "d3il_count_metrics", "d3il_set_timing",
-           "d3il_last_step_ms", "d3il_set_option", "d3il_debug_stats", "d3il_debug_wave_stats", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
+           "d3il_last_step_ms", "d3il_set_option", "d3il_debug_stats", "d3il_debug_wave_stats", "d3il_debug_scratch", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
 
 
 class D3ilError(RuntimeError):
@@ -75,6 +75,7 @@ def load():
         L.d3il_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.d3il_last_step_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.d3il_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.d3il_debug_scratch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         if L.d3il_blob_sizeof() != C.sizeof(ModelBlob):
             raise D3ilError("model blob layout mismatch between include/d3il_model_blob.h and d3il_amd/model/blob.py")
         _LIB = L

@@ -794,6 +794,17 @@ int d3il_debug_stats(uint64_t* out32, int reset) {
 #endif
 }
 
+/* diagnostics: one environment's column of the solver scratch area (contact records of its last sub-step; layout in the task's
+ * *_step.h) copied to the host */
+int d3il_debug_scratch(d3il_handle h, int env, double* out, int count) {
+  if (!h || !out) return fail(D3IL_EINVAL, "d3il_debug_scratch: null argument");
+  if (!h->d_scratch || env < 0 || env >= h->n) return fail(D3IL_EINVAL, "d3il_debug_scratch: no scratch area / env out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy2D(out, sizeof(double), h->d_scratch + env, (size_t)h->stride * sizeof(double), sizeof(double), (size_t)count, hipMemcpyDeviceToHost));
+  return D3IL_OK;
+}
+
 int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }

@@ -96,7 +96,8 @@ constexpr int ST_LIM = ST_HULP + 6;             // per arm dof: sign, D, aref
 constexpr int ST_SIZE = ST_LIM + 27;            // 717
 // g area: contact records
 constexpr int SREC = 36;    // pos[3] frame[9] dist bodyA bodyB set | aref[4] D[4] mu | jar[4] jp[4] | pad
-constexpr int SG_SIZE = SK_MAXCON * SREC;
+constexpr int SG_DIAG = SK_MAXCON * SREC;   // diagnostics of the last sub-step: Newton iterations, final max |gradient|, converged, contacts
+constexpr int SG_SIZE = SG_DIAG + 4;
 
 // ------------------------------------------------------------------------------------------------ convex pairs: MPR
 // Same algorithm as the oracle's mpr_penetration (libccd's ccdMPRPenetration as MuJoCo 2.3.2 runs it for mesh geoms [ext]); the
@@ -468,6 +469,7 @@ D3IL_NOINLINE inline bool sk_solve(const StackConsts& kc_, const StackScratch sc
     }
     double gm = 0, gn = 0;
     for (int i = 0; i < SK_NV; i++) { gm = fmax(gm, fabs(SL(ST_G + i))); gn += SL(ST_G + i) * SL(ST_G + i); }
+    SG(SG_DIAG) = (double)it; SG(SG_DIAG + 1) = gm;
     if (gm <= D3IL_TOL.grad_tol) { converged = true; break; }
     if (!sk_chol(sc, cm)) return false;
     for (int i = 0; i < SK_NV; i++) SL(ST_P + i) = -SL(ST_G + i);
@@ -734,7 +736,8 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
   }
   // ---- solve
   for (int i = 0; i < SK_NV; i++) SL(ST_X + i) = SL(ST_A0 + i);
-  if (ncon > 0 || any_lim) { if (!sk_solve(kc, sc, ncon)) st.flags |= F_SOLVER_FAIL; }
+  SG(SG_DIAG) = 0; SG(SG_DIAG + 1) = 0; SG(SG_DIAG + 2) = 1; SG(SG_DIAG + 3) = (double)ncon;
+  if (ncon > 0 || any_lim) { const bool ok = sk_solve(kc, sc, ncon); SG(SG_DIAG + 2) = ok ? 1.0 : 0.0; if (!ok) st.flags |= F_SOLVER_FAIL; }
   // ---- mj_Euler: implicit in the finger-joint damping (M + h B) qacc = M x on the arm block
   {
     double Mh[45], rhs[NDOF], L[45], d[NDOF], id[NDOF];

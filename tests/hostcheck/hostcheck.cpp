@@ -3,6 +3,7 @@
 // It is NOT part of the product: libd3il_rollout.so never links or calls this file, and the product
 // fails loudly when no HIP device is present.
 #define D3IL_HOST_STATS 1
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include "../../d3il_amd/csrc/gen_step.h"
@@ -193,12 +194,19 @@ void hc_stack_reset(void* h, const double* init_qpos, const double* ctx, double*
   StackScratch sc{p->t, p->g, 1};
   stack_env_reset(p->c, p->kc, ss, sc, init_qpos, ctx, obs); stack_pack(ss, s, f);
 }
+static int g_stack_poison = 0;
+void hc_stack_poison(int on) { g_stack_poison = on; }
 void hc_stack_step(void* h, double* s, int* f, const double* action, float* obs, unsigned char* done, double* mean_dist) {
   StackHost* p = (StackHost*)h; StackState ss; stack_unpack(s, f, ss);
+  if (g_stack_poison) {   // read-before-write detector: the scratch areas hold NaN before every step
+    for (int i = 0; i < ST_SIZE; i++) p->t[i] = std::nan("");
+    for (int i = 0; i < SG_SIZE; i++) p->g[i] = std::nan("");
+  }
   StackScratch sc{p->t, p->g, 1};
   stack_env_step(p->c, p->kc, ss, sc, action, obs, done, mean_dist, p->c.n_substeps, p->c.max_steps);
   stack_pack(ss, s, f);
 }
+void hc_stack_scratch(void* h, double* out, int count) { StackHost* p = (StackHost*)h; std::memcpy(out, p->g, (size_t)count * sizeof(double)); }
 // contacts of the last sub-step: per contact dist, pos3, normal3, bodyA, bodyB, set
 int hc_stack_contacts(void* h, double* out) {
   StackHost* p = (StackHost*)h; int n = 0;
