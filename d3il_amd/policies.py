@@ -1,0 +1,364 @@
+"""Native batched policies for the rollout boundary: the reference's evaluation-time policies restated for a
+BATCH of environments on device-resident observations.
+
+The reference agents are batch-1 and numpy-in / numpy-out (``agent.predict(np.ndarray[obs]) -> np.ndarray[1, act]``,
+agents/base_agent.py:110-122) with a host <-> device round trip, an EMA parameter swap (store / copy_to / restore over every
+parameter) and a Python deque of the observation history inside EVERY call (ddpm_agent.py:213-274, beso_agent.py:316-443).  With the
+simulator at millions of env-steps/s the policy is the bottleneck, so the classes below run the same computation once per step on
+the whole batch: ``predict_batch(obs[N, obs_dim]) -> act[N, act_dim]`` with
+  * the scaler (agents/utils/scaler.py:72-113) folded into two affine maps on the device,
+  * the observation / action history in device ring buffers ``[N, W, dim]`` with a per-lane length (lanes that start a new
+    trajectory - ``begin_episodes(mask)`` - restart their history),
+  * the EMA weights swapped in ONCE (``use_ema(shadow_params)``) instead of per call,
+  * the denoising loops (DDPM ancestral sampling, gc_diffusion.py:144-200; BESO Euler-ancestral on the Karras-preconditioned
+    denoiser, gc_sampling.py:217-256, score_wrappers.py:20-99) running on the batch.
+Networks are re-stated with the reference's parameter names, so a reference checkpoint (``model_state_dict``) loads unchanged
+(``load_reference_state_dict``); tests/golden/gen_agent_goldens.py builds the reference agents with fixed-seed weights in the build
+container and stores weights, inputs, noise and the reference's outputs, and tests/test_policies.py replays them here (row i of the
+batch == the reference's batch-1 ``predict`` of environment i).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+# ------------------------------------------------------------------------------------------------ scaler
+class Scaler:
+    """agents/utils/scaler.py:72-113 for ``scale_data=True``: x -> (x - mean) / (std + 1e-12), y -> y (std + 1e-12) + mean."""
+
+    def __init__(self, x_mean, x_std, y_mean, y_std, y_bounds=None, device="cuda"):
+        f = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)
+        self.x_mean, self.x_std, self.y_mean, self.y_std = f(x_mean), f(x_std), f(y_mean), f(y_std)
+        self.y_bounds = None if y_bounds is None else f(y_bounds)
+
+    def scale_input(self, x):
+        return ((x - self.x_mean) / (self.x_std + 1e-12)).to(torch.float32)
+
+    def inverse_scale_output(self, y):
+        return y * (self.y_std + 1e-12) + self.y_mean
+
+
+# ------------------------------------------------------------------------------------------------ networks
+class _ResBlock(nn.Module):          # TwoLayerPreActivationResNetLinear, agents/models/common/mlp.py:9-46 (no norm, no dropout at eval)
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.l1, self.l2 = nn.Linear(hidden_dim, hidden_dim), nn.Linear(hidden_dim, hidden_dim)
+
+    def forward(self, x):
+        return x + self.l2(F.mish(self.l1(F.mish(x))))
+
+
+class ResidualMLP(nn.Module):
+    """ResidualMLPNetwork (agents/models/common/mlp.py:114-182), Mish: Linear, num_hidden_layers / 2 pre-activation residual blocks, Linear."""
+
+    def __init__(self, input_dim, hidden_dim, num_hidden_layers, output_dim):
+        super().__init__()
+        assert num_hidden_layers % 2 == 0
+        self.layers = nn.ModuleList([nn.Linear(input_dim, hidden_dim)] + [_ResBlock(hidden_dim) for _ in range(1, num_hidden_layers, 2)] + [nn.Linear(hidden_dim, output_dim)])
+
+    def forward(self, x):
+        x = x.to(torch.float32)
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class _SinusoidalPosEmb(nn.Module):   # agents/models/diffusion/utils.py:9-22
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, x):
+        half = self.dim // 2
+        emb = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
+        emb = x[:, None] * emb[None, :]
+        return torch.cat((emb.sin(), emb.cos()), dim=-1)
+
+
+class DiffusionMLP(nn.Module):
+    """DiffusionMLPNetwork (agents/models/diffusion/diffusion_models.py:20-118), residual style, not goal conditioned:
+    eps(x, t, state) = ResidualMLP(cat(x, time_mlp(t), state))."""
+
+    def __init__(self, action_dim, obs_dim, t_dim, hidden_dim, num_hidden_layers):
+        super().__init__()
+        self.temp_layers = nn.Sequential(_SinusoidalPosEmb(t_dim), nn.Linear(t_dim, t_dim * 2), nn.Mish(), nn.Linear(t_dim * 2, t_dim))
+        self.layers = ResidualMLP(obs_dim + action_dim + t_dim, hidden_dim, num_hidden_layers, action_dim)
+
+    def forward(self, x, t, state):
+        t = self.temp_layers(t)
+        if state.dim() == 3:
+            return self.layers(torch.cat([x, t[:, None, :].expand(-1, state.shape[1], -1), state], dim=2))
+        return self.layers(torch.cat([x, t, state], dim=1))
+
+
+class _CausalSelfAttention(nn.Module):     # score_gpts.py:15-80
+    def __init__(self, n_embd, n_heads, block_size):
+        super().__init__()
+        self.key, self.query, self.value, self.proj = (nn.Linear(n_embd, n_embd) for _ in range(4))
+        self.register_buffer("mask", torch.tril(torch.ones(block_size, block_size)).view(1, 1, block_size, block_size))
+        self.n_head = n_heads
+
+    def forward(self, x):
+        B, T, C = x.size()
+        k = self.key(x).view(B, T, self.n_head, C // self.n_head).transpose(1, 2)
+        q = self.query(x).view(B, T, self.n_head, C // self.n_head).transpose(1, 2)
+        v = self.value(x).view(B, T, self.n_head, C // self.n_head).transpose(1, 2)
+        att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(k.size(-1)))
+        att = att.masked_fill(self.mask[:, :, :T, :T] == 0, float("-inf"))
+        y = F.softmax(att, dim=-1) @ v
+        return self.proj(y.transpose(1, 2).contiguous().view(B, T, C))
+
+
+class _Block(nn.Module):                   # score_gpts.py:83-115
+    def __init__(self, n_embd, n_heads, block_size):
+        super().__init__()
+        self.ln1, self.ln2 = nn.LayerNorm(n_embd), nn.LayerNorm(n_embd)
+        self.attn = _CausalSelfAttention(n_embd, n_heads, block_size)
+        self.mlp = nn.Sequential(nn.Linear(n_embd, 4 * n_embd), nn.GELU(), nn.Linear(4 * n_embd, n_embd), nn.Dropout(0.0))
+
+    def forward(self, x):
+        x = x + self.attn(self.ln1(x))
+        return x + self.mlp(self.ln2(x))
+
+
+class DiffusionGPT(nn.Module):
+    """DiffusionGPT (score_gpts.py:118-361), not goal conditioned: tokens = [sigma, s_1, a_1, ..., s_t, a_t], causal transformer,
+    the action positions are decoded."""
+
+    def __init__(self, state_dim, action_dim, embed_dim, n_layers, n_heads, obs_seq_len, linear_output=True):
+        super().__init__()
+        block_size = 2 * obs_seq_len + 1
+        self.tok_emb = nn.Linear(state_dim, embed_dim)
+        self.pos_emb = nn.Parameter(torch.zeros(1, obs_seq_len + 1, embed_dim))
+        self.blocks = nn.Sequential(*[_Block(embed_dim, n_heads, block_size) for _ in range(n_layers)])
+        self.ln_f = nn.LayerNorm(embed_dim)
+        self.sigma_emb = nn.Linear(1, embed_dim)
+        self.action_emb = nn.Linear(action_dim, embed_dim)
+        self.action_pred = nn.Linear(embed_dim, action_dim) if linear_output else nn.Sequential(nn.Linear(embed_dim, 100), nn.SiLU(), nn.Linear(100, action_dim))
+        self.obs_seq_len, self.embed_dim = obs_seq_len, embed_dim
+
+    def forward(self, states, actions, sigma):
+        b, t, _ = states.size()
+        emb_t = self.sigma_emb((sigma.log() / 4).reshape(b, 1).to(torch.float32)).unsqueeze(1)
+        pos = self.pos_emb[:, :t, :]
+        state_x, action_x = self.tok_emb(states) + pos, self.action_emb(actions) + pos
+        sa = torch.stack([state_x, action_x], dim=1).permute(0, 2, 1, 3).reshape(b, 2 * t, self.embed_dim)
+        x = self.ln_f(self.blocks(torch.cat([emb_t, sa], dim=1)))[:, 1:, :]
+        x = x.reshape(b, x.size(1) // 2, 2, self.embed_dim).permute(0, 2, 1, 3)
+        return self.action_pred(x[:, 1])
+
+
+# ------------------------------------------------------------------------------------------------ history ring buffer
+class _History:
+    """Device ring buffer [N, W, dim], newest entry last, with a per-lane length: the deque(maxlen=W) of the reference agents for a
+    batch.  Lanes are grouped by length for the network call (all lanes run in lock step unless some restart their trajectory)."""
+
+    def __init__(self, n, w, dim, device):
+        self.buf = torch.zeros(n, w, dim, dtype=torch.float32, device=device)
+        self.len = torch.zeros(n, dtype=torch.int64, device=device)
+        self.w = w
+        self.lockstep = 0           # host copy of the common length, or -1 when lanes differ
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.len.zero_(); self.lockstep = 0
+        else:
+            self.len = torch.where(mask.bool(), torch.zeros_like(self.len), self.len)
+            self.lockstep = -1
+
+    def append(self, x):
+        self.buf = torch.cat((self.buf[:, 1:], x.unsqueeze(1)), dim=1)
+        self.len = (self.len + 1).clamp_max(self.w)
+        if self.lockstep >= 0:
+            self.lockstep = min(self.lockstep + 1, self.w)
+
+    def groups(self):
+        """[(L, lane index tensor or None for all lanes)] - one entry when the lanes are in lock step."""
+        if self.lockstep >= 0:
+            return [(self.lockstep, None)]
+        lens = torch.unique(self.len).tolist()          # host sync, only while lanes differ
+        if len(lens) == 1:
+            self.lockstep = int(lens[0])
+            return [(self.lockstep, None)]
+        return [(int(L), torch.nonzero(self.len == L).reshape(-1)) for L in lens]
+
+
+# ------------------------------------------------------------------------------------------------ policies
+class BCPolicy:
+    """BC_Agent.predict (agents/bc_agent.py:240-271) on a batch: scale, MLP, clamp to the data bounds, inverse scale."""
+
+    def __init__(self, model: ResidualMLP, scaler: Scaler, min_action, max_action):
+        self.model, self.scaler = model.eval(), scaler
+        dev = scaler.x_mean.device
+        self.min_action, self.max_action = torch.as_tensor(min_action, device=dev), torch.as_tensor(max_action, device=dev)
+
+    def reset(self):
+        pass
+
+    @torch.no_grad()
+    def predict_batch(self, obs):
+        out = self.model(self.scaler.scale_input(obs.to(torch.float32)))
+        return self.scaler.inverse_scale_output(torch.clamp(out, self.min_action, self.max_action))
+
+
+def cosine_beta_schedule(timesteps, s=0.008):     # agents/models/diffusion/utils.py:31-42 (float64 numpy -> float32)
+    import numpy as np
+    steps = timesteps + 1
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return torch.tensor(np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999), dtype=torch.float32)
+
+
+class DDPMPolicy:
+    """DiffusionAgent.predict (ddpm_agent.py:213-274) with the Diffusion sampler (gc_diffusion.py:101-216: epsilon prediction, clipped
+    x0, posterior mean / variance, n_timesteps ancestral steps, final clamp) on a batch.  ``noise_fn(shape)`` supplies the Gaussian
+    noise (default torch.randn on the policy's device); window_size > 1 keeps the observation history per lane."""
+
+    def __init__(self, model: DiffusionMLP, scaler: Scaler, n_timesteps: int, window_size: int = 1, n_envs: int | None = None, noise_fn=None):
+        self.model, self.scaler, self.T, self.W = model.eval(), scaler, int(n_timesteps), int(window_size)
+        dev = scaler.x_mean.device
+        self.device = dev
+        betas = cosine_beta_schedule(self.T).to(dev)
+        alphas = 1.0 - betas
+        ac = torch.cumprod(alphas, dim=0)
+        ac_prev = torch.cat([torch.ones(1, device=dev), ac[:-1]])
+        self.sqrt_recip_ac, self.sqrt_recipm1_ac = torch.sqrt(1.0 / ac), torch.sqrt(1.0 / ac - 1)
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        self.post_logvar = torch.log(torch.clamp(post_var, min=1e-20))
+        self.coef1, self.coef2 = betas * torch.sqrt(ac_prev) / (1.0 - ac), (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac)
+        self.min_action, self.max_action = scaler.y_bounds[0], scaler.y_bounds[1]
+        self.noise_fn = noise_fn or (lambda shape: torch.randn(shape, device=dev))
+        self.hist = None
+        self.n_envs = n_envs
+
+    def load_reference_state_dict(self, sd):
+        """``Diffusion.state_dict()`` of the reference: the denoiser sits under ``model.``."""
+        self.model.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")})
+
+    def use_ema(self, shadow_params):
+        """One EMA swap per rollout (the reference swaps per predict call): shadow parameters in ``model.parameters()`` order."""
+        with torch.no_grad():
+            for p, s in zip(self.model.parameters(), shadow_params):
+                p.copy_(torch.as_tensor(s, dtype=p.dtype, device=p.device))
+
+    def reset(self):
+        if self.hist is not None:
+            self.hist.reset()
+
+    def begin_episodes(self, mask):
+        if self.hist is not None:
+            self.hist.reset(mask)
+
+    def _sample(self, state):
+        shape = (state.shape[0], state.shape[1], self.min_action.shape[0]) if state.dim() == 3 else (state.shape[0], self.min_action.shape[0])
+        x = self.noise_fn(shape)
+        for i in reversed(range(self.T)):
+            t = torch.full((shape[0],), i, device=self.device, dtype=torch.long)
+            eps = self.model(x, t, state)
+            x0 = (self.sqrt_recip_ac[i] * x - self.sqrt_recipm1_ac[i] * eps).clamp(self.min_action, self.max_action)
+            mean = self.coef1[i] * x0 + self.coef2[i] * x
+            noise = self.noise_fn(shape)
+            x = mean + (0.0 if i == 0 else 1.0) * (0.5 * self.post_logvar[i]).exp() * noise
+        return x.clamp(self.min_action, self.max_action)
+
+    @torch.no_grad()
+    def predict_batch(self, obs):
+        s = self.scaler.scale_input(obs.to(device=self.device, dtype=torch.float32))
+        if self.W <= 1:
+            return self.scaler.inverse_scale_output(self._sample(s))
+        if self.hist is None:
+            self.hist = _History(s.shape[0], self.W, s.shape[1], self.device)
+        self.hist.append(s)
+        out = torch.empty(s.shape[0], self.min_action.shape[0], device=self.device)
+        for L, idx in self.hist.groups():
+            st = self.hist.buf[:, self.W - L:] if idx is None else self.hist.buf[idx, self.W - L:]
+            a = self._sample(st)[:, -1, :]
+            if idx is None:
+                out = a
+            else:
+                out[idx] = a
+        return self.scaler.inverse_scale_output(out)
+
+
+class BESOPolicy:
+    """BesoAgent.predict (beso_agent.py:316-443) on a batch: observation history (deque maxlen W) and action history (deque maxlen
+    W - 1 of the clamped scaled actions), x_T = N(0, sigma_max^2) for the newest action, Euler-ancestral sampling over the linear noise
+    schedule (beso_agent.py:122, gc_sampling.py:41-44, 217-256) of the Karras-preconditioned DiffusionGPT (score_wrappers.py:33-99),
+    last action of the sequence, clamp, inverse scale."""
+
+    def __init__(self, inner: DiffusionGPT, scaler: Scaler, window_size: int, num_sampling_steps: int, sigma_min: float, sigma_max: float,
+                 sigma_data: float = 0.5, noise_fn=None):
+        self.inner, self.scaler, self.W = inner.eval(), scaler, int(window_size)
+        dev = scaler.x_mean.device
+        self.device = dev
+        self.n_steps, self.sigma_min, self.sigma_max, self.sigma_data = int(num_sampling_steps), float(sigma_min), float(sigma_max), float(sigma_data)
+        self.min_action, self.max_action = scaler.y_bounds[0], scaler.y_bounds[1]
+        self.noise_fn = noise_fn or (lambda shape: torch.randn(shape, device=dev))
+        self.obs_hist = self.act_hist = None
+
+    def load_reference_state_dict(self, sd):
+        """``GCDenoiser.state_dict()`` of the reference: the transformer sits under ``inner_model.``."""
+        own = self.inner.state_dict()
+        self.inner.load_state_dict({k[len("inner_model."):]: v for k, v in sd.items() if k.startswith("inner_model.") and k[len("inner_model."):] in own})
+
+    def use_ema(self, shadow_params):
+        with torch.no_grad():
+            for p, s in zip(self.inner.parameters(), shadow_params):
+                p.copy_(torch.as_tensor(s, dtype=p.dtype, device=p.device))
+
+    def reset(self):
+        for h in (self.obs_hist, self.act_hist):
+            if h is not None:
+                h.reset()
+
+    def begin_episodes(self, mask):
+        for h in (self.obs_hist, self.act_hist):
+            if h is not None:
+                h.reset(mask)
+
+    def _denoise(self, states, actions, sigma):
+        sd2 = self.sigma_data ** 2
+        c_skip, c_out, c_in = sd2 / (sigma ** 2 + sd2), sigma * self.sigma_data / (sigma ** 2 + sd2) ** 0.5, 1 / (sigma ** 2 + sd2) ** 0.5
+        s_in = torch.full((actions.shape[0],), float(sigma), device=self.device)
+        return self.inner(states, actions * c_in, s_in) * c_out + actions * c_skip
+
+    def _sample(self, states, x):
+        sigmas = torch.cat([torch.linspace(self.sigma_max, self.sigma_min, self.n_steps, device=self.device), torch.zeros(1, device=self.device)])
+        for i in range(len(sigmas) - 1):
+            s_from, s_to = float(sigmas[i]), float(sigmas[i + 1])
+            den = self._denoise(states, x, sigmas[i])
+            s_up = min(s_to, (s_to ** 2 * (s_from ** 2 - s_to ** 2) / s_from ** 2) ** 0.5)
+            s_down = (s_to ** 2 - s_up ** 2) ** 0.5
+            x = x + (x - den) / sigmas[i] * (s_down - sigmas[i])
+            if s_down > 0:
+                x = x + self.noise_fn(tuple(x.shape)) * s_up
+        return x
+
+    @torch.no_grad()
+    def predict_batch(self, obs):
+        s = self.scaler.scale_input(obs.to(device=self.device, dtype=torch.float32))
+        n, act_dim = s.shape[0], self.min_action.shape[0]
+        if self.obs_hist is None:
+            self.obs_hist = _History(n, self.W, s.shape[1], self.device)
+            self.act_hist = _History(n, self.W - 1, act_dim, self.device) if self.W > 1 else None
+        self.obs_hist.append(s)
+        noise = self.noise_fn((n, 1, act_dim)) * self.sigma_max
+        x0_all = torch.empty(n, act_dim, device=self.device)
+        for L, idx in self.obs_hist.groups():
+            sel = slice(None) if idx is None else idx
+            st = self.obs_hist.buf[sel, self.W - L:]
+            x = noise[sel]
+            if L > 1:                          # previous actions: the action deque holds min(L - 1, W - 1) entries
+                x = torch.cat([self.act_hist.buf[sel, (self.W - 1) - (L - 1):], x], dim=1)
+            x0 = self._sample(st, x)[:, -1, :].clamp(self.min_action, self.max_action)
+            x0_all[sel] = x0
+        if self.act_hist is not None:
+            self.act_hist.append(x0_all)
+            self.act_hist.len = (self.obs_hist.len - 1).clamp_min(0).clamp_max(self.W - 1)
+            self.act_hist.lockstep = -1 if self.obs_hist.lockstep < 0 else min(max(self.obs_hist.lockstep - 1, 0), self.W - 1)
+        return self.scaler.inverse_scale_output(x0_all)

@@ -230,8 +230,10 @@ def test_api_errors(lib_loaded):
     assert L.d3il_create(0, 0, 0, C.byref(b), C.sizeof(b), C.byref(h)) == -1          # n_envs <= 0
     assert L.d3il_create(0, 8, 0, C.byref(b), 17, C.byref(h)) == -2                     # blob size
     assert L.d3il_create(1, 8, 0, C.byref(b), C.sizeof(b), C.byref(h)) == -1           # task id does not match the blob
-    b3 = blob.load("avoiding"); b3.task_id = 3
-    assert L.d3il_create(3, 8, 0, C.byref(b3), C.sizeof(b3), C.byref(h)) == -5          # task not implemented (stacking)
+    b3 = blob.load("avoiding"); b3.task_id = 7
+    assert L.d3il_create(7, 8, 0, C.byref(b3), C.sizeof(b3), C.byref(h)) == -5          # unknown task id
+    b5 = blob.load("avoiding"); b5.task_id = 3
+    assert L.d3il_create(3, 8, 0, C.byref(b5), C.sizeof(b5), C.byref(h)) == -2          # a Stacking blob must carry three boxes and the finger hull
     b4 = blob.load("avoiding"); b4.task_id = 2
     assert L.d3il_create(2, 8, 0, C.byref(b4), C.sizeof(b4), C.byref(h)) == -2 and b"task objects" in L.d3il_last_error()   # a Sorting blob without cubes
     b2 = blob.load("avoiding"); b2.body_mass[35] *= 1.01
