@@ -28,7 +28,7 @@ FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
 PUSH_STATE_BOX, PUSH_STATE_WARM, PUSH_STATE_F64 = 42, 68, 89
 PFLAG_FIRST_MASK, PFLAG_MODE_MASK, PFLAG_WARM_VALID, PFLAG_CON_OVERFLOW, PFLAG_OFF_TABLE = 0x7, 0x38, 1 << 6, 1 << 18, 1 << 19
 TASK_AVOIDING, TASK_PUSHING, TASK_SORTING, TASK_STACKING = 0, 1, 2, 3
-STACK_STATE_BOX, STACK_STATE_F64 = 28, 67
+STACK_STATE_BOX, STACK_STATE_WARM, STACK_STATE_F64 = 28, 67, 94
 SFLAG_HAND_NEAR = 1 << 20
 TALLY_ROW = 514
 SORT_STATE_BOX, SORT_STATE_WARM, SORT_STATE_TASK, SORT_STATE_F64 = 42, 94, 127, 129

@@ -25,6 +25,7 @@ __device__ __forceinline__ void stack_load(const double* __restrict__ state, con
     for (int i = 0; i < 4; i++) ss.box[b].quat[i] = s[(size_t)(k++) * stride];
     for (int i = 0; i < 6; i++) ss.box[b].vel[i] = s[(size_t)(k++) * stride];
   }
+  for (int i = 0; i < SK_NV; i++) ss.warm[i] = s[(size_t)(SK_STATE_WARM + i) * stride];
   st.flags = flags[e]; st.step = steps[e];
 }
 __device__ __forceinline__ void stack_store(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps, int stride, int e, const StackState& ss) {
@@ -40,6 +41,7 @@ __device__ __forceinline__ void stack_store(double* __restrict__ state, unsigned
     for (int i = 0; i < 4; i++) s[(size_t)(k++) * stride] = ss.box[b].quat[i];
     for (int i = 0; i < 6; i++) s[(size_t)(k++) * stride] = ss.box[b].vel[i];
   }
+  for (int i = 0; i < SK_NV; i++) s[(size_t)(SK_STATE_WARM + i) * stride] = ss.warm[i];
   flags[e] = st.flags; steps[e] = st.step;
 }
 

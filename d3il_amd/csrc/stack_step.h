@@ -54,11 +54,13 @@ struct StackConsts {
 enum : unsigned {
   SKF_NMODE_MASK = 0x3u,          // number of boxes that have reached the target so far (stacking.py:395-419)
   SKF_IND_SHIFT = 2,              // min_inds[3], two bits each
+  SKF_WARM_VALID = 1u << 8,       // the warm-start rows hold the accelerations of the previous sub-step
   SKF_CON_OVERFLOW = 1u << 18,    // more than SK_MAXCON contacts in one sub-step (extra contacts dropped)
   SKF_OFF_TABLE = 1u << 19,       // a box left the modelled part of the table
   SKF_HAND_NEAR = 1u << 20,       // a box reached the hand mesh (a pair this engine does not evaluate)
 };
-constexpr int SK_STATE_BOX = 28, SK_STATE_F64 = SK_STATE_BOX + 13 * SK_NB;     // arm q[9] v[9] bias[7] tcp[3] | boxes (pos3 quat4 vel6) x 3
+// arm q[9] v[9] bias[7] tcp[3] | boxes (pos3 quat4 vel6) x 3 | the solver's warm start qacc[27] (MuJoCo: qacc_warmstart)
+constexpr int SK_STATE_BOX = 28, SK_STATE_WARM = SK_STATE_BOX + 13 * SK_NB, SK_STATE_F64 = SK_STATE_WARM + SK_NV;
 constexpr int SK_OBS = 12, SK_ACT = 8;
 
 #if defined(__HIPCC__)
@@ -97,7 +99,7 @@ constexpr int ST_SIZE = ST_LIM + 27;            // 717
 // g area: contact records
 constexpr int SREC = 36;    // pos[3] frame[9] dist bodyA bodyB set | aref[4] D[4] mu | jar[4] jp[4] | pad
 constexpr int SG_DIAG = SK_MAXCON * SREC;   // diagnostics of the last sub-step: Newton iterations, final max |gradient|, converged, contacts
-constexpr int SG_SIZE = SG_DIAG + 4;
+constexpr int SG_SIZE = SG_DIAG + 12;      // [4 .. 11]: clock ticks per phase, accumulated (diagnostics build -DD3IL_DEVICE_STATS only)
 
 // ------------------------------------------------------------------------------------------------ convex pairs: MPR
 // Same algorithm as the oracle's mpr_penetration (libccd's ccdMPRPenetration as MuJoCo 2.3.2 runs it for mesh geoms [ext]); the
@@ -275,68 +277,85 @@ D3IL_HD void sk_cone(int dim, const double* jar, const double* D, double mu, con
       Hc[4 * a + b] = Dm * h;
     }
 }
-// one side of a contact: the body's dofs and the dim x n block of the constraint Jacobian (J(body) as such; the caller applies the
-// sign - the contact's rows are J(body B) - J(body A)).  off = first solver dof, n = 0 (static), 6 (box) or 9 (arm).
-struct SkSide { int off, n; double J[4][NDOF]; };
-D3IL_HD void sk_side(const StackScratch sc, int body, const double* pos, const double* frame, int dim, SkSide& s) {
-  if (body == SKB_STATIC) { s.off = 0; s.n = 0; return; }
-  if (body < SK_NB) {
-    s.off = 6 * body; s.n = 6;
-    double R[9], r[3];
+// Rows of a contact.  The four body pairings have compile-time sizes, so their row blocks live in registers:
+//   (NA, NB) = (0, 6) static-box, (6, 6) box-box, (6, 9) box-finger, (0, 9) finger-finger (one row set J(finger B) - J(finger A)).
+// A = body 1 (enters with -), B = body 2 (+); a box block has 6 columns, the arm block 9.  Blocks are ordered box 0 | 1 | 2 | arm and
+// body 1 precedes body 2 in the model's geom order, so the cross block of the Hessian is always H[B rows][A columns].
+template <int NA, int NB> struct SkRows { int oa, ob, dim; double A[4][NA ? NA : 1], B[4][NB]; };
+D3IL_HD void sk_box_rows(const StackScratch sc, int body, const double* pos, const double* frame, int dim, double (*J)[6]) {
+  double R[9], r[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = SL(ST_BR + 9 * body + k);
+  for (int k = 0; k < 9; k++) R[k] = SL(ST_BR + 9 * body + k);
 #pragma unroll
-    for (int k = 0; k < 3; k++) r[k] = pos[k] - SL(ST_BP + 3 * body + k);
-    for (int rr = 0; rr < 3; rr++) box_row_r(R, r, frame + 3 * rr, s.J[rr]);
-    if (dim > 3) {     // torsional row: relative angular velocity about the normal; box angular dofs are body axes
-      s.J[3][0] = s.J[3][1] = s.J[3][2] = 0;
-      s.J[3][3] = R[0] * frame[0] + R[3] * frame[1] + R[6] * frame[2];
-      s.J[3][4] = R[1] * frame[0] + R[4] * frame[1] + R[7] * frame[2];
-      s.J[3][5] = R[2] * frame[0] + R[5] * frame[1] + R[8] * frame[2];
-    }
-    return;
-  }
-  const int f = (body - SKB_FINGER) & 1;       // finger body or its tip: the same dofs
-  s.off = SK_ARM0; s.n = NDOF;
+  for (int k = 0; k < 3; k++) r[k] = pos[k] - SL(ST_BP + 3 * body + k);
+#pragma unroll
+  for (int rr = 0; rr < 3; rr++) box_row_r(R, r, frame + 3 * rr, J[rr]);
+  J[3][0] = J[3][1] = J[3][2] = 0;      // torsional row (dim 4): relative angular velocity about the normal; box angular dofs are body axes
+  J[3][3] = R[0] * frame[0] + R[3] * frame[1] + R[6] * frame[2];
+  J[3][4] = R[1] * frame[0] + R[4] * frame[1] + R[7] * frame[2];
+  J[3][5] = R[2] * frame[0] + R[5] * frame[1] + R[8] * frame[2];
+  (void)dim;
+}
+D3IL_HD void sk_arm_rows(const StackScratch sc, int f, double sign, const double* pos, const double* frame, double (*J)[NDOF], bool accumulate) {
+#pragma unroll
   for (int k = 0; k < NARM; k++) {
     double z[3] = {SL(ST_Z + 3 * k), SL(ST_Z + 3 * k + 1), SL(ST_Z + 3 * k + 2)};
     double d[3] = {pos[0] - SL(ST_O + 3 * k), pos[1] - SL(ST_O + 3 * k + 1), pos[2] - SL(ST_O + 3 * k + 2)}, col[3];
     cross3(z, d, col);
-    for (int rr = 0; rr < 3; rr++) s.J[rr][k] = dot3(frame + 3 * rr, col);
-    s.J[3][k] = dot3(frame, z);
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) { const double v = sign * dot3(frame + 3 * rr, col); J[rr][k] = accumulate ? J[rr][k] + v : v; }
+    const double w = sign * dot3(frame, z);
+    J[3][k] = accumulate ? J[3][k] + w : w;
   }
+#pragma unroll
   for (int g = 0; g < NFING; g++) {
     double ax[3] = {SL(ST_FAX + 3 * g), SL(ST_FAX + 3 * g + 1), SL(ST_FAX + 3 * g + 2)};
-    for (int rr = 0; rr < 3; rr++) s.J[rr][NARM + g] = g == f ? dot3(frame + 3 * rr, ax) : 0.0;
-    s.J[3][NARM + g] = 0;
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) { const double v = g == f ? sign * dot3(frame + 3 * rr, ax) : 0.0; J[rr][NARM + g] = accumulate ? J[rr][NARM + g] + v : v; }
+    if (!accumulate) J[3][NARM + g] = 0;
   }
 }
-// rows of contact record ci: A = body 1 (enters with -), B = body 2 (+)
-struct SkCon { int dim, set; SkSide A, B; };
-D3IL_HD void sk_rows(const StackConsts& kc_, const StackScratch sc, int ci, SkCon& c) {
+template <int NA, int NB>
+D3IL_HD void sk_build_rows(const StackConsts& kc_, const StackScratch sc, int ci, SkRows<NA, NB>& R, int* set_out) {
   D3IL_STACK_CONSTS(kc_, kc);
   const int base = ci * SREC;
   double rec[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) rec[k] = SG(base + k);
-  c.set = (int)rec[15]; c.dim = kc.set[c.set].dim;
-  sk_side(sc, (int)rec[13], rec, rec + 3, c.dim, c.A);
-  sk_side(sc, (int)rec[14], rec, rec + 3, c.dim, c.B);
-  if (c.A.n == NDOF && c.B.n == NDOF) {     // finger <-> finger: both sides are the arm block, one row set J(B) - J(A)
-    for (int r = 0; r < 4; r++) for (int k = 0; k < NDOF; k++) c.B.J[r][k] -= c.A.J[r][k];
-    c.A.n = 0;
+  const int a = (int)rec[13], b = (int)rec[14], set = (int)rec[15];
+  *set_out = set; R.dim = kc.set[set].dim;
+  if constexpr (NA == 6) { R.oa = 6 * a; sk_box_rows(sc, a, rec, rec + 3, R.dim, R.A); } else R.oa = 0;
+  if constexpr (NB == 6) { R.ob = 6 * b; sk_box_rows(sc, b, rec, rec + 3, R.dim, R.B); }
+  else {
+    R.ob = SK_ARM0;
+    sk_arm_rows(sc, (b - SKB_FINGER) & 1, 1.0, rec, rec + 3, R.B, false);
+    if constexpr (NA == 0) sk_arm_rows(sc, (a - SKB_FINGER) & 1, -1.0, rec, rec + 3, R.B, true);     // finger <-> finger
   }
+}
+template <int NA, int NB> D3IL_HD double sk_dot(const StackScratch sc, const SkRows<NA, NB>& R, int r, int vec) {
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < NB; k++) s += R.B[r][k] * SL(vec + R.ob + k);
+  if constexpr (NA > 0) {
+#pragma unroll
+    for (int k = 0; k < NA; k++) s -= R.A[r][k] * SL(vec + R.oa + k);
+  }
+  return s;
 }
 // friction coefficients of the rows 1 .. 3 of a contact: tangent, tangent, torsional (mjContact.friction[0, 1, 2] of MuJoCo's
 // 5-vector (slide, slide, spin, roll, roll))
 D3IL_HD void sk_row_fric(const StackSet& ps, double* fr) { fr[0] = ps.fric[0]; fr[1] = ps.fric[0]; fr[2] = ps.fric[1]; }
-D3IL_HD double sk_row_dot(const StackScratch sc, const SkCon& c, int r, int vec) {   // row r of the contact times the t-area vector at vec
-  double s = 0;
-  for (int k = 0; k < c.B.n; k++) s += c.B.J[r][k] * SL(vec + c.B.off + k);
-  for (int k = 0; k < c.A.n; k++) s -= c.A.J[r][k] * SL(vec + c.A.off + k);
-  return s;
-}
+// accumulation into the t area (device: LDS atomic add, fire and forget - the lane owns its column, so there is no contention)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SL_ADD(i, v) ((void)__hip_atomic_fetch_add(&SL(i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT))
+#else
+#define SL_ADD(i, v) (SL(i) += (v))
+#endif
+D3IL_HD int sk_kind(int a, int b) { return b < SK_NB ? (a == SKB_STATIC ? 0 : 1) : (a < SK_NB ? 2 : 3); }
+D3IL_HD int sk_blk_of(int body) { return body == SKB_STATIC ? -1 : (body < SK_NB ? body : SK_NB); }
 D3IL_HD int sk_blk(int dof) { return dof >= SK_ARM0 ? SK_NB : dof / 6; }
+D3IL_HD int sk_blk0(int b) { return b < SK_NB ? 6 * b : SK_ARM0; }
+D3IL_HD int sk_blkn(int b) { return b < SK_NB ? 6 : NDOF; }
 D3IL_HD double sk_Mv(const StackConsts& kc_, const StackScratch sc, int i, int va, int vb) {   // (M (v_a - v_b))_i of the block-diagonal mass matrix
   D3IL_STACK_CONSTS(kc_, kc);
   if (i < SK_ARM0) {
@@ -349,166 +368,227 @@ D3IL_HD double sk_Mv(const StackConsts& kc_, const StackScratch sc, int i, int v
   return s;
 }
 
-// Cholesky of the packed Hessian with block skipping: cm[i] = bit mask of the blocks coupled with block i (after fill closure)
-D3IL_HD int sk_blk0(int b) { return b < SK_NB ? 6 * b : SK_ARM0; }
-D3IL_HD int sk_blkn(int b) { return b < SK_NB ? 6 : NDOF; }
-D3IL_NOINLINE inline bool sk_chol(const StackScratch sc, const unsigned* cm) {
+// gradient / Hessian contribution of one contact at x (ST_X): g -= J' f, H += J' Hc J; the row residuals are cached in the record
+template <int NA, int NB>
+D3IL_NOINLINE inline void sk_contact_gh(const StackConsts& kc_, const StackScratch sc, int ci, bool with_h) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  SkRows<NA, NB> R; int set;
+  sk_build_rows(kc, sc, ci, R, &set);
+  const int base = ci * SREC, dim = R.dim;
+  double jar[4] = {0, 0, 0, 0}, D[4], f[4], Hc[16], fr[3];
+  for (int r = 0; r < 4; r++) { if (r < dim) jar[r] = sk_dot(sc, R, r, ST_X) - SG(base + 16 + r); D[r] = SG(base + 20 + r); SG(base + 25 + r) = jar[r]; }
+  sk_row_fric(kc.set[set], fr);
+  sk_cone(dim, jar, D, SG(base + 24), fr, f, Hc);
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 16; i++) any = any || Hc[i] != 0;
+  if (!any) return;                      // contact in the top zone of its cone: no force, no curvature
+#pragma unroll
+  for (int k = 0; k < NB; k++) { double acc = 0; for (int r = 0; r < 4; r++) acc += R.B[r][k] * f[r]; SL_ADD(ST_G + R.ob + k, -acc); }
+  if constexpr (NA > 0) {
+#pragma unroll
+    for (int k = 0; k < NA; k++) { double acc = 0; for (int r = 0; r < 4; r++) acc += R.A[r][k] * f[r]; SL_ADD(ST_G + R.oa + k, acc); }
+  }
+  if (!with_h) return;                   // gradient-only pass (warm-start acceptance test)
+  // H blocks (rows beyond dim carry zero force / curvature: f and Hc are zero there)
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    double t[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) t[q] = R.B[0][i] * Hc[q] + R.B[1][i] * Hc[4 + q] + R.B[2][i] * Hc[8 + q] + R.B[3][i] * Hc[12 + q];
+#pragma unroll
+    for (int k = 0; k <= i; k++) SL_ADD(ST_H + tri(R.ob + i, R.ob + k), t[0] * R.B[0][k] + t[1] * R.B[1][k] + t[2] * R.B[2][k] + t[3] * R.B[3][k]);
+    if constexpr (NA > 0) {
+#pragma unroll
+      for (int k = 0; k < NA; k++) SL_ADD(ST_H + tri(R.ob + i, R.oa + k), -(t[0] * R.A[0][k] + t[1] * R.A[1][k] + t[2] * R.A[2][k] + t[3] * R.A[3][k]));
+    }
+  }
+  if constexpr (NA > 0) {
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+      double t[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) t[q] = R.A[0][i] * Hc[q] + R.A[1][i] * Hc[4 + q] + R.A[2][i] * Hc[8 + q] + R.A[3][i] * Hc[12 + q];
+#pragma unroll
+      for (int k = 0; k <= i; k++) SL_ADD(ST_H + tri(R.oa + i, R.oa + k), t[0] * R.A[0][k] + t[1] * R.A[1][k] + t[2] * R.A[2][k] + t[3] * R.A[3][k]);
+    }
+  }
+}
+// J p of one contact for the line search (cached in the record), or J v -> reference acceleration and regularisation (mode 1)
+template <int NA, int NB>
+D3IL_NOINLINE inline void sk_contact_dot(const StackConsts& kc_, const StackScratch sc, int ci, int mode) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  SkRows<NA, NB> R; int set;
+  sk_build_rows(kc, sc, ci, R, &set);
+  const int base = ci * SREC;
+  if (mode == 0) {
+    for (int r = 0; r < 4; r++) SG(base + 29 + r) = r < R.dim ? sk_dot(sc, R, r, ST_P) : 0.0;
+    return;
+  }
+  // mj_makeImpedance for an elliptic contact [ext]
+  const StackSet& ps = kc.set[set];
+  const double dist = SG(base + 12);
+  const double imp = impedance(ps.solimp, dist - ps.margin);
+  const int a = (int)SG(base + 13), b = (int)SG(base + 14);
+  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])); };
+  const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
+  const double R1 = R0 / fmax(1e-15, kc.impratio);
+  for (int r = 0; r < 4; r++) {
+    const double v = r < R.dim ? sk_dot(sc, R, r, ST_VEL) : 0.0;
+    SG(base + 16 + r) = r < R.dim ? -ps.B * v - (r == 0 ? ps.K * imp * (dist - ps.margin) : 0.0) : 0.0;
+  }
+  SG(base + 20) = 1 / R0; SG(base + 21) = 1 / R1; SG(base + 22) = 1 / R1;
+  SG(base + 23) = 1 / (R1 * ps.fric[0] * ps.fric[0] / (ps.fric[1] * ps.fric[1]));
+  SG(base + 24) = ps.fric[0] * sqrt(R1 / R0);
+}
+template <int OP> D3IL_HD void sk_contact_dispatch(const StackConsts& kc, const StackScratch sc, int ci, int mode) {
+  const int kind = sk_kind((int)SG(ci * SREC + 13), (int)SG(ci * SREC + 14));
+  if (OP == 0) {
+    if (kind == 0) sk_contact_gh<0, 6>(kc, sc, ci, mode != 0); else if (kind == 1) sk_contact_gh<6, 6>(kc, sc, ci, mode != 0);
+    else if (kind == 2) sk_contact_gh<6, 9>(kc, sc, ci, mode != 0); else sk_contact_gh<0, 9>(kc, sc, ci, mode != 0);
+  } else {
+    if (kind == 0) sk_contact_dot<0, 6>(kc, sc, ci, mode); else if (kind == 1) sk_contact_dot<6, 6>(kc, sc, ci, mode);
+    else if (kind == 2) sk_contact_dot<6, 9>(kc, sc, ci, mode); else sk_contact_dot<0, 9>(kc, sc, ci, mode);
+  }
+}
+
+// Cholesky of the island's part of the packed Hessian.  bm: blocks of the island; cm[i]: blocks coupled with block i (after fill
+// closure).  Structurally empty blocks are skipped.
+D3IL_NOINLINE inline bool sk_chol(const StackScratch sc, unsigned bm, const unsigned* cm) {
   bool ok = true;
-  for (int i = 0; i < SK_NV; i++) {
-    const int bi = sk_blk(i);
-    for (int j = 0; j <= i; j++) {
-      const int bj = sk_blk(j);
-      if (bi != bj && !((cm[bi] >> bj) & 1u)) { SL(ST_H + tri(i, j)) = 0; continue; }
-      double s = SL(ST_H + tri(i, j));
-      for (int bk = 0; bk <= bj; bk++) {      // columns of the blocks coupled with both rows
-        if (!(bk == bj || ((cm[bj] >> bk) & 1u)) || !(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
-        const int k0 = sk_blk0(bk), k1 = k0 + sk_blkn(bk) < j ? k0 + sk_blkn(bk) : j;
-        for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(i, k)) * SL(ST_H + tri(j, k));
+  for (int bi = 0; bi <= SK_NB; bi++) {
+    if (!((bm >> bi) & 1u)) continue;
+    for (int i = sk_blk0(bi); i < sk_blk0(bi) + sk_blkn(bi); i++) {
+      for (int bj = 0; bj <= bi; bj++) {
+        if (!((bm >> bj) & 1u) || (bi != bj && !((cm[bi] >> bj) & 1u))) continue;
+        const int jend = bi == bj ? i + 1 : sk_blk0(bj) + sk_blkn(bj);
+        for (int j = sk_blk0(bj); j < jend; j++) {
+          double s = SL(ST_H + tri(i, j));
+          for (int bk = 0; bk <= bj; bk++) {      // columns of the blocks coupled with both rows
+            if (!((bm >> bk) & 1u) || !(bk == bj || ((cm[bj] >> bk) & 1u)) || !(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
+            const int k0 = sk_blk0(bk), k1 = k0 + sk_blkn(bk) < j ? k0 + sk_blkn(bk) : j;
+            for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(i, k)) * SL(ST_H + tri(j, k));
+          }
+          if (i == j) {
+            if (!(s > 0)) { ok = false; s = 1; }
+            SL(ST_H + tri(i, i)) = sqrt(s);
+          } else SL(ST_H + tri(i, j)) = s / SL(ST_H + tri(j, j));
+        }
       }
-      if (i == j) {
-        if (!(s > 0)) { ok = false; s = 1; }
-        SL(ST_H + tri(i, i)) = sqrt(s);
-      } else SL(ST_H + tri(i, j)) = s / SL(ST_H + tri(j, j));
     }
   }
   return ok;
 }
-D3IL_NOINLINE inline void sk_chol_solve(const StackScratch sc, const unsigned* cm, int vec) {
-  for (int i = 0; i < SK_NV; i++) {
-    const int bi = sk_blk(i);
-    double s = SL(vec + i);
-    for (int bk = 0; bk <= bi; bk++) {
-      if (!(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
-      const int k0 = sk_blk0(bk), k1 = k0 + sk_blkn(bk) < i ? k0 + sk_blkn(bk) : i;
-      for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(i, k)) * SL(vec + k);
+D3IL_NOINLINE inline void sk_chol_solve(const StackScratch sc, unsigned bm, const unsigned* cm, int vec) {
+  for (int bi = 0; bi <= SK_NB; bi++) {
+    if (!((bm >> bi) & 1u)) continue;
+    for (int i = sk_blk0(bi); i < sk_blk0(bi) + sk_blkn(bi); i++) {
+      double s = SL(vec + i);
+      for (int bk = 0; bk <= bi; bk++) {
+        if (!((bm >> bk) & 1u) || !(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
+        const int k0 = sk_blk0(bk), k1 = k0 + sk_blkn(bk) < i ? k0 + sk_blkn(bk) : i;
+        for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(i, k)) * SL(vec + k);
+      }
+      SL(vec + i) = s / SL(ST_H + tri(i, i));
     }
-    SL(vec + i) = s / SL(ST_H + tri(i, i));
   }
-  for (int i = SK_NV - 1; i >= 0; i--) {
-    const int bi = sk_blk(i);
-    double s = SL(vec + i);
-    for (int bk = bi; bk <= SK_NB; bk++) {
-      if (!(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
-      const int k0 = sk_blk0(bk) > i + 1 ? sk_blk0(bk) : i + 1, k1 = sk_blk0(bk) + sk_blkn(bk);
-      for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(k, i)) * SL(vec + k);
+  for (int bi = SK_NB; bi >= 0; bi--) {
+    if (!((bm >> bi) & 1u)) continue;
+    for (int i = sk_blk0(bi) + sk_blkn(bi) - 1; i >= sk_blk0(bi); i--) {
+      double s = SL(vec + i);
+      for (int bk = bi; bk <= SK_NB; bk++) {
+        if (!((bm >> bk) & 1u) || !(bk == bi || ((cm[bi] >> bk) & 1u))) continue;
+        const int k0 = sk_blk0(bk) > i + 1 ? sk_blk0(bk) : i + 1, k1 = sk_blk0(bk) + sk_blkn(bk);
+        for (int k = k0; k < k1; k++) s -= SL(ST_H + tri(k, i)) * SL(vec + k);
+      }
+      SL(vec + i) = s / SL(ST_H + tri(i, i));
     }
-    SL(vec + i) = s / SL(ST_H + tri(i, i));
   }
 }
 
 // ------------------------------------------------------------------------------------------------ the Newton solve
-// x (ST_X) in: start point, out: optimum.  ncon contact records in the g area with aref / D / mu filled in; limit rows in ST_LIM.
-D3IL_NOINLINE inline bool sk_solve(const StackConsts& kc_, const StackScratch sc, int ncon) {
+// Primal Newton on ONE island (bm: its blocks) of the constraint system: x (ST_X) in: start point, out: optimum.  The contacts of the
+// island are those whose (non-static) bodies lie in bm; the joint-limit rows belong to the arm block.
+D3IL_NOINLINE inline bool sk_solve_island(const StackConsts& kc_, const StackScratch sc, int ncon, unsigned bm, const unsigned* cm, bool warm) {
   D3IL_STACK_CONSTS(kc_, kc);
-  // block coupling through the contacts, closed under fill (4 blocks)
-  unsigned cm[SK_NB + 1] = {0, 0, 0, 0};
-  for (int ci = 0; ci < ncon; ci++) {
-    const int a = (int)SG(ci * SREC + 13), b = (int)SG(ci * SREC + 14);
-    const int ba = a == SKB_STATIC ? -1 : (a < SK_NB ? a : SK_NB), bb = b == SKB_STATIC ? -1 : (b < SK_NB ? b : SK_NB);
-    if (ba >= 0 && bb >= 0 && ba != bb) { cm[ba] |= 1u << bb; cm[bb] |= 1u << ba; }
-  }
-  for (int k = 0; k <= SK_NB; k++)       // eliminating block k couples every pair of later blocks it touches
-    for (int i = k + 1; i <= SK_NB; i++) if ((cm[k] >> i) & 1u)
-      for (int j = k + 1; j <= SK_NB; j++) if (j != i && ((cm[k] >> j) & 1u)) cm[i] |= 1u << j;
+  const bool arm = ((bm >> SK_NB) & 1u) != 0;
+#define SK_FOR_DOFS(i) for (int b_ = 0; b_ <= SK_NB; b_++) if ((bm >> b_) & 1u) for (int i = sk_blk0(b_); i < sk_blk0(b_) + sk_blkn(b_); i++)
+#define SK_IN_ISLAND(ci) ((bm >> sk_blk_of((int)SG((ci) * SREC + 14))) & 1u)     /* body 2 is never static */
   bool converged = false;
+  if (warm) {      // warm start: a start point that still satisfies the gradient tolerance (a resting box) is accepted after ONE gradient pass
+    SK_FOR_DOFS(i) SL(ST_G + i) = sk_Mv(kc, sc, i, ST_X, ST_A0);
+    if (arm)
+      for (int a = 0; a < NDOF; a++) {
+        const double sg = SL(ST_LIM + 3 * a), D = SL(ST_LIM + 3 * a + 1), ar = SL(ST_LIM + 3 * a + 2);
+        if (sg != 0) { const double jar = sg * SL(ST_X + SK_ARM0 + a) - ar; if (jar < 0) SL(ST_G + SK_ARM0 + a) += sg * D * jar; }
+      }
+    for (int ci = 0; ci < ncon; ci++) if (SK_IN_ISLAND(ci)) sk_contact_dispatch<0>(kc, sc, ci, 0);
+    double gm = 0;
+    SK_FOR_DOFS(i) gm = fmax(gm, fabs(SL(ST_G + i)));
+    if (gm <= D3IL_TOL.grad_tol) return true;
+  }
   for (int it = 0; it < 60 && !converged; it++) {
     // gradient and Hessian at x
-    for (int i = 0; i < SK_NH; i++) SL(ST_H + i) = 0;
-    for (int i = 0; i < SK_NV; i++) SL(ST_G + i) = sk_Mv(kc, sc, i, ST_X, ST_A0);
-    for (int b = 0; b < SK_NB; b++) for (int k = 0; k < 6; k++) SL(ST_H + tri(6 * b + k, 6 * b + k)) = k < 3 ? kc.box_mass[b] : kc.box_inertia[b][k - 3];
-    for (int a = 0; a < NDOF; a++) for (int k = 0; k <= a; k++) SL(ST_H + tri(SK_ARM0 + a, SK_ARM0 + k)) = SL(ST_M + tri(a, k));
-    for (int a = 0; a < NDOF; a++) {     // joint-limit rows
-      const double sg = SL(ST_LIM + 3 * a), D = SL(ST_LIM + 3 * a + 1), ar = SL(ST_LIM + 3 * a + 2);
-      if (sg != 0) {
-        const double jar = sg * SL(ST_X + SK_ARM0 + a) - ar;
-        if (jar < 0) { SL(ST_G + SK_ARM0 + a) += sg * D * jar; SL(ST_H + tri(SK_ARM0 + a, SK_ARM0 + a)) += D; }
-      }
-    }
-    for (int ci = 0; ci < ncon; ci++) {
-      SkCon c; sk_rows(kc, sc, ci, c);
-      const int base = ci * SREC;
-      double jar[4] = {0, 0, 0, 0}, D[4], f[4], Hc[16];
-      for (int r = 0; r < c.dim; r++) jar[r] = sk_row_dot(sc, c, r, ST_X) - SG(base + 16 + r);
-      for (int r = 0; r < 4; r++) { D[r] = SG(base + 20 + r); SG(base + 25 + r) = jar[r]; }
-      double fr[3]; sk_row_fric(kc.set[c.set], fr);
-      sk_cone(c.dim, jar, D, SG(base + 24), fr, f, Hc);
-      // g -= J' f ; H += J' Hc J  (J = [ -A | +B ])
-      for (int side = 0; side < 2; side++) {
-        const SkSide& S = side ? c.B : c.A;
-        const double sg = side ? 1.0 : -1.0;
-        for (int k = 0; k < S.n; k++) {
-          double acc = 0;
-          for (int r = 0; r < c.dim; r++) acc += S.J[r][k] * f[r];
-          SL(ST_G + S.off + k) -= sg * acc;
+    for (int bi = 0; bi <= SK_NB; bi++) if ((bm >> bi) & 1u)
+      for (int i = sk_blk0(bi); i < sk_blk0(bi) + sk_blkn(bi); i++)
+        for (int bj = 0; bj <= bi; bj++) if ((bm >> bj) & 1u) {
+          const int jend = bi == bj ? i + 1 : sk_blk0(bj) + sk_blkn(bj);
+          for (int j = sk_blk0(bj); j < jend; j++) SL(ST_H + tri(i, j)) = 0;
         }
-      }
-      bool any = false;
-      for (int i = 0; i < 16; i++) any = any || Hc[i] != 0;
-      if (!any) continue;
-      for (int s1 = 0; s1 < 2; s1++) {
-        const SkSide& S1 = s1 ? c.B : c.A;
-        for (int s2 = 0; s2 <= s1; s2++) {
-          const SkSide& S2 = s2 ? c.B : c.A;
-          if (S1.n == 0 || S2.n == 0) continue;
-          const double sg = (s1 == s2) ? 1.0 : -1.0;
-          // the block with the larger offset supplies the rows of the packed lower triangle
-          const bool swap = S1.off < S2.off;
-          const SkSide& Rw = swap ? S2 : S1; const SkSide& Cl = swap ? S1 : S2;
-          for (int i = 0; i < Rw.n; i++) {
-            double t[4] = {0, 0, 0, 0};     // (J_rw' Hc)_i over the rows
-            for (int r = 0; r < c.dim; r++) for (int q = 0; q < c.dim; q++) t[q] += Rw.J[r][i] * (swap ? Hc[4 * q + r] : Hc[4 * r + q]);
-            const int kmax = (s1 == s2) ? i + 1 : Cl.n;
-            for (int k = 0; k < kmax; k++) {
-              double acc = 0;
-              for (int q = 0; q < c.dim; q++) acc += t[q] * Cl.J[q][k];
-              SL(ST_H + tri(Rw.off + i, Cl.off + k)) += sg * acc;
-            }
-          }
+    SK_FOR_DOFS(i) SL(ST_G + i) = sk_Mv(kc, sc, i, ST_X, ST_A0);
+    for (int b = 0; b < SK_NB; b++) if ((bm >> b) & 1u) for (int k = 0; k < 6; k++) SL(ST_H + tri(6 * b + k, 6 * b + k)) = k < 3 ? kc.box_mass[b] : kc.box_inertia[b][k - 3];
+    if (arm) {
+      for (int a = 0; a < NDOF; a++) for (int k = 0; k <= a; k++) SL(ST_H + tri(SK_ARM0 + a, SK_ARM0 + k)) = SL(ST_M + tri(a, k));
+      for (int a = 0; a < NDOF; a++) {     // joint-limit rows
+        const double sg = SL(ST_LIM + 3 * a), D = SL(ST_LIM + 3 * a + 1), ar = SL(ST_LIM + 3 * a + 2);
+        if (sg != 0) {
+          const double jar = sg * SL(ST_X + SK_ARM0 + a) - ar;
+          if (jar < 0) { SL(ST_G + SK_ARM0 + a) += sg * D * jar; SL(ST_H + tri(SK_ARM0 + a, SK_ARM0 + a)) += D; }
         }
       }
     }
-    double gm = 0, gn = 0;
-    for (int i = 0; i < SK_NV; i++) { gm = fmax(gm, fabs(SL(ST_G + i))); gn += SL(ST_G + i) * SL(ST_G + i); }
-    SG(SG_DIAG) = (double)it; SG(SG_DIAG + 1) = gm;
+    for (int ci = 0; ci < ncon; ci++) if (SK_IN_ISLAND(ci)) sk_contact_dispatch<0>(kc, sc, ci, 1);
+    double gm = 0;
+    SK_FOR_DOFS(i) gm = fmax(gm, fabs(SL(ST_G + i)));
+    SG(SG_DIAG) += 1; SG(SG_DIAG + 1) = fmax(SG(SG_DIAG + 1), gm);
     if (gm <= D3IL_TOL.grad_tol) { converged = true; break; }
-    if (!sk_chol(sc, cm)) return false;
-    for (int i = 0; i < SK_NV; i++) SL(ST_P + i) = -SL(ST_G + i);
-    sk_chol_solve(sc, cm, ST_P);
+    if (!sk_chol(sc, bm, cm)) return false;
+    SK_FOR_DOFS(i) SL(ST_P + i) = -SL(ST_G + i);
+    sk_chol_solve(sc, bm, cm, ST_P);
     // line search: phi'(alpha) = p' M (x - a0) + alpha p' M p - sum f(jar + alpha Jp) . Jp, safeguarded Newton on alpha
     double pMp = 0, pMa = 0, gTp = 0;
-    for (int i = 0; i < SK_NV; i++) {
-      const double p = SL(ST_P + i);
-      gTp += SL(ST_G + i) * p;
-    }
-    {   // p' M p and p' M (x - a0) with the block-diagonal M
-      for (int i = 0; i < SK_ARM0; i++) { const int b = i / 6, k = i % 6; const double m = k < 3 ? kc.box_mass[b] : kc.box_inertia[b][k - 3], p = SL(ST_P + i); pMp += m * p * p; pMa += m * p * (SL(ST_X + i) - SL(ST_A0 + i)); }
+    SK_FOR_DOFS(i) gTp += SL(ST_G + i) * SL(ST_P + i);
+    for (int b = 0; b < SK_NB; b++) if ((bm >> b) & 1u)
+      for (int k = 0; k < 6; k++) { const int i = 6 * b + k; const double m = k < 3 ? kc.box_mass[b] : kc.box_inertia[b][k - 3], p = SL(ST_P + i); pMp += m * p * p; pMa += m * p * (SL(ST_X + i) - SL(ST_A0 + i)); }
+    if (arm)
       for (int a = 0; a < NDOF; a++) {
         double mp = 0, ma = 0;
         for (int k = 0; k < NDOF; k++) { const double m = SL(ST_M + (a >= k ? tri(a, k) : tri(k, a))); mp += m * SL(ST_P + SK_ARM0 + k); ma += m * (SL(ST_X + SK_ARM0 + k) - SL(ST_A0 + SK_ARM0 + k)); }
         pMp += SL(ST_P + SK_ARM0 + a) * mp; pMa += SL(ST_P + SK_ARM0 + a) * ma;
       }
-    }
-    for (int ci = 0; ci < ncon; ci++) {
-      SkCon c; sk_rows(kc, sc, ci, c);
-      for (int r = 0; r < 4; r++) SG(ci * SREC + 29 + r) = r < c.dim ? sk_row_dot(sc, c, r, ST_P) : 0.0;
-    }
+    for (int ci = 0; ci < ncon; ci++) if (SK_IN_ISLAND(ci)) sk_contact_dispatch<1>(kc, sc, ci, 0);
     double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 50; ls++) {
       double d1 = pMa + alpha * pMp, d2 = pMp;
-      for (int a = 0; a < NDOF; a++) {
-        const double sg = SL(ST_LIM + 3 * a), D = SL(ST_LIM + 3 * a + 1), ar = SL(ST_LIM + 3 * a + 2);
-        if (sg != 0) {
-          const double jp = sg * SL(ST_P + SK_ARM0 + a), jar = sg * SL(ST_X + SK_ARM0 + a) - ar + alpha * jp;
-          if (jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
+      if (arm)
+        for (int a = 0; a < NDOF; a++) {
+          const double sg = SL(ST_LIM + 3 * a), D = SL(ST_LIM + 3 * a + 1), ar = SL(ST_LIM + 3 * a + 2);
+          if (sg != 0) {
+            const double jp = sg * SL(ST_P + SK_ARM0 + a), jar = sg * SL(ST_X + SK_ARM0 + a) - ar + alpha * jp;
+            if (jar < 0) { d1 += D * jar * jp; d2 += D * jp * jp; }
+          }
         }
-      }
-      for (int ci = 0; ci < ncon; ci++) {
+      for (int ci = 0; ci < ncon; ci++) if (SK_IN_ISLAND(ci)) {
         const int base = ci * SREC, set = (int)SG(base + 15), dim = kc.set[set].dim;
-        double jt[4], jp[4], D[4], f[4], Hc[16];
+        double jt[4], jp[4], D[4], f[4], Hc[16], fr[3];
+#pragma unroll
         for (int r = 0; r < 4; r++) { jp[r] = SG(base + 29 + r); jt[r] = SG(base + 25 + r) + alpha * jp[r]; D[r] = SG(base + 20 + r); }
-        double fr[3]; sk_row_fric(kc.set[set], fr);
+        sk_row_fric(kc.set[set], fr);
         sk_cone(dim, jt, D, SG(base + 24), fr, f, Hc);
-        for (int r = 0; r < dim; r++) { d1 -= f[r] * jp[r]; for (int q = 0; q < dim; q++) d2 += jp[r] * Hc[4 * r + q] * jp[q]; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { d1 -= f[r] * jp[r];
+#pragma unroll
+          for (int q = 0; q < 4; q++) d2 += jp[r] * Hc[4 * r + q] * jp[q]; }
       }
       best = alpha;
       if (ls == 0 && d1 <= D3IL_TOL.ls_full * fabs(gTp)) break;
@@ -525,15 +605,42 @@ D3IL_NOINLINE inline bool sk_solve(const StackConsts& kc_, const StackScratch sc
       alpha = na;
     }
     double smax = 0, xmax = 0;
-    for (int i = 0; i < SK_NV; i++) { const double dx = best * SL(ST_P + i); SL(ST_X + i) += dx; smax = fmax(smax, fabs(dx)); xmax = fmax(xmax, fabs(SL(ST_X + i))); }
+    SK_FOR_DOFS(i) { const double dx = best * SL(ST_P + i); SL(ST_X + i) += dx; smax = fmax(smax, fabs(dx)); xmax = fmax(xmax, fabs(SL(ST_X + i))); }
     if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
-    (void)gn;
   }
+#undef SK_FOR_DOFS
+#undef SK_IN_ISLAND
   return converged;
+}
+// All islands of the sub-step: connected components of {box 0, box 1, box 2, arm} under the contacts.  Blocks without any
+// constraint keep x = a0.
+D3IL_HD bool sk_solve(const StackConsts& kc, const StackScratch sc, int ncon, bool any_lim, bool warm) {
+  unsigned adj[SK_NB + 1] = {0, 0, 0, 0}, has = 0;
+  for (int ci = 0; ci < ncon; ci++) {
+    const int ba = sk_blk_of((int)SG(ci * SREC + 13)), bb = sk_blk_of((int)SG(ci * SREC + 14));
+    has |= 1u << bb;
+    if (ba >= 0) { has |= 1u << ba; if (ba != bb) { adj[ba] |= 1u << bb; adj[bb] |= 1u << ba; } }
+  }
+  if (any_lim) has |= 1u << SK_NB;
+  bool ok = true;
+  unsigned done = 0;
+  for (int b0 = 0; b0 <= SK_NB; b0++) {
+    if (!((has >> b0) & 1u) || ((done >> b0) & 1u)) continue;
+    unsigned bm = 1u << b0;
+    for (int rep = 0; rep <= SK_NB; rep++) for (int b = 0; b <= SK_NB; b++) if ((bm >> b) & 1u) bm |= adj[b];
+    done |= bm;
+    unsigned cm[SK_NB + 1];
+    for (int b = 0; b <= SK_NB; b++) cm[b] = adj[b] & bm;
+    for (int k = 0; k <= SK_NB; k++)       // fill closure: eliminating block k couples every pair of later blocks it touches
+      for (int i = k + 1; i <= SK_NB; i++) if ((cm[k] >> i) & 1u)
+        for (int j = k + 1; j <= SK_NB; j++) if (j != i && ((cm[k] >> j) & 1u)) cm[i] |= 1u << j;
+    ok = sk_solve_island(kc, sc, ncon, bm, cm, warm) && ok;
+  }
+  return ok;
 }
 
 // ------------------------------------------------------------------------------------------------ sub-step
-struct StackState { EnvState arm; BoxState box[SK_NB]; };
+struct StackState { EnvState arm; BoxState box[SK_NB]; double warm[SK_NV]; };
 
 D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& ncon, unsigned& flags, const double* rec7, double nsign, int bodyA, int bodyB, int set) {
   if (ncon >= SK_MAXCON) { flags |= SKF_CON_OVERFLOW; return; }
@@ -545,14 +652,13 @@ D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& 
   SG(base + 12) = rec7[0]; SG(base + 13) = (double)bodyA; SG(base + 14) = (double)bodyB; SG(base + 15) = (double)set;
   ncon++;
 }
-D3IL_HD double sk_invw(const StackConsts& kc_, int body) {
-  D3IL_STACK_CONSTS(kc_, kc);
-  if (body == SKB_STATIC) return 0.0;
-  if (body < SK_NB) return 1.0 / kc.box_mass[body];
-  const int f = (body - SKB_FINGER) & 1;
-  return body >= SKB_TIP ? kc.invw_tip[f] : kc.invw_finger[f];
-}
-
+#if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define SK_TIC unsigned long long sk_t0_ = wall_clock64()
+#define SK_TOC(slot) do { unsigned long long t_ = wall_clock64(); SG(SG_DIAG + 4 + (slot)) += (double)(t_ - sk_t0_); sk_t0_ = t_; } while (0)
+#else
+#define SK_TIC ((void)0)
+#define SK_TOC(slot) ((void)0)
+#endif
 // One physics sub-step (mj_step) with the torques of this sub-step's control law.
 template <class C>
 D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
@@ -560,6 +666,7 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
   D3IL_REFRESH(c0, c);
   EnvState& st = ss.arm;
   const double h = c.timestep;
+  SK_TIC;
   // ---- arm forward pass
   DynOut dyn;
   dynamics(c0, st.q, st.v, dyn);
@@ -613,6 +720,7 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
     for (int k = 0; k < 6; k++) SL(ST_VEL + 6 * b + k) = ss.box[b].vel[k];
     if (ss.box[b].pos[0] < kc.ws_lo[0] || ss.box[b].pos[0] > kc.ws_hi[0] || ss.box[b].pos[1] < kc.ws_lo[1] || ss.box[b].pos[1] > kc.ws_hi[1]) st.flags |= SKF_OFF_TABLE;
   }
+  SK_TOC(0);
   // ---- collision, in the model's geom order: static < boxes < left hull < left tip < right hull < right tip
   int ncon = 0;
   double rec[8][7];
@@ -638,6 +746,7 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
       const int n = box_box(ss.box[b1].pos, R1, kc.box_half[b1], ss.box[b2].pos, R2, kc.box_half[b2], kc.set[SKS_BOXBOX].margin, rec, 8);
       for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, b1, b2, SKS_BOXBOX);
     }
+  SK_TOC(1);
   const double r_tip = rcirc(kc.tip_half);
   double r_hull = 0;
   for (int i = 0; i < kc.hull_nv; i++) { double d[3] = {kc.hull_v[i][0] - kc.hull_center[0], kc.hull_v[i][1] - kc.hull_center[1], kc.hull_v[i][2] - kc.hull_center[2]}; r_hull = fmax(r_hull, dot3(d, d)); }
@@ -702,6 +811,7 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
     const int n = box_box(fP[0][1], fR[0][1], kc.tip_half, fP[1][1], fR[1][1], kc.tip_half, kc.set[SKS_TIPTIP].margin, rec, 8);
     for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, SKB_TIP, SKB_TIP + 1, SKS_TIPTIP);
   }
+  SK_TOC(2);
   // ---- joint-limit rows (mj_instantiateLimit) of the 9 arm dofs
   bool any_lim = false;
   for (int k = 0; k < NDOF; k++) {
@@ -718,26 +828,25 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
     SL(ST_LIM + 3 * k) = sign; SL(ST_LIM + 3 * k + 1) = D; SL(ST_LIM + 3 * k + 2) = ar;
   }
   // ---- reference accelerations and regularisation of the contact rows (mj_makeImpedance, elliptic cones)
-  for (int ci = 0; ci < ncon; ci++) {
-    SkCon cn; sk_rows(kc, sc, ci, cn);
-    const int base = ci * SREC;
-    const StackSet& ps = kc.set[cn.set];
-    const double dist = SG(base + 12);
-    const double imp = impedance(ps.solimp, dist - ps.margin);
-    const double R0 = fmax(1e-15, (1 - imp) / imp * (sk_invw(kc, (int)SG(base + 13)) + sk_invw(kc, (int)SG(base + 14))));
-    const double R1 = R0 / fmax(1e-15, kc.impratio);
-    for (int r = 0; r < 4; r++) {
-      const double v = r < cn.dim ? sk_row_dot(sc, cn, r, ST_VEL) : 0.0;
-      SG(base + 16 + r) = r < cn.dim ? -ps.B * v - (r == 0 ? ps.K * imp * (dist - ps.margin) : 0.0) : 0.0;
-    }
-    SG(base + 20) = 1 / R0; SG(base + 21) = 1 / R1; SG(base + 22) = 1 / R1;
-    SG(base + 23) = 1 / (R1 * ps.fric[0] * ps.fric[0] / (ps.fric[1] * ps.fric[1]));
-    SG(base + 24) = ps.fric[0] * sqrt(R1 / R0);
-  }
+  for (int ci = 0; ci < ncon; ci++) sk_contact_dispatch<1>(kc, sc, ci, 1);
+  SK_TOC(3);
   // ---- solve
+  // start point: the previous sub-step's accelerations (MuJoCo's qacc_warmstart), else the smooth accelerations; blocks without any
+  // constraint are not touched by the solver and take the smooth acceleration
+  const bool warm = (st.flags & SKF_WARM_VALID) != 0;
   for (int i = 0; i < SK_NV; i++) SL(ST_X + i) = SL(ST_A0 + i);
   SG(SG_DIAG) = 0; SG(SG_DIAG + 1) = 0; SG(SG_DIAG + 2) = 1; SG(SG_DIAG + 3) = (double)ncon;
-  if (ncon > 0 || any_lim) { const bool ok = sk_solve(kc, sc, ncon); SG(SG_DIAG + 2) = ok ? 1.0 : 0.0; if (!ok) st.flags |= F_SOLVER_FAIL; }
+  if (ncon > 0 || any_lim) {
+    if (warm) {
+      unsigned has = any_lim ? 1u << SK_NB : 0u;
+      for (int ci = 0; ci < ncon; ci++) { const int ba = sk_blk_of((int)SG(ci * SREC + 13)); has |= 1u << sk_blk_of((int)SG(ci * SREC + 14)); if (ba >= 0) has |= 1u << ba; }
+      for (int b = 0; b <= SK_NB; b++) if ((has >> b) & 1u) for (int i = sk_blk0(b); i < sk_blk0(b) + sk_blkn(b); i++) SL(ST_X + i) = ss.warm[i];
+    }
+    const bool ok = sk_solve(kc, sc, ncon, any_lim, warm); SG(SG_DIAG + 2) = ok ? 1.0 : 0.0; if (!ok) st.flags |= F_SOLVER_FAIL;
+  }
+  for (int i = 0; i < SK_NV; i++) ss.warm[i] = SL(ST_X + i);
+  st.flags |= SKF_WARM_VALID;
+  SK_TOC(4);
   // ---- mj_Euler: implicit in the finger-joint damping (M + h B) qacc = M x on the arm block
   {
     double Mh[45], rhs[NDOF], L[45], d[NDOF], id[NDOF];
@@ -753,6 +862,7 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
     for (int k = 0; k < 6; k++) acc[k] = SL(ST_X + 6 * b + k);
     cube_integrate(ss.box[b], acc, h);
   }
+  SK_TOC(5);
 }
 
 // ------------------------------------------------------------------------------------------------ env level (stacking.py)
@@ -823,6 +933,7 @@ D3IL_HD void stack_env_reset(const C& c, const StackConsts& kc_, StackState& ss,
   EnvState& st = ss.arm;
   for (int k = 0; k < NDOF; k++) { st.q[k] = k < NARM ? init_qpos[k] : 0.0; st.v[k] = 0; }
   st.flags = 0; st.step = 0;
+  for (int i = 0; i < SK_NV; i++) ss.warm[i] = 0;
   {   // mj_forward at the beamed pose: qfrc_bias and TCP of that pass are what the first controller call reads
     DynOut dyn;
     dynamics(c, st.q, st.v, dyn);

@@ -169,6 +169,7 @@ static void stack_unpack(const double* s, const int* f, StackState& ss) {
   for (int i = 0; i < NARM; i++) ss.arm.bias[i] = s[k++];
   for (int i = 0; i < 3; i++) ss.arm.tcp[i] = s[k++];
   for (int b = 0; b < SK_NB; b++) { for (int i = 0; i < 3; i++) ss.box[b].pos[i] = s[k++]; for (int i = 0; i < 4; i++) ss.box[b].quat[i] = s[k++]; for (int i = 0; i < 6; i++) ss.box[b].vel[i] = s[k++]; }
+  for (int i = 0; i < SK_NV; i++) ss.warm[i] = s[k++];
   ss.arm.flags = (unsigned)f[0]; ss.arm.step = f[1];
 }
 static void stack_pack(const StackState& ss, double* s, int* f) {
@@ -178,6 +179,7 @@ static void stack_pack(const StackState& ss, double* s, int* f) {
   for (int i = 0; i < NARM; i++) s[k++] = ss.arm.bias[i];
   for (int i = 0; i < 3; i++) s[k++] = ss.arm.tcp[i];
   for (int b = 0; b < SK_NB; b++) { for (int i = 0; i < 3; i++) s[k++] = ss.box[b].pos[i]; for (int i = 0; i < 4; i++) s[k++] = ss.box[b].quat[i]; for (int i = 0; i < 6; i++) s[k++] = ss.box[b].vel[i]; }
+  for (int i = 0; i < SK_NV; i++) s[k++] = ss.warm[i];
   f[0] = (int)ss.arm.flags; f[1] = ss.arm.step;
 }
 void* hc_stack_create(const d3il_model_blob* blob, const char** err) {

@@ -43,13 +43,13 @@ def test_reset_matches_oracle_on_reference_contexts(stack_blob, ctx100):
     assert it == 72
     obs = env.reset(context=ctx100).cpu().numpy()
     st, fl, sc = env.get_state()
-    assert env.obs.shape == (n, 12) and env.state_rows == 67 and env.robot_state().shape == (n, 8)
+    assert env.obs.shape == (n, 12) and env.state_rows == 94 and env.robot_state().shape == (n, 8)
     o = Oracle(stack_blob)
     o.env_start(q0)
     for e in range(0, n, 7):
         oo = o.stack_reset(ctx100[e])
         np.testing.assert_array_equal(obs[e], oo)
-        np.testing.assert_allclose(st[:, e], o.stack_state(), atol=1e-10, rtol=0)
+        np.testing.assert_allclose(st[:67, e], o.stack_state(), atol=1e-10, rtol=0)
         np.testing.assert_allclose(env.robot_state()[e].cpu().numpy(), o.stack_robot_state(), atol=1e-10)
         assert sc[e] == 0 and not (fl[e] & BAD)
     env.close()
@@ -81,7 +81,7 @@ def test_pick_and_place_followed_by_the_oracle(stack_js, stack_blob, ctx100):
         for k in range(4):
             oo, do, io = oracles[k].stack_step(trajs[k][t])
             e = k + 4 * (t % 12)                      # a different lane of the same context every step: results do not depend on the lane
-            err = float(np.abs(st[:, e] - oracles[k].stack_state()).max())
+            err = float(np.abs(st[:67, e] - oracles[k].stack_state()).max())
             worst = max(worst, err)
             assert err < 1e-5, (t, k, err)
             assert bool(done[e]) == do and bool(info["success"][e]) == io["success"]
@@ -91,9 +91,9 @@ def test_pick_and_place_followed_by_the_oracle(stack_js, stack_blob, ctx100):
     assert lifted > 0.08 and worst < 1e-5, (lifted, worst)
     # lanes with the same context are bit-identical
     for k in range(4):
-        ref = st[:, k]
+        ref = st[:67, k]
         for e in range(k + 4, n, 4):
-            assert np.array_equal(st[:, e], ref)
+            assert np.array_equal(st[:67, e], ref)
     env.close()
 
 
@@ -125,7 +125,7 @@ def test_one_step_parity_from_mid_episode_states(stack_js, stack_blob, ctx100, s
             st1, fl1, sc1 = env.get_state()
             for k in (t // 6 % n, (t // 6 + 3) % n):
                 nm = int(fl0[k] & 3)
-                o.stack_set_state(st0[:, k], step=int(sc0[k]), terminated=bool(fl0[k] & (1 << 12)), min_inds=[int((fl0[k] >> (2 + 2 * i)) & 3) for i in range(nm)])
+                o.stack_set_state(st0[:67, k], step=int(sc0[k]), terminated=bool(fl0[k] & (1 << 12)), min_inds=[int((fl0[k] >> (2 + 2 * i)) & 3) for i in range(nm)])
                 o.stack_step(trajs[k][t])
                 so = o.stack_state()
                 worst_p = max(worst_p, float(np.abs(st1[pos, k] - so[pos]).max())); worst_v = max(worst_v, float(np.abs(st1[vel, k] - so[vel]).max()))
