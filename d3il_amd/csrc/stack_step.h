@@ -27,7 +27,10 @@ namespace d3il {
 
 constexpr int SK_NB = 3, SK_NV = 6 * SK_NB + NDOF, SK_ARM0 = 6 * SK_NB, SK_NH = SK_NV * (SK_NV + 1) / 2;   // 27 dofs, 378 packed
 constexpr int SK_MAXCON = 48, SK_MAXNS = 4, SK_MAXHV = 96;
-constexpr int SK_LANES = 24;            // environments per workgroup (one per lane; LDS bound)
+#ifndef D3IL_SK_LANES
+#define D3IL_SK_LANES 24
+#endif
+constexpr int SK_LANES = D3IL_SK_LANES;   // environments per workgroup (one per lane; LDS: 5.6 KiB per environment)
 // contact parameter sets
 enum { SKS_STATIC = 0 /* + static index */, SKS_BOXBOX = SK_MAXNS, SKS_BOXHULL, SKS_BOXTIP, SKS_HULLHULL, SKS_HULLTIP, SKS_TIPTIP, SKS_N };
 // bodies of a contact: boxes 0..2, then
@@ -99,8 +102,15 @@ constexpr int ST_SIZE = ST_LIM + 27;            // 717
 // g area: contact records
 constexpr int SREC = 36;    // pos[3] frame[9] dist bodyA bodyB set | aref[4] D[4] mu | jar[4] jp[4] | pad
 constexpr int SG_DIAG = SK_MAXCON * SREC;   // diagnostics of the last sub-step: Newton iterations, final max |gradient|, converged, contacts
-constexpr int SG_SIZE = SG_DIAG + 12;      // [4 .. 11]: clock ticks per phase, accumulated (diagnostics build -DD3IL_DEVICE_STATS only)
+constexpr int SG_SIZE = SG_DIAG + 20;      // [4 .. 11]: clock ticks per phase, accumulated (diagnostics build -DD3IL_DEVICE_STATS only)
 
+#if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define SK_TIC unsigned long long sk_t0_ = wall_clock64()
+#define SK_TOC(slot) do { unsigned long long t_ = wall_clock64(); SG(SG_DIAG + 4 + (slot)) += (double)(t_ - sk_t0_); sk_t0_ = t_; } while (0)
+#else
+#define SK_TIC ((void)0)
+#define SK_TOC(slot) ((void)0)
+#endif
 // ------------------------------------------------------------------------------------------------ convex pairs: MPR
 // Same algorithm as the oracle's mpr_penetration (libccd's ccdMPRPenetration as MuJoCo 2.3.2 runs it for mesh geoms [ext]); the
 // tie rule of the support functions (lowest index within 1e-10, box components >= -1e-10 positive) makes the portal independent
@@ -515,6 +525,7 @@ D3IL_NOINLINE inline bool sk_solve_island(const StackConsts& kc_, const StackScr
 #define SK_FOR_DOFS(i) for (int b_ = 0; b_ <= SK_NB; b_++) if ((bm >> b_) & 1u) for (int i = sk_blk0(b_); i < sk_blk0(b_) + sk_blkn(b_); i++)
 #define SK_IN_ISLAND(ci) ((bm >> sk_blk_of((int)SG((ci) * SREC + 14))) & 1u)     /* body 2 is never static */
   bool converged = false;
+  SK_TIC;
   if (warm) {      // warm start: a start point that still satisfies the gradient tolerance (a resting box) is accepted after ONE gradient pass
     SK_FOR_DOFS(i) SL(ST_G + i) = sk_Mv(kc, sc, i, ST_X, ST_A0);
     if (arm)
@@ -525,6 +536,7 @@ D3IL_NOINLINE inline bool sk_solve_island(const StackConsts& kc_, const StackScr
     for (int ci = 0; ci < ncon; ci++) if (SK_IN_ISLAND(ci)) sk_contact_dispatch<0>(kc, sc, ci, 0);
     double gm = 0;
     SK_FOR_DOFS(i) gm = fmax(gm, fabs(SL(ST_G + i)));
+    SK_TOC(6);
     if (gm <= D3IL_TOL.grad_tol) return true;
   }
   for (int it = 0; it < 60 && !converged; it++) {
@@ -547,14 +559,18 @@ D3IL_NOINLINE inline bool sk_solve_island(const StackConsts& kc_, const StackScr
         }
       }
     }
+    SK_TOC(7);
     for (int ci = 0; ci < ncon; ci++) if (SK_IN_ISLAND(ci)) sk_contact_dispatch<0>(kc, sc, ci, 1);
+    SK_TOC(8);
     double gm = 0;
     SK_FOR_DOFS(i) gm = fmax(gm, fabs(SL(ST_G + i)));
     SG(SG_DIAG) += 1; SG(SG_DIAG + 1) = fmax(SG(SG_DIAG + 1), gm);
     if (gm <= D3IL_TOL.grad_tol) { converged = true; break; }
     if (!sk_chol(sc, bm, cm)) return false;
+    SK_TOC(9);
     SK_FOR_DOFS(i) SL(ST_P + i) = -SL(ST_G + i);
     sk_chol_solve(sc, bm, cm, ST_P);
+    SK_TOC(10);
     // line search: phi'(alpha) = p' M (x - a0) + alpha p' M p - sum f(jar + alpha Jp) . Jp, safeguarded Newton on alpha
     double pMp = 0, pMa = 0, gTp = 0;
     SK_FOR_DOFS(i) gTp += SL(ST_G + i) * SL(ST_P + i);
@@ -567,6 +583,7 @@ D3IL_NOINLINE inline bool sk_solve_island(const StackConsts& kc_, const StackScr
         pMp += SL(ST_P + SK_ARM0 + a) * mp; pMa += SL(ST_P + SK_ARM0 + a) * ma;
       }
     for (int ci = 0; ci < ncon; ci++) if (SK_IN_ISLAND(ci)) sk_contact_dispatch<1>(kc, sc, ci, 0);
+    SK_TOC(11);
     double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
     for (int ls = 0; ls < 50; ls++) {
       double d1 = pMa + alpha * pMp, d2 = pMp;
@@ -604,6 +621,7 @@ D3IL_NOINLINE inline bool sk_solve_island(const StackConsts& kc_, const StackScr
       if (na == alpha) break;
       alpha = na;
     }
+    SK_TOC(12);
     double smax = 0, xmax = 0;
     SK_FOR_DOFS(i) { const double dx = best * SL(ST_P + i); SL(ST_X + i) += dx; smax = fmax(smax, fabs(dx)); xmax = fmax(xmax, fabs(SL(ST_X + i))); }
     if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
@@ -652,13 +670,6 @@ D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& 
   SG(base + 12) = rec7[0]; SG(base + 13) = (double)bodyA; SG(base + 14) = (double)bodyB; SG(base + 15) = (double)set;
   ncon++;
 }
-#if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
-#define SK_TIC unsigned long long sk_t0_ = wall_clock64()
-#define SK_TOC(slot) do { unsigned long long t_ = wall_clock64(); SG(SG_DIAG + 4 + (slot)) += (double)(t_ - sk_t0_); sk_t0_ = t_; } while (0)
-#else
-#define SK_TIC ((void)0)
-#define SK_TOC(slot) ((void)0)
-#endif
 // One physics sub-step (mj_step) with the torques of this sub-step's control law.
 template <class C>
 D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
