@@ -199,6 +199,40 @@ def _pmc(task, n):
     return None, None
 
 
+POLICY_TEXT = {
+    "random": "random policy",
+    "mlp": "ResidualMLP %d->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)",
+    "ddpm": "DDPM policy of BASELINE config 4 (DiffusionMLP %d->256x8->2, t_dim 8, 4 denoising steps, fixed random weights, torch f32)",
+    "beso": "BESO policy of BASELINE config 5 (DiffusionGPT 6 layers x 6 heads x 120, window 5, 16 Euler-ancestral steps, fixed random weights, torch f32)",
+    "scripted_push": "scripted pushing policy (every rod drives a cube to its target / bin: the contact regime)",
+    "scripted_stack": "scripted pick-and-place policy (joint-space table from host IK: grasp, carry, stack - the contact regime of the task)",
+}
+
+
+def _random_ddpm(obs_dim, dev):
+    """BASELINE config 4's policy: the reference's DDPM agent as scripts/sorting_4/ddpm_benchmark.sh configures it (DiffusionMLP obs
+    16 -> act 2, hidden 256 x 8 layers, t_dim 8, n_timesteps 4, window 1) with fixed random weights (torch seed 0; no checkpoints
+    offline), scaled actions clamped to +-1 = +-0.01 m (the env's action box, pushing.py:203-205)."""
+    import torch
+    from d3il_amd.policies import DDPMPolicy, DiffusionMLP, Scaler
+    torch.manual_seed(0)
+    net = DiffusionMLP(action_dim=2, obs_dim=obs_dim, t_dim=8, hidden_dim=256, num_hidden_layers=8).to(dev)
+    sc = Scaler([0.0] * obs_dim, [1.0] * obs_dim, [0.0, 0.0], [0.01, 0.01], y_bounds=[[-1.0, -1.0], [1.0, 1.0]], device=dev)
+    return DDPMPolicy(net, sc, n_timesteps=4, window_size=1)
+
+
+def _random_beso(dev):
+    """BASELINE config 5's policy: the reference's BESO agent as scripts/stacking/beso_benchmark.sh configures it (DiffusionGPT state 20,
+    action 8, n_embd 120, 6 layers, 6 heads, window 5; 16 Euler-ancestral steps, sigma 0.01 .. 1) with fixed random weights (torch
+    seed 0).  Action scaling: joint deltas +-0.01 rad, gripper command 0.04 +- 0.04 (open iff > 0.075, stacking.py:337-346)."""
+    import torch
+    from d3il_amd.policies import BESOPolicy, DiffusionGPT, Scaler
+    torch.manual_seed(0)
+    net = DiffusionGPT(state_dim=20, action_dim=8, embed_dim=120, n_layers=6, n_heads=6, obs_seq_len=5).to(dev)
+    sc = Scaler([0.0] * 20, [1.0] * 20, [0.0] * 7 + [0.04], [0.01] * 7 + [0.04], y_bounds=[[-1.0] * 8, [1.0] * 8], device=dev)
+    return BESOPolicy(net, sc, window_size=5, num_sampling_steps=16, sigma_min=0.01, sigma_max=1.0)
+
+
 # ---------------------------------------------------------------------------------------------------- the benchmark
 def run(args):
     import numpy as np
@@ -225,7 +259,7 @@ def run(args):
         ctx60 = load_test_contexts()
     elif task == "sorting":
         from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
-        env = SortingVecEnv(n, device=dev)
+        env = SortingVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 700)     # configs/sorting_4_config.yaml:80
         ctx60 = sample_contexts(60, 4, seed=0)     # the reference's 4_test_contexts.pkl is not part of its tree
     else:
         from d3il_amd.envs.stacking import CubeStackingVecEnv, load_test_contexts as load_stack_contexts
@@ -263,6 +297,8 @@ def run(args):
             pol = ScriptedStackPolicy(tables, ctx_id.to(torch.int64), device=dev)
         elif policy == "mlp":
             pol = RandomResidualMLPPolicy(input_dim=20, output_dim=8, device=dev, bound=0.01)
+        elif policy == "beso":
+            pol = _random_beso(dev)
         else:
             raise SystemExit("--policy %s is not available for task %s" % (policy, task))
         last_cmd = env.robot_state().to(torch.float32).clone()                      # stacking_sim.py:90-91
@@ -272,6 +308,8 @@ def run(args):
             pol = RandomResidualMLPPolicy(input_dim=2 + env.obs.shape[1], device=dev)
         elif policy == "scripted_push":
             pol = ScriptedPushPolicy(task, device=dev)
+        elif policy == "ddpm":
+            pol = _random_ddpm(2 + env.obs.shape[1], dev)
         else:
             raise SystemExit("--policy %s is not available for task %s" % (policy, task))
         actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
@@ -376,15 +414,12 @@ def run(args):
             "avoiding": "Avoiding task, %d envs per GPU, random policy (Philox seed 42), state obs, 35 fused physics sub-steps per env step, "
                         "250-step episodes with auto-reset" % n,
             "pushing": "Pushing task, %d envs per GPU, the 60 reference test contexts tiled, %s, 35 fused physics sub-steps per env step, "
-                       "400-step episodes with auto-reset" % (n, "ResidualMLP 10->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)"
-                                                              if policy == "mlp" else "scripted pushing policy (every rod drives its cube to the target: contact regime)"),
+                       "400-step episodes with auto-reset" % (n, POLICY_TEXT[policy] % 10 if policy in ("mlp", "ddpm") else POLICY_TEXT[policy]),
             "sorting": "Sorting-4 task, %d envs per GPU, 60 contexts sampled like BlockContextManager.sample tiled, %s, 35 fused physics sub-steps per "
-                       "env step, 500-step episodes with auto-reset" % (n, "ResidualMLP 16->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)"
-                                                                        if policy == "mlp" else "scripted pushing policy (every rod pushes a cube towards its bin: contact regime)"),
+                       "env step, %d-step episodes with auto-reset" % (n, POLICY_TEXT[policy] % 16 if policy in ("mlp", "ddpm") else POLICY_TEXT[policy], max_steps),
             "stacking": "Stacking task, %d envs per GPU, the first %d of the reference's 100 test contexts tiled, %s, 30 fused physics sub-steps per env step, "
                         "1000-step episodes with auto-reset" % (n, len(ctx60) if ctx60 is not None else 0,
-                                                                "scripted pick-and-place policy (joint-space table from host IK: grasp, carry, stack - the contact regime of the task)"
-                                                                if policy == "scripted_stack" else "ResidualMLP 20->128x6->8 (Mish) stand-in policy with fixed random weights (torch, f32)"),
+                                                                POLICY_TEXT[policy] if policy != "mlp" else "ResidualMLP 20->128x6->8 (Mish) stand-in policy with fixed random weights (torch, f32)"),
         }[task]
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -421,8 +456,9 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--policy", default=None, choices=["random", "mlp", "scripted_push", "scripted_stack"],
+    ap.add_argument("--policy", default=None, choices=["random", "mlp", "scripted_push", "scripted_stack", "ddpm", "beso"],
                     help="default: random (Avoiding), mlp (Pushing / Sorting), scripted_stack (Stacking: pick-and-place, the contact regime of the task)")
+    ap.add_argument("--max-steps", type=int, default=None, help="Sorting: episode cap (default 700 = configs/sorting_4_config.yaml:80; the Sim class default is 500)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stack-contexts", type=int, default=16, help="Stacking: number of reference test contexts in the tile (host IK of the scripted policy: ~1.3 s each)")
     ap.add_argument("--no-auto-reset", action="store_true")

@@ -29,7 +29,10 @@ namespace d3il {
 constexpr int GEN_MAXNB = 4, GEN_MAXNS = 12, GEN_SEG = 24, GEN_MAXCON = GEN_MAXNB * GEN_SEG, GEN_MAXSET = GEN_MAXNS + 2;
 constexpr int GEN_MAXNV = 6 * GEN_MAXNB + NDOF;     // 33
 constexpr int GEN_NH = GEN_MAXNV * (GEN_MAXNV + 1) / 2;   // 561
-constexpr int GEN_LANES = 16;           // environments per workgroup (x GEN_MAXNB lanes each = one wavefront)
+#ifndef D3IL_GEN_LANES
+#define D3IL_GEN_LANES 16
+#endif
+constexpr int GEN_LANES = D3IL_GEN_LANES;     // environments per workgroup (x GEN_MAXNB lanes each = one wavefront); a power of two
 
 struct GenConsts {
   int nb, ns, set_bb, set_rod;

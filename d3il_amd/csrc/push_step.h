@@ -106,7 +106,10 @@ struct PushState {
 // per-lane views of the scratch areas: h = coupled-solver table (LDS on the device), g = memory-resident solver (HBM), w =
 // warm start.  On the device the pointers carry their address space so that accesses compile to ds_* / global_*
 // instructions instead of flat ones, and the LDS lane stride is a compile-time constant.
-constexpr int PUSH_LANES = 24;          // environments per workgroup (push_kernels.h)
+#ifndef D3IL_PUSH_LANES
+#define D3IL_PUSH_LANES 24
+#endif
+constexpr int PUSH_LANES = D3IL_PUSH_LANES;   // environments per workgroup (push_kernels.h)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) double push_lds_double;
 typedef __attribute__((address_space(1))) double push_glb_double;
