@@ -529,7 +529,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     HIPCHK_H(hipMalloc(&b.info_f64, S * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * sizeof(double)));
     HIPCHK_H(hipMalloc(&h->d_scratch, S * SG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * SG_SIZE * sizeof(double)));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_step, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
-    HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_reset, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_reset, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS_RESET));
   }
   h->task_id = task_id;
   HIPCHK_H(hipEventCreate(&h->ev0)); HIPCHK_H(hipEventCreate(&h->ev1));
@@ -592,7 +592,7 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   }
   if (h->task_id == D3IL_TASK_STACKING) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Stacking task needs contexts (device f64 [n_envs][21])");
-    hipLaunchKernelGGL(k_stacking_reset, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
+    hipLaunchKernelGGL(k_stacking_reset, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS_RESET, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
                        b.flags, b.step_count, b.obs, b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride);
     HIPCHK(hipGetLastError());
     return D3IL_OK;
@@ -801,6 +801,11 @@ int d3il_debug_scratch(d3il_handle h, int env, double* out, int count) {
   if (!h->d_scratch || env < 0 || env >= h->n) return fail(D3IL_EINVAL, "d3il_debug_scratch: no scratch area / env out of range");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
+  if (h->task_id == D3IL_TASK_STACKING) {     // contiguous per environment
+    if (count > SG_SIZE) return fail(D3IL_EINVAL, "d3il_debug_scratch: count exceeds the environment's scratch area");
+    HIPCHK(hipMemcpy(out, h->d_scratch + (size_t)env * SG_SIZE, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return D3IL_OK;
+  }
   HIPCHK(hipMemcpy2D(out, sizeof(double), h->d_scratch + env, (size_t)h->stride * sizeof(double), sizeof(double), (size_t)count, hipMemcpyDeviceToHost));
   return D3IL_OK;
 }

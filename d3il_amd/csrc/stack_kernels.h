@@ -1,16 +1,21 @@
 // stack_kernels.h - HIP kernels of the Stacking task (included by rollout.hip).
 //
-// First, correctness-first shape: ONE LANE PER ENVIRONMENT, SK_LANES = 24 environments per workgroup (one wave, the other lanes
-// idle): a lane's vectors, kinematic tables and the packed 27 x 27 Newton Hessian live in LDS (717 doubles per environment,
-// lane-strided => conflict-free, 134.4 KiB per workgroup = one workgroup per CU), contact records in an HBM scratch area
-// (36 doubles x 48 per environment, lane-strided => coalesced).  The arm is the gripper robot of panda_invisible.xml, its
+// A workgroup is ONE wave that owns SK_LANES environments (4: 1024 workgroups for 4096 environments, one per SIMD).  The per-lane
+// parts of a sub-step (arm dynamics, collision, limit rows, integration: one lane per environment, the other lanes idle) alternate
+// with the wave-cooperative constraint solve (sk_solve_coop: all 64 lanes on one environment, the workgroup's environments one after
+// the other, so an environment iterates exactly as long as IT needs and the lanes of a wave never wait for each other's Newton
+// iterations).  LDS: 717 doubles per environment (vectors, kinematic tables, packed 27 x 27 Hessian; contiguous per environment) + the
+// wave's contact-row area (60 x 32 doubles) = 38.3 KiB per workgroup, four workgroups per CU; contact records in an HBM scratch
+// area (36 doubles x 32 per environment, contiguous per environment).  The arm is the gripper robot of panda_invisible.xml, its
 // constants baked at build time (csrc/gen/stacking_consts.inc).  No controller wave: the task's control law is a joint PD.
+// The reset kernel runs the one-lane solver (sk_solve) - it is the host build's code path and off the hot path.
 #pragma once
 #include "stack_step.h"
 
 namespace d3il {
 
-constexpr int STACK_LDS = ST_SIZE * SK_LANES * 8;
+constexpr int STACK_LDS_RESET = ST_SIZE * SK_LANES * 8;
+constexpr int STACK_LDS = (ST_SIZE * SK_LANES + SKC_JSIZE) * 8;
 
 __device__ __forceinline__ void stack_load(const double* __restrict__ state, const unsigned* __restrict__ flags, const int* __restrict__ steps, int stride, int e, StackState& ss) {
   const double* s = state + e;
@@ -53,21 +58,52 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
   extern __shared__ double smem[];
   const int lane = threadIdx.x;
   const int e = blockIdx.x * SK_LANES + lane;
-  if (lane >= SK_LANES || e >= n) return;
-  StackScratch sc{(sk_lds_double*)(smem + lane), (sk_glb_double*)(scratch + e), stride};
+  const bool live = lane < SK_LANES && e < n;
+  const int le = live ? lane : 0;
+  const size_t ee = live ? e : 0;
+  const StackScratch sc{(sk_lds_double*)(smem + le * ST_SIZE), (sk_glb_double*)(scratch + ee * SG_SIZE)};
+  sk_lds_double* Jw = (sk_lds_double*)(smem + SK_LANES * ST_SIZE);
   StackState ss;
-  stack_load(state, flags, steps, stride, e, ss);
   double act[SK_ACT];
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < SK_ACT; k++) { act[k] = actions[(size_t)e * SK_ACT + k]; unsigned long long b; __builtin_memcpy(&b, &act[k], 8); bad = bad || ((b >> 52) & 0x7ffull) == 0x7ffull; }
-  if (bad) {    // NaN / Inf action: hold the current joints with an open gripper; the lane is flagged and terminated
-#pragma unroll
-    for (int k = 0; k < NARM; k++) act[k] = ss.arm.q[k];
-    act[7] = 1.0;
-  }
+  bool bad = false, open = true;
   float o[SK_OBS]; unsigned char dn = 0; double md = 0;
-  stack_env_step(kStackingConsts, g_stack_consts, ss, sc, act, o, &dn, &md, n_substeps, max_steps);
+  if (live) {
+    stack_load(state, flags, steps, stride, e, ss);
+#pragma unroll
+    for (int k = 0; k < SK_ACT; k++) { act[k] = actions[(size_t)e * SK_ACT + k]; unsigned long long b; __builtin_memcpy(&b, &act[k], 8); bad = bad || ((b >> 52) & 0x7ffull) == 0x7ffull; }
+    if (bad) {    // NaN / Inf action: hold the current joints with an open gripper; the lane is flagged and terminated
+#pragma unroll
+      for (int k = 0; k < NARM; k++) act[k] = ss.arm.q[k];
+      act[7] = 1.0;
+    }
+    for (int i = 0; i < SK_NV; i++) SL(ST_X + i) = ss.warm[i];     // the warm start lives in the t area between the sub-steps
+    open = stack_env_begin(g_stack_consts, ss, act, o, &dn, max_steps);
+  }
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < n_substeps; s++) {
+    int ncon = 0; bool any_lim = false;
+    if (live) {
+      double tau[NARM], ff[NFING];
+      stack_control(kStackingConsts, ss.arm, act, open ? 0.04 : 0.0, !open, tau, ff);
+      stack_substep_pre<true>(kStackingConsts, g_stack_consts, ss, sc, tau, ff, ncon, any_lim);
+    }
+    const int need = (live && (ncon > 0 || any_lim)) ? 1 : 0;
+    const int warm = (live && (ss.arm.flags & SKF_WARM_VALID)) ? 1 : 0;
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int e2 = 0; e2 < SK_LANES; e2++) {
+      if (!__builtin_amdgcn_readlane(need, e2)) continue;
+      const bool ok = sk_solve_coop(g_stack_consts, (sk_lds_double*)(smem + e2 * ST_SIZE), Jw,
+                                    (sk_glb_double*)(scratch + ((size_t)blockIdx.x * SK_LANES + e2) * SG_SIZE), lane,
+                                    __builtin_amdgcn_readlane(ncon, e2), __builtin_amdgcn_readlane(warm, e2) != 0);
+      if (!ok && lane == e2) ss.arm.flags |= F_SOLVER_FAIL;
+    }
+    __syncthreads();
+    if (live) stack_substep_post<true>(kStackingConsts, g_stack_consts, ss, sc);
+  }
+  if (!live) return;
+  for (int i = 0; i < SK_NV; i++) ss.warm[i] = SL(ST_X + i);
+  stack_env_end(g_stack_consts, ss, &md);
   if (bad) ss.arm.flags |= F_SOLVER_FAIL | F_TERMINATED;
   stack_store(state, flags, steps, stride, e, ss);
 #pragma unroll
@@ -86,7 +122,7 @@ __global__ __launch_bounds__(WAVE) void k_stacking_reset(const double* __restric
   const int e = blockIdx.x * SK_LANES + lane;
   if (lane >= SK_LANES || e >= n) return;
   if (mask && !mask[e]) return;
-  StackScratch sc{(sk_lds_double*)(smem + lane), (sk_glb_double*)(scratch + e), stride};
+  const StackScratch sc{(sk_lds_double*)(smem + lane * ST_SIZE), (sk_glb_double*)(scratch + (size_t)e * SG_SIZE)};
   StackState ss;
   double iq[NARM], ctx[21];
 #pragma unroll

@@ -26,9 +26,9 @@
 namespace d3il {
 
 constexpr int SK_NB = 3, SK_NV = 6 * SK_NB + NDOF, SK_ARM0 = 6 * SK_NB, SK_NH = SK_NV * (SK_NV + 1) / 2;   // 27 dofs, 378 packed
-constexpr int SK_MAXCON = 48, SK_MAXNS = 4, SK_MAXHV = 96;
+constexpr int SK_MAXCON = 32, SK_MAXNS = 4, SK_MAXHV = 96;
 #ifndef D3IL_SK_LANES
-#define D3IL_SK_LANES 24
+#define D3IL_SK_LANES 4
 #endif
 constexpr int SK_LANES = D3IL_SK_LANES;   // environments per workgroup (one per lane; LDS: 5.6 KiB per environment)
 // contact parameter sets
@@ -79,15 +79,15 @@ __constant__ StackConsts g_stack_consts;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) double sk_lds_double;
 typedef __attribute__((address_space(1))) double sk_glb_double;
-#define SK_TS SK_LANES
 #else
 typedef double sk_lds_double;
 typedef double sk_glb_double;
-#define SK_TS 1
 #endif
-struct StackScratch { sk_lds_double* t; sk_glb_double* g; int gs; };
-#define SL(i) sc.t[(i) * SK_TS]
-#define SG(i) sc.g[(long)(i) * sc.gs]
+// both areas are contiguous per environment (t: ST_SIZE doubles, odd => the lanes of a wave hit different LDS banks; g: SG_SIZE doubles),
+// so that the wave-cooperative solver (sk_solve_coop) can address one environment's data from all lanes
+struct StackScratch { sk_lds_double* t; sk_glb_double* g; };
+#define SL(i) sc.t[(i)]
+#define SG(i) sc.g[(i)]
 // t area
 constexpr int ST_H = 0, ST_X = SK_NH, ST_A0 = ST_X + SK_NV, ST_G = ST_A0 + SK_NV, ST_P = ST_G + SK_NV, ST_VEL = ST_P + SK_NV;
 constexpr int ST_M = ST_VEL + SK_NV;            // arm mass matrix, packed lower 45
@@ -657,6 +657,293 @@ D3IL_HD bool sk_solve(const StackConsts& kc, const StackScratch sc, int ncon, bo
   return ok;
 }
 
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------------ wave-cooperative Newton solve
+// The same problem as sk_solve, solved for ONE environment by the 64 lanes of its wave (the kernel runs it for the environments of the
+// workgroup one after the other):
+//   * lane c < ncon owns contact c: its rows are built once per solve into the wave's J area ([4 x 15][SK_MAXCON] doubles, body 1's six
+//     columns negated | body 2's nine), reference accelerations / regularisation / residuals stay in the lane's registers; the passes
+//     over the contacts (gradient + Hessian, J p, every trial of the line search) run on all contacts at once, sums through LDS atomics
+//     or wave reductions;
+//   * lane i < 27 owns dof i: its gradient entry, its row of the Hessian and of the Cholesky factor (registers, columns broadcast with
+//     v_readlane, all loops unrolled over the 27 x 27 lower triangle), its entry of the search direction;
+//   * no islands: the block-diagonal system is factorised as a whole (MuJoCo 2.3.2 solves it as a whole too); blocks without
+//     constraints start at their smooth acceleration with zero gradient and do not move.
+// Same stopping rule, line search and tolerances as sk_solve_island.
+__device__ __forceinline__ double sk_bcast(double v, int src /* wave-uniform */) {
+  unsigned long long u; __builtin_memcpy(&u, &v, 8);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+  const unsigned long long r = ((unsigned long long)hi << 32) | lo; double out; __builtin_memcpy(&out, &r, 8); return out;
+}
+__device__ __forceinline__ double sk_wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ double sk_wave_max(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+  return v;
+}
+constexpr int SKC_NJ = 15;                       // columns of a contact row in the J area
+constexpr int SKC_JSIZE = 4 * SKC_NJ * SK_MAXCON;   // doubles per wave
+#define SKJ(r, k) Jw[((r) * SKC_NJ + (k)) * SK_MAXCON + lane]
+struct SkCoopCon { int oa, ob, nb, dim; double aref[4], D[4], mu, fr[3]; };
+template <int NA, int NB>
+__device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, const StackScratch sc, sk_lds_double* Jw, int lane, SkCoopCon& cc) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  SkRows<NA, NB> R; int set;
+  sk_build_rows(kc, sc, lane, R, &set);
+  const StackSet& ps = kc.set[set];
+  cc.oa = R.oa; cc.ob = R.ob; cc.nb = NB; cc.dim = R.dim;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const bool live = r < R.dim;
+#pragma unroll
+    for (int k = 0; k < 6; k++) SKJ(r, k) = (NA > 0 && live) ? -R.A[r][NA ? k : 0] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) SKJ(r, 6 + k) = (k < NB && live) ? R.B[r][k < NB ? k : 0] : 0.0;
+  }
+  // mj_makeImpedance for an elliptic contact [ext] (sk_contact_dot, mode 1)
+  const int base = lane * SREC;
+  const double dist = SG(base + 12);
+  const double imp = impedance(ps.solimp, dist - ps.margin);
+  const int a = (int)SG(base + 13), b = (int)SG(base + 14);
+  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])); };
+  const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
+  const double R1 = R0 / fmax(1e-15, kc.impratio);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const double v = r < R.dim ? sk_dot(sc, R, r, ST_VEL) : 0.0;
+    cc.aref[r] = r < R.dim ? -ps.B * v - (r == 0 ? ps.K * imp * (dist - ps.margin) : 0.0) : 0.0;
+  }
+  cc.D[0] = 1 / R0; cc.D[1] = 1 / R1; cc.D[2] = 1 / R1; cc.D[3] = 1 / (R1 * ps.fric[0] * ps.fric[0] / (ps.fric[1] * ps.fric[1]));
+  cc.mu = ps.fric[0] * sqrt(R1 / R0);
+  sk_row_fric(ps, cc.fr);
+}
+
+// t / g: areas of the environment being solved (wave-uniform), Jw: the wave's J area.  Returns false when the factorisation met a
+// non-positive pivot or the iteration cap was reached (wave-uniform).
+__device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_double* t, sk_lds_double* Jw, sk_glb_double* g, const int lane, const int ncon, const bool warm) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const StackScratch sc{t, g};
+  const bool con = lane < ncon;
+  const int i = lane;                       // dof owned by this lane
+  const bool row = lane < SK_NV, armrow = row && lane >= SK_ARM0;
+  const int ia = armrow ? lane - SK_ARM0 : 0;
+  SK_TIC;
+  // ---- contacts: rows, reference accelerations, regularisation
+  SkCoopCon cc;
+  cc.oa = 0; cc.ob = 0; cc.nb = 6; cc.dim = 3; cc.mu = 1;
+#pragma unroll
+  for (int r = 0; r < 4; r++) { cc.aref[r] = 0; cc.D[r] = 1; }
+  cc.fr[0] = cc.fr[1] = cc.fr[2] = 1;
+  if (con) {
+    const int kind = sk_kind((int)SG(lane * SREC + 13), (int)SG(lane * SREC + 14));
+    if (kind == 0) sk_coop_build<0, 6>(kc, sc, Jw, lane, cc); else if (kind == 1) sk_coop_build<6, 6>(kc, sc, Jw, lane, cc);
+    else if (kind == 2) sk_coop_build<6, 9>(kc, sc, Jw, lane, cc); else sk_coop_build<0, 9>(kc, sc, Jw, lane, cc);
+  }
+  // ---- rows of the block-diagonal mass matrix and the joint-limit row of this lane's dof
+  double mdiag = 0, Ma[NDOF];
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) Ma[k] = 0;
+  if (row && !armrow) { const int b = i / 6, k = i - 6 * b; mdiag = k < 3 ? kc.box_mass[b] : kc.box_inertia[b][k - 3]; }
+  if (armrow) {
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) Ma[k] = t[ST_M + (ia >= k ? tri(ia, k) : tri(k, ia))];
+  }
+  double lsg = 0, lD = 0, lar = 0;
+  if (armrow) { lsg = t[ST_LIM + 3 * ia]; lD = t[ST_LIM + 3 * ia + 1]; lar = t[ST_LIM + 3 * ia + 2]; }
+  __syncthreads();
+  SK_TOC(3);
+  auto col = [&](int k) { return k < 6 ? cc.oa + k : cc.ob + k - 6; };
+  auto m_times = [&](int va, int vb) -> double {      // (M (v_a - v_b))_i
+    if (!row) return 0.0;
+    if (!armrow) return mdiag * (t[va + i] - (vb >= 0 ? t[vb + i] : 0.0));
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) s += Ma[k] * (t[va + SK_ARM0 + k] - (vb >= 0 ? t[vb + SK_ARM0 + k] : 0.0));
+    return s;
+  };
+  double jar[4] = {0, 0, 0, 0}, gi = 0, mxa = 0, xi = row ? t[ST_X + i] : 0.0;
+  // gradient (and Hessian) at x: g -> ST_G and gi, H -> ST_H; returns max |g|
+  auto grad_pass = [&](bool with_h) -> double {
+    if (with_h) for (int q = lane; q < SK_NH; q += WAVE) t[ST_H + q] = 0;
+    __syncthreads();
+    mxa = m_times(ST_X, ST_A0);
+    double gl = mxa;
+    if (row && with_h) {
+      if (!armrow) t[ST_H + tri(i, i)] = mdiag;
+      else {
+#pragma unroll
+        for (int k = 0; k < NDOF; k++) if (k <= ia) t[ST_H + tri(i, SK_ARM0 + k)] = Ma[k];
+      }
+    }
+    if (lsg != 0) { const double lj = lsg * xi - lar; if (lj < 0) { gl += lsg * lD * lj; if (with_h) t[ST_H + tri(i, i)] += lD; } }
+    if (row) t[ST_G + i] = gl;
+    __syncthreads();
+    if (con) {
+      double J[4][SKC_NJ], xk[SKC_NJ], f[4], Hc[16];
+#pragma unroll
+      for (int k = 0; k < SKC_NJ; k++) xk[k] = t[ST_X + col(k)];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < SKC_NJ; k++) { J[r][k] = SKJ(r, k); s += J[r][k] * xk[k]; }
+        jar[r] = s - cc.aref[r];
+      }
+      sk_cone(cc.dim, jar, cc.D, cc.mu, cc.fr, f, Hc);
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < 16; q++) any = any || Hc[q] != 0;
+      if (any) {
+#pragma unroll
+        for (int k = 0; k < SKC_NJ; k++) {
+          if (k >= 6 + cc.nb || (k < 6 && cc.oa == cc.ob && false)) continue;
+          const double acc = J[0][k] * f[0] + J[1][k] * f[1] + J[2][k] * f[2] + J[3][k] * f[3];
+          if (acc != 0) (void)__hip_atomic_fetch_add(&t[ST_G + col(k)], -acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (with_h) {
+#pragma unroll
+          for (int a = 0; a < SKC_NJ; a++) {
+            if (a >= 6 + cc.nb) continue;
+            double w[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[q] = J[0][a] * Hc[q] + J[1][a] * Hc[4 + q] + J[2][a] * Hc[8 + q] + J[3][a] * Hc[12 + q];
+            if (w[0] == 0 && w[1] == 0 && w[2] == 0 && w[3] == 0) continue;      // zero column (body 1 static, or a row beyond dim)
+            const int ra = col(a);
+#pragma unroll
+            for (int b = 0; b <= a; b++) {      // column index <= row index in dof order: body 1's block precedes body 2's
+              const double v = w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b];
+              if (v != 0) (void)__hip_atomic_fetch_add(&t[ST_H + tri(ra, col(b))], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    gi = row ? t[ST_G + i] : 0.0;
+    return sk_wave_max(fabs(gi));
+  };
+  bool converged = false, ok = true;
+  double iters = 0, gm = 0;
+  if (warm) {
+    gm = grad_pass(false);
+    SK_TOC(6);
+    if (gm <= g_solver_tol.grad_tol) converged = true;
+  }
+  for (int it = 0; it < 60 && !converged && ok; it++) {
+    gm = grad_pass(true);
+    iters += 1;
+    SK_TOC(8);
+    if (gm <= g_solver_tol.grad_tol) { converged = true; break; }
+    // ---- Cholesky: lane i holds row i
+    double Lr[SK_NV], dinv = 1;
+    {
+      double Hr[SK_NV];
+#pragma unroll
+      for (int k = 0; k < SK_NV; k++) { const bool in = row && k <= i; const double v = t[ST_H + (in ? tri(i, k) : 0)]; Hr[k] = in ? v : 0.0; }
+#pragma unroll
+      for (int j = 0; j < SK_NV; j++) {
+        double s = Hr[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= Lr[k] * sk_bcast(Lr[k], j);
+        double sj = sk_bcast(s, j);
+        if (!(sj > 0)) { ok = false; sj = 1; }
+        const double d = sqrt(sj), di = 1.0 / d;
+        Lr[j] = i == j ? d : (i > j ? s * di : 0.0);
+        if (i == j) dinv = di;
+      }
+    }
+    if (!ok) break;
+    SK_TOC(9);
+    // ---- p = -H^-1 g: forward substitution with the rows, backward with the columns (factor handed over through ST_H)
+    double y = row ? -gi : 0.0;
+#pragma unroll
+    for (int j = 0; j < SK_NV; j++) {
+      const double yj = sk_bcast(y * dinv, j);
+      y = i == j ? yj : (i > j ? y - Lr[j] * yj : y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SK_NV; k++) if (row && k <= i) t[ST_H + tri(i, k)] = Lr[k];
+    __syncthreads();
+    {
+      double Lc[SK_NV];
+#pragma unroll
+      for (int k = 0; k < SK_NV; k++) { const bool in = row && k > i; const double v = t[ST_H + (in ? tri(k, i) : 0)]; Lc[k] = in ? v : 0.0; }
+#pragma unroll
+      for (int j = SK_NV - 1; j >= 0; j--) {
+        const double xj = sk_bcast(y * dinv, j);
+        y = i == j ? xj : (i < j ? y - Lc[j] * xj : y);
+      }
+    }
+    const double pi = row ? y : 0.0;
+    if (row) t[ST_P + i] = pi;
+    __syncthreads();
+    SK_TOC(10);
+    // ---- line search: phi'(alpha) = p' M (x - a0) + alpha p' M p - sum f(jar + alpha Jp) . Jp, safeguarded Newton on alpha
+    const double Mp = m_times(ST_P, -1);
+    const double gTp = sk_wave_sum(gi * pi), pMp = sk_wave_sum(pi * Mp), pMa = sk_wave_sum(pi * mxa);
+    double jp[4] = {0, 0, 0, 0};
+    if (con) {
+      double pk[SKC_NJ];
+#pragma unroll
+      for (int k = 0; k < SKC_NJ; k++) pk[k] = t[ST_P + col(k)];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < SKC_NJ; k++) s += SKJ(r, k) * pk[k];
+        jp[r] = s;
+      }
+    }
+    const double ljp = lsg * pi, ljar = lsg * xi - lar;
+    SK_TOC(11);
+    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
+    for (int ls = 0; ls < 50; ls++) {
+      double d1c = 0, d2c = 0;
+      if (lsg != 0) { const double lj = ljar + alpha * ljp; if (lj < 0) { d1c += lD * lj * ljp; d2c += lD * ljp * ljp; } }
+      if (con) {
+        double jt[4], f[4], Hc[16];
+#pragma unroll
+        for (int r = 0; r < 4; r++) jt[r] = jar[r] + alpha * jp[r];
+        sk_cone(cc.dim, jt, cc.D, cc.mu, cc.fr, f, Hc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { d1c -= f[r] * jp[r];
+#pragma unroll
+          for (int q = 0; q < 4; q++) d2c += jp[r] * Hc[4 * r + q] * jp[q]; }
+      }
+      const double d1 = pMa + alpha * pMp + sk_wave_sum(d1c), d2 = pMp + sk_wave_sum(d2c);
+      best = alpha;
+      if (ls == 0 && d1 <= g_solver_tol.ls_full * fabs(gTp)) break;
+      if (fabs(d1) <= g_solver_tol.ls_c2 * fabs(gTp) || fabs(d1) <= g_solver_tol.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 / d2;
+      if (hi >= 0) {
+        const double wbr = hi - lo;
+        const bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+    SK_TOC(12);
+    const double dx = best * pi;
+    xi += dx;
+    if (row) t[ST_X + i] = xi;
+    const double smax = sk_wave_max(fabs(dx)), xmax = sk_wave_max(fabs(xi));
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= g_solver_tol.step_rel * (1 + xmax))) converged = true;
+    __syncthreads();
+  }
+  if (lane == 0) { SG(SG_DIAG) = iters; SG(SG_DIAG + 1) = gm; SG(SG_DIAG + 2) = (converged && ok) ? 1.0 : 0.0; }
+  return converged && ok;
+}
+#undef SKJ
+#endif
+
 // ------------------------------------------------------------------------------------------------ sub-step
 struct StackState { EnvState arm; BoxState box[SK_NB]; double warm[SK_NV]; };
 
@@ -670,9 +957,13 @@ D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& 
   SG(base + 12) = rec7[0]; SG(base + 13) = (double)bodyA; SG(base + 14) = (double)bodyB; SG(base + 15) = (double)set;
   ncon++;
 }
-// One physics sub-step (mj_step) with the torques of this sub-step's control law.
-template <class C>
-D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
+// One physics sub-step (mj_step) with the torques of this sub-step's control law, in three parts: stack_substep_pre (kinematics,
+// smooth accelerations, collision, limit rows, start point of the solver), the constraint solve (sk_solve on one lane, or
+// sk_solve_coop by the whole wave), stack_substep_post (mj_Euler).  WARM_LDS: the warm start is the x vector left in the t area by
+// the previous sub-step (device step kernel) instead of ss.warm.
+template <bool WARM_LDS, class C>
+D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing,
+                                            int& ncon_out, bool& any_lim_out) {
   D3IL_STACK_CONSTS(kc_, kc);
   D3IL_REFRESH(c0, c);
   EnvState& st = ss.arm;
@@ -838,31 +1129,35 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
     }
     SL(ST_LIM + 3 * k) = sign; SL(ST_LIM + 3 * k + 1) = D; SL(ST_LIM + 3 * k + 2) = ar;
   }
-  // ---- reference accelerations and regularisation of the contact rows (mj_makeImpedance, elliptic cones)
-  for (int ci = 0; ci < ncon; ci++) sk_contact_dispatch<1>(kc, sc, ci, 1);
   SK_TOC(3);
-  // ---- solve
-  // start point: the previous sub-step's accelerations (MuJoCo's qacc_warmstart), else the smooth accelerations; blocks without any
-  // constraint are not touched by the solver and take the smooth acceleration
+  // start point of the solver: the previous sub-step's accelerations (MuJoCo's qacc_warmstart) for the blocks that carry constraints,
+  // the smooth accelerations otherwise (those blocks are not moved by the solver)
   const bool warm = (st.flags & SKF_WARM_VALID) != 0;
-  for (int i = 0; i < SK_NV; i++) SL(ST_X + i) = SL(ST_A0 + i);
-  SG(SG_DIAG) = 0; SG(SG_DIAG + 1) = 0; SG(SG_DIAG + 2) = 1; SG(SG_DIAG + 3) = (double)ncon;
-  if (ncon > 0 || any_lim) {
-    if (warm) {
-      unsigned has = any_lim ? 1u << SK_NB : 0u;
-      for (int ci = 0; ci < ncon; ci++) { const int ba = sk_blk_of((int)SG(ci * SREC + 13)); has |= 1u << sk_blk_of((int)SG(ci * SREC + 14)); if (ba >= 0) has |= 1u << ba; }
-      for (int b = 0; b <= SK_NB; b++) if ((has >> b) & 1u) for (int i = sk_blk0(b); i < sk_blk0(b) + sk_blkn(b); i++) SL(ST_X + i) = ss.warm[i];
+  unsigned has = any_lim ? 1u << SK_NB : 0u;
+  for (int ci = 0; ci < ncon; ci++) { const int ba = sk_blk_of((int)SG(ci * SREC + 13)); has |= 1u << sk_blk_of((int)SG(ci * SREC + 14)); if (ba >= 0) has |= 1u << ba; }
+  for (int b = 0; b <= SK_NB; b++) {
+    const bool keep = warm && ((has >> b) & 1u);
+    for (int i = sk_blk0(b); i < sk_blk0(b) + sk_blkn(b); i++) {
+      if (!keep) SL(ST_X + i) = SL(ST_A0 + i);
+      else if (!WARM_LDS) SL(ST_X + i) = ss.warm[i];
     }
-    const bool ok = sk_solve(kc, sc, ncon, any_lim, warm); SG(SG_DIAG + 2) = ok ? 1.0 : 0.0; if (!ok) st.flags |= F_SOLVER_FAIL;
   }
-  for (int i = 0; i < SK_NV; i++) ss.warm[i] = SL(ST_X + i);
+  SG(SG_DIAG) = 0; SG(SG_DIAG + 1) = 0; SG(SG_DIAG + 2) = 1; SG(SG_DIAG + 3) = (double)ncon;
+  ncon_out = ncon; any_lim_out = any_lim;
+}
+// mj_Euler: implicit in the finger-joint damping, (M + h B) qacc = M x on the arm block; the arm mass matrix is still in the t area
+template <bool WARM_LDS, class C>
+D3IL_NOINLINE inline void stack_substep_post(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc) {
+  D3IL_REFRESH(c0, c);
+  EnvState& st = ss.arm;
+  const double h = c.timestep;
+  SK_TIC;
+  if (!WARM_LDS) for (int i = 0; i < SK_NV; i++) ss.warm[i] = SL(ST_X + i);
   st.flags |= SKF_WARM_VALID;
-  SK_TOC(4);
-  // ---- mj_Euler: implicit in the finger-joint damping (M + h B) qacc = M x on the arm block
   {
     double Mh[45], rhs[NDOF], L[45], d[NDOF], id[NDOF];
-    for (int k = 0; k < 45; k++) Mh[k] = dyn.M[k];
-    for (int a = 0; a < NDOF; a++) { double s = 0; for (int k = 0; k < NDOF; k++) s += dyn.M[a >= k ? tri(a, k) : tri(k, a)] * SL(ST_X + SK_ARM0 + k); rhs[a] = s; }
+    for (int k = 0; k < 45; k++) Mh[k] = SL(ST_M + k);
+    for (int a = 0; a < NDOF; a++) { double s = 0; for (int k = 0; k < NDOF; k++) s += Mh[a >= k ? tri(a, k) : tri(k, a)] * SL(ST_X + SK_ARM0 + k); rhs[a] = s; }
     for (int k = 0; k < NFING; k++) Mh[tri(NARM + k, NARM + k)] += h * c.f_damping[k];
     if (!ldl9(Mh, L, d, id)) st.flags |= F_SOLVER_FAIL;
     ldl9_solve(L, id, rhs);
@@ -874,6 +1169,22 @@ D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& 
     cube_integrate(ss.box[b], acc, h);
   }
   SK_TOC(5);
+  (void)kc_;
+}
+// the sub-step on one lane (host build, reset kernel)
+template <class C>
+D3IL_NOINLINE inline void stack_physics_substep(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  int ncon; bool any_lim;
+  stack_substep_pre<false>(c0, kc, ss, sc, tau, ffing, ncon, any_lim);
+  SK_TIC;
+  // reference accelerations and regularisation of the contact rows (mj_makeImpedance, elliptic cones)
+  for (int ci = 0; ci < ncon; ci++) sk_contact_dispatch<1>(kc, sc, ci, 1);
+  if (ncon > 0 || any_lim) {
+    const bool ok = sk_solve(kc, sc, ncon, any_lim, (ss.arm.flags & SKF_WARM_VALID) != 0); SG(SG_DIAG + 2) = ok ? 1.0 : 0.0; if (!ok) ss.arm.flags |= F_SOLVER_FAIL;
+  }
+  SK_TOC(4);
+  stack_substep_post<false>(c0, kc, ss, sc);
 }
 
 // ------------------------------------------------------------------------------------------------ env level (stacking.py)
@@ -917,25 +1228,36 @@ D3IL_HD void stack_control(const C& c, const EnvState& st, const double* q_des, 
   double zero[NARM] = {0, 0, 0, 0, 0, 0, 0};
   push_control(c, st, q_des, zero, set_width, grasp, tau, ff);
 }
-template <class C>
-D3IL_HD void stack_env_step(const C& c, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* action, float* obs, unsigned char* done,
-                            double* mean_dist, int n_substeps, int max_steps) {
+// env.step in three parts: stack_env_begin (gripper command, observation and done flag BEFORE the physics), n_substeps x (control +
+// sub-step), stack_env_end (counter, success, mode)
+D3IL_HD bool stack_env_begin(const StackConsts& kc_, StackState& ss, const double* action, float* obs, unsigned char* done, int max_steps) {
   D3IL_STACK_CONSTS(kc_, kc);
   const bool open = action[7] > kc.grip_thresh;
-  const double width = open ? 0.04 : 0.0;
   stack_obs(ss, obs);
   bool fin = (ss.arm.flags & F_TERMINATED) != 0;
   if (!fin && stack_success(kc, ss)) { ss.arm.flags |= F_TERMINATED; fin = true; }
   if (!fin && ss.arm.step >= max_steps - 1) fin = true;
   *done = fin ? 1 : 0;
+  return open;
+}
+D3IL_HD void stack_env_end(const StackConsts& kc_, StackState& ss, double* mean_dist) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  ss.arm.step += 1;
+  if (stack_success(kc, ss)) ss.arm.flags |= F_SUCCESS | F_TERMINATED; else ss.arm.flags &= ~F_SUCCESS;
+  stack_check_mode(kc, ss, mean_dist);
+}
+template <class C>
+D3IL_HD void stack_env_step(const C& c, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* action, float* obs, unsigned char* done,
+                            double* mean_dist, int n_substeps, int max_steps) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const bool open = stack_env_begin(kc, ss, action, obs, done, max_steps);
+  const double width = open ? 0.04 : 0.0;
   for (int s = 0; s < n_substeps; s++) {
     double tau[NARM], ff[NFING];
     stack_control(c, ss.arm, action, width, !open, tau, ff);
     stack_physics_substep(c, kc, ss, sc, tau, ff);
   }
-  ss.arm.step += 1;
-  if (stack_success(kc, ss)) ss.arm.flags |= F_SUCCESS | F_TERMINATED; else ss.arm.flags &= ~F_SUCCESS;
-  stack_check_mode(kc, ss, mean_dist);
+  stack_env_end(kc, ss, mean_dist);
 }
 // reset(random=False, context): scene.reset + beam to init_qpos + open_fingers + contexts + one sub-step (stacking.py:449-481)
 template <class C>

@@ -193,7 +193,7 @@ void* hc_stack_create(const d3il_model_blob* blob, const char** err) {
 int hc_stack_state_size() { return SK_STATE_F64; }
 void hc_stack_reset(void* h, const double* init_qpos, const double* ctx, double* s, int* f, float* obs) {
   StackHost* p = (StackHost*)h; StackState ss; std::memset(&ss, 0, sizeof ss);
-  StackScratch sc{p->t, p->g, 1};
+  StackScratch sc{p->t, p->g};
   stack_env_reset(p->c, p->kc, ss, sc, init_qpos, ctx, obs); stack_pack(ss, s, f);
 }
 static int g_stack_poison = 0;
@@ -204,7 +204,7 @@ void hc_stack_step(void* h, double* s, int* f, const double* action, float* obs,
     for (int i = 0; i < ST_SIZE; i++) p->t[i] = std::nan("");
     for (int i = 0; i < SG_SIZE; i++) p->g[i] = std::nan("");
   }
-  StackScratch sc{p->t, p->g, 1};
+  StackScratch sc{p->t, p->g};
   stack_env_step(p->c, p->kc, ss, sc, action, obs, done, mean_dist, p->c.n_substeps, p->c.max_steps);
   stack_pack(ss, s, f);
 }

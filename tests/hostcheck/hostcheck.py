@@ -182,7 +182,14 @@ class StackHostCheck:
         mode = "".join("rgb"[(fl >> (2 + 2 * i)) & 3] for i in range(n))
         return obs, bool(done.value), dict(mode=mode, success=bool(fl & (1 << 13)), mean_distance=md.value, flags=fl)
 
+    def scratch(self, count):
+        """First ``count`` doubles of the solver scratch area (contact records 32 x 36, then the diagnostics of the last sub-step)."""
+        out = np.zeros(count)
+        self.L.hc_stack_scratch(self.h, _p(out), count)
+        return out
+
     def contacts(self):
+        ncon = int(self.scratch(32 * 36 + 4)[32 * 36 + 3])
         out = np.zeros((48, 10))
         n = self.L.hc_stack_contacts(self.h, _p(out))
-        return out[:n]
+        return out[:min(n, ncon)]

@@ -29,7 +29,7 @@ for batch in (1, 24, 64):          # alone, and as lane 5 of a batch whose other
         env.step(torch.as_tensor(acts, dtype=torch.float64, device=env.device).contiguous())
         torch.cuda.synchronize()
         st1, fl1, sc1 = env.get_state()
-        buf = np.zeros(48 * 36 + 4)
+        buf = np.zeros(32 * 36 + 4)
         capi.check(env.L.d3il_debug_scratch(env.h, lane, buf.ctypes.data_as(C.c_void_p), len(buf)))
         res.append(st1[:, lane].copy()); scr.append(buf)
     out["s1_b%d" % batch] = np.array(res); out["scr_b%d" % batch] = np.array(scr)
