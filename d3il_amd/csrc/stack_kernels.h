@@ -81,11 +81,20 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
   }
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
-    int ncon = 0; bool any_lim = false;
+    int ncon = 0; bool any_lim = false, over = false;
+    unsigned has = 0;
     if (live) {
       double tau[NARM], ff[NFING];
       stack_control(kStackingConsts, ss.arm, act, open ? 0.04 : 0.0, !open, tau, ff);
-      stack_substep_pre<true>(kStackingConsts, g_stack_consts, ss, sc, tau, ff, ncon, any_lim);
+      stack_pre_kin(kStackingConsts, g_stack_consts, ss, sc, tau, ff);
+    }
+    __syncthreads();
+    SK_TIC;
+    sk_collide_coop(g_stack_consts, (sk_lds_double*)smem, Jw, (sk_glb_double*)(scratch + (size_t)blockIdx.x * SK_LANES * SG_SIZE), lane, live ? 1 : 0, ncon, has, over);
+    if (live) {
+      SK_TOC(1);
+      if (over) ss.arm.flags |= SKF_CON_OVERFLOW;
+      stack_pre_finish<true>(kStackingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
     }
     const int need = (live && (ncon > 0 || any_lim)) ? 1 : 0;
     const int warm = (live && (ss.arm.flags & SKF_WARM_VALID)) ? 1 : 0;

@@ -43,7 +43,7 @@ struct StackConsts {
   double st_c[SK_MAXNS][3], st_h[SK_MAXNS][3], st_R[SK_MAXNS][9];
   // finger geoms in the link-7 frame at finger position 0: the frame moves by f_axis * q_finger
   double tip_R[NFING][9], tip_p[NFING][3], tip_half[3];
-  double hull_R[NFING][9], hull_p[NFING][3], hull_center[3];
+  double hull_R[NFING][9], hull_p[NFING][3], hull_center[3], hull_r, tip_r, box_r[SK_NB];     // *_r: bounding radii about the centres
   double hull_v[SK_MAXHV][3];
   double invw_finger[NFING], invw_tip[NFING];     // translational body_invweight0 of the finger / finger-tip bodies
   StackSet set[SKS_N];
@@ -98,11 +98,12 @@ constexpr int ST_O = ST_Z + 21;                 // world joint origins 7 x 3
 constexpr int ST_FAX = ST_O + 21;               // world finger slide axes 2 x 3
 constexpr int ST_TIPR = ST_FAX + 6, ST_TIPP = ST_TIPR + 18, ST_HULR = ST_TIPP + 6, ST_HULP = ST_HULR + 18;
 constexpr int ST_LIM = ST_HULP + 6;             // per arm dof: sign, D, aref
-constexpr int ST_SIZE = ST_LIM + 27;            // 717
+constexpr int ST_AUX = ST_LIM + 27;             // finger opening q7 + q8 (gate of the finger <-> finger pairs), spare
+constexpr int ST_SIZE = ST_AUX + 2;             // 719 (odd)
 // g area: contact records
 constexpr int SREC = 36;    // pos[3] frame[9] dist bodyA bodyB set | aref[4] D[4] mu | jar[4] jp[4] | pad
 constexpr int SG_DIAG = SK_MAXCON * SREC;   // diagnostics of the last sub-step: Newton iterations, final max |gradient|, converged, contacts
-constexpr int SG_SIZE = SG_DIAG + 20;      // [4 .. 11]: clock ticks per phase, accumulated (diagnostics build -DD3IL_DEVICE_STATS only)
+constexpr int SG_SIZE = SG_DIAG + 24;      // [4 .. 11]: clock ticks per phase, accumulated (diagnostics build -DD3IL_DEVICE_STATS only)
 
 #if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
 #define SK_TIC unsigned long long sk_t0_ = wall_clock64()
@@ -123,10 +124,29 @@ D3IL_HD void sk_support1(const StackConsts& kc_, const SkShape& s, const double*
   double dl[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2], R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
   double loc[3];
   if (s.hull) {
+    // lowest-index vertex within 1e-10 of the maximum: pass 1 finds the maximum and the first vertex attaining it, pass 2 looks for an
+    // earlier vertex inside the tolerance.  Four vertices per iteration: the (wave-uniform) vertex table comes through the scalar
+    // cache, one wait per four vertices instead of one per vertex.
+    const int nv = kc.hull_nv;
+    auto dotv = [&](int i) { return kc.hull_v[i][0] * dl[0] + kc.hull_v[i][1] * dl[1] + kc.hull_v[i][2] * dl[2]; };
     double bd = -1e300;
-    for (int i = 0; i < kc.hull_nv; i++) { double d = kc.hull_v[i][0] * dl[0] + kc.hull_v[i][1] * dl[1] + kc.hull_v[i][2] * dl[2]; if (d > bd) bd = d; }
-    int best = 0; bool found = false;
-    for (int i = 0; i < kc.hull_nv; i++) { double d = kc.hull_v[i][0] * dl[0] + kc.hull_v[i][1] * dl[1] + kc.hull_v[i][2] * dl[2]; if (!found && d >= bd - 1e-10) { best = i; found = true; } }
+    int imax = 0, i = 0;
+    for (; i + 4 <= nv; i += 4) {
+      const double d0 = dotv(i), d1 = dotv(i + 1), d2 = dotv(i + 2), d3 = dotv(i + 3);
+      if (d0 > bd) { bd = d0; imax = i; }
+      if (d1 > bd) { bd = d1; imax = i + 1; }
+      if (d2 > bd) { bd = d2; imax = i + 2; }
+      if (d3 > bd) { bd = d3; imax = i + 3; }
+    }
+    for (; i < nv; i++) { const double d = dotv(i); if (d > bd) { bd = d; imax = i; } }
+    int best = imax;
+    const double thr = bd - 1e-10;
+    for (i = 0; i + 4 <= imax; i += 4) {
+      const double d0 = dotv(i), d1 = dotv(i + 1), d2 = dotv(i + 2), d3 = dotv(i + 3);
+      const int hit = d0 >= thr ? i : (d1 >= thr ? i + 1 : (d2 >= thr ? i + 2 : (d3 >= thr ? i + 3 : -1)));
+      if (hit >= 0) { best = hit; break; }
+    }
+    if (best == imax) for (; i < imax; i++) if (dotv(i) >= thr) { best = i; break; }
     loc[0] = kc.hull_v[best][0]; loc[1] = kc.hull_v[best][1]; loc[2] = kc.hull_v[best][2];
   } else {
 #pragma unroll
@@ -175,8 +195,14 @@ D3IL_HD void sk_tri_closest_origin(const double* a, const double* b, const doubl
   for (int k = 0; k < 3; k++) out[k] = a[k] + ab[k] * v + ac[k] * w;
 }
 // out = {dist, pos[3], normal[3]} (normal from shape a to shape b); false when the inflated shapes do not overlap
+#if defined(SK_MPR_STATS)
+#define SK_MPR_COUNT(x) (x)
+#else
+#define SK_MPR_COUNT(x) ((void)0)
+#endif
 D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const SkShape b, double margin, double* out) {
   D3IL_STACK_CONSTS(kc_, kc);
+  SK_MPR_COUNT(g_calls++);
   SkPt P[4], v4;
   double dir[3], va[3], vb[3];
   for (int s = 0; s < 2; s++) {
@@ -208,6 +234,7 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
   cross3(va, vb, dir); sk_norm3(dir);
   if (dot3(dir, P[0].v) > 0) { SkPt t = P[1]; P[1] = P[2]; P[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
   for (int guard = 0; guard < 100; guard++) {
+    SK_MPR_COUNT(g_disc++);
     sk_support(kc, a, b, dir, margin, P[3]);
     dot = dot3(P[3].v, dir);
     if (sk_zero(dot) || dot < 0) return false;
@@ -223,6 +250,7 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
     sk_portal_dir(P, dir);
     dot = dot3(dir, P[1].v);
     if (sk_zero(dot) || dot > 0) break;
+    SK_MPR_COUNT(g_ref++);
     sk_support(kc, a, b, dir, margin, v4);
     dot = dot3(v4.v, dir);
     if (!(sk_zero(dot) || dot > 0) || sk_reach_tol(P, v4, dir) || guard > 100) return false;
@@ -230,6 +258,7 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
   }
   for (int it = 0; ; it++) {                // penetration
     sk_portal_dir(P, dir);
+    SK_MPR_COUNT((g_pen++, g_maxpen = it + 1 > g_maxpen ? it + 1 : g_maxpen));
     sk_support(kc, a, b, dir, margin, v4);
     if (sk_reach_tol(P, v4, dir) || it > 50) {
       double w[3]; sk_tri_closest_origin(P[1].v, P[2].v, P[3].v, w);
@@ -688,14 +717,14 @@ __device__ __forceinline__ double sk_wave_max(double v) {
 constexpr int SKC_NJ = 15;                       // columns of a contact row in the J area
 constexpr int SKC_JSIZE = 4 * SKC_NJ * SK_MAXCON;   // doubles per wave
 #define SKJ(r, k) Jw[((r) * SKC_NJ + (k)) * SK_MAXCON + lane]
-struct SkCoopCon { int oa, ob, nb, dim; double aref[4], D[4], mu, fr[3]; };
+struct SkCoopCon { int oa, ob, na, nb, dim; double aref[4], D[4], mu, fr[3]; };
 template <int NA, int NB>
 __device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, const StackScratch sc, sk_lds_double* Jw, int lane, SkCoopCon& cc) {
   D3IL_STACK_CONSTS(kc_, kc);
   SkRows<NA, NB> R; int set;
   sk_build_rows(kc, sc, lane, R, &set);
   const StackSet& ps = kc.set[set];
-  cc.oa = R.oa; cc.ob = R.ob; cc.nb = NB; cc.dim = R.dim;
+  cc.oa = R.oa; cc.ob = R.ob; cc.na = NA; cc.nb = NB; cc.dim = R.dim;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const bool live = r < R.dim;
@@ -734,7 +763,7 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
   SK_TIC;
   // ---- contacts: rows, reference accelerations, regularisation
   SkCoopCon cc;
-  cc.oa = 0; cc.ob = 0; cc.nb = 6; cc.dim = 3; cc.mu = 1;
+  cc.oa = 0; cc.ob = 0; cc.na = 0; cc.nb = 6; cc.dim = 3; cc.mu = 1;
 #pragma unroll
   for (int r = 0; r < 4; r++) { cc.aref[r] = 0; cc.D[r] = 1; }
   cc.fr[0] = cc.fr[1] = cc.fr[2] = 1;
@@ -766,6 +795,7 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
     return s;
   };
   double jar[4] = {0, 0, 0, 0}, gi = 0, mxa = 0, xi = row ? t[ST_X + i] : 0.0;
+  // gradient (and Hessian) at x: g -> ST_G and gi, H -> ST_H; returns max |g|
   // gradient (and Hessian) at x: g -> ST_G and gi, H -> ST_H; returns max |g|
   auto grad_pass = [&](bool with_h) -> double {
     if (with_h) for (int q = lane; q < SK_NH; q += WAVE) t[ST_H + q] = 0;
@@ -846,9 +876,10 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
       for (int k = 0; k < SK_NV; k++) { const bool in = row && k <= i; const double v = t[ST_H + (in ? tri(i, k) : 0)]; Hr[k] = in ? v : 0.0; }
 #pragma unroll
       for (int j = 0; j < SK_NV; j++) {
-        double s = Hr[j];
+        double s = Hr[j], s2 = 0;      // two accumulators: the dependent FMA chain is half as long
 #pragma unroll
-        for (int k = 0; k < j; k++) s -= Lr[k] * sk_bcast(Lr[k], j);
+        for (int k = 0; k < j; k++) { if (k & 1) s2 -= Lr[k] * sk_bcast(Lr[k], j); else s -= Lr[k] * sk_bcast(Lr[k], j); }
+        s += s2;
         double sj = sk_bcast(s, j);
         if (!(sj > 0)) { ok = false; sj = 1; }
         const double d = sqrt(sj), di = 1.0 / d;
@@ -961,9 +992,8 @@ D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& 
 // smooth accelerations, collision, limit rows, start point of the solver), the constraint solve (sk_solve on one lane, or
 // sk_solve_coop by the whole wave), stack_substep_post (mj_Euler).  WARM_LDS: the warm start is the x vector left in the t area by
 // the previous sub-step (device step kernel) instead of ss.warm.
-template <bool WARM_LDS, class C>
-D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing,
-                                            int& ncon_out, bool& any_lim_out) {
+template <class C>
+D3IL_NOINLINE inline void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
   D3IL_STACK_CONSTS(kc_, kc);
   D3IL_REFRESH(c0, c);
   EnvState& st = ss.arm;
@@ -1022,19 +1052,42 @@ D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_,
     for (int k = 0; k < 6; k++) SL(ST_VEL + 6 * b + k) = ss.box[b].vel[k];
     if (ss.box[b].pos[0] < kc.ws_lo[0] || ss.box[b].pos[0] > kc.ws_hi[0] || ss.box[b].pos[1] < kc.ws_lo[1] || ss.box[b].pos[1] > kc.ws_hi[1]) st.flags |= SKF_OFF_TABLE;
   }
+  for (int b = 0; b < SK_NB; b++) {
+    double R[9];
+    for (int k = 0; k < 9; k++) R[k] = SL(ST_BR + 9 * b + k);
+    {   // hand mesh: not evaluated; flag a box that reaches its bounding box
+      double Rh[9], ph[3], pm[3];
+      for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) Rh[3 * r + cc] = dyn.R7[3 * r] * kc.hand_R[cc] + dyn.R7[3 * r + 1] * kc.hand_R[3 + cc] + dyn.R7[3 * r + 2] * kc.hand_R[6 + cc];
+      mulE(dyn.R7, kc.hand_p, pm);
+      for (int k = 0; k < 3; k++) ph[k] = dyn.p7[k] + pm[k];
+      double dw[3] = {ss.box[b].pos[0] - ph[0], ss.box[b].pos[1] - ph[1], ss.box[b].pos[2] - ph[2]};
+      bool inside = true;
+      for (int i = 0; i < 3; i++) {
+        double ci = Rh[i] * dw[0] + Rh[3 + i] * dw[1] + Rh[6 + i] * dw[2], ei = 0;
+        for (int j = 0; j < 3; j++) ei += fabs(Rh[i] * R[j] + Rh[3 + i] * R[3 + j] + Rh[6 + i] * R[6 + j]) * kc.box_half[b][j];
+        if (ci - ei > kc.hand_hi[i] || ci + ei < kc.hand_lo[i]) inside = false;
+      }
+      if (inside) st.flags |= SKF_HAND_NEAR;
+    }
+  }
+  SL(ST_AUX) = st.q[NARM] + st.q[NARM + 1];
   SK_TOC(0);
-  // ---- collision, in the model's geom order: static < boxes < left hull < left tip < right hull < right tip
+}
+// collision on one lane, in the model's geom order: static < boxes < left hull < left tip < right hull < right tip
+D3IL_NOINLINE inline int stack_pre_collide(const StackConsts& kc_, StackState& ss, const StackScratch sc) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  EnvState& st = ss.arm;
+  SK_TIC;
   int ncon = 0;
   double rec[8][7];
   auto boxR = [&](int b, double* R) { for (int k = 0; k < 9; k++) R[k] = SL(ST_BR + 9 * b + k); };
-  auto rcirc = [&](const double* hf) { return sqrt(hf[0] * hf[0] + hf[1] * hf[1] + hf[2] * hf[2]); };
   for (int s = 0; s < kc.ns; s++)
     for (int b = 0; b < SK_NB; b++) {
       double R[9]; boxR(b, R);
       // sphere against the static box (exact distance of the centre from the box)
       double d[3] = {ss.box[b].pos[0] - kc.st_c[s][0], ss.box[b].pos[1] - kc.st_c[s][1], ss.box[b].pos[2] - kc.st_c[s][2]}, ex = 0;
       for (int i = 0; i < 3; i++) { double loc = kc.st_R[s][i] * d[0] + kc.st_R[s][3 + i] * d[1] + kc.st_R[s][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[s][i]; if (o > 0) ex += o * o; }
-      const double rc = rcirc(kc.box_half[b]) + kc.set[SKS_STATIC + s].margin;
+      const double rc = kc.box_r[b] + kc.set[SKS_STATIC + s].margin;
       if (ex > rc * rc) continue;
       const int n = box_box(kc.st_c[s], kc.st_R[s], kc.st_h[s], ss.box[b].pos, R, kc.box_half[b], kc.set[SKS_STATIC + s].margin, rec, 8);
       for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, SKB_STATIC, b, SKS_STATIC + s);
@@ -1042,17 +1095,14 @@ D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_,
   for (int b1 = 0; b1 < SK_NB; b1++)
     for (int b2 = b1 + 1; b2 < SK_NB; b2++) {
       double d[3] = {ss.box[b2].pos[0] - ss.box[b1].pos[0], ss.box[b2].pos[1] - ss.box[b1].pos[1], ss.box[b2].pos[2] - ss.box[b1].pos[2]};
-      const double rc = rcirc(kc.box_half[b1]) + rcirc(kc.box_half[b2]) + kc.set[SKS_BOXBOX].margin;
+      const double rc = kc.box_r[b1] + kc.box_r[b2] + kc.set[SKS_BOXBOX].margin;
       if (dot3(d, d) > rc * rc) continue;
       double R1[9], R2[9]; boxR(b1, R1); boxR(b2, R2);
       const int n = box_box(ss.box[b1].pos, R1, kc.box_half[b1], ss.box[b2].pos, R2, kc.box_half[b2], kc.set[SKS_BOXBOX].margin, rec, 8);
       for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, b1, b2, SKS_BOXBOX);
     }
   SK_TOC(1);
-  const double r_tip = rcirc(kc.tip_half);
-  double r_hull = 0;
-  for (int i = 0; i < kc.hull_nv; i++) { double d[3] = {kc.hull_v[i][0] - kc.hull_center[0], kc.hull_v[i][1] - kc.hull_center[1], kc.hull_v[i][2] - kc.hull_center[2]}; r_hull = fmax(r_hull, dot3(d, d)); }
-  r_hull = sqrt(r_hull);
+  const double r_tip = kc.tip_r, r_hull = kc.hull_r;
   double fR[NFING][2][9], fP[NFING][2][3], hullC[NFING][3];
   for (int f = 0; f < NFING; f++) {
     for (int k = 0; k < 9; k++) { fR[f][0][k] = SL(ST_HULR + 9 * f + k); fR[f][1][k] = SL(ST_TIPR + 9 * f + k); }
@@ -1061,7 +1111,7 @@ D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_,
   }
   for (int b = 0; b < SK_NB; b++) {
     double R[9]; boxR(b, R);
-    const double rb = rcirc(kc.box_half[b]);
+    const double rb = kc.box_r[b];
     for (int f = 0; f < NFING; f++) {
       {   // box <-> finger hull (geom order: box first)
         double d[3] = {hullC[f][0] - ss.box[b].pos[0], hullC[f][1] - ss.box[b].pos[1], hullC[f][2] - ss.box[b].pos[2]};
@@ -1081,22 +1131,8 @@ D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_,
         }
       }
     }
-    {   // hand mesh: not evaluated; flag a box that reaches its bounding box
-      double Rh[9], ph[3], pm[3];
-      for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) Rh[3 * r + cc] = dyn.R7[3 * r] * kc.hand_R[cc] + dyn.R7[3 * r + 1] * kc.hand_R[3 + cc] + dyn.R7[3 * r + 2] * kc.hand_R[6 + cc];
-      mulE(dyn.R7, kc.hand_p, pm);
-      for (int k = 0; k < 3; k++) ph[k] = dyn.p7[k] + pm[k];
-      double dw[3] = {ss.box[b].pos[0] - ph[0], ss.box[b].pos[1] - ph[1], ss.box[b].pos[2] - ph[2]};
-      bool inside = true;
-      for (int i = 0; i < 3; i++) {
-        double ci = Rh[i] * dw[0] + Rh[3 + i] * dw[1] + Rh[6 + i] * dw[2], ei = 0;
-        for (int j = 0; j < 3; j++) ei += fabs(Rh[i] * R[j] + Rh[3 + i] * R[3 + j] + Rh[6 + i] * R[6 + j]) * kc.box_half[b][j];
-        if (ci - ei > kc.hand_hi[i] || ci + ei < kc.hand_lo[i]) inside = false;
-      }
-      if (inside) st.flags |= SKF_HAND_NEAR;
-    }
   }
-  if (st.q[NARM] + st.q[NARM + 1] < 0.004) {     // finger <-> finger: only a (nearly) closed gripper (the gaps are q1 + q2 - 1 mm or less)
+  if (SL(ST_AUX) < 0.004) {     // finger <-> finger: only a (nearly) closed gripper (the gaps are q1 + q2 - 1 mm or less)
     double r7[7];
     {
       SkShape A{fR[0][0], fP[0][0], nullptr, 1}, B{fR[1][0], fP[1][0], nullptr, 1};
@@ -1114,6 +1150,13 @@ D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_,
     for (int i = 0; i < n; i++) sk_add_contact(kc, sc, ncon, st.flags, rec[i], 1.0, SKB_TIP, SKB_TIP + 1, SKS_TIPTIP);
   }
   SK_TOC(2);
+  return ncon;
+}
+template <bool WARM_LDS, class C>
+D3IL_NOINLINE inline void stack_pre_finish(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const int ncon, unsigned has, bool& any_lim_out) {
+  D3IL_REFRESH(c0, c);
+  EnvState& st = ss.arm;
+  SK_TIC;
   // ---- joint-limit rows (mj_instantiateLimit) of the 9 arm dofs
   bool any_lim = false;
   for (int k = 0; k < NDOF; k++) {
@@ -1133,8 +1176,7 @@ D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_,
   // start point of the solver: the previous sub-step's accelerations (MuJoCo's qacc_warmstart) for the blocks that carry constraints,
   // the smooth accelerations otherwise (those blocks are not moved by the solver)
   const bool warm = (st.flags & SKF_WARM_VALID) != 0;
-  unsigned has = any_lim ? 1u << SK_NB : 0u;
-  for (int ci = 0; ci < ncon; ci++) { const int ba = sk_blk_of((int)SG(ci * SREC + 13)); has |= 1u << sk_blk_of((int)SG(ci * SREC + 14)); if (ba >= 0) has |= 1u << ba; }
+  if (any_lim) has |= 1u << SK_NB;
   for (int b = 0; b <= SK_NB; b++) {
     const bool keep = warm && ((has >> b) & 1u);
     for (int i = sk_blk0(b); i < sk_blk0(b) + sk_blkn(b); i++) {
@@ -1143,8 +1185,149 @@ D3IL_NOINLINE inline void stack_substep_pre(const C& c0, const StackConsts& kc_,
     }
   }
   SG(SG_DIAG) = 0; SG(SG_DIAG + 1) = 0; SG(SG_DIAG + 2) = 1; SG(SG_DIAG + 3) = (double)ncon;
-  ncon_out = ncon; any_lim_out = any_lim;
+  any_lim_out = any_lim;
+  (void)kc_;
 }
+// blocks that carry contacts (bit b: box b, bit SK_NB: the arm), from the records
+D3IL_HD unsigned sk_has_mask(const StackScratch sc, int ncon) {
+  unsigned has = 0;
+  for (int ci = 0; ci < ncon; ci++) { const int ba = sk_blk_of((int)SG(ci * SREC + 13)); has |= 1u << sk_blk_of((int)SG(ci * SREC + 14)); if (ba >= 0) has |= 1u << ba; }
+  return has;
+}
+template <bool WARM_LDS, class C>
+D3IL_HD void stack_substep_pre(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing,
+                               int& ncon_out, bool& any_lim_out) {
+  stack_pre_kin(c0, kc_, ss, sc, tau, ffing);
+  const int ncon = stack_pre_collide(kc_, ss, sc);
+  stack_pre_finish<WARM_LDS>(c0, kc_, ss, sc, ncon, sk_has_mask(sc, ncon), any_lim_out);
+  ncon_out = ncon;
+}
+#if defined(__HIPCC__)
+// Collision of the workgroup's environments with one lane per (environment, pair group), lane = group * SK_LANES + environment:
+//   group 0 .. 2  : box b against the static boxes          3 .. 5 : the box pairs (0, 1) (0, 2) (1, 2)
+//   group 6 .. 11 : box b against finger f: tip, hull (MPR)    12  : finger <-> finger (nearly closed gripper)
+// Every lane collects the contacts of its group, the counts go through LDS (stage = the wave's J area, free at this point) and the
+// records are written group by group into the environment's record area.  For lane < SK_LANES (environment = lane) ncon / has
+// return the contact count and the blocks that carry contacts, over = more contacts than the record area holds.
+constexpr int SKP_GROUPS = 13, SKP_MAXL = 12;
+static_assert(SKP_GROUPS * SK_LANES <= WAVE, "the lane-per-pair collision needs 13 lanes per environment");
+__device__ __attribute__((noinline)) void sk_collide_coop(const StackConsts& kc_, sk_lds_double* smem, sk_lds_double* stage, sk_glb_double* scratch_wg, const int lane,
+                                                          const int live, int& ncon, unsigned& has, bool& over) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const int e = lane % SK_LANES, grp = lane / SK_LANES;
+  const bool act = grp < SKP_GROUPS && __shfl(live, e) != 0;
+  sk_lds_double* t = smem + e * ST_SIZE;
+  double rec[SKP_MAXL][7], tmp[8][7];
+  int meta[SKP_MAXL], n = 0;
+  bool lost = false;
+  unsigned mask = 0;
+  auto push = [&](const double* r7, int a, int b, int set) {
+    if (n >= SKP_MAXL) { lost = true; return; }
+    for (int k = 0; k < 7; k++) rec[n][k] = r7[k];
+    meta[n] = a | (b << 4) | (set << 8);
+    mask |= 1u << sk_blk_of(b); if (sk_blk_of(a) >= 0) mask |= 1u << sk_blk_of(a);
+    n++;
+  };
+  auto ld = [&](int off, int cnt, double* out) { for (int k = 0; k < cnt; k++) out[k] = t[off + k]; };
+#if defined(D3IL_DEVICE_STATS)
+  unsigned long long skp_t0 = wall_clock64();      // lane 0 (environment 0, group 0) times the phases of the whole wave: slots 13 set-up, 14 box-box, 15 MPR
+#define SKP_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0) scratch_wg[SG_DIAG + 4 + (slot)] += (double)(t_ - skp_t0); skp_t0 = t_; } while (0)
+#else
+#define SKP_TOC(slot) ((void)0)
+#endif
+  // Jobs: every lane sets up at most one pair test per round and all lanes run the test of a round at ONE call site per kind (box-box,
+  // MPR), so that lanes of different groups do not serialise through separately inlined copies of the same routine.
+  //   round   group 0..2 (box b)   3..5 (box pair)   6..11 (box b, finger f)   12 (fingers)
+  //     0     static 0  [BB]        b1-b2 [BB]         box - tip   [BB]          tip - tip   [BB]
+  //     1     static 1  [BB]                           box - hull  [MPR]         hull - hull [MPR]
+  //     2     static 2  [BB]                                                     hull0 - tip1 [MPR]
+  //     3     static 3  [BB]                                                     tip0 - hull1 [MPR]
+  const bool fingers = grp == 12 && act && t[ST_AUX] < 0.004;     // only a (nearly) closed gripper (the gaps are q1 + q2 - 1 mm or less)
+  for (int round = 0; round < 4; round++) {
+    int kind = 0, ba = 0, bb = 0, set = 0;      // kind: 0 none, 1 box-box, 2 MPR
+    double RA[9], pA[3], hA[3], RB[9], pB[3], hB[3], margin = 0, rsum = 0;
+    int hullA = 0, hullB = 0;
+    auto box_shape = [&](int b, double* R, double* p, double* h) { ld(ST_BR + 9 * b, 9, R); ld(ST_BP + 3 * b, 3, p); for (int k = 0; k < 3; k++) h[k] = kc.box_half[b][k]; };
+    auto tip_shape = [&](int f, double* R, double* p, double* h) { ld(ST_TIPR + 9 * f, 9, R); ld(ST_TIPP + 3 * f, 3, p); for (int k = 0; k < 3; k++) h[k] = kc.tip_half[k]; };
+    auto hull_shape = [&](int f, double* R, double* p, double* h) { ld(ST_HULR + 9 * f, 9, R); ld(ST_HULP + 3 * f, 3, p); h[0] = h[1] = h[2] = 0; };
+    if (act) {
+      if (grp < 3) {
+        if (round < kc.ns) {
+          const int sidx = round, b = grp;
+          box_shape(b, RB, pB, hB);
+          double d[3] = {pB[0] - kc.st_c[sidx][0], pB[1] - kc.st_c[sidx][1], pB[2] - kc.st_c[sidx][2]}, ex = 0;
+          for (int i = 0; i < 3; i++) { double loc = kc.st_R[sidx][i] * d[0] + kc.st_R[sidx][3 + i] * d[1] + kc.st_R[sidx][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[sidx][i]; if (o > 0) ex += o * o; }
+          const double rc = kc.box_r[b] + kc.set[SKS_STATIC + sidx].margin;
+          if (ex <= rc * rc) {
+            kind = 1; ba = SKB_STATIC; bb = b; set = SKS_STATIC + sidx;
+            for (int k = 0; k < 9; k++) RA[k] = kc.st_R[sidx][k];
+            for (int k = 0; k < 3; k++) { pA[k] = kc.st_c[sidx][k]; hA[k] = kc.st_h[sidx][k]; }
+          }
+        }
+      } else if (grp < 6) {
+        if (round == 0) {
+          const int b1 = grp == 5 ? 1 : 0, b2 = grp == 3 ? 1 : 2;
+          box_shape(b1, RA, pA, hA); box_shape(b2, RB, pB, hB);
+          kind = 1; ba = b1; bb = b2; set = SKS_BOXBOX; rsum = kc.box_r[b1] + kc.box_r[b2];
+        }
+      } else if (grp < 12) {
+        const int b = (grp - 6) >> 1, f = (grp - 6) & 1;
+        if (round == 0) { box_shape(b, RA, pA, hA); tip_shape(f, RB, pB, hB); kind = 1; ba = b; bb = SKB_TIP + f; set = SKS_BOXTIP; rsum = kc.box_r[b] + kc.tip_r; }
+        else if (round == 1) { box_shape(b, RA, pA, hA); hull_shape(f, RB, pB, hB); hullB = 1; kind = 2; ba = b; bb = SKB_FINGER + f; set = SKS_BOXHULL; rsum = kc.box_r[b] + kc.hull_r; }
+      } else if (fingers) {
+        if (round == 0) { tip_shape(0, RA, pA, hA); tip_shape(1, RB, pB, hB); kind = 1; ba = SKB_TIP; bb = SKB_TIP + 1; set = SKS_TIPTIP; }
+        else if (round == 1) { hull_shape(0, RA, pA, hA); hull_shape(1, RB, pB, hB); hullA = hullB = 1; kind = 2; ba = SKB_FINGER; bb = SKB_FINGER + 1; set = SKS_HULLHULL; }
+        else if (round == 2) { hull_shape(0, RA, pA, hA); tip_shape(1, RB, pB, hB); hullA = 1; kind = 2; ba = SKB_FINGER; bb = SKB_TIP + 1; set = SKS_HULLTIP; }
+        else { tip_shape(0, RA, pA, hA); hull_shape(1, RB, pB, hB); hullB = 1; kind = 2; ba = SKB_TIP; bb = SKB_FINGER + 1; set = SKS_HULLTIP; }
+      }
+      if (kind != 0) {
+        margin = kc.set[set].margin;
+        if (rsum > 0) {      // bounding spheres about the geom centres (the hull's centre is its mesh centre)
+          double cA[3] = {pA[0], pA[1], pA[2]}, cB[3] = {pB[0], pB[1], pB[2]};
+          if (hullA) for (int k = 0; k < 3; k++) cA[k] += RA[3 * k] * kc.hull_center[0] + RA[3 * k + 1] * kc.hull_center[1] + RA[3 * k + 2] * kc.hull_center[2];
+          if (hullB) for (int k = 0; k < 3; k++) cB[k] += RB[3 * k] * kc.hull_center[0] + RB[3 * k + 1] * kc.hull_center[1] + RB[3 * k + 2] * kc.hull_center[2];
+          const double d[3] = {cB[0] - cA[0], cB[1] - cA[1], cB[2] - cA[2]}, rc = rsum + margin;
+          if (dot3(d, d) > rc * rc) kind = 0;
+        }
+      }
+    }
+    if (!__any(kind != 0)) continue;
+    SKP_TOC(13);
+    if (kind == 1) {
+      const int m = box_box(pA, RA, hA, pB, RB, hB, margin, tmp, 8);
+      for (int i = 0; i < m; i++) push(tmp[i], ba, bb, set);
+    }
+    SKP_TOC(14);
+    if (kind == 2) {
+      SkShape A{RA, pA, hA, hullA}, B{RB, pB, hB, hullB};
+      double r7[7];
+      if (sk_mpr(kc, A, B, margin, r7)) push(r7, ba, bb, set);
+    }
+    SKP_TOC(15);
+  }
+  // counts / masks through LDS, then the records in group order
+  stage[lane] = (double)n; stage[WAVE + lane] = (double)(mask | (lost ? 256u : 0u));
+  __syncthreads();
+  int off = 0, total = 0; unsigned all = 0;
+  for (int g = 0; g < SKP_GROUPS; g++) { const int c = (int)stage[g * SK_LANES + e]; if (g < grp) off += c; total += c; all |= (unsigned)stage[WAVE + g * SK_LANES + e]; }
+  sk_glb_double* gq = scratch_wg + (size_t)e * SG_SIZE;
+  for (int i = 0; i < n; i++) {
+    const int slot = off + i;
+    if (slot >= SK_MAXCON) break;
+    sk_glb_double* r = gq + slot * SREC;
+    double nn[3] = {rec[i][4], rec[i][5], rec[i][6]}, t1[3], t2[3];
+    make_frame(nn, t1, t2);
+    r[0] = rec[i][1]; r[1] = rec[i][2]; r[2] = rec[i][3];
+    for (int k = 0; k < 3; k++) { r[3 + k] = nn[k]; r[6 + k] = t1[k]; r[9 + k] = t2[k]; }
+    r[12] = rec[i][0]; r[13] = (double)(meta[i] & 15); r[14] = (double)((meta[i] >> 4) & 15); r[15] = (double)(meta[i] >> 8);
+  }
+  ncon = total < SK_MAXCON ? total : SK_MAXCON;
+  has = all & 15u;
+  over = total > SK_MAXCON || (all & 256u) != 0;
+  __syncthreads();
+}
+#endif
+
 // mj_Euler: implicit in the finger-joint damping, (M + h B) qacc = M x on the arm block; the arm mass matrix is still in the t area
 template <bool WARM_LDS, class C>
 D3IL_NOINLINE inline void stack_substep_post(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc) {
@@ -1388,6 +1571,13 @@ D3IL_HOSTFN inline int build_stack_consts(const d3il_model_blob& m, const PandaC
   kc.hull_nv = m.mesh_nvert[mi];
   for (int i = 0; i < kc.hull_nv; i++) for (int k = 0; k < 3; k++) kc.hull_v[i][k] = m.mesh_vert[mi][i][k];
   for (int k = 0; k < 3; k++) kc.hull_center[k] = m.mesh_center[mi][k];
+  {   // bounding radii (sqrt of the same sums the per-step code used to form)
+    double r2 = 0;
+    for (int i = 0; i < kc.hull_nv; i++) { double d[3] = {kc.hull_v[i][0] - kc.hull_center[0], kc.hull_v[i][1] - kc.hull_center[1], kc.hull_v[i][2] - kc.hull_center[2]}; r2 = std::fmax(r2, dot3(d, d)); }
+    kc.hull_r = std::sqrt(r2);
+    kc.tip_r = std::sqrt(kc.tip_half[0] * kc.tip_half[0] + kc.tip_half[1] * kc.tip_half[1] + kc.tip_half[2] * kc.tip_half[2]);
+    for (int b = 0; b < SK_NB; b++) kc.box_r[b] = std::sqrt(kc.box_half[b][0] * kc.box_half[b][0] + kc.box_half[b][1] * kc.box_half[b][1] + kc.box_half[b][2] * kc.box_half[b][2]);
+  }
   if (mix(gb[0], gb[1], kc.set[SKS_BOXBOX]) || mix(gb[0], ghull[0], kc.set[SKS_BOXHULL]) || mix(gb[0], gtip[0], kc.set[SKS_BOXTIP]) ||
       mix(ghull[0], ghull[1], kc.set[SKS_HULLHULL]) || mix(ghull[0], gtip[1], kc.set[SKS_HULLTIP]) || mix(gtip[0], gtip[1], kc.set[SKS_TIPTIP])) { *err = "unsupported contact dimension"; return -1; }
   // translational body_invweight0 of the finger and finger-tip bodies at qpos0: mean diagonal of Jp M^-1 Jp' at the body's COM
