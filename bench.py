@@ -230,7 +230,7 @@ def _random_beso(dev):
     torch.manual_seed(0)
     net = DiffusionGPT(state_dim=20, action_dim=8, embed_dim=120, n_layers=6, n_heads=6, obs_seq_len=5).to(dev)
     sc = Scaler([0.0] * 20, [1.0] * 20, [0.0] * 7 + [0.04], [0.01] * 7 + [0.04], y_bounds=[[-1.0] * 8, [1.0] * 8], device=dev)
-    return BESOPolicy(net, sc, window_size=5, num_sampling_steps=16, sigma_min=0.01, sigma_max=1.0)
+    return BESOPolicy(net, sc, window_size=5, num_sampling_steps=16, sigma_min=0.01, sigma_max=1.0, use_graph=os.environ.get("D3IL_POLICY_GRAPH", "1") == "1")
 
 
 # ---------------------------------------------------------------------------------------------------- the benchmark

@@ -262,6 +262,59 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_auto_reset(const PandaConsts*
   for (int k = 0; k < 3; k++) des[k * (size_t)stride + e] = st.tcp[k];
 }
 
+// Causal self-attention for the short token sequences of the BESO policy (DiffusionGPT of BASELINE config 5: T = 11 tokens, 6 heads
+// of 20): one lane per (sequence b, head h, query i).  qkv: f32 [B * T][3 C] (query | key | value of a token, C = H * D, as written
+// by ONE fused linear layer), out: f32 [B * T][C] in token-major layout (what the output projection reads) - no transposes, no
+// [B, H, T, T] score tensor, no batched GEMM of 11 x 20 matrices.  Softmax over the keys j <= i with the 1 / sqrt(D) scaling
+// (score_gpts.py:59-76).  D <= 32, T <= 32.
+template <int D4>      // D4 = D / 4 float4 chunks per head row (D a multiple of 4: 16-byte loads), or 0: scalar loads for any D <= 32
+__global__ __launch_bounds__(256) void k_attention_causal_f32(const float* __restrict__ qkv, float* __restrict__ out, int B, int T, int H, int D) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // ((b * H) + h) * T + i: the queries of one (b, h) sit in adjacent lanes
+  const long total = (long)B * H * T;
+  if (idx >= total) return;
+  const int i = (int)(idx % T), h = (int)((idx / T) % H);
+  const long b = idx / ((long)T * H);
+  const int C = H * D;
+  const float* base = qkv + (b * T) * (long)(3 * C) + h * D;
+  constexpr int DR = D4 > 0 ? 4 * D4 : 32;
+  float q[DR], acc[DR], kk[DR], vv[DR];
+  const float scale = 1.0f / sqrtf((float)D);
+  auto load = [&](const float* p, float* r) {
+    if constexpr (D4 > 0) {
+#pragma unroll
+      for (int c = 0; c < D4; c++) { const float4 t = reinterpret_cast<const float4*>(p)[c]; r[4 * c] = t.x; r[4 * c + 1] = t.y; r[4 * c + 2] = t.z; r[4 * c + 3] = t.w; }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 32; d++) r[d] = d < D ? p[d] : 0.0f;
+    }
+  };
+  load(base + (long)i * 3 * C, q);
+#pragma unroll
+  for (int d = 0; d < DR; d++) { q[d] *= scale; acc[d] = 0.0f; }
+  float m = -INFINITY, l = 0.0f;
+  for (int j = 0; j <= i; j++) {      // online softmax
+    const float* kj = base + (long)j * 3 * C + C;
+    load(kj, kk); load(kj + C, vv);
+    float sc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DR; d++) sc += q[d] * kk[d];
+    const float mn = fmaxf(m, sc), corr = __expf(m - mn), pj = __expf(sc - mn);
+    l = l * corr + pj;
+#pragma unroll
+    for (int d = 0; d < DR; d++) acc[d] = acc[d] * corr + pj * vv[d];
+    m = mn;
+  }
+  float* o = out + (b * T + i) * (long)C + h * D;
+  const float inv = 1.0f / l;
+  if constexpr (D4 > 0) {
+#pragma unroll
+    for (int c = 0; c < D4; c++) reinterpret_cast<float4*>(o)[c] = make_float4(acc[4 * c] * inv, acc[4 * c + 1] * inv, acc[4 * c + 2] * inv, acc[4 * c + 3] * inv);
+  } else {
+#pragma unroll
+    for (int d = 0; d < 32; d++) if (d < D) o[d] = acc[d] * inv;
+  }
+}
+
 // ---- random-policy harness (avoiding_sim.py:51-66 with a uniform random agent)
 __device__ __forceinline__ void philox4x32_10(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned* out) {
   const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
@@ -709,6 +762,20 @@ int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32
   HIPCHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_policy_action, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->buf.policy_des, actions, (unsigned long long)seed,
                      (unsigned long long)env_offset, t, h->n, h->stride);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_attention_causal_f32(const float* qkv, float* out, int B, int T, int H, int D, void* stream) {
+  if (!qkv || !out) return fail(D3IL_EINVAL, "d3il_attention_causal_f32: null argument");
+  if (B < 0 || T < 1 || T > 32 || H < 1 || D < 1 || D > 32) return fail(D3IL_EINVAL, "d3il_attention_causal_f32: needs 1 <= T <= 32, 1 <= D <= 32");
+  const long total = (long)B * H * T;
+  if (total == 0) return D3IL_OK;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  const bool aligned = D % 4 == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  if (aligned && D == 20) hipLaunchKernelGGL(k_attention_causal_f32<5>, grid, block, 0, (hipStream_t)stream, qkv, out, B, T, H, D);
+  else if (aligned && D == 16) hipLaunchKernelGGL(k_attention_causal_f32<4>, grid, block, 0, (hipStream_t)stream, qkv, out, B, T, H, D);
+  else if (aligned && D == 32) hipLaunchKernelGGL(k_attention_causal_f32<8>, grid, block, 0, (hipStream_t)stream, qkv, out, B, T, H, D);
+  else hipLaunchKernelGGL(k_attention_causal_f32<0>, grid, block, 0, (hipStream_t)stream, qkv, out, B, T, H, D);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }

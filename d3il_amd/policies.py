@@ -104,9 +104,20 @@ class _CausalSelfAttention(nn.Module):     # score_gpts.py:15-80
 
     def forward(self, x):
         B, T, C = x.size()
-        k = self.key(x).view(B, T, self.n_head, C // self.n_head).transpose(1, 2)
-        q = self.query(x).view(B, T, self.n_head, C // self.n_head).transpose(1, 2)
-        v = self.value(x).view(B, T, self.n_head, C // self.n_head).transpose(1, 2)
+        hd = C // self.n_head
+        if x.is_cuda and x.dtype == torch.float32 and T <= 32 and hd <= 32:
+            # device path: ONE linear layer for query | key | value, then the fused short-sequence attention kernel of the rollout
+            # library (d3il_attention_causal_f32) which writes token-major output - no [B, H, T, T] tensors, no batched 11 x 20 GEMMs
+            from . import capi
+            w = torch.cat((self.query.weight, self.key.weight, self.value.weight), dim=0)
+            bqkv = torch.cat((self.query.bias, self.key.bias, self.value.bias), dim=0)
+            qkv = F.linear(x, w, bqkv).contiguous()
+            y = torch.empty(B, T, C, dtype=torch.float32, device=x.device)
+            capi.check(capi.load().d3il_attention_causal_f32(qkv.data_ptr(), y.data_ptr(), B, T, self.n_head, hd, torch.cuda.current_stream(x.device).cuda_stream))
+            return self.proj(y)
+        k = self.key(x).view(B, T, self.n_head, hd).transpose(1, 2)
+        q = self.query(x).view(B, T, self.n_head, hd).transpose(1, 2)
+        v = self.value(x).view(B, T, self.n_head, hd).transpose(1, 2)
         att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(k.size(-1)))
         att = att.masked_fill(self.mask[:, :, :T, :T] == 0, float("-inf"))
         y = F.softmax(att, dim=-1) @ v
@@ -292,14 +303,20 @@ class BESOPolicy:
     last action of the sequence, clamp, inverse scale."""
 
     def __init__(self, inner: DiffusionGPT, scaler: Scaler, window_size: int, num_sampling_steps: int, sigma_min: float, sigma_max: float,
-                 sigma_data: float = 0.5, noise_fn=None):
+                 sigma_data: float = 0.5, noise_fn=None, use_graph: bool = False):
         self.inner, self.scaler, self.W = inner.eval(), scaler, int(window_size)
+        # use_graph: capture the sampling loop for full windows ([N, W] sequences, ~1500 small kernels) in a HIP graph and replay it
+        # (default noise only: the generator state is part of the capture)
+        self.use_graph = bool(use_graph) and noise_fn is None
+        self._graph = None
         dev = scaler.x_mean.device
         self.device = dev
         self.n_steps, self.sigma_min, self.sigma_max, self.sigma_data = int(num_sampling_steps), float(sigma_min), float(sigma_max), float(sigma_data)
         self.min_action, self.max_action = scaler.y_bounds[0], scaler.y_bounds[1]
         self.noise_fn = noise_fn or (lambda shape: torch.randn(shape, device=dev))
         self.obs_hist = self.act_hist = None
+        # the noise schedule as host floats (one transfer here instead of a device synchronisation per sampling step)
+        self.sigmas = torch.cat([torch.linspace(self.sigma_max, self.sigma_min, self.n_steps, device=dev), torch.zeros(1, device=dev)]).tolist()
 
     def load_reference_state_dict(self, sd):
         """``GCDenoiser.state_dict()`` of the reference: the transformer sits under ``inner_model.``."""
@@ -321,23 +338,58 @@ class BESOPolicy:
             if h is not None:
                 h.reset(mask)
 
-    def _denoise(self, states, actions, sigma):
+    def _denoise(self, states, actions, sigma: float):
         sd2 = self.sigma_data ** 2
         c_skip, c_out, c_in = sd2 / (sigma ** 2 + sd2), sigma * self.sigma_data / (sigma ** 2 + sd2) ** 0.5, 1 / (sigma ** 2 + sd2) ** 0.5
-        s_in = torch.full((actions.shape[0],), float(sigma), device=self.device)
+        s_in = torch.full((actions.shape[0],), sigma, device=self.device)
         return self.inner(states, actions * c_in, s_in) * c_out + actions * c_skip
 
     def _sample(self, states, x):
-        sigmas = torch.cat([torch.linspace(self.sigma_max, self.sigma_min, self.n_steps, device=self.device), torch.zeros(1, device=self.device)])
+        sigmas = self.sigmas
         for i in range(len(sigmas) - 1):
-            s_from, s_to = float(sigmas[i]), float(sigmas[i + 1])
-            den = self._denoise(states, x, sigmas[i])
+            s_from, s_to = sigmas[i], sigmas[i + 1]
+            den = self._denoise(states, x, s_from)
             s_up = min(s_to, (s_to ** 2 * (s_from ** 2 - s_to ** 2) / s_from ** 2) ** 0.5)
             s_down = (s_to ** 2 - s_up ** 2) ** 0.5
-            x = x + (x - den) / sigmas[i] * (s_down - sigmas[i])
+            x = x + (x - den) / s_from * (s_down - s_from)
             if s_down > 0:
                 x = x + self.noise_fn(tuple(x.shape)) * s_up
         return x
+
+    def _sample_full(self, states, x):
+        """``_sample`` for full windows; with ``use_graph`` one HIP-graph replay instead of the eager kernel sequence."""
+        if not (self.use_graph and states.is_cuda and states.shape[1] == self.W):
+            return self._sample(states, x)
+        if self._graph is None or self._g_st.shape != states.shape:
+            self._g_st, self._g_x = states.clone(), x.clone()
+            side = torch.cuda.Stream(device=states.device)
+            side.wait_stream(torch.cuda.current_stream(states.device))
+            with torch.cuda.stream(side):                      # warm-up outside the capture (library handles, workspaces)
+                for _ in range(2):
+                    self._sample(self._g_st, self._g_x)
+            torch.cuda.current_stream(states.device).wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._g_out = self._sample(self._g_st, self._g_x)
+        self._g_st.copy_(states); self._g_x.copy_(x)
+        self._graph.replay()
+        return self._g_out
+
+    def _padded_inputs(self, noise):
+        """Lanes with different history lengths in ONE batch: the sequences are left-aligned and padded on the right to the window
+        size.  The transformer is causal and its position embedding counts from the first token, so the tokens of a lane never see
+        the padding behind them; the newest action of lane i sits at position len_i - 1."""
+        W, L = self.W, self.obs_hist.len
+        j = torch.arange(W, device=self.device)
+        src = ((W - L).unsqueeze(1) + j).clamp_max(W - 1)
+        st = torch.gather(self.obs_hist.buf, 1, src.unsqueeze(2).expand(-1, -1, self.obs_hist.buf.shape[2])) * (j < L.unsqueeze(1)).unsqueeze(2)
+        newest = (j == (L - 1).unsqueeze(1)).unsqueeze(2)
+        x = newest * noise
+        if self.act_hist is not None:
+            srca = ((W - L).unsqueeze(1) + j).clamp(0, W - 2)
+            xa = torch.gather(self.act_hist.buf, 1, srca.unsqueeze(2).expand(-1, -1, self.act_hist.buf.shape[2]))
+            x = x + xa * (j < (L - 1).unsqueeze(1)).unsqueeze(2)
+        return st, x
 
     @torch.no_grad()
     def predict_batch(self, obs):
@@ -348,15 +400,17 @@ class BESOPolicy:
             self.act_hist = _History(n, self.W - 1, act_dim, self.device) if self.W > 1 else None
         self.obs_hist.append(s)
         noise = self.noise_fn((n, 1, act_dim)) * self.sigma_max
-        x0_all = torch.empty(n, act_dim, device=self.device)
-        for L, idx in self.obs_hist.groups():
-            sel = slice(None) if idx is None else idx
-            st = self.obs_hist.buf[sel, self.W - L:]
-            x = noise[sel]
+        L = self.obs_hist.lockstep
+        if L >= 0:                             # all lanes have the same history length: the reference's shapes
+            st = self.obs_hist.buf[:, self.W - L:]
+            x = noise
             if L > 1:                          # previous actions: the action deque holds min(L - 1, W - 1) entries
-                x = torch.cat([self.act_hist.buf[sel, (self.W - 1) - (L - 1):], x], dim=1)
-            x0 = self._sample(st, x)[:, -1, :].clamp(self.min_action, self.max_action)
-            x0_all[sel] = x0
+                x = torch.cat([self.act_hist.buf[:, (self.W - 1) - (L - 1):], x], dim=1)
+            x0_all = self._sample_full(st, x)[:, -1, :].clamp(self.min_action, self.max_action)
+        else:                                  # lanes restarted at different times: one padded batch, no host synchronisation
+            st, x = self._padded_inputs(noise)
+            out = self._sample_full(st, x)
+            x0_all = out.gather(1, (self.obs_hist.len - 1).view(n, 1, 1).expand(-1, 1, act_dim)).squeeze(1).clamp(self.min_action, self.max_action)
         if self.act_hist is not None:
             self.act_hist.append(x0_all)
             self.act_hist.len = (self.obs_hist.len - 1).clamp_min(0).clamp_max(self.W - 1)

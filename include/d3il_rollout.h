@@ -126,6 +126,12 @@ int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32
  * Counterpart of starting the next trajectory in the rollout loops (avoiding_sim.py:45-54, pushing_sim.py:43-66). */
 int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream);
 
+/* Policy-side helper (batched policy adapters): causal self-attention of the reference's DiffusionGPT
+ * (agents/models/beso/agents/diffusion_agents/k_diffusion/score_gpts.py:15-80) for its short token sequences, fused: qkv f32
+ * [B * T][3 H D] (query | key | value per token), out f32 [B * T][H D]; softmax over the keys j <= i, scores scaled by
+ * 1 / sqrt(D).  Device pointers, T <= 32, D <= 32; needs no handle. */
+int d3il_attention_causal_f32(const float* qkv, float* out, int B, int T, int H, int D, void* stream);
+
 /* Per-context episode tally, filled by d3il_auto_reset before it resets: table i64 [n_ctx][D3IL_TALLY_ROW] (caller-owned device
  * memory, caller zeroes it), row ctx_id[env] (device i32[n_envs]; NULL = row 0) += {episodes, successes, successes by mode code}
  * with the mode code = Avoiding: 9-bit mode encoding; Pushing: info['mode'] + 1; Sorting: np.packbits code.  These are the
