@@ -7,7 +7,7 @@ O=gpurun_out/r02p; mkdir -p $O
 TASKS=${@:-"avoiding pushing sorting stacking"}
 for T in $TASKS; do
   X=""; K=k_${T}_step
-  if [ $T = stacking ]; then X="--steps 40 --warmup 5 --preroll 400"; fi
+  if [ $T = stacking ]; then X="--steps 100 --warmup 5"; fi
   if [ $T = avoiding ]; then python bench.py 2>/dev/null | tail -1 > $O/bench_line_$T.json; python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_${T}_20steps.json
   else python bench.py --task $T $X --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_$T.json; fi
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/prof_$T.log 2>&1
@@ -28,3 +28,10 @@ if echo $TASKS | grep -q avoiding; then
   for N in 4096 8192 16384 32768 65536 131072 262144; do python bench.py --envs $N --steps 120 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1; done > $O/avoiding_batch_sweep.jsonl
 fi
 ls -la $O
+# BASELINE configs 4 / 5 with their own policies (fixed random weights), and the Stacking phase timers (diagnostics build)
+if echo $TASKS | grep -q sorting; then python bench.py --task sorting --policy ddpm --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_sorting_ddpm.json; fi
+if echo $TASKS | grep -q stacking; then
+  python bench.py --task stacking --policy beso --steps 40 --warmup 5 --preroll 200 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_stacking_beso.json
+  D3IL_STATS_LIB=1 python tools/gpu_stack_phases.py 4096 > $O/stacking_phases.log 2>&1
+  python tools/gpu_beso_profile.py > $O/beso_policy_profile.log 2>&1
+fi
