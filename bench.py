@@ -401,9 +401,10 @@ def run(args):
         traffic, valu = None, None
         if pm is not None:
             traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
-            if task == "avoiding":
-                # binding resource: FP64 VALU issue.  Instruction count from the PMC pass, ~2/3 of the VALU stream is FP64
-                # arithmetic (static mix), an FMA counts 2 flop; peak = 78.6 TFLOP/s vector FP64 (whole chip, 1024 SIMDs)
+            if "SQ_INSTS_VALU" in pm and "SQ_WAVE_CYCLES" in pm:
+                # binding resource: FP64 VALU issue.  Instruction count from the PMC pass; ~2/3 of the VALU stream is FP64 arithmetic
+                # (static mix of the Avoiding kernel, used as the estimate for all tasks), an FMA counts 2 flop; lanes idle inside
+                # partially filled waves are counted as if they worked (an upper estimate); peak = 78.6 TFLOP/s vector FP64 (1024 SIMDs)
                 insts = pm["SQ_INSTS_VALU"]["mean_per_dispatch"]
                 tflops = insts * 0.66 * 1.6 * 64 / (k_ms * 1e-3) / 1e12
                 valu = {"bound": "fp64_valu", "source": pm_path, "valu_insts_per_launch": insts, "achieved_tflops_est": tflops,
