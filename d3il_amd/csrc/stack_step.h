@@ -200,7 +200,10 @@ D3IL_HD void sk_tri_closest_origin(const double* a, const double* b, const doubl
 #else
 #define SK_MPR_COUNT(x) ((void)0)
 #endif
-D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const SkShape b, double margin, double* out) {
+// SUP(dir, pt): support point of the Minkowski difference a - b in direction dir (sk_support on one lane; the device collision phase
+// spreads the hull vertices of a pair over a group of eight lanes)
+template <class SUP>
+D3IL_HD bool sk_mpr_t(const StackConsts& kc_, const SkShape a, const SkShape b, double margin, double* out, SUP sup) {
   D3IL_STACK_CONSTS(kc_, kc);
   SK_MPR_COUNT(g_calls++);
   SkPt P[4], v4;
@@ -215,7 +218,7 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
   if (sk_zero(P[0].v[0]) && sk_zero(P[0].v[1]) && sk_zero(P[0].v[2])) P[0].v[0] += 10 * 2.220446049250313e-16;
   for (int k = 0; k < 3; k++) dir[k] = -P[0].v[k];
   sk_norm3(dir);
-  sk_support(kc, a, b, dir, margin, P[1]);
+  sup(dir, P[1]);
   double dot = dot3(P[1].v, dir);
   if (sk_zero(dot) || dot < 0) return false;
   cross3(P[0].v, P[1].v, dir);
@@ -227,7 +230,7 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
     return true;
   }
   sk_norm3(dir);
-  sk_support(kc, a, b, dir, margin, P[2]);
+  sup(dir, P[2]);
   dot = dot3(P[2].v, dir);
   if (sk_zero(dot) || dot < 0) return false;
   for (int k = 0; k < 3; k++) { va[k] = P[1].v[k] - P[0].v[k]; vb[k] = P[2].v[k] - P[0].v[k]; }
@@ -235,7 +238,7 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
   if (dot3(dir, P[0].v) > 0) { SkPt t = P[1]; P[1] = P[2]; P[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
   for (int guard = 0; guard < 100; guard++) {
     SK_MPR_COUNT(g_disc++);
-    sk_support(kc, a, b, dir, margin, P[3]);
+    sup(dir, P[3]);
     dot = dot3(P[3].v, dir);
     if (sk_zero(dot) || dot < 0) return false;
     bool cont = false;
@@ -251,7 +254,7 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
     dot = dot3(dir, P[1].v);
     if (sk_zero(dot) || dot > 0) break;
     SK_MPR_COUNT(g_ref++);
-    sk_support(kc, a, b, dir, margin, v4);
+    sup(dir, v4);
     dot = dot3(v4.v, dir);
     if (!(sk_zero(dot) || dot > 0) || sk_reach_tol(P, v4, dir) || guard > 100) return false;
     sk_expand(P, v4);
@@ -259,7 +262,7 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
   for (int it = 0; ; it++) {                // penetration
     sk_portal_dir(P, dir);
     SK_MPR_COUNT((g_pen++, g_maxpen = it + 1 > g_maxpen ? it + 1 : g_maxpen));
-    sk_support(kc, a, b, dir, margin, v4);
+    sup(dir, v4);
     if (sk_reach_tol(P, v4, dir) || it > 50) {
       double w[3]; sk_tri_closest_origin(P[1].v, P[2].v, P[3].v, w);
       double depth = sqrt(dot3(w, w));
@@ -289,6 +292,9 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
     }
     sk_expand(P, v4);
   }
+}
+D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const SkShape b, double margin, double* out) {
+  return sk_mpr_t(kc_, a, b, margin, out, [&](const double* dir, SkPt& pt) { sk_support(kc_, a, b, dir, margin, pt); });
 }
 
 // ------------------------------------------------------------------------------------------------ contact rows
@@ -1203,6 +1209,40 @@ D3IL_HD void stack_substep_pre(const C& c0, const StackConsts& kc_, StackState& 
   ncon_out = ncon;
 }
 #if defined(__HIPCC__)
+// Support point of one shape by a group of EIGHT lanes that hold the same shape / direction: lane s of the group evaluates the hull
+// vertices s, s + 8, ...; the maximum and the lowest index within 1e-10 of it come from reductions over the group (xor shuffles with
+// masks 4, 2, 1 stay inside it) - the vertex sk_support1 finds with its two passes over the table.
+constexpr int SKG = 8, SKG_NV = (SK_MAXHV + SKG - 1) / SKG;
+__device__ __forceinline__ void sk_support1_group(const StackConsts& kc_, const SkShape& s, const double* dir, double margin, double* out, const int sub) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const double* R = s.R;
+  double dl[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2], R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
+  double loc[3];
+  if (s.hull) {
+    const int nv = kc.hull_nv;
+    double d[SKG_NV], bd = -1e300;
+#pragma unroll
+    for (int m = 0; m < SKG_NV; m++) {
+      const int v = sub + SKG * m;
+      d[m] = v < nv ? kc.hull_v[v][0] * dl[0] + kc.hull_v[v][1] * dl[1] + kc.hull_v[v][2] * dl[2] : -1e300;
+      bd = fmax(bd, d[m]);
+    }
+#pragma unroll
+    for (int m = SKG / 2; m >= 1; m >>= 1) bd = fmax(bd, __shfl_xor(bd, m));
+    const double thr = bd - 1e-10;
+    int best = 1 << 20;
+#pragma unroll
+    for (int m = SKG_NV - 1; m >= 0; m--) if (d[m] >= thr) best = sub + SKG * m;
+#pragma unroll
+    for (int m = SKG / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(best, m); best = o < best ? o : best; }
+    loc[0] = kc.hull_v[best][0]; loc[1] = kc.hull_v[best][1]; loc[2] = kc.hull_v[best][2];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) loc[k] = dl[k] >= -1e-10 ? s.half[k] : -s.half[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[k] = R[3 * k] * loc[0] + R[3 * k + 1] * loc[1] + R[3 * k + 2] * loc[2] + s.p[k] + 0.5 * margin * dir[k];
+}
 // Collision of the workgroup's environments with one lane per (environment, pair group), lane = group * SK_LANES + environment:
 //   group 0 .. 2  : box b against the static boxes          3 .. 5 : the box pairs (0, 1) (0, 2) (1, 2)
 //   group 6 .. 11 : box b against finger f: tip, hull (MPR)    12  : finger <-> finger (nearly closed gripper)
@@ -1298,10 +1338,42 @@ __device__ __attribute__((noinline)) void sk_collide_coop(const StackConsts& kc_
       for (int i = 0; i < m; i++) push(tmp[i], ba, bb, set);
     }
     SKP_TOC(14);
-    if (kind == 2) {
-      SkShape A{RA, pA, hA, hullA}, B{RB, pB, hB, hullB};
-      double r7[7];
-      if (sk_mpr(kc, A, B, margin, r7)) push(r7, ba, bb, set);
+    // MPR jobs: up to eight at a time, each on a GROUP of eight lanes (job j of the batch on lanes 8 j .. 8 j + 7).  The owner lane's
+    // shapes are fetched by its group, the portal iteration runs redundantly on the eight lanes (uniform inside a group) and the hull
+    // support function is spread over them (sk_support1_group: nine vertices per lane instead of 68 on one lane).
+    for (unsigned long long pend = __ballot(kind == 2); pend != 0;) {
+      const int grp8 = lane >> 3, sub = lane & 7;
+      int owner = -1;      // owner lane of this group's job (-1: no job in this batch)
+      unsigned long long batch = 0, rest = pend;
+      for (int j = 0; j < WAVE / SKG && rest != 0; j++) { const int L = __builtin_ctzll(rest); rest &= rest - 1; batch |= 1ull << L; if (j == grp8) owner = L; }
+      pend = rest;
+      const int src = owner >= 0 ? owner : lane;
+      double uRA[9], upA[3], uhA[3], uRB[9], upB[3], uhB[3];
+#pragma unroll
+      for (int k = 0; k < 9; k++) { uRA[k] = __shfl(RA[k], src); uRB[k] = __shfl(RB[k], src); }
+#pragma unroll
+      for (int k = 0; k < 3; k++) { upA[k] = __shfl(pA[k], src); uhA[k] = __shfl(hA[k], src); upB[k] = __shfl(pB[k], src); uhB[k] = __shfl(hB[k], src); }
+      const double um = __shfl(margin, src);
+      const int uhullA = __shfl(hullA, src), uhullB = __shfl(hullB, src);
+      double r7[7] = {0, 0, 0, 0, 0, 0, 0};
+      int hit = 0;
+      if (owner >= 0) {
+        const SkShape A{uRA, upA, uhA, uhullA}, B{uRB, upB, uhB, uhullB};
+        hit = sk_mpr_t(kc, A, B, um, r7, [&](const double* dir, SkPt& pt) {
+          const double nd[3] = {-dir[0], -dir[1], -dir[2]};
+          sk_support1_group(kc, A, dir, um, pt.v1, sub); sk_support1_group(kc, B, nd, um, pt.v2, sub);
+#pragma unroll
+          for (int k = 0; k < 3; k++) pt.v[k] = pt.v1[k] - pt.v2[k];
+        }) ? 1 : 0;
+      }
+      // results back to the owner lanes: owner L reads lane 8 * (rank of L in the batch)
+      const bool mine = ((batch >> lane) & 1ull) != 0;
+      const int from = mine ? SKG * __popcll(batch & ((1ull << lane) - 1ull)) : lane;
+      const int ghit = __shfl(hit, from);
+      double g7[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) g7[k] = __shfl(r7[k], from);
+      if (mine && ghit) push(g7, ba, bb, set);
     }
     SKP_TOC(15);
   }
