@@ -888,7 +888,7 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
         s += s2;
         double sj = sk_bcast(s, j);
         if (!(sj > 0)) { ok = false; sj = 1; }
-        const double d = sqrt(sj), di = 1.0 / d;
+        const double di = rsqrtd(sj), d = sj * di;      // v_rsq_f64 + two Newton steps instead of a square root and a division
         Lr[j] = i == j ? d : (i > j ? s * di : 0.0);
         if (i == j) dinv = di;
       }
