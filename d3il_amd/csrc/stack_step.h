@@ -710,15 +710,26 @@ __device__ __forceinline__ double sk_bcast(double v, int src /* wave-uniform */)
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
   const unsigned long long r = ((unsigned long long)hi << 32) | lo; double out; __builtin_memcpy(&out, &r, 8); return out;
 }
+// Reductions over the 64 lanes (all active): butterfly inside the rows of 16 lanes with DPP moves (quad permutes, half-row and row
+// mirrors: no LDS crossbar round trips), then the four row results through v_readlane.  Every lane gets the result.
+__device__ __forceinline__ double sk_dpp_mov(double v, const int ctrl_sel) {
+  unsigned long long u; __builtin_memcpy(&u, &v, 8);
+  int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+  switch (ctrl_sel) {      // compile-time selector -> immediate DPP control
+    case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+    case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+    default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+  }
+  const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; double out; __builtin_memcpy(&out, &r, 8); return out;
+}
 __device__ __forceinline__ double sk_wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
+  v += sk_dpp_mov(v, 0); v += sk_dpp_mov(v, 1); v += sk_dpp_mov(v, 2); v += sk_dpp_mov(v, 3);      // every lane: the sum of its row of 16
+  return (sk_bcast(v, 0) + sk_bcast(v, 16)) + (sk_bcast(v, 32) + sk_bcast(v, 48));
 }
 __device__ __forceinline__ double sk_wave_max(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-  return v;
+  v = fmax(v, sk_dpp_mov(v, 0)); v = fmax(v, sk_dpp_mov(v, 1)); v = fmax(v, sk_dpp_mov(v, 2)); v = fmax(v, sk_dpp_mov(v, 3));
+  return fmax(fmax(sk_bcast(v, 0), sk_bcast(v, 16)), fmax(sk_bcast(v, 32), sk_bcast(v, 48)));
 }
 constexpr int SKC_NJ = 15;                       // columns of a contact row in the J area
 constexpr int SKC_JSIZE = 4 * SKC_NJ * SK_MAXCON;   // doubles per wave
