@@ -300,27 +300,32 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
 // ------------------------------------------------------------------------------------------------ contact rows
 // elliptic cone of dimension dim (3 or 4): force and Hessian block at the row residuals jar; D[r] = 1 / R[r], fr[j] = friction
 // coefficient of row j + 1 (tangent, tangent, torsional).  Zones as in MuJoCo's PGS / Newton cone [ext]; mirrors cone_eval (dim 3).
-D3IL_HD void sk_cone(int dim, const double* jar, const double* D, double mu, const double* fr, double* force, double* Hc /* 4 x 4 */) {
+// imu = 1 / max(1e-15, mu^2 (1 + mu^2)) is a constant of the contact
+D3IL_HD void sk_cone_pre(int dim, const double* jar, const double* D, double mu, double imu, const double* fr, double* force, double* Hc /* 4 x 4 */) {
 #pragma unroll
   for (int i = 0; i < 16; i++) Hc[i] = 0;
   double U[4] = {jar[0] * mu, 0, 0, 0}, T2 = 0;
   for (int j = 1; j < dim; j++) { U[j] = jar[j] * fr[j - 1]; T2 += U[j] * U[j]; }
-  const double N = U[0], T = sqrt(T2);
+  const double N = U[0], iT = T2 > 0 ? rsqrtd(T2) : 0.0, T = T2 * iT;      // 1 / T by v_rsq_f64 + Newton steps: no square root, no divisions below
   if (N >= mu * T || (T <= 0 && N >= 0)) { force[0] = force[1] = force[2] = force[3] = 0; return; }
   if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
     for (int j = 0; j < 4; j++) { force[j] = j < dim ? -D[j] * jar[j] : 0.0; if (j < dim) Hc[5 * j] = D[j]; }
     return;
   }
-  const double Dm = D[0] / fmax(1e-15, mu * mu * (1 + mu * mu)), NmT = N - mu * T;
-  double g[4] = {mu, 0, 0, 0};
-  for (int j = 1; j < dim; j++) g[j] = -mu * fr[j - 1] * U[j] / T;
+  const double Dm = D[0] * imu, NmT = N - mu * T;
+  double g[4] = {mu, 0, 0, 0}, Un[4] = {0, 0, 0, 0};      // Un = U / T
+  for (int j = 1; j < dim; j++) { Un[j] = U[j] * iT; g[j] = -mu * fr[j - 1] * Un[j]; }
   for (int j = 0; j < 4; j++) force[j] = j < dim ? -Dm * NmT * g[j] : 0.0;
+  const double kT = NmT * (-mu) * iT;
   for (int a = 0; a < dim; a++)
     for (int b = 0; b < dim; b++) {
       double h = g[a] * g[b];
-      if (a > 0 && b > 0) h += NmT * (-mu) * fr[a - 1] * fr[b - 1] * ((a == b ? 1.0 / T : 0.0) - U[a] * U[b] / (T * T * T));
+      if (a > 0 && b > 0) h += kT * fr[a - 1] * fr[b - 1] * ((a == b ? 1.0 : 0.0) - Un[a] * Un[b]);
       Hc[4 * a + b] = Dm * h;
     }
+}
+D3IL_HD void sk_cone(int dim, const double* jar, const double* D, double mu, const double* fr, double* force, double* Hc /* 4 x 4 */) {
+  sk_cone_pre(dim, jar, D, mu, 1.0 / fmax(1e-15, mu * mu * (1 + mu * mu)), fr, force, Hc);
 }
 // Rows of a contact.  The four body pairings have compile-time sizes, so their row blocks live in registers:
 //   (NA, NB) = (0, 6) static-box, (6, 6) box-box, (6, 9) box-finger, (0, 9) finger-finger (one row set J(finger B) - J(finger A)).
@@ -734,7 +739,7 @@ __device__ __forceinline__ double sk_wave_max(double v) {
 constexpr int SKC_NJ = 15;                       // columns of a contact row in the J area
 constexpr int SKC_JSIZE = 4 * SKC_NJ * SK_MAXCON;   // doubles per wave
 #define SKJ(r, k) Jw[((r) * SKC_NJ + (k)) * SK_MAXCON + lane]
-struct SkCoopCon { int oa, ob, na, nb, dim; double aref[4], D[4], mu, fr[3]; };
+struct SkCoopCon { int oa, ob, na, nb, dim; double aref[4], D[4], mu, imu, fr[3]; };
 template <int NA, int NB>
 __device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, const StackScratch sc, sk_lds_double* Jw, int lane, SkCoopCon& cc) {
   D3IL_STACK_CONSTS(kc_, kc);
@@ -765,6 +770,7 @@ __device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, 
   }
   cc.D[0] = 1 / R0; cc.D[1] = 1 / R1; cc.D[2] = 1 / R1; cc.D[3] = 1 / (R1 * ps.fric[0] * ps.fric[0] / (ps.fric[1] * ps.fric[1]));
   cc.mu = ps.fric[0] * sqrt(R1 / R0);
+  cc.imu = 1.0 / fmax(1e-15, cc.mu * cc.mu * (1 + cc.mu * cc.mu));
   sk_row_fric(ps, cc.fr);
 }
 
@@ -780,7 +786,7 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
   SK_TIC;
   // ---- contacts: rows, reference accelerations, regularisation
   SkCoopCon cc;
-  cc.oa = 0; cc.ob = 0; cc.na = 0; cc.nb = 6; cc.dim = 3; cc.mu = 1;
+  cc.oa = 0; cc.ob = 0; cc.na = 0; cc.nb = 6; cc.dim = 3; cc.mu = 1; cc.imu = 0.5;
 #pragma unroll
   for (int r = 0; r < 4; r++) { cc.aref[r] = 0; cc.D[r] = 1; }
   cc.fr[0] = cc.fr[1] = cc.fr[2] = 1;
@@ -840,7 +846,7 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
         for (int k = 0; k < SKC_NJ; k++) { J[r][k] = SKJ(r, k); s += J[r][k] * xk[k]; }
         jar[r] = s - cc.aref[r];
       }
-      sk_cone(cc.dim, jar, cc.D, cc.mu, cc.fr, f, Hc);
+      sk_cone_pre(cc.dim, jar, cc.D, cc.mu, cc.imu, cc.fr, f, Hc);
       bool any = false;
 #pragma unroll
       for (int q = 0; q < 16; q++) any = any || Hc[q] != 0;
@@ -957,7 +963,7 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
         double jt[4], f[4], Hc[16];
 #pragma unroll
         for (int r = 0; r < 4; r++) jt[r] = jar[r] + alpha * jp[r];
-        sk_cone(cc.dim, jt, cc.D, cc.mu, cc.fr, f, Hc);
+        sk_cone_pre(cc.dim, jt, cc.D, cc.mu, cc.imu, cc.fr, f, Hc);
 #pragma unroll
         for (int r = 0; r < 4; r++) { d1c -= f[r] * jp[r];
 #pragma unroll
