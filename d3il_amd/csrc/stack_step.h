@@ -853,9 +853,9 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
       if (any) {
 #pragma unroll
         for (int k = 0; k < SKC_NJ; k++) {
-          if (k >= 6 + cc.nb || (k < 6 && cc.oa == cc.ob && false)) continue;
+          if (k >= 6 + cc.nb || (k < 6 && cc.na == 0)) continue;      // structural zeros: columns beyond body 2's block, a static body 1
           const double acc = J[0][k] * f[0] + J[1][k] * f[1] + J[2][k] * f[2] + J[3][k] * f[3];
-          if (acc != 0) (void)__hip_atomic_fetch_add(&t[ST_G + col(k)], -acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_add(&t[ST_G + col(k)], -acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (with_h) {
 #pragma unroll
@@ -864,13 +864,17 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
             double w[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) w[q] = J[0][a] * Hc[q] + J[1][a] * Hc[4 + q] + J[2][a] * Hc[8 + q] + J[3][a] * Hc[12 + q];
-            if (w[0] == 0 && w[1] == 0 && w[2] == 0 && w[3] == 0) continue;      // zero column (body 1 static, or a row beyond dim)
+            if (w[0] == 0 && w[1] == 0 && w[2] == 0 && w[3] == 0) continue;      // zero column (body 1 static, the other finger's slide dof)
             const int ra = col(a);
+            // column index <= row index in dof order: body 1's block precedes body 2's.  No test per entry: the blocks are dense
+            if (a >= 6 && cc.na > 0) {
 #pragma unroll
-            for (int b = 0; b <= a; b++) {      // column index <= row index in dof order: body 1's block precedes body 2's
-              const double v = w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b];
-              if (v != 0) (void)__hip_atomic_fetch_add(&t[ST_H + tri(ra, col(b))], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              for (int b = 0; b < 6; b++)
+                (void)__hip_atomic_fetch_add(&t[ST_H + tri(ra, cc.oa + b)], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+#pragma unroll
+            for (int b = (a < 6 ? 0 : 6); b <= a; b++)
+              (void)__hip_atomic_fetch_add(&t[ST_H + tri(ra, col(b))], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
       }
