@@ -116,6 +116,34 @@ def _cpu_worker(task, blob_bytes, init_qpos, contexts, budget_s, seed):
     return n, time.perf_counter() - t0
 
 
+def _available_cores():
+    """(cores this process may use, logical CPUs of the host): the scheduler affinity capped by the cgroup CPU quota (cpu.max of cgroup
+    v2, cfs_quota_us / cfs_period_us of v1) - a container with a 16-CPU quota on a 256-thread host runs 16 workers, not 256."""
+    logical = os.cpu_count() or 1
+    cores = logical
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        cores = max(1, min(cores, int(quota + 0.5)))
+    return cores, logical
+
+
 def cpu_baseline(task, blob, init_qpos, contexts, budget_s=10.0):
     """The oracle timed on the GPU box's host cores on a bounded sample of the same workload: first one environment on one core,
     then one environment per core on all cores (independent OS processes, like the reference's n_cores workers; plain
@@ -123,11 +151,7 @@ def cpu_baseline(task, blob, init_qpos, contexts, budget_s=10.0):
     import tempfile
     import numpy as np
     n1, t1 = _cpu_worker(task, bytes(blob), init_qpos, contexts, budget_s * 0.5, 0)
-    cores = os.cpu_count() or 1
-    try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
+    cores, logical = _available_cores()
     with tempfile.TemporaryDirectory() as td:
         arg = os.path.join(td, "args.npz")
         np.savez(arg, blob=np.frombuffer(bytes(blob), dtype=np.uint8), init_qpos=np.asarray(init_qpos, dtype=np.float64),
@@ -143,8 +167,8 @@ def cpu_baseline(task, blob, init_qpos, contexts, budget_s=10.0):
     busy = max(r[1] for r in res) if res else float("nan")
     pol = {"avoiding": "random policy", "stacking": "scripted pick-and-place"}.get(task, "ResidualMLP stand-in policy on the CPU")
     return {"value": total / busy, "unit": "env-steps/s", "cores": len(res), "kind": "port",
-            "single_core_value": n1 / t1,
-            "sample": "one oracle environment per core on all %d host cores (%s, %d env steps of 35 (Stacking: 30) sub-steps in %.1f s of stepping per worker, %.1f s wall "
+            "single_core_value": n1 / t1, "host_logical_cpus": logical,
+            "sample": "one oracle environment per core on all %d cores this container may use (affinity capped by the cgroup CPU quota) (%s, %d env steps of 35 (Stacking: 30) sub-steps in %.1f s of stepping per worker, %.1f s wall "
                       "including interpreter start-up), after one environment on one core (%d env steps in %.1f s); scalar C oracle (oracle/d3il_oracle.c, the CPU "
                       "restatement of the reference path - the Python reference itself is bounded above by 146 env-steps/s/core, BASELINE.md section 2)"
                       % (len(res), pol, total, busy, wall, n1, t1)}
