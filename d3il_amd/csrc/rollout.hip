@@ -267,6 +267,31 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_auto_reset(const PandaConsts*
 // by ONE fused linear layer), out: f32 [B * T][C] in token-major layout (what the output projection reads) - no transposes, no
 // [B, H, T, T] score tensor, no batched GEMM of 11 x 20 matrices.  Softmax over the keys j <= i with the 1 / sqrt(D) scaling
 // (score_gpts.py:59-76).  D <= 32, T <= 32.
+// LayerNorm over the last dimension for the narrow rows of the policy transformer (C = 120): 32 lanes per row, four consecutive
+// floats per lane (C <= 128, C a multiple of 4), two rows per wave; mean and variance by xor shuffles inside the half wave; the
+// biased variance and eps inside the square root like torch.nn.LayerNorm.  x, y: f32 [rows][C].
+__global__ __launch_bounds__(256) void k_layernorm_f32(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                                                       long rows, int C, float eps) {
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int sub = threadIdx.x & 31;
+  const bool live = row < rows && 4 * sub < C;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) v = reinterpret_cast<const float4*>(x + row * C)[sub];
+  float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  const float mean = s / (float)C;
+  const float dx = live ? v.x - mean : 0.f, dy = live ? v.y - mean : 0.f, dz = live ? v.z - mean : 0.f, dw = live ? v.w - mean : 0.f;
+  float q = dx * dx + dy * dy + dz * dz + dw * dw;
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+  const float inv = rsqrtf(q / (float)C + eps);
+  if (live) {
+    const float4 ww = reinterpret_cast<const float4*>(w)[sub], bb = reinterpret_cast<const float4*>(b)[sub];
+    reinterpret_cast<float4*>(y + row * C)[sub] = make_float4(dx * inv * ww.x + bb.x, dy * inv * ww.y + bb.y, dz * inv * ww.z + bb.z, dw * inv * ww.w + bb.w);
+  }
+}
+
 template <int D4>      // D4 = D / 4 float4 chunks per head row (D a multiple of 4: 16-byte loads), or 0: scalar loads for any D <= 32
 __global__ __launch_bounds__(256) void k_attention_causal_f32(const float* __restrict__ qkv, float* __restrict__ out, int B, int T, int H, int D) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // ((b * H) + h) * T + i: the queries of one (b, h) sit in adjacent lanes
@@ -776,6 +801,16 @@ int d3il_attention_causal_f32(const float* qkv, float* out, int B, int T, int H,
   else if (aligned && D == 16) hipLaunchKernelGGL(k_attention_causal_f32<4>, grid, block, 0, (hipStream_t)stream, qkv, out, B, T, H, D);
   else if (aligned && D == 32) hipLaunchKernelGGL(k_attention_causal_f32<8>, grid, block, 0, (hipStream_t)stream, qkv, out, B, T, H, D);
   else hipLaunchKernelGGL(k_attention_causal_f32<0>, grid, block, 0, (hipStream_t)stream, qkv, out, B, T, H, D);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_layernorm_f32(const float* x, const float* weight, const float* bias, float* y, long rows, int C, float eps, void* stream) {
+  if (!x || !weight || !bias || !y) return fail(D3IL_EINVAL, "d3il_layernorm_f32: null argument");
+  if (rows < 0 || C < 4 || C > 128 || C % 4 != 0) return fail(D3IL_EINVAL, "d3il_layernorm_f32: needs 4 <= C <= 128, C a multiple of 4");
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias) % 16 != 0) return fail(D3IL_EINVAL, "d3il_layernorm_f32: pointers must be 16-byte aligned");
+  if (rows == 0) return D3IL_OK;
+  const long threads = rows * 32;
+  hipLaunchKernelGGL(k_layernorm_f32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, rows, C, eps);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }

@@ -132,6 +132,11 @@ int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream)
  * 1 / sqrt(D).  Device pointers, T <= 32, D <= 32; needs no handle. */
 int d3il_attention_causal_f32(const float* qkv, float* out, int B, int T, int H, int D, void* stream);
 
+/* Policy-side helper: LayerNorm over the last dimension (torch.nn.LayerNorm semantics) for rows of 4 .. 128 floats (a multiple of 4):
+ * the transformer of the reference's BESO policy normalises [B * T][120] activations 13 times per denoising call
+ * (score_gpts.py:83-115, :353).  x, y f32 [rows][C]; 16-byte aligned device pointers. */
+int d3il_layernorm_f32(const float* x, const float* weight, const float* bias, float* y, long rows, int C, float eps, void* stream);
+
 /* Per-context episode tally, filled by d3il_auto_reset before it resets: table i64 [n_ctx][D3IL_TALLY_ROW] (caller-owned device
  * memory, caller zeroes it), row ctx_id[env] (device i32[n_envs]; NULL = row 0) += {episodes, successes, successes by mode code}
  * with the mode code = Avoiding: 9-bit mode encoding; Pushing: info['mode'] + 1; Sorting: np.packbits code.  These are the

@@ -166,6 +166,23 @@ def test_fused_attention_kernel_equals_torch_math():
 
 
 @pytest.mark.gpu
+def test_fused_layernorm_kernel_equals_torch():
+    from d3il_amd import capi
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    for rows, C_ in ((45056, 120), (7, 128), (1, 4), (333, 64)):
+        x = (torch.randn(rows, C_, generator=g) * 3 + 0.5).to(dev)
+        ln = torch.nn.LayerNorm(C_).to(dev)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(C_, generator=g)); ln.bias.copy_(torch.randn(C_, generator=g))
+        y = torch.empty_like(x)
+        capi.check(capi.load().d3il_layernorm_f32(x.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), y.data_ptr(), rows, C_, float(ln.eps), torch.cuda.current_stream(dev).cuda_stream))
+        ref = torch.nn.functional.layer_norm(x.double(), (C_,), ln.weight.double(), ln.bias.double(), ln.eps)
+        assert float((y.double() - ref).abs().max()) < 2e-5
+    assert capi.load().d3il_layernorm_f32(x.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), y.data_ptr(), 4, 130, 1e-5, 0) != 0      # C > 128 is refused
+
+
+@pytest.mark.gpu
 def test_beso_graph_replay_equals_eager():
     """use_graph: the captured sampling loop gives the eager result for the same generator state."""
     import bench
