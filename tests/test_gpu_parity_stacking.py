@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SK_BOX_Z = 28 + 2          # state row of the red box's z
 BAD = (1 << 16) | (1 << 18) | (1 << 19)          # solver fail, contact overflow, off table
 
 
@@ -95,6 +96,41 @@ def test_pick_and_place_followed_by_the_oracle(stack_js, stack_blob, ctx100):
         for e in range(k + 4, n, 4):
             assert np.array_equal(st[:67, e], ref)
     env.close()
+
+
+def test_full_size_results_do_not_depend_on_lane_or_workgroup(stack_js, ctx100):
+    """4096 environments (BASELINE config 5's per-GPU size) through a grasp-and-lift: every lane of a context ends bit-identical, whether
+    the four environments of a workgroup belong to four different contexts (cooperative solves of different sizes side by side,
+    lane-per-pair collision with mixed jobs) or to one."""
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    ids = [0, 3, 11, 42]
+    n = 4096
+    finals = []
+    for mixed in (True, False):
+        which = (np.arange(n) % 4) if mixed else (np.arange(n) // (n // 4))
+        env = _env(n)
+        q0, _, _ = env.start()
+        env.reset(context=ctx100[[ids[w] for w in which]])
+        trajs = [build_trajectory(stack_js, q0, ctx100[i], n_boxes=1, speed=0.8) for i in ids]
+        T = min(min(len(t) for t in trajs), 90)                 # approach, grasp, lift
+        sel = torch.as_tensor(which, device=env.device)
+        for t in range(T):
+            act = torch.as_tensor(np.stack([tr[t] for tr in trajs]), dtype=torch.float64, device=env.device)[sel].contiguous()
+            env.step(act)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        assert not (fl & BAD).any()
+        per_ctx = []
+        for k in range(4):
+            lanes = np.nonzero(which == k)[0]
+            ref = st[:67, lanes[0]]
+            assert all(np.array_equal(st[:67, e], ref) for e in lanes[1:])
+            per_ctx.append(ref.copy())
+        finals.append(per_ctx)
+        assert max(float(p[SK_BOX_Z]) for p in per_ctx) > 0.05          # the red boxes are off the table
+        env.close()
+    for k in range(4):
+        assert np.array_equal(finals[0][k], finals[1][k])
 
 
 @pytest.mark.parametrize("strict", [0, 1])
