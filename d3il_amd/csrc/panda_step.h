@@ -1492,17 +1492,18 @@ template <class C> D3IL_HD void step_begin(const C& c, EnvState& st, float* obs,
 // A NaN / Inf action (a diverged policy) must not reach the dynamics: integer test of the exponent field, which
 // -ffinite-math-only cannot fold away.  A bad action is replaced by a fixed reachable set-point; the caller flags the lane
 // (F_SOLVER_FAIL | F_TERMINATED).  The reference has no such check (MuJoCo would warn and reset its data on the NaN qacc).
-D3IL_HD bool sanitize_action(double* act) {
+// The test reads the action words from MEMORY as integers (memcpy from the source pointer): tested on an already loaded double, the
+// exponent pattern is recognised as an fp-class test and -ffinite-math-only folds its NaN half away (seen in the Stacking kernel:
+// Inf was caught, NaN was not).
+D3IL_HD bool action_is_bad(const double* __restrict__ a, int count = 7) {
   bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 7; k++) { unsigned long long b; __builtin_memcpy(&b, &act[k], 8); bad = bad || ((b >> 52) & 0x7ffull) == 0x7ffull; }
-  if (bad) { act[0] = 0.5; act[1] = 0.0; act[2] = 0.3; act[3] = 0.0; act[4] = 1.0; act[5] = 0.0; act[6] = 0.0; }
+  for (int k = 0; k < count; k++) { unsigned long long b; __builtin_memcpy(&b, a + k, 8); bad = bad || ((b >> 52) & 0x7ffull) == 0x7ffull; }
   return bad;
 }
-D3IL_HD bool action_is_bad(const double* __restrict__ a) {
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 7; k++) { unsigned long long b; __builtin_memcpy(&b, &a[k], 8); bad = bad || ((b >> 52) & 0x7ffull) == 0x7ffull; }
+// act: the action as loaded, mem: where it was loaded from
+D3IL_HD bool sanitize_action(double* act, const double* __restrict__ mem) {
+  const bool bad = action_is_bad(mem);
+  if (bad) { act[0] = 0.5; act[1] = 0.0; act[2] = 0.3; act[3] = 0.0; act[4] = 1.0; act[5] = 0.0; act[6] = 0.0; }
   return bad;
 }
 D3IL_HD void make_setpoint(const double* action, double* des) {

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_pushing_step_split(double* __restr
 #pragma unroll
       for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
       fl = flags[e];
-      sanitize_action(act);
+      sanitize_action(act, actions + (size_t)e * 7);
       make_setpoint(act, des);
     }
 #pragma clang loop unroll(disable)

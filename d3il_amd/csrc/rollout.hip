@@ -82,7 +82,7 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_step(const PandaConsts* __res
   double act[7];
 #pragma unroll
   for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
-  const bool bad_action = sanitize_action(act);
+  const bool bad_action = sanitize_action(act, actions + (size_t)e * 7);
   float o[2]; unsigned char dn;
 #if defined(D3IL_DEVICE_STATS)
   unsigned long long t0 = wall_clock64();
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
 #pragma unroll
     for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
     unsigned fl = flags[e];
-    sanitize_action(act);
+    sanitize_action(act, actions + (size_t)e * 7);
     make_setpoint(act, des);
     double vwarm[7];
     vwarm[6] = 0.0; trg[0][2 * NARM][lane] = 0.0;

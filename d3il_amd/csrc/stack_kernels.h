@@ -70,7 +70,8 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
   if (live) {
     stack_load(state, flags, steps, stride, e, ss);
 #pragma unroll
-    for (int k = 0; k < SK_ACT; k++) { act[k] = actions[(size_t)e * SK_ACT + k]; unsigned long long b; __builtin_memcpy(&b, &act[k], 8); bad = bad || ((b >> 52) & 0x7ffull) == 0x7ffull; }
+    for (int k = 0; k < SK_ACT; k++) act[k] = actions[(size_t)e * SK_ACT + k];
+    bad = action_is_bad(actions + (size_t)e * SK_ACT, SK_ACT);      // integer test on the words in memory (see panda_step.h)
     if (bad) {    // NaN / Inf action: hold the current joints with an open gripper; the lane is flagged and terminated
 #pragma unroll
       for (int k = 0; k < NARM; k++) act[k] = ss.arm.q[k];

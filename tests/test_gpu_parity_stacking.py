@@ -133,6 +133,53 @@ def test_full_size_results_do_not_depend_on_lane_or_workgroup(stack_js, ctx100):
         assert np.array_equal(finals[0][k], finals[1][k])
 
 
+@pytest.mark.parametrize("n", [1, 5, 4097])
+def test_ragged_batches_masked_reset_and_bad_actions(stack_js, ctx100, n):
+    """Batch sizes that do not fill the last workgroup (4 environments each), a masked reset of single environments, a NaN / Inf action:
+    the affected lanes are handled, every other lane equals the lane of a plain run bit for bit."""
+    from d3il_amd import capi
+    env, ref = _env(n), _env(n)
+    q0, _, _ = env.start(); ref.start()
+    ctx = ctx100[np.arange(n) % 7]
+    env.reset(context=ctx); ref.reset(context=ctx)
+    a0 = torch.cat([torch.as_tensor(q0, dtype=torch.float64, device=env.device).expand(n, 7), torch.ones(n, 1, dtype=torch.float64, device=env.device)], dim=1)
+    acts = [(a0 + 0.003 * (t + 1) * torch.tensor([1, -1, 1, -1, 1, -1, 1, 0], dtype=torch.float64, device=env.device)).contiguous() for t in range(6)]
+    for t in range(3):
+        env.step(acts[t]); ref.step(acts[t])
+    torch.cuda.synchronize()
+    s_env, _, _ = env.get_state(); s_ref, _, _ = ref.get_state()
+    assert np.array_equal(s_env[:67], s_ref[:67])
+    # masked reset of the last environment (and of environment 2 when there is one)
+    mask = torch.zeros(n, dtype=torch.uint8, device=env.device); mask[n - 1] = 1
+    if n > 2:
+        mask[2] = 1
+    env.reset(mask=mask)
+    torch.cuda.synchronize()
+    s1, f1, c1 = env.get_state()
+    fresh = _env(n); fresh.start(); fresh.reset(context=ctx); torch.cuda.synchronize()
+    s0, _, _ = fresh.get_state(); fresh.close()
+    hit = mask.cpu().numpy().astype(bool)
+    assert np.array_equal(s1[:67, hit], s0[:67, hit]) and (c1[:n][hit] == 0).all()            # restarted on their own context
+    assert np.array_equal(s1[:67, ~hit], s_ref[:67, ~hit]) and (c1[:n][~hit] == 3).all()       # the others untouched
+    # a NaN / Inf action: flagged and terminated, state finite, neighbours of the same workgroup unaffected
+    bad = acts[3].clone(); bad[0, 2] = float("nan")
+    if n > 4:
+        bad[4, 7] = float("inf")
+    env.step(bad)
+    good = env.robot_state()          # (forces the kernel to finish before the next reset)
+    torch.cuda.synchronize()
+    s2, f2, _ = env.get_state()
+    assert np.isfinite(s2[:67]).all()
+    flagged = (f2[:n] & capi.FLAG_SOLVER_FAIL) != 0
+    assert flagged[0] and flagged.sum() == (2 if n > 4 else 1) and (f2[:n][flagged] & capi.FLAG_TERMINATED).all()
+    if n > 1:      # lane 1 shares the workgroup of lane 0: compare with a run that has no bad action
+        ref.reset(mask=mask); ref.step(acts[3]); torch.cuda.synchronize()
+        s3, _, _ = ref.get_state()
+        ok = ~flagged
+        assert np.array_equal(s2[:67, ok], s3[:67, ok])
+    env.close(); ref.close()
+
+
 @pytest.mark.parametrize("strict", [0, 1])
 def test_one_step_parity_from_mid_episode_states(stack_js, stack_blob, ctx100, strict):
     from d3il_amd.controllers.scripted_stacking import build_trajectory
