@@ -89,12 +89,15 @@ def test_nan_action_is_flagged_not_propagated():
     from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
     from d3il_amd.envs.pushing import BlockPushVecEnv
     ctx60 = np.load(os.path.join(ROOT, "d3il_amd", "data", "pushing_test_contexts.npy"))
-    for cls in (ObstacleAvoidanceVecEnv, BlockPushVecEnv):
+    from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
+    for cls in (ObstacleAvoidanceVecEnv, BlockPushVecEnv, SortingVecEnv):
         n = 70
         env = cls(n, device=0)
-        env.set_init_qpos(G["avoiding__traj_last"].copy())
+        env.set_init_qpos(G["sorting__traj_last" if cls is SortingVecEnv else "avoiding__traj_last"].copy())
         if cls is BlockPushVecEnv:
             env.reset(context=ctx60[np.arange(n) % 60])
+        elif cls is SortingVecEnv:
+            env.reset(context=sample_contexts(n, 4, seed=3))
         else:
             env.reset()
         rs = env.robot_state().clone()
