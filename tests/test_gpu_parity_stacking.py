@@ -180,6 +180,37 @@ def test_ragged_batches_masked_reset_and_bad_actions(stack_js, ctx100, n):
     env.close(); ref.close()
 
 
+def test_state_snapshot_restores_the_rollout_exactly(stack_js, ctx100):
+    """d3il_get_state / d3il_set_state carry everything a rollout depends on (arm, boxes, the solver's warm start, flags, counters):
+    restoring a mid-grasp snapshot and repeating the steps reproduces the continuation bit for bit."""
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    n = 9
+    env = _env(n)
+    q0, _, _ = env.start()
+    env.reset(context=ctx100[np.arange(n) % 3])
+    trajs = [build_trajectory(stack_js, q0, ctx100[i], n_boxes=1, speed=0.8) for i in range(3)]
+
+    def act(t):
+        return torch.as_tensor(np.stack([trajs[i % 3][t] for i in range(n)]), dtype=torch.float64, device=env.device).contiguous()
+
+    for t in range(70):           # into the grasp
+        env.step(act(t))
+    torch.cuda.synchronize()
+    snap = env.get_state()
+    for t in range(70, 80):
+        env.step(act(t))
+    torch.cuda.synchronize()
+    a_state, a_flags, a_steps = env.get_state()
+    env.set_state(*snap)
+    for t in range(70, 80):
+        env.step(act(t))
+    torch.cuda.synchronize()
+    b_state, b_flags, b_steps = env.get_state()
+    assert np.array_equal(a_state, b_state) and np.array_equal(a_flags, b_flags) and np.array_equal(a_steps, b_steps)
+    assert not (a_flags & BAD).any()
+    env.close()
+
+
 @pytest.mark.parametrize("strict", [0, 1])
 def test_one_step_parity_from_mid_episode_states(stack_js, stack_blob, ctx100, strict):
     from d3il_amd.controllers.scripted_stacking import build_trajectory
