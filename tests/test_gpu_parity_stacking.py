@@ -10,6 +10,11 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SK_BOX_Z = 28 + 2          # state row of the red box's z
+def CubeStackingVecEnv_(n, cap):
+    from d3il_amd.envs.stacking import CubeStackingVecEnv
+    return CubeStackingVecEnv(n, device=0, max_steps_per_episode=cap)
+
+
 BAD = (1 << 16) | (1 << 18) | (1 << 19)          # solver fail, contact overflow, off table
 
 
@@ -247,6 +252,37 @@ def test_one_step_parity_from_mid_episode_states(stack_js, stack_blob, ctx100, s
                 checked += 1
     assert checked > 40 and grasp > 5
     assert worst_p < 1e-7 and worst_v < 1e-5, (worst_p, worst_v)       # north star 1e-4
+    env.close()
+
+
+def test_device_auto_reset_restarts_lanes_on_their_contexts(ctx100):
+    """d3il_auto_reset for Stacking: finished lanes (episode cap) are tallied per context, restarted on the context they were created
+    with, marked in last_reset; the restarted state equals a fresh reset of that context bit for bit."""
+    n, cap = 14, 6
+    env = CubeStackingVecEnv_(n, cap)
+    q0, _, _ = env.start()
+    ctx_id = np.arange(n) % 3
+    env.reset(context=ctx100[ctx_id])
+    table = env.set_tally(3, torch.as_tensor(ctx_id, dtype=torch.int32))
+    counts = torch.zeros(2, dtype=torch.int64, device=env.device)
+    torch.cuda.synchronize()
+    fresh, _, _ = env.get_state()
+    act = torch.cat([torch.as_tensor(q0, dtype=torch.float64, device=env.device).expand(n, 7) + 0.01, torch.ones(n, 1, dtype=torch.float64, device=env.device)], dim=1).contiguous()
+    resets = 0
+    for t in range(20):
+        env.step(act)
+        env.auto_reset(counts)
+        torch.cuda.synchronize()
+        lr = env.last_reset.cpu().numpy().astype(bool)
+        if lr.any():
+            assert lr.all()                       # all lanes share the cap, so they finish together
+            st, fl, sc = env.get_state()
+            assert np.array_equal(st[:67], fresh[:67]) and (sc[:n] == 0).all()
+            resets += 1
+    assert resets == 3                            # done is raised at step index cap - 1, i.e. by the step() calls 6, 12, 18
+    tb = table.cpu().numpy()
+    assert tb[:, 0].tolist() == [3 * int((ctx_id == c).sum()) for c in range(3)] and tb[:, 1].sum() == 0
+    assert counts.cpu().tolist() == [3 * n, 0]
     env.close()
 
 
