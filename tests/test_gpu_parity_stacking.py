@@ -255,6 +255,34 @@ def test_one_step_parity_from_mid_episode_states(stack_js, stack_blob, ctx100, s
     env.close()
 
 
+def test_empty_gripper_closes_on_itself_like_the_oracle(stack_blob, ctx100):
+    """close_fingers with nothing between the fingers: the finger <-> finger pairs (tip boxes: box-box, finger hulls: three MPR jobs on
+    eight-lane groups) carry the closing force - the collision group of the device kernel no other test reaches."""
+    from oracle.oracle import Oracle
+    n = 6
+    env = _env(n)
+    q0, _, _ = env.start()
+    env.reset(context=ctx100[np.arange(n) % 2])
+    oracles = []
+    for k in range(2):
+        o = Oracle(stack_blob); o.env_start(q0); o.stack_reset(ctx100[k]); oracles.append(o)
+    a = np.concatenate([q0, [0.0]])
+    act = torch.as_tensor(np.tile(a, (n, 1)), dtype=torch.float64, device=env.device).contiguous()
+    worst = 0.0
+    for t in range(14):
+        env.step(act)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        assert not (fl & BAD).any()
+        for k in range(2):
+            oracles[k].stack_step(a)
+            worst = max(worst, float(np.abs(st[:67, k + 2 * (t % 3)] - oracles[k].stack_state()).max()))
+    assert worst < 1e-6, worst
+    w = float(env.robot_state()[0, 7])
+    assert 0.0 < w < 0.002, w                     # the contact equilibrium of the pads, not the joint stops
+    env.close()
+
+
 def test_device_auto_reset_restarts_lanes_on_their_contexts(ctx100):
     """d3il_auto_reset for Stacking: finished lanes (episode cap) are tallied per context, restarted on the context they were created
     with, marked in last_reset; the restarted state equals a fresh reset of that context bit for bit."""
