@@ -283,6 +283,34 @@ def test_empty_gripper_closes_on_itself_like_the_oracle(stack_blob, ctx100):
     env.close()
 
 
+def test_contact_overflow_is_flagged_and_contained(ctx100):
+    """More contacts than the record area holds (three boxes pushed into each other on the table: 3 x 8 box-box + 3 x 4 table contacts):
+    the lane raises CON_OVERFLOW, stays finite, and the other lanes of its workgroup are not disturbed."""
+    n = 8
+    env, ref = _env(n), _env(n)
+    q0, _, _ = env.start(); ref.start()
+    ctx = ctx100[np.arange(n) % 4]
+    env.reset(context=ctx); ref.reset(context=ctx)
+    torch.cuda.synchronize()
+    st, fl, sc = env.get_state()
+    lane = 1
+    for b in range(3):            # the three boxes of one lane nearly on top of each other (1 mm offsets), resting height
+        o = 28 + 13 * b
+        st[o:o + 3, lane] = [0.5 + 0.001 * b, 0.1 - 0.001 * b, st[28 + 2, lane]]
+        st[o + 3:o + 7, lane] = [1, 0, 0, 0]
+        st[o + 7:o + 13, lane] = 0
+    env.set_state(st, fl, sc)
+    a = torch.cat([torch.as_tensor(q0, dtype=torch.float64, device=env.device).expand(n, 7), torch.ones(n, 1, dtype=torch.float64, device=env.device)], dim=1).contiguous()
+    env.step(a); ref.step(a)
+    torch.cuda.synchronize()
+    s1, f1, _ = env.get_state(); s0, f0, _ = ref.get_state()
+    assert f1[lane] & (1 << 18), hex(int(f1[lane]))
+    assert np.isfinite(s1[:67]).all()
+    others = np.arange(n) != lane
+    assert np.array_equal(s1[:67, others], s0[:67, others]) and np.array_equal(f1[:n][others], f0[:n][others])
+    env.close(); ref.close()
+
+
 def test_device_auto_reset_restarts_lanes_on_their_contexts(ctx100):
     """d3il_auto_reset for Stacking: finished lanes (episode cap) are tallied per context, restarted on the context they were created
     with, marked in last_reset; the restarted state equals a fresh reset of that context bit for bit."""
