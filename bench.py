@@ -34,15 +34,18 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
-PROFILE_DIRS = ("r02", "r01")  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
+PROFILE_DIRS = ("r03", "r02", "r01")  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
 
-# algorithmic HBM bytes per env step (DESIGN.md sections 3, 12.3, 13.3): the state column read + written once (f64 rows + flags +
-# step counter), the action read (56 B), observation + done/success/mode written
-ALG_BYTES = {
+# Algorithmic HBM bytes per env step: SURVEY.md section 8(d)'s per-unit figures B_alg = 2 S + A + O + F (state read once + written once per
+# fused step, f64 state, f32 action / observation) - these define `roofline.achieved`.  IMPL_BYTES is what THIS implementation's state
+# column moves per env step (it also carries the flag / counter words, f64 actions, the stale-TCP / bias rows and - contact tasks - the
+# solver's warm start); reported next to it as `implementation_bytes_per_launch`, not used for `frac`.
+ALG_BYTES = {"avoiding": 704, "pushing": 1152, "sorting": 1620, "stacking": 1228}
+IMPL_BYTES = {
     "avoiding": 2 * (42 * 8 + 4 + 4) + 56 + 8 + 4,
-    "pushing": 2 * (68 * 8 + 4 + 4) + 56 + 32 + 4 + 16,
+    "pushing": 2 * (89 * 8 + 4 + 4) + 56 + 32 + 4 + 16,
     "sorting": 2 * (129 * 8 + 4 + 4) + 56 + 56 + 4,
-    "stacking": 2 * (67 * 8 + 4 + 4) + 64 + 48 + 4 + 8,      # state column 67 f64, action 8 f64, obs 12 f32, done/success/mode, mean distance
+    "stacking": 2 * (94 * 8 + 4 + 4) + 64 + 48 + 4 + 8,
 }
 KERNEL = {"avoiding": "k_avoiding_step_split<true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step"}
 PMC_FILE = {"avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json"}
@@ -374,6 +377,24 @@ def run(args):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # the metric reduction is the library's own RCCL all-reduce (d3il_reduce_metrics); the communicator is set up once, outside the timed
+    # region.  If RCCL cannot be resolved / initialised (e.g. the gloo test mode with every rank on one GPU) the line says so and the
+    # reduction goes through torch.distributed instead - the numbers are integer sums either way.
+    lib_comm, reduction = None, "none (single process)"
+    if world > 1:
+        reduction = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
+        if torch.distributed.get_backend() == "nccl" and os.environ.get("D3IL_LIB_REDUCE", "1") == "1":
+            try:
+                lib_comm = D.LibraryComm(dev)
+                reduction = "libd3il_rollout d3il_reduce_metrics: one RCCL ncclAllReduce(sum, int64) of the tally table"
+            except Exception as exc:      # noqa: BLE001
+                print("warning: library RCCL communicator unavailable (%s); reducing through torch.distributed" % exc, file=sys.stderr)
+                ok = torch.tensor([0], device=dev)
+            ok = torch.tensor([1 if lib_comm is not None else 0], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)       # all ranks take the same path
+            if int(ok.item()) == 0 and lib_comm is not None:
+                lib_comm.close(); lib_comm = None
+                reduction = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
     t_run = 0
     preroll = 0
     if not args.no_preroll and not args.no_auto_reset:
@@ -398,7 +419,7 @@ def run(args):
         # previous pair costs one event sync on an already finished kernel every 16 steps
         if t % 16 == 15:
             kernel_ms_lib.append(env.last_step_ms())
-    D.reduce_counts(table)          # the one collective of the path: int64 episode tally
+    D.reduce_counts(table, lib_comm, env.h)          # the one collective of the path: int64 episode tally, RCCL inside the library
     barrier()
     dt = time.perf_counter() - t0
     env.set_timing(False)
@@ -454,13 +475,15 @@ def run(args):
                        "preroll_steps_untimed": preroll, "phase_mix": "steady state (staggered episode phases)" if preroll else "fresh reset",
                        "auto_reset": not args.no_auto_reset, "finite": finite, "flagged_envs": flagged,
                        "episodes_finished_all_ranks": int(tb[:, 0].sum()), "episodes_success_all_ranks": int(tb[:, 1].sum()),
-                       "episodes_finished_rank0": int(episodes[0].item())},
+                       "episodes_finished_rank0": int(episodes[0].item()),
+                       "metric_reduction": reduction},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run)" % pm_path) if pm_path else None,
                          "kernel": KERNEL[task], "kernel_ms": k_ms,
                          "kernel_ms_library_events_every_16th": float(np.mean(kernel_ms_lib)) if kernel_ms_lib else None,
                          "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
-                         "algorithmic_bytes_per_launch": alg * n,
+                         "algorithmic_bytes_per_launch": alg * n, "algorithmic_bytes_per_env_step": alg,
+                         "implementation_bytes_per_launch": IMPL_BYTES[task] * n,
                          "note": "the path is FP64-VALU issue/latency bound, not HBM bound: < 2.2 KB of HBM per env step with all 35 sub-steps "
                                  "fused in registers / LDS (DESIGN.md sections 4, 12.3, 13.3); `frac` is the (structurally tiny) HBM fraction the contract asks for, "
                                  "`valu` the binding resource",
@@ -469,6 +492,8 @@ def run(args):
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(task, env.blob, q, ctx60)
         print(json.dumps(line))
+    if lib_comm is not None:
+        lib_comm.close()
     env.close()
     if world > 1:
         torch.distributed.destroy_process_group()

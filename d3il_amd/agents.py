@@ -243,3 +243,94 @@ class ScriptedStackPolicy:
         out = a.clone()
         out[:, :7] -= obs20[:, :7].to(torch.float64)
         return out
+
+
+class ScriptedGoalPushPolicy:
+    """Closed-loop scripted policy that FINISHES the pushing tasks (evaluation harness for the integer-count parity tests and the
+    contact-regime bench lines; not part of the reference).  Same interface as the rollout loops of the sims:
+    ``predict_batch([des_xy, obs]) -> delta_xy`` with |delta| <= ``STEP`` (the env's action box is +-1 cm, pushing.py:203-205).
+
+    * ``task='pushing'``: the two cubes are pushed to the two targets in one of the FOUR behaviour modes of pushing.py:341-377, chosen per
+      lane by ``plan`` (0: red->red target then green->green target, 1: green->green then red->red, 2: red->green target then
+      green->red target, 3: green->red then red->green) - so a batch produces a non-trivial mode table.
+    * ``task='sorting'``: every cube still on the platform is pushed over the platform edge into the bin of its colour (red: x 0.4, blue:
+      x 0.625; sorting.py:300-301), front-most cube first; the completion order (the mode code, sorting.py:460-507) follows from the context.
+
+    A push: walk (around the cube if necessary) to a stand-off point behind the cube on the line cube -> goal, then advance along that
+    line while steering the lateral offset to zero; the line is re-aimed every step from the observed cube position."""
+
+    STEP = 0.006
+    GOALS = ((0.42, 0.3), (0.63, 0.3))                                   # pushing_objects.py:11-15: red target, green target
+    PLANS = (((0, 0), (1, 1)), ((1, 1), (0, 0)), ((0, 1), (1, 0)), ((1, 0), (0, 1)))   # ((cube, target), (cube, target)) per mode
+
+    def __init__(self, task: str, plan=None, device="cuda"):
+        assert task in ("pushing", "sorting")
+        self.task, self.device = task, torch.device(device)
+        self.plan = None if plan is None else torch.as_tensor(plan, dtype=torch.long, device=self.device)
+        self.stage = None
+
+    def reset(self):
+        self.stage = None
+
+    def begin_episodes(self, mask: torch.Tensor):
+        if self.stage is not None:
+            self.stage = torch.where(mask.bool(), torch.zeros_like(self.stage), self.stage)
+
+    def _current(self, obs, n, dev):
+        """(cube xy, goal xy, active) of the push every lane is working on."""
+        f64 = dict(dtype=torch.float64, device=dev)
+        if self.task == "pushing":
+            cubes = torch.stack((obs[:, 2:4], obs[:, 5:7]), dim=1)                      # [n, 2, 2]
+            plan = self.plan if self.plan is not None else torch.zeros(n, dtype=torch.long, device=dev)
+            table = torch.tensor(self.PLANS, dtype=torch.long, device=dev)[plan]        # [n, 2 stages, (cube, target)]
+            goals = torch.tensor(self.GOALS, **f64)
+            ar = torch.arange(n, device=dev)
+            for _ in range(2):                                                           # a finished stage hands over to the next one
+                st = self.stage.clamp_max(1)
+                cube_i, goal_i = table[ar, st, 0], table[ar, st, 1]
+                box, goal = cubes[ar, cube_i], goals[goal_i]
+                arrived = ((goal - box).norm(dim=1) < 0.02) & (self.stage < 2)
+                self.stage = self.stage + arrived.long()
+            return box, goal, self.stage < 2
+        nb = (obs.shape[1] - 2) // 3
+        xy = obs[:, 2:].reshape(n, nb, 3)[:, :, :2]
+        goal_x = torch.tensor([0.4] * (nb // 2) + [0.625] * (nb // 2), **f64)
+        on_platform = xy[:, :, 1] < 0.232                                               # not yet over the bin wall (y = 0.22 +- 0.005)
+        key = torch.where(on_platform, xy[:, :, 1], torch.full_like(xy[:, :, 1], -1e9))
+        k = torch.argmax(key, dim=1)                                                    # front-most cube still on the platform
+        ar = torch.arange(n, device=dev)
+        box = xy[ar, k]
+        gx = goal_x[k]
+        # first sideways on the platform to the x of the cube's bin (at its own y, at most 0.10: away from the edge), then straight over it
+        lined_up = (box[:, 0] - gx).abs() < 0.025
+        goal = torch.stack((gx, torch.where(lined_up, torch.full((n,), 0.34, **f64), box[:, 1].clamp_max(0.10))), dim=1)
+        return box, goal, on_platform.any(dim=1)
+
+    @torch.no_grad()
+    def predict_batch(self, obs_in: torch.Tensor) -> torch.Tensor:
+        o = obs_in.to(torch.float64)
+        n, dev = o.shape[0], o.device
+        des, obs = o[:, :2], o[:, 2:]
+        if self.stage is None:
+            self.stage = torch.zeros(n, dtype=torch.long, device=dev)
+        box, goal, active = self._current(obs, n, dev)
+        togo = goal - box
+        dirn = togo / togo.norm(dim=1, keepdim=True).clamp_min(1e-9)
+        behind = box - dirn * 0.06
+        off = des - behind
+        along = (off * dirn).sum(1, keepdim=True)
+        lateral = off - along * dirn
+        latn = lateral.norm(dim=1, keepdim=True)
+        aligned = (latn < 0.015) & (along > -0.03) & (along < 0.05)
+        push = self.STEP * dirn - lateral * torch.clamp(0.003 / latn.clamp_min(1e-9), max=0.5)
+        d = behind - des
+        dn = d.norm(dim=1, keepdim=True)
+        walk = d / dn.clamp_min(1e-9) * torch.minimum(dn, torch.full_like(dn, self.STEP))
+        rel = des - box                                                                   # around the cube, not through it
+        rn = rel.norm(dim=1, keepdim=True)
+        away = rel / rn.clamp_min(1e-9)
+        tang = torch.stack((-away[:, 1], away[:, 0]), dim=1)
+        tang = tang * torch.sign((tang * (behind - des)).sum(1, keepdim=True) + 1e-12)
+        around = self.STEP * (0.8 * tang + 0.6 * (0.075 - rn) / 0.01 * away).clamp(-1.0, 1.0)
+        step = torch.where(aligned, push, torch.where((rn < 0.08) & (dn > 0.02), around, walk))
+        return step * active.unsqueeze(1).to(torch.float64)

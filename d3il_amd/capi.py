@@ -29,12 +29,14 @@ PUSH_STATE_BOX, PUSH_STATE_WARM, PUSH_STATE_F64 = 42, 68, 89
 PFLAG_FIRST_MASK, PFLAG_MODE_MASK, PFLAG_WARM_VALID, PFLAG_CON_OVERFLOW, PFLAG_OFF_TABLE = 0x7, 0x38, 1 << 6, 1 << 18, 1 << 19
 TASK_AVOIDING, TASK_PUSHING, TASK_SORTING, TASK_STACKING = 0, 1, 2, 3
 STACK_STATE_BOX, STACK_STATE_WARM, STACK_STATE_F64 = 28, 67, 94
-SFLAG_HAND_NEAR = 1 << 20
-TALLY_ROW = 514
+SFLAG_MODE_MASK, SFLAG_WARM_VALID, SFLAG_HAND_NEAR = 0xFF, 1 << 8, 1 << 20
+TALLY_ROW, TALLY_ALL = 514, 256
+ERCCL = -7
 SORT_STATE_BOX, SORT_STATE_WARM, SORT_STATE_TASK, SORT_STATE_F64 = 42, 94, 127, 129
 
 EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
-           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_attention_causal_f32", "d3il_layernorm_f32", "d3il_auto_reset", "d3il_set_tally", "d3il_count_metrics", "d3il_set_timing",
+           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_attention_causal_f32", "d3il_layernorm_f32", "d3il_auto_reset", "d3il_set_tally", "d3il_count_metrics",
+           "d3il_comm_unique_id", "d3il_comm_init", "d3il_comm_destroy", "d3il_reduce_metrics", "d3il_set_timing",
            "d3il_last_step_ms", "d3il_set_option", "d3il_debug_stats", "d3il_debug_wave_stats", "d3il_debug_scratch", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
 
 
@@ -74,6 +76,10 @@ def load():
         L.d3il_layernorm_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p]
         L.d3il_auto_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.d3il_set_tally.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.d3il_comm_unique_id.argtypes = [C.c_void_p]
+        L.d3il_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.d3il_comm_destroy.argtypes = [C.c_void_p]
+        L.d3il_reduce_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.d3il_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.d3il_last_step_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.d3il_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
 #include <string>
 #include "../../include/d3il_rollout.h"
 #include "panda_step.h"
@@ -315,9 +317,14 @@ __global__ __launch_bounds__(256) void k_attention_causal_f32(const float* __res
   };
   load(base + (long)i * 3 * C, q);
 #pragma unroll
-  for (int d = 0; d < DR; d++) { q[d] *= scale; acc[d] = 0.0f; }
-  float m = -INFINITY, l = 0.0f;
-  for (int j = 0; j <= i; j++) {      // online softmax
+  for (int d = 0; d < DR; d++) q[d] *= scale;
+  // online softmax; key 0 is peeled (m = score_0, l = 1, acc = v_0) so that no infinity is ever formed: the device pass is built
+  // with -ffinite-math-only, under which arithmetic on infinities is undefined
+  load(base + C, kk); load(base + 2 * C, acc);
+  float m = 0.0f, l = 1.0f;
+#pragma unroll
+  for (int d = 0; d < DR; d++) m += q[d] * kk[d];
+  for (int j = 1; j <= i; j++) {
     const float* kj = base + (long)j * 3 * C + C;
     load(kj, kk); load(kj + C, vv);
     float sc = 0.0f;
@@ -384,9 +391,10 @@ __global__ void k_count_metrics(const unsigned char* __restrict__ done, const un
 // Episode tally of the rollout harnesses (avoiding_sim.py:45-54, pushing_sim.py:43-86, sorting_sim.py:100-133 loop over contexts and
 // trajectories and record success / mode of the step that returned done): every finished environment adds to row ctx_id[e] of an
 // int64 table [n_ctx][D3IL_TALLY_ROW]: [0] episodes, [1] successes, [2 + code] successes by mode code (Avoiding: 9-bit code,
-// Pushing: info['mode'] + 1, Sorting: np.packbits code).  Integer sums: bit-exact and order independent.
+// Pushing: info['mode'] + 1, Sorting: np.packbits code, Stacking: n | c0 << 2 | c1 << 4 | c2 << 6), and for Stacking
+// [2 + D3IL_TALLY_ALL + code] ALL finished episodes by code.  Integer sums: bit-exact and order independent.
 __global__ void k_episode_tally(const unsigned char* __restrict__ done, const unsigned char* __restrict__ success, const unsigned short* __restrict__ mode,
-                                const int* __restrict__ ctx_id, long long* __restrict__ table, long long* __restrict__ episode_counts, int n, int n_ctx, int mode_bias) {
+                                const int* __restrict__ ctx_id, long long* __restrict__ table, long long* __restrict__ episode_counts, int n, int n_ctx, int mode_bias, int all_by_code) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n || !done[e]) return;
   if (episode_counts) {
@@ -398,11 +406,14 @@ __global__ void k_episode_tally(const unsigned char* __restrict__ done, const un
   if (c < 0 || c >= n_ctx) return;
   long long* row = table + (size_t)c * D3IL_TALLY_ROW;
   atomicAdd((unsigned long long*)&row[0], 1ull);
+  int code = (int)(short)mode[e] + mode_bias;
   if (success[e]) {
     atomicAdd((unsigned long long*)&row[1], 1ull);
-    int code = (int)(short)mode[e] + mode_bias;
     if (code >= 0 && code < D3IL_TALLY_ROW - 2) atomicAdd((unsigned long long*)&row[2 + code], 1ull);
   }
+  // Stacking: info['success_1'] / ['success_2'] (stacking_sim.py:118-136) belong to episodes that did NOT stack all three boxes too,
+  // so every finished episode is also counted by its order code (number of letters + colours, < 256) in the upper half of the row
+  if (all_by_code && code >= 0 && code < 256) atomicAdd((unsigned long long*)&row[2 + D3IL_TALLY_ALL + code], 1ull);
 }
 // contexts of the last reset of every environment (what auto-reset starts the next trajectory of that lane from)
 __global__ void k_store_contexts(const unsigned char* __restrict__ mask, const double* __restrict__ src, double* __restrict__ dst, int n, int dim) {
@@ -416,6 +427,13 @@ __global__ void k_store_contexts(const unsigned char* __restrict__ mask, const d
 
 // ====================================================================== C ABI
 using namespace d3il;
+
+// the public header documents the layouts the engines define: keep them in step
+static_assert(D3IL_STACK_STATE_BOX == SK_STATE_BOX && D3IL_STACK_STATE_WARM == SK_STATE_WARM && D3IL_STACK_STATE_F64 == SK_STATE_F64, "d3il_rollout.h: Stacking state layout");
+static_assert(D3IL_SFLAG_WARM_VALID == SKF_WARM_VALID && D3IL_SFLAG_HAND_NEAR == SKF_HAND_NEAR && D3IL_PFLAG_CON_OVERFLOW == SKF_CON_OVERFLOW && D3IL_PFLAG_OFF_TABLE == SKF_OFF_TABLE,
+              "d3il_rollout.h: Stacking flag bits");
+static_assert(D3IL_SFLAG_MODE_MASK == (SKF_NMODE_MASK | (0x3Fu << SKF_IND_SHIFT)), "d3il_rollout.h: Stacking order code");
+static_assert(D3IL_PUSH_STATE_F64 == PUSH_STATE_F64 && D3IL_TALLY_ALL + 256 <= D3IL_TALLY_ROW - 2, "d3il_rollout.h: Pushing state rows / tally row");
 
 struct d3il_handle_s {
   int task_id, n, stride, device;
@@ -448,6 +466,9 @@ struct d3il_handle_s {
 struct ActiveModel { int refs; bool valid; PushConsts pc; GenConsts gc; StackConsts kc; };
 static ActiveModel g_active_push[16], g_active_gen[16], g_active_stack[16];
 static int g_active_tol[16];   // solver tolerance set currently in the device's g_solver_tol (0 production)
+// g_active_* / g_active_tol are process-global (one __constant__ object per device): every read-modify-write of them - d3il_create,
+// d3il_destroy, the solver-rule switch - holds this mutex (two host threads with one handle each raced on them)
+static std::mutex g_model_mutex;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -463,6 +484,7 @@ static void free_handle(d3il_handle_s* h) {
   if (!h) return;
   int dev = h->device;
   if (dev >= 0 && dev < 16) {
+    std::lock_guard<std::mutex> lock(g_model_mutex);
     if (h->task_id == D3IL_TASK_PUSHING && g_active_push[dev].refs > 0) g_active_push[dev].refs--;
     if (h->task_id == D3IL_TASK_SORTING && g_active_gen[dev].refs > 0) g_active_gen[dev].refs--;
     if (h->task_id == D3IL_TASK_STACKING && g_active_stack[dev].refs > 0) g_active_stack[dev].refs--;
@@ -524,14 +546,18 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   // one Pushing / Sorting model per device while handles are alive (constant memory)
   if (pushing) {
     ActiveModel& am = g_active_push[device_id];
-    if (am.refs > 0 && std::memcmp(&am.pc, &h->pc, sizeof(PushConsts)) != 0) {
+    bool other;
+    { std::lock_guard<std::mutex> lock(g_model_mutex); other = am.refs > 0 && std::memcmp(&am.pc, &h->pc, sizeof(PushConsts)) != 0; }
+    if (other) {
       free_handle(h);
       return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Pushing handle on this device uses a different model (the kernels read one model per device from constant memory); destroy it first");
     }
   }
   if (sorting) {
     ActiveModel& am = g_active_gen[device_id];
-    if (am.refs > 0 && std::memcmp(&am.gc, &h->gc, sizeof(GenConsts)) != 0) {
+    bool other;
+    { std::lock_guard<std::mutex> lock(g_model_mutex); other = am.refs > 0 && std::memcmp(&am.gc, &h->gc, sizeof(GenConsts)) != 0; }
+    if (other) {
       free_handle(h);
       return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Sorting handle on this device uses a different model, e.g. another num_boxes (the kernels read one model per device from constant memory); destroy it first");
     }
@@ -539,7 +565,9 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   const bool stacking = task_id == D3IL_TASK_STACKING;
   if (stacking) {
     ActiveModel& am = g_active_stack[device_id];
-    if (am.refs > 0 && std::memcmp(&am.kc, &h->kc, sizeof(StackConsts)) != 0) {
+    bool other;
+    { std::lock_guard<std::mutex> lock(g_model_mutex); other = am.refs > 0 && std::memcmp(&am.kc, &h->kc, sizeof(StackConsts)) != 0; }
+    if (other) {
       free_handle(h);
       return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Stacking handle on this device uses a different model (the kernels read one model per device from constant memory); destroy it first");
     }
@@ -570,12 +598,15 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (h->ctx_dim) { HIPCHK_H(hipMalloc(&h->d_ctx, S * h->ctx_dim * sizeof(double))); HIPCHK_H(hipMemset(h->d_ctx, 0, S * h->ctx_dim * sizeof(double))); }
   if (pushing) {
     ActiveModel& am = g_active_push[device_id];
-    if (am.refs == 0) {
-      HIPCHK_H(hipDeviceSynchronize());
-      HIPCHK_H(hipMemcpyToSymbol(HIP_SYMBOL(g_push_consts), &h->pc, sizeof(PushConsts)));
-      am.pc = h->pc;
+    {
+      std::unique_lock<std::mutex> lock(g_model_mutex);
+      if (am.refs == 0) {
+        hipError_t e1 = hipDeviceSynchronize(), e2 = hipMemcpyToSymbol(HIP_SYMBOL(g_push_consts), &h->pc, sizeof(PushConsts));
+        if (e1 != hipSuccess || e2 != hipSuccess) { lock.unlock(); free_handle(h); return fail(D3IL_EHIP, "d3il_create: loading the Pushing model into constant memory failed"); }
+        am.pc = h->pc;
+      }
+      am.refs++; h->task_id = task_id;
     }
-    am.refs++; h->task_id = task_id;
     HIPCHK_H(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
     HIPCHK_H(hipMalloc(&h->d_scratch, S * PG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * PG_SIZE * sizeof(double)));
     // the physics wave keeps the coupled solver's tables in LDS: 137.5 KiB + the set-point exchange, above the 64 KiB default cap
@@ -585,12 +616,15 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   }
   if (sorting) {
     ActiveModel& am = g_active_gen[device_id];
-    if (am.refs == 0) {
-      HIPCHK_H(hipDeviceSynchronize());
-      HIPCHK_H(hipMemcpyToSymbol(HIP_SYMBOL(g_gen_consts), &h->gc, sizeof(GenConsts)));
-      am.gc = h->gc;
+    {
+      std::unique_lock<std::mutex> lock(g_model_mutex);
+      if (am.refs == 0) {
+        hipError_t e1 = hipDeviceSynchronize(), e2 = hipMemcpyToSymbol(HIP_SYMBOL(g_gen_consts), &h->gc, sizeof(GenConsts));
+        if (e1 != hipSuccess || e2 != hipSuccess) { lock.unlock(); free_handle(h); return fail(D3IL_EHIP, "d3il_create: loading the Sorting model into constant memory failed"); }
+        am.gc = h->gc;
+      }
+      am.refs++; h->task_id = task_id;
     }
-    am.refs++; h->task_id = task_id;
     HIPCHK_H(hipMalloc(&h->d_scratch, S * GG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * GG_SIZE * sizeof(double)));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
@@ -598,12 +632,15 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   }
   if (stacking) {
     ActiveModel& am = g_active_stack[device_id];
-    if (am.refs == 0) {
-      HIPCHK_H(hipDeviceSynchronize());
-      HIPCHK_H(hipMemcpyToSymbol(HIP_SYMBOL(g_stack_consts), &h->kc, sizeof(StackConsts)));
-      am.kc = h->kc;
+    {
+      std::unique_lock<std::mutex> lock(g_model_mutex);
+      if (am.refs == 0) {
+        hipError_t e1 = hipDeviceSynchronize(), e2 = hipMemcpyToSymbol(HIP_SYMBOL(g_stack_consts), &h->kc, sizeof(StackConsts));
+        if (e1 != hipSuccess || e2 != hipSuccess) { lock.unlock(); free_handle(h); return fail(D3IL_EHIP, "d3il_create: loading the Stacking model into constant memory failed"); }
+        am.kc = h->kc;
+      }
+      am.refs++; h->task_id = task_id;
     }
-    am.refs++; h->task_id = task_id;
     HIPCHK_H(hipMalloc(&b.info_f64, S * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * sizeof(double)));
     HIPCHK_H(hipMalloc(&h->d_scratch, S * SG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * SG_SIZE * sizeof(double)));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_step, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
@@ -637,8 +674,15 @@ int d3il_start(d3il_handle h, const double* init_qpos7) {
 // loaded re-loads it on its stream before launching (handles with different settings must not run concurrently on one device)
 static int sync_solver_tol(d3il_handle_s* h, hipStream_t s) {
   static const SolverTol k_tol[2] = {SOLVER_TOL_PRODUCTION, SOLVER_TOL_STRICT};
-  if (h->task_id == D3IL_TASK_AVOIDING || g_active_tol[h->device] == h->tol_mode) return D3IL_OK;
-  HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_solver_tol), &k_tol[h->tol_mode ? 1 : 0], sizeof(SolverTol), 0, hipMemcpyHostToDevice, s));
+  if (h->task_id == D3IL_TASK_AVOIDING) return D3IL_OK;
+  std::lock_guard<std::mutex> lock(g_model_mutex);
+  if (g_active_tol[h->device] == h->tol_mode) return D3IL_OK;
+  // a switch of the rule is rare (parity A/B): fence the whole device on both sides of the copy, so that kernels of OTHER streams /
+  // handles neither run across the change nor start before the copy has landed
+  (void)s;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_solver_tol), &k_tol[h->tol_mode ? 1 : 0], sizeof(SolverTol)));
+  HIPCHK(hipDeviceSynchronize());
   g_active_tol[h->device] = h->tol_mode;
   return D3IL_OK;
 }
@@ -784,6 +828,7 @@ int d3il_policy_begin(d3il_handle h, const uint8_t* env_mask, void* stream) {
 }
 int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, void* stream) {
   if (!h || !actions) return fail(D3IL_EINVAL, "d3il_policy_action: null argument");
+  if (h->buf.action_dim != 7) return fail(D3IL_EUNSUPPORTED, "d3il_policy_action: the random Cartesian policy writes 7-wide rows (Avoiding / Pushing / Sorting); Stacking actions are 8 wide");
   HIPCHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_policy_action, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->buf.policy_des, actions, (unsigned long long)seed,
                      (unsigned long long)env_offset, t, h->n, h->stride);
@@ -828,16 +873,17 @@ int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream)
   d3il_buffers& b = h->buf;
   hipStream_t s = (hipStream_t)stream;
   const bool avoiding = h->task_id == D3IL_TASK_AVOIDING;
+  if (avoiding && !episode_counts_device) return fail(D3IL_EINVAL, "d3il_auto_reset: the Avoiding task needs episode_counts (device i64[2])");   // before anything is enqueued
   // which environments this call resets (buf.last_reset): the harness re-latches its per-lane state (agent history) from it
   HIPCHK(hipMemcpyAsync(h->d_mask, b.done, (size_t)h->n, hipMemcpyDeviceToDevice, s));
   if (h->tally_table || (!avoiding && episode_counts_device)) {
     // Avoiding counts its episodes in the fused reset kernel below
     hipLaunchKernelGGL(k_episode_tally, dim3((h->n + 255) / 256), dim3(256), 0, s, b.done, b.success, b.mode, h->tally_ctx, (long long*)h->tally_table,
-                       avoiding ? (long long*)nullptr : (long long*)episode_counts_device, h->n, h->tally_nctx, h->task_id == D3IL_TASK_PUSHING ? 1 : 0);
+                       avoiding ? (long long*)nullptr : (long long*)episode_counts_device, h->n, h->tally_nctx, h->task_id == D3IL_TASK_PUSHING ? 1 : 0,
+                       h->task_id == D3IL_TASK_STACKING ? 1 : 0);
     HIPCHK(hipGetLastError());
   }
   if (avoiding) {
-    if (!episode_counts_device) return fail(D3IL_EINVAL, "d3il_auto_reset: null argument");
     hipLaunchKernelGGL(k_avoiding_auto_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, s, h->dc, h->d_init_qpos, b.state, b.flags, b.step_count,
                        b.obs, b.done, b.success, b.mode, b.policy_des, (long long*)episode_counts_device, h->n, h->stride);
     HIPCHK(hipGetLastError());
@@ -857,6 +903,82 @@ int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream) 
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }
+// ---- cross-GPU reduction of the integer metric tables with RCCL, inside the library (north_star: "RCCL ... over xGMI only
+// for the final success-rate / entropy reduction").  RCCL is resolved at run time: the symbols of an RCCL already loaded into the process
+// (PyTorch-ROCm ships one: a communicator must be used with the library that made it) or, failing that, librccl.so from the ROCm install;
+// the library itself links only the HIP runtime, so single-GPU users need no RCCL at all.
+namespace {
+struct RcclApi {
+  int (*GetUniqueId)(void*);
+  int (*CommInitRank)(void**, int, d3il_rccl_unique_id, int);     // ncclUniqueId is a 128-byte struct passed by value
+  int (*CommDestroy)(void*);
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  const char* (*GetErrorString)(int);
+  bool ok;
+};
+RcclApi* rccl_api() {
+  static RcclApi api = [] {
+    RcclApi a{}; a.ok = false;
+    void* hnd = RTLD_DEFAULT;
+    if (!dlsym(hnd, "ncclAllReduce")) {
+      hnd = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!hnd) hnd = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!hnd) hnd = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!hnd) return a;
+    }
+    a.GetUniqueId = (int (*)(void*))dlsym(hnd, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void**, int, d3il_rccl_unique_id, int))dlsym(hnd, "ncclCommInitRank");
+    a.CommDestroy = (int (*)(void*))dlsym(hnd, "ncclCommDestroy");
+    a.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(hnd, "ncclAllReduce");
+    a.GetErrorString = (const char* (*)(int))dlsym(hnd, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
+    return a;
+  }();
+  return &api;
+}
+int rccl_fail(const char* what, int rc) {
+  RcclApi* a = rccl_api();
+  return fail(D3IL_ERCCL, std::string(what) + ": " + (a->GetErrorString ? a->GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+}  // namespace
+
+int d3il_comm_unique_id(d3il_rccl_unique_id* out) {
+  if (!out) return fail(D3IL_EINVAL, "d3il_comm_unique_id: null argument");
+  RcclApi* a = rccl_api();
+  if (!a->ok) return fail(D3IL_ERCCL, "d3il_comm_unique_id: RCCL (librccl.so) could not be resolved");
+  if (int rc = a->GetUniqueId(out)) return rccl_fail("ncclGetUniqueId", rc);
+  return D3IL_OK;
+}
+int d3il_comm_init(const d3il_rccl_unique_id* id, int rank, int world, int device_id, d3il_comm* out) {
+  if (!id || !out) return fail(D3IL_EINVAL, "d3il_comm_init: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(D3IL_EINVAL, "d3il_comm_init: need 0 <= rank < world");
+  RcclApi* a = rccl_api();
+  if (!a->ok) return fail(D3IL_ERCCL, "d3il_comm_init: RCCL (librccl.so) could not be resolved");
+  HIPCHK(hipSetDevice(device_id));
+  void* comm = nullptr;
+  if (int rc = a->CommInitRank(&comm, world, *id, rank)) return rccl_fail("ncclCommInitRank", rc);
+  *out = (d3il_comm)comm;
+  return D3IL_OK;
+}
+int d3il_comm_destroy(d3il_comm comm) {
+  if (!comm) return fail(D3IL_EINVAL, "d3il_comm_destroy: null communicator");
+  RcclApi* a = rccl_api();
+  if (!a->ok) return fail(D3IL_ERCCL, "d3il_comm_destroy: RCCL could not be resolved");
+  if (int rc = a->CommDestroy((void*)comm)) return rccl_fail("ncclCommDestroy", rc);
+  return D3IL_OK;
+}
+int d3il_reduce_metrics(d3il_handle h, d3il_comm comm, int64_t* table_device, size_t count, void* stream) {
+  if (!h || !comm) return fail(D3IL_EINVAL, "d3il_reduce_metrics: null argument");
+  if (!table_device) { table_device = h->tally_table; count = (size_t)h->tally_nctx * D3IL_TALLY_ROW; }      // default: the table of d3il_set_tally
+  if (!table_device || count == 0) return fail(D3IL_EINVAL, "d3il_reduce_metrics: no table (pass one, or register it with d3il_set_tally)");
+  RcclApi* a = rccl_api();
+  if (!a->ok) return fail(D3IL_ERCCL, "d3il_reduce_metrics: RCCL could not be resolved");
+  HIPCHK(hipSetDevice(h->device));
+  // ONE in-place all-reduce(sum) of int64 counts: integer sums are bit-exact and independent of the rank order (ncclInt64 = 4, ncclSum = 0)
+  if (int rc = a->AllReduce(table_device, table_device, count, 4, 0, (void*)comm, (hipStream_t)stream)) return rccl_fail("ncclAllReduce", rc);
+  return D3IL_OK;
+}
+
 int d3il_set_timing(d3il_handle h, int enabled) {
   if (!h) return fail(D3IL_EINVAL, "d3il_set_timing: null handle");
   h->timing = enabled != 0; h->ev_valid = false;

@@ -33,8 +33,18 @@ typedef struct d3il_handle_s* d3il_handle;
 
 enum {
   D3IL_OK = 0, D3IL_EINVAL = -1, D3IL_EBLOB = -2, D3IL_ENODEVICE = -3, D3IL_EHIP = -4, D3IL_EUNSUPPORTED = -5,
-  D3IL_ESTATE = -6
+  D3IL_ESTATE = -6, D3IL_ERCCL = -7
 };
+
+/* Tasks (task_id of d3il_create; the enum itself is D3IL_TASK_* in d3il_model_blob.h: 0 Avoiding, 1 Pushing, 2 Sorting, 3 Stacking) and
+ * their shapes:
+ *   task      reference env (environments/d3il/envs/...)            action (device f64, row-major)              obs f32   contexts f64     state rows
+ *   Avoiding  gym_avoiding/envs/avoiding.py ObstacleAvoidanceEnv    [n][7] desired TCP x y z qw qx qy qz        [n][2]    none             42
+ *   Pushing   gym_pushing/envs/pushing.py Block_Push_Env            [n][7] same                                 [n][8]    [n][14]          89
+ *   Sorting   gym_sorting/envs/sorting.py Sorting_Env (2 / 4 boxes) [n][7] same                                 [n][2+3b] [n][7 b]         42+13b+(9+6b)+2
+ *   Stacking  gym_stacking/envs/stacking.py CubeStacking_Env        [n][8] 7 desired joint positions + gripper   [n][12]   [n][21]          94
+ *                                                                   command (open iff > 0.075, stacking.py:337-346)
+ */
 
 /* f64 state fields per environment, in SoA order */
 enum {
@@ -51,7 +61,12 @@ enum {
   /* Sorting-4 (sorting.py): per cube pos[3] quat[4] vel[6] in the order red_1, red_2, blue_1, blue_2, the solver's warm start
    * qacc[33] (cubes, arm), then the task state of Sorting_Env as two words stored as doubles: word 0 = mode[6], two bits each
    * (value + 1), | mode_step << 12;  word 1 = min_inds[6], three bits each (sorting.py:405-411, 460-507) */
-  D3IL_SORT_STATE_BOX = 42, D3IL_SORT_STATE_WARM = 94, D3IL_SORT_STATE_TASK = 127, D3IL_SORT_STATE_F64 = 129
+  D3IL_SORT_STATE_BOX = 42, D3IL_SORT_STATE_WARM = 94, D3IL_SORT_STATE_TASK = 127, D3IL_SORT_STATE_F64 = 129,
+  /* Stacking (stacking.py; robot panda_invisible.xml, joint-space controller: no IK rows): rows 0..27 as above up to the TCP (qpos 9, qvel 9,
+   * qfrc_bias 7, TCP 3), then per box pos[3] quat[4] vel[6] in the order red, green, blue (D3IL_STACK_STATE_BOX + 13 k), then the
+   * constraint solver's warm start qacc[27] (box 0, box 1, box 2, arm 9).  The task state of CubeStacking_Env (order in which the boxes
+   * reached the target zone, stacking.py:395-419) lives in the flag word (D3IL_SFLAG_*). */
+  D3IL_STACK_STATE_BOX = 28, D3IL_STACK_STATE_WARM = 67, D3IL_STACK_STATE_F64 = 94
 };
 /* bits of the per-environment u32 flag word */
 enum {
@@ -66,7 +81,13 @@ enum {
   D3IL_PFLAG_MODE_MASK = 0x38,       /* (mode + 1) << 3 */
   D3IL_PFLAG_WARM_VALID = 1 << 6,
   D3IL_PFLAG_CON_OVERFLOW = 1 << 18, /* more contacts than the solver holds (24) in some sub-step */
-  D3IL_PFLAG_OFF_TABLE = 1 << 19     /* a cube left the modelled part of the table */
+  D3IL_PFLAG_OFF_TABLE = 1 << 19,    /* a cube left the modelled part of the table */
+  /* Stacking reuses TERMINATED / SUCCESS / SOLVER_FAIL / CON_OVERFLOW (more than 32 contacts) / OFF_TABLE and replaces the low bits: */
+  D3IL_SFLAG_MODE_MASK = 0xFF,       /* order code n | c0 << 2 | c1 << 4 | c2 << 6: n boxes have reached the target zone, c_i = colour (0 r, 1 g, 2 b) of the
+                                        i-th one (info['mode'] = "rgb"[c0] + ... , stacking.py:395-419); also what buf.mode holds */
+  D3IL_SFLAG_WARM_VALID = 1 << 8,    /* the warm-start rows hold the accelerations of the previous sub-step (the gripper command is re-derived from the action every step, so
+                                        RobotBase.grasp_flag needs no bit) */
+  D3IL_SFLAG_HAND_NEAR = 1 << 20     /* a box came within the bounding box of a robot collision geom this engine does not evaluate */
 };
 
 typedef struct d3il_buffers {
@@ -74,13 +95,14 @@ typedef struct d3il_buffers {
   float* obs;            /* [n_envs][obs_dim] f32, what get_observation() returns (avoiding.py:117-119, pushing.py:255-280) */
   uint8_t* done;         /* [n_envs] result of is_finished() of the last step (gym_env_wrapper.py:124-137) */
   uint8_t* success;      /* [n_envs] info[1] (avoiding.py:171) */
-  uint16_t* mode;        /* [n_envs] Avoiding: 9-bit mode encoding, bit i = mode_encoding[i] (info[0]); Pushing: info['mode'] as int16 (-1..3) */
+  uint16_t* mode;        /* [n_envs] Avoiding: 9-bit mode encoding, bit i = mode_encoding[i] (info[0]); Pushing: info['mode'] as int16 (-1..3);
+                            Sorting: int(np.packbits(mode)[0]); Stacking: order code (D3IL_SFLAG_MODE_MASK) */
   double* state;         /* [state_rows][stride] */
   uint32_t* flags;       /* [stride] */
   int32_t* step_count;   /* [stride] env_step_counter */
   double* policy_des;    /* [3][stride] random-policy harness state: desired x, y and fixed z */
-  double* info_f64;      /* [n_info_f64][stride] extra f64 step outputs; Pushing: info['mean_distance'], reward (pushing.py:335-407) */
-  int32_t n_info_f64, state_rows;   /* state_rows: f64 state fields per environment (42 Avoiding, 89 Pushing) */
+  double* info_f64;      /* [n_info_f64][stride] extra f64 step outputs; Pushing: info['mean_distance'], reward (pushing.py:335-407); Stacking: info['mean_distance'] */
+  int32_t n_info_f64, state_rows;   /* state_rows: f64 state fields per environment (42 Avoiding, 89 Pushing, 129 Sorting-4, 94 Stacking) */
   uint8_t* last_reset;   /* [n_envs] environments reset by the last d3il_auto_reset (non-zero): per-lane harness / agent state re-latches from it */
 } d3il_buffers;
 
@@ -97,12 +119,16 @@ int d3il_start(d3il_handle h, const double* init_qpos7);
  * NULL for all.  contexts: NULL for Avoiding; Pushing (pushing.py:461-483 with random=False): device f64 [n_envs][14] =
  * per env 2 x (x, y, z, qw, qx, qy, qz) written into the cubes' qpos as BlockContextManager.set_context does (z = 0);
  * Sorting-4 (sorting.py:545-575): device f64 [n_envs][28] = 4 x (x, y, z = 0.05, quat), red boxes first (sorting.py:121-187).
- * Sorting outputs: obs f32 [n_envs][14] (TCP xy, then x, y, tan(yaw) per box), mode = int(np.packbits(mode[:4])[0]). */
+ * Sorting outputs: obs f32 [n_envs][14] (TCP xy, then x, y, tan(yaw) per box), mode = int(np.packbits(mode[:4])[0]).
+ * Stacking (stacking.py:449-481 with random=False): device f64 [n_envs][21] = 3 x (x, y, z = 0, qw, qx, qy, qz) for the red, green and blue box
+ * (BlockContextManager.set_context, stacking.py:99-125); fingers opened before the reset sub-step (:474).  Stacking outputs: obs f32 [n_envs][12] =
+ * (x, y, z, tan(yaw)) per box (stacking.py:228-277), mode = the order code of D3IL_SFLAG_MODE_MASK, info_f64[0] = info['mean_distance']. */
 int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, void* stream);
 
 /* Replaces env.step(action) (avoiding.py:168-171 over gym_env_wrapper.py:45-100): n_substeps fused physics
  * sub-steps.  actions: device f64[n_envs][7] = desired TCP (x, y, z, qw, qx, qy, qz), the array the harness
- * builds at avoiding_sim.py:64-66. */
+ * builds at avoiding_sim.py:64-66.  Stacking (stacking.py:331-393, 30 sub-steps): device f64[n_envs][8] = 7 desired joint positions of the
+ * joint-space PD law + the gripper command (open iff > 0.075, else close_fingers), the array the harness builds at stacking_sim.py:99-106. */
 int d3il_step(d3il_handle h, const double* actions, void* stream);
 
 int d3il_get_buffers(d3il_handle h, d3il_buffers* out);
@@ -141,14 +167,31 @@ int d3il_layernorm_f32(const float* x, const float* weight, const float* bias, f
  * memory, caller zeroes it), row ctx_id[env] (device i32[n_envs]; NULL = row 0) += {episodes, successes, successes by mode code}
  * with the mode code = Avoiding: 9-bit mode encoding; Pushing: info['mode'] + 1; Sorting: np.packbits code.  These are the
  * integer tables the metric tails work from (avoiding_sim.py:128-135, pushing_sim.py:140-167, sorting_sim.py:191-208) and the
- * input of the single cross-GPU all-reduce.  table = NULL switches the tally off. */
-enum { D3IL_TALLY_ROW = 2 + 512 };
+ * input of the single cross-GPU all-reduce.  table = NULL switches the tally off.
+ * Stacking: order code of D3IL_SFLAG_MODE_MASK (< 256) and, because info['success_1'] / ['success_2'] (stacking_sim.py:118-136) also count
+ * episodes that did not stack all three boxes, row[2 + D3IL_TALLY_ALL + code] += 1 for EVERY finished episode. */
+enum { D3IL_TALLY_ROW = 2 + 512, D3IL_TALLY_ALL = 256 };
 int d3il_set_tally(d3il_handle h, const int32_t* ctx_id_device, int n_ctx, int64_t* table_device);
 
 /* Integer metric counts on device: out_counts i64[2 + 512] = {n_done, n_success, histogram of 9-bit mode codes
  * among successful envs}; input to the cross-GPU reduction (one RCCL all-reduce, done by the Python layer)
  * and to success-rate / entropy (avoiding_sim.py:128-135). */
 int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream);
+
+/* The one exchange step of the path: the int64 metric tables of all GPUs are summed with ONE RCCL all-reduce over xGMI, issued by
+ * the library on the caller's stream.  Replaces the shared-memory tensors the reference's worker processes write their results into
+ * (avoiding_sim.py:104-118 `successes` / `mode_encoding` with share_memory_(), pushing_sim.py:96-131, sorting_sim.py:144-181,
+ * stacking_sim.py:182-216).  RCCL is resolved at run time (an RCCL already in the process - PyTorch's - or librccl.so), so the library
+ * does not link it.  Protocol: rank 0 calls d3il_comm_unique_id and hands the 128 bytes to the other ranks by any host channel (bench.py:
+ * a torch.distributed broadcast); every rank calls d3il_comm_init(id, rank, world, device_id) - collective -, then
+ * d3il_reduce_metrics(h, comm, table, count, stream) in place on device i64[count] (table = NULL: the table of d3il_set_tally), and
+ * d3il_comm_destroy.  Integer sums: bit-exact, independent of rank order and of the number of GPUs. */
+typedef struct d3il_comm_s* d3il_comm;
+typedef struct { char internal[128]; } d3il_rccl_unique_id;   /* = ncclUniqueId */
+int d3il_comm_unique_id(d3il_rccl_unique_id* out);
+int d3il_comm_init(const d3il_rccl_unique_id* id, int rank, int world, int device_id, d3il_comm* out);
+int d3il_comm_destroy(d3il_comm comm);
+int d3il_reduce_metrics(d3il_handle h, d3il_comm comm, int64_t* table_device, size_t count, void* stream);
 
 /* Timing of the last d3il_step kernel launch on its own stream (HIP events recorded around the launch when
  * enabled); used by bench.py for the roofline figure. */

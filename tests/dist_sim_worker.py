@@ -14,6 +14,7 @@ from d3il_amd import distributed as D  # noqa: E402
 from d3il_amd.simulation.avoiding_sim import Avoiding_Sim  # noqa: E402
 from d3il_amd.simulation.pushing_sim import Pushing_Sim  # noqa: E402
 from d3il_amd.simulation.sorting_sim import Sorting_Sim  # noqa: E402
+from d3il_amd.simulation.stacking_sim import Stacking_Sim  # noqa: E402
 
 
 class ChaseAgent:
@@ -71,6 +72,23 @@ def main():
     r3 = sim3.last_rollout
     out["sorting"] = dict(counts=[int(v) for v in r3["counts"]], mode_hist=[int(v) for v in r3["mode_hist"]], shard=list(r3["shard"]),
                           successes=res3["Metrics/successes"], entropy=res3["Metrics/entropy"])
+    # Stacking (BASELINE config 5's Sim class): scripted pick-and-place of the first box on 5 contexts x 2 rollouts, sharded over the ranks
+    import numpy as np
+    from d3il_amd.agents import ScriptedStackPolicy
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    from d3il_amd.distributed import shard_range
+    from d3il_amd.envs.stacking import load_test_contexts
+    from d3il_amd.model import blob
+    q0 = np.load(os.path.join(ROOT, "tests", "golden", "ref_offline_ik.npz"))["stacking__traj_last"]
+    nctx, ntraj = 5, 2
+    ctx = load_test_contexts()[:nctx]
+    tables = [build_trajectory(blob.load_json("stacking"), q0, c, n_boxes=1, speed=0.8) for c in ctx]
+    lo, hi = shard_range(nctx * ntraj, rank, world)
+    sim4 = Stacking_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=nctx, n_trajectories_per_context=ntraj,
+                        max_steps_per_episode=max(len(t) for t in tables) + 5, contexts=ctx)
+    sim4.test_agent(ScriptedStackPolicy(tables, torch.arange(lo, hi) // ntraj, device="cuda:0"))
+    r4 = sim4.last_rollout
+    out["stacking"] = dict(counts=[int(v) for v in r4["counts"]], shard=list(r4["shard"]), successes_1_box=r4["metrics"]["successes_1_box"])
     if rank == 0:
         print("RESULT " + json.dumps(out), flush=True)
     if world > 1:

@@ -41,9 +41,13 @@ def test_cpu_worker_counts_oracle_steps():
 
 
 def test_algorithmic_bytes_follow_the_survey():
-    # 2 S + A + O + F with S = the f64 state column + flags / counter words
-    assert bench.ALG_BYTES["avoiding"] == 2 * (42 * 8 + 8) + 56 + 8 + 4 == 756
-    assert bench.ALG_BYTES["pushing"] == 1212 and bench.ALG_BYTES["stacking"] == 1212 and bench.ALG_BYTES["sorting"] == 2 * (129 * 8 + 8) + 116
+    # B_alg = 2 S + A + O + F per env step - Avoiding 704 (S 328, A 28, O 16, F 4), Pushing 1152 (S 536, A 28, O 40, F 12),
+    # Sorting-4 1620 (S 760, A 28, O 64, F 8), Stacking 1228 (S 552, A 32, O 80, F 12); `roofline.achieved` is built from THESE
+    assert bench.ALG_BYTES == {"avoiding": 2 * 328 + 28 + 16 + 4, "pushing": 2 * 536 + 28 + 40 + 12, "sorting": 2 * 760 + 28 + 64 + 8,
+                               "stacking": 2 * 552 + 32 + 80 + 12}
+    assert bench.ALG_BYTES == {"avoiding": 704, "pushing": 1152, "sorting": 1620, "stacking": 1228}
+    # what the implementation's state column moves is reported next to it and is never smaller
+    assert all(bench.IMPL_BYTES[k] >= bench.ALG_BYTES[k] for k in bench.ALG_BYTES)
 
 
 @pytest.mark.gpu
@@ -61,3 +65,25 @@ def test_json_line_of_a_short_run():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["single_core_value"] > 0
     assert abs(line["value"] - 512 * 5 / (line["ms_per_step"] * 5e-3)) / line["value"] < 1e-6
+    assert r["algorithmic_bytes_per_env_step"] == 704 and r["algorithmic_bytes_per_launch"] == 704 * 512
+
+
+@pytest.mark.gpu
+def test_gpus_2_self_spawn_runs_two_ranks():
+    """`python bench.py --gpus 2` without a launcher re-launches itself under torch.distributed.run.  On the one-GPU box
+    both ranks are pinned to GPU 0 and rendezvous over gloo (RCCL needs distinct GPUs); shards, Philox offsets, the tally reduction and the
+    max-over-ranks timing are the code path of the 8-GPU run."""
+    env = dict(os.environ, D3IL_BENCH_FORCE_DEVICE="0", D3IL_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--preroll", "270", "--envs", "256"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "env-shard x2" and line["config"]["envs_per_gpu"] == 256
+    assert abs(line["value"] - 2 * 256 * 6 / (line["ms_per_step"] * 6e-3)) / line["value"] < 1e-6
+    assert "cpu_baseline" not in line                                  # rank 0 at N = 1 only
+    assert line["config"]["episodes_finished_all_ranks"] >= line["config"]["episodes_finished_rank0"] > 0
+    assert "torch.distributed" in line["config"]["metric_reduction"]

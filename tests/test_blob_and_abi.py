@@ -64,3 +64,49 @@ def test_product_fails_loudly_without_device():
     from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
     with pytest.raises(capi.D3ilError):
         ObstacleAvoidanceVecEnv(4, device="cpu")
+
+
+def _header_enums():
+    """{name: value} of every `NAME = value` inside the enums of include/d3il_rollout.h and d3il_model_blob.h (plain C constant expressions)."""
+    vals = {}
+    for fn in ("d3il_model_blob.h", "d3il_rollout.h"):
+        with open(os.path.join(ROOT, "include", fn)) as f:
+            text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+        for body in re.findall(r"enum\s*\{(.*?)\}", text, flags=re.S):
+            for name, expr in re.findall(r"\b(D3IL_[A-Z0-9_]+)\s*=\s*([^,}]+)", body):
+                vals[name] = int(eval(expr.strip(), {"__builtins__": {}}, dict(vals)))
+    return vals
+
+
+def test_python_binding_constants_agree_with_the_header():
+    """capi.py mirrors include/d3il_rollout.h by hand (the header had no Stacking layout): every constant the binding
+    defines must equal the header's."""
+    from d3il_amd import capi
+    h = _header_enums()
+    pairs = {"STATE_F64": "D3IL_STATE_F64", "STATE_QPOS": "D3IL_STATE_QPOS", "STATE_QVEL": "D3IL_STATE_QVEL", "STATE_BIAS": "D3IL_STATE_BIAS",
+             "STATE_TCP": "D3IL_STATE_TCP", "STATE_IK_Q": "D3IL_STATE_IK_Q", "STATE_IK_QD": "D3IL_STATE_IK_QD",
+             "FLAG_MODE_MASK": "D3IL_FLAG_MODE_MASK", "FLAG_TERMINATED": "D3IL_FLAG_TERMINATED", "FLAG_SUCCESS": "D3IL_FLAG_SUCCESS",
+             "FLAG_ROD_CONTACT": "D3IL_FLAG_ROD_CONTACT", "FLAG_IK_VALID": "D3IL_FLAG_IK_VALID", "FLAG_SOLVER_FAIL": "D3IL_FLAG_SOLVER_FAIL",
+             "FLAG_MULTI_CONTACT": "D3IL_FLAG_MULTI_CONTACT",
+             "PUSH_STATE_BOX": "D3IL_PUSH_STATE_BOX", "PUSH_STATE_WARM": "D3IL_PUSH_STATE_WARM", "PUSH_STATE_F64": "D3IL_PUSH_STATE_F64",
+             "PFLAG_FIRST_MASK": "D3IL_PFLAG_FIRST_MASK", "PFLAG_MODE_MASK": "D3IL_PFLAG_MODE_MASK", "PFLAG_WARM_VALID": "D3IL_PFLAG_WARM_VALID",
+             "PFLAG_CON_OVERFLOW": "D3IL_PFLAG_CON_OVERFLOW", "PFLAG_OFF_TABLE": "D3IL_PFLAG_OFF_TABLE",
+             "SORT_STATE_BOX": "D3IL_SORT_STATE_BOX", "SORT_STATE_WARM": "D3IL_SORT_STATE_WARM", "SORT_STATE_TASK": "D3IL_SORT_STATE_TASK",
+             "SORT_STATE_F64": "D3IL_SORT_STATE_F64",
+             "STACK_STATE_BOX": "D3IL_STACK_STATE_BOX", "STACK_STATE_WARM": "D3IL_STACK_STATE_WARM", "STACK_STATE_F64": "D3IL_STACK_STATE_F64",
+             "SFLAG_MODE_MASK": "D3IL_SFLAG_MODE_MASK", "SFLAG_WARM_VALID": "D3IL_SFLAG_WARM_VALID", "SFLAG_HAND_NEAR": "D3IL_SFLAG_HAND_NEAR",
+             "TASK_AVOIDING": "D3IL_TASK_AVOIDING", "TASK_PUSHING": "D3IL_TASK_PUSHING", "TASK_SORTING": "D3IL_TASK_SORTING",
+             "TASK_STACKING": "D3IL_TASK_STACKING", "TALLY_ROW": "D3IL_TALLY_ROW", "TALLY_ALL": "D3IL_TALLY_ALL", "ERCCL": "D3IL_ERCCL"}
+    for py, c in pairs.items():
+        assert c in h, c
+        assert getattr(capi, py) == h[c], (py, getattr(capi, py), h[c])
+    assert h["D3IL_STACK_STATE_F64"] == 28 + 3 * 13 + 27 and h["D3IL_SORT_STATE_F64"] == 42 + 4 * 13 + 33 + 2
+    # Buffers mirrors d3il_buffers field by field
+    with open(os.path.join(ROOT, "include", "d3il_rollout.h")) as f:
+        body = re.search(r"typedef struct d3il_buffers \{(.*?)\} d3il_buffers;", re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S), flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            fields += [n.strip().lstrip("*") for n in decl.split(None, 1)[1].split(",")]
+    assert fields == [f[0] for f in capi.Buffers._fields_]

