@@ -421,3 +421,38 @@ def test_library_rccl_reduction_single_rank():
     assert L.d3il_reduce_metrics(env.h, comm.comm, None, 0, None) == -1     # no table registered with d3il_set_tally
     comm.close()
     env.close()
+
+
+def test_config5_total_size_32768_environments(stack_js, ctx100):
+    """BASELINE config 5's TOTAL size (32768 environments; per GPU it is 4096) on one GPU: the engine is not tied to the per-GPU shard size.
+    Eight reference contexts tiled, scripted approach - grasp - lift: every state finite, no flag, all 4096 lanes of a context bit-identical and
+    equal to the same context in a 64-environment batch."""
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    ids = [0, 3, 11, 42, 57, 64, 80, 99]
+    finals = {}
+    for n in (64, 32768):
+        env = _env(n)
+        q0, _, _ = env.start()
+        which = np.arange(n) % len(ids)
+        env.reset(context=ctx100[[ids[w] for w in which]])
+        trajs = [build_trajectory(stack_js, q0, ctx100[i], n_boxes=1, speed=0.8) for i in ids]
+        T = min(min(len(t) for t in trajs), 75)
+        tab = torch.as_tensor(np.stack([tr[:T] for tr in trajs]), dtype=torch.float64, device=env.device)      # [ctx, T, 8]
+        sel = torch.as_tensor(which, device=env.device)
+        for t in range(T):
+            env.step(tab[sel, t].contiguous())
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        assert np.isfinite(st).all() and (sc == T).all()
+        assert not (fl & (BAD | (1 << 20))).any(), hex(int(np.bitwise_or.reduce(fl)))
+        per_ctx = []
+        for k in range(len(ids)):
+            lanes = np.nonzero(which == k)[0]
+            ref = st[:, lanes[0]]
+            assert (st[:, lanes] == ref[:, None]).all()
+            per_ctx.append(ref.copy())
+        finals[n] = per_ctx
+        assert max(float(p[SK_BOX_Z]) for p in per_ctx) > 0.03          # boxes have left the table
+        env.close()
+    for k in range(len(ids)):
+        assert np.array_equal(finals[64][k], finals[32768][k])
