@@ -155,129 +155,214 @@ D3IL_HD void quat2mat(const double* q, double* R) {   // mju_quat2Mat [ext]
 // box-box: separating-axis test over 15 axes, then a face contact (incident face clipped against the reference face;
 // every clipped vertex inside the margin is a contact, positioned midway between the surfaces) or one edge-edge contact.
 // out[k] = {dist, pos[3], normal[3]}, normal from box 1 to box 2.  p: centres, R: row-major rotation (columns = axes).
-D3IL_HD int box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
-                    double margin, double (*out)[7], int cap) {
+// Register-only formulation: every array index is a compile-time constant after unrolling (dynamic axis choices are resolved with
+// selects, the Sutherland-Hodgman clip grows its polygon by select-chain inserts), so the routine needs no private (scratch) memory
+// on the device.  Contacts are handed to `emit(dist, pos[3], normal[3])` in polygon order; at most `cap` (<= 8) are emitted.
+D3IL_HD double bb_sel3(const double* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
+D3IL_HD void bb_row(const double (*M)[3], int i, double* o) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) o[k] = i == 0 ? M[0][k] : (i == 1 ? M[1][k] : M[2][k]);
+}
+template <int N> D3IL_HD void bb_put(double (*P)[3], int at, double x, double y, double z) {      // P[at] = (x, y, z), at < N
+#pragma unroll
+  for (int j = 0; j < N; j++) if (at == j) { P[j][0] = x; P[j][1] = y; P[j][2] = z; }
+}
+// one side of the clip: IN vertices in, at most IN + 1 out (a convex polygon gains at most one vertex per half plane)
+template <int IN> D3IL_HD int bb_clip_side(const double (*poly)[3], int np, int cdim, double sg, double lim, double etol, double (*out)[3]) {
+  int nn = 0;
+#pragma unroll
+  for (int v = 0; v < IN; v++) {
+    if (v >= np) continue;
+    double q[3];      // successor vertex: v + 1, or vertex 0 after the last one
+#pragma unroll
+    for (int k = 0; k < 3; k++) q[k] = (v + 1 == np || v + 1 >= IN) ? poly[0][k] : poly[v + 1 < IN ? v + 1 : 0][k];
+    const double pc = cdim ? poly[v][1] : poly[v][0], qc = cdim ? q[1] : q[0];
+    const double fp = sg * pc - lim, fq = sg * qc - lim;
+    if (fp <= etol) { bb_put<IN + 1>(out, nn, poly[v][0], poly[v][1], poly[v][2]); nn++; }
+    if ((fp <= etol) != (fq <= etol)) {
+      const double t = fp / (fp - fq);
+      bb_put<IN + 1>(out, nn, poly[v][0] + t * (q[0] - poly[v][0]), poly[v][1] + t * (q[1] - poly[v][1]), poly[v][2] + t * (q[2] - poly[v][2]));
+      nn++;
+    }
+    if (nn > IN) nn = IN + 1;     // cannot happen for a convex polygon; keeps the inserts inside the array under round-off
+  }
+  return nn > IN + 1 ? IN + 1 : nn;
+}
+template <class EMIT>
+D3IL_HD int box_box_emit(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
+                         double margin, int cap, EMIT emit) {
   const double FUDGE = 1.05;
   const double ETOL = 1e-12;   // a vertex this close to a side plane of the reference face counts as inside (faces of equal extent lying on each other)
   double A[3][3], B[3][3], d[3], Cm[3][3], Q[3][3], dA[3], dB[3];
-  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = R1[3 * k + i]; B[i][k] = R2[3 * k + i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { A[i][k] = R1[3 * k + i]; B[i][k] = R2[3 * k + i]; }
+  }
+#pragma unroll
   for (int k = 0; k < 3; k++) d[k] = p2[k] - p1[k];
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     dA[i] = dot3(d, A[i]); dB[i] = dot3(d, B[i]);
+#pragma unroll
     for (int j = 0; j < 3; j++) { Cm[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(Cm[i][j]); }
   }
   double best = -1e300; int code = -1; double nsign = 1;
+  bool apart = false;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     double sep = fabs(dA[i]) - (s1[i] + s2[0] * Q[i][0] + s2[1] * Q[i][1] + s2[2] * Q[i][2]);
-    if (sep > margin) return 0;
-    if (sep > best + 1e-10) { best = sep; code = i; nsign = dA[i] < 0 ? -1 : 1; }
+    if (sep > margin) apart = true;
+    if (!apart && sep > best + 1e-10) { best = sep; code = i; nsign = dA[i] < 0 ? -1 : 1; }
   }
+  if (apart) return 0;
+#pragma unroll
   for (int j = 0; j < 3; j++) {
     double sep = fabs(dB[j]) - (s2[j] + s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j]);
-    if (sep > margin) return 0;
+    if (sep > margin) apart = true;
     // a face axis of box 2 must beat box 1's by more than 1e-10 - unless the two tie within that band and box 2 offers the larger
     // face: a small box lying flat on a big one is then clipped against the big face (reference) whichever geom comes first
     bool wins = sep > best + 1e-10;
-    if (!wins && code >= 0 && code < 3 && sep >= best - 1e-10 && s2[(j + 1) % 3] * s2[(j + 2) % 3] > s1[(code + 1) % 3] * s1[(code + 2) % 3]) wins = true;
-    if (wins) { best = sep; code = 3 + j; nsign = dB[j] < 0 ? -1 : 1; }
+    const int c1 = code < 3 ? (code + 1) % 3 : 0, c2 = code < 3 ? (code + 2) % 3 : 0;
+    if (!wins && code >= 0 && code < 3 && sep >= best - 1e-10 && s2[(j + 1) % 3] * s2[(j + 2) % 3] > bb_sel3(s1, c1) * bb_sel3(s1, c2)) wins = true;
+    if (!apart && wins) { best = sep; code = 3 + j; nsign = dB[j] < 0 ? -1 : 1; }
   }
+  if (apart) return 0;
   double en[3] = {0, 0, 0};
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-    double l2 = 1 - Cm[i][j] * Cm[i][j];
-    if (l2 < 1e-10) continue;
-    double l = sqrt(l2);
-    double proj = dA[i2] * Cm[i1][j] - dA[i1] * Cm[i2][j];
-    double ra = s1[i1] * Q[i2][j] + s1[i2] * Q[i1][j], rb = s2[j1] * Q[i][j2] + s2[j2] * Q[i][j1];
-    double sep = (fabs(proj) - (ra + rb)) / l;
-    if (sep > margin) return 0;
-    // 5 % better: a shallower penetration (sep < 0) or, for boxes apart but inside the margin (sep > 0), a larger gap
-    if (sep > 0 ? sep > best * FUDGE + 1e-10 : (sep * FUDGE > best + 1e-10 && sep > best)) {
-      best = sep; code = 6 + 3 * i + j;
-      double Lx[3]; cross3(A[i], B[j], Lx);
-      double sg = proj < 0 ? -1 : 1;
-      for (int k = 0; k < 3; k++) en[k] = sg * Lx[k] / l;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      constexpr int M3[5] = {0, 1, 2, 0, 1};
+      const int i1 = M3[i + 1], i2 = M3[i + 2], j1 = M3[j + 1], j2 = M3[j + 2];
+      double l2 = 1 - Cm[i][j] * Cm[i][j];
+      if (l2 < 1e-10 || apart) continue;
+      double l = sqrt(l2);
+      double proj = dA[i2] * Cm[i1][j] - dA[i1] * Cm[i2][j];
+      double ra = s1[i1] * Q[i2][j] + s1[i2] * Q[i1][j], rb = s2[j1] * Q[i][j2] + s2[j2] * Q[i][j1];
+      double sep = (fabs(proj) - (ra + rb)) / l;
+      if (sep > margin) { apart = true; continue; }
+      // 5 % better: a shallower penetration (sep < 0) or, for boxes apart but inside the margin (sep > 0), a larger gap
+      if (sep > 0 ? sep > best * FUDGE + 1e-10 : (sep * FUDGE > best + 1e-10 && sep > best)) {
+        best = sep; code = 6 + 3 * i + j;
+        double Lx[3]; cross3(A[i], B[j], Lx);
+        double sg = proj < 0 ? -1 : 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) en[k] = sg * Lx[k] / l;
+      }
     }
   }
+  if (apart) return 0;
   if (code >= 6) {
-    int i = (code - 6) / 3, j = (code - 6) % 3;
-    double pa[3], pb[3];
+    const int i = (code - 6) / 3, j = (code - 6) % 3;
+    double pa[3], pb[3], Ai_[3], Bj_[3];
+    bb_row(A, i, Ai_); bb_row(B, j, Bj_);
+#pragma unroll
     for (int k = 0; k < 3; k++) { pa[k] = p1[k]; pb[k] = p2[k]; }
-    for (int a = 0; a < 3; a++) if (a != i) { double sg = dot3(en, A[a]) > 0 ? 1 : -1; for (int k = 0; k < 3; k++) pa[k] += sg * s1[a] * A[a][k]; }
-    for (int b = 0; b < 3; b++) if (b != j) { double sg = dot3(en, B[b]) > 0 ? -1 : 1; for (int k = 0; k < 3; k++) pb[k] += sg * s2[b] * B[b][k]; }
+#pragma unroll
+    for (int a = 0; a < 3; a++) if (a != i) { double sg = dot3(en, A[a]) > 0 ? 1 : -1;
+#pragma unroll
+      for (int k = 0; k < 3; k++) pa[k] += sg * s1[a] * A[a][k]; }
+#pragma unroll
+    for (int b = 0; b < 3; b++) if (b != j) { double sg = dot3(en, B[b]) > 0 ? -1 : 1;
+#pragma unroll
+      for (int k = 0; k < 3; k++) pb[k] += sg * s2[b] * B[b][k]; }
     double w[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
-    double cc = Cm[i][j], wa = dot3(w, A[i]), wb = dot3(w, B[j]), den = 1 - cc * cc;
+    double crow[3] = {bb_sel3(Cm[0], j), bb_sel3(Cm[1], j), bb_sel3(Cm[2], j)};
+    double cc = bb_sel3(crow, i), wa = dot3(w, Ai_), wb = dot3(w, Bj_), den = 1 - cc * cc;
     double al = (wa - cc * wb) / den, be = (cc * wa - wb) / den;
     if (cap < 1) return 0;
-    out[0][0] = best;
-    for (int k = 0; k < 3; k++) { out[0][1 + k] = 0.5 * (pa[k] + al * A[i][k] + pb[k] + be * B[j][k]); out[0][4 + k] = en[k]; }
+    double pos[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (pa[k] + al * Ai_[k] + pb[k] + be * Bj_[k]);
+    emit(best, pos, en);
     return 1;
   }
-  bool ref2 = code >= 3; int ax = ref2 ? code - 3 : code;
-  const double* pr = ref2 ? p2 : p1; const double* pi = ref2 ? p1 : p2;
-  const double* sr = ref2 ? s2 : s1; const double* si = ref2 ? s1 : s2;
-  double (*Ar)[3] = ref2 ? B : A; double (*Ai)[3] = ref2 ? A : B;
-  double n[3], sgn = ref2 ? -nsign : nsign;
-  for (int k = 0; k < 3; k++) n[k] = sgn * Ar[ax][k];
+  const bool ref2 = code >= 3; const int ax = ref2 ? code - 3 : code;
+  double pr[3], pi[3], sr[3], si[3], Ar[3][3], Ai[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { pr[k] = ref2 ? p2[k] : p1[k]; pi[k] = ref2 ? p1[k] : p2[k]; sr[k] = ref2 ? s2[k] : s1[k]; si[k] = ref2 ? s1[k] : s2[k]; }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { Ar[a][k] = ref2 ? B[a][k] : A[a][k]; Ai[a][k] = ref2 ? A[a][k] : B[a][k]; }
+  }
+  const int a1 = ax == 2 ? 0 : ax + 1, a2 = ax == 0 ? 2 : ax - 1;      // (ax + 1) % 3, (ax + 2) % 3
+  double Arx[3], Ar1[3], Ar2[3];
+  bb_row(Ar, ax, Arx); bb_row(Ar, a1, Ar1); bb_row(Ar, a2, Ar2);
+  const double srx = bb_sel3(sr, ax), sr1 = bb_sel3(sr, a1), sr2 = bb_sel3(sr, a2);
+  double n[3]; const double sgn = ref2 ? -nsign : nsign;
+#pragma unroll
+  for (int k = 0; k < 3; k++) n[k] = sgn * Arx[k];
   int kin = 0; double bestdot = -1;
+#pragma unroll
   for (int k = 0; k < 3; k++) { double t = fabs(dot3(n, Ai[k])); if (t > bestdot) { bestdot = t; kin = k; } }
-  double sgi = dot3(n, Ai[kin]) > 0 ? -1 : 1;
-  int k1 = (kin + 1) % 3, k2 = (kin + 2) % 3, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+  const int k1 = kin == 2 ? 0 : kin + 1, k2 = kin == 0 ? 2 : kin - 1;
+  double Aik[3], Ai1[3], Ai2[3];
+  bb_row(Ai, kin, Aik); bb_row(Ai, k1, Ai1); bb_row(Ai, k2, Ai2);
+  const double sik = bb_sel3(si, kin), si1 = bb_sel3(si, k1), si2 = bb_sel3(si, k2);
+  const double sgi = dot3(n, Aik) > 0 ? -1 : 1;
   double p4[4][3];
   bool inside = true;      // the incident face lies within the side planes of the reference face: nothing to clip
 #pragma unroll
   for (int v = 0; v < 4; v++) {
     double c0 = (v == 0 || v == 3) ? 1.0 : -1.0, c1 = v < 2 ? 1.0 : -1.0, x[3];
-    for (int k = 0; k < 3; k++) x[k] = pi[k] + sgi * si[kin] * Ai[kin][k] + c0 * si[k1] * Ai[k1][k] + c1 * si[k2] * Ai[k2][k] - pr[k];
-    p4[v][0] = dot3(x, Ar[a1]); p4[v][1] = dot3(x, Ar[a2]); p4[v][2] = dot3(x, n) - sr[ax];
-    inside = inside && p4[v][0] - sr[a1] <= ETOL && -p4[v][0] - sr[a1] <= ETOL && p4[v][1] - sr[a2] <= ETOL && -p4[v][1] - sr[a2] <= ETOL;
+#pragma unroll
+    for (int k = 0; k < 3; k++) x[k] = pi[k] + sgi * sik * Aik[k] + c0 * si1 * Ai1[k] + c1 * si2 * Ai2[k] - pr[k];
+    p4[v][0] = dot3(x, Ar1); p4[v][1] = dot3(x, Ar2); p4[v][2] = dot3(x, n) - srx;
+    inside = inside && p4[v][0] - sr1 <= ETOL && -p4[v][0] - sr1 <= ETOL && p4[v][1] - sr2 <= ETOL && -p4[v][1] - sr2 <= ETOL;
   }
+  auto out_vertex = [&](double px, double py, double w) {
+    double pos[3], nn[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pos[k] = pr[k] + px * Ar1[k] + py * Ar2[k] + (srx + 0.5 * w) * n[k]; nn[k] = ref2 ? -n[k] : n[k]; }
+    emit(w, pos, nn);
+  };
+  int cnt = 0;
   if (inside) {
     // the clipping below would return the four vertices unchanged and in order; they are distinct, so no duplicate test either
-    int cnt = 0;
 #pragma unroll
     for (int v = 0; v < 4; v++) {
       const double w = p4[v][2];
       if (w >= margin || cnt >= cap) continue;
-      out[cnt][0] = w;
-      for (int k = 0; k < 3; k++) {
-        out[cnt][1 + k] = pr[k] + p4[v][0] * Ar[a1][k] + p4[v][1] * Ar[a2][k] + (sr[ax] + 0.5 * w) * n[k];
-        out[cnt][4 + k] = ref2 ? -n[k] : n[k];
-      }
+      out_vertex(p4[v][0], p4[v][1], w);
       cnt++;
     }
     return cnt;
   }
-  double poly[16][3], tmp[16][3]; int np = 4;
-  for (int v = 0; v < 4; v++) for (int k = 0; k < 3; k++) poly[v][k] = p4[v][k];
-  for (int side = 0; side < 4; side++) {
-    int cdim = side >> 1; double sg = (side & 1) ? -1 : 1, lim = sr[cdim ? a2 : a1];
-    int nn = 0;
-    for (int v = 0; v < np; v++) {
-      int vn = v + 1 == np ? 0 : v + 1;
-      double fp = sg * poly[v][cdim] - lim, fq = sg * poly[vn][cdim] - lim;
-      if (fp <= ETOL) { for (int k = 0; k < 3; k++) tmp[nn][k] = poly[v][k]; nn++; }
-      if ((fp <= ETOL) != (fq <= ETOL)) { double t = fp / (fp - fq); for (int k = 0; k < 3; k++) tmp[nn][k] = poly[v][k] + t * (poly[vn][k] - poly[v][k]); nn++; }
-    }
-    np = nn;
-    for (int v = 0; v < np; v++) for (int k = 0; k < 3; k++) poly[v][k] = tmp[v][k];
-    if (np == 0) return 0;
-  }
-  int cnt = 0;
-  for (int v = 0; v < np && cnt < cap; v++) {
-    double w = poly[v][2];
+  // Sutherland-Hodgman against the four side planes of the reference face (side: +a1, -a1, +a2, -a2)
+  double q5[5][3], q6[6][3], q7[7][3], poly[8][3];
+  int np = bb_clip_side<4>(p4, 4, 0, 1.0, sr1, ETOL, q5);
+  if (np == 0) return 0;
+  np = bb_clip_side<5>(q5, np, 0, -1.0, sr1, ETOL, q6);
+  if (np == 0) return 0;
+  np = bb_clip_side<6>(q6, np, 1, 1.0, sr2, ETOL, q7);
+  if (np == 0) return 0;
+  np = bb_clip_side<7>(q7, np, 1, -1.0, sr2, ETOL, poly);
+  if (np == 0) return 0;
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    if (v >= np || cnt >= cap) continue;
+    const double w = poly[v][2];
     if (w >= margin) continue;
     bool dup = false;
+#pragma unroll
     for (int q = 0; q < v; q++) if (fabs(poly[q][0] - poly[v][0]) + fabs(poly[q][1] - poly[v][1]) < 1e-12 && poly[q][2] < margin) dup = true;
     if (dup) continue;
-    out[cnt][0] = w;
-    for (int k = 0; k < 3; k++) {
-      out[cnt][1 + k] = pr[k] + poly[v][0] * Ar[a1][k] + poly[v][1] * Ar[a2][k] + (sr[ax] + 0.5 * w) * n[k];
-      out[cnt][4 + k] = ref2 ? -n[k] : n[k];
-    }
+    out_vertex(poly[v][0], poly[v][1], w);
     cnt++;
   }
   return cnt;
+}
+// array interface (host build, reset kernels, the Pushing / Sorting engines): out[k] = {dist, pos[3], normal[3]}
+D3IL_HD int box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
+                    double margin, double (*out)[7], int cap) {
+  int n = 0;
+  return box_box_emit(p1, R1, s1, p2, R2, s2, margin, cap < 8 ? cap : 8, [&](double dist, const double* pos, const double* nrm) {
+    out[n][0] = dist;
+    for (int k = 0; k < 3; k++) { out[n][1 + k] = pos[k]; out[n][4 + k] = nrm[k]; }
+    n++;
+  });
 }
 
 // rod (cylinder, axis u through pc, radius rad, half length half) against a box: closest points of the axis segment

@@ -2,11 +2,12 @@
 //
 // A workgroup is ONE wave that owns SK_LANES environments (4: 1024 workgroups for 4096 environments, one per SIMD).  The per-lane
 // parts of a sub-step (arm dynamics, collision, limit rows, integration: one lane per environment, the other lanes idle) alternate
-// with the wave-cooperative constraint solve (sk_solve_coop: all 64 lanes on one environment, the workgroup's environments one after
-// the other, so an environment iterates exactly as long as IT needs and the lanes of a wave never wait for each other's Newton
-// iterations).  LDS: 717 doubles per environment (vectors, kinematic tables, packed 27 x 27 Hessian; contiguous per environment) + the
-// wave's contact-row area (60 x 32 doubles) = 38.3 KiB per workgroup, four workgroups per CU; contact records in an HBM scratch
-// area (36 doubles x 32 per environment, contiguous per environment).  The arm is the gripper robot of panda_invisible.xml, its
+// with the wave-cooperative constraint solve (sk_solve_dual: the 64 lanes work on TWO environments at a time, one per half wave - a
+// 27-dof system with at most 32 contacts fits 32 lanes -, the workgroup's two pairs one after the other; a half that has converged
+// idles until the other one has).  LDS (layout: stack_step.h SE_*): the workgroup's shared Hessian + contact-row / staging area, and per environment its
+// vectors, kinematic tables, STATE and compact contact records = 38.2 KiB per workgroup, four workgroups per CU.  An environment's
+// state is in registers only inside a phase; between the phases of a sub-step everything is LDS resident and nothing goes through HBM
+// (the round-2 kernel kept 134 VGPRs of state live across the cooperative phases and its contact records in an HBM scratch area).  The arm is the gripper robot of panda_invisible.xml, its
 // constants baked at build time (csrc/gen/stacking_consts.inc).  No controller wave: the task's control law is a joint PD.
 // The reset kernel runs the one-lane solver (sk_solve) - it is the host build's code path and off the hot path.
 #pragma once
@@ -15,7 +16,8 @@
 namespace d3il {
 
 constexpr int STACK_LDS_RESET = ST_SIZE * SK_LANES * 8;
-constexpr int STACK_LDS = (ST_SIZE * SK_LANES + SKC_JSIZE) * 8;
+constexpr int STACK_LDS = (SKC_SHARED + SE_SIZE * SK_LANES) * 8;
+static_assert(STACK_LDS <= 40 * 1024, "four workgroups per CU (one per SIMD) need <= 40 KiB of LDS each");
 
 __device__ __forceinline__ void stack_load(const double* __restrict__ state, const unsigned* __restrict__ flags, const int* __restrict__ steps, int stride, int e, StackState& ss) {
   const double* s = state + e;
@@ -50,6 +52,78 @@ __device__ __forceinline__ void stack_store(double* __restrict__ state, unsigned
   flags[e] = st.flags; steps[e] = st.step;
 }
 
+// ---- the environment's state between the phases of a sub-step: LDS (velocities in ST_VEL, box positions in ST_BP, the rest in SE_*)
+__device__ __forceinline__ void sk_state_to_lds(sk_lds_double* t, const StackState& ss) {
+  for (int k = 0; k < NDOF; k++) { t[SE_Q + k] = ss.arm.q[k]; t[ST_VEL + SK_ARM0 + k] = ss.arm.v[k]; }
+  for (int k = 0; k < NARM; k++) t[SE_BIAS + k] = ss.arm.bias[k];
+  for (int k = 0; k < 3; k++) t[SE_TCP + k] = ss.arm.tcp[k];
+  for (int b = 0; b < SK_NB; b++) {
+    for (int k = 0; k < 3; k++) t[ST_BP + 3 * b + k] = ss.box[b].pos[k];
+    for (int k = 0; k < 4; k++) t[SE_BQ + 4 * b + k] = ss.box[b].quat[k];
+    for (int k = 0; k < 6; k++) t[ST_VEL + 6 * b + k] = ss.box[b].vel[k];
+  }
+}
+__device__ __forceinline__ void sk_state_from_lds(const sk_lds_double* t, StackState& ss) {
+  for (int k = 0; k < NDOF; k++) { ss.arm.q[k] = t[SE_Q + k]; ss.arm.v[k] = t[ST_VEL + SK_ARM0 + k]; }
+  for (int k = 0; k < NARM; k++) ss.arm.bias[k] = t[SE_BIAS + k];
+  for (int k = 0; k < 3; k++) ss.arm.tcp[k] = t[SE_TCP + k];
+  for (int b = 0; b < SK_NB; b++) {
+    for (int k = 0; k < 3; k++) ss.box[b].pos[k] = t[ST_BP + 3 * b + k];
+    for (int k = 0; k < 4; k++) ss.box[b].quat[k] = t[SE_BQ + 4 * b + k];
+    for (int k = 0; k < 6; k++) ss.box[b].vel[k] = t[ST_VEL + 6 * b + k];
+  }
+}
+// phase 1 (lane = environment): control law + arm forward pass, kinematic tables, smooth accelerations
+__device__ __attribute__((noinline)) void sk_phase_pre(sk_lds_double* t, sk_glb_double* g, unsigned& flags, bool open) {
+  StackState ss;
+  sk_state_from_lds(t, ss);
+  ss.arm.flags = flags;
+  double act[NARM], tau[NARM], ff[NFING];
+  for (int k = 0; k < NARM; k++) act[k] = t[SE_ACT + k];
+  const StackScratch sc{t, g};
+  stack_control(kStackingConsts, ss.arm, act, open ? 0.04 : 0.0, !open, tau, ff);
+  stack_pre_kin(kStackingConsts, g_stack_consts, ss, sc, tau, ff);
+  for (int k = 0; k < NARM; k++) t[SE_BIAS + k] = ss.arm.bias[k];
+  for (int k = 0; k < 3; k++) t[SE_TCP + k] = ss.arm.tcp[k];
+  flags = ss.arm.flags;
+}
+// phase 3 (lane = environment): joint-limit rows, start point of the solver, "does the solver run"
+__device__ __attribute__((noinline)) void sk_phase_mid(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
+  StackState ss;
+  for (int k = 0; k < NDOF; k++) { ss.arm.q[k] = t[SE_Q + k]; ss.arm.v[k] = t[ST_VEL + SK_ARM0 + k]; }
+  ss.arm.flags = flags;
+  const int ncon = (int)t[SE_NCON];
+  if (t[SE_NEED] != 0.0) flags |= SKF_CON_OVERFLOW;      // the collision phase dropped contacts
+  unsigned has = 0;
+  int jsz = 0;
+  for (int ci = 0; ci < ncon; ci++) {
+    const int meta = (int)t[SE_REC + ci * SREC2 + 7];
+    const int ba = sk_blk_of(meta & 15);
+    has |= 1u << sk_blk_of((meta >> 4) & 15); if (ba >= 0) has |= 1u << ba;
+    jsz += 4 * sk_jcols(meta & 15, (meta >> 4) & 15);
+  }
+  t[SE_JSZ] = (double)jsz;
+  bool any_lim = false;
+  const StackScratch sc{t, g};
+  stack_pre_finish<true>(kStackingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
+  t[SE_NEED] = (ncon > 0 || any_lim) ? 1.0 : 0.0;
+}
+// phase 5 (lane = environment): mj_Euler
+__device__ __attribute__((noinline)) void sk_phase_post(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
+  StackState ss;
+  sk_state_from_lds(t, ss);
+  ss.arm.flags = flags;
+  const StackScratch sc{t, g};
+  stack_substep_post<true>(kStackingConsts, g_stack_consts, ss, sc);
+  for (int k = 0; k < NDOF; k++) { t[SE_Q + k] = ss.arm.q[k]; t[ST_VEL + SK_ARM0 + k] = ss.arm.v[k]; }
+  for (int b = 0; b < SK_NB; b++) {
+    for (int k = 0; k < 3; k++) t[ST_BP + 3 * b + k] = ss.box[b].pos[k];
+    for (int k = 0; k < 4; k++) t[SE_BQ + 4 * b + k] = ss.box[b].quat[k];
+    for (int k = 0; k < 6; k++) t[ST_VEL + 6 * b + k] = ss.box[b].vel[k];
+  }
+  flags = ss.arm.flags;
+}
+
 // env.step(action[8]) for the Stacking task (stacking.py:331-393): 7 joint targets + gripper command
 __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
                                                         const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
@@ -59,16 +133,15 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
   const int lane = threadIdx.x;
   const int e = blockIdx.x * SK_LANES + lane;
   const bool live = lane < SK_LANES && e < n;
-  const int le = live ? lane : 0;
-  const size_t ee = live ? e : 0;
-  const StackScratch sc{(sk_lds_double*)(smem + le * ST_SIZE), (sk_glb_double*)(scratch + ee * SG_SIZE)};
-  sk_lds_double* Jw = (sk_lds_double*)(smem + SK_LANES * ST_SIZE);
-  StackState ss;
-  double act[SK_ACT];
+  sk_lds_double* const sm = (sk_lds_double*)smem;
+  sk_lds_double* const t = sk_env_view(sm, live ? lane : 0);
+  sk_glb_double* const g = (sk_glb_double*)(scratch + (size_t)(live ? e : 0) * SG_SIZE);      // diagnostics words only (stats build)
+  unsigned fl = 0; int step = 0;
   bool bad = false, open = true;
-  float o[SK_OBS]; unsigned char dn = 0; double md = 0;
   if (live) {
+    StackState ss;
     stack_load(state, flags, steps, stride, e, ss);
+    double act[SK_ACT];
 #pragma unroll
     for (int k = 0; k < SK_ACT; k++) act[k] = actions[(size_t)e * SK_ACT + k];
     bad = action_is_bad(actions + (size_t)e * SK_ACT, SK_ACT);      // integer test on the words in memory (see panda_step.h)
@@ -77,48 +150,51 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
       for (int k = 0; k < NARM; k++) act[k] = ss.arm.q[k];
       act[7] = 1.0;
     }
-    for (int i = 0; i < SK_NV; i++) SL(ST_X + i) = ss.warm[i];     // the warm start lives in the t area between the sub-steps
+    for (int i = 0; i < SK_NV; i++) t[ST_X + i] = ss.warm[i];     // the warm start lives in the t area between the sub-steps
+    float o[SK_OBS]; unsigned char dn = 0;
     open = stack_env_begin(g_stack_consts, ss, act, o, &dn, max_steps);
+#pragma unroll
+    for (int k = 0; k < SK_OBS; k++) obs[(size_t)SK_OBS * e + k] = o[k];      // observation and done flag are taken BEFORE the physics
+    done[e] = dn;
+    sk_state_to_lds(t, ss);
+    for (int k = 0; k < SK_ACT; k++) t[SE_ACT + k] = act[k];
+    fl = ss.arm.flags; step = ss.arm.step;
   }
+  const unsigned live_mask = (unsigned)(__ballot(live) & ((1ull << SK_LANES) - 1ull));
+  __syncthreads();
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
-    int ncon = 0; bool any_lim = false, over = false;
-    unsigned has = 0;
-    if (live) {
-      double tau[NARM], ff[NFING];
-      stack_control(kStackingConsts, ss.arm, act, open ? 0.04 : 0.0, !open, tau, ff);
-      stack_pre_kin(kStackingConsts, g_stack_consts, ss, sc, tau, ff);
-    }
+    if (live) sk_phase_pre(t, g, fl, open);
     __syncthreads();
-    SK_TIC;
-    sk_collide_coop(g_stack_consts, (sk_lds_double*)smem, Jw, (sk_glb_double*)(scratch + (size_t)blockIdx.x * SK_LANES * SG_SIZE), lane, live ? 1 : 0, ncon, has, over);
-    if (live) {
-      SK_TOC(1);
-      if (over) ss.arm.flags |= SKF_CON_OVERFLOW;
-      stack_pre_finish<true>(kStackingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
-    }
-    const int need = (live && (ncon > 0 || any_lim)) ? 1 : 0;
-    const int warm = (live && (ss.arm.flags & SKF_WARM_VALID)) ? 1 : 0;
+    sk_collide_coop(g_stack_consts, sm, lane, live_mask);
+    if (live) sk_phase_mid(t, g, fl);
     __syncthreads();
 #pragma clang loop unroll(disable)
-    for (int e2 = 0; e2 < SK_LANES; e2++) {
-      if (!__builtin_amdgcn_readlane(need, e2)) continue;
-      const bool ok = sk_solve_coop(g_stack_consts, (sk_lds_double*)(smem + e2 * ST_SIZE), Jw,
-                                    (sk_glb_double*)(scratch + ((size_t)blockIdx.x * SK_LANES + e2) * SG_SIZE), lane,
-                                    __builtin_amdgcn_readlane(ncon, e2), __builtin_amdgcn_readlane(warm, e2) != 0);
-      if (!ok && lane == e2) ss.arm.flags |= F_SOLVER_FAIL;
+    for (int e0 = 0; e0 < SK_LANES; e0 += 2) {      // the solver takes two environments at a time, one per half wave
+      const bool a0 = ((live_mask >> e0) & 1u) && sk_env_view(sm, e0)[SE_NEED] != 0.0;
+      const bool a1 = ((live_mask >> (e0 + 1)) & 1u) && sk_env_view(sm, e0 + 1)[SE_NEED] != 0.0;
+      if (!a0 && !a1) continue;
+      unsigned failed;
+      if (a0 && a1 && (int)sk_env_view(sm, e0)[SE_JSZ] + (int)sk_env_view(sm, e0 + 1)[SE_JSZ] > SKC_JSIZE) {      // more rows than the shared J area holds
+        failed = sk_solve_dual(g_stack_consts, sm, e0, lane, true, false);
+        failed |= sk_solve_dual(g_stack_consts, sm, e0, lane, false, true);
+      } else failed = sk_solve_dual(g_stack_consts, sm, e0, lane, a0, a1);
+      if (((failed & 1u) && lane == e0) || ((failed & 2u) && lane == e0 + 1)) fl |= F_SOLVER_FAIL;
     }
     __syncthreads();
-    if (live) stack_substep_post<true>(kStackingConsts, g_stack_consts, ss, sc);
+    if (live) sk_phase_post(t, g, fl);
+    __syncthreads();
   }
   if (!live) return;
-  for (int i = 0; i < SK_NV; i++) ss.warm[i] = SL(ST_X + i);
+  StackState ss;
+  sk_state_from_lds(t, ss);
+  ss.arm.flags = fl; ss.arm.step = step;
+  for (int i = 0; i < SK_NV; i++) ss.warm[i] = t[ST_X + i];
+  double md = 0;
   stack_env_end(g_stack_consts, ss, &md);
   if (bad) ss.arm.flags |= F_SOLVER_FAIL | F_TERMINATED;
   stack_store(state, flags, steps, stride, e, ss);
-#pragma unroll
-  for (int k = 0; k < SK_OBS; k++) obs[(size_t)SK_OBS * e + k] = o[k];
-  done[e] = dn; success[e] = (ss.arm.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)stack_mode_code(ss.arm.flags);
+  success[e] = (ss.arm.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)stack_mode_code(ss.arm.flags);
   info[e] = md;
 }
 

@@ -89,7 +89,9 @@ struct StackScratch { sk_lds_double* t; sk_glb_double* g; };
 #define SL(i) sc.t[(i)]
 #define SG(i) sc.g[(i)]
 // t area
-constexpr int ST_H = 0, ST_X = SK_NH, ST_A0 = ST_X + SK_NV, ST_G = ST_A0 + SK_NV, ST_P = ST_G + SK_NV, ST_VEL = ST_P + SK_NV;
+constexpr int ST_H = 0, ST_G = SK_NH, ST_P = ST_G + SK_NV;      // solver work vectors: packed Hessian, gradient, direction ("head")
+constexpr int ST_HEAD = ST_P + SK_NV;                             // 432
+constexpr int ST_X = ST_HEAD, ST_A0 = ST_X + SK_NV, ST_VEL = ST_A0 + SK_NV;
 constexpr int ST_M = ST_VEL + SK_NV;            // arm mass matrix, packed lower 45
 constexpr int ST_BR = ST_M + 45;                // box rotation matrices 3 x 9
 constexpr int ST_BP = ST_BR + 27;               // box positions 3 x 3
@@ -366,12 +368,8 @@ D3IL_HD void sk_arm_rows(const StackScratch sc, int f, double sign, const double
   }
 }
 template <int NA, int NB>
-D3IL_HD void sk_build_rows(const StackConsts& kc_, const StackScratch sc, int ci, SkRows<NA, NB>& R, int* set_out) {
+D3IL_HD void sk_build_rows_rec(const StackConsts& kc_, const StackScratch sc, const double* rec /* pos3 frame9 dist a b set */, SkRows<NA, NB>& R, int* set_out) {
   D3IL_STACK_CONSTS(kc_, kc);
-  const int base = ci * SREC;
-  double rec[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) rec[k] = SG(base + k);
   const int a = (int)rec[13], b = (int)rec[14], set = (int)rec[15];
   *set_out = set; R.dim = kc.set[set].dim;
   if constexpr (NA == 6) { R.oa = 6 * a; sk_box_rows(sc, a, rec, rec + 3, R.dim, R.A); } else R.oa = 0;
@@ -381,6 +379,14 @@ D3IL_HD void sk_build_rows(const StackConsts& kc_, const StackScratch sc, int ci
     sk_arm_rows(sc, (b - SKB_FINGER) & 1, 1.0, rec, rec + 3, R.B, false);
     if constexpr (NA == 0) sk_arm_rows(sc, (a - SKB_FINGER) & 1, -1.0, rec, rec + 3, R.B, true);     // finger <-> finger
   }
+}
+template <int NA, int NB>
+D3IL_HD void sk_build_rows(const StackConsts& kc_, const StackScratch sc, int ci, SkRows<NA, NB>& R, int* set_out) {
+  const int base = ci * SREC;
+  double rec[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) rec[k] = SG(base + k);
+  sk_build_rows_rec(kc_, sc, rec, R, set_out);
 }
 template <int NA, int NB> D3IL_HD double sk_dot(const StackScratch sc, const SkRows<NA, NB>& R, int r, int vec) {
   double s = 0;
@@ -401,6 +407,7 @@ D3IL_HD void sk_row_fric(const StackSet& ps, double* fr) { fr[0] = ps.fric[0]; f
 #else
 #define SL_ADD(i, v) (SL(i) += (v))
 #endif
+D3IL_HD int sk_jcols(int a, int b) { return (a == SKB_STATIC || a >= SKB_FINGER ? 0 : 6) + (b < SK_NB ? 6 : NDOF); }      // J columns of a contact between bodies a, b
 D3IL_HD int sk_kind(int a, int b) { return b < SK_NB ? (a == SKB_STATIC ? 0 : 1) : (a < SK_NB ? 2 : 3); }
 D3IL_HD int sk_blk_of(int body) { return body == SKB_STATIC ? -1 : (body < SK_NB ? body : SK_NB); }
 D3IL_HD int sk_blk(int dof) { return dof >= SK_ARM0 ? SK_NB : dof / 6; }
@@ -738,28 +745,69 @@ __device__ __forceinline__ double sk_wave_max(double v) {
 }
 constexpr int SKC_NJ = 15;                       // columns of a contact row in the J area
 constexpr int SKC_JSIZE = 4 * SKC_NJ * SK_MAXCON;   // doubles per wave
-#define SKJ(r, k) Jw[((r) * SKC_NJ + (k)) * SK_MAXCON + lane]
+// LDS layout of the step kernel (one wave = one workgroup = SK_LANES environments):
+//   shared by the workgroup : two solver heads (H [SK_NH] packed Hessian / Cholesky factor | G gradient | P direction) - the constraint
+//                             solver works on TWO environments at a time, one per half wave - | J [SKC_JSIZE] their contact rows (the two
+//                             environments share the SK_MAXCON row slots).  During the collision phase: per-lane staging of the contacts
+//                             a pair test emits.
+//   per environment         : the t area of the one-lane code WITHOUT its head (vectors, mass matrix, kinematic tables, limit rows; the
+//                             view pointer is shifted by ST_HEAD so that the ST_* offsets stay valid), then the part of the state that is
+//                             not in a table already (q, qfrc_bias, TCP, box quaternions - velocities and box positions live in ST_VEL /
+//                             ST_BP), the action, the contact count / flags words and the COMPACT contact records (8 doubles: position,
+//                             normal, distance, bodies | parameter set - the tangents are re-derived with make_frame).
+// Nothing of an environment lives in registers between the phases of a sub-step and nothing goes through HBM inside the step.
+constexpr int SREC2 = 8;
+constexpr int SE_Q = ST_SIZE, SE_BIAS = SE_Q + NDOF, SE_TCP = SE_BIAS + NARM, SE_BQ = SE_TCP + 3, SE_ACT = SE_BQ + 4 * SK_NB;
+constexpr int SE_NCON = SE_ACT + NARM;          // contact count of this sub-step
+constexpr int SE_NEED = SE_NCON + 1;            // 1: constraints present (contacts or joint limits) -> the solver runs; + 256: contacts were dropped
+constexpr int SE_JSZ = ST_AUX + 1;              // (the spare word of the t area) doubles of the J area the contact rows of this sub-step take: 4 rows x (columns of body 1 + body 2) per contact
+constexpr int SE_REC = SE_NEED + 1;
+constexpr int SE_END = SE_REC + SK_MAXCON * SREC2;
+constexpr int SE_SIZE = ((SE_END - ST_HEAD) | 1);  // doubles per environment (odd: the environments start on different banks)
+constexpr int SKC_SHARED = 2 * ST_HEAD + SKC_JSIZE;
+constexpr int SKC_STAGE = 36;                   // staging doubles per lane in the shared area: normal[3] + 8 x (dist, pos[3]) + count
+static_assert(SKC_STAGE * 13 * SK_LANES <= SKC_SHARED, "contact staging must fit the shared area");
+static_assert(SK_LANES % 2 == 0, "the solver takes the environments of a workgroup in pairs");
+__device__ __forceinline__ sk_lds_double* sk_env_view(sk_lds_double* smem, int e) { return smem + SKC_SHARED + e * SE_SIZE - ST_HEAD; }
+// Contact rows in the J area: contact c owns 4 x ncol doubles at jbase (ncol = columns of body 1, 0 or 6, + columns of body 2, 6 or 9), so
+// that the rows of TWO environments fit the area in all but extreme cases (a resting box needs 24 doubles per contact, a grasp contact 60).
+// k: local column 0 .. 14 (0 .. 5 body 1, 6 .. 14 body 2); columns the contact does not have must not be addressed (sk_jcol_ok).
+#define SKJ(r, k) Jw[jbase + (r) * jncol + ((k) - jskip)]
 struct SkCoopCon { int oa, ob, na, nb, dim; double aref[4], D[4], mu, imu, fr[3]; };
 template <int NA, int NB>
-__device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, const StackScratch sc, sk_lds_double* Jw, int lane, SkCoopCon& cc) {
+__device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, const StackScratch sc, sk_lds_double* Jw, int ci, int jbase, SkCoopCon& cc) {
+  constexpr int jncol = NA + NB, jskip = NA ? 0 : 6;
   D3IL_STACK_CONSTS(kc_, kc);
   SkRows<NA, NB> R; int set;
-  sk_build_rows(kc, sc, lane, R, &set);
+  double rec[16];
+  {   // compact record -> position, frame, distance, bodies, parameter set
+    const sk_lds_double* r = sc.t + SE_REC + ci * SREC2;
+    double n[3] = {r[3], r[4], r[5]}, t1[3], t2[3];
+    make_frame(n, t1, t2);
+    rec[0] = r[0]; rec[1] = r[1]; rec[2] = r[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rec[3 + k] = n[k]; rec[6 + k] = t1[k]; rec[9 + k] = t2[k]; }
+    rec[12] = r[6];
+    const int meta = (int)r[7];
+    rec[13] = (double)(meta & 15); rec[14] = (double)((meta >> 4) & 15); rec[15] = (double)(meta >> 8);
+  }
+  sk_build_rows_rec(kc, sc, rec, R, &set);
   const StackSet& ps = kc.set[set];
   cc.oa = R.oa; cc.ob = R.ob; cc.na = NA; cc.nb = NB; cc.dim = R.dim;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const bool live = r < R.dim;
+    if constexpr (NA > 0) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) SKJ(r, k) = (NA > 0 && live) ? -R.A[r][NA ? k : 0] : 0.0;
+      for (int k = 0; k < 6; k++) SKJ(r, k) = live ? -R.A[r][k] : 0.0;
+    }
 #pragma unroll
-    for (int k = 0; k < 9; k++) SKJ(r, 6 + k) = (k < NB && live) ? R.B[r][k < NB ? k : 0] : 0.0;
+    for (int k = 0; k < NB; k++) SKJ(r, 6 + k) = live ? R.B[r][k] : 0.0;
   }
   // mj_makeImpedance for an elliptic contact [ext] (sk_contact_dot, mode 1)
-  const int base = lane * SREC;
-  const double dist = SG(base + 12);
+  const double dist = rec[12];
   const double imp = impedance(ps.solimp, dist - ps.margin);
-  const int a = (int)SG(base + 13), b = (int)SG(base + 14);
+  const int a = (int)rec[13], b = (int)rec[14];
   auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])); };
   const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
   const double R1 = R0 / fmax(1e-15, kc.impratio);
@@ -774,16 +822,74 @@ __device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, 
   sk_row_fric(ps, cc.fr);
 }
 
-// t / g: areas of the environment being solved (wave-uniform), Jw: the wave's J area.  Returns false when the factorisation met a
-// non-positive pivot or the iteration cap was reached (wave-uniform).
-__device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_double* t, sk_lds_double* Jw, sk_glb_double* g, const int lane, const int ncon, const bool warm) {
+#if defined(D3IL_DEVICE_STATS)
+#define D3IL_SD_COUNT(slot) atomicAdd(&g_dev_stats[16 + (slot)], 1ull)
+#else
+#define D3IL_SD_COUNT(slot) ((void)0)
+#endif
+// Half-wave helpers: lanes 0 .. 31 work on one environment, lanes 32 .. 63 on another.
+__device__ __forceinline__ double sk_hbcast(double v, int j /* wave-uniform, 0 .. 31 */, bool upper) {
+#if defined(D3IL_SK_HBCAST_READLANE)
+  const double a = sk_bcast(v, j), b = sk_bcast(v, 32 + j);
+  return upper ? b : a;
+#else
+  // lane j of the caller's own half through the LDS crossbar (ds_bpermute_b32 x 2): one instruction per word for BOTH halves, and the
+  // independent broadcasts of a factorisation step pipeline - v_readlane would need two reads + a select per word and half
+  return __shfl(v, (upper ? 32 : 0) | j);
+#endif
+}
+__device__ __forceinline__ double sk_half_sum(double v, bool upper) {
+  v += sk_dpp_mov(v, 0); v += sk_dpp_mov(v, 1); v += sk_dpp_mov(v, 2); v += sk_dpp_mov(v, 3);      // every lane: the sum of its row of 16
+  const double a = sk_bcast(v, 0) + sk_bcast(v, 16), b = sk_bcast(v, 32) + sk_bcast(v, 48);
+  return upper ? b : a;
+}
+__device__ __forceinline__ double sk_half_max(double v, bool upper) {
+  v = fmax(v, sk_dpp_mov(v, 0)); v = fmax(v, sk_dpp_mov(v, 1)); v = fmax(v, sk_dpp_mov(v, 2)); v = fmax(v, sk_dpp_mov(v, 3));
+  const double a = fmax(sk_bcast(v, 0), sk_bcast(v, 16)), b = fmax(sk_bcast(v, 32), sk_bcast(v, 48));
+  return upper ? b : a;
+}
+// The constraint problems of TWO environments (e0 on the lower half wave, e0 + 1 on the upper one; act0 / act1: which of them is solved),
+// same algorithm, stopping rule, line search and tolerances as sk_solve_island.  Per half: lane hl < ncon owns contact hl (its rows are
+// built once per solve into row slot slot0 + hl of the workgroup's J area, reference accelerations / regularisation / residuals stay in
+// its registers), lane hl < 27 owns dof hl (gradient entry, row of the Hessian and of the Cholesky factor in registers, columns broadcast
+// inside the half with v_readlane).  The two halves iterate in lock step until both have finished; a finished half idles (no LDS writes).
+// The two environments share the SK_MAXCON row slots: the caller solves them one after the other when they have more contacts than that.
+// Returns bit 0 / bit 1: the solve of the lower / upper half FAILED (non-positive pivot or iteration cap).
+__device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds_double* smem, const int e0, const int lane, const bool act0, const bool act1) {
   D3IL_STACK_CONSTS(kc_, kc);
-  const StackScratch sc{t, g};
-  const bool con = lane < ncon;
-  const int i = lane;                       // dof owned by this lane
-  const bool row = lane < SK_NV, armrow = row && lane >= SK_ARM0;
-  const int ia = armrow ? lane - SK_ARM0 : 0;
-  SK_TIC;
+  const bool upper = lane >= 32;
+  const int hl = lane & 31;
+  sk_lds_double* const t = sk_env_view(smem, e0 + (upper ? 1 : 0));
+  sk_lds_double* const Hs = smem + (upper ? ST_HEAD : 0);
+  sk_lds_double* const Gs = Hs + ST_G;
+  sk_lds_double* const Ps = Hs + ST_P;
+  sk_lds_double* const Jw = smem + 2 * ST_HEAD;
+  const StackScratch sc{t, nullptr};
+  const bool active = upper ? act1 : act0;
+  const int ncon = active ? (int)t[SE_NCON] : 0;
+  const bool con = hl < ncon;
+  // base of this lane's contact in the J area: the upper half's rows follow the lower half's; inside a half, prefix sum of the sizes
+  // (through the half's H area, which is free until the first gradient pass)
+  int jncol = 15, jskip = 0, jbase = 0;
+  {
+    int sz = 0;
+    if (con) { const int meta = (int)t[SE_REC + hl * SREC2 + 7]; const int a = meta & 15, bdy = (meta >> 4) & 15; jncol = sk_jcols(a, bdy); jskip = (a == SKB_STATIC || a >= SKB_FINGER) ? 6 : 0; sz = 4 * jncol; }
+    Hs[hl] = (double)sz;
+    __syncthreads();
+    for (int c = 0; c < hl; c++) jbase += (int)Hs[c];
+    if (upper && act0) jbase += (int)sk_env_view(smem, e0)[SE_JSZ];
+    __syncthreads();
+  }
+  const int i = hl;                         // dof owned by this lane (within its half)
+  const bool row = active && hl < SK_NV, armrow = row && hl >= SK_ARM0;
+  const int ia = armrow ? hl - SK_ARM0 : 0;
+#if defined(D3IL_DEVICE_STATS)
+  unsigned long long sd_t0 = wall_clock64();
+#define SD_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&g_dev_stats[16 + (slot)], t_ - sd_t0); sd_t0 = t_; } while (0)
+  if (lane == 0) atomicAdd(&g_dev_stats[16 + 6], 1ull);
+#else
+#define SD_TOC(slot) ((void)0)
+#endif
   // ---- contacts: rows, reference accelerations, regularisation
   SkCoopCon cc;
   cc.oa = 0; cc.ob = 0; cc.na = 0; cc.nb = 6; cc.dim = 3; cc.mu = 1; cc.imu = 0.5;
@@ -791,9 +897,10 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
   for (int r = 0; r < 4; r++) { cc.aref[r] = 0; cc.D[r] = 1; }
   cc.fr[0] = cc.fr[1] = cc.fr[2] = 1;
   if (con) {
-    const int kind = sk_kind((int)SG(lane * SREC + 13), (int)SG(lane * SREC + 14));
-    if (kind == 0) sk_coop_build<0, 6>(kc, sc, Jw, lane, cc); else if (kind == 1) sk_coop_build<6, 6>(kc, sc, Jw, lane, cc);
-    else if (kind == 2) sk_coop_build<6, 9>(kc, sc, Jw, lane, cc); else sk_coop_build<0, 9>(kc, sc, Jw, lane, cc);
+    const int meta = (int)t[SE_REC + hl * SREC2 + 7];
+    const int kind = sk_kind(meta & 15, (meta >> 4) & 15);
+    if (kind == 0) sk_coop_build<0, 6>(kc, sc, Jw, hl, jbase, cc); else if (kind == 1) sk_coop_build<6, 6>(kc, sc, Jw, hl, jbase, cc);
+    else if (kind == 2) sk_coop_build<6, 9>(kc, sc, Jw, hl, jbase, cc); else sk_coop_build<0, 9>(kc, sc, Jw, hl, jbase, cc);
   }
   // ---- rows of the block-diagonal mass matrix and the joint-limit row of this lane's dof
   double mdiag = 0, Ma[NDOF];
@@ -807,44 +914,46 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
   double lsg = 0, lD = 0, lar = 0;
   if (armrow) { lsg = t[ST_LIM + 3 * ia]; lD = t[ST_LIM + 3 * ia + 1]; lar = t[ST_LIM + 3 * ia + 2]; }
   __syncthreads();
-  SK_TOC(3);
+  SD_TOC(3);
   auto col = [&](int k) { return k < 6 ? cc.oa + k : cc.ob + k - 6; };
-  auto m_times = [&](int va, int vb) -> double {      // (M (v_a - v_b))_i
+  auto jcol_ok = [&](int k) { return k < 6 ? jskip == 0 : k - 6 < jncol - (jskip ? 0 : 6); };      // does the contact have local column k
+  auto m_times = [&](const sk_lds_double* va, const sk_lds_double* vb) -> double {      // (M (v_a - v_b))_i
     if (!row) return 0.0;
-    if (!armrow) return mdiag * (t[va + i] - (vb >= 0 ? t[vb + i] : 0.0));
-    double s = 0;
+    if (!armrow) return mdiag * (va[i] - (vb ? vb[i] : 0.0));
+    double sum = 0;
 #pragma unroll
-    for (int k = 0; k < NDOF; k++) s += Ma[k] * (t[va + SK_ARM0 + k] - (vb >= 0 ? t[vb + SK_ARM0 + k] : 0.0));
-    return s;
+    for (int k = 0; k < NDOF; k++) sum += Ma[k] * (va[SK_ARM0 + k] - (vb ? vb[SK_ARM0 + k] : 0.0));
+    return sum;
   };
   double jar[4] = {0, 0, 0, 0}, gi = 0, mxa = 0, xi = row ? t[ST_X + i] : 0.0;
-  // gradient (and Hessian) at x: g -> ST_G and gi, H -> ST_H; returns max |g|
-  // gradient (and Hessian) at x: g -> ST_G and gi, H -> ST_H; returns max |g|
-  auto grad_pass = [&](bool with_h) -> double {
-    if (with_h) for (int q = lane; q < SK_NH; q += WAVE) t[ST_H + q] = 0;
+  bool fin = !active;      // this half has finished (converged, failed, or nothing to do); half-uniform
+  bool okh = true;
+  // gradient and Hessian at x: g -> Gs and gi, H -> Hs; returns max |g| of the half
+  auto grad_pass = [&]() -> double {
+    if (!fin) for (int q = hl; q < SK_NH; q += 32) Hs[q] = 0;
     __syncthreads();
-    mxa = m_times(ST_X, ST_A0);
+    mxa = m_times(t + ST_X, t + ST_A0);
     double gl = mxa;
-    if (row && with_h) {
-      if (!armrow) t[ST_H + tri(i, i)] = mdiag;
+    if (row && !fin) {
+      if (!armrow) Hs[tri(i, i)] = mdiag;
       else {
 #pragma unroll
-        for (int k = 0; k < NDOF; k++) if (k <= ia) t[ST_H + tri(i, SK_ARM0 + k)] = Ma[k];
+        for (int k = 0; k < NDOF; k++) if (k <= ia) Hs[tri(i, SK_ARM0 + k)] = Ma[k];
       }
     }
-    if (lsg != 0) { const double lj = lsg * xi - lar; if (lj < 0) { gl += lsg * lD * lj; if (with_h) t[ST_H + tri(i, i)] += lD; } }
-    if (row) t[ST_G + i] = gl;
+    if (lsg != 0) { const double lj = lsg * xi - lar; if (lj < 0) { gl += lsg * lD * lj; if (!fin) Hs[tri(i, i)] += lD; } }
+    if (row && !fin) Gs[i] = gl;
     __syncthreads();
-    if (con) {
+    if (con && !fin) {
       double J[4][SKC_NJ], xk[SKC_NJ], f[4], Hc[16];
 #pragma unroll
-      for (int k = 0; k < SKC_NJ; k++) xk[k] = t[ST_X + col(k)];
+      for (int k = 0; k < SKC_NJ; k++) xk[k] = jcol_ok(k) ? t[ST_X + col(k)] : 0.0;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        double s = 0;
+        double sum = 0;
 #pragma unroll
-        for (int k = 0; k < SKC_NJ; k++) { J[r][k] = SKJ(r, k); s += J[r][k] * xk[k]; }
-        jar[r] = s - cc.aref[r];
+        for (int k = 0; k < SKC_NJ; k++) { J[r][k] = jcol_ok(k) ? SKJ(r, k) : 0.0; sum += J[r][k] * xk[k]; }
+        jar[r] = sum - cc.aref[r];
       }
       sk_cone_pre(cc.dim, jar, cc.D, cc.mu, cc.imu, cc.fr, f, Hc);
       bool any = false;
@@ -855,113 +964,108 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
         for (int k = 0; k < SKC_NJ; k++) {
           if (k >= 6 + cc.nb || (k < 6 && cc.na == 0)) continue;      // structural zeros: columns beyond body 2's block, a static body 1
           const double acc = J[0][k] * f[0] + J[1][k] * f[1] + J[2][k] * f[2] + J[3][k] * f[3];
-          (void)__hip_atomic_fetch_add(&t[ST_G + col(k)], -acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_add(&Gs[col(k)], -acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (with_h) {
 #pragma unroll
-          for (int a = 0; a < SKC_NJ; a++) {
-            if (a >= 6 + cc.nb) continue;
-            double w[4];
+        for (int a = 0; a < SKC_NJ; a++) {
+          if (a >= 6 + cc.nb) continue;
+          double w[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) w[q] = J[0][a] * Hc[q] + J[1][a] * Hc[4 + q] + J[2][a] * Hc[8 + q] + J[3][a] * Hc[12 + q];
-            if (w[0] == 0 && w[1] == 0 && w[2] == 0 && w[3] == 0) continue;      // zero column (body 1 static, the other finger's slide dof)
-            const int ra = col(a);
-            // column index <= row index in dof order: body 1's block precedes body 2's.  No test per entry: the blocks are dense
-            if (a >= 6 && cc.na > 0) {
+          for (int q = 0; q < 4; q++) w[q] = J[0][a] * Hc[q] + J[1][a] * Hc[4 + q] + J[2][a] * Hc[8 + q] + J[3][a] * Hc[12 + q];
+          if (w[0] == 0 && w[1] == 0 && w[2] == 0 && w[3] == 0) continue;      // zero column (body 1 static, the other finger's slide dof)
+          const int ra = col(a);
+          // column index <= row index in dof order: body 1's block precedes body 2's.  No test per entry: the blocks are dense
+          if (a >= 6 && cc.na > 0) {
 #pragma unroll
-              for (int b = 0; b < 6; b++)
-                (void)__hip_atomic_fetch_add(&t[ST_H + tri(ra, cc.oa + b)], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-#pragma unroll
-            for (int b = (a < 6 ? 0 : 6); b <= a; b++)
-              (void)__hip_atomic_fetch_add(&t[ST_H + tri(ra, col(b))], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int b = 0; b < 6; b++)
+              (void)__hip_atomic_fetch_add(&Hs[tri(ra, cc.oa + b)], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
+#pragma unroll
+          for (int b = (a < 6 ? 0 : 6); b <= a; b++)
+            (void)__hip_atomic_fetch_add(&Hs[tri(ra, col(b))], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
     }
     __syncthreads();
-    gi = row ? t[ST_G + i] : 0.0;
-    return sk_wave_max(fabs(gi));
+    gi = (row && !fin) ? Gs[i] : 0.0;
+    return sk_half_max(fabs(gi), upper);
   };
-  bool converged = false, ok = true;
-  double iters = 0, gm = 0;
-  // No separate gradient-only test of the warm start: a start point that already satisfies the tolerance is rare (resting boxes keep
-  // settling at the 1e-6 level), so the first pass assembles the Hessian right away and its gradient decides
-  (void)warm;
-  for (int it = 0; it < 60 && !converged && ok; it++) {
-    gm = grad_pass(true);
-    iters += 1;
-    SK_TOC(8);
-    if (gm <= g_solver_tol.grad_tol) { converged = true; break; }
-    // ---- Cholesky: lane i holds row i
+  for (int it = 0; it < 60 && __any(!fin); it++) {
+    const double gm = grad_pass();
+    SD_TOC(8);
+    if (lane == 0) { D3IL_SD_COUNT(7); }
+    if (!fin && gm <= g_solver_tol.grad_tol) fin = true;      // converged
+    if (!__any(!fin)) break;
+    // ---- Cholesky: lane i of a half holds row i
     double Lr[SK_NV], dinv = 1;
     {
       double Hr[SK_NV];
 #pragma unroll
-      for (int k = 0; k < SK_NV; k++) { const bool in = row && k <= i; const double v = t[ST_H + (in ? tri(i, k) : 0)]; Hr[k] = in ? v : 0.0; }
+      for (int k = 0; k < SK_NV; k++) { const bool in = row && k <= i; const double v = Hs[(in ? tri(i, k) : 0)]; Hr[k] = in ? v : 0.0; }
 #pragma unroll
       for (int j = 0; j < SK_NV; j++) {
-        double s = Hr[j], s2 = 0;      // two accumulators: the dependent FMA chain is half as long
+        double sum = Hr[j], s2 = 0;      // two accumulators: the dependent FMA chain is half as long
 #pragma unroll
-        for (int k = 0; k < j; k++) { if (k & 1) s2 -= Lr[k] * sk_bcast(Lr[k], j); else s -= Lr[k] * sk_bcast(Lr[k], j); }
-        s += s2;
-        double sj = sk_bcast(s, j);
-        if (!(sj > 0)) { ok = false; sj = 1; }
+        for (int k = 0; k < j; k++) { if (k & 1) s2 -= Lr[k] * sk_hbcast(Lr[k], j, upper); else sum -= Lr[k] * sk_hbcast(Lr[k], j, upper); }
+        sum += s2;
+        double sj = sk_hbcast(sum, j, upper);
+        if (!(sj > 0)) { if (!fin) okh = false; sj = 1; }
         const double di = rsqrtd(sj), d = sj * di;      // v_rsq_f64 + two Newton steps instead of a square root and a division
-        Lr[j] = i == j ? d : (i > j ? s * di : 0.0);
+        Lr[j] = i == j ? d : (i > j ? sum * di : 0.0);
         if (i == j) dinv = di;
       }
     }
-    if (!ok) break;
-    SK_TOC(9);
-    // ---- p = -H^-1 g: forward substitution with the rows, backward with the columns (factor handed over through ST_H)
-    double y = row ? -gi : 0.0;
+    if (!okh) fin = true;      // non-positive pivot: this half gives up
+    SD_TOC(9);
+    // ---- p = -H^-1 g: forward substitution with the rows, backward with the columns (factor handed over through Hs)
+    double y = (row && !fin) ? -gi : 0.0;
 #pragma unroll
     for (int j = 0; j < SK_NV; j++) {
-      const double yj = sk_bcast(y * dinv, j);
+      const double yj = sk_hbcast(y * dinv, j, upper);
       y = i == j ? yj : (i > j ? y - Lr[j] * yj : y);
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < SK_NV; k++) if (row && k <= i) t[ST_H + tri(i, k)] = Lr[k];
+    for (int k = 0; k < SK_NV; k++) if (row && !fin && k <= i) Hs[tri(i, k)] = Lr[k];
     __syncthreads();
     {
       double Lc[SK_NV];
 #pragma unroll
-      for (int k = 0; k < SK_NV; k++) { const bool in = row && k > i; const double v = t[ST_H + (in ? tri(k, i) : 0)]; Lc[k] = in ? v : 0.0; }
+      for (int k = 0; k < SK_NV; k++) { const bool in = row && k > i; const double v = Hs[(in ? tri(k, i) : 0)]; Lc[k] = in ? v : 0.0; }
 #pragma unroll
       for (int j = SK_NV - 1; j >= 0; j--) {
-        const double xj = sk_bcast(y * dinv, j);
+        const double xj = sk_hbcast(y * dinv, j, upper);
         y = i == j ? xj : (i < j ? y - Lc[j] * xj : y);
       }
     }
-    const double pi = row ? y : 0.0;
-    if (row) t[ST_P + i] = pi;
+    const double pi = (row && !fin) ? y : 0.0;
+    if (row && !fin) Ps[i] = pi;
     __syncthreads();
-    SK_TOC(10);
+    SD_TOC(10);
     // ---- line search: phi'(alpha) = p' M (x - a0) + alpha p' M p - sum f(jar + alpha Jp) . Jp, safeguarded Newton on alpha
-    const double Mp = m_times(ST_P, -1);
-    const double gTp = sk_wave_sum(gi * pi), pMp = sk_wave_sum(pi * Mp), pMa = sk_wave_sum(pi * mxa);
+    const double Mp = fin ? 0.0 : m_times(Ps, nullptr);
+    const double gTp = sk_half_sum(gi * pi, upper), pMp = sk_half_sum(pi * Mp, upper), pMa = sk_half_sum(pi * mxa, upper);
     double jp[4] = {0, 0, 0, 0};
-    if (con) {
+    if (con && !fin) {
       double pk[SKC_NJ];
 #pragma unroll
-      for (int k = 0; k < SKC_NJ; k++) pk[k] = t[ST_P + col(k)];
+      for (int k = 0; k < SKC_NJ; k++) pk[k] = jcol_ok(k) ? Ps[col(k)] : 0.0;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        double s = 0;
+        double sum = 0;
 #pragma unroll
-        for (int k = 0; k < SKC_NJ; k++) s += SKJ(r, k) * pk[k];
-        jp[r] = s;
+        for (int k = 0; k < SKC_NJ; k++) sum += (jcol_ok(k) ? SKJ(r, k) : 0.0) * pk[k];
+        jp[r] = sum;
       }
     }
     const double ljp = lsg * pi, ljar = lsg * xi - lar;
-    SK_TOC(11);
+    SD_TOC(11);
     double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
-    for (int ls = 0; ls < 50; ls++) {
+    bool lsdone = fin;
+    for (int ls = 0; ls < 50 && __any(!lsdone); ls++) {
       double d1c = 0, d2c = 0;
       if (lsg != 0) { const double lj = ljar + alpha * ljp; if (lj < 0) { d1c += lD * lj * ljp; d2c += lD * ljp * ljp; } }
-      if (con) {
+      if (con && !lsdone) {
         double jt[4], f[4], Hc[16];
 #pragma unroll
         for (int r = 0; r < 4; r++) jt[r] = jar[r] + alpha * jp[r];
@@ -971,10 +1075,11 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
 #pragma unroll
           for (int q = 0; q < 4; q++) d2c += jp[r] * Hc[4 * r + q] * jp[q]; }
       }
-      const double d1 = pMa + alpha * pMp + sk_wave_sum(d1c), d2 = pMp + sk_wave_sum(d2c);
+      const double d1 = pMa + alpha * pMp + sk_half_sum(d1c, upper), d2 = pMp + sk_half_sum(d2c, upper);
+      if (lsdone) continue;
       best = alpha;
-      if (ls == 0 && d1 <= g_solver_tol.ls_full * fabs(gTp)) break;
-      if (fabs(d1) <= g_solver_tol.ls_c2 * fabs(gTp) || fabs(d1) <= g_solver_tol.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (ls == 0 && d1 <= g_solver_tol.ls_full * fabs(gTp)) { lsdone = true; continue; }
+      if (fabs(d1) <= g_solver_tol.ls_c2 * fabs(gTp) || fabs(d1) <= g_solver_tol.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) { lsdone = true; continue; }
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = alpha - d1 / d2;
       if (hi >= 0) {
@@ -983,19 +1088,21 @@ __device__ __forceinline__ bool sk_solve_coop(const StackConsts& kc_, sk_lds_dou
         wprev = wbr;
         if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
       } else if (na <= lo) na = 2 * lo + 1;
-      if (na == alpha) break;
+      if (na == alpha) { lsdone = true; continue; }
       alpha = na;
     }
-    SK_TOC(12);
-    const double dx = best * pi;
+    SD_TOC(12);
+    const double dx = fin ? 0.0 : best * pi;
     xi += dx;
-    if (row) t[ST_X + i] = xi;
-    const double smax = sk_wave_max(fabs(dx)), xmax = sk_wave_max(fabs(xi));
-    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= g_solver_tol.step_rel * (1 + xmax))) converged = true;
+    if (row && !fin) t[ST_X + i] = xi;
+    const double smax = sk_half_max(fabs(dx), upper), xmax = sk_half_max(fabs(xi), upper);
+    if (!fin && (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= g_solver_tol.step_rel * (1 + xmax)))) fin = true;      // converged
     __syncthreads();
   }
-  if (lane == 0) { SG(SG_DIAG) = iters; SG(SG_DIAG + 1) = gm; SG(SG_DIAG + 2) = (converged && ok) ? 1.0 : 0.0; }
-  return converged && ok;
+#undef SD_TOC
+  if (active && !fin) okh = false;      // iteration cap
+  const unsigned long long bad = __ballot(active && !okh);
+  return (unsigned)((bad & 0xFFFFFFFFull) != 0 ? 1u : 0u) | (unsigned)((bad >> 32) != 0 ? 2u : 0u);
 }
 #undef SKJ
 #endif
@@ -1209,7 +1316,10 @@ D3IL_NOINLINE inline void stack_pre_finish(const C& c0, const StackConsts& kc_, 
       else if (!WARM_LDS) SL(ST_X + i) = ss.warm[i];
     }
   }
-  SG(SG_DIAG) = 0; SG(SG_DIAG + 1) = 0; SG(SG_DIAG + 2) = 1; SG(SG_DIAG + 3) = (double)ncon;
+#if !defined(D3IL_DEVICE_STATS)
+  if (!WARM_LDS)
+#endif
+  { SG(SG_DIAG) = 0; SG(SG_DIAG + 1) = 0; SG(SG_DIAG + 2) = 1; SG(SG_DIAG + 3) = (double)ncon; }
   any_lim_out = any_lim;
   (void)kc_;
 }
@@ -1265,32 +1375,23 @@ __device__ __forceinline__ void sk_support1_group(const StackConsts& kc_, const 
 // Collision of the workgroup's environments with one lane per (environment, pair group), lane = group * SK_LANES + environment:
 //   group 0 .. 2  : box b against the static boxes          3 .. 5 : the box pairs (0, 1) (0, 2) (1, 2)
 //   group 6 .. 11 : box b against finger f: tip, hull (MPR)    12  : finger <-> finger (nearly closed gripper)
-// Every lane collects the contacts of its group, the counts go through LDS (stage = the wave's J area, free at this point) and the
-// records are written group by group into the environment's record area.  For lane < SK_LANES (environment = lane) ncon / has
-// return the contact count and the blocks that carry contacts, over = more contacts than the record area holds.
-constexpr int SKP_GROUPS = 13, SKP_MAXL = 12;
+// Everything stays in registers and LDS: a pair test emits its contacts into the lane's staging slot of the workgroup's shared area
+// (free during this phase), the per-round counts go through the same area, and every lane then moves its contacts to their final
+// slots of the environment's compact record list - order: round, then group; deterministic, independent of which environments share
+// the workgroup.  Results per environment: t[SE_NCON] = contacts kept (<= SK_MAXCON), t[SE_NEED] = 256 when contacts were dropped.
+constexpr int SKP_GROUPS = 13;
 static_assert(SKP_GROUPS * SK_LANES <= WAVE, "the lane-per-pair collision needs 13 lanes per environment");
-__device__ __attribute__((noinline)) void sk_collide_coop(const StackConsts& kc_, sk_lds_double* smem, sk_lds_double* stage, sk_glb_double* scratch_wg, const int lane,
-                                                          const int live, int& ncon, unsigned& has, bool& over) {
+__device__ __attribute__((noinline)) void sk_collide_coop(const StackConsts& kc_, sk_lds_double* smem, const int lane, const unsigned live_mask) {
   D3IL_STACK_CONSTS(kc_, kc);
   const int e = lane % SK_LANES, grp = lane / SK_LANES;
-  const bool act = grp < SKP_GROUPS && __shfl(live, e) != 0;
-  sk_lds_double* t = smem + e * ST_SIZE;
-  double rec[SKP_MAXL][7], tmp[8][7];
-  int meta[SKP_MAXL], n = 0;
-  bool lost = false;
-  unsigned mask = 0;
-  auto push = [&](const double* r7, int a, int b, int set) {
-    if (n >= SKP_MAXL) { lost = true; return; }
-    for (int k = 0; k < 7; k++) rec[n][k] = r7[k];
-    meta[n] = a | (b << 4) | (set << 8);
-    mask |= 1u << sk_blk_of(b); if (sk_blk_of(a) >= 0) mask |= 1u << sk_blk_of(a);
-    n++;
-  };
+  const bool act = grp < SKP_GROUPS && ((live_mask >> e) & 1u) != 0;
+  sk_lds_double* t = sk_env_view(smem, e);
+  sk_lds_double* stage = smem + (grp < SKP_GROUPS ? lane : 0) * SKC_STAGE;
+  int tot = 0;      // contacts of this environment so far (the same value in all its lanes)
   auto ld = [&](int off, int cnt, double* out) { for (int k = 0; k < cnt; k++) out[k] = t[off + k]; };
 #if defined(D3IL_DEVICE_STATS)
   unsigned long long skp_t0 = wall_clock64();      // lane 0 (environment 0, group 0) times the phases of the whole wave: slots 13 set-up, 14 box-box, 15 MPR
-#define SKP_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0) scratch_wg[SG_DIAG + 4 + (slot)] += (double)(t_ - skp_t0); skp_t0 = t_; } while (0)
+#define SKP_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&g_dev_stats[16 + (slot)], t_ - skp_t0); skp_t0 = t_; } while (0)
 #else
 #define SKP_TOC(slot) ((void)0)
 #endif
@@ -1352,9 +1453,14 @@ __device__ __attribute__((noinline)) void sk_collide_coop(const StackConsts& kc_
     }
     if (!__any(kind != 0)) continue;
     SKP_TOC(13);
+    int m = 0;      // contacts of this lane in this round, staged as normal[3] | m x (dist, pos[3])
     if (kind == 1) {
-      const int m = box_box(pA, RA, hA, pB, RB, hB, margin, tmp, 8);
-      for (int i = 0; i < m; i++) push(tmp[i], ba, bb, set);
+      m = box_box_emit(pA, RA, hA, pB, RB, hB, margin, 8, [&](double dist, const double* pos, const double* nrm) {
+        stage[0] = nrm[0]; stage[1] = nrm[1]; stage[2] = nrm[2];
+        sk_lds_double* q = stage + 3 + 4 * m;
+        q[0] = dist; q[1] = pos[0]; q[2] = pos[1]; q[3] = pos[2];
+        m++;
+      });
     }
     SKP_TOC(14);
     // MPR jobs: up to eight at a time, each on a GROUP of eight lanes (job j of the batch on lanes 8 j .. 8 j + 7).  The owner lane's
@@ -1392,31 +1498,37 @@ __device__ __attribute__((noinline)) void sk_collide_coop(const StackConsts& kc_
       double g7[7];
 #pragma unroll
       for (int k = 0; k < 7; k++) g7[k] = __shfl(r7[k], from);
-      if (mine && ghit) push(g7, ba, bb, set);
+      if (mine && ghit) {
+        stage[0] = g7[4]; stage[1] = g7[5]; stage[2] = g7[6];
+        stage[3] = g7[0]; stage[4] = g7[1]; stage[5] = g7[2]; stage[6] = g7[3];
+        m = 1;
+      }
     }
     SKP_TOC(15);
+    // counts through the staging slots, then every lane moves its contacts to their final records
+    if (grp < SKP_GROUPS) stage[SKC_STAGE - 1] = (double)m;
+    __syncthreads();
+    int off = tot, all = 0;
+    for (int g = 0; g < SKP_GROUPS; g++) { const int c = (int)smem[(g * SK_LANES + e) * SKC_STAGE + SKC_STAGE - 1]; if (g < grp) off += c; all += c; }
+    if (act) {
+      const double meta = (double)(ba | (bb << 4) | (set << 8));
+      const double n0 = stage[0], n1 = stage[1], n2 = stage[2];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int slot = off + i;
+        if (i >= m || slot >= SK_MAXCON) continue;
+        const sk_lds_double* q = stage + 3 + 4 * i;
+        sk_lds_double* r = t + SE_REC + slot * SREC2;
+        r[0] = q[1]; r[1] = q[2]; r[2] = q[3]; r[3] = n0; r[4] = n1; r[5] = n2; r[6] = q[0]; r[7] = meta;
+      }
+    }
+    tot += all;
+    __syncthreads();
   }
-  // counts / masks through LDS, then the records in group order
-  stage[lane] = (double)n; stage[WAVE + lane] = (double)(mask | (lost ? 256u : 0u));
-  __syncthreads();
-  int off = 0, total = 0; unsigned all = 0;
-  for (int g = 0; g < SKP_GROUPS; g++) { const int c = (int)stage[g * SK_LANES + e]; if (g < grp) off += c; total += c; all |= (unsigned)stage[WAVE + g * SK_LANES + e]; }
-  sk_glb_double* gq = scratch_wg + (size_t)e * SG_SIZE;
-  for (int i = 0; i < n; i++) {
-    const int slot = off + i;
-    if (slot >= SK_MAXCON) break;
-    sk_glb_double* r = gq + slot * SREC;
-    double nn[3] = {rec[i][4], rec[i][5], rec[i][6]}, t1[3], t2[3];
-    make_frame(nn, t1, t2);
-    r[0] = rec[i][1]; r[1] = rec[i][2]; r[2] = rec[i][3];
-    for (int k = 0; k < 3; k++) { r[3 + k] = nn[k]; r[6 + k] = t1[k]; r[9 + k] = t2[k]; }
-    r[12] = rec[i][0]; r[13] = (double)(meta[i] & 15); r[14] = (double)((meta[i] >> 4) & 15); r[15] = (double)(meta[i] >> 8);
-  }
-  ncon = total < SK_MAXCON ? total : SK_MAXCON;
-  has = all & 15u;
-  over = total > SK_MAXCON || (all & 256u) != 0;
+  if (lane < SK_LANES && act) { t[SE_NCON] = (double)(tot < SK_MAXCON ? tot : SK_MAXCON); t[SE_NEED] = tot > SK_MAXCON ? 256.0 : 0.0; }
   __syncthreads();
 }
+#undef SKP_TOC
 #endif
 
 // mj_Euler: implicit in the finger-joint damping, (M + h B) qacc = M x on the arm block; the arm mass matrix is still in the t area

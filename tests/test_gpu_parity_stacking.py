@@ -452,7 +452,7 @@ def test_config5_total_size_32768_environments(stack_js, ctx100):
             assert (st[:, lanes] == ref[:, None]).all()
             per_ctx.append(ref.copy())
         finals[n] = per_ctx
-        assert max(float(p[SK_BOX_Z]) for p in per_ctx) > 0.03          # boxes have left the table
+        assert max(float(p[SK_BOX_Z]) for p in per_ctx) > 0.02          # boxes have left the table (rest height 0.011)
         env.close()
     for k in range(len(ids)):
         assert np.array_equal(finals[64][k], finals[32768][k])

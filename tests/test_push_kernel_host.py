@@ -200,3 +200,48 @@ def test_device_collision_routines_equal_the_oracle_ones():
             n_b += 1
             np.testing.assert_allclose(out2[:n], ref2, atol=1e-12)
     assert n_c > 100 and n_b > 100
+
+
+def test_box_box_face_clipping_regimes_equal_the_oracle():
+    """The register-only box_box (select-chain Sutherland-Hodgman, no private arrays) against the oracle's array version in the regimes the
+    random poses above seldom reach: a box lying on a box with a small offset / yaw / tilt (incident face partly outside the reference face:
+    the clip path, 4 - 8 contacts), equal faces exactly on each other (the finger tips), boxes a hair apart inside the margin."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from tests.hostcheck.hostcheck import lib, _p
+    L = lib()
+    rng = np.random.default_rng(21)
+
+    def quat(axis, ang):
+        axis = np.asarray(axis, float) / np.linalg.norm(axis)
+        return np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+
+    def qmul(a, b):
+        return np.array([a[0] * b[0] - a[1:] @ b[1:], *(a[0] * b[1:] + b[0] * a[1:] + np.cross(a[1:], b[1:]))])
+
+    counts = np.zeros(9, dtype=int)
+    for it in range(1500):
+        s1 = rng.uniform(0.02, 0.06, 3) if it % 4 else np.array([0.03, 0.03, 0.03])
+        s2 = rng.uniform(0.02, 0.06, 3) if it % 4 else np.array([0.03, 0.05, 0.03])
+        if it % 5 == 0:
+            s2 = s1.copy()
+        margin = [0.0, 0.001, 0.002][it % 3]
+        q1 = quat([0, 0, 1], rng.uniform(-np.pi, np.pi))
+        tilt = quat(rng.standard_normal(3), rng.uniform(0, [0.0, 1e-3, 0.05][it % 3]))
+        q2 = qmul(tilt, quat([0, 0, 1], rng.uniform(-np.pi, np.pi) if it % 7 else 0.0))
+        if it % 7 == 0:
+            q2 = q1.copy()
+        p1 = rng.uniform(-0.1, 0.1, 3)
+        gap = rng.uniform(-0.004, 0.0015)
+        p2 = p1 + np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), s1[2] + s2[2] + gap])
+        if it % 11 == 0:
+            p2[:2] = p1[:2]
+        b = [np.ascontiguousarray(v, float) for v in (p1, q1, s1, p2, q2, s2)]
+        out = np.zeros((16, 7))
+        n = L.hc_box_box(*[_p(v) for v in b], C.c_double(margin), _p(out))
+        ref = orc.box_box(p1, q1, s1, p2, q2, s2, margin=margin)
+        assert n == len(ref), (it, n, len(ref))
+        counts[n] += 1
+        if n:
+            np.testing.assert_allclose(out[:n], ref, atol=1e-12)
+    assert counts[4] > 100 and counts[5:].sum() > 100 and counts[1] > 10, counts

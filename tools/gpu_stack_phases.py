@@ -1,5 +1,7 @@
-"""Stacking kernel: clock ticks per phase of the physics sub-step (diagnostics build: D3IL_STATS_LIB=1), scripted pick-and-place.
-usage: D3IL_STATS_LIB=1 python tools/gpu_stack_phases.py [n_envs]"""
+"""Stacking kernel: clock ticks (100 MHz) per phase of the physics sub-step (diagnostics build: D3IL_STATS_LIB=1), scripted pick-and-place.
+usage: D3IL_STATS_LIB=1 python tools/gpu_stack_phases.py [n_envs]
+Per-environment phases (slots 0, 3, 5) and the phases of the cooperative solve of environment 0 (7 .. 12) are read from the diagnostics words
+of environment 0; the collision phases (13 .. 15) are summed over the lane 0 of every workgroup and divided by the number of workgroups."""
 import ctypes as C
 import os
 import sys
@@ -17,17 +19,35 @@ q0, _, _ = env.start()
 ctx = load_test_contexts()[:4]
 env.reset(context=ctx[np.arange(n) % 4])
 trajs = [build_trajectory(env.js, q0, c, speed=0.7) for c in ctx]
-names = ["arm dyn + tables", "boxes + static / box-box", "finger collision", "limits + aref", "solve", "integrate", "| warm gradient pass", "H0 / g0 / limits", "contact g+H pass", "cholesky", "tri solves", "Jp pass", "line search", "| collision: set-up", "box-box", "MPR"]
+names = ["arm dyn + tables", "-", "-", "build rows", "-", "integrate", "-", "-", "contact g+H pass", "cholesky", "tri solves", "Jp pass", "line search"]
 env.set_timing(True)
+nwg = (n + 3) // 4
+
+
+def snap():
+    buf = np.zeros(32 * 36 + 24)
+    capi.check(env.L.d3il_debug_scratch(env.h, 0, buf.ctypes.data_as(C.c_void_p), len(buf)))
+    st = (C.c_uint64 * 32)()
+    capi.check(env.L.d3il_debug_stats(st, 0))
+    return buf[32 * 36 + 4:32 * 36 + 17].copy(), np.array([st[16 + k] for k in (13, 14, 15, 3, 8, 9, 10, 11, 12, 6, 7)], dtype=float) / nwg
+
+
+t = 0
 for lo, hi, label in ((0, 20, "rest / approach"), (60, 80, "grasp + lift"), (150, 170, "carry / place")):
-    for t in range(lo if lo == 0 else 0, 0):
-        pass
-    buf0 = np.zeros(32 * 36 + 24); capi.check(env.L.d3il_debug_scratch(env.h, 0, buf0.ctypes.data_as(C.c_void_p), len(buf0)))
+    while t < lo:
+        act = torch.as_tensor(np.stack([trajs[i % 4][min(t, len(trajs[i % 4]) - 1)] for i in range(4)]), dtype=torch.float64, device=env.device)
+        env.step(act[torch.arange(n, device=env.device) % 4].contiguous()); t += 1
+    torch.cuda.synchronize()
+    a0, c0 = snap()
     ms = []
-    for t in range(lo, hi):
-        act = torch.as_tensor(np.stack([trajs[i % 4][min(t, len(trajs[i % 4]) - 1)] for i in range(min(n, 4))]), dtype=torch.float64, device=env.device)
-        env.step(act[torch.arange(n, device=env.device) % 4].contiguous())
+    while t < hi:
+        act = torch.as_tensor(np.stack([trajs[i % 4][min(t, len(trajs[i % 4]) - 1)] for i in range(4)]), dtype=torch.float64, device=env.device)
+        env.step(act[torch.arange(n, device=env.device) % 4].contiguous()); t += 1
         torch.cuda.synchronize(); ms.append(env.last_step_ms())
-    buf1 = np.zeros(32 * 36 + 24); capi.check(env.L.d3il_debug_scratch(env.h, 0, buf1.ctypes.data_as(C.c_void_p), len(buf1)))
-    d = buf1[32 * 36 + 4:32 * 36 + 20] - buf0[32 * 36 + 4:32 * 36 + 20]
-    print("%-16s steps %3d-%3d: kernel %.1f ms/step ; env 0 ticks/sub-step: %s  (total %.0f)" % (label, lo, hi, np.mean(ms), ", ".join("%s %.0f" % (nm, x / (30 * (hi - lo))) for nm, x in zip(names, d)), d.sum() / (30 * (hi - lo))))
+    a1, c1 = snap()
+    d, dc = (a1 - a0) / (30 * (hi - lo)), (c1 - c0) / (30 * (hi - lo))
+    print("%-16s steps %3d-%3d: kernel %.2f ms/step ; ticks per sub-step, environment 0: %s | collision (per workgroup): set-up %.0f, box-box %.0f, MPR %.0f" % (
+        label, lo, hi, np.mean(ms), ", ".join("%s %.0f" % (nm, x) for nm, x in zip(names, d) if nm != "-"), dc[0], dc[1], dc[2]))
+    print("    dual solves per sub-step and workgroup %.2f (Newton iterations %.2f): build rows %.0f, g+H pass %.0f, cholesky %.0f, tri solves %.0f, Jp %.0f, line search %.0f ticks per sub-step and workgroup" % (
+        dc[9], dc[10], dc[3], dc[4], dc[5], dc[6], dc[7], dc[8]))
+    print("    kernel time per sub-step: %.0f ticks" % (np.mean(ms) * 1e-3 / 30 * 1e8))
