@@ -158,10 +158,21 @@ D3IL_HD void quat2mat(const double* q, double* R) {   // mju_quat2Mat [ext]
 // Register-only formulation: every array index is a compile-time constant after unrolling (dynamic axis choices are resolved with
 // selects, the Sutherland-Hodgman clip grows its polygon by select-chain inserts), so the routine needs no private (scratch) memory
 // on the device.  Contacts are handed to `emit(dist, pos[3], normal[3])` in polygon order; at most `cap` (<= 8) are emitted.
-D3IL_HD double bb_sel3(const double* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
+// Device: the three candidates pass through an opaque move before the select.  Without it the compiler turns "select of loaded values"
+// back into "load from a selected address", which keeps the source arrays in private memory (dynamic scratch indexing).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define D3IL_OPAQUE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#else
+#define D3IL_OPAQUE3(a, b, c) ((void)0)
+#endif
+D3IL_HD double bb_sel3(const double* v, int i) {
+  double a = v[0], b = v[1], c = v[2];
+  D3IL_OPAQUE3(a, b, c);
+  return i == 0 ? a : (i == 1 ? b : c);
+}
 D3IL_HD void bb_row(const double (*M)[3], int i, double* o) {
 #pragma unroll
-  for (int k = 0; k < 3; k++) o[k] = i == 0 ? M[0][k] : (i == 1 ? M[1][k] : M[2][k]);
+  for (int k = 0; k < 3; k++) { double a = M[0][k], b = M[1][k], c = M[2][k]; D3IL_OPAQUE3(a, b, c); o[k] = i == 0 ? a : (i == 1 ? b : c); }
 }
 template <int N> D3IL_HD void bb_put(double (*P)[3], int at, double x, double y, double z) {      // P[at] = (x, y, z), at < N
 #pragma unroll

@@ -74,7 +74,7 @@ __device__ __forceinline__ void sk_state_from_lds(const sk_lds_double* t, StackS
   }
 }
 // phase 1 (lane = environment): control law + arm forward pass, kinematic tables, smooth accelerations
-__device__ __attribute__((noinline)) void sk_phase_pre(sk_lds_double* t, sk_glb_double* g, unsigned& flags, bool open) {
+__device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g, unsigned& flags, bool open) {
   StackState ss;
   sk_state_from_lds(t, ss);
   ss.arm.flags = flags;
@@ -88,7 +88,7 @@ __device__ __attribute__((noinline)) void sk_phase_pre(sk_lds_double* t, sk_glb_
   flags = ss.arm.flags;
 }
 // phase 3 (lane = environment): joint-limit rows, start point of the solver, "does the solver run"
-__device__ __attribute__((noinline)) void sk_phase_mid(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
+__device__ __forceinline__ void sk_phase_mid(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
   StackState ss;
   for (int k = 0; k < NDOF; k++) { ss.arm.q[k] = t[SE_Q + k]; ss.arm.v[k] = t[ST_VEL + SK_ARM0 + k]; }
   ss.arm.flags = flags;
@@ -109,7 +109,7 @@ __device__ __attribute__((noinline)) void sk_phase_mid(sk_lds_double* t, sk_glb_
   t[SE_NEED] = (ncon > 0 || any_lim) ? 1.0 : 0.0;
 }
 // phase 5 (lane = environment): mj_Euler
-__device__ __attribute__((noinline)) void sk_phase_post(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
+__device__ __forceinline__ void sk_phase_post(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
   StackState ss;
   sk_state_from_lds(t, ss);
   ss.arm.flags = flags;
@@ -169,16 +169,18 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
     sk_collide_coop(g_stack_consts, sm, lane, live_mask);
     if (live) sk_phase_mid(t, g, fl);
     __syncthreads();
+    // the solver takes two environments at a time, one per half wave; a pair whose contact rows do not fit the shared J area together is
+    // solved one environment after the other (job 2 p: pair p or its first environment, job 2 p + 1: its second environment).  ONE call
+    // site: the solver is inlined once
 #pragma clang loop unroll(disable)
-    for (int e0 = 0; e0 < SK_LANES; e0 += 2) {      // the solver takes two environments at a time, one per half wave
-      const bool a0 = ((live_mask >> e0) & 1u) && sk_env_view(sm, e0)[SE_NEED] != 0.0;
-      const bool a1 = ((live_mask >> (e0 + 1)) & 1u) && sk_env_view(sm, e0 + 1)[SE_NEED] != 0.0;
+    for (int job = 0; job < SK_LANES; job++) {
+      const int e0 = job & ~1;
+      const bool n0 = ((live_mask >> e0) & 1u) && sk_env_view(sm, e0)[SE_NEED] != 0.0;
+      const bool n1 = ((live_mask >> (e0 + 1)) & 1u) && sk_env_view(sm, e0 + 1)[SE_NEED] != 0.0;
+      const bool split = n0 && n1 && (int)sk_env_view(sm, e0)[SE_JSZ] + (int)sk_env_view(sm, e0 + 1)[SE_JSZ] > SKC_JSIZE;
+      const bool a0 = (job & 1) ? false : n0, a1 = (job & 1) ? (split && n1) : (n1 && !split);
       if (!a0 && !a1) continue;
-      unsigned failed;
-      if (a0 && a1 && (int)sk_env_view(sm, e0)[SE_JSZ] + (int)sk_env_view(sm, e0 + 1)[SE_JSZ] > SKC_JSIZE) {      // more rows than the shared J area holds
-        failed = sk_solve_dual(g_stack_consts, sm, e0, lane, true, false);
-        failed |= sk_solve_dual(g_stack_consts, sm, e0, lane, false, true);
-      } else failed = sk_solve_dual(g_stack_consts, sm, e0, lane, a0, a1);
+      const unsigned failed = sk_solve_dual(g_stack_consts, sm, e0, lane, a0, a1);
       if (((failed & 1u) && lane == e0) || ((failed & 2u) && lane == e0 + 1)) fl |= F_SOLVER_FAIL;
     }
     __syncthreads();

@@ -169,10 +169,19 @@ D3IL_HD void sk_portal_dir(const SkPt* P, double* dir) {
   double a[3] = {P[2].v[0] - P[1].v[0], P[2].v[1] - P[1].v[1], P[2].v[2] - P[1].v[2]}, b[3] = {P[3].v[0] - P[1].v[0], P[3].v[1] - P[1].v[1], P[3].v[2] - P[1].v[2]};
   cross3(a, b, dir); sk_norm3(dir);
 }
+// dst = c ? src : dst, element by element: value selects keep the portal in registers (a conditional struct store is merged by the
+// compiler into one store through a SELECTED POINTER, which pins the whole portal array in private memory)
+D3IL_HD void sk_sel(SkPt& dst, const SkPt& src, bool c) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) { dst.v[k] = c ? src.v[k] : dst.v[k]; dst.v1[k] = c ? src.v1[k] : dst.v1[k]; dst.v2[k] = c ? src.v2[k] : dst.v2[k]; }
+}
 D3IL_HD void sk_expand(SkPt* P, const SkPt& v4) {
   double w[3]; cross3(v4.v, P[0].v, w);
-  if (dot3(P[1].v, w) > 0) { if (dot3(P[2].v, w) > 0) P[1] = v4; else P[3] = v4; }
-  else { if (dot3(P[3].v, w) > 0) P[2] = v4; else P[1] = v4; }
+  const bool b1 = dot3(P[1].v, w) > 0, b2 = dot3(P[2].v, w) > 0, b3 = dot3(P[3].v, w) > 0;
+  // b1 ? (b2 ? P[1] : P[3]) : (b3 ? P[2] : P[1]) = v4
+  sk_sel(P[1], v4, (b1 && b2) || (!b1 && !b3));
+  sk_sel(P[2], v4, !b1 && b3);
+  sk_sel(P[3], v4, b1 && !b2);
 }
 D3IL_HD bool sk_reach_tol(const SkPt* P, const SkPt& v4, const double* dir) {
   double dv4 = dot3(v4.v, dir);
@@ -204,17 +213,17 @@ D3IL_HD void sk_tri_closest_origin(const double* a, const double* b, const doubl
 #endif
 // SUP(dir, pt): support point of the Minkowski difference a - b in direction dir (sk_support on one lane; the device collision phase
 // spreads the hull vertices of a pair over a group of eight lanes)
-template <class SUP>
-D3IL_HD bool sk_mpr_t(const StackConsts& kc_, const SkShape a, const SkShape b, double margin, double* out, SUP sup) {
+template <class SH, class SUP>
+D3IL_HD bool sk_mpr_t(const StackConsts& kc_, const SH a, const SH b, double margin, double* out, SUP sup) {
   D3IL_STACK_CONSTS(kc_, kc);
   SK_MPR_COUNT(g_calls++);
   SkPt P[4], v4;
   double dir[3], va[3], vb[3];
-  for (int s = 0; s < 2; s++) {
-    const SkShape& sh = s ? b : a;
-    double* c = s ? P[0].v2 : P[0].v1;
-    if (sh.hull) { for (int k = 0; k < 3; k++) c[k] = sh.R[3 * k] * kc.hull_center[0] + sh.R[3 * k + 1] * kc.hull_center[1] + sh.R[3 * k + 2] * kc.hull_center[2] + sh.p[k]; }
-    else { c[0] = sh.p[0]; c[1] = sh.p[1]; c[2] = sh.p[2]; }
+  {   // geom centres (written out per shape: a pointer selected at run time into P[] would pin the whole portal in private memory)
+    if (a.hull) { for (int k = 0; k < 3; k++) P[0].v1[k] = a.R[3 * k] * kc.hull_center[0] + a.R[3 * k + 1] * kc.hull_center[1] + a.R[3 * k + 2] * kc.hull_center[2] + a.p[k]; }
+    else { P[0].v1[0] = a.p[0]; P[0].v1[1] = a.p[1]; P[0].v1[2] = a.p[2]; }
+    if (b.hull) { for (int k = 0; k < 3; k++) P[0].v2[k] = b.R[3 * k] * kc.hull_center[0] + b.R[3 * k + 1] * kc.hull_center[1] + b.R[3 * k + 2] * kc.hull_center[2] + b.p[k]; }
+    else { P[0].v2[0] = b.p[0]; P[0].v2[1] = b.p[1]; P[0].v2[2] = b.p[2]; }
   }
   for (int k = 0; k < 3; k++) P[0].v[k] = P[0].v1[k] - P[0].v2[k];
   if (sk_zero(P[0].v[0]) && sk_zero(P[0].v[1]) && sk_zero(P[0].v[2])) P[0].v[0] += 10 * 2.220446049250313e-16;
@@ -237,17 +246,23 @@ D3IL_HD bool sk_mpr_t(const StackConsts& kc_, const SkShape a, const SkShape b, 
   if (sk_zero(dot) || dot < 0) return false;
   for (int k = 0; k < 3; k++) { va[k] = P[1].v[k] - P[0].v[k]; vb[k] = P[2].v[k] - P[0].v[k]; }
   cross3(va, vb, dir); sk_norm3(dir);
-  if (dot3(dir, P[0].v) > 0) { SkPt t = P[1]; P[1] = P[2]; P[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+  {
+    const bool sw = dot3(dir, P[0].v) > 0;
+    const SkPt t1 = P[1], t2 = P[2];
+    sk_sel(P[1], t2, sw); sk_sel(P[2], t1, sw);
+    if (sw) { dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+  }
   for (int guard = 0; guard < 100; guard++) {
     SK_MPR_COUNT(g_disc++);
     sup(dir, P[3]);
     dot = dot3(P[3].v, dir);
     if (sk_zero(dot) || dot < 0) return false;
-    bool cont = false;
     cross3(P[1].v, P[3].v, va); dot = dot3(va, P[0].v);
-    if (dot < 0 && !sk_zero(dot)) { P[2] = P[3]; cont = true; }
-    if (!cont) { cross3(P[3].v, P[2].v, va); dot = dot3(va, P[0].v); if (dot < 0 && !sk_zero(dot)) { P[1] = P[3]; cont = true; } }
-    if (!cont) break;
+    const bool c2 = dot < 0 && !sk_zero(dot);
+    cross3(P[3].v, P[2].v, va); dot = dot3(va, P[0].v);      // evaluated with the portal BEFORE the replacement; only used when c2 is false
+    const bool c1 = !c2 && dot < 0 && !sk_zero(dot);
+    { const SkPt t3 = P[3]; sk_sel(P[2], t3, c2); sk_sel(P[1], t3, c1); }
+    if (!c2 && !c1) break;
     for (int k = 0; k < 3; k++) { va[k] = P[1].v[k] - P[0].v[k]; vb[k] = P[2].v[k] - P[0].v[k]; }
     cross3(va, vb, dir); sk_norm3(dir);
   }
@@ -304,27 +319,36 @@ D3IL_NOINLINE inline bool sk_mpr(const StackConsts& kc_, const SkShape a, const 
 // coefficient of row j + 1 (tangent, tangent, torsional).  Zones as in MuJoCo's PGS / Newton cone [ext]; mirrors cone_eval (dim 3).
 // imu = 1 / max(1e-15, mu^2 (1 + mu^2)) is a constant of the contact
 D3IL_HD void sk_cone_pre(int dim, const double* jar, const double* D, double mu, double imu, const double* fr, double* force, double* Hc /* 4 x 4 */) {
+  // all loops run to the fixed bound 4 with a row predicate: every index is a compile-time constant, nothing is addressed in private memory
 #pragma unroll
   for (int i = 0; i < 16; i++) Hc[i] = 0;
   double U[4] = {jar[0] * mu, 0, 0, 0}, T2 = 0;
-  for (int j = 1; j < dim; j++) { U[j] = jar[j] * fr[j - 1]; T2 += U[j] * U[j]; }
+#pragma unroll
+  for (int j = 1; j < 4; j++) if (j < dim) { U[j] = jar[j] * fr[j - 1]; T2 += U[j] * U[j]; }
   const double N = U[0], iT = T2 > 0 ? rsqrtd(T2) : 0.0, T = T2 * iT;      // 1 / T by v_rsq_f64 + Newton steps: no square root, no divisions below
   if (N >= mu * T || (T <= 0 && N >= 0)) { force[0] = force[1] = force[2] = force[3] = 0; return; }
   if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+#pragma unroll
     for (int j = 0; j < 4; j++) { force[j] = j < dim ? -D[j] * jar[j] : 0.0; if (j < dim) Hc[5 * j] = D[j]; }
     return;
   }
   const double Dm = D[0] * imu, NmT = N - mu * T;
   double g[4] = {mu, 0, 0, 0}, Un[4] = {0, 0, 0, 0};      // Un = U / T
-  for (int j = 1; j < dim; j++) { Un[j] = U[j] * iT; g[j] = -mu * fr[j - 1] * Un[j]; }
+#pragma unroll
+  for (int j = 1; j < 4; j++) if (j < dim) { Un[j] = U[j] * iT; g[j] = -mu * fr[j - 1] * Un[j]; }
+#pragma unroll
   for (int j = 0; j < 4; j++) force[j] = j < dim ? -Dm * NmT * g[j] : 0.0;
   const double kT = NmT * (-mu) * iT;
-  for (int a = 0; a < dim; a++)
-    for (int b = 0; b < dim; b++) {
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      if (a >= dim || b >= dim) continue;
       double h = g[a] * g[b];
       if (a > 0 && b > 0) h += kT * fr[a - 1] * fr[b - 1] * ((a == b ? 1.0 : 0.0) - Un[a] * Un[b]);
       Hc[4 * a + b] = Dm * h;
     }
+  }
 }
 D3IL_HD void sk_cone(int dim, const double* jar, const double* D, double mu, const double* fr, double* force, double* Hc /* 4 x 4 */) {
   sk_cone_pre(dim, jar, D, mu, 1.0 / fmax(1e-15, mu * mu * (1 + mu * mu)), fr, force, Hc);
@@ -945,6 +969,11 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     if (row && !fin) Gs[i] = gl;
     __syncthreads();
     if (con && !fin) {
+      // block offsets re-read per pass through an opaque move: the row / column addresses derived from them are then recomputed here
+      // instead of being hoisted out of the Newton loop and spilled (a scratch reload + full wait in front of every LDS add otherwise)
+      int oa = cc.oa, ob = cc.ob;
+      asm volatile("" : "+v"(oa), "+v"(ob));
+      auto col = [&](int k) { return k < 6 ? oa + k : ob + k - 6; };
       double J[4][SKC_NJ], xk[SKC_NJ], f[4], Hc[16];
 #pragma unroll
       for (int k = 0; k < SKC_NJ; k++) xk[k] = jcol_ok(k) ? t[ST_X + col(k)] : 0.0;
@@ -978,7 +1007,7 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
           if (a >= 6 && cc.na > 0) {
 #pragma unroll
             for (int b = 0; b < 6; b++)
-              (void)__hip_atomic_fetch_add(&Hs[tri(ra, cc.oa + b)], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              (void)__hip_atomic_fetch_add(&Hs[tri(ra, oa + b)], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
 #pragma unroll
           for (int b = (a < 6 ? 0 : 6); b <= a; b++)
@@ -990,6 +1019,26 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     gi = (row && !fin) ? Gs[i] : 0.0;
     return sk_half_max(fabs(gi), upper);
   };
+  // Block structure of the Cholesky factor, union over the two halves: blocks box 0 | 1 | 2 | arm; cpl bit (4 bi + bk), bk < bi: block row bi
+  // of the factor has entries in column block bk (a contact couples the two blocks, or fill: an earlier block couples with both)
+  unsigned cpl = 0;
+  {
+    int ba = -1, bb = 0;
+    if (con) { const int meta = (int)t[SE_REC + hl * SREC2 + 7]; ba = sk_blk_of(meta & 15); bb = sk_blk_of((meta >> 4) & 15); }
+#pragma unroll
+    for (int bi = 1; bi <= SK_NB; bi++) {
+#pragma unroll
+      for (int bk = 0; bk < bi; bk++) if (__any(con && ((ba == bk && bb == bi) || (ba == bi && bb == bk)))) cpl |= 1u << (4 * bi + bk);
+    }
+#pragma unroll
+    for (int k = 0; k < SK_NB; k++) {
+#pragma unroll
+      for (int bi = k + 1; bi <= SK_NB; bi++) {
+#pragma unroll
+        for (int bj = k + 1; bj < bi; bj++) if (((cpl >> (4 * bi + k)) & 1u) && ((cpl >> (4 * bj + k)) & 1u)) cpl |= 1u << (4 * bi + bj);
+      }
+    }
+  }
   for (int it = 0; it < 60 && __any(!fin); it++) {
     const double gm = grad_pass();
     SD_TOC(8);
@@ -1005,8 +1054,19 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
 #pragma unroll
       for (int j = 0; j < SK_NV; j++) {
         double sum = Hr[j], s2 = 0;      // two accumulators: the dependent FMA chain is half as long
+        constexpr int NBLK = SK_NB + 1;
+        const int bj = j >= SK_ARM0 ? SK_NB : j / 6;
 #pragma unroll
-        for (int k = 0; k < j; k++) { if (k & 1) s2 -= Lr[k] * sk_hbcast(Lr[k], j, upper); else sum -= Lr[k] * sk_hbcast(Lr[k], j, upper); }
+        for (int bk = 0; bk < NBLK; bk++) {
+          if (bk > bj) continue;
+          if (bk < bj && !((cpl >> (4 * bj + bk)) & 1u)) continue;      // row j of the factor has no entries in this column block (wave-uniform)
+          const int k0 = bk == SK_NB ? SK_ARM0 : 6 * bk, k1 = bk == SK_NB ? SK_NV : 6 * bk + 6;
+          double bc[NDOF];      // the broadcasts of a block are independent: issued back to back, one wait
+#pragma unroll
+          for (int k = k0; k < k1; k++) if (k < j) bc[k - k0] = sk_hbcast(Lr[k], j, upper);
+#pragma unroll
+          for (int k = k0; k < k1; k++) if (k < j) { if (k & 1) s2 -= Lr[k] * bc[k - k0]; else sum -= Lr[k] * bc[k - k0]; }
+        }
         sum += s2;
         double sj = sk_hbcast(sum, j, upper);
         if (!(sj > 0)) { if (!fin) okh = false; sj = 1; }
@@ -1125,7 +1185,7 @@ D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& 
 // sk_solve_coop by the whole wave), stack_substep_post (mj_Euler).  WARM_LDS: the warm start is the x vector left in the t area by
 // the previous sub-step (device step kernel) instead of ss.warm.
 template <class C>
-D3IL_NOINLINE inline void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
+D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
   D3IL_STACK_CONSTS(kc_, kc);
   D3IL_REFRESH(c0, c);
   EnvState& st = ss.arm;
@@ -1285,7 +1345,7 @@ D3IL_NOINLINE inline int stack_pre_collide(const StackConsts& kc_, StackState& s
   return ncon;
 }
 template <bool WARM_LDS, class C>
-D3IL_NOINLINE inline void stack_pre_finish(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const int ncon, unsigned has, bool& any_lim_out) {
+D3IL_HD void stack_pre_finish(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const int ncon, unsigned has, bool& any_lim_out) {
   D3IL_REFRESH(c0, c);
   EnvState& st = ss.arm;
   SK_TIC;
@@ -1372,158 +1432,204 @@ __device__ __forceinline__ void sk_support1_group(const StackConsts& kc_, const 
 #pragma unroll
   for (int k = 0; k < 3; k++) out[k] = R[3 * k] * loc[0] + R[3 * k + 1] * loc[1] + R[3 * k + 2] * loc[2] + s.p[k] + 0.5 * margin * dir[k];
 }
+// shape of an MPR job with its pose in the LDS tables (re-read by every support evaluation: nothing of it stays live across the portal iterations)
+struct SkShapeL { const sk_lds_double* R; const sk_lds_double* p; double half[3]; int hull; };
+__device__ __forceinline__ void sk_support1_group_l(const StackConsts& kc_, const SkShapeL& s, const double* dir, double margin, double* out, const int sub) {
+  double R[9], p[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = s.R[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) p[k] = s.p[k];
+  const SkShape sh{R, p, s.half, s.hull};
+  sk_support1_group(kc_, sh, dir, margin, out, sub);
+}
 // Collision of the workgroup's environments with one lane per (environment, pair group), lane = group * SK_LANES + environment:
 //   group 0 .. 2  : box b against the static boxes          3 .. 5 : the box pairs (0, 1) (0, 2) (1, 2)
 //   group 6 .. 11 : box b against finger f: tip, hull (MPR)    12  : finger <-> finger (nearly closed gripper)
+// Jobs: every lane has at most one pair test per round and all lanes run the test of a round at ONE call site per kind (box-box, MPR),
+// so that lanes of different groups do not serialise through separately inlined copies of the same routine.
+//   round   group 0..2 (box b)   3..5 (box pair)   6..11 (box b, finger f)   12 (fingers)
+//     0     static 0  [BB]        b1-b2 [BB]         box - tip   [BB]          tip - tip   [BB]
+//     1     static 1  [BB]                           box - hull  [MPR]         hull - hull [MPR]
+//     2     static 2  [BB]                                                     hull0 - tip1 [MPR]
+//     3     static 3  [BB]                                                     tip0 - hull1 [MPR]
 // Everything stays in registers and LDS: a pair test emits its contacts into the lane's staging slot of the workgroup's shared area
 // (free during this phase), the per-round counts go through the same area, and every lane then moves its contacts to their final
 // slots of the environment's compact record list - order: round, then group; deterministic, independent of which environments share
-// the workgroup.  Results per environment: t[SE_NCON] = contacts kept (<= SK_MAXCON), t[SE_NEED] = 256 when contacts were dropped.
+// the workgroup.  The box-box and the MPR jobs of a round run in two separate (non-inlined) functions that derive a lane's job from
+// (lane, round) and fetch the shapes from the LDS tables, so that neither carries the other's registers (the combined function spilled
+// ~130 doubles per lane and round to scratch: most of the kernel's HBM traffic).
+// Results per environment: t[SE_NCON] = contacts kept (<= SK_MAXCON), t[SE_NEED] = 256 when contacts were dropped.
 constexpr int SKP_GROUPS = 13;
 static_assert(SKP_GROUPS * SK_LANES <= WAVE, "the lane-per-pair collision needs 13 lanes per environment");
-__device__ __attribute__((noinline)) void sk_collide_coop(const StackConsts& kc_, sk_lds_double* smem, const int lane, const unsigned live_mask) {
+struct SkJob { int kind, ba, bb, set, hullA, hullB; double margin; };      // kind: 0 none, 1 box-box, 2 MPR
+// the job of lane L in a round (L may be another lane: the MPR groups rebuild their owner's job); shapes from the tables of L's environment
+__device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* smem, const int L, const int round, const unsigned live_mask,
+                                        double* RA, double* pA, double* hA, double* RB, double* pB, double* hB) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const int e = L % SK_LANES, grp = L / SK_LANES;
+  const bool act = grp < SKP_GROUPS && ((live_mask >> e) & 1u) != 0;
+  const sk_lds_double* t = sk_env_view(smem, e);
+  SkJob j; j.kind = 0; j.ba = 0; j.bb = 0; j.set = 0; j.hullA = 0; j.hullB = 0; j.margin = 0;
+  double rsum = 0;
+  auto ld = [&](int off, int cnt, double* out) { for (int k = 0; k < cnt; k++) out[k] = t[off + k]; };
+  auto box_shape = [&](int b, double* R, double* p, double* h) { ld(ST_BR + 9 * b, 9, R); ld(ST_BP + 3 * b, 3, p); for (int k = 0; k < 3; k++) h[k] = kc.box_half[b][k]; };
+  auto tip_shape = [&](int f, double* R, double* p, double* h) { ld(ST_TIPR + 9 * f, 9, R); ld(ST_TIPP + 3 * f, 3, p); for (int k = 0; k < 3; k++) h[k] = kc.tip_half[k]; };
+  auto hull_shape = [&](int f, double* R, double* p, double* h) { ld(ST_HULR + 9 * f, 9, R); ld(ST_HULP + 3 * f, 3, p); h[0] = h[1] = h[2] = 0; };
+  if (!act) return j;
+  if (grp < 3) {
+    if (round < kc.ns) {
+      const int sidx = round, b = grp;
+      box_shape(b, RB, pB, hB);
+      double d[3] = {pB[0] - kc.st_c[sidx][0], pB[1] - kc.st_c[sidx][1], pB[2] - kc.st_c[sidx][2]}, ex = 0;
+      for (int i = 0; i < 3; i++) { double loc = kc.st_R[sidx][i] * d[0] + kc.st_R[sidx][3 + i] * d[1] + kc.st_R[sidx][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[sidx][i]; if (o > 0) ex += o * o; }
+      const double rc = kc.box_r[b] + kc.set[SKS_STATIC + sidx].margin;
+      if (ex <= rc * rc) {
+        j.kind = 1; j.ba = SKB_STATIC; j.bb = b; j.set = SKS_STATIC + sidx;
+        for (int k = 0; k < 9; k++) RA[k] = kc.st_R[sidx][k];
+        for (int k = 0; k < 3; k++) { pA[k] = kc.st_c[sidx][k]; hA[k] = kc.st_h[sidx][k]; }
+      }
+    }
+  } else if (grp < 6) {
+    if (round == 0) {
+      const int b1 = grp == 5 ? 1 : 0, b2 = grp == 3 ? 1 : 2;
+      box_shape(b1, RA, pA, hA); box_shape(b2, RB, pB, hB);
+      j.kind = 1; j.ba = b1; j.bb = b2; j.set = SKS_BOXBOX; rsum = kc.box_r[b1] + kc.box_r[b2];
+    }
+  } else if (grp < 12) {
+    const int b = (grp - 6) >> 1, f = (grp - 6) & 1;
+    if (round == 0) { box_shape(b, RA, pA, hA); tip_shape(f, RB, pB, hB); j.kind = 1; j.ba = b; j.bb = SKB_TIP + f; j.set = SKS_BOXTIP; rsum = kc.box_r[b] + kc.tip_r; }
+    else if (round == 1) { box_shape(b, RA, pA, hA); hull_shape(f, RB, pB, hB); j.hullB = 1; j.kind = 2; j.ba = b; j.bb = SKB_FINGER + f; j.set = SKS_BOXHULL; rsum = kc.box_r[b] + kc.hull_r; }
+  } else if (t[ST_AUX] < 0.004) {     // finger <-> finger: only a (nearly) closed gripper (the gaps are q1 + q2 - 1 mm or less)
+    if (round == 0) { tip_shape(0, RA, pA, hA); tip_shape(1, RB, pB, hB); j.kind = 1; j.ba = SKB_TIP; j.bb = SKB_TIP + 1; j.set = SKS_TIPTIP; }
+    else if (round == 1) { hull_shape(0, RA, pA, hA); hull_shape(1, RB, pB, hB); j.hullA = j.hullB = 1; j.kind = 2; j.ba = SKB_FINGER; j.bb = SKB_FINGER + 1; j.set = SKS_HULLHULL; }
+    else if (round == 2) { hull_shape(0, RA, pA, hA); tip_shape(1, RB, pB, hB); j.hullA = 1; j.kind = 2; j.ba = SKB_FINGER; j.bb = SKB_TIP + 1; j.set = SKS_HULLTIP; }
+    else { tip_shape(0, RA, pA, hA); hull_shape(1, RB, pB, hB); j.hullB = 1; j.kind = 2; j.ba = SKB_TIP; j.bb = SKB_FINGER + 1; j.set = SKS_HULLTIP; }
+  }
+  if (j.kind != 0) {
+    j.margin = kc.set[j.set].margin;
+    if (rsum > 0) {      // bounding spheres about the geom centres (the hull's centre is its mesh centre)
+      double cA[3] = {pA[0], pA[1], pA[2]}, cB[3] = {pB[0], pB[1], pB[2]};
+      if (j.hullA) for (int k = 0; k < 3; k++) cA[k] += RA[3 * k] * kc.hull_center[0] + RA[3 * k + 1] * kc.hull_center[1] + RA[3 * k + 2] * kc.hull_center[2];
+      if (j.hullB) for (int k = 0; k < 3; k++) cB[k] += RB[3 * k] * kc.hull_center[0] + RB[3 * k + 1] * kc.hull_center[1] + RB[3 * k + 2] * kc.hull_center[2];
+      const double d[3] = {cB[0] - cA[0], cB[1] - cA[1], cB[2] - cA[2]}, rc = rsum + j.margin;
+      if (dot3(d, d) > rc * rc) j.kind = 0;
+    }
+  }
+  return j;
+}
+// box-box jobs of a round: contacts -> the lane's staging slot (normal[3] | m x (dist, pos[3])); returns m | meta << 8 (0 when the lane has no such job)
+__device__ __forceinline__ int sk_round_boxbox(const StackConsts& kc_, sk_lds_double* smem, const int lane, const int round, const unsigned live_mask) {
+  double RA[9], pA[3], hA[3], RB[9], pB[3], hB[3];
+  const SkJob j = sk_job(kc_, smem, lane, round, live_mask, RA, pA, hA, RB, pB, hB);
+  if (j.kind != 1) return 0;
+  sk_lds_double* stage = smem + lane * SKC_STAGE;
+  int m = 0;
+  box_box_emit(pA, RA, hA, pB, RB, hB, j.margin, 8, [&](double dist, const double* pos, const double* nrm) {
+    stage[0] = nrm[0]; stage[1] = nrm[1]; stage[2] = nrm[2];
+    sk_lds_double* q = stage + 3 + 4 * m;
+    q[0] = dist; q[1] = pos[0]; q[2] = pos[1]; q[3] = pos[2];
+    m++;
+  });
+  return m | ((j.ba | (j.bb << 4) | (j.set << 8)) << 8);
+}
+// MPR jobs of a round: up to eight at a time, each on a GROUP of eight lanes (job k of the batch on lanes 8 k .. 8 k + 7).  The group
+// rebuilds its owner lane's job (shapes from the LDS tables), the portal iteration runs redundantly on the eight lanes (uniform inside a
+// group) and the hull support function is spread over them (sk_support1_group: nine vertices per lane instead of 68 on one lane).
+__device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_double* smem, const int lane, const int round, const unsigned live_mask) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  int mine_kind = 0, mine_meta = 0;
+  {
+    double RA[9], pA[3], hA[3], RB[9], pB[3], hB[3];
+    const SkJob j = sk_job(kc, smem, lane, round, live_mask, RA, pA, hA, RB, pB, hB);
+    mine_kind = j.kind; mine_meta = j.ba | (j.bb << 4) | (j.set << 8);
+  }
+  int m = 0;
+  for (unsigned long long pend = __ballot(mine_kind == 2); pend != 0;) {
+    const int grp8 = lane >> 3, sub = lane & 7;
+    int owner = -1;      // owner lane of this group's job (-1: no job in this batch)
+    unsigned long long batch = 0, rest = pend;
+    for (int k = 0; k < WAVE / SKG && rest != 0; k++) { const int L = __builtin_ctzll(rest); rest &= rest - 1; batch |= 1ull << L; if (k == grp8) owner = L; }
+    pend = rest;
+    double r7[7] = {0, 0, 0, 0, 0, 0, 0};
+    int hit = 0;
+    if (owner >= 0) {
+      // the owner's job, shapes as LDS table offsets (groups 6 .. 11: box b - hull f; group 12: hull - hull, hull0 - tip1, tip0 - hull1)
+      const int oe = owner % SK_LANES, og = owner / SK_LANES;
+      const sk_lds_double* to = sk_env_view(smem, oe);
+      SkShapeL A, B;
+      int set;
+      auto box_l = [&](int bx, SkShapeL& S) { S.R = to + ST_BR + 9 * bx; S.p = to + ST_BP + 3 * bx; for (int k = 0; k < 3; k++) S.half[k] = kc.box_half[bx][k]; S.hull = 0; };
+      auto tip_l = [&](int f, SkShapeL& S) { S.R = to + ST_TIPR + 9 * f; S.p = to + ST_TIPP + 3 * f; for (int k = 0; k < 3; k++) S.half[k] = kc.tip_half[k]; S.hull = 0; };
+      auto hull_l = [&](int f, SkShapeL& S) { S.R = to + ST_HULR + 9 * f; S.p = to + ST_HULP + 3 * f; S.half[0] = S.half[1] = S.half[2] = 0; S.hull = 1; };
+      if (og < 12) { box_l((og - 6) >> 1, A); hull_l((og - 6) & 1, B); set = SKS_BOXHULL; }
+      else if (round == 1) { hull_l(0, A); hull_l(1, B); set = SKS_HULLHULL; }
+      else if (round == 2) { hull_l(0, A); tip_l(1, B); set = SKS_HULLTIP; }
+      else { tip_l(0, A); hull_l(1, B); set = SKS_HULLTIP; }
+      const double um = kc.set[set].margin;
+      hit = sk_mpr_t(kc, A, B, um, r7, [&](const double* dir, SkPt& pt) {
+        const double nd[3] = {-dir[0], -dir[1], -dir[2]};
+        sk_support1_group_l(kc, A, dir, um, pt.v1, sub); sk_support1_group_l(kc, B, nd, um, pt.v2, sub);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pt.v[k] = pt.v1[k] - pt.v2[k];
+      }) ? 1 : 0;
+    }
+    // results back to the owner lanes: owner L reads lane 8 * (rank of L in the batch)
+    const bool mine = ((batch >> lane) & 1ull) != 0;
+    const int from = mine ? SKG * __popcll(batch & ((1ull << lane) - 1ull)) : lane;
+    const int ghit = __shfl(hit, from);
+    double g7[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) g7[k] = __shfl(r7[k], from);
+    if (mine && ghit) {
+      sk_lds_double* stage = smem + lane * SKC_STAGE;
+      stage[0] = g7[4]; stage[1] = g7[5]; stage[2] = g7[6];
+      stage[3] = g7[0]; stage[4] = g7[1]; stage[5] = g7[2]; stage[6] = g7[3];
+      m = 1;
+    }
+  }
+  return m | (mine_meta << 8);
+}
+__device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_double* smem, const int lane, const unsigned live_mask) {
   D3IL_STACK_CONSTS(kc_, kc);
   const int e = lane % SK_LANES, grp = lane / SK_LANES;
   const bool act = grp < SKP_GROUPS && ((live_mask >> e) & 1u) != 0;
   sk_lds_double* t = sk_env_view(smem, e);
   sk_lds_double* stage = smem + (grp < SKP_GROUPS ? lane : 0) * SKC_STAGE;
   int tot = 0;      // contacts of this environment so far (the same value in all its lanes)
-  auto ld = [&](int off, int cnt, double* out) { for (int k = 0; k < cnt; k++) out[k] = t[off + k]; };
 #if defined(D3IL_DEVICE_STATS)
-  unsigned long long skp_t0 = wall_clock64();      // lane 0 (environment 0, group 0) times the phases of the whole wave: slots 13 set-up, 14 box-box, 15 MPR
+  unsigned long long skp_t0 = wall_clock64();      // lane 0 (environment 0, group 0) times the phases of the whole wave: slots 14 box-box, 15 MPR, 13 bookkeeping
 #define SKP_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&g_dev_stats[16 + (slot)], t_ - skp_t0); skp_t0 = t_; } while (0)
 #else
 #define SKP_TOC(slot) ((void)0)
 #endif
-  // Jobs: every lane sets up at most one pair test per round and all lanes run the test of a round at ONE call site per kind (box-box,
-  // MPR), so that lanes of different groups do not serialise through separately inlined copies of the same routine.
-  //   round   group 0..2 (box b)   3..5 (box pair)   6..11 (box b, finger f)   12 (fingers)
-  //     0     static 0  [BB]        b1-b2 [BB]         box - tip   [BB]          tip - tip   [BB]
-  //     1     static 1  [BB]                           box - hull  [MPR]         hull - hull [MPR]
-  //     2     static 2  [BB]                                                     hull0 - tip1 [MPR]
-  //     3     static 3  [BB]                                                     tip0 - hull1 [MPR]
-  const bool fingers = grp == 12 && act && t[ST_AUX] < 0.004;     // only a (nearly) closed gripper (the gaps are q1 + q2 - 1 mm or less)
-  for (int round = 0; round < 4; round++) {
-    int kind = 0, ba = 0, bb = 0, set = 0;      // kind: 0 none, 1 box-box, 2 MPR
-    double RA[9], pA[3], hA[3], RB[9], pB[3], hB[3], margin = 0, rsum = 0;
-    int hullA = 0, hullB = 0;
-    auto box_shape = [&](int b, double* R, double* p, double* h) { ld(ST_BR + 9 * b, 9, R); ld(ST_BP + 3 * b, 3, p); for (int k = 0; k < 3; k++) h[k] = kc.box_half[b][k]; };
-    auto tip_shape = [&](int f, double* R, double* p, double* h) { ld(ST_TIPR + 9 * f, 9, R); ld(ST_TIPP + 3 * f, 3, p); for (int k = 0; k < 3; k++) h[k] = kc.tip_half[k]; };
-    auto hull_shape = [&](int f, double* R, double* p, double* h) { ld(ST_HULR + 9 * f, 9, R); ld(ST_HULP + 3 * f, 3, p); h[0] = h[1] = h[2] = 0; };
-    if (act) {
-      if (grp < 3) {
-        if (round < kc.ns) {
-          const int sidx = round, b = grp;
-          box_shape(b, RB, pB, hB);
-          double d[3] = {pB[0] - kc.st_c[sidx][0], pB[1] - kc.st_c[sidx][1], pB[2] - kc.st_c[sidx][2]}, ex = 0;
-          for (int i = 0; i < 3; i++) { double loc = kc.st_R[sidx][i] * d[0] + kc.st_R[sidx][3 + i] * d[1] + kc.st_R[sidx][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[sidx][i]; if (o > 0) ex += o * o; }
-          const double rc = kc.box_r[b] + kc.set[SKS_STATIC + sidx].margin;
-          if (ex <= rc * rc) {
-            kind = 1; ba = SKB_STATIC; bb = b; set = SKS_STATIC + sidx;
-            for (int k = 0; k < 9; k++) RA[k] = kc.st_R[sidx][k];
-            for (int k = 0; k < 3; k++) { pA[k] = kc.st_c[sidx][k]; hA[k] = kc.st_h[sidx][k]; }
-          }
-        }
-      } else if (grp < 6) {
-        if (round == 0) {
-          const int b1 = grp == 5 ? 1 : 0, b2 = grp == 3 ? 1 : 2;
-          box_shape(b1, RA, pA, hA); box_shape(b2, RB, pB, hB);
-          kind = 1; ba = b1; bb = b2; set = SKS_BOXBOX; rsum = kc.box_r[b1] + kc.box_r[b2];
-        }
-      } else if (grp < 12) {
-        const int b = (grp - 6) >> 1, f = (grp - 6) & 1;
-        if (round == 0) { box_shape(b, RA, pA, hA); tip_shape(f, RB, pB, hB); kind = 1; ba = b; bb = SKB_TIP + f; set = SKS_BOXTIP; rsum = kc.box_r[b] + kc.tip_r; }
-        else if (round == 1) { box_shape(b, RA, pA, hA); hull_shape(f, RB, pB, hB); hullB = 1; kind = 2; ba = b; bb = SKB_FINGER + f; set = SKS_BOXHULL; rsum = kc.box_r[b] + kc.hull_r; }
-      } else if (fingers) {
-        if (round == 0) { tip_shape(0, RA, pA, hA); tip_shape(1, RB, pB, hB); kind = 1; ba = SKB_TIP; bb = SKB_TIP + 1; set = SKS_TIPTIP; }
-        else if (round == 1) { hull_shape(0, RA, pA, hA); hull_shape(1, RB, pB, hB); hullA = hullB = 1; kind = 2; ba = SKB_FINGER; bb = SKB_FINGER + 1; set = SKS_HULLHULL; }
-        else if (round == 2) { hull_shape(0, RA, pA, hA); tip_shape(1, RB, pB, hB); hullA = 1; kind = 2; ba = SKB_FINGER; bb = SKB_TIP + 1; set = SKS_HULLTIP; }
-        else { tip_shape(0, RA, pA, hA); hull_shape(1, RB, pB, hB); hullB = 1; kind = 2; ba = SKB_TIP; bb = SKB_FINGER + 1; set = SKS_HULLTIP; }
-      }
-      if (kind != 0) {
-        margin = kc.set[set].margin;
-        if (rsum > 0) {      // bounding spheres about the geom centres (the hull's centre is its mesh centre)
-          double cA[3] = {pA[0], pA[1], pA[2]}, cB[3] = {pB[0], pB[1], pB[2]};
-          if (hullA) for (int k = 0; k < 3; k++) cA[k] += RA[3 * k] * kc.hull_center[0] + RA[3 * k + 1] * kc.hull_center[1] + RA[3 * k + 2] * kc.hull_center[2];
-          if (hullB) for (int k = 0; k < 3; k++) cB[k] += RB[3 * k] * kc.hull_center[0] + RB[3 * k + 1] * kc.hull_center[1] + RB[3 * k + 2] * kc.hull_center[2];
-          const double d[3] = {cB[0] - cA[0], cB[1] - cA[1], cB[2] - cA[2]}, rc = rsum + margin;
-          if (dot3(d, d) > rc * rc) kind = 0;
-        }
-      }
-    }
-    if (!__any(kind != 0)) continue;
-    SKP_TOC(13);
-    int m = 0;      // contacts of this lane in this round, staged as normal[3] | m x (dist, pos[3])
-    if (kind == 1) {
-      m = box_box_emit(pA, RA, hA, pB, RB, hB, margin, 8, [&](double dist, const double* pos, const double* nrm) {
-        stage[0] = nrm[0]; stage[1] = nrm[1]; stage[2] = nrm[2];
-        sk_lds_double* q = stage + 3 + 4 * m;
-        q[0] = dist; q[1] = pos[0]; q[2] = pos[1]; q[3] = pos[2];
-        m++;
-      });
-    }
+  const int n_rounds = kc.ns > 4 ? kc.ns : 4;
+  for (int round = 0; round < n_rounds; round++) {
+    int r = sk_round_boxbox(kc, smem, lane, round, live_mask);
     SKP_TOC(14);
-    // MPR jobs: up to eight at a time, each on a GROUP of eight lanes (job j of the batch on lanes 8 j .. 8 j + 7).  The owner lane's
-    // shapes are fetched by its group, the portal iteration runs redundantly on the eight lanes (uniform inside a group) and the hull
-    // support function is spread over them (sk_support1_group: nine vertices per lane instead of 68 on one lane).
-    for (unsigned long long pend = __ballot(kind == 2); pend != 0;) {
-      const int grp8 = lane >> 3, sub = lane & 7;
-      int owner = -1;      // owner lane of this group's job (-1: no job in this batch)
-      unsigned long long batch = 0, rest = pend;
-      for (int j = 0; j < WAVE / SKG && rest != 0; j++) { const int L = __builtin_ctzll(rest); rest &= rest - 1; batch |= 1ull << L; if (j == grp8) owner = L; }
-      pend = rest;
-      const int src = owner >= 0 ? owner : lane;
-      double uRA[9], upA[3], uhA[3], uRB[9], upB[3], uhB[3];
-#pragma unroll
-      for (int k = 0; k < 9; k++) { uRA[k] = __shfl(RA[k], src); uRB[k] = __shfl(RB[k], src); }
-#pragma unroll
-      for (int k = 0; k < 3; k++) { upA[k] = __shfl(pA[k], src); uhA[k] = __shfl(hA[k], src); upB[k] = __shfl(pB[k], src); uhB[k] = __shfl(hB[k], src); }
-      const double um = __shfl(margin, src);
-      const int uhullA = __shfl(hullA, src), uhullB = __shfl(hullB, src);
-      double r7[7] = {0, 0, 0, 0, 0, 0, 0};
-      int hit = 0;
-      if (owner >= 0) {
-        const SkShape A{uRA, upA, uhA, uhullA}, B{uRB, upB, uhB, uhullB};
-        hit = sk_mpr_t(kc, A, B, um, r7, [&](const double* dir, SkPt& pt) {
-          const double nd[3] = {-dir[0], -dir[1], -dir[2]};
-          sk_support1_group(kc, A, dir, um, pt.v1, sub); sk_support1_group(kc, B, nd, um, pt.v2, sub);
-#pragma unroll
-          for (int k = 0; k < 3; k++) pt.v[k] = pt.v1[k] - pt.v2[k];
-        }) ? 1 : 0;
-      }
-      // results back to the owner lanes: owner L reads lane 8 * (rank of L in the batch)
-      const bool mine = ((batch >> lane) & 1ull) != 0;
-      const int from = mine ? SKG * __popcll(batch & ((1ull << lane) - 1ull)) : lane;
-      const int ghit = __shfl(hit, from);
-      double g7[7];
-#pragma unroll
-      for (int k = 0; k < 7; k++) g7[k] = __shfl(r7[k], from);
-      if (mine && ghit) {
-        stage[0] = g7[4]; stage[1] = g7[5]; stage[2] = g7[6];
-        stage[3] = g7[0]; stage[4] = g7[1]; stage[5] = g7[2]; stage[6] = g7[3];
-        m = 1;
-      }
-    }
+    if (round >= 1) { const int r2 = sk_round_mpr(kc, smem, lane, round, live_mask); if ((r2 & 255) != 0) r = r2; }
     SKP_TOC(15);
+    const int m = r & 255;
     // counts through the staging slots, then every lane moves its contacts to their final records
     if (grp < SKP_GROUPS) stage[SKC_STAGE - 1] = (double)m;
     __syncthreads();
     int off = tot, all = 0;
     for (int g = 0; g < SKP_GROUPS; g++) { const int c = (int)smem[(g * SK_LANES + e) * SKC_STAGE + SKC_STAGE - 1]; if (g < grp) off += c; all += c; }
-    if (act) {
-      const double meta = (double)(ba | (bb << 4) | (set << 8));
+    if (act && m > 0) {
+      const double meta = (double)(r >> 8);
       const double n0 = stage[0], n1 = stage[1], n2 = stage[2];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int slot = off + i;
         if (i >= m || slot >= SK_MAXCON) continue;
         const sk_lds_double* q = stage + 3 + 4 * i;
-        sk_lds_double* r = t + SE_REC + slot * SREC2;
-        r[0] = q[1]; r[1] = q[2]; r[2] = q[3]; r[3] = n0; r[4] = n1; r[5] = n2; r[6] = q[0]; r[7] = meta;
+        sk_lds_double* rr = t + SE_REC + slot * SREC2;
+        rr[0] = q[1]; rr[1] = q[2]; rr[2] = q[3]; rr[3] = n0; rr[4] = n1; rr[5] = n2; rr[6] = q[0]; rr[7] = meta;
       }
     }
     tot += all;
     __syncthreads();
+    SKP_TOC(13);
   }
   if (lane < SK_LANES && act) { t[SE_NCON] = (double)(tot < SK_MAXCON ? tot : SK_MAXCON); t[SE_NEED] = tot > SK_MAXCON ? 256.0 : 0.0; }
   __syncthreads();
@@ -1533,7 +1639,7 @@ __device__ __attribute__((noinline)) void sk_collide_coop(const StackConsts& kc_
 
 // mj_Euler: implicit in the finger-joint damping, (M + h B) qacc = M x on the arm block; the arm mass matrix is still in the t area
 template <bool WARM_LDS, class C>
-D3IL_NOINLINE inline void stack_substep_post(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc) {
+D3IL_HD void stack_substep_post(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc) {
   D3IL_REFRESH(c0, c);
   EnvState& st = ss.arm;
   const double h = c.timestep;
