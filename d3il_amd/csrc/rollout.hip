@@ -454,6 +454,7 @@ struct d3il_handle_s {
   hipEvent_t ev0, ev1;
   bool ev_valid, ev_created;
   int tol_mode;            // 0 production stopping rule of the contact solvers, 1 the oracle's (solver_strict)
+  int stack_reset_coop;    // Stacking: 1 (default) env.reset() runs through the step kernel's cooperative phases, 0 the one-lane reset kernel
   double* d_ctx;           // [n][ctx_dim] context of the last reset of every environment (Pushing 14, Sorting 7 nb)
   int ctx_dim;
   uint8_t* d_mask;         // [stride] environments reset by the last d3il_auto_reset (buf.last_reset)
@@ -514,7 +515,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   std::memset(&h->buf, 0, sizeof h->buf);
   h->task_id = -1; h->device = device_id;      // task_id is set once the model reference is taken (free_handle)
   h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr; h->d_ctx = nullptr; h->d_mask = nullptr; h->ev_created = false;
-  h->tally_ctx = nullptr; h->tally_nctx = 0; h->tally_table = nullptr; h->tol_mode = 0; h->ctx_dim = 0;
+  h->tally_ctx = nullptr; h->tally_nctx = 0; h->tally_table = nullptr; h->tol_mode = 0; h->ctx_dim = 0; h->stack_reset_coop = 1;
   const char* err = "";
   int rc = build_panda_consts(m, h->hc, &err);
   if (rc) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
@@ -714,8 +715,12 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   }
   if (h->task_id == D3IL_TASK_STACKING) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Stacking task needs contexts (device f64 [n_envs][21])");
-    hipLaunchKernelGGL(k_stacking_reset, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS_RESET, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
-                       b.flags, b.step_count, b.obs, b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride);
+    if (h->stack_reset_coop)      // the step kernel in reset mode: cooperative phases, workgroups without a masked environment leave at once
+      hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, (hipStream_t)stream, b.state, b.flags, b.step_count, (const double*)nullptr, b.obs,
+                         b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, 1, h->hc.max_steps, 1, env_mask, h->d_init_qpos, contexts);
+    else
+      hipLaunchKernelGGL(k_stacking_reset, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS_RESET, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
+                         b.flags, b.step_count, b.obs, b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride);
     HIPCHK(hipGetLastError());
     return D3IL_OK;
   }
@@ -762,7 +767,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   if (h->task_id == D3IL_TASK_STACKING) {
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
-                       b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+                       b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, 0, (const unsigned char*)nullptr, (const double*)nullptr, (const double*)nullptr);
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
     return D3IL_OK;
@@ -1038,6 +1043,7 @@ int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "solver_strict") == 0) { h->tol_mode = value != 0; return D3IL_OK; }
+  if (std::strcmp(name, "stack_reset_coop") == 0) { h->stack_reset_coop = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "split_waves") == 0) { h->split = value; return D3IL_OK; }
   if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }
   if (std::strcmp(name, "lanes_per_wave") == 0) { if (value < 1 || value > WAVE) return fail(D3IL_EINVAL, "lanes_per_wave must be in 1..64"); h->lanes = value; return D3IL_OK; }
