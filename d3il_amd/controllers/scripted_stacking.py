@@ -74,3 +74,23 @@ def build_trajectory(js: dict, init_qpos, ctx21, order=(0, 1, 2), speed: float =
         seg([TARGET[0], TARGET[1], z_place], 0.0, 1.0, 6)      # open
         seg([TARGET[0], TARGET[1], z_place + 0.10], 0.0, 1.0, 12)
     return np.array(acts)
+
+
+def build_palm_press(js: dict, init_qpos, ctx21, box: int = 0, z_low: float = -0.004) -> np.ndarray:
+    """Per-step actions f64 [T, 8] that press the PALM of the open gripper onto box ``box``: the fingers straddle the box and the TCP is sent
+    to ``z_low`` (the palm, 3.9 cm above the TCP, meets the 6 cm box top at TCP z = 0.002), hold, retreat.  Exercises the box <-> hand-hull
+    pair (panda_invisible.xml:72, mesh handv) that no pick-and-place reaches."""
+    chain = UrdfChain(js["urdf_chain"])
+    c = js["controller"]
+    qmin, qmax = np.array(c["joint_pos_min"]), np.array(c["joint_pos_max"])
+    ctx = np.asarray(ctx21, dtype=np.float64).reshape(3, 7)
+    x, y = ctx[box, 0], ctx[box, 1]
+    phi = grasp_yaw(box, ctx[box, 3:7])
+    q = np.asarray(init_qpos, dtype=np.float64).copy()
+    acts = []
+    for pos, n in (([x, y, 0.16], 30), ([x, y, 0.06], 20), ([x, y, z_low], 30), ([x, y, z_low], 15), ([x, y, 0.12], 20)):
+        qt = offline_ik(chain, q, list(pos) + list(_grip_quat(phi)), qmin, qmax, eps=1e-8, it_max=600)[0]
+        for k in range(n):
+            acts.append(np.concatenate([q + (qt - q) * min(1.0, (k + 1) / (0.7 * n)), [1.0]]))
+        q = qt
+    return np.array(acts)

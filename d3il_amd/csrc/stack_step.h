@@ -26,15 +26,16 @@
 namespace d3il {
 
 constexpr int SK_NB = 3, SK_NV = 6 * SK_NB + NDOF, SK_ARM0 = 6 * SK_NB, SK_NH = SK_NV * (SK_NV + 1) / 2;   // 27 dofs, 378 packed
-constexpr int SK_MAXCON = 32, SK_MAXNS = 4, SK_MAXHV = 96;
+constexpr int SK_MAXCON = 32, SK_MAXNS = 4, SK_MAXHV = 96, SK_MAXHANDV = 800;
 #ifndef D3IL_SK_LANES
 #define D3IL_SK_LANES 4
 #endif
 constexpr int SK_LANES = D3IL_SK_LANES;   // environments per workgroup (one per lane; LDS: 5.6 KiB per environment)
 // contact parameter sets
-enum { SKS_STATIC = 0 /* + static index */, SKS_BOXBOX = SK_MAXNS, SKS_BOXHULL, SKS_BOXTIP, SKS_HULLHULL, SKS_HULLTIP, SKS_TIPTIP, SKS_N };
+enum { SKS_STATIC = 0 /* + static index */, SKS_BOXBOX = SK_MAXNS, SKS_BOXHULL, SKS_BOXTIP, SKS_HULLHULL, SKS_HULLTIP, SKS_TIPTIP, SKS_BOXHAND, SKS_N };
 // bodies of a contact: boxes 0..2, then
-enum { SKB_STATIC = 3, SKB_FINGER = 4 /* + finger: the finger body (hull geom) */, SKB_TIP = 6 /* + finger: the tip body (tip box) */ };
+enum { SKB_STATIC = 3, SKB_FINGER = 4 /* + finger: the finger body (hull geom) */, SKB_TIP = 6 /* + finger: the tip body (tip box) */, SKB_HAND = 8 /* the hand body (mesh handv): arm dofs only */ };
+D3IL_HD int sk_finger_of(int body) { return body >= SKB_HAND ? -1 : (body - SKB_FINGER) & 1; }      // finger whose slide joint moves the body (-1: none)
 
 struct StackSet { double K, B, solimp[5], fric[3], margin; int dim, pad; };
 struct StackConsts {
@@ -50,7 +51,11 @@ struct StackConsts {
   double impratio;
   double target[3], min_dist, grip_thresh;       // stacking_objects.py:17, stacking.py:193, :337
   double ws_lo[2], ws_hi[2];                     // modelled workspace of the box centres (x, y): the table top without its rim
-  double hand_R[9], hand_p[3], hand_lo[3], hand_hi[3];   // bounding box of the hand mesh in the hand frame (pair not evaluated: flagged)
+  double hand_R[9], hand_p[3], hand_lo[3], hand_hi[3];   // hand geom (panda_invisible.xml:72, mesh handv) in the link-7 frame; bounding box of its hull in the geom frame: the exact cull of the box <-> hand pairs
+  double f_axis0[3];                                     // slide axis of the left finger joint in the link-7 frame
+  double hand_center[3], hand_r, invw_hand;              // centroid of the hull (seeds the MPR portal), bounding radius about it, translational body_invweight0 of the hand body
+  int hand_nv, hand_pad;
+  double hand_v[SK_MAXHANDV][3];                         // convex hull of handv.stl (773 vertices), geom frame
 };
 
 // flag bits of the Stacking task (EnvState::flags).  F_TERMINATED / F_SUCCESS / F_SOLVER_FAIL keep their positions.
@@ -118,7 +123,7 @@ constexpr int SG_SIZE = SG_DIAG + 24;      // [4 .. 11]: clock ticks per phase, 
 // Same algorithm as the oracle's mpr_penetration (libccd's ccdMPRPenetration as MuJoCo 2.3.2 runs it for mesh geoms [ext]); the
 // tie rule of the support functions (lowest index within 1e-10, box components >= -1e-10 positive) makes the portal independent
 // of round-off in flat-on-flat configurations.  Written with exact divisions / square roots: the portal logic branches on signs.
-struct SkShape { const double* R; const double* p; const double* half; int hull; };   // hull != 0: the finger hull, else a box
+struct SkShape { const double* R; const double* p; const double* half; int hull; };   // hull: 0 a box, 1 the finger hull, 2 the hand hull
 struct SkPt { double v[3], v1[3], v2[3]; };
 D3IL_HD void sk_support1(const StackConsts& kc_, const SkShape& s, const double* dir, double margin, double* out) {
   D3IL_STACK_CONSTS(kc_, kc);
@@ -128,9 +133,10 @@ D3IL_HD void sk_support1(const StackConsts& kc_, const SkShape& s, const double*
   if (s.hull) {
     // lowest-index vertex within 1e-10 of the maximum: pass 1 finds the maximum and the first vertex attaining it, pass 2 looks for an
     // earlier vertex inside the tolerance.  Four vertices per iteration: the (wave-uniform) vertex table comes through the scalar
-    // cache, one wait per four vertices instead of one per vertex.
-    const int nv = kc.hull_nv;
-    auto dotv = [&](int i) { return kc.hull_v[i][0] * dl[0] + kc.hull_v[i][1] * dl[1] + kc.hull_v[i][2] * dl[2]; };
+    // cache, one wait per four vertices instead of one per vertex.  hull: 1 the finger hull, 2 the hand hull.
+    const int nv = s.hull == 2 ? kc.hand_nv : kc.hull_nv;
+    const double (*tab)[3] = s.hull == 2 ? kc.hand_v : kc.hull_v;
+    auto dotv = [&](int i) { return tab[i][0] * dl[0] + tab[i][1] * dl[1] + tab[i][2] * dl[2]; };
     double bd = -1e300;
     int imax = 0, i = 0;
     for (; i + 4 <= nv; i += 4) {
@@ -149,7 +155,7 @@ D3IL_HD void sk_support1(const StackConsts& kc_, const SkShape& s, const double*
       if (hit >= 0) { best = hit; break; }
     }
     if (best == imax) for (; i < imax; i++) if (dotv(i) >= thr) { best = i; break; }
-    loc[0] = kc.hull_v[best][0]; loc[1] = kc.hull_v[best][1]; loc[2] = kc.hull_v[best][2];
+    loc[0] = tab[best][0]; loc[1] = tab[best][1]; loc[2] = tab[best][2];
   } else {
 #pragma unroll
     for (int k = 0; k < 3; k++) loc[k] = dl[k] >= -1e-10 ? s.half[k] : -s.half[k];
@@ -213,16 +219,18 @@ D3IL_HD void sk_tri_closest_origin(const double* a, const double* b, const doubl
 #endif
 // SUP(dir, pt): support point of the Minkowski difference a - b in direction dir (sk_support on one lane; the device collision phase
 // spreads the hull vertices of a pair over a group of eight lanes)
-template <class SH, class SUP>
-D3IL_HD bool sk_mpr_t(const StackConsts& kc_, const SH a, const SH b, double margin, double* out, SUP sup) {
+template <class SHA, class SHB, class SUP>
+D3IL_HD bool sk_mpr_t(const StackConsts& kc_, const SHA a, const SHB b, double margin, double* out, SUP sup) {
   D3IL_STACK_CONSTS(kc_, kc);
   SK_MPR_COUNT(g_calls++);
   SkPt P[4], v4;
   double dir[3], va[3], vb[3];
   {   // geom centres (written out per shape: a pointer selected at run time into P[] would pin the whole portal in private memory)
-    if (a.hull) { for (int k = 0; k < 3; k++) P[0].v1[k] = a.R[3 * k] * kc.hull_center[0] + a.R[3 * k + 1] * kc.hull_center[1] + a.R[3 * k + 2] * kc.hull_center[2] + a.p[k]; }
+    const double* ca = a.hull == 2 ? kc.hand_center : kc.hull_center;
+    const double* cb = b.hull == 2 ? kc.hand_center : kc.hull_center;
+    if (a.hull) { for (int k = 0; k < 3; k++) P[0].v1[k] = a.R[3 * k] * ca[0] + a.R[3 * k + 1] * ca[1] + a.R[3 * k + 2] * ca[2] + a.p[k]; }
     else { P[0].v1[0] = a.p[0]; P[0].v1[1] = a.p[1]; P[0].v1[2] = a.p[2]; }
-    if (b.hull) { for (int k = 0; k < 3; k++) P[0].v2[k] = b.R[3 * k] * kc.hull_center[0] + b.R[3 * k + 1] * kc.hull_center[1] + b.R[3 * k + 2] * kc.hull_center[2] + b.p[k]; }
+    if (b.hull) { for (int k = 0; k < 3; k++) P[0].v2[k] = b.R[3 * k] * cb[0] + b.R[3 * k + 1] * cb[1] + b.R[3 * k + 2] * cb[2] + b.p[k]; }
     else { P[0].v2[0] = b.p[0]; P[0].v2[1] = b.p[1]; P[0].v2[2] = b.p[2]; }
   }
   for (int k = 0; k < 3; k++) P[0].v[k] = P[0].v1[k] - P[0].v2[k];
@@ -400,8 +408,8 @@ D3IL_HD void sk_build_rows_rec(const StackConsts& kc_, const StackScratch sc, co
   if constexpr (NB == 6) { R.ob = 6 * b; sk_box_rows(sc, b, rec, rec + 3, R.dim, R.B); }
   else {
     R.ob = SK_ARM0;
-    sk_arm_rows(sc, (b - SKB_FINGER) & 1, 1.0, rec, rec + 3, R.B, false);
-    if constexpr (NA == 0) sk_arm_rows(sc, (a - SKB_FINGER) & 1, -1.0, rec, rec + 3, R.B, true);     // finger <-> finger
+    sk_arm_rows(sc, sk_finger_of(b), 1.0, rec, rec + 3, R.B, false);
+    if constexpr (NA == 0) sk_arm_rows(sc, sk_finger_of(a), -1.0, rec, rec + 3, R.B, true);     // finger <-> finger
   }
 }
 template <int NA, int NB>
@@ -511,7 +519,7 @@ D3IL_NOINLINE inline void sk_contact_dot(const StackConsts& kc_, const StackScra
   const double dist = SG(base + 12);
   const double imp = impedance(ps.solimp, dist - ps.margin);
   const int a = (int)SG(base + 13), b = (int)SG(base + 14);
-  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])); };
+  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1]))); };
   const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
   const double R1 = R0 / fmax(1e-15, kc.impratio);
   for (int r = 0; r < 4; r++) {
@@ -790,7 +798,7 @@ constexpr int SE_END = SE_REC + SK_MAXCON * SREC2;
 constexpr int SE_SIZE = ((SE_END - ST_HEAD) | 1);  // doubles per environment (odd: the environments start on different banks)
 constexpr int SKC_SHARED = 2 * ST_HEAD + SKC_JSIZE;
 constexpr int SKC_STAGE = 36;                   // staging doubles per lane in the shared area: normal[3] + 8 x (dist, pos[3]) + count
-static_assert(SKC_STAGE * 13 * SK_LANES <= SKC_SHARED, "contact staging must fit the shared area");
+static_assert(SKC_STAGE * 16 * SK_LANES <= SKC_SHARED, "contact staging must fit the shared area");
 static_assert(SK_LANES % 2 == 0, "the solver takes the environments of a workgroup in pairs");
 __device__ __forceinline__ sk_lds_double* sk_env_view(sk_lds_double* smem, int e) { return smem + SKC_SHARED + e * SE_SIZE - ST_HEAD; }
 // Contact rows in the J area: contact c owns 4 x ncol doubles at jbase (ncol = columns of body 1, 0 or 6, + columns of body 2, 6 or 9), so
@@ -832,7 +840,7 @@ __device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, 
   const double dist = rec[12];
   const double imp = impedance(ps.solimp, dist - ps.margin);
   const int a = (int)rec[13], b = (int)rec[14];
-  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])); };
+  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1]))); };
   const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
   const double R1 = R0 / fmax(1e-15, kc.impratio);
 #pragma unroll
@@ -1244,26 +1252,36 @@ D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, 
     for (int k = 0; k < 6; k++) SL(ST_VEL + 6 * b + k) = ss.box[b].vel[k];
     if (ss.box[b].pos[0] < kc.ws_lo[0] || ss.box[b].pos[0] > kc.ws_hi[0] || ss.box[b].pos[1] < kc.ws_lo[1] || ss.box[b].pos[1] > kc.ws_hi[1]) st.flags |= SKF_OFF_TABLE;
   }
-  for (int b = 0; b < SK_NB; b++) {
-    double R[9];
-    for (int k = 0; k < 9; k++) R[k] = SL(ST_BR + 9 * b + k);
-    {   // hand mesh: not evaluated; flag a box that reaches its bounding box
-      double Rh[9], ph[3], pm[3];
-      for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) Rh[3 * r + cc] = dyn.R7[3 * r] * kc.hand_R[cc] + dyn.R7[3 * r + 1] * kc.hand_R[3 + cc] + dyn.R7[3 * r + 2] * kc.hand_R[6 + cc];
-      mulE(dyn.R7, kc.hand_p, pm);
-      for (int k = 0; k < 3; k++) ph[k] = dyn.p7[k] + pm[k];
-      double dw[3] = {ss.box[b].pos[0] - ph[0], ss.box[b].pos[1] - ph[1], ss.box[b].pos[2] - ph[2]};
-      bool inside = true;
-      for (int i = 0; i < 3; i++) {
-        double ci = Rh[i] * dw[0] + Rh[3 + i] * dw[1] + Rh[6 + i] * dw[2], ei = 0;
-        for (int j = 0; j < 3; j++) ei += fabs(Rh[i] * R[j] + Rh[3 + i] * R[3 + j] + Rh[6 + i] * R[6 + j]) * kc.box_half[b][j];
-        if (ci - ei > kc.hand_hi[i] || ci + ei < kc.hand_lo[i]) inside = false;
-      }
-      if (inside) st.flags |= SKF_HAND_NEAR;
-    }
-  }
   SL(ST_AUX) = st.q[NARM] + st.q[NARM + 1];
   SK_TOC(0);
+}
+// World pose of the hand geom in this sub-step, from the tables the kinematics phase wrote: link 7's frame is recovered from the left
+// finger tip's (tip = R7 tip_R[0], R7 (tip_p[0] + f_axis[0] qf) + p7), then the hand geom's constant pose in the link-7 frame is applied.
+// TS: reads the t area (LDS view or plain memory)
+template <class TS>
+D3IL_HD void sk_hand_pose(const StackConsts& kc_, const TS t, const double qf /* position of the left finger joint */, double* Rh, double* ph) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  double TR[9], R7[9], pl[3], pw[3];
+  for (int k = 0; k < 9; k++) TR[k] = t[ST_TIPR + k];
+  for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) R7[3 * r + cc] = TR[3 * r] * kc.tip_R[0][3 * cc] + TR[3 * r + 1] * kc.tip_R[0][3 * cc + 1] + TR[3 * r + 2] * kc.tip_R[0][3 * cc + 2];
+  for (int k = 0; k < 3; k++) pl[k] = kc.tip_p[0][k] + kc.f_axis0[k] * qf;
+  mulE(R7, pl, pw);
+  double p7[3] = {t[ST_TIPP] - pw[0], t[ST_TIPP + 1] - pw[1], t[ST_TIPP + 2] - pw[2]};
+  for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) Rh[3 * r + cc] = R7[3 * r] * kc.hand_R[cc] + R7[3 * r + 1] * kc.hand_R[3 + cc] + R7[3 * r + 2] * kc.hand_R[6 + cc];
+  mulE(R7, kc.hand_p, pw);
+  for (int k = 0; k < 3; k++) ph[k] = p7[k] + pw[k];
+}
+// exact cull of a box <-> hand pair: the box against the bounding box of the hand hull (in the hand geom frame) grown by the margin
+D3IL_HD bool sk_hand_near(const StackConsts& kc_, const double* Rh, const double* ph, const double* Rb, const double* pb, const double* hb, double margin) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const double dw[3] = {pb[0] - ph[0], pb[1] - ph[1], pb[2] - ph[2]};
+  for (int i = 0; i < 3; i++) {
+    const double ci = Rh[i] * dw[0] + Rh[3 + i] * dw[1] + Rh[6 + i] * dw[2];
+    double ei = 0;
+    for (int j = 0; j < 3; j++) ei += fabs(Rh[i] * Rb[j] + Rh[3 + i] * Rb[3 + j] + Rh[6 + i] * Rb[6 + j]) * hb[j];
+    if (ci - ei > kc.hand_hi[i] + margin || ci + ei < kc.hand_lo[i] - margin) return false;
+  }
+  return true;
 }
 // collision on one lane, in the model's geom order: static < boxes < left hull < left tip < right hull < right tip
 D3IL_NOINLINE inline int stack_pre_collide(const StackConsts& kc_, StackState& ss, const StackScratch sc) {
@@ -1300,6 +1318,17 @@ D3IL_NOINLINE inline int stack_pre_collide(const StackConsts& kc_, StackState& s
     for (int k = 0; k < 9; k++) { fR[f][0][k] = SL(ST_HULR + 9 * f + k); fR[f][1][k] = SL(ST_TIPR + 9 * f + k); }
     for (int k = 0; k < 3; k++) { fP[f][0][k] = SL(ST_HULP + 3 * f + k); fP[f][1][k] = SL(ST_TIPP + 3 * f + k); }
     for (int k = 0; k < 3; k++) hullC[f][k] = fR[f][0][3 * k] * kc.hull_center[0] + fR[f][0][3 * k + 1] * kc.hull_center[1] + fR[f][0][3 * k + 2] * kc.hull_center[2] + fP[f][0][k];
+  }
+  {   // box <-> hand hull (panda_hand:geom2): exact bounding-box cull, then MPR on the 773-vertex hull
+    double Rh[9], ph[3];
+    sk_hand_pose(kc, sc.t, st.q[NARM], Rh, ph);
+    for (int b = 0; b < SK_NB; b++) {
+      double R[9]; boxR(b, R);
+      if (!sk_hand_near(kc, Rh, ph, R, ss.box[b].pos, kc.box_half[b], kc.set[SKS_BOXHAND].margin)) continue;
+      SkShape A{R, ss.box[b].pos, kc.box_half[b], 0}, B{Rh, ph, nullptr, 2};
+      double r7[7];
+      if (sk_mpr(kc, A, B, kc.set[SKS_BOXHAND].margin, r7)) sk_add_contact(kc, sc, ncon, st.flags, r7, 1.0, b, SKB_HAND, SKS_BOXHAND);
+    }
   }
   for (int b = 0; b < SK_NB; b++) {
     double R[9]; boxR(b, R);
@@ -1446,11 +1475,12 @@ __device__ __forceinline__ void sk_support1_group_l(const StackConsts& kc_, cons
 // Collision of the workgroup's environments with one lane per (environment, pair group), lane = group * SK_LANES + environment:
 //   group 0 .. 2  : box b against the static boxes          3 .. 5 : the box pairs (0, 1) (0, 2) (1, 2)
 //   group 6 .. 11 : box b against finger f: tip, hull (MPR)    12  : finger <-> finger (nearly closed gripper)
+//   group 13 .. 15: box b against the hand hull (773 vertices: MPR by the WHOLE wave, one job at a time, after an exact bounding-box cull)
 // Jobs: every lane has at most one pair test per round and all lanes run the test of a round at ONE call site per kind (box-box, MPR),
 // so that lanes of different groups do not serialise through separately inlined copies of the same routine.
 //   round   group 0..2 (box b)   3..5 (box pair)   6..11 (box b, finger f)   12 (fingers)
 //     0     static 0  [BB]        b1-b2 [BB]         box - tip   [BB]          tip - tip   [BB]
-//     1     static 1  [BB]                           box - hull  [MPR]         hull - hull [MPR]
+//     1     static 1  [BB]                           box - hull  [MPR]         hull - hull [MPR]       (groups 13 .. 15: box - hand [wave MPR])
 //     2     static 2  [BB]                                                     hull0 - tip1 [MPR]
 //     3     static 3  [BB]                                                     tip0 - hull1 [MPR]
 // Everything stays in registers and LDS: a pair test emits its contacts into the lane's staging slot of the workgroup's shared area
@@ -1460,9 +1490,9 @@ __device__ __forceinline__ void sk_support1_group_l(const StackConsts& kc_, cons
 // (lane, round) and fetch the shapes from the LDS tables, so that neither carries the other's registers (the combined function spilled
 // ~130 doubles per lane and round to scratch: most of the kernel's HBM traffic).
 // Results per environment: t[SE_NCON] = contacts kept (<= SK_MAXCON), t[SE_NEED] = 256 when contacts were dropped.
-constexpr int SKP_GROUPS = 13;
-static_assert(SKP_GROUPS * SK_LANES <= WAVE, "the lane-per-pair collision needs 13 lanes per environment");
-struct SkJob { int kind, ba, bb, set, hullA, hullB; double margin; };      // kind: 0 none, 1 box-box, 2 MPR
+constexpr int SKP_GROUPS = 16;
+static_assert(SKP_GROUPS * SK_LANES <= WAVE, "the lane-per-pair collision needs 16 lanes per environment");
+struct SkJob { int kind, ba, bb, set, hullA, hullB; double margin; };      // kind: 0 none, 1 box-box, 2 MPR (eight-lane group), 3 MPR against the hand hull (whole wave)
 // the job of lane L in a round (L may be another lane: the MPR groups rebuild their owner's job); shapes from the tables of L's environment
 __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* smem, const int L, const int round, const unsigned live_mask,
                                         double* RA, double* pA, double* hA, double* RB, double* pB, double* hB) {
@@ -1500,6 +1530,14 @@ __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* s
     const int b = (grp - 6) >> 1, f = (grp - 6) & 1;
     if (round == 0) { box_shape(b, RA, pA, hA); tip_shape(f, RB, pB, hB); j.kind = 1; j.ba = b; j.bb = SKB_TIP + f; j.set = SKS_BOXTIP; rsum = kc.box_r[b] + kc.tip_r; }
     else if (round == 1) { box_shape(b, RA, pA, hA); hull_shape(f, RB, pB, hB); j.hullB = 1; j.kind = 2; j.ba = b; j.bb = SKB_FINGER + f; j.set = SKS_BOXHULL; rsum = kc.box_r[b] + kc.hull_r; }
+  } else if (grp >= 13) {     // box <-> hand: cull with the hull's bounding box; the shapes are rebuilt by the wave-wide MPR stage
+    if (round == 1) {
+      const int b = grp - 13;
+      double Rh[9], ph[3];
+      box_shape(b, RA, pA, hA);
+      sk_hand_pose(kc, t, t[SE_Q + NARM], Rh, ph);
+      if (sk_hand_near(kc, Rh, ph, RA, pA, hA, kc.set[SKS_BOXHAND].margin)) { j.kind = 3; j.ba = b; j.bb = SKB_HAND; j.set = SKS_BOXHAND; }
+    }
   } else if (t[ST_AUX] < 0.004) {     // finger <-> finger: only a (nearly) closed gripper (the gaps are q1 + q2 - 1 mm or less)
     if (round == 0) { tip_shape(0, RA, pA, hA); tip_shape(1, RB, pB, hB); j.kind = 1; j.ba = SKB_TIP; j.bb = SKB_TIP + 1; j.set = SKS_TIPTIP; }
     else if (round == 1) { hull_shape(0, RA, pA, hA); hull_shape(1, RB, pB, hB); j.hullA = j.hullB = 1; j.kind = 2; j.ba = SKB_FINGER; j.bb = SKB_FINGER + 1; j.set = SKS_HULLHULL; }
@@ -1533,6 +1571,31 @@ __device__ __forceinline__ int sk_round_boxbox(const StackConsts& kc_, sk_lds_do
   });
   return m | ((j.ba | (j.bb << 4) | (j.set << 8)) << 8);
 }
+// support point of the hand hull by the whole wave: lane l evaluates the vertices l, l + 64, ...; maximum and lowest index within 1e-10 of it by
+// wave reductions (the vertex sk_support1 finds with its two passes).  R, p: pose of the hand geom (the same values in all lanes).
+constexpr int SKH_NV = (SK_MAXHANDV + WAVE - 1) / WAVE;
+__device__ __forceinline__ void sk_support_hand_wave(const StackConsts& kc_, const double* R, const double* p, const double* dir, double margin, double* out, const int lane) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const double dl[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2], R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
+  const int nv = kc.hand_nv;
+  double d[SKH_NV], bd = -1e300;
+#pragma unroll
+  for (int m = 0; m < SKH_NV; m++) {
+    const int v = lane + WAVE * m;
+    d[m] = v < nv ? kc.hand_v[v][0] * dl[0] + kc.hand_v[v][1] * dl[1] + kc.hand_v[v][2] * dl[2] : -1e300;
+    bd = fmax(bd, d[m]);
+  }
+  bd = sk_wave_max(bd);
+  const double thr = bd - 1e-10;
+  int best = 1 << 20;
+#pragma unroll
+  for (int m = SKH_NV - 1; m >= 0; m--) if (d[m] >= thr) best = lane + WAVE * m;
+  best = (int)(-sk_wave_max(-(double)best));      // lowest index (exact in a double)
+  const double loc[3] = {kc.hand_v[best][0], kc.hand_v[best][1], kc.hand_v[best][2]};
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[k] = R[3 * k] * loc[0] + R[3 * k + 1] * loc[1] + R[3 * k + 2] * loc[2] + p[k] + 0.5 * margin * dir[k];
+}
+struct SkShapeR { double R[9], p[3]; int hull; };      // a shape with its pose in registers (the hand geom)
 // MPR jobs of a round: up to eight at a time, each on a GROUP of eight lanes (job k of the batch on lanes 8 k .. 8 k + 7).  The group
 // rebuilds its owner lane's job (shapes from the LDS tables), the portal iteration runs redundantly on the eight lanes (uniform inside a
 // group) and the hull support function is spread over them (sk_support1_group: nine vertices per lane instead of 68 on one lane).
@@ -1585,6 +1648,31 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
       sk_lds_double* stage = smem + lane * SKC_STAGE;
       stage[0] = g7[4]; stage[1] = g7[5]; stage[2] = g7[6];
       stage[3] = g7[0]; stage[4] = g7[1]; stage[5] = g7[2]; stage[6] = g7[3];
+      m = 1;
+    }
+  }
+  // box <-> hand jobs (rare: only inside the hull's bounding box): one at a time by the whole wave, the 773 hull vertices spread over the lanes
+  for (unsigned long long pendh = __ballot(mine_kind == 3); pendh != 0; pendh &= pendh - 1) {
+    const int owner = __builtin_ctzll(pendh);
+    const int oe = owner % SK_LANES, bx = owner / SK_LANES - 13;
+    const sk_lds_double* to = sk_env_view(smem, oe);
+    SkShapeL A;
+    A.R = to + ST_BR + 9 * bx; A.p = to + ST_BP + 3 * bx; for (int k = 0; k < 3; k++) A.half[k] = kc.box_half[bx][k]; A.hull = 0;
+    SkShapeR B;
+    sk_hand_pose(kc, to, to[SE_Q + NARM], B.R, B.p); B.hull = 2;
+    const double um = kc.set[SKS_BOXHAND].margin;
+    double r7[7] = {0, 0, 0, 0, 0, 0, 0};
+    const bool hit = sk_mpr_t(kc, A, B, um, r7, [&](const double* dir, SkPt& pt) {
+      const double nd[3] = {-dir[0], -dir[1], -dir[2]};
+      sk_support1_group_l(kc, A, dir, um, pt.v1, lane & 7);      // a box: no vertex table, every lane evaluates it
+      sk_support_hand_wave(kc, B.R, B.p, nd, um, pt.v2, lane);
+#pragma unroll
+      for (int k = 0; k < 3; k++) pt.v[k] = pt.v1[k] - pt.v2[k];
+    });
+    if (lane == owner && hit) {
+      sk_lds_double* stage = smem + lane * SKC_STAGE;
+      stage[0] = r7[4]; stage[1] = r7[5]; stage[2] = r7[6];
+      stage[3] = r7[0]; stage[4] = r7[1]; stage[5] = r7[2]; stage[6] = r7[3];
       m = 1;
     }
   }
@@ -1921,11 +2009,50 @@ D3IL_HOSTFN inline int build_stack_consts(const d3il_model_blob& m, const PandaC
   kc.impratio = m.impratio;
   for (int k = 0; k < 3; k++) kc.target[k] = m.task_f[k];
   kc.min_dist = m.task_f[3]; kc.grip_thresh = m.task_f[4];
-  {   // hand mesh: frame in the link-7 frame, bounding box from the blob's task constants (task_f[5..10])
+  {   // hand geom (panda_hand:geom2, mesh handv): frame in the link-7 frame, hull, bounding box of the hull (task_f[5..10]), contact parameters, invweight
     int hand = m.body_parent[m.jnt_body[m.act_jnt[NARM]]];
-    Xf xh = rel(link7, hand);
+    int gh = -1;
+    for (int g = 0; g < m.ngeom; g++) if (m.geom_body[g] == hand && m.geom_type[g] == D3IL_GEOM_MESH && m.geom_contype[g] && m.geom_mesh[g] >= 0) gh = g;
+    if (gh < 0) { *err = "stacking needs the hand hull (blob meshes: handv)"; return -1; }
+    Xf gl; quat2mat(m.geom_quat[gh], gl.R); std::memcpy(gl.p, m.geom_pos[gh], sizeof gl.p);
+    Xf xh = compose(rel(link7, hand), gl);
     std::memcpy(kc.hand_R, xh.R, sizeof xh.R); std::memcpy(kc.hand_p, xh.p, sizeof xh.p);
-    for (int k = 0; k < 3; k++) { kc.hand_lo[k] = m.task_f[5 + k]; kc.hand_hi[k] = m.task_f[8 + k]; }
+    for (int k = 0; k < 3; k++) { kc.hand_lo[k] = m.task_f[5 + k]; kc.hand_hi[k] = m.task_f[8 + k]; kc.f_axis0[k] = pcst.f_axis[0][k]; }
+    const int hm = m.geom_mesh[gh];
+    if (m.mesh_nvert[hm] > SK_MAXHANDV) { *err = "hand hull too large"; return -1; }
+    kc.hand_nv = m.mesh_nvert[hm];
+    double r2 = 0;
+    for (int i = 0; i < kc.hand_nv; i++) {
+      double d[3];
+      for (int k = 0; k < 3; k++) { kc.hand_v[i][k] = m.mesh_vert[hm][i][k]; d[k] = kc.hand_v[i][k] - m.mesh_center[hm][k]; }
+      r2 = std::fmax(r2, dot3(d, d));
+      for (int k = 0; k < 3; k++) if (kc.hand_v[i][k] < kc.hand_lo[k] - 1e-9 || kc.hand_v[i][k] > kc.hand_hi[k] + 1e-9) { *err = "hand hull outside its bounding box"; return -1; }
+    }
+    for (int k = 0; k < 3; k++) kc.hand_center[k] = m.mesh_center[hm][k];
+    kc.hand_r = std::sqrt(r2);
+    if (!(gb[SK_NB - 1] < gh && gh < ghull[0])) { *err = "unexpected hand geom order"; return -1; }
+    if (mix(gb[0], gh, kc.set[SKS_BOXHAND])) { *err = "unsupported contact dimension"; return -1; }
+    {   // translational body_invweight0 of the hand body at qpos0 (as for the finger bodies above; arm dofs only)
+      double q[NDOF] = {0}, v[NDOF] = {0};
+      DynOut dyn;
+      dynamics(pcst, q, v, dyn);
+      double L[45], d[NDOF], id[NDOF], Minv[NDOF][NDOF];
+      ldl9(dyn.M, L, d, id);
+      for (int col = 0; col < NDOF; col++) { double e[NDOF] = {0}; e[col] = 1; ldl9_solve(L, id, e); for (int r = 0; r < NDOF; r++) Minv[r][col] = e[r]; }
+      double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3];
+      for (int i = 0; i < NARM; i++) { sn[i] = 0; cs[i] = 1; }
+      world_chain(pcst, sn, cs, R7, p7, ax, og);
+      Xf xb = rel(link7, hand);
+      double cl[3], cw[3];
+      mv(xb.R, m.body_ipos[hand], cl); for (int k = 0; k < 3; k++) cl[k] += xb.p[k];
+      mulE(R7, cl, cw); for (int k = 0; k < 3; k++) cw[k] += p7[k];
+      double J[3][NDOF];
+      for (int k = 0; k < NARM; k++) { double dd[3] = {cw[0] - og[k][0], cw[1] - og[k][1], cw[2] - og[k][2]}, col[3]; cross3(ax[k], dd, col); for (int r = 0; r < 3; r++) J[r][k] = col[r]; }
+      for (int g = 0; g < NFING; g++) for (int r = 0; r < 3; r++) J[r][NARM + g] = 0.0;
+      double tr = 0;
+      for (int r = 0; r < 3; r++) for (int a = 0; a < NDOF; a++) for (int b = 0; b < NDOF; b++) tr += J[r][a] * Minv[a][b] * J[r][b];
+      kc.invw_hand = std::fmax(1e-15, tr / 3);
+    }
   }
   return 0;
 }

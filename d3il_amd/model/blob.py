@@ -14,10 +14,10 @@ import json
 import os
 
 MAGIC = 0x4C493344  # 'D3IL'
-VERSION = 4
+VERSION = 5
 
 MAXBODY, MAXJNT, MAXGEOM, MAXACT, MAXEXCL, MAXCHAIN, MAXOBST = 64, 16, 80, 12, 16, 16, 8
-MAXMESH, MAXMVERT = 2, 96
+MAXMESH, MAXMVERT = 2, 800
 
 TASK_IDS = {"avoiding": 0, "pushing": 1, "sorting": 2, "stacking": 3}
 JNT_TYPES = {"free": 0, "hinge": 2, "slide": 3}       # numeric values follow mjtJoint [ext]
@@ -88,7 +88,7 @@ FIELDS = [
     ("task_f", F64, (32,), ""),
     # free-joint task objects in observation order (pushing.py:255-280: push_box, push_box2)
     ("n_obj", I32, (), ""), ("obj_pad", I32, (), ""), ("obj_body", I32, (8,), "body ids"),
-    # convex hulls of the mesh geoms that take part in collision (Stacking: fingerv.stl of panda_invisible.xml:97-109); vertices in
+    # convex hulls of the mesh geoms that take part in collision (Stacking: fingerv.stl, handv.stl of panda_invisible.xml:69-109); vertices in
     # mesh-file coordinates, i.e. in the frame geom_pos / geom_quat place on the body; centre = centroid of the hull volume
     ("nmesh", I32, (), ""), ("mesh_pad", I32, (), ""), ("mesh_nvert", I32, (MAXMESH,), ""),
     ("geom_mesh", I32, (MAXGEOM,), "mesh id of a mesh geom whose hull is carried, -1 otherwise"),

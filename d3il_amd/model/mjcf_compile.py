@@ -552,12 +552,14 @@ def build_stacking():
         objects=["red_box", "green_box", "blue_box"],
         target_pos=[0.5, 0.2, 0.0], pos_min_dist=0.06,       # stacking_objects.py:17, stacking.py:193
         gripper_open_threshold=0.075,                        # stacking.py:337
-        collision_meshes=["fingerv"],                    # mesh geoms whose hull is carried (finger <-> box grasp contacts)
+        collision_meshes=["fingerv", "handv"],           # mesh geoms whose hull is carried: finger <-> box grasp contacts, hand (palm) <-> box
     )
     blob = to_blob(m, "stacking", tc)
-    hv, cen = mesh_hull(os.path.join(D3IL, "models/mj/robot/assets/fingerv.stl"))
-    blob["meshes"] = {"fingerv": dict(vert=hv.tolist(), center=cen.tolist())}
-    # the hand mesh is not collided (773 hull vertices); its bounding box lets the engine flag a box that reaches it
+    blob["meshes"] = {}
+    for name in tc["collision_meshes"]:      # panda_invisible.xml:72 (panda_hand:geom2, mesh handv: 773 hull vertices), :99 / :108 (finger geoms, mesh fingerv: 68)
+        hv, cen = mesh_hull(os.path.join(D3IL, "models/mj/robot/assets/%s.stl" % name))
+        blob["meshes"][name] = dict(vert=hv.tolist(), center=cen.tolist())
+    # bounding box of the hand mesh in its geom frame: the engine's exact cull of the box <-> hand pairs (the 773-vertex MPR only runs inside it)
     hand = load_stl_vertices(os.path.join(D3IL, "models/mj/robot/assets/handv.stl"))
     blob["task_const"]["hand_bbox_min"] = hand.min(0).tolist()
     blob["task_const"]["hand_bbox_max"] = hand.max(0).tolist()

@@ -456,3 +456,39 @@ def test_config5_total_size_32768_environments(stack_js, ctx100):
         env.close()
     for k in range(len(ids)):
         assert np.array_equal(finals[64][k], finals[32768][k])
+
+
+def test_palm_pressed_on_a_box_follows_the_oracle(stack_js, stack_blob, ctx100):
+    """The box <-> hand-hull pair on the device (groups 13 .. 15 of the lane-per-pair collision: bounding-box cull, MPR by the whole wave over the 773
+    hull vertices): the open gripper is lowered until the palm presses on the red box; two contexts followed by the oracle on all state rows;
+    SKF_HAND_NEAR is never raised any more (the pair is evaluated, not flagged)."""
+    from d3il_amd.controllers.scripted_stacking import build_palm_press
+    from oracle.oracle import Oracle
+    names = [g["name"] for g in stack_js["geoms"]]
+    hand_g = names.index("panda_rb0_hand:geom2")
+    ids = [0, 42]
+    n = 8
+    env = _env(n)
+    q0, _, _ = env.start()
+    env.reset(context=ctx100[[ids[i % 2] for i in range(n)]])
+    trajs = [build_palm_press(stack_js, q0, ctx100[i]) for i in ids]
+    oracles = []
+    for i in ids:
+        o = Oracle(stack_blob); o.env_start(q0); o.stack_reset(ctx100[i]); oracles.append(o)
+    worst, n_hand = 0.0, 0
+    for t in range(len(trajs[0])):
+        act = torch.as_tensor(np.stack([trajs[i % 2][t] for i in range(n)]), dtype=torch.float64, device=env.device).contiguous()
+        env.step(act)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        assert not (fl & (BAD | (1 << 20))).any(), hex(int(np.bitwise_or.reduce(fl)))
+        for k in range(2):
+            oracles[k].stack_step(trajs[k][t])
+            e = k + 2 * (t % 4)
+            err = float(np.abs(st[:67, e] - oracles[k].stack_state()).max())
+            worst = max(worst, err)
+            assert err < 1e-5, (t, k, err)
+            if any(int(c[8]) == hand_g or int(c[9]) == hand_g for c in oracles[k].contacts()):
+                n_hand += 1
+    assert n_hand >= 20 and worst < 1e-5, (n_hand, worst)
+    env.close()
