@@ -917,8 +917,8 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
   const int ia = armrow ? hl - SK_ARM0 : 0;
 #if defined(D3IL_DEVICE_STATS)
   unsigned long long sd_t0 = wall_clock64();
-#define SD_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&g_dev_stats[16 + (slot)], t_ - sd_t0); sd_t0 = t_; } while (0)
-  if (lane == 0) atomicAdd(&g_dev_stats[16 + 6], 1ull);
+#define SD_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0 && blockIdx.x == 0) atomicAdd(&g_dev_stats[16 + (slot)], t_ - sd_t0); sd_t0 = t_; } while (0)
+  if (lane == 0 && blockIdx.x == 0) atomicAdd(&g_dev_stats[16 + 6], 1ull);
 #else
 #define SD_TOC(slot) ((void)0)
 #endif
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
   for (int it = 0; it < 60 && __any(!fin); it++) {
     const double gm = grad_pass();
     SD_TOC(8);
-    if (lane == 0) { D3IL_SD_COUNT(7); }
+    if (lane == 0 && blockIdx.x == 0) { D3IL_SD_COUNT(7); }
     if (!fin && gm <= g_solver_tol.grad_tol) fin = true;      // converged
     if (!__any(!fin)) break;
     // ---- Cholesky: lane i of a half holds row i
@@ -1461,6 +1461,45 @@ __device__ __forceinline__ void sk_support1_group(const StackConsts& kc_, const 
 #pragma unroll
   for (int k = 0; k < 3; k++) out[k] = R[3 * k] * loc[0] + R[3 * k + 1] * loc[1] + R[3 * k + 2] * loc[2] + s.p[k] + 0.5 * margin * dir[k];
 }
+// The same with the lane's share of the finger-hull vertices (sub, sub + 8, ...) held in registers for the whole MPR job: the table is read once
+// per job instead of once per support evaluation (an MPR job evaluates the support function ~100 times)
+__device__ __forceinline__ void sk_support1_group_pre(const StackConsts& kc_, const SkShape& s, const double (*hv)[3], const double* dir, double margin, double* out, const int sub) {
+  D3IL_STACK_CONSTS(kc_, kc);
+  const double* R = s.R;
+  double dl[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2], R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
+  double loc[3];
+  if (s.hull) {
+    const int nv = kc.hull_nv;
+    double d[SKG_NV], bd = -1e300;
+#pragma unroll
+    for (int m = 0; m < SKG_NV; m++) {
+      const int v = sub + SKG * m;
+      d[m] = v < nv ? hv[m][0] * dl[0] + hv[m][1] * dl[1] + hv[m][2] * dl[2] : -1e300;
+      bd = fmax(bd, d[m]);
+    }
+#pragma unroll
+    for (int m = SKG / 2; m >= 1; m >>= 1) bd = fmax(bd, __shfl_xor(bd, m));
+    const double thr = bd - 1e-10;
+    int best = 1 << 20, bm = 0;
+#pragma unroll
+    for (int m = SKG_NV - 1; m >= 0; m--) if (d[m] >= thr) { best = sub + SKG * m; bm = m; }
+    int gbest = best;
+#pragma unroll
+    for (int m = SKG / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(gbest, m); gbest = o < gbest ? o : gbest; }
+    // the winning vertex sits in the registers of lane (gbest % 8) of the group, slot gbest / 8: fetched with three shuffles
+    double mine[3] = {0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < SKG_NV; m++) if (m == bm) { mine[0] = hv[m][0]; mine[1] = hv[m][1]; mine[2] = hv[m][2]; }
+    const int src = (threadIdx.x & ~(SKG - 1)) | (gbest & (SKG - 1));
+#pragma unroll
+    for (int k = 0; k < 3; k++) loc[k] = __shfl(mine[k], src);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) loc[k] = dl[k] >= -1e-10 ? s.half[k] : -s.half[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[k] = R[3 * k] * loc[0] + R[3 * k + 1] * loc[1] + R[3 * k + 2] * loc[2] + s.p[k] + 0.5 * margin * dir[k];
+}
 // shape of an MPR job with its pose in the LDS tables (re-read by every support evaluation: nothing of it stays live across the portal iterations)
 struct SkShapeL { const sk_lds_double* R; const sk_lds_double* p; double half[3]; int hull; };
 __device__ __forceinline__ void sk_support1_group_l(const StackConsts& kc_, const SkShapeL& s, const double* dir, double margin, double* out, const int sub) {
@@ -1471,6 +1510,15 @@ __device__ __forceinline__ void sk_support1_group_l(const StackConsts& kc_, cons
   for (int k = 0; k < 3; k++) p[k] = s.p[k];
   const SkShape sh{R, p, s.half, s.hull};
   sk_support1_group(kc_, sh, dir, margin, out, sub);
+}
+__device__ __forceinline__ void sk_support1_group_lp(const StackConsts& kc_, const SkShapeL& s, const double (*hv)[3], const double* dir, double margin, double* out, const int sub) {
+  double R[9], p[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = s.R[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) p[k] = s.p[k];
+  const SkShape sh{R, p, s.half, s.hull};
+  sk_support1_group_pre(kc_, sh, hv, dir, margin, out, sub);
 }
 // Collision of the workgroup's environments with one lane per (environment, pair group), lane = group * SK_LANES + environment:
 //   group 0 .. 2  : box b against the static boxes          3 .. 5 : the box pairs (0, 1) (0, 2) (1, 2)
@@ -1630,9 +1678,12 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
       else if (round == 2) { hull_l(0, A); tip_l(1, B); set = SKS_HULLTIP; }
       else { tip_l(0, A); hull_l(1, B); set = SKS_HULLTIP; }
       const double um = kc.set[set].margin;
+      double hv[SKG_NV][3];      // this lane's share of the finger-hull vertices (every job of these groups involves the finger hull)
+#pragma unroll
+      for (int m2 = 0; m2 < SKG_NV; m2++) { const int v = sub + SKG * m2; const int vv = v < kc.hull_nv ? v : 0; hv[m2][0] = kc.hull_v[vv][0]; hv[m2][1] = kc.hull_v[vv][1]; hv[m2][2] = kc.hull_v[vv][2]; }
       hit = sk_mpr_t(kc, A, B, um, r7, [&](const double* dir, SkPt& pt) {
         const double nd[3] = {-dir[0], -dir[1], -dir[2]};
-        sk_support1_group_l(kc, A, dir, um, pt.v1, sub); sk_support1_group_l(kc, B, nd, um, pt.v2, sub);
+        sk_support1_group_lp(kc, A, hv, dir, um, pt.v1, sub); sk_support1_group_lp(kc, B, hv, nd, um, pt.v2, sub);
 #pragma unroll
         for (int k = 0; k < 3; k++) pt.v[k] = pt.v1[k] - pt.v2[k];
       }) ? 1 : 0;
@@ -1687,7 +1738,7 @@ __device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_d
   int tot = 0;      // contacts of this environment so far (the same value in all its lanes)
 #if defined(D3IL_DEVICE_STATS)
   unsigned long long skp_t0 = wall_clock64();      // lane 0 (environment 0, group 0) times the phases of the whole wave: slots 14 box-box, 15 MPR, 13 bookkeeping
-#define SKP_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&g_dev_stats[16 + (slot)], t_ - skp_t0); skp_t0 = t_; } while (0)
+#define SKP_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0 && blockIdx.x == 0) atomicAdd(&g_dev_stats[16 + (slot)], t_ - skp_t0); skp_t0 = t_; } while (0)
 #else
 #define SKP_TOC(slot) ((void)0)
 #endif

@@ -1,7 +1,7 @@
 """Stacking kernel: clock ticks (100 MHz) per phase of the physics sub-step (diagnostics build: D3IL_STATS_LIB=1), scripted pick-and-place.
 usage: D3IL_STATS_LIB=1 python tools/gpu_stack_phases.py [n_envs]
 Per-environment phases (slots 0, 3, 5) and the phases of the cooperative solve of environment 0 (7 .. 12) are read from the diagnostics words
-of environment 0; the collision phases (13 .. 15) are summed over the lane 0 of every workgroup and divided by the number of workgroups."""
+of environment 0; the solver and collision phases are timed by lane 0 of workgroup 0."""
 import ctypes as C
 import os
 import sys
@@ -29,7 +29,7 @@ def snap():
     capi.check(env.L.d3il_debug_scratch(env.h, 0, buf.ctypes.data_as(C.c_void_p), len(buf)))
     st = (C.c_uint64 * 32)()
     capi.check(env.L.d3il_debug_stats(st, 0))
-    return buf[32 * 36 + 4:32 * 36 + 17].copy(), np.array([st[16 + k] for k in (13, 14, 15, 3, 8, 9, 10, 11, 12, 6, 7)], dtype=float) / nwg
+    return buf[32 * 36 + 4:32 * 36 + 17].copy(), np.array([st[16 + k] for k in (13, 14, 15, 3, 8, 9, 10, 11, 12, 6, 7)], dtype=float)
 
 
 t = 0
