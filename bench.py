@@ -226,6 +226,18 @@ def _pmc(task, n):
     return None, None
 
 
+def _isa_mix(task):
+    """Counted FP64 instruction mix of the task's step kernel (tools/isa_fp64_mix.py), newest committed profile round first."""
+    for d in PROFILE_DIRS:
+        path = os.path.join(ROOT, "profiles", d, "isa_fp64_mix.json")
+        try:
+            with open(path) as f:
+                return json.load(f)[task], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 POLICY_TEXT = {
     "random": "random policy",
     "mlp": "ResidualMLP %d->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)",
@@ -447,14 +459,18 @@ def run(args):
         if pm is not None:
             traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
             if "SQ_INSTS_VALU" in pm and "SQ_WAVE_CYCLES" in pm:
-                # binding resource: FP64 VALU issue.  Instruction count from the PMC pass; ~2/3 of the VALU stream is FP64 arithmetic
-                # (static mix of the Avoiding kernel, used as the estimate for all tasks), an FMA counts 2 flop; lanes idle inside
-                # partially filled waves are counted as if they worked (an upper estimate); peak = 78.6 TFLOP/s vector FP64 (1024 SIMDs)
+                # binding resource: FP64 VALU issue.  Dynamic VALU instruction count from the PMC pass x the flop per VALU instruction COUNTED in the
+                # kernel's ISA (tools/isa_fp64_mix.py -> profiles/<round>/isa_fp64_mix.json: FMA-class FP64 = 2 flop, other FP64 arithmetic = 1, the
+                # rest 0; a static mix - loops and branches weight it differently at run time); lanes idle inside partially filled waves are counted
+                # as if they worked (an upper estimate); peak = 78.6 TFLOP/s vector FP64 (1024 SIMDs)
                 insts = pm["SQ_INSTS_VALU"]["mean_per_dispatch"]
-                tflops = insts * 0.66 * 1.6 * 64 / (k_ms * 1e-3) / 1e12
-                valu = {"bound": "fp64_valu", "source": pm_path, "valu_insts_per_launch": insts, "achieved_tflops_est": tflops,
-                        "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac_est": tflops / FP64_VALU_PEAK_TFLOPS,
-                        "valu_active_frac_of_wave_cycles": pm["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / pm["SQ_WAVE_CYCLES"]["mean_per_dispatch"]}
+                mix, mix_path = _isa_mix(task)
+                if mix is not None:
+                    tflops = insts * mix["flop_per_valu"] * 64 / (k_ms * 1e-3) / 1e12
+                    valu = {"bound": "fp64_valu", "source": pm_path, "valu_insts_per_launch": insts, "flop_per_valu_inst": mix["flop_per_valu"],
+                            "fp64_share_of_valu_insts": mix["fp64_share_of_valu"], "mix_source": mix_path + " (static ISA count)",
+                            "achieved_tflops_est": tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac_est": tflops / FP64_VALU_PEAK_TFLOPS,
+                            "valu_active_frac_of_wave_cycles": pm["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / pm["SQ_WAVE_CYCLES"]["mean_per_dispatch"]}
         tb = table.cpu().numpy()
         workload = {
             "avoiding": "Avoiding task, %d envs per GPU, random policy (Philox seed 42), state obs, 35 fused physics sub-steps per env step, "
