@@ -455,6 +455,8 @@ struct d3il_handle_s {
   bool ev_valid, ev_created;
   int tol_mode;            // 0 production stopping rule of the contact solvers, 1 the oracle's (solver_strict)
   int stack_reset_coop;    // Stacking: 1 (default) env.reset() runs through the step kernel's cooperative phases, 0 the one-lane reset kernel
+  int push_coop;           // Pushing: 1 env.step() on the wave-cooperative engine (k_pushing_step_coop), 0 (default) the two-wave kernel (k_pushing_step_split)
+  unsigned long long kc_id; // identity of this handle's StackConsts in the device's g_stack_consts cache (Stacking, Pushing on the cooperative engine)
   double* d_ctx;           // [n][ctx_dim] context of the last reset of every environment (Pushing 14, Sorting 7 nb)
   int ctx_dim;
   uint8_t* d_mask;         // [stride] environments reset by the last d3il_auto_reset (buf.last_reset)
@@ -470,6 +472,13 @@ static int g_active_tol[16];   // solver tolerance set currently in the device's
 // g_active_* / g_active_tol are process-global (one __constant__ object per device): every read-modify-write of them - d3il_create,
 // d3il_destroy, the solver-rule switch - holds this mutex (two host threads with one handle each raced on them)
 static std::mutex g_model_mutex;
+
+// g_stack_consts (one __constant__ object per device) serves the Stacking engine AND its Pushing variant: it is a cache of the constants of
+// the handle that launched last.  A handle with other constants reloads it before its launch, fenced by device synchronisations (handles
+// with different engine constants must not have kernels in flight on one device at the same time - they never share a stream in practice).
+static unsigned long long g_stack_loaded_id[16];
+static StackConsts g_stack_loaded[16];
+static unsigned long long g_kc_counter = 0;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -515,7 +524,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   std::memset(&h->buf, 0, sizeof h->buf);
   h->task_id = -1; h->device = device_id;      // task_id is set once the model reference is taken (free_handle)
   h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr; h->d_ctx = nullptr; h->d_mask = nullptr; h->ev_created = false;
-  h->tally_ctx = nullptr; h->tally_nctx = 0; h->tally_table = nullptr; h->tol_mode = 0; h->ctx_dim = 0; h->stack_reset_coop = 1;
+  h->tally_ctx = nullptr; h->tally_nctx = 0; h->tally_table = nullptr; h->tol_mode = 0; h->ctx_dim = 0; h->stack_reset_coop = 1; h->push_coop = 0; h->kc_id = 0;
   const char* err = "";
   int rc = build_panda_consts(m, h->hc, &err);
   if (rc) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
@@ -609,11 +618,18 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
       am.refs++; h->task_id = task_id;
     }
     HIPCHK_H(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
-    HIPCHK_H(hipMalloc(&h->d_scratch, S * PG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * PG_SIZE * sizeof(double)));
+    { const size_t per = PG_SIZE > SG_SIZE ? PG_SIZE : SG_SIZE; HIPCHK_H(hipMalloc(&h->d_scratch, S * per * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * per * sizeof(double))); }
     // the physics wave keeps the coupled solver's tables in LDS: 137.5 KiB + the set-point exchange, above the 64 KiB default cap
     HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_reset, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_H));
+    {   // the Pushing variant of the wave-cooperative engine
+      const char* e2 = "";
+      if (build_coop_push_consts(h->hc, h->pc, h->kc, &e2)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + e2); }
+      std::lock_guard<std::mutex> lock(g_model_mutex);
+      h->kc_id = ++g_kc_counter;
+    }
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_coop, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
   }
   if (sorting) {
     ActiveModel& am = g_active_gen[device_id];
@@ -635,12 +651,9 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     ActiveModel& am = g_active_stack[device_id];
     {
       std::unique_lock<std::mutex> lock(g_model_mutex);
-      if (am.refs == 0) {
-        hipError_t e1 = hipDeviceSynchronize(), e2 = hipMemcpyToSymbol(HIP_SYMBOL(g_stack_consts), &h->kc, sizeof(StackConsts));
-        if (e1 != hipSuccess || e2 != hipSuccess) { lock.unlock(); free_handle(h); return fail(D3IL_EHIP, "d3il_create: loading the Stacking model into constant memory failed"); }
-        am.kc = h->kc;
-      }
+      if (am.refs == 0) am.kc = h->kc;
       am.refs++; h->task_id = task_id;
+      h->kc_id = ++g_kc_counter;      // loaded into g_stack_consts by the first launch (sync_stack_consts)
     }
     HIPCHK_H(hipMalloc(&b.info_f64, S * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * sizeof(double)));
     HIPCHK_H(hipMalloc(&h->d_scratch, S * SG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * SG_SIZE * sizeof(double)));
@@ -668,6 +681,17 @@ int d3il_start(d3il_handle h, const double* init_qpos7) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpy(h->d_init_qpos, init_qpos7, 7 * sizeof(double), hipMemcpyHostToDevice));
   h->started = true;
+  return D3IL_OK;
+}
+
+static int sync_stack_consts(d3il_handle_s* h) {
+  std::lock_guard<std::mutex> lock(g_model_mutex);
+  if (g_stack_loaded_id[h->device] == h->kc_id) return D3IL_OK;
+  if (g_stack_loaded_id[h->device] != 0 && std::memcmp(&g_stack_loaded[h->device], &h->kc, sizeof(StackConsts)) == 0) { g_stack_loaded_id[h->device] = h->kc_id; return D3IL_OK; }
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stack_consts), &h->kc, sizeof(StackConsts)));
+  HIPCHK(hipDeviceSynchronize());
+  g_stack_loaded[h->device] = h->kc; g_stack_loaded_id[h->device] = h->kc_id;
   return D3IL_OK;
 }
 
@@ -715,6 +739,7 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   }
   if (h->task_id == D3IL_TASK_STACKING) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Stacking task needs contexts (device f64 [n_envs][21])");
+    if (int rc = sync_stack_consts(h)) return rc;
     if (h->stack_reset_coop)      // the step kernel in reset mode: cooperative phases, workgroups without a masked environment leave at once
       hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, (hipStream_t)stream, b.state, b.flags, b.step_count, (const double*)nullptr, b.obs,
                          b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, 1, h->hc.max_steps, 1, env_mask, h->d_init_qpos, contexts);
@@ -740,8 +765,12 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   if (int rc = sync_solver_tol(h, s)) return rc;
   if (h->task_id == D3IL_TASK_PUSHING) {
     int nwgp = (h->n + PUSH_LANES - 1) / PUSH_LANES;
+    if (h->push_coop && h->fast) { if (int rc = sync_stack_consts(h)) return rc; }
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
-    if (h->fast)
+    if (h->push_coop && h->fast)
+      hipLaunchKernelGGL(k_pushing_step_coop, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                         b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    else if (h->fast)
       hipLaunchKernelGGL((k_pushing_step_split<true>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                          b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
     else
@@ -765,6 +794,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     return D3IL_OK;
   }
   if (h->task_id == D3IL_TASK_STACKING) {
+    if (int rc = sync_stack_consts(h)) return rc;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                        b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, 0, (const unsigned char*)nullptr, (const double*)nullptr, (const double*)nullptr);
@@ -1044,6 +1074,7 @@ int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "solver_strict") == 0) { h->tol_mode = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "stack_reset_coop") == 0) { h->stack_reset_coop = value != 0; return D3IL_OK; }
+  if (std::strcmp(name, "push_coop") == 0) { h->push_coop = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "split_waves") == 0) { h->split = value; return D3IL_OK; }
   if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }
   if (std::strcmp(name, "lanes_per_wave") == 0) { if (value < 1 || value > WAVE) return fail(D3IL_EINVAL, "lanes_per_wave must be in 1..64"); h->lanes = value; return D3IL_OK; }

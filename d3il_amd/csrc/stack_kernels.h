@@ -12,6 +12,7 @@
 // The reset kernel runs the one-lane solver (sk_solve) - it is the host build's code path and off the hot path.
 #pragma once
 #include "stack_step.h"
+#include "push_kernels.h"
 
 namespace d3il {
 
@@ -74,20 +75,34 @@ __device__ __forceinline__ void sk_state_from_lds(const sk_lds_double* t, StackS
   }
 }
 // phase 1 (lane = environment): control law + arm forward pass, kinematic tables, smooth accelerations
+template <int V>
 __device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g, unsigned& flags, bool open) {
   StackState ss;
   sk_state_from_lds(t, ss);
   ss.arm.flags = flags;
-  double act[NARM], tau[NARM], ff[NFING];
-  for (int k = 0; k < NARM; k++) act[k] = t[SE_ACT + k];
+  double tau[NARM], ff[NFING];
   const StackScratch sc{t, g};
-  stack_control(kStackingConsts, ss.arm, act, open ? 0.04 : 0.0, !open, tau, ff);
-  stack_pre_kin(kStackingConsts, g_stack_consts, ss, sc, tau, ff);
+  if constexpr (V == SKV_PUSHING) {
+    // CartPosQuatImpedenceController (IKControllers.py:163-323): the virtual joint target advances open loop by three damped least-squares
+    // iterations per sub-step, then the joint PD law with gravity compensation; fingers commanded open (gym_env_wrapper.py:67)
+    double ikq[NARM], ikqd[NARM], des[7], vwarm[7];
+    for (int k = 0; k < NARM; k++) { ikq[k] = t[ST_TIPR + SV_IKQ + k]; ikqd[k] = t[ST_TIPR + SV_IKQD + k]; des[k] = t[ST_TIPR + SV_DES + k]; vwarm[k] = t[ST_TIPR + SV_VWARM + k]; }
+    ik_update<true>(kAvoidingConsts, des, des + 3, ss.arm.q, ss.arm.flags, ikq, ikqd, vwarm);
+    for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ikq[k]; t[ST_TIPR + SV_IKQD + k] = ikqd[k]; t[ST_TIPR + SV_VWARM + k] = vwarm[k]; }
+    push_control(kAvoidingConsts, ss.arm, ikq, ikqd, 0.04, false, tau, ff);
+    stack_pre_kin<SKV_PUSHING>(kAvoidingConsts, g_stack_consts, ss, sc, tau, ff);
+  } else {
+    double act[NARM];
+    for (int k = 0; k < NARM; k++) act[k] = t[SE_ACT + k];
+    stack_control(kStackingConsts, ss.arm, act, open ? 0.04 : 0.0, !open, tau, ff);
+    stack_pre_kin<SKV_STACKING>(kStackingConsts, g_stack_consts, ss, sc, tau, ff);
+  }
   for (int k = 0; k < NARM; k++) t[SE_BIAS + k] = ss.arm.bias[k];
   for (int k = 0; k < 3; k++) t[SE_TCP + k] = ss.arm.tcp[k];
   flags = ss.arm.flags;
 }
 // phase 3 (lane = environment): joint-limit rows, start point of the solver, "does the solver run"
+template <int V>
 __device__ __forceinline__ void sk_phase_mid(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
   StackState ss;
   for (int k = 0; k < NDOF; k++) { ss.arm.q[k] = t[SE_Q + k]; ss.arm.v[k] = t[ST_VEL + SK_ARM0 + k]; }
@@ -105,16 +120,19 @@ __device__ __forceinline__ void sk_phase_mid(sk_lds_double* t, sk_glb_double* g,
   t[SE_JSZ] = (double)jsz;
   bool any_lim = false;
   const StackScratch sc{t, g};
-  stack_pre_finish<true>(kStackingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
+  if constexpr (V == SKV_PUSHING) stack_pre_finish<true>(kAvoidingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
+  else stack_pre_finish<true>(kStackingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
   t[SE_NEED] = (ncon > 0 || any_lim) ? 1.0 : 0.0;
 }
 // phase 5 (lane = environment): mj_Euler
+template <int V>
 __device__ __forceinline__ void sk_phase_post(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
   StackState ss;
   sk_state_from_lds(t, ss);
   ss.arm.flags = flags;
   const StackScratch sc{t, g};
-  stack_substep_post<true>(kStackingConsts, g_stack_consts, ss, sc);
+  if constexpr (V == SKV_PUSHING) stack_substep_post<true>(kAvoidingConsts, g_stack_consts, ss, sc);
+  else stack_substep_post<true>(kStackingConsts, g_stack_consts, ss, sc);
   for (int k = 0; k < NDOF; k++) { t[SE_Q + k] = ss.arm.q[k]; t[ST_VEL + SK_ARM0 + k] = ss.arm.v[k]; }
   for (int b = 0; b < SK_NB; b++) {
     for (int k = 0; k < 3; k++) t[ST_BP + 3 * b + k] = ss.box[b].pos[k];
@@ -130,12 +148,13 @@ __device__ __forceinline__ void sk_phase_post(sk_lds_double* t, sk_glb_double* g
 // hold with the fingers commanded open - through the same cooperative collision / solver phases as a step - and the observation of the new
 // state is written.  Workgroups without a masked environment leave at once, so the auto-reset of the few episodes that end in a step costs
 // one sub-step of one workgroup instead of a one-lane solve (0.8 ms per call in round 2).
-__global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
-                                                        const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
-                                                        unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
-                                                        double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps,
-                                                        const int reset, const unsigned char* __restrict__ reset_mask, const double* __restrict__ init_qpos,
-                                                        const double* __restrict__ contexts) {
+template <int V>
+__device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+                                               const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
+                                               unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
+                                               double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps,
+                                               const int reset, const unsigned char* __restrict__ reset_mask, const double* __restrict__ init_qpos,
+                                               const double* __restrict__ contexts) {
   extern __shared__ double smem[];
   const int lane = threadIdx.x;
   const int e = blockIdx.x * SK_LANES + lane;
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
   sk_glb_double* const g = (sk_glb_double*)(scratch + (size_t)(live ? e : 0) * SG_SIZE);      // diagnostics words only (stats build)
   unsigned fl = 0; int step = 0;
   bool bad = false, open = true;
-  if (live && reset) {
+  if (V == SKV_STACKING && live && reset) {
     StackState ss;
     EnvState& st = ss.arm;
     for (int k = 0; k < NDOF; k++) { st.q[k] = k < NARM ? init_qpos[k] : 0.0; st.v[k] = 0; }
@@ -166,6 +185,33 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
     sk_state_to_lds(t, ss);
     for (int k = 0; k < NARM; k++) t[SE_ACT + k] = init_qpos[k];      // joint PD hold at init_qpos, open_fingers() (stacking.py:474)
     fl = 0; step = 0;
+  } else if (live && V == SKV_PUSHING) {
+    // Block_Push_Env.step (pushing.py:335-339 over gym_env_wrapper.py:45-100): set-point, observation / reward / done BEFORE the physics
+    PushState ps;
+    push_load(state, flags, steps, stride, e, ps, true);
+    double act[7], des[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
+    bad = sanitize_action(act, actions + (size_t)e * 7);
+    make_setpoint(act, des);
+    float o[PUSH_OBS]; unsigned char dn = 0; double reward = 0;
+    push_step_begin(g_push_consts, ps, o, &reward, &dn, max_steps);
+#pragma unroll
+    for (int k = 0; k < PUSH_OBS; k++) obs[(size_t)PUSH_OBS * e + k] = o[k];
+    done[e] = dn; info[(size_t)stride + e] = reward;
+    StackState ss;
+    ss.arm = ps.arm; ss.box[0] = ps.box[0]; ss.box[1] = ps.box[1];
+    for (int k = 0; k < 3; k++) ss.box[2].pos[k] = 100.0;      // the engine's third block is not part of this task: parked, inert
+    ss.box[2].quat[0] = 1; ss.box[2].quat[1] = ss.box[2].quat[2] = ss.box[2].quat[3] = 0;
+    for (int k = 0; k < 6; k++) ss.box[2].vel[k] = 0;
+    const double* sw = state + e + (size_t)PUSH_STATE_WARM * stride;      // warm start: cube 1 [6] cube 2 [6] arm [9]
+    for (int i = 0; i < 12; i++) t[ST_X + i] = sw[(size_t)i * stride];
+    for (int i = 12; i < 18; i++) t[ST_X + i] = 0;
+    for (int i = 0; i < NDOF; i++) t[ST_X + SK_ARM0 + i] = sw[(size_t)(12 + i) * stride];
+    sk_state_to_lds(t, ss);
+    for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ps.arm.ikq[k]; t[ST_TIPR + SV_IKQD + k] = ps.arm.ikqd[k]; t[ST_TIPR + SV_DES + k] = des[k]; t[ST_TIPR + SV_VWARM + k] = 0; }
+    fl = ps.arm.flags | ((ps.arm.flags & PF_WARM_VALID) ? SKF_WARM_VALID : 0u);
+    step = ps.arm.step;
   } else if (live) {
     StackState ss;
     stack_load(state, flags, steps, stride, e, ss);
@@ -192,10 +238,14 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
   __syncthreads();
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
-    if (live) sk_phase_pre(t, g, fl, open);
+    if (live) sk_phase_pre<V>(t, g, fl, open);
     __syncthreads();
+#if defined(D3IL_DEVICE_STATS)
+    sk_collide_coop(g_stack_consts, sm, lane, live_mask, scratch + (size_t)blockIdx.x * SK_LANES * SG_SIZE);
+#else
     sk_collide_coop(g_stack_consts, sm, lane, live_mask);
-    if (live) sk_phase_mid(t, g, fl);
+#endif
+    if (live) sk_phase_mid<V>(t, g, fl);
     __syncthreads();
     // the solver takes two environments at a time, one per half wave; a pair whose contact rows do not fit the shared J area together is
     // solved one environment after the other (job 2 p: pair p or its first environment, job 2 p + 1: its second environment).  ONE call
@@ -212,13 +262,43 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
       if (((failed & 1u) && lane == e0) || ((failed & 2u) && lane == e0 + 1)) fl |= F_SOLVER_FAIL;
     }
     __syncthreads();
-    if (live) sk_phase_post(t, g, fl);
+    if (live) sk_phase_post<V>(t, g, fl);
     __syncthreads();
   }
   if (!live) return;
+#if defined(D3IL_DEVICE_STATS)
+  {   // diagnostics build: the contact records of the last sub-step (count, then 8 doubles per contact) into the environment's scratch column
+    const int nc = (int)t[SE_NCON];
+    g[0] = (double)nc; g[1] = t[SE_NEED]; g[2] = t[SE_JSZ];
+    for (int i = 0; i < nc * SREC2; i++) g[8 + i] = t[SE_REC + i];
+    for (int i = 0; i < 48; i++) g[500 + i] = t[ST_TIPR + i];
+    for (int i = 0; i < 42; i++) g[560 + i] = t[ST_Z + i];
+    for (int i = 0; i < 3 * SK_NV; i++) g[610 + i] = t[ST_X + i];      // x, a0, vel
+    for (int i = 0; i < 45; i++) g[700 + i] = t[ST_M + i];
+    for (int i = 0; i < 27; i++) g[750 + i] = t[ST_LIM + i];
+    for (int i = 0; i < SE_REC - SE_Q; i++) g[780 + i] = t[SE_Q + i];
+  }
+#endif
   StackState ss;
   sk_state_from_lds(t, ss);
   ss.arm.flags = fl; ss.arm.step = step;
+  if constexpr (V == SKV_PUSHING) {
+    PushState ps;
+    ps.arm = ss.arm; ps.box[0] = ss.box[0]; ps.box[1] = ss.box[1];
+    for (int k = 0; k < NARM; k++) { ps.arm.ikq[k] = t[ST_TIPR + SV_IKQ + k]; ps.arm.ikqd[k] = t[ST_TIPR + SV_IKQD + k]; }
+    ps.arm.flags = (fl & ~SKF_WARM_VALID) | F_IK_VALID | PF_WARM_VALID;
+    if (bad) ps.arm.flags |= F_SOLVER_FAIL | F_TERMINATED;
+    double md = 0;
+    push_step_end(g_push_consts, ps, &md);
+    push_store(state, flags, steps, stride, e, ps, true);
+    double* sw = state + e + (size_t)PUSH_STATE_WARM * stride;
+    for (int i = 0; i < 12; i++) sw[(size_t)i * stride] = t[ST_X + i];
+    for (int i = 0; i < NDOF; i++) sw[(size_t)(12 + i) * stride] = t[ST_X + SK_ARM0 + i];
+    success[e] = (ps.arm.flags & F_SUCCESS) ? 1 : 0;
+    mode[e] = (unsigned short)(short)((int)((ps.arm.flags & PF_MODE_MASK) >> PF_MODE_SHIFT) - 1);
+    info[e] = md;
+    return;
+  }
   for (int i = 0; i < SK_NV; i++) ss.warm[i] = t[ST_X + i];
   if (reset) {
     float o[SK_OBS];
@@ -235,6 +315,25 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
   stack_store(state, flags, steps, stride, e, ss);
   success[e] = (ss.arm.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)stack_mode_code(ss.arm.flags);
   info[e] = md;
+}
+
+__global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+                                                        const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
+                                                        unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
+                                                        double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps,
+                                                        const int reset, const unsigned char* __restrict__ reset_mask, const double* __restrict__ init_qpos,
+                                                        const double* __restrict__ contexts) {
+  coop_step_body<SKV_STACKING>(state, flags, steps, actions, obs, done, success, mode, info, scratch, n, stride, n_substeps, max_steps, reset, reset_mask, init_qpos, contexts);
+}
+// env.step() for the Pushing task on the wave-cooperative engine (variant 1 of the Stacking engine: the rod robot, two cubes + an inert third
+// block, rod <-> cube contacts by cyl_box, Cartesian controller evaluated by the environment's lane): 4 environments per one-wave workgroup,
+// 1024 workgroups for 4096 environments = every SIMD of the chip, where the two-wave kernel (k_pushing_step_split, 24 environments per
+// workgroup) runs on 171 CUs.  actions f64 [n][7], state layout of the Pushing task (D3IL_PUSH_STATE_*).
+__global__ __launch_bounds__(WAVE) void k_pushing_step_coop(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+                                                            const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
+                                                            unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
+                                                            double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
+  coop_step_body<SKV_PUSHING>(state, flags, steps, actions, obs, done, success, mode, info, scratch, n, stride, n_substeps, max_steps, 0, nullptr, nullptr, nullptr);
 }
 
 // env.reset(random=False, context) for masked environments; contexts: f64 [n][21] = 3 x (pos3, quat4), red green blue

@@ -32,9 +32,9 @@ constexpr int SK_MAXCON = 32, SK_MAXNS = 4, SK_MAXHV = 96, SK_MAXHANDV = 800;
 #endif
 constexpr int SK_LANES = D3IL_SK_LANES;   // environments per workgroup (one per lane; LDS: 5.6 KiB per environment)
 // contact parameter sets
-enum { SKS_STATIC = 0 /* + static index */, SKS_BOXBOX = SK_MAXNS, SKS_BOXHULL, SKS_BOXTIP, SKS_HULLHULL, SKS_HULLTIP, SKS_TIPTIP, SKS_BOXHAND, SKS_N };
+enum { SKS_STATIC = 0 /* + static index */, SKS_BOXBOX = SK_MAXNS, SKS_BOXHULL, SKS_BOXTIP, SKS_HULLHULL, SKS_HULLTIP, SKS_TIPTIP, SKS_BOXHAND, SKS_BOXROD, SKS_N };
 // bodies of a contact: boxes 0..2, then
-enum { SKB_STATIC = 3, SKB_FINGER = 4 /* + finger: the finger body (hull geom) */, SKB_TIP = 6 /* + finger: the tip body (tip box) */, SKB_HAND = 8 /* the hand body (mesh handv): arm dofs only */ };
+enum { SKB_STATIC = 3, SKB_FINGER = 4 /* + finger: the finger body (hull geom) */, SKB_TIP = 6 /* + finger: the tip body (tip box) */, SKB_HAND = 8 /* the hand body (mesh handv): arm dofs only */, SKB_ROD = 9 /* the rod (Pushing variant): arm dofs only */ };
 D3IL_HD int sk_finger_of(int body) { return body >= SKB_HAND ? -1 : (body - SKB_FINGER) & 1; }      // finger whose slide joint moves the body (-1: none)
 
 struct StackSet { double K, B, solimp[5], fric[3], margin; int dim, pad; };
@@ -56,7 +56,14 @@ struct StackConsts {
   double hand_center[3], hand_r, invw_hand;              // centroid of the hull (seeds the MPR portal), bounding radius about it, translational body_invweight0 of the hand body
   int hand_nv, hand_pad;
   double hand_v[SK_MAXHANDV][3];                         // convex hull of handv.stl (773 vertices), geom frame
+  // Pushing variant of the engine (variant 1: the rod robot of panda_rod_invisible.xml, two free cubes + an inert third block, rod <-> cube contacts,
+  // Cartesian controller): rod cylinder in the link-7 frame, translational body_invweight0 of the rod body
+  int variant, var_pad;
+  double rod_c7[3], rod_u7[3], rod_r, rod_h, invw_rod;
 };
+enum { SKV_STACKING = 0, SKV_PUSHING = 1 };
+// Pushing variant: the finger-geom tables of the t area are not needed; their place holds the rod pose and the controller state
+constexpr int SV_ROD = 0 /* + ST_TIPR: rod centre[3], axis[3] */, SV_IKQ = 6, SV_IKQD = 13, SV_DES = 20 /* desired pose pos[3] quat[4] */, SV_VWARM = 27 /* 7 */, SV_END = 34;
 
 // flag bits of the Stacking task (EnvState::flags).  F_TERMINATED / F_SUCCESS / F_SOLVER_FAIL keep their positions.
 enum : unsigned {
@@ -519,7 +526,7 @@ D3IL_NOINLINE inline void sk_contact_dot(const StackConsts& kc_, const StackScra
   const double dist = SG(base + 12);
   const double imp = impedance(ps.solimp, dist - ps.margin);
   const int a = (int)SG(base + 13), b = (int)SG(base + 14);
-  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1]))); };
+  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body == SKB_ROD ? kc.invw_rod : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])))); };
   const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
   const double R1 = R0 / fmax(1e-15, kc.impratio);
   for (int r = 0; r < 4; r++) {
@@ -840,7 +847,7 @@ __device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, 
   const double dist = rec[12];
   const double imp = impedance(ps.solimp, dist - ps.margin);
   const int a = (int)rec[13], b = (int)rec[14];
-  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1]))); };
+  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body == SKB_ROD ? kc.invw_rod : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])))); };
   const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
   const double R1 = R0 / fmax(1e-15, kc.impratio);
 #pragma unroll
@@ -1192,7 +1199,7 @@ D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& 
 // smooth accelerations, collision, limit rows, start point of the solver), the constraint solve (sk_solve on one lane, or
 // sk_solve_coop by the whole wave), stack_substep_post (mj_Euler).  WARM_LDS: the warm start is the x vector left in the t area by
 // the previous sub-step (device step kernel) instead of ss.warm.
-template <class C>
+template <int V = SKV_STACKING, class C>
 D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
   D3IL_STACK_CONSTS(kc_, kc);
   D3IL_REFRESH(c0, c);
@@ -1222,7 +1229,14 @@ D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, 
     double R7[9], p7[3], ax[NARM][3], og[NARM][3];
     world_chain(c0, dyn.sn, dyn.cs, R7, p7, ax, og);
     for (int k = 0; k < NARM; k++) for (int i = 0; i < 3; i++) { SL(ST_Z + 3 * k + i) = ax[k][i]; SL(ST_O + 3 * k + i) = og[k][i]; }
-    for (int f = 0; f < NFING; f++) {
+    if constexpr (V == SKV_PUSHING) {      // rod cylinder: centre and axis in the world
+      double t3[3];
+      mulE(R7, kc.rod_c7, t3);
+      for (int i = 0; i < 3; i++) SL(ST_TIPR + SV_ROD + i) = p7[i] + t3[i];
+      mulE(R7, kc.rod_u7, t3);
+      for (int i = 0; i < 3; i++) SL(ST_TIPR + SV_ROD + 3 + i) = t3[i];
+    }
+    for (int f = 0; f < NFING && V == SKV_STACKING; f++) {
       double axw[3]; mulE(R7, c.f_axis[f], axw);
       for (int i = 0; i < 3; i++) SL(ST_FAX + 3 * f + i) = axw[i];
       const double qf = st.q[NARM + f];
@@ -1248,9 +1262,10 @@ D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, 
     const double* w = ss.box[b].vel + 3;
     const double Iw[3] = {I[0] * w[0], I[1] * w[1], I[2] * w[2]};
     double gy[3]; cross3(w, Iw, gy);
-    for (int k = 0; k < 3; k++) { SL(ST_A0 + 6 * b + k) = c.gravity[k]; SL(ST_A0 + 6 * b + 3 + k) = -gy[k] / I[k]; }
+    const bool inert = b >= kc.nb;      // a block this variant does not use: parked far away, no gravity, never touched by a constraint
+    for (int k = 0; k < 3; k++) { SL(ST_A0 + 6 * b + k) = inert ? 0.0 : c.gravity[k]; SL(ST_A0 + 6 * b + 3 + k) = inert ? 0.0 : -gy[k] / I[k]; }
     for (int k = 0; k < 6; k++) SL(ST_VEL + 6 * b + k) = ss.box[b].vel[k];
-    if (ss.box[b].pos[0] < kc.ws_lo[0] || ss.box[b].pos[0] > kc.ws_hi[0] || ss.box[b].pos[1] < kc.ws_lo[1] || ss.box[b].pos[1] > kc.ws_hi[1]) st.flags |= SKF_OFF_TABLE;
+    if (!inert && (ss.box[b].pos[0] < kc.ws_lo[0] || ss.box[b].pos[0] > kc.ws_hi[0] || ss.box[b].pos[1] < kc.ws_lo[1] || ss.box[b].pos[1] > kc.ws_hi[1])) st.flags |= SKF_OFF_TABLE;
   }
   SL(ST_AUX) = st.q[NARM] + st.q[NARM + 1];
   SK_TOC(0);
@@ -1491,6 +1506,13 @@ __device__ __forceinline__ void sk_support1_group_pre(const StackConsts& kc_, co
 #pragma unroll
     for (int m = 0; m < SKG_NV; m++) if (m == bm) { mine[0] = hv[m][0]; mine[1] = hv[m][1]; mine[2] = hv[m][2]; }
     const int src = (threadIdx.x & ~(SKG - 1)) | (gbest & (SKG - 1));
+    // The selected vertex goes through an opaque register move before the shuffles.  Without it hipcc (ROCm 7.2, -O3, 512 registers per lane)
+    // produced a kernel whose trajectories left those of the table-reading build (-DD3IL_SK_NO_PRELOAD, the same arithmetic) for ~1e-4 of the
+    // environments with a closing gripper and ended in SOLVER_FAIL flags; a fetch from the table, a checked fetch, an s_nop or an s_waitcnt at
+    // this place all remove it.  Guards: tests/test_gpu_parity_stacking.py::test_random_policy_*, tools/gpu_stack_ab.py.
+#if !defined(D3IL_SK_PRELOAD_RAW)      // the build without the move, kept to show that the guards catch it
+    asm volatile("" : "+v"(mine[0]), "+v"(mine[1]), "+v"(mine[2]));
+#endif
 #pragma unroll
     for (int k = 0; k < 3; k++) loc[k] = __shfl(mine[k], src);
   } else {
@@ -1540,6 +1562,9 @@ __device__ __forceinline__ void sk_support1_group_lp(const StackConsts& kc_, con
 // Results per environment: t[SE_NCON] = contacts kept (<= SK_MAXCON), t[SE_NEED] = 256 when contacts were dropped.
 constexpr int SKP_GROUPS = 16;
 static_assert(SKP_GROUPS * SK_LANES <= WAVE, "the lane-per-pair collision needs 16 lanes per environment");
+// Pushing variant: lane = group * SK_LANES + environment with group 0 .. 1: cube b against the static slabs (one per round), 2: the cube pair,
+// 3 .. 4: the rod cylinder against cube b (cyl_box: one contact, normal from the cube to the rod)
+constexpr int SKP_GROUPS_PUSH = 5;
 struct SkJob { int kind, ba, bb, set, hullA, hullB; double margin; };      // kind: 0 none, 1 box-box, 2 MPR (eight-lane group), 3 MPR against the hand hull (whole wave)
 // the job of lane L in a round (L may be another lane: the MPR groups rebuild their owner's job); shapes from the tables of L's environment
 __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* smem, const int L, const int round, const unsigned live_mask,
@@ -1555,6 +1580,40 @@ __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* s
   auto tip_shape = [&](int f, double* R, double* p, double* h) { ld(ST_TIPR + 9 * f, 9, R); ld(ST_TIPP + 3 * f, 3, p); for (int k = 0; k < 3; k++) h[k] = kc.tip_half[k]; };
   auto hull_shape = [&](int f, double* R, double* p, double* h) { ld(ST_HULR + 9 * f, 9, R); ld(ST_HULP + 3 * f, 3, p); h[0] = h[1] = h[2] = 0; };
   if (!act) return j;
+  if (kc.variant == SKV_PUSHING) {
+    if (grp < 2) {
+      if (round < kc.ns) {
+        const int sidx = round, b = grp;
+        box_shape(b, RB, pB, hB);
+        double d[3] = {pB[0] - kc.st_c[sidx][0], pB[1] - kc.st_c[sidx][1], pB[2] - kc.st_c[sidx][2]}, ex = 0;
+        for (int i = 0; i < 3; i++) { double loc = kc.st_R[sidx][i] * d[0] + kc.st_R[sidx][3 + i] * d[1] + kc.st_R[sidx][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[sidx][i]; if (o > 0) ex += o * o; }
+        const double rc = kc.box_r[b] + kc.set[SKS_STATIC + sidx].margin;
+        if (ex <= rc * rc) {
+          j.kind = 1; j.ba = SKB_STATIC; j.bb = b; j.set = SKS_STATIC + sidx;
+          for (int k = 0; k < 9; k++) RA[k] = kc.st_R[sidx][k];
+          for (int k = 0; k < 3; k++) { pA[k] = kc.st_c[sidx][k]; hA[k] = kc.st_h[sidx][k]; }
+        }
+      }
+    } else if (grp == 2) {
+      if (round == 0) { box_shape(0, RA, pA, hA); box_shape(1, RB, pB, hB); j.kind = 1; j.ba = 0; j.bb = 1; j.set = SKS_BOXBOX; rsum = kc.box_r[0] + kc.box_r[1]; }
+    } else if (grp < SKP_GROUPS_PUSH) {
+      if (round == 0) {      // rod <-> cube: pA = rod centre, RA[0..2] = rod axis, hA = (radius, half length, -)
+        const int b = grp - 3;
+        box_shape(b, RB, pB, hB);
+        ld(ST_TIPR + SV_ROD, 3, pA); ld(ST_TIPR + SV_ROD + 3, 3, RA);
+        hA[0] = kc.rod_r; hA[1] = kc.rod_h; hA[2] = 0;
+        const double w[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]};
+        const double al = fmin(fmax(w[0] * RA[0] + w[1] * RA[1] + w[2] * RA[2], -kc.rod_h), kc.rod_h);      // closest point of the axis segment to the cube centre
+        const double dd[3] = {w[0] - al * RA[0], w[1] - al * RA[1], w[2] - al * RA[2]}, rc = kc.box_r[b] + kc.rod_r + kc.set[SKS_BOXROD].margin;
+        if (dot3(dd, dd) <= rc * rc) { j.kind = 4; j.ba = b; j.bb = SKB_ROD; j.set = SKS_BOXROD; }
+      }
+    }
+    if (j.kind != 0) {
+      j.margin = kc.set[j.set].margin;
+      if (rsum > 0) { const double d[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]}, rc = rsum + j.margin; if (dot3(d, d) > rc * rc) j.kind = 0; }
+    }
+    return j;
+  }
   if (grp < 3) {
     if (round < kc.ns) {
       const int sidx = round, b = grp;
@@ -1608,8 +1667,15 @@ __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* s
 __device__ __forceinline__ int sk_round_boxbox(const StackConsts& kc_, sk_lds_double* smem, const int lane, const int round, const unsigned live_mask) {
   double RA[9], pA[3], hA[3], RB[9], pB[3], hB[3];
   const SkJob j = sk_job(kc_, smem, lane, round, live_mask, RA, pA, hA, RB, pB, hB);
-  if (j.kind != 1) return 0;
   sk_lds_double* stage = smem + lane * SKC_STAGE;
+  if (j.kind == 4) {      // rod cylinder against a cube: cyl_box returns {dist, pos, normal from the cube to the rod}
+    double r7[7];
+    if (!cyl_box(pA, RA, hA[0], hA[1], pB, RB, hB, j.margin, r7)) return 0;
+    stage[0] = r7[4]; stage[1] = r7[5]; stage[2] = r7[6];
+    stage[3] = r7[0]; stage[4] = r7[1]; stage[5] = r7[2]; stage[6] = r7[3];
+    return 1 | ((j.ba | (j.bb << 4) | (j.set << 8)) << 8);
+  }
+  if (j.kind != 1) return 0;
   int m = 0;
   box_box_emit(pA, RA, hA, pB, RB, hB, j.margin, 8, [&](double dist, const double* pos, const double* nrm) {
     stage[0] = nrm[0]; stage[1] = nrm[1]; stage[2] = nrm[2];
@@ -1683,7 +1749,11 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
       for (int m2 = 0; m2 < SKG_NV; m2++) { const int v = sub + SKG * m2; const int vv = v < kc.hull_nv ? v : 0; hv[m2][0] = kc.hull_v[vv][0]; hv[m2][1] = kc.hull_v[vv][1]; hv[m2][2] = kc.hull_v[vv][2]; }
       hit = sk_mpr_t(kc, A, B, um, r7, [&](const double* dir, SkPt& pt) {
         const double nd[3] = {-dir[0], -dir[1], -dir[2]};
+#if defined(D3IL_SK_NO_PRELOAD)
+        sk_support1_group_l(kc, A, dir, um, pt.v1, sub); sk_support1_group_l(kc, B, nd, um, pt.v2, sub);
+#else
         sk_support1_group_lp(kc, A, hv, dir, um, pt.v1, sub); sk_support1_group_lp(kc, B, hv, nd, um, pt.v2, sub);
+#endif
 #pragma unroll
         for (int k = 0; k < 3; k++) pt.v[k] = pt.v1[k] - pt.v2[k];
       }) ? 1 : 0;
@@ -1729,7 +1799,7 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
   }
   return m | (mine_meta << 8);
 }
-__device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_double* smem, const int lane, const unsigned live_mask) {
+__device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_double* smem, const int lane, const unsigned live_mask, double* dbg = nullptr) {
   D3IL_STACK_CONSTS(kc_, kc);
   const int e = lane % SK_LANES, grp = lane / SK_LANES;
   const bool act = grp < SKP_GROUPS && ((live_mask >> e) & 1u) != 0;
@@ -1742,13 +1812,16 @@ __device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_d
 #else
 #define SKP_TOC(slot) ((void)0)
 #endif
-  const int n_rounds = kc.ns > 4 ? kc.ns : 4;
+  const int n_rounds = kc.variant == SKV_PUSHING ? kc.ns : (kc.ns > 4 ? kc.ns : 4);
   for (int round = 0; round < n_rounds; round++) {
     int r = sk_round_boxbox(kc, smem, lane, round, live_mask);
     SKP_TOC(14);
     if (round >= 1) { const int r2 = sk_round_mpr(kc, smem, lane, round, live_mask); if ((r2 & 255) != 0) r = r2; }
     SKP_TOC(15);
     const int m = r & 255;
+#if defined(D3IL_DEVICE_STATS)
+    if (dbg && grp < SKP_GROUPS) dbg[(size_t)e * SG_SIZE + 300 + round * 16 + grp] = (double)r + 0.5 * (t[ST_AUX] < 0.004 ? 1 : 0);
+#endif
     // counts through the staging slots, then every lane moves its contacts to their final records
     if (grp < SKP_GROUPS) stage[SKC_STAGE - 1] = (double)m;
     __syncthreads();
@@ -2105,6 +2178,35 @@ D3IL_HOSTFN inline int build_stack_consts(const d3il_model_blob& m, const PandaC
       kc.invw_hand = std::fmax(1e-15, tr / 3);
     }
   }
+  return 0;
+}
+
+// Constants of the Pushing variant of the engine, from the Pushing constants (push_step.h) and the arm constants of the rod robot
+D3IL_HOSTFN inline int build_coop_push_consts(const PandaConsts& pcst, const PushConsts& pc, StackConsts& kc, const char** err) {
+  std::memset(&kc, 0, sizeof kc);
+  kc.variant = SKV_PUSHING; kc.nb = PUSH_NB; kc.ns = 2;
+  for (int b = 0; b < SK_NB; b++) {
+    const bool real = b < PUSH_NB;
+    for (int k = 0; k < 3; k++) { kc.box_half[b][k] = real ? pc.box_half[k] : 0.01; kc.box_inertia[b][k] = real ? pc.box_inertia : 1.0; }
+    kc.box_mass[b] = real ? pc.box_mass : 1.0;
+    kc.box_r[b] = std::sqrt(kc.box_half[b][0] * kc.box_half[b][0] + kc.box_half[b][1] * kc.box_half[b][1] + kc.box_half[b][2] * kc.box_half[b][2]);
+  }
+  if (std::fabs(pc.box_invw_t * pc.box_mass - 1.0) > 1e-12) { *err = "cube invweight"; return -1; }
+  for (int s2 = 0; s2 < 2; s2++) {
+    for (int k = 0; k < 3; k++) { kc.st_c[s2][k] = pc.slab_c[s2][k]; kc.st_h[s2][k] = pc.slab_h[s2][k]; }
+    kc.st_R[s2][0] = kc.st_R[s2][4] = kc.st_R[s2][8] = 1.0;
+  }
+  auto fill = [&](StackSet& ps, int i) {
+    ps.K = pc.ct_K[i]; ps.B = pc.ct_B[i];
+    for (int k = 0; k < 5; k++) ps.solimp[k] = pc.ct_solimp[i][k];
+    ps.fric[0] = pc.ct_fric[i]; ps.fric[1] = 0.005; ps.fric[2] = 0.0001;      // condim 3: only the sliding coefficient enters
+    ps.margin = 0.0; ps.dim = 3;
+  };
+  fill(kc.set[SKS_STATIC + 0], 0); fill(kc.set[SKS_STATIC + 1], 0); fill(kc.set[SKS_BOXBOX], 1); fill(kc.set[SKS_BOXROD], 1);
+  kc.impratio = pc.impratio;
+  for (int k = 0; k < 2; k++) { kc.ws_lo[k] = pc.slab_c[0][k] - (pc.slab_h[0][k] - 0.06); kc.ws_hi[k] = pc.slab_c[0][k] + (pc.slab_h[0][k] - 0.06); }      // push_step.h: PF_OFF_TABLE
+  for (int k = 0; k < 3; k++) { kc.rod_c7[k] = pcst.rod_c7[k]; kc.rod_u7[k] = pcst.rod_u7[k]; }
+  kc.rod_r = pcst.rod_r; kc.rod_h = pcst.rod_h; kc.invw_rod = pcst.rod_invweight0;
   return 0;
 }
 

@@ -200,7 +200,9 @@ int d3il_last_step_ms(d3il_handle h, float* ms);
 
 /* "ik_fast_path" (default 1), "split_waves" (-1 auto, 0, 1), "lanes_per_wave", "lds_pad_bytes";
  * "solver_strict" (default 0): 1 = the contact solvers of Pushing / Sorting / Stacking iterate to round-off like the CPU oracle (parity A/B);
- * "stack_reset_coop" (default 1): Stacking env.reset() through the step kernel's wave-cooperative phases, 0 = the one-lane reset kernel (A/B) */
+ * "stack_reset_coop" (default 1): Stacking env.reset() through the step kernel's wave-cooperative phases, 0 = the one-lane reset kernel (A/B);
+ * "push_coop" (default 0): 1 = Pushing env.step() on the Pushing variant of the wave-cooperative Stacking engine (4 environments per one-wave workgroup; a second,
+ * independent device implementation of the same step: parity-tested, measured SLOWER than the two-wave kernel - 0.50 vs 0.65 M env-steps/s -, kept for cross-checks) */
 int d3il_set_option(d3il_handle h, const char* name, int value);
 /* Diagnostics builds only (-DD3IL_DEVICE_STATS): per-path lane/wave counters of the step kernel. */
 int d3il_debug_stats(uint64_t* out32, int reset);
