@@ -336,6 +336,41 @@ def test_copies_of_an_environment_in_one_workgroup_stay_bit_identical(ctx100):
     env.close()
 
 
+def test_permuted_batch_gives_every_environment_the_same_trajectory(ctx100):
+    """Every environment has its own context and its own open-loop actions (random joint motions, the gripper closing on nothing and opening again);
+    the batch runs twice, the second time permuted (other workgroup mates, other workgroup positions, other MPR lane groups, other solver halves).
+    Each environment's state must be bit-identical in both runs at every step (tools/gpu_stack_perm.py is the long version of this test)."""
+    n, steps = 2048, 150
+    rng = np.random.default_rng(5)
+    cid = rng.integers(0, 100, size=n)
+    phase, period = rng.integers(0, 40, size=n), rng.integers(20, 60, size=n)
+    delta = rng.uniform(-0.01, 0.01, size=(steps, n, 7))
+    perm = rng.permutation(n)
+    runs = []
+    for order in (np.arange(n), perm):
+        env = _env(n)
+        q0, _, _ = env.start()
+        env.reset(context=ctx100[cid[order]])
+        cmd = np.tile(np.asarray(q0, dtype=np.float64), (n, 1))
+        inv = np.argsort(order)
+        out = []
+        for t in range(steps):
+            cmd = cmd + delta[t]
+            grip = np.where((t + phase) % period < 0.7 * period, 0.0, 0.08)
+            act = np.concatenate([cmd, grip[:, None]], axis=1)[order]
+            env.step(torch.as_tensor(act, dtype=torch.float64, device=env.device).contiguous())
+            torch.cuda.synchronize()
+            st, fl, _ = env.get_state()
+            assert not (fl & (1 << 16)).any(), (t, np.nonzero(fl & (1 << 16))[0][:8].tolist())
+            out.append(st[:, inv].copy())
+        runs.append(out)
+        env.close()
+    for t in range(steps):
+        d = np.nonzero((runs[0][t] != runs[1][t]).any(axis=0))[0]
+        assert d.size == 0, "step %d: environments %s differ between the two arrangements (positions %s / %s)" % (t, d[:6].tolist(), (d[:6] % 4).tolist(), (np.argsort(perm)[d[:6]] % 4).tolist())
+    assert float((runs[0][-1][7] + runs[0][-1][8]).min()) < 0.004
+
+
 def test_contact_overflow_is_flagged_and_contained(ctx100):
     """More contacts than the record area holds (three boxes pushed into each other on the table: 3 x 8 box-box + 3 x 4 table contacts):
     the lane raises CON_OVERFLOW, stays finite, and the other lanes of its workgroup are not disturbed."""

@@ -45,3 +45,9 @@ if os.environ.get("D3IL_DUMP") == "1":      # diagnostics build: LDS words of th
     for a, b, nm in names:
         d = np.nonzero((cols[a:b] != cols[a:b, :1]).any(axis=1))[0]
         print("%-28s differing words: %s" % (nm, [(int(i), ["%.6g" % v for v in cols[a + i]]) for i in d[:12]]))
+    if os.environ.get("D3IL_DUMP_MPR") == "1":
+        for L_ in (0, 8, 16, 24, 25, 31):
+            blk = cols[840 + (L_ % 8) * 40: 840 + (L_ % 8) * 40 + 40, L_ // 8].reshape(4, 10)
+            print("lane %2d:" % L_)
+            for r in blk:
+                print("    dir %s v1 %s v2 %s" % (np.array2string(r[0:3], precision=12), np.array2string(r[3:6], precision=12), np.array2string(r[6:9], precision=12)))
