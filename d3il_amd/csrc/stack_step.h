@@ -1507,10 +1507,10 @@ __device__ __forceinline__ void sk_support1_group_pre(const StackConsts& kc_, co
     for (int m = 0; m < SKG_NV; m++) if (m == bm) { mine[0] = hv[m][0]; mine[1] = hv[m][1]; mine[2] = hv[m][2]; }
     const int src = (threadIdx.x & ~(SKG - 1)) | (gbest & (SKG - 1));
     // The selected vertex goes through an opaque register move before the shuffles.  Without it (-DD3IL_SK_PRELOAD_RAW) hipcc (ROCm 7.2, -O3, 512
-    // registers per lane, 160 B of scratch) produces a kernel whose results depend on the workgroup position of an environment: the fourth MPR lane
+    // registers per lane, 272 B of scratch) produces a kernel whose results depend on the workgroup position of an environment: the fourth MPR lane
     // group of a batch reports a finger <-> finger contact that the other three, on identical data, do not (and SOLVER_FAIL flags follow); the
     // table-reading variant (-DD3IL_SK_NO_PRELOAD) shows the same defect at ~1e-6 per environment step.  Instrumented builds do not show it, the ISA
-    // of this sequence is correct in both builds: the register allocation differs, not the arithmetic (DESIGN section 16).  This build is clean in
+    // of this sequence is correct in both builds: the register allocation differs, not the arithmetic (DESIGN section 17.3).  This build is clean in
     // 2e7 environment steps of tools/gpu_stack_perm.py; guards: tests/test_gpu_parity_stacking.py::test_random_policy_*, ::test_copies_*, ::test_permuted_*.
 #if !defined(D3IL_SK_PRELOAD_RAW)      // the build without the move, kept to show that the guards catch it
     asm volatile("" : "+v"(mine[0]), "+v"(mine[1]), "+v"(mine[2]));

@@ -101,7 +101,7 @@ def test_bounded_horizon_rollout_matches_oracle(ctx60, init_qpos, pushing_blob, 
 def test_cooperative_engine_variant_follows_the_oracle(ctx60, init_qpos, pushing_blob):
     """Option push_coop=1 runs Pushing on the Stacking task's wave-cooperative engine (k_pushing_step_coop: lane-per-pair collision with the
     rod as a cylinder job, two environments per wave in the solver) instead of the lock-step kernel - off by default because it is slower
-    for this task (DESIGN section 15), kept as a second implementation of the same step: bounded-horizon parity with the oracle through
+    for this task (DESIGN section 17.5), kept as a second implementation of the same step: bounded-horizon parity with the oracle through
     the first rod <-> cube contacts, and the same integer outputs."""
     from oracle.oracle import Oracle
     n = 96

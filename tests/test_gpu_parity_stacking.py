@@ -287,7 +287,7 @@ def test_random_policy_raises_no_solver_failure(ctx100):
     """BASELINE config 5's closed loop with the randomly initialised BESO policy (bench.py --task stacking --policy beso): 4096 environments,
     60 policy steps of small random joint motions with the gripper opening and closing at random.  Round 3 found SOLVER_FAIL flags here
     (about one environment in 1e4 per step, always with a nearly closed empty gripper: the finger <-> finger MPR jobs) that none of the
-    scripted tests reached; cause and fix: stack_step.h sk_support1_group_pre / DESIGN section 16.  No flag may be raised."""
+    scripted tests reached; cause and fix: stack_step.h sk_support1_group_pre / DESIGN section 17.3.  No flag may be raised."""
     import bench
     n = 4096
     env = _env(n)

@@ -1,7 +1,7 @@
 """Stacking soak 2: every environment has its own context and its own open-loop action sequence (random joint motions, gripper closing on nothing and
 opening again with a random phase); the batch is run twice, the second time with the environments PERMUTED (other workgroup mates, other workgroup
 positions).  Each environment's state must be bit-identical in both runs at every step: the engine's results may not depend on where an environment
-sits (DESIGN section 16).  usage (GPU box): [D3IL_LIB_PATH=...] python tools/gpu_stack_perm.py [envs] [steps] [seed]"""
+sits (DESIGN section 17.3).  usage (GPU box): [D3IL_LIB_PATH=...] python tools/gpu_stack_perm.py [envs] [steps] [seed]"""
 import os
 import sys
 

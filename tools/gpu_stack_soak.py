@@ -1,6 +1,6 @@
 """Stacking soak: workgroups of four identical copies under random joint motions with the gripper closing on nothing and opening again (random phase per
 workgroup); counts environments whose state differs from position 0 of their workgroup and SOLVER_FAIL flags.  A position-dependent result is an
-engine defect by construction (DESIGN section 16).  usage (GPU box): [D3IL_LIB_PATH=...] python tools/gpu_stack_soak.py [envs] [steps] [seed]"""
+engine defect by construction (DESIGN section 17.3).  usage (GPU box): [D3IL_LIB_PATH=...] python tools/gpu_stack_soak.py [envs] [steps] [seed]"""
 import os
 import sys
 

@@ -11,13 +11,14 @@ for T in $TASKS; do
   if [ $T = avoiding ]; then python bench.py 2>/dev/null | tail -1 > $O/bench_line_$T.json; python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_${T}_20steps.json
   else python bench.py --task $T $X --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_$T.json; fi
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/prof_$T.log 2>&1
-  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_a_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/pmc_a_$T.log 2>&1
-  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/pmc_w_$T.log 2>&1
-  timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $O/pmc_b_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/pmc_b_$T.log 2>&1
-  timeout 900 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_c_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/pmc_c_$T.log 2>&1
+  timeout 900 rocprofv3 --kernel-include-regex "$K" --pmc FETCH_SIZE --output-format csv -d $O/pmc_a_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/pmc_a_$T.log 2>&1
+  timeout 900 rocprofv3 --kernel-include-regex "$K" --pmc WRITE_SIZE --output-format csv -d $O/pmc_w_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/pmc_w_$T.log 2>&1
+  timeout 900 rocprofv3 --kernel-include-regex "$K" --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $O/pmc_b_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/pmc_b_$T.log 2>&1
+  timeout 900 rocprofv3 --kernel-include-regex "$K" --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_c_$T -- python bench.py --task $T $X --no-cpu-baseline > $O/pmc_c_$T.log 2>&1
   N=$K; if [ $T = avoiding ]; then N=k_avoiding_step_split; fi; if [ $T = pushing ]; then N=k_pushing_step_split; fi
   F=pmc_summary_$T.json; if [ $T = avoiding ]; then F=pmc_summary_bench300.json; fi
-  python tools/pmc_summarize.py $N $O/$F $O/pmc_a_$T $O/pmc_w_$T $O/pmc_b_$T $O/pmc_c_$T
+  B=""; if [ $T = stacking ]; then B="--bimodal"; fi
+  python tools/pmc_summarize.py $B $N $O/$F $O/pmc_a_$T $O/pmc_w_$T $O/pmc_b_$T $O/pmc_c_$T
   f=$(find $O/prof_$T -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_$T.csv
   rm -rf $O/prof_$T $O/pmc_a_$T $O/pmc_w_$T $O/pmc_b_$T $O/pmc_c_$T
 done
@@ -34,4 +35,6 @@ if echo $TASKS | grep -q stacking; then
   python bench.py --task stacking --policy beso --steps 40 --warmup 5 --preroll 200 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_stacking_beso.json
   D3IL_STATS_LIB=1 python tools/gpu_stack_phases.py 4096 > $O/stacking_phases.log 2>&1
   python tools/gpu_beso_profile.py > $O/beso_policy_profile.log 2>&1
+  for S in 5 11; do python tools/gpu_stack_perm.py 8192 300 $S 2>&1 | grep "^lib"; done > $O/stacking_permutation_soak.log
+  for N in 1024 4096 8192 16384 32768; do python bench.py --task stacking --envs $N --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1; done > $O/stacking_batch_sweep.jsonl
 fi
