@@ -101,7 +101,7 @@ def test_sorting_success_and_mode_tables_over_full_episodes():
 
 
 def test_stacking_success_and_mode_tables_over_full_episodes():
-    """Stacking, the first 16 of the reference's 100 test contexts (bench.py's tile), 1000-step episodes (configs/stacking_config.yaml:84),
+    """Stacking, all 100 of the reference's test contexts (bench.py tiles the first 16), 1000-step episodes (configs/stacking_config.yaml:84),
     scripted three-box pick-and-place (stacking_sim.py:88-136: order string, success, 1- / 2-box successes)."""
     from d3il_amd.agents import ScriptedStackPolicy
     from d3il_amd.controllers.scripted_stacking import build_trajectory
@@ -109,7 +109,7 @@ def test_stacking_success_and_mode_tables_over_full_episodes():
     from d3il_amd.model import blob
     from d3il_amd.simulation.stacking_sim import Stacking_Sim
     from tests import oracle_episodes as oe
-    nctx = 16
+    nctx = 100
     ctx = load_test_contexts()[:nctx]
     js = blob.load_json("stacking")
     env = CubeStackingVecEnv(1, device=0)
@@ -124,6 +124,6 @@ def test_stacking_success_and_mode_tables_over_full_episodes():
     dev_rows = [(bool(s), mode_string(int(m))) for s, m in zip(r["success"].cpu().numpy(), r["mode"].cpu().numpy())]
     res = oe.run_many(oe.stacking_episode, [(i, ctx[i], q0, 1000, tables[i]) for i in range(nctx)])
     orc_rows = [(s, m) for _, s, m, _ in res]
-    s = _compare("stacking", dev_rows, orc_rows, max_mismatch=2)
+    s = _compare("stacking", dev_rows, orc_rows, max_mismatch=6)
     assert s["oracle_successes"] >= nctx // 2, "the scripted pick-and-place should stack three boxes on most contexts"
-    assert abs(s["device_successes"] - s["oracle_successes"]) <= 1
+    assert abs(s["device_successes"] - s["oracle_successes"]) <= 3
