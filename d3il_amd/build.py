@@ -86,8 +86,26 @@ def build_stats_variant(verbose: bool = False) -> str:
     return out
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """Comparison / diagnostics builds of the Stacking kernel, loaded with D3IL_LIB_PATH=<file>:
+    poison: every LDS word starts as a NaN and dead areas are poisoned again every sub-step (-DD3IL_SK_POISON);
+    raw: without the opaque move in sk_support1_group_pre - shows the position-dependence defect (-DD3IL_SK_PRELOAD_RAW);
+    nopreload: the table-reading support function (-DD3IL_SK_NO_PRELOAD)."""
+    out = os.path.join(PKG, "libd3il_rollout_%s.so" % name)
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-o", out] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=ROOT)
+    return out
+
+
+VARIANTS = {"poison": ["D3IL_SK_POISON"], "raw": ["D3IL_SK_PRELOAD_RAW"], "nopreload": ["D3IL_SK_NO_PRELOAD"], "poisonraw": ["D3IL_SK_POISON", "D3IL_SK_PRELOAD_RAW"]}
+
 if __name__ == "__main__":
     import sys
     print(build(force=True, verbose=True))
     if "--stats" in sys.argv:
         print(build_stats_variant(verbose=True))
+    for name, defs in VARIANTS.items():
+        if "--" + name in sys.argv:
+            print(build_variant(name, defs, verbose=True))

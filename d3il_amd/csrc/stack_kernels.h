@@ -165,6 +165,14 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
   sk_glb_double* const g = (sk_glb_double*)(scratch + (size_t)(live ? e : 0) * SG_SIZE);      // diagnostics words only (stats build)
   unsigned fl = 0; int step = 0;
   bool bad = false, open = true;
+#if defined(D3IL_SK_POISON)
+  // diagnostics build: every LDS word starts as a NaN, and at the start of every sub-step the areas that hold nothing live (the shared
+  // solver / staging region, smooth accelerations, mass matrix, kinematic tables, limit rows, contact records) are poisoned again: a read of a
+  // word this sub-step has not written shows up as a NaN in the state or as a solver failure instead of as a plausible stale number
+  auto poison = [&](int q) { ((unsigned long long*)smem)[q] = 0x7ff8dead00000000ull; };
+  for (int q = lane; q < STACK_LDS / 8; q += WAVE) poison(q);
+  __syncthreads();
+#endif
   if (V == SKV_STACKING && live && reset) {
     StackState ss;
     EnvState& st = ss.arm;
@@ -238,6 +246,19 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
   __syncthreads();
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
+#if defined(D3IL_SK_POISON)
+    if (V == SKV_STACKING) {
+      for (int q = lane; q < SKC_SHARED; q += WAVE) poison(q);
+      if (live) {
+        const int base = SKC_SHARED + lane * SE_SIZE - ST_HEAD;
+        for (int q = ST_A0; q < ST_A0 + SK_NV; q++) poison(base + q);
+        for (int q = ST_M; q < ST_BP; q++) poison(base + q);          // mass matrix, box rotations
+        for (int q = ST_Z; q < ST_AUX + 2; q++) poison(base + q);     // joint axes / origins, finger axes, tip / hull poses, limit rows, aux, row size
+        for (int q = SE_NCON; q < SE_END; q++) poison(base + q);      // contact count, need, records
+      }
+      __syncthreads();
+    }
+#endif
     if (live) sk_phase_pre<V>(t, g, fl, open);
     __syncthreads();
 #if defined(D3IL_DEVICE_STATS)
