@@ -33,7 +33,11 @@ def snap():
 
 
 t = 0
-for lo, hi, label in ((0, 20, "rest / approach"), (60, 80, "grasp + lift"), (150, 170, "carry / place")):
+windows = ((0, 20, "rest / approach"), (60, 80, "grasp + lift"), (150, 170, "carry / place"))
+if len(sys.argv) > 2 and sys.argv[2] == "scan":      # the whole scripted episode in windows of 10 steps every 50: where is the slowest phase?
+    T = max(len(tr) for tr in trajs)
+    windows = tuple((k, k + 10, "steps %d.." % k) for k in range(0, T, 50))
+for lo, hi, label in windows:
     while t < lo:
         act = torch.as_tensor(np.stack([trajs[i % 4][min(t, len(trajs[i % 4]) - 1)] for i in range(4)]), dtype=torch.float64, device=env.device)
         env.step(act[torch.arange(n, device=env.device) % 4].contiguous()); t += 1
