@@ -1446,6 +1446,34 @@ D3IL_HD void stack_substep_pre(const C& c0, const StackConsts& kc_, StackState& 
 // vertices s, s + 8, ...; the maximum and the lowest index within 1e-10 of it come from reductions over the group (xor shuffles with
 // masks 4, 2, 1 stay inside it) - the vertex sk_support1 finds with its two passes over the table.
 constexpr int SKG = 8, SKG_NV = (SK_MAXHV + SKG - 1) / SKG;
+// reductions over a group of eight lanes (all active together): quad permutes + half-row mirror as DPP moves - three VALU stages instead of
+// three LDS-crossbar round trips (ds_bpermute) per reduction; -DD3IL_SK_SHFL_REDUCE keeps the shuffle version for comparison
+__device__ __forceinline__ int sk_dpp_movi(int v, const int ctrl_sel) {
+  switch (ctrl_sel) {
+    case 0: return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);
+    case 1: return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);
+  }
+}
+__device__ __forceinline__ double sk_group_max(double v) {
+#if defined(D3IL_SK_SHFL_REDUCE)
+#pragma unroll
+  for (int m = SKG / 2; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+#else
+  v = fmax(v, sk_dpp_mov(v, 0)); v = fmax(v, sk_dpp_mov(v, 1)); v = fmax(v, sk_dpp_mov(v, 2));
+#endif
+  return v;
+}
+__device__ __forceinline__ int sk_group_min(int v) {
+#if defined(D3IL_SK_SHFL_REDUCE)
+#pragma unroll
+  for (int m = SKG / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
+#else
+#pragma unroll
+  for (int st = 0; st < 3; st++) { const int o = sk_dpp_movi(v, st); v = o < v ? o : v; }
+#endif
+  return v;
+}
 __device__ __forceinline__ void sk_support1_group(const StackConsts& kc_, const SkShape& s, const double* dir, double margin, double* out, const int sub) {
   D3IL_STACK_CONSTS(kc_, kc);
   const double* R = s.R;
@@ -1460,14 +1488,12 @@ __device__ __forceinline__ void sk_support1_group(const StackConsts& kc_, const 
       d[m] = v < nv ? kc.hull_v[v][0] * dl[0] + kc.hull_v[v][1] * dl[1] + kc.hull_v[v][2] * dl[2] : -1e300;
       bd = fmax(bd, d[m]);
     }
-#pragma unroll
-    for (int m = SKG / 2; m >= 1; m >>= 1) bd = fmax(bd, __shfl_xor(bd, m));
+    bd = sk_group_max(bd);
     const double thr = bd - 1e-10;
     int best = 1 << 20;
 #pragma unroll
     for (int m = SKG_NV - 1; m >= 0; m--) if (d[m] >= thr) best = sub + SKG * m;
-#pragma unroll
-    for (int m = SKG / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(best, m); best = o < best ? o : best; }
+    best = sk_group_min(best);
     loc[0] = kc.hull_v[best][0]; loc[1] = kc.hull_v[best][1]; loc[2] = kc.hull_v[best][2];
   } else {
 #pragma unroll
@@ -1492,15 +1518,12 @@ __device__ __forceinline__ void sk_support1_group_pre(const StackConsts& kc_, co
       d[m] = v < nv ? hv[m][0] * dl[0] + hv[m][1] * dl[1] + hv[m][2] * dl[2] : -1e300;
       bd = fmax(bd, d[m]);
     }
-#pragma unroll
-    for (int m = SKG / 2; m >= 1; m >>= 1) bd = fmax(bd, __shfl_xor(bd, m));
+    bd = sk_group_max(bd);
     const double thr = bd - 1e-10;
     int best = 1 << 20, bm = 0;
 #pragma unroll
     for (int m = SKG_NV - 1; m >= 0; m--) if (d[m] >= thr) { best = sub + SKG * m; bm = m; }
-    int gbest = best;
-#pragma unroll
-    for (int m = SKG / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(gbest, m); gbest = o < gbest ? o : gbest; }
+    const int gbest = sk_group_min(best);
     // the winning vertex sits in the registers of lane (gbest % 8) of the group, slot gbest / 8: fetched with three shuffles
     double mine[3] = {0, 0, 0};
 #pragma unroll
