@@ -19,7 +19,7 @@ VERSION = 5
 MAXBODY, MAXJNT, MAXGEOM, MAXACT, MAXEXCL, MAXCHAIN, MAXOBST = 64, 16, 80, 12, 16, 16, 8
 MAXMESH, MAXMVERT = 2, 800
 
-TASK_IDS = {"avoiding": 0, "pushing": 1, "sorting": 2, "stacking": 3}
+TASK_IDS = {"avoiding": 0, "pushing": 1, "sorting": 2, "stacking": 3, "aligning": 4}
 JNT_TYPES = {"free": 0, "hinge": 2, "slide": 3}       # numeric values follow mjtJoint [ext]
 GEOM_TYPES = {"plane": 0, "sphere": 2, "cylinder": 5, "box": 6, "mesh": 7}  # mjtGeom [ext]
 
@@ -29,7 +29,7 @@ I32, U32, F64 = C.c_int32, C.c_uint32, C.c_double
 FIELDS = [
     ("magic", U32, (), "D3IL_BLOB_MAGIC"),
     ("version", U32, (), "D3IL_BLOB_VERSION"),
-    ("task_id", I32, (), "0 avoiding, 1 pushing, 2 sorting, 3 stacking"),
+    ("task_id", I32, (), "0 avoiding, 1 pushing, 2 sorting, 3 stacking, 4 aligning (oracle only)"),
     ("nbody", I32, (), ""), ("njnt", I32, (), ""), ("ngeom", I32, (), ""),
     ("nu", I32, (), ""), ("nexclude", I32, (), ""), ("nchain", I32, (), ""),
     ("iterations", I32, (), "solver iteration cap (MuJoCo default 100)"),
@@ -272,6 +272,9 @@ def pack(js: dict) -> ModelBlob:
         for k in range(3):
             b.task_f[k], b.task_f[3 + k] = tc["target_pos1"][k], tc["target_pos2"][k]
         b.task_f[6] = tc["target_min_dist"]
+    if js["task"] == "aligning":
+        b.task_f[0], b.task_f[1], b.task_f[2] = tc["pos_min_dist"], tc["rot_min_dist"], tc["robot_box_dist"]
+        b.task_f[3] = bname[tc["target_body"]]
     return b
 
 

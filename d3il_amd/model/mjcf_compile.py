@@ -502,6 +502,35 @@ def build_sorting(num_boxes=4):
     return to_blob(m, "sorting", tc)
 
 
+def aligning_objects():
+    """aligning_objects.py:13-66 restated as data: the push box (models/mj/common-objects/robot_push_box/robot_push_box.xml: ONE free body with five
+    box geoms - a 10 x 10 x 2 cm plate of 1 kg, friction 0.3 with priority 1, and four 1 g walls) and the target (target_box.xml: sites only, no
+    geoms, no joint - it only carries the goal pose); both start at pos 0.6 0.15 0, quat 1 0 0 0 (MjXmlLoadable overrides the file's pose)."""
+    objs = []
+    for fname, name in (("robot_push_box.xml", "aligning_box"), ("target_box.xml", "target_box")):
+        root = ET.parse(os.path.join(D3IL, "models/mj/common-objects/robot_push_box", fname)).getroot()
+        body = root.find("worldbody").find("body")
+        body.set("name", name)
+        body.set("pos", "0.6 0.15 0.0")
+        body.set("quat", "1 0 0 0")
+        for site in body.findall("site"):
+            body.remove(site)
+        objs.append(body)
+    return objs
+
+
+def build_aligning():
+    m = build_scene("panda_rod_invisible.xml", aligning_objects(), "aligning")
+    tc = dict(
+        n_substeps=35, max_steps=400,                        # aligning.py:134-135
+        init_end_eff_pos=[0.525, -0.35, 0.25], init_end_eff_quat=[0, 1, 0, 0],   # aligning_objects.py:13, aligning.py:274-287
+        rod_geom="rod:geom_rb0", tcp_body="tcp_rb0",
+        objects=["aligning_box"], target_body="target_box",
+        pos_min_dist=0.018, rot_min_dist=0.048, robot_box_dist=0.051,             # aligning.py:215-218
+    )
+    return to_blob(m, "aligning", tc)
+
+
 def load_stl_vertices(path):
     """Unique vertices of a binary STL file (models/mj/robot/assets/*.stl)."""
     import struct
@@ -585,6 +614,10 @@ def main():
     with open(os.path.join(out_dir, "sorting_2.json"), "w") as f:
         json.dump(blob, f, indent=1)
     print("sorting-2: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
+    blob = build_aligning()
+    with open(os.path.join(out_dir, "aligning.json"), "w") as f:
+        json.dump(blob, f, indent=1)
+    print("aligning: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
     blob = build_stacking()
     with open(os.path.join(out_dir, "stacking.json"), "w") as f:
         json.dump(blob, f, indent=1)

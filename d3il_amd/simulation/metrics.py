@@ -87,3 +87,11 @@ def stacking_metrics(counts_1, counts_2, counts_3, n_success_1: int, n_success_2
     e3, k3 = mode_entropy_kl(counts_3, n_trajectories_per_context, prior_3, 6)
     return dict(successes=r3, successes_1_box=r1, successes_2_boxes=r2, entropy_1=e1, KL_1=k1, entropy_2=e2, KL_2=k2,
                 entropy_3=e3, KL_3=k3, score=r1 + r2 + r3)
+
+
+def aligning_metrics(mode_counts, n_success: int, n_rollouts: int, n_trajectories_per_context: int, distance_sum: float = 0.0):
+    """Metric tail of ``Aligning_Sim.test_agent`` (simulation/aligning_sim.py:160-204) from integer counts: the Pushing formulas with TWO behaviour
+    modes (0: the rod pushed from inside the box walls, 1: from outside; aligning.py:288-312).  Returns what the reference logs:
+    (score = 0.5 (success rate + entropy), success rate, entropy, mean distance, mode_probs)."""
+    success_rate, entropy, mode_probs = pushing_metrics(mode_counts, n_success, n_rollouts, n_trajectories_per_context, n_modes=2)
+    return 0.5 * (success_rate + entropy), success_rate, entropy, float(distance_sum) / max(n_rollouts, 1), mode_probs

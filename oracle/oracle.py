@@ -251,6 +251,30 @@ class Oracle:
                               C.byref(md), C.byref(rew))
         return obs, bool(succ.value), mode.value, first.value, md.value, rew.value
 
+    # ---- env level (Aligning; oracle only so far - DESIGN section 17.8)
+    def align_reset(self, ctx):
+        """ctx f64[14]: box (x, y, 0, quat) | target (x, y, 0, quat) -> obs f32[17] (robot xyz | box pos, quat | target pos, quat)."""
+        ctx = np.ascontiguousarray(ctx, float).reshape(14)
+        obs = np.zeros(17, dtype=np.float32)
+        self.L.orc_align_reset(self.h, _p(ctx), _p(obs))
+        return obs
+
+    def align_step(self, action):
+        action = np.ascontiguousarray(action, float)
+        obs = np.zeros(17, dtype=np.float32)
+        done, mode, succ = C.c_int(0), C.c_int(0), C.c_int(0)
+        rew, md = C.c_double(0), C.c_double(0)
+        self.L.orc_align_step(self.h, _p(action), _p(obs), C.byref(done), C.byref(rew), C.byref(mode), C.byref(succ), C.byref(md))
+        return obs, rew.value, bool(done.value), dict(mode=mode.value, success=bool(succ.value), mean_distance=md.value)
+
+    def align_logic(self, box7, target7, tcp):
+        box7, target7, tcp = (np.ascontiguousarray(x, float) for x in (box7, target7, tcp))
+        obs = np.zeros(17, dtype=np.float32)
+        succ, mode = C.c_int(0), C.c_int(0)
+        md, rew = C.c_double(0), C.c_double(0)
+        self.L.orc_align_logic(self.h, _p(box7), _p(target7), _p(tcp), _p(obs), C.byref(succ), C.byref(mode), C.byref(md), C.byref(rew))
+        return obs, bool(succ.value), mode.value, md.value, rew.value
+
     # ---- env level (Sorting; oracle only so far)
     def sort_reset(self, ctx):
         ctx = np.ascontiguousarray(ctx, float).reshape(-1)

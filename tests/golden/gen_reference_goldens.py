@@ -493,6 +493,90 @@ def gen_sort_stack_task():
     np.savez_compressed(os.path.join(HERE, "ref_sort_stack_task.npz"), **out)
 
 
+def gen_aligning_task():
+    """Robot_Push_Env task logic of the Aligning task (aligning.py:223-340: observation, check_mode, reward, early termination) and the metric
+    tail of Aligning_Sim.test_agent (aligning_sim.py:160-204, two behaviour modes: pushing from inside / from outside), driven with synthetic
+    box / target poses through a fake scene; plus the reference's test contexts as data."""
+    from envs.gym_aligning_env.gym_aligning.envs.aligning import Robot_Push_Env, rotation_distance
+    import simulation.aligning_sim as S
+    import torch
+
+    rng = np.random.default_rng(11)
+    env = object.__new__(Robot_Push_Env)
+    env.push_box, env.target_box = "box", "target"
+    env.if_vision = False
+    env.pos_min_dist, env.rot_min_dist, env.robot_box_dist = 0.018, 0.048, 0.051          # aligning.py:215-218
+    poses = {}
+    scene = type("S", (), {})()
+    scene.get_obj_pos = lambda o: poses[o][0].copy()
+    scene.get_obj_quat = lambda o: poses[o][1].copy()
+    env.scene = scene
+    tcp = np.zeros(3)
+    env.robot_state = lambda: tcp.copy()
+    E, T = 60, 48
+    box = np.zeros((E, T, 7)); target = np.zeros((E, 7)); rob = np.zeros((E, T, 3))
+    obs = np.zeros((E, T, 17), dtype=np.float32)
+    mode = np.zeros((E, T), dtype=np.int64); meand = np.zeros((E, T)); succ = np.zeros((E, T), dtype=bool); rew = np.zeros((E, T))
+
+    def yawq(a):
+        return np.array([np.cos(a / 2), 0.0, 0.0, np.sin(a / 2)])
+
+    for e in range(E):
+        env.terminated = False
+        tp = np.array([rng.uniform(0.4, 0.6), rng.uniform(0.2, 0.35), 0.0]); ta = rng.uniform(-np.pi / 2, np.pi / 2)
+        poses["target"] = (tp, yawq(ta)); target[e, :3], target[e, 3:] = tp, yawq(ta)
+        p = np.array([rng.uniform(0.4, 0.6), rng.uniform(-0.25, -0.1), rng.uniform(0.0, 0.012)]); a = rng.uniform(-np.pi / 2, np.pi / 2)
+        for t in range(T):
+            # the box drifts to the target pose (position and yaw), some episodes with noise, a sign-flipped or un-normalised quaternion, a tilt
+            p = p + 0.12 * (tp + np.array([0, 0, 0.0105]) - p) + rng.normal(scale=0.002, size=3) * (e % 3 != 0)
+            a = a + 0.12 * (ta - a) + rng.normal(scale=0.01) * (e % 3 != 0)
+            q = yawq(a)
+            if e % 4 == 1:
+                q = -q
+            if e % 5 == 2:
+                q = q * (1 + 1e-3 * rng.normal())
+            if e % 6 == 3:
+                q = q + np.array([0, 0.01, -0.01, 0]) * rng.normal()
+            poses["box"] = (p.copy(), q)
+            box[e, t, :3], box[e, t, 3:] = p, q
+            # the rod: inside the box walls, just outside them, or far away
+            r = rng.uniform(0, 0.1) if t % 3 else rng.uniform(0.045, 0.057)
+            ang = rng.uniform(0, 2 * np.pi)
+            tcp[:] = [p[0] + r * np.cos(ang), p[1] + r * np.sin(ang), rng.uniform(0.02, 0.25)]
+            rob[e, t] = tcp
+            obs[e, t] = env.get_observation()
+            succ[e, t] = env._check_early_termination()
+            mode[e, t], meand[e, t] = env.check_mode()
+            rew[e, t] = env.get_reward()
+    rd = np.array([rotation_distance(box[e, t, 3:], target[e, 3:]) for e in range(E) for t in range(T)]).reshape(E, T)
+    # metric tail with a stubbed rollout
+    nc, nt = 30, 8
+    me = rng.integers(0, 2, size=(nc, nt)).astype(np.float32)
+    su = (rng.uniform(size=(nc, nt)) < 0.6).astype(np.float32)
+    su[5] = 0
+    md = rng.uniform(0, 0.3, size=(nc, nt)).astype(np.float32)
+
+    def fake_eval(self, agent, contexts, n_trajectories, mode_encoding, successes, mean_distance, pid, cpu_set):
+        mode_encoding[:] = torch.tensor(me)
+        successes[:] = torch.tensor(su)
+        mean_distance[:] = torch.tensor(md)
+
+    logged = {}
+    S.Aligning_Sim.eval_agent = fake_eval
+    S.wandb.log = lambda d, *a, **k: logged.update(d)
+    sim = S.Aligning_Sim(seed=0, device="cpu", render=False, n_cores=1, n_contexts=nc, n_trajectories_per_context=nt)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim.test_agent(agent=None)
+    ctx = np.load(os.path.join(ref_shims.REF, "environments/dataset/data/aligning/test_contexts.pkl"), allow_pickle=True)
+    ctx_arr = np.array([np.concatenate([np.asarray(a_, dtype=np.float64).reshape(-1) for a_ in c]) for c in ctx])   # [n][3 + 4 + 3 + 4]: (x, y, yaw deg), quat, target ...
+    np.savez_compressed(os.path.join(HERE, "ref_aligning_task.npz"), box=box, target=target, rob=rob, obs=obs, mode=mode, mean_distance=meand, succ=succ,
+                        reward=rew, rot_dist=rd, metric_mode=me, metric_succ=su, metric_dist=md,
+                        metric_success_rate=float(logged["Metrics/successes"]), metric_entropy=float(logged["Metrics/entropy"]),
+                        metric_distance=float(logged["Metrics/distance"]), metric_score=float(logged["score"]), test_contexts=ctx_arr)
+    print("aligning task: success %.4f entropy %.6f; modes seen %s; successes %d; %d test contexts" % (
+        logged["Metrics/successes"], logged["Metrics/entropy"], np.unique(mode), succ.sum(), len(ctx_arr)))
+
+
 if __name__ == "__main__":
     gen_ik()
     gen_pd_finger()
@@ -501,3 +585,4 @@ if __name__ == "__main__":
     gen_pushing_task()
     gen_sorting_stacking_metrics()
     gen_sort_stack_task()
+    gen_aligning_task()
