@@ -20,6 +20,7 @@ batch == the reference's batch-1 ``predict`` of environment i).
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -137,6 +138,36 @@ def _layer_norm(ln: nn.LayerNorm, x):
     return ln(x)
 
 
+_MLP_PACK_IDX = {}
+
+
+def mlp_pack_index(C: int, H: int, device) -> torch.Tensor:
+    """Gather index that puts the two weight matrices of a transformer MLP (fc1.weight [H, C], fc2.weight [C, H], flattened and concatenated, plus one
+    trailing zero) into the per-chunk order d3il_mlp_gelu_residual_f32 copies to LDS: chunk c (16 hidden units) = 16 blocks of [4 g][16 i][4 e] floats (lane 16 g + i reads its float4 at [block][lane]);
+    blocks q < 8: fc1.weight[16 c + i][4 (4 q + e) + g] (the A operand of step s = 4 q + e of the first product, zero for s >= C / 4); blocks 8 + t:
+    fc2.weight[16 t + i][16 c + 4 g + e] (the A operand of step e of output tile t of the second product, zero for rows >= C)."""
+    key = (C, H, str(device))
+    if key not in _MLP_PACK_IDX:
+        c = torch.arange(H // 16).view(-1, 1, 1, 1, 1)
+        blk = torch.arange(8).view(1, -1, 1, 1, 1)
+        g = torch.arange(4).view(1, 1, -1, 1, 1)          # lane = 16 g + i: the float4 of a lane sits at [block][lane]
+        i = torch.arange(16).view(1, 1, 1, -1, 1)
+        e = torch.arange(4).view(1, 1, 1, 1, -1)
+        zero = C * H * 2
+        s = 4 * blk + e
+        i1 = torch.where(s < C // 4, (16 * c + i) * C + 4 * s + g, torch.full_like(s + c + i + g, zero))
+        row = 16 * blk + i
+        i2 = torch.where(row < C, C * H + row * H + 16 * c + 4 * g + e, torch.full_like(row + c + g + e, zero))
+        _MLP_PACK_IDX[key] = torch.cat((i1.expand(H // 16, 8, 4, 16, 4), i2.expand(H // 16, 8, 4, 16, 4)), dim=1).reshape(-1).to(device)
+    return _MLP_PACK_IDX[key]
+
+
+def pack_mlp_weights(fc1: nn.Linear, fc2: nn.Linear) -> torch.Tensor:
+    H, C = fc1.weight.shape
+    flat = torch.cat((fc1.weight.reshape(-1), fc2.weight.reshape(-1), fc1.weight.new_zeros(1)))
+    return flat[mlp_pack_index(C, H, fc1.weight.device)]
+
+
 class _Block(nn.Module):                   # score_gpts.py:83-115
     def __init__(self, n_embd, n_heads, block_size):
         super().__init__()
@@ -146,7 +177,20 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
 
     def forward(self, x):
         x = x + self.attn(_layer_norm(self.ln1, x))
-        return x + self.mlp(_layer_norm(self.ln2, x))
+        h = _layer_norm(self.ln2, x)
+        fc1, fc2 = self.mlp[0], self.mlp[2]
+        if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and h.is_contiguous() and fc1.weight.shape == (480, 120)
+                and x.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0 and os.environ.get("D3IL_POLICY_FUSED_MLP", "1") == "1"):
+            # device path: fc1 + GELU + fc2 + residual in ONE kernel on the f32 matrix cores (d3il_mlp_gelu_residual_f32): the [B T][480] hidden
+            # activations never reach memory.  The weights are re-packed every call (one gather, 0.5 MB) so that an EMA swap or a captured
+            # graph never sees a stale copy.
+            from . import capi
+            wp = pack_mlp_weights(fc1, fc2)
+            out = torch.empty_like(x)
+            capi.check(capi.load().d3il_mlp_gelu_residual_f32(h.data_ptr(), x.data_ptr(), wp.data_ptr(), fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(),
+                                                               x.numel() // x.shape[-1], 120, 480, torch.cuda.current_stream(x.device).cuda_stream))
+            return out
+        return x + self.mlp(h)
 
 
 class DiffusionGPT(nn.Module):

@@ -162,6 +162,10 @@ int d3il_attention_causal_f32(const float* qkv, float* out, int B, int T, int H,
  * the transformer of the reference's BESO policy normalises [B * T][120] activations 13 times per denoising call
  * (score_gpts.py:83-115, :353).  x, y f32 [rows][C]; 16-byte aligned device pointers. */
 int d3il_layernorm_f32(const float* x, const float* weight, const float* bias, float* y, long rows, int C, float eps, void* stream);
+/* Fused transformer MLP of the batched DiffusionGPT (score_gpts.py:83-115: x + fc2(GELU(fc1(h))), h = ln2(x)) on the f32 matrix cores:
+ * out[rows][C] = x + b2 + W2 GELU(W1 h + b1).  w_packed = both weight matrices in the per-chunk LDS order of the kernel (d3il_amd/policies.py
+ * pack_mlp_weights; H / 16 chunks of 4096 floats).  Built for C = 120, H = 480 (D3IL_EUNSUPPORTED otherwise); all device pointers, 16-byte aligned. */
+int d3il_mlp_gelu_residual_f32(const float* h, const float* x, const float* w_packed, const float* b1, const float* b2, float* out, long rows, int C, int H, void* stream);
 
 /* Per-context episode tally, filled by d3il_auto_reset before it resets: table i64 [n_ctx][D3IL_TALLY_ROW] (caller-owned device
  * memory, caller zeroes it), row ctx_id[env] (device i32[n_envs]; NULL = row 0) += {episodes, successes, successes by mode code}
