@@ -282,16 +282,37 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_auto_reset(const PandaConsts*
 // a workgroup.  1860 MFMAs per 16 rows; 14.7 MFLOP per 64-row workgroup against 32 KB of weight traffic from L2.
 typedef float mlp_f4 __attribute__((ext_vector_type(4)));
 constexpr int MLP_C = 120, MLP_H = 480, MLP_CHUNKS = MLP_H / 16, MLP_CHUNK_F = 16 * 256;      // floats per packed chunk
+// The row of a lane in the B-operand order of the products below: lane (g, j) holds elements 4 s + g of row j.  With ln_w the row is layer-normalised
+// first (nn.LayerNorm over the 120 features, biased variance): the four lane groups of a row each hold 30 of its elements, so the two row sums are
+// a 30-term sum per lane and two cross-group exchanges.
+__device__ __forceinline__ void mlp_load_row(const float* __restrict__ src, long rr, int g, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, float* hk) {
+#pragma unroll
+  for (int s2 = 0; s2 < MLP_C / 4; s2++) hk[s2] = src[rr * MLP_C + 4 * s2 + g];
+  if (ln_w) {
+    float sum = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < MLP_C / 4; s2++) sum += hk[s2];
+    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / MLP_C);
+    float var = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < MLP_C / 4; s2++) { const float d = hk[s2] - mean; var += d * d; }
+    var += __shfl_xor(var, 16); var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / MLP_C) + eps);
+#pragma unroll
+    for (int s2 = 0; s2 < MLP_C / 4; s2++) hk[s2] = (hk[s2] - mean) * rstd * ln_w[4 * s2 + g] + ln_b[4 * s2 + g];
+  }
+}
 __global__ __launch_bounds__(256) void k_mlp_gelu_residual_f32(const float* __restrict__ h, const float* __restrict__ x, const float* __restrict__ wp,
-                                                                const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, long M) {
+                                                                const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, long M,
+                                                                const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
   __shared__ mlp_f4 sw[2][MLP_CHUNK_F / 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const long row0 = (long)blockIdx.x * 64 + wave * 16, row = row0 + j;
   const bool live = row < M;
   const long rr = live ? row : (M - 1);
   float hk[MLP_C / 4];
-#pragma unroll
-  for (int s2 = 0; s2 < MLP_C / 4; s2++) hk[s2] = h[rr * MLP_C + 4 * s2 + g];
+  mlp_load_row(h, rr, g, ln_w, ln_b, eps, hk);
   mlp_f4 acc2[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) acc2[t] = mlp_f4{0.f, 0.f, 0.f, 0.f};
@@ -338,6 +359,53 @@ __global__ __launch_bounds__(256) void k_mlp_gelu_residual_f32(const float* __re
     if (col >= MLP_C) continue;
     const mlp_f4 xr = *(const mlp_f4*)(x + row * MLP_C + col), bb = *(const mlp_f4*)(b2 + col);
     *(mlp_f4*)(out + row * MLP_C + col) = xr + bb + acc2[t];
+  }
+}
+// out[M][N] = (LayerNorm)(xin)[M][120] W^T + bias (+ resid): the linear layers of the DiffusionGPT block with 120 input features (query | key | value in
+// one product, the attention output projection with the residual) on the f32 matrix cores.  Same operand scheme as the first product of the MLP kernel:
+// D[n][row] per tile of 16 outputs (30 MFMA steps), the lane's four D registers are four consecutive outputs of its row - one float4 store.
+__global__ __launch_bounds__(256) void k_linear120_f32(const float* __restrict__ xin, const float* __restrict__ wp, const float* __restrict__ bias, const float* __restrict__ resid,
+                                                        float* __restrict__ out, long M, int N, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
+  __shared__ mlp_f4 sw[2][8 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const long row = (long)blockIdx.x * 64 + wave * 16 + j;
+  const bool live = row < M;
+  const long rr = live ? row : (M - 1);
+  float hk[MLP_C / 4];
+  mlp_load_row(xin, rr, g, ln_w, ln_b, eps, hk);
+  const int ntiles = (N + 15) / 16;
+  const mlp_f4* wp4 = (const mlp_f4*)wp;
+  mlp_f4 pre[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) sw[0][tid + 256 * q] = wp4[tid + 256 * q];
+  __syncthreads();
+  for (int t = 0; t < ntiles; t++) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) pre[q] = wp4[(long)(t + 1) * 512 + tid + 256 * q];
+    }
+    mlp_f4 acc = mlp_f4{0.f, 0.f, 0.f, 0.f}, acc_b = mlp_f4{0.f, 0.f, 0.f, 0.f};      // two accumulators: the dependent MFMA chain is half as long
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const mlp_f4 a4 = sw[cur][q * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (4 * q + e < MLP_C / 4) {
+        if (e & 1) acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], hk[4 * q + e], acc_b, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], hk[4 * q + e], acc, 0, 0, 0);
+      }
+    }
+    const int col = 16 * t + 4 * g;
+    if (live && col < N) {
+      mlp_f4 v = acc + acc_b + *(const mlp_f4*)(bias + col);
+      if (resid) v += *(const mlp_f4*)(resid + row * (long)N + col);
+      *(mlp_f4*)(out + row * (long)N + col) = v;
+    }
+    if (t + 1 < ntiles) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) sw[cur ^ 1][tid + 256 * q] = pre[q];
+    }
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void k_layernorm_f32(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
@@ -962,13 +1030,29 @@ int d3il_layernorm_f32(const float* x, const float* weight, const float* bias, f
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }
+int d3il_linear120_f32(const float* xin, const float* ln_weight, const float* ln_bias, float ln_eps, const float* w_packed, const float* bias, const float* resid, float* out,
+                       long rows, int N, void* stream) {
+  if (!xin || !w_packed || !bias || !out) return fail(D3IL_EINVAL, "d3il_linear120_f32: null argument");
+  if ((ln_weight == nullptr) != (ln_bias == nullptr)) return fail(D3IL_EINVAL, "d3il_linear120_f32: LayerNorm weight and bias come together");
+  if (rows < 0 || N < 4 || N % 4 != 0) return fail(D3IL_EINVAL, "d3il_linear120_f32: needs rows >= 0 and N a positive multiple of 4");
+  if (((uintptr_t)xin | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)resid | (uintptr_t)out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_linear120_f32: pointers must be 16-byte aligned");
+  if (rows == 0) return D3IL_OK;
+  hipLaunchKernelGGL(k_linear120_f32, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, xin, w_packed, bias, resid, out, rows, N, ln_weight, ln_bias, ln_eps);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
 int d3il_mlp_gelu_residual_f32(const float* h, const float* x, const float* w_packed, const float* b1, const float* b2, float* out, long rows, int C, int H, void* stream) {
+  return d3il_mlp_ln_gelu_residual_f32(h, nullptr, nullptr, 0.f, x, w_packed, b1, b2, out, rows, C, H, stream);
+}
+int d3il_mlp_ln_gelu_residual_f32(const float* h, const float* ln_weight, const float* ln_bias, float ln_eps, const float* x, const float* w_packed, const float* b1, const float* b2,
+                                  float* out, long rows, int C, int H, void* stream) {
+  if ((ln_weight == nullptr) != (ln_bias == nullptr)) return fail(D3IL_EINVAL, "d3il_mlp_ln_gelu_residual_f32: LayerNorm weight and bias come together");
   if (!h || !x || !w_packed || !b1 || !b2 || !out) return fail(D3IL_EINVAL, "d3il_mlp_gelu_residual_f32: null argument");
   if (C != MLP_C || H != MLP_H) return fail(D3IL_EUNSUPPORTED, "d3il_mlp_gelu_residual_f32: built for n_embd 120, hidden 480 (the DiffusionGPT of the BESO configs)");
   if (rows < 0) return fail(D3IL_EINVAL, "d3il_mlp_gelu_residual_f32: negative row count");
   if (((uintptr_t)h | (uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b2 | (uintptr_t)out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_mlp_gelu_residual_f32: pointers must be 16-byte aligned");
   if (rows == 0) return D3IL_OK;
-  hipLaunchKernelGGL(k_mlp_gelu_residual_f32, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, x, w_packed, b1, b2, out, rows);
+  hipLaunchKernelGGL(k_mlp_gelu_residual_f32, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, x, w_packed, b1, b2, out, rows, ln_weight, ln_bias, ln_eps);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }

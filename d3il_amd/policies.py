@@ -162,6 +162,28 @@ def mlp_pack_index(C: int, H: int, device) -> torch.Tensor:
     return _MLP_PACK_IDX[key]
 
 
+def linear120_pack_index(N: int, device) -> torch.Tensor:
+    """Gather index for d3il_linear120_f32: weight [N, 120] (flattened, plus one trailing zero) -> ceil(N / 16) tiles of 8 blocks of [4 g][16 i][4 e] floats,
+    block q of tile t: W[16 t + i][4 (4 q + e) + g] (zero beyond N rows / 30 steps)."""
+    key = ("lin", N, str(device))
+    if key not in _MLP_PACK_IDX:
+        nt = (N + 15) // 16
+        t = torch.arange(nt).view(-1, 1, 1, 1, 1)
+        q = torch.arange(8).view(1, -1, 1, 1, 1)
+        g = torch.arange(4).view(1, 1, -1, 1, 1)
+        i = torch.arange(16).view(1, 1, 1, -1, 1)
+        e = torch.arange(4).view(1, 1, 1, 1, -1)
+        s_, row = 4 * q + e, 16 * t + i
+        idx = torch.where((s_ < 30) & (row < N), row * 120 + 4 * s_ + g, torch.full_like(row + s_ + g, N * 120))
+        _MLP_PACK_IDX[key] = idx.reshape(-1).to(device)
+    return _MLP_PACK_IDX[key]
+
+
+def pack_linear120_weights(weight: torch.Tensor) -> torch.Tensor:
+    flat = torch.cat((weight.reshape(-1), weight.new_zeros(1)))
+    return flat[linear120_pack_index(weight.shape[0], weight.device)]
+
+
 def pack_mlp_weights(fc1: nn.Linear, fc2: nn.Linear) -> torch.Tensor:
     H, C = fc1.weight.shape
     flat = torch.cat((fc1.weight.reshape(-1), fc2.weight.reshape(-1), fc1.weight.new_zeros(1)))
@@ -175,22 +197,63 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
         self.attn = _CausalSelfAttention(n_embd, n_heads, block_size)
         self.mlp = nn.Sequential(nn.Linear(n_embd, 4 * n_embd), nn.GELU(), nn.Linear(4 * n_embd, n_embd), nn.Dropout(0.0))
 
+    def _fused_static_ok(self):
+        return (self.mlp[0].weight.shape == (480, 120) and self.mlp[0].weight.is_cuda and self.mlp[0].weight.dtype == torch.float32 and 120 // self.attn.n_head <= 32
+                and os.environ.get("D3IL_POLICY_FUSED_MLP", "1") == "1")
+
+    def _fused_ok(self, x):
+        return self._fused_static_ok() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 120 and x.data_ptr() % 16 == 0 and x.shape[1] <= 32
+
+    def ensure_packed(self):
+        """Packed copies of the block's weights in the tile order of the matrix-core kernels, in PERSISTENT device buffers refreshed in place whenever a
+        parameter has changed (tensor version counters: no device synchronisation).  The addresses never change, so a captured HIP graph keeps reading the
+        current weights as long as this runs before every replay (BESOPolicy.predict_batch does) - e.g. after the EMA swap of a rollout."""
+        a, fc1, fc2 = self.attn, self.mlp[0], self.mlp[2]
+        params = (a.query.weight, a.key.weight, a.value.weight, a.query.bias, a.key.bias, a.value.bias, a.proj.weight, fc1.weight, fc2.weight)
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if getattr(self, "_pack_key", None) == key:
+            return
+        dev = fc1.weight.device
+        if getattr(self, "_wp_qkv", None) is None or self._wp_qkv.device != dev:
+            self._wp_qkv = torch.empty(linear120_pack_index(360, dev).numel(), dtype=torch.float32, device=dev)
+            self._wp_proj = torch.empty(linear120_pack_index(120, dev).numel(), dtype=torch.float32, device=dev)
+            self._wp_mlp = torch.empty(mlp_pack_index(120, 480, dev).numel(), dtype=torch.float32, device=dev)
+            self._b_qkv = torch.empty(360, dtype=torch.float32, device=dev)
+        z = fc1.weight.new_zeros(1)
+        with torch.no_grad():
+            torch.index_select(torch.cat((a.query.weight.reshape(-1), a.key.weight.reshape(-1), a.value.weight.reshape(-1), z)), 0, linear120_pack_index(360, dev), out=self._wp_qkv)
+            torch.index_select(torch.cat((a.proj.weight.reshape(-1), z)), 0, linear120_pack_index(120, dev), out=self._wp_proj)
+            torch.index_select(torch.cat((fc1.weight.reshape(-1), fc2.weight.reshape(-1), z)), 0, mlp_pack_index(120, 480, dev), out=self._wp_mlp)
+            torch.cat((a.query.bias, a.key.bias, a.value.bias), dim=0, out=self._b_qkv)
+        self._pack_key = key
+
     def forward(self, x):
-        x = x + self.attn(_layer_norm(self.ln1, x))
-        h = _layer_norm(self.ln2, x)
-        fc1, fc2 = self.mlp[0], self.mlp[2]
-        if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and h.is_contiguous() and fc1.weight.shape == (480, 120)
-                and x.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0 and os.environ.get("D3IL_POLICY_FUSED_MLP", "1") == "1"):
-            # device path: fc1 + GELU + fc2 + residual in ONE kernel on the f32 matrix cores (d3il_mlp_gelu_residual_f32): the [B T][480] hidden
-            # activations never reach memory.  The weights are re-packed every call (one gather, 0.5 MB) so that an EMA swap or a captured
-            # graph never sees a stale copy.
+        if self._fused_ok(x):
+            # device path, four kernels of the rollout library per block, all GEMMs on the f32 matrix cores with the LayerNorms, biases, GELU and residuals
+            # fused in: ln1 + (query | key | value) product -> causal attention -> output projection + residual -> ln2 + fc1 + GELU + fc2 + residual
+            # (the [B T][480] hidden activations stay in registers)
             from . import capi
-            wp = pack_mlp_weights(fc1, fc2)
+            L = capi.load()
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            B, T, C = x.shape
+            M = B * T
+            a = self.attn
+            if not torch.cuda.is_current_stream_capturing():
+                self.ensure_packed()
+            qkv = torch.empty(B, T, 3 * C, dtype=torch.float32, device=x.device)
+            capi.check(L.d3il_linear120_f32(x.data_ptr(), self.ln1.weight.data_ptr(), self.ln1.bias.data_ptr(), float(self.ln1.eps), self._wp_qkv.data_ptr(), self._b_qkv.data_ptr(), None,
+                                            qkv.data_ptr(), M, 3 * C, st))
+            y = torch.empty_like(x)
+            capi.check(L.d3il_attention_causal_f32(qkv.data_ptr(), y.data_ptr(), B, T, a.n_head, C // a.n_head, st))
+            x1 = torch.empty_like(x)
+            capi.check(L.d3il_linear120_f32(y.data_ptr(), None, None, 0.0, self._wp_proj.data_ptr(), a.proj.bias.data_ptr(), x.data_ptr(), x1.data_ptr(), M, C, st))
+            fc1, fc2 = self.mlp[0], self.mlp[2]
             out = torch.empty_like(x)
-            capi.check(capi.load().d3il_mlp_gelu_residual_f32(h.data_ptr(), x.data_ptr(), wp.data_ptr(), fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(),
-                                                               x.numel() // x.shape[-1], 120, 480, torch.cuda.current_stream(x.device).cuda_stream))
+            capi.check(L.d3il_mlp_ln_gelu_residual_f32(x1.data_ptr(), self.ln2.weight.data_ptr(), self.ln2.bias.data_ptr(), float(self.ln2.eps), x1.data_ptr(), self._wp_mlp.data_ptr(),
+                                                       fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
             return out
-        return x + self.mlp(h)
+        x = x + self.attn(_layer_norm(self.ln1, x))
+        return x + self.mlp(_layer_norm(self.ln2, x))
 
 
 class DiffusionGPT(nn.Module):
@@ -452,6 +515,10 @@ class BESOPolicy:
     def predict_batch(self, obs):
         s = self.scaler.scale_input(obs.to(device=self.device, dtype=torch.float32))
         n, act_dim = s.shape[0], self.min_action.shape[0]
+        if s.is_cuda:                          # packed weight copies of the fused blocks: refreshed here, OUTSIDE a captured sampling loop (an EMA swap changes them)
+            for blk in self.inner.blocks:
+                if blk._fused_static_ok():
+                    blk.ensure_packed()
         if self.obs_hist is None:
             self.obs_hist = _History(n, self.W, s.shape[1], self.device)
             self.act_hist = _History(n, self.W - 1, act_dim, self.device) if self.W > 1 else None

@@ -166,6 +166,14 @@ int d3il_layernorm_f32(const float* x, const float* weight, const float* bias, f
  * out[rows][C] = x + b2 + W2 GELU(W1 h + b1).  w_packed = both weight matrices in the per-chunk LDS order of the kernel (d3il_amd/policies.py
  * pack_mlp_weights; H / 16 chunks of 4096 floats).  Built for C = 120, H = 480 (D3IL_EUNSUPPORTED otherwise); all device pointers, 16-byte aligned. */
 int d3il_mlp_gelu_residual_f32(const float* h, const float* x, const float* w_packed, const float* b1, const float* b2, float* out, long rows, int C, int H, void* stream);
+/* The same with the LayerNorm in front fused in (h = the block's residual stream x itself, ln_weight / ln_bias / ln_eps of ln2; NULL weights = no LayerNorm). */
+int d3il_mlp_ln_gelu_residual_f32(const float* h, const float* ln_weight, const float* ln_bias, float ln_eps, const float* x, const float* w_packed, const float* b1, const float* b2,
+                                  float* out, long rows, int C, int H, void* stream);
+/* out[rows][N] = (LayerNorm)(xin)[rows][120] W^T + bias (+ resid[rows][N]) on the f32 matrix cores: the 120-input linear layers of the DiffusionGPT block
+ * (query | key | value as ONE product with N = 360 after ln1; the attention output projection with the residual, N = 120).  w_packed = W [N][120] in the
+ * kernel's tile order (d3il_amd/policies.py pack_linear120_weights: ceil(N / 16) tiles of 2048 floats).  ln_weight NULL = no LayerNorm; resid NULL = none. */
+int d3il_linear120_f32(const float* xin, const float* ln_weight, const float* ln_bias, float ln_eps, const float* w_packed, const float* bias, const float* resid, float* out,
+                       long rows, int N, void* stream);
 
 /* Per-context episode tally, filled by d3il_auto_reset before it resets: table i64 [n_ctx][D3IL_TALLY_ROW] (caller-owned device
  * memory, caller zeroes it), row ctx_id[env] (device i32[n_envs]; NULL = row 0) += {episodes, successes, successes by mode code}

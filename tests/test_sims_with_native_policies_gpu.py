@@ -87,3 +87,46 @@ def test_beso_policy_with_and_without_the_fused_mlp():
             os.environ.pop("D3IL_POLICY_GRAPH", None)
     d = float((outs["1"] - outs["0"]).abs().max())
     assert torch.isfinite(outs["1"]).all() and d < 2e-5, d
+
+
+def test_fused_linear120_and_layernorm_kernels_match_torch():
+    """d3il_linear120_f32 (LayerNorm + linear layer with 120 inputs + bias + residual on the f32 matrix cores) and the LayerNorm-fused MLP kernel against
+    torch, for the two shapes of the DiffusionGPT block (N = 360 after ln1, N = 120 with residual) and ragged row counts."""
+    import torch
+    from d3il_amd import capi, policies as P
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    L = capi.load()
+    ln = torch.nn.LayerNorm(120).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.2, 0.2)
+    st = torch.cuda.current_stream().cuda_stream
+    for N, use_ln, use_res in ((360, True, False), (120, False, True), (120, True, True), (24, False, False)):
+        lin = torch.nn.Linear(120, N).to(dev)
+        for M in (1, 17, 64, 1000, 4096 * 11):
+            x = torch.randn(M, 120, device=dev) * 2 + 0.3
+            res = torch.randn(M, N, device=dev)
+            with torch.no_grad():
+                h64 = torch.nn.functional.layer_norm(x.double(), (120,), ln.weight.double(), ln.bias.double(), ln.eps) if use_ln else x.double()
+                ref64 = torch.nn.functional.linear(h64, lin.weight.double(), lin.bias.double()) + (res.double() if use_res else 0)
+                ref32 = lin(ln(x) if use_ln else x) + (res if use_res else 0)
+                out = torch.full((M, N), float("nan"), device=dev)
+                wp = P.pack_linear120_weights(lin.weight)
+                capi.check(L.d3il_linear120_f32(x.data_ptr(), ln.weight.data_ptr() if use_ln else None, ln.bias.data_ptr() if use_ln else None, float(ln.eps), wp.data_ptr(),
+                                                lin.bias.data_ptr(), res.data_ptr() if use_res else None, out.data_ptr(), M, N, st))
+                torch.cuda.synchronize()
+            e_f, e_t = float((out.double() - ref64).abs().max()), float((ref32.double() - ref64).abs().max())
+            assert e_f < 5e-6 and e_f < 3 * e_t + 2e-7, (N, use_ln, use_res, M, e_f, e_t)
+    fc1, fc2 = torch.nn.Linear(120, 480).to(dev), torch.nn.Linear(480, 120).to(dev)
+    for M in (5, 4096):
+        x = torch.randn(M, 120, device=dev)
+        with torch.no_grad():
+            h64 = torch.nn.functional.layer_norm(x.double(), (120,), ln.weight.double(), ln.bias.double(), ln.eps)
+            ref64 = x.double() + torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(h64, fc1.weight.double(), fc1.bias.double())), fc2.weight.double(), fc2.bias.double())
+            out = torch.empty_like(x)
+            wp = P.pack_mlp_weights(fc1, fc2)
+            capi.check(L.d3il_mlp_ln_gelu_residual_f32(x.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps), x.data_ptr(), wp.data_ptr(), fc1.bias.data_ptr(),
+                                                       fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
+            torch.cuda.synchronize()
+        assert float((out.double() - ref64).abs().max()) < 4e-6
+
