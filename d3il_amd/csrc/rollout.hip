@@ -327,13 +327,17 @@ __global__ __launch_bounds__(256) void k_mlp_gelu_residual_f32(const float* __re
 #pragma unroll
       for (int q = 0; q < 4; q++) pre[q] = wp4[(long)(c + 1) * (MLP_CHUNK_F / 4) + tid + 256 * q];
     }
-    mlp_f4 acc1 = mlp_f4{0.f, 0.f, 0.f, 0.f};
+    mlp_f4 acc1 = mlp_f4{0.f, 0.f, 0.f, 0.f}, acc1b = mlp_f4{0.f, 0.f, 0.f, 0.f};      // two accumulators: the dependent MFMA chain is half as long
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const mlp_f4 a4 = sw[cur][q * 64 + lane];
 #pragma unroll
-      for (int e = 0; e < 4; e++) if (4 * q + e < MLP_C / 4) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], hk[4 * q + e], acc1, 0, 0, 0);
+      for (int e = 0; e < 4; e++) if (4 * q + e < MLP_C / 4) {
+        if (e & 1) acc1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], hk[4 * q + e], acc1b, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], hk[4 * q + e], acc1, 0, 0, 0);
+      }
     }
+    acc1 += acc1b;
     float gv[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
