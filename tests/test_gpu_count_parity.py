@@ -74,6 +74,28 @@ def test_pushing_success_and_mode_tables_over_full_episodes():
     assert abs(s["device_successes"] - s["oracle_successes"]) <= 3
 
 
+def test_pushing_tables_on_sampled_contexts():
+    """The same comparison on 120 contexts drawn like BlockContextManager.sample (seed 3) instead of the reference's 60 test contexts."""
+    from d3il_amd.agents import ScriptedGoalPushPolicy
+    from d3il_amd.envs.pushing import BlockPushVecEnv, sample_contexts
+    from d3il_amd.simulation.pushing_sim import Pushing_Sim
+    from tests import oracle_episodes as oe
+    n = 120
+    ctx = sample_contexts(n, seed=3)
+    sim = Pushing_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=n, n_trajectories_per_context=1, max_steps_per_episode=400, contexts=ctx)
+    sim.test_agent(ScriptedGoalPushPolicy("pushing", plan=np.arange(n) % 4, device="cuda:0"))
+    r = sim.last_rollout
+    assert not (r["flags"].cpu().numpy() & ((1 << 16) | (1 << 18) | (1 << 19))).any()
+    dev_rows = list(zip(r["success"].cpu().numpy().astype(bool).tolist(), r["mode"].cpu().numpy().tolist()))
+    env = BlockPushVecEnv(1, device=0)
+    q0 = env.start()[0]
+    env.close()
+    res = oe.run_many(oe.pushing_episode, [(i, ctx[i], q0, 400, i % 4) for i in range(n)])
+    orc_rows = [(s, m) for _, s, m, _, _ in res]
+    s = _compare("pushing_sampled", dev_rows, orc_rows, max_mismatch=12)
+    assert abs(s["device_successes"] - s["oracle_successes"]) <= 5 and s["oracle_successes"] >= n // 2
+
+
 def test_sorting_success_and_mode_tables_over_full_episodes():
     """Sorting-4, 60 contexts sampled like BlockContextManager.sample (seed 0: bench.py's tile), 700-step episodes
     (configs/sorting_4_config.yaml:80), scripted push-over-the-edge policy (sorting_sim.py:118-133, 191-208)."""
