@@ -436,54 +436,61 @@ __global__ __launch_bounds__(256) void k_layernorm_f32(const float* __restrict__
 
 template <int D4>      // D4 = D / 4 float4 chunks per head row (D a multiple of 4: 16-byte loads), or 0: scalar loads for any D <= 32
 __global__ __launch_bounds__(256) void k_attention_causal_f32(const float* __restrict__ qkv, float* __restrict__ out, int B, int T, int H, int D) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // ((b * H) + h) * T + i: the queries of one (b, h) sit in adjacent lanes
-  const long total = (long)B * H * T;
+  // One lane serves TWO queries of a (sequence, head): i and T - 1 - i.  Query i attends to i + 1 keys, so the pair costs T + 1 key steps whatever i is:
+  // the lanes of a wave run the same number of steps (one query per lane leaves half of the lane-steps idle under the causal mask).
+  const int TP = (T + 1) / 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // ((b * H) + h) * TP + p: the query pairs of one (b, h) sit in adjacent lanes
+  const long total = (long)B * H * TP;
   if (idx >= total) return;
-  const int i = (int)(idx % T), h = (int)((idx / T) % H);
-  const long b = idx / ((long)T * H);
+  const int p = (int)(idx % TP), h = (int)((idx / TP) % H);
+  const long b = idx / ((long)TP * H);
   const int C = H * D;
   const float* base = qkv + (b * T) * (long)(3 * C) + h * D;
   constexpr int DR = D4 > 0 ? 4 * D4 : 32;
-  float q[DR], acc[DR], kk[DR], vv[DR];
   const float scale = 1.0f / sqrtf((float)D);
-  auto load = [&](const float* p, float* r) {
+  auto load = [&](const float* ptr, float* r) {
     if constexpr (D4 > 0) {
 #pragma unroll
-      for (int c = 0; c < D4; c++) { const float4 t = reinterpret_cast<const float4*>(p)[c]; r[4 * c] = t.x; r[4 * c + 1] = t.y; r[4 * c + 2] = t.z; r[4 * c + 3] = t.w; }
+      for (int c = 0; c < D4; c++) { const float4 t = reinterpret_cast<const float4*>(ptr)[c]; r[4 * c] = t.x; r[4 * c + 1] = t.y; r[4 * c + 2] = t.z; r[4 * c + 3] = t.w; }
     } else {
 #pragma unroll
-      for (int d = 0; d < 32; d++) r[d] = d < D ? p[d] : 0.0f;
+      for (int d = 0; d < 32; d++) r[d] = d < D ? ptr[d] : 0.0f;
     }
   };
-  load(base + (long)i * 3 * C, q);
+  for (int half = 0; half < 2; half++) {
+    const int i = half == 0 ? p : T - 1 - p;
+    if (half == 1 && i == p) break;      // the middle query of an odd T
+    float q[DR], acc[DR], kk[DR], vv[DR];
+    load(base + (long)i * 3 * C, q);
 #pragma unroll
-  for (int d = 0; d < DR; d++) q[d] *= scale;
-  // online softmax; key 0 is peeled (m = score_0, l = 1, acc = v_0) so that no infinity is ever formed: the device pass is built
-  // with -ffinite-math-only, under which arithmetic on infinities is undefined
-  load(base + C, kk); load(base + 2 * C, acc);
-  float m = 0.0f, l = 1.0f;
+    for (int d = 0; d < DR; d++) q[d] *= scale;
+    // online softmax; key 0 is peeled (m = score_0, l = 1, acc = v_0) so that no infinity is ever formed: the device pass is built
+    // with -ffinite-math-only, under which arithmetic on infinities is undefined
+    load(base + C, kk); load(base + 2 * C, acc);
+    float m = 0.0f, l = 1.0f;
 #pragma unroll
-  for (int d = 0; d < DR; d++) m += q[d] * kk[d];
-  for (int j = 1; j <= i; j++) {
-    const float* kj = base + (long)j * 3 * C + C;
-    load(kj, kk); load(kj + C, vv);
-    float sc = 0.0f;
+    for (int d = 0; d < DR; d++) m += q[d] * kk[d];
+    for (int j = 1; j <= i; j++) {
+      const float* kj = base + (long)j * 3 * C + C;
+      load(kj, kk); load(kj + C, vv);
+      float sc = 0.0f;
 #pragma unroll
-    for (int d = 0; d < DR; d++) sc += q[d] * kk[d];
-    const float mn = fmaxf(m, sc), corr = __expf(m - mn), pj = __expf(sc - mn);
-    l = l * corr + pj;
+      for (int d = 0; d < DR; d++) sc += q[d] * kk[d];
+      const float mn = fmaxf(m, sc), corr = __expf(m - mn), pj = __expf(sc - mn);
+      l = l * corr + pj;
 #pragma unroll
-    for (int d = 0; d < DR; d++) acc[d] = acc[d] * corr + pj * vv[d];
-    m = mn;
-  }
-  float* o = out + (b * T + i) * (long)C + h * D;
-  const float inv = 1.0f / l;
-  if constexpr (D4 > 0) {
+      for (int d = 0; d < DR; d++) acc[d] = acc[d] * corr + pj * vv[d];
+      m = mn;
+    }
+    float* o = out + (b * T + i) * (long)C + h * D;
+    const float inv = 1.0f / l;
+    if constexpr (D4 > 0) {
 #pragma unroll
-    for (int c = 0; c < D4; c++) reinterpret_cast<float4*>(o)[c] = make_float4(acc[4 * c] * inv, acc[4 * c + 1] * inv, acc[4 * c + 2] * inv, acc[4 * c + 3] * inv);
-  } else {
+      for (int c = 0; c < D4; c++) reinterpret_cast<float4*>(o)[c] = make_float4(acc[4 * c] * inv, acc[4 * c + 1] * inv, acc[4 * c + 2] * inv, acc[4 * c + 3] * inv);
+    } else {
 #pragma unroll
-    for (int d = 0; d < 32; d++) if (d < D) o[d] = acc[d] * inv;
+      for (int d = 0; d < 32; d++) if (d < D) o[d] = acc[d] * inv;
+    }
   }
 }
 
@@ -1013,7 +1020,7 @@ int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32
 int d3il_attention_causal_f32(const float* qkv, float* out, int B, int T, int H, int D, void* stream) {
   if (!qkv || !out) return fail(D3IL_EINVAL, "d3il_attention_causal_f32: null argument");
   if (B < 0 || T < 1 || T > 32 || H < 1 || D < 1 || D > 32) return fail(D3IL_EINVAL, "d3il_attention_causal_f32: needs 1 <= T <= 32, 1 <= D <= 32");
-  const long total = (long)B * H * T;
+  const long total = (long)B * H * ((T + 1) / 2);      // one lane per pair of queries (i, T - 1 - i)
   if (total == 0) return D3IL_OK;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   const bool aligned = D % 4 == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0;
