@@ -272,6 +272,43 @@ def _random_beso(dev):
     return BESOPolicy(net, sc, window_size=5, num_sampling_steps=16, sigma_min=0.01, sigma_max=1.0, use_graph=os.environ.get("D3IL_POLICY_GRAPH", "1") == "1")
 
 
+def _beso_policy_roofline(pol, n, dev):
+    """Config 5 is policy-bound: time of one policy step and of its dominant kernel (the fused transformer MLP on the f32 matrix cores, DESIGN section
+    17.9), event-timed on the current stream after the benchmark loop; achieved TFLOP/s of that kernel against the dense f32 MFMA peak."""
+    import torch
+    from d3il_amd import capi
+    from d3il_amd.policies import pack_mlp_weights
+    F32_MFMA_PEAK_TFLOPS = 157.3
+    blk = pol.inner.blocks[0]
+    fc1, fc2 = blk.mlp[0], blk.mlp[2]
+    T = 2 * pol.W + 1
+    M = n * T
+    x = torch.randn(M, 120, device=dev)
+    out = torch.empty_like(x)
+    wp = pack_mlp_weights(fc1, fc2)
+    L = capi.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def run():
+        capi.check(L.d3il_mlp_ln_gelu_residual_f32(x.data_ptr(), blk.ln2.weight.data_ptr(), blk.ln2.bias.data_ptr(), float(blk.ln2.eps), x.data_ptr(), wp.data_ptr(),
+                                                   fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        run()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / 50
+    flops = 2.0 * M * (120 * 480) * 2
+    calls = len(pol.inner.blocks) * (len(pol.sigmas) - 1)
+    return {"bound": "mfma", "kernel": "k_mlp_gelu_residual_f32", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "kernel_ms": ms, "rows": M, "launches_per_policy_step": calls,
+            "note": "dense f32 MFMA peak of MI355X (MI355X_MICROARCH.md); the kernel runs %d times per policy step (6 blocks x 16 sampling steps), next to two linear "
+                    "kernels and the attention kernel per block" % calls}
+
+
 # ---------------------------------------------------------------------------------------------------- the benchmark
 def run(args):
     import numpy as np
@@ -505,6 +542,8 @@ def run(args):
                                  "`valu` the binding resource",
                          "valu": valu},
         }
+        if policy == "beso":
+            line["policy_roofline"] = _beso_policy_roofline(pol, n, dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(task, env.blob, q, ctx60)
         print(json.dumps(line))
