@@ -227,7 +227,9 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
             torch.cat((a.query.bias, a.key.bias, a.value.bias), dim=0, out=self._b_qkv)
         self._pack_key = key
 
-    def forward(self, x):
+    def forward(self, x, keep=None):
+        """keep: token positions (LongTensor) whose outputs are needed; the block then returns [B, len(keep), C] - attention still sees every token, the output
+        projection and the MLP run on the kept rows only (the last block of DiffusionGPT: only the action positions are decoded)."""
         if self._fused_ok(x):
             # device path, four kernels of the rollout library per block, all GEMMs on the f32 matrix cores with the LayerNorms, biases, GELU and residuals
             # fused in: ln1 + (query | key | value) product -> causal attention -> output projection + residual -> ln2 + fc1 + GELU + fc2 + residual
@@ -245,6 +247,9 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
                                             qkv.data_ptr(), M, 3 * C, st))
             y = torch.empty_like(x)
             capi.check(L.d3il_attention_causal_f32(qkv.data_ptr(), y.data_ptr(), B, T, a.n_head, C // a.n_head, st))
+            if keep is not None:
+                y, x = y.index_select(1, keep), x.index_select(1, keep)
+                M = y.shape[0] * y.shape[1]
             x1 = torch.empty_like(x)
             capi.check(L.d3il_linear120_f32(y.data_ptr(), None, None, 0.0, self._wp_proj.data_ptr(), a.proj.bias.data_ptr(), x.data_ptr(), x1.data_ptr(), M, C, st))
             fc1, fc2 = self.mlp[0], self.mlp[2]
@@ -253,6 +258,8 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
                                                        fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
             return out
         x = x + self.attn(_layer_norm(self.ln1, x))
+        if keep is not None:
+            x = x.index_select(1, keep)
         return x + self.mlp(_layer_norm(self.ln2, x))
 
 
@@ -278,9 +285,14 @@ class DiffusionGPT(nn.Module):
         pos = self.pos_emb[:, :t, :]
         state_x, action_x = self.tok_emb(states) + pos, self.action_emb(actions) + pos
         sa = torch.stack([state_x, action_x], dim=1).permute(0, 2, 1, 3).reshape(b, 2 * t, self.embed_dim)
-        x = _layer_norm(self.ln_f, self.blocks(torch.cat([emb_t, sa], dim=1)))[:, 1:, :]
-        x = x.reshape(b, x.size(1) // 2, 2, self.embed_dim).permute(0, 2, 1, 3)
-        return self.action_pred(x[:, 1])
+        x = torch.cat([emb_t, sa], dim=1)
+        for blk in self.blocks[:-1]:
+            x = blk(x)
+        # only the action positions (tokens 2, 4, ..., 2 t) are decoded: the last block's output projection and MLP, the final LayerNorm and the head run
+        # on those rows only (row-wise operations: the same numbers as decoding everything and slicing, score_gpts.py:340-361)
+        keep = torch.arange(2, 2 * t + 1, 2, device=x.device)
+        x = _layer_norm(self.ln_f, self.blocks[-1](x, keep=keep).contiguous())
+        return self.action_pred(x)
 
 
 # ------------------------------------------------------------------------------------------------ history ring buffer
