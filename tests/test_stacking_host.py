@@ -146,3 +146,26 @@ def test_palm_on_a_box_hand_hull_contact(stack_js, stack_blob, stack_init_qpos, 
             deepest = min(deepest, min(c[0] for c in hand))
     assert n_hand >= 15 and deepest < -5e-4, (n_hand, deepest)
     assert worst < 1e-6, worst
+
+
+def test_host_engine_reads_nothing_it_has_not_written(stack_blob, stack_init_qpos, stack_contexts):
+    """Read-before-write detector of the one-lane engine (hc_stack_poison: both scratch areas hold NaN before every env step; the warm start is carried in
+    the state rows): an empty gripper closing on itself - the finger <-> finger pairs - and the first steps of a grasp give the same states as without
+    the poison, bit for bit, and stay finite."""
+    from tests.hostcheck.hostcheck import lib
+    a = np.concatenate([stack_init_qpos, [0.0]])
+    runs = []
+    for poison in (0, 1):
+        lib().hc_stack_poison(poison)
+        try:
+            hc = StackHostCheck(stack_blob)
+            hc.reset(stack_init_qpos, stack_contexts[1])
+            states = []
+            for t in range(12):
+                hc.step(a)
+                states.append(hc.s.copy())
+            runs.append(np.stack(states))
+        finally:
+            lib().hc_stack_poison(0)
+    assert np.isfinite(runs[1]).all() and np.array_equal(runs[0], runs[1])
+
