@@ -26,7 +26,7 @@
 namespace d3il {
 
 constexpr int SK_NB = 3, SK_NV = 6 * SK_NB + NDOF, SK_ARM0 = 6 * SK_NB, SK_NH = SK_NV * (SK_NV + 1) / 2;   // 27 dofs, 378 packed
-constexpr int SK_MAXCON = 32, SK_MAXNS = 4, SK_MAXHV = 96, SK_MAXHANDV = 800;
+constexpr int SK_MAXCON = 32, SK_MAXNS = 4, SK_MAXHV = 72, SK_MAXHANDV = 800;      // SK_MAXHV: capacity for the finger hull (68 vertices) = nine per lane of an eight-lane MPR group
 #ifndef D3IL_SK_LANES
 #define D3IL_SK_LANES 4
 #endif
@@ -1530,7 +1530,7 @@ __device__ __forceinline__ void sk_support1_group_pre(const StackConsts& kc_, co
     for (int m = 0; m < SKG_NV; m++) if (m == bm) { mine[0] = hv[m][0]; mine[1] = hv[m][1]; mine[2] = hv[m][2]; }
     const int src = (threadIdx.x & ~(SKG - 1)) | (gbest & (SKG - 1));
     // The selected vertex goes through an opaque register move before the shuffles.  Without it (-DD3IL_SK_PRELOAD_RAW) hipcc (ROCm 7.2, -O3, 512
-    // registers per lane, 272 B of scratch) produces a kernel whose results depend on the workgroup position of an environment: the fourth MPR lane
+    // registers per lane, 224 B of scratch) produces a kernel whose results depend on the workgroup position of an environment: the fourth MPR lane
     // group of a batch reports a finger <-> finger contact that the other three, on identical data, do not (and SOLVER_FAIL flags follow); the
     // table-reading variant (-DD3IL_SK_NO_PRELOAD) shows the same defect at ~1e-6 per environment step.  Instrumented builds do not show it, the ISA
     // of this sequence is correct in both builds: the register allocation differs, not the arithmetic.  This build is clean in
