@@ -1738,7 +1738,11 @@ struct SkShapeR { double R[9], p[3]; int hull; };      // a shape with its pose 
 // MPR jobs of a round: up to eight at a time, each on a GROUP of eight lanes (job k of the batch on lanes 8 k .. 8 k + 7).  The group
 // rebuilds its owner lane's job (shapes from the LDS tables), the portal iteration runs redundantly on the eight lanes (uniform inside a
 // group) and the hull support function is spread over them (sk_support1_group: nine vertices per lane instead of 68 on one lane).
+#if defined(D3IL_SK_MPR_NOINLINE)      // experiment of DESIGN section 18.2: the MPR phase as a function of its own (own SGPR / VGPR allocation)
+__device__ __attribute__((noinline)) int sk_round_mpr(const StackConsts& kc_, sk_lds_double* smem, const int lane, const int round, const unsigned live_mask) {
+#else
 __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_double* smem, const int lane, const int round, const unsigned live_mask) {
+#endif
   D3IL_STACK_CONSTS(kc_, kc);
   int mine_kind = 0, mine_meta = 0;
   {
