@@ -429,21 +429,14 @@ def run(args):
     # the metric reduction is the library's own RCCL all-reduce (d3il_reduce_metrics); the communicator is set up once, outside the timed
     # region.  If RCCL cannot be resolved / initialised (e.g. the gloo test mode with every rank on one GPU) the line says so and the
     # reduction goes through torch.distributed instead - the numbers are integer sums either way.
-    lib_comm, reduction = None, "none (single process)"
+    lib_comm, reduction, rccl_ranks = None, "none (single process)", None
     if world > 1:
-        reduction = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
-        if torch.distributed.get_backend() == "nccl" and os.environ.get("D3IL_LIB_REDUCE", "1") == "1":
-            try:
-                lib_comm = D.LibraryComm(dev)
-                reduction = "libd3il_rollout d3il_reduce_metrics: one RCCL ncclAllReduce(sum, int64) of the tally table"
-            except Exception as exc:      # noqa: BLE001
-                print("warning: library RCCL communicator unavailable (%s); reducing through torch.distributed" % exc, file=sys.stderr)
-                ok = torch.tensor([0], device=dev)
-            ok = torch.tensor([1 if lib_comm is not None else 0], device=dev)
-            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)       # all ranks take the same path
-            if int(ok.item()) == 0 and lib_comm is not None:
-                lib_comm.close(); lib_comm = None
-                reduction = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
+        lib_comm = D.auto_comm(dev)          # collective; every failure mode is agreed on by all ranks inside LibraryComm (no rank is left behind)
+        if lib_comm is not None:
+            rccl_ranks = lib_comm.ranks()    # ncclCommCount: what RCCL itself sees - the driver's SCALE run can check it against n_gpus
+            reduction = "libd3il_rollout d3il_reduce_metrics: one RCCL ncclAllReduce(sum, int64) of the tally table"
+        else:
+            reduction = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
     t_run = 0
     preroll = 0
     if not args.no_preroll and not args.no_auto_reset:
@@ -529,7 +522,7 @@ def run(args):
                        "auto_reset": not args.no_auto_reset, "finite": finite, "flagged_envs": flagged,
                        "episodes_finished_all_ranks": int(tb[:, 0].sum()), "episodes_success_all_ranks": int(tb[:, 1].sum()),
                        "episodes_finished_rank0": int(episodes[0].item()),
-                       "metric_reduction": reduction},
+                       "metric_reduction": reduction, "rccl_ranks": rccl_ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run)" % pm_path) if pm_path else None,
                          "kernel": KERNEL[task], "kernel_ms": k_ms,
@@ -547,9 +540,7 @@ def run(args):
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(task, env.blob, q, ctx60)
         print(json.dumps(line))
-    if lib_comm is not None:
-        lib_comm.close()
-    env.close()
+    env.close()          # (the library communicator is process-wide: distributed.auto_comm)
     if world > 1:
         torch.distributed.destroy_process_group()
 

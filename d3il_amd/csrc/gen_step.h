@@ -26,7 +26,7 @@
 
 namespace d3il {
 
-constexpr int GEN_MAXNB = 4, GEN_MAXNS = 12, GEN_SEG = 24, GEN_MAXCON = GEN_MAXNB * GEN_SEG, GEN_MAXSET = GEN_MAXNS + 2;
+constexpr int GEN_MAXNB = 4, GEN_MAXNS = 20, GEN_SEG = 24, GEN_MAXCON = GEN_MAXNB * GEN_SEG, GEN_MAXSET = GEN_MAXNS + 2;
 constexpr int GEN_MAXNV = 6 * GEN_MAXNB + NDOF;     // 33
 constexpr int GEN_NH = GEN_MAXNV * (GEN_MAXNV + 1) / 2;   // 561
 #ifndef D3IL_GEN_LANES
@@ -36,12 +36,14 @@ constexpr int GEN_LANES = D3IL_GEN_LANES;     // environments per workgroup (x G
 
 struct GenConsts {
   int nb, ns, set_bb, set_rod;
+  int ns_core;                    // statics [0, ns_core): everything inside the table; [ns_core, ns): the frame beams around the table edge (only tested near it)
   double box_half[3], box_mass, box_inertia, box_invw_t;
   double st_c[GEN_MAXNS][3], st_h[GEN_MAXNS][3], st_R[GEN_MAXNS][9];
   int st_first[GEN_MAXNS];        // 1: the static geom precedes the cube geoms in the model (it is geom 1 of the pair)
   double ct_K[GEN_MAXSET], ct_B[GEN_MAXSET], ct_solimp[GEN_MAXSET][5], ct_fric[GEN_MAXSET];   // set s < ns: static s <-> cube
   double impratio, rod_invw;
-  double ws_lo[2], ws_hi[2];      // modelled workspace of the cube centres (x, y)
+  double ws_lo[2], ws_hi[2];      // modelled workspace of the cube centres (x, y): the table with its frame; a centre beyond it raises PF_OFF_TABLE
+  double in_lo[2], in_hi[2];      // the part of it in which no frame beam can be reached
   double absent[7];               // pose reported for boxes the model does not have (body id -1)
 };
 
@@ -769,7 +771,10 @@ D3IL_NOINLINE inline int gen_phase2(const GenConsts& gc_, const PushScratch sc, 
   const double rcirc2 = gc.box_half[0] * gc.box_half[0] + gc.box_half[1] * gc.box_half[1] + gc.box_half[2] * gc.box_half[2];
   int cnt = 0;
   double rec[8][7];
-  for (int s = 0; s < gc.ns; s++) {
+  // the frame beams (lab_surrounding.xml:3-114: a 19 mm rim around the table top) come last in the list and are skipped for a cube well inside the table
+  const bool near_edge = pc[0] < gc.in_lo[0] || pc[0] > gc.in_hi[0] || pc[1] < gc.in_lo[1] || pc[1] > gc.in_hi[1];
+  const int ns = near_edge ? gc.ns : gc.ns_core;
+  for (int s = 0; s < ns; s++) {
     double d2 = 0;   // sphere against the static box (in its frame): cheap exact rejection
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -1171,16 +1176,20 @@ D3IL_HOSTFN inline int build_gen_consts(const d3il_model_blob& m, const PandaCon
     gc.ct_solimp[set][0] = std::fmin(0.9999, std::fmax(0.0001, si[0])); gc.ct_solimp[set][1] = dmax;
     gc.ct_fric[set] = fr;
   };
-  // Static boxes a cube can meet: box geoms on joint-less body chains whose collision bits match the cubes' and whose
-  // bounding box reaches the modelled workspace - the table_plane footprint shrunk by 8 cm (a cube centre leaving it raises
-  // PF_OFF_TABLE), grown by the cube's circumradius, from the table top upwards.  In the Sorting scene: table_plane,
-  // support_body, the eight bin walls and the platform; the aluminium profiles around the table edge stay outside.
+  // Static boxes a cube can meet: box geoms on joint-less body chains whose collision bits match the cubes' and whose bounding box
+  // reaches the region above the table top (grown by the cube's circumradius).  Two groups: (i) what stands INSIDE the table_plane
+  // footprint shrunk by 8 cm - in the Sorting scene table_plane, support_body, the eight bin walls and the platform -, tested every
+  // sub-step; (ii) the aluminium profiles of the frame whose tops form a 19 mm rim around the table top (lab_surrounding.xml:3-114:
+  // front / back / side upper beams and the four posts), tested only for a cube whose centre has left the shrunk footprint.  A cube
+  // centre beyond the outer faces of the frame raises PF_OFF_TABLE (it would drop to the floor plane, which this engine does not model).
   const double rcirc = std::sqrt(gc.box_half[0] * gc.box_half[0] + gc.box_half[1] * gc.box_half[1] + gc.box_half[2] * gc.box_half[2]);
   int ns = 0, table = -1;
-  double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
-  for (int pass = 0; pass < 2; pass++)
+  double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0}, olo[2] = {0, 0}, ohi[2] = {0, 0};
+  bool taken[D3IL_MAXGEOM];
+  for (int g = 0; g < D3IL_MAXGEOM; g++) taken[g] = false;
+  for (int pass = 0; pass < 3; pass++) {
   for (int g = 0; g < m.ngeom; g++) {
-    if (m.geom_type[g] != D3IL_GEOM_BOX) continue;
+    if (m.geom_type[g] != D3IL_GEOM_BOX || taken[g]) continue;
     if (!((m.geom_contype[g] & m.geom_conaffinity[g0]) || (m.geom_contype[g0] & m.geom_conaffinity[g]))) continue;
     bool is_static = true;
     double p[3] = {m.geom_pos[g][0], m.geom_pos[g][1], m.geom_pos[g][2]}, R[9];
@@ -1195,25 +1204,34 @@ D3IL_HOSTFN inline int build_gen_consts(const d3il_model_blob& m, const PandaCon
       for (int i = 0; i < 9; i++) R[i] = Rn[i];
     }
     if (!is_static) continue;
-    if (m.geom_margin[g] != 0 || m.geom_gap[g] != 0) { *err = "static boxes with a contact margin are not supported"; return -1; }
     double ext[3];
     for (int i = 0; i < 3; i++) ext[i] = std::fabs(R[3 * i]) * m.geom_size[g][0] + std::fabs(R[3 * i + 1]) * m.geom_size[g][1] + std::fabs(R[3 * i + 2]) * m.geom_size[g][2];
     if (pass == 0) {   // the table top: the 0.49 x 0.98 x 0.001 slab (lab_surrounding.xml:3-4)
       if (std::fabs(m.geom_size[g][0] - 0.49) < 1e-12 && std::fabs(m.geom_size[g][1] - 0.98) < 1e-12 && std::fabs(m.geom_size[g][2] - 0.001) < 1e-12) {
         table = g;
-        for (int i = 0; i < 2; i++) { wlo[i] = p[i] - ext[i] + 0.08; whi[i] = p[i] + ext[i] - 0.08; gc.ws_lo[i] = wlo[i]; gc.ws_hi[i] = whi[i]; wlo[i] -= rcirc; whi[i] += rcirc; }
+        for (int i = 0; i < 2; i++) {
+          wlo[i] = p[i] - ext[i] + 0.08; whi[i] = p[i] + ext[i] - 0.08; gc.in_lo[i] = wlo[i]; gc.in_hi[i] = whi[i]; wlo[i] -= rcirc; whi[i] += rcirc;
+          olo[i] = p[i] - ext[i] - rcirc; ohi[i] = p[i] + ext[i] + rcirc;      // anything a cube ON the table can touch
+          gc.ws_lo[i] = p[i] - ext[i]; gc.ws_hi[i] = p[i] + ext[i];            // grown below to the outer faces of the frame
+        }
         wlo[2] = p[2] + ext[2] - rcirc;
       }
       continue;
     }
     if (table < 0) { *err = "table slab not found"; return -1; }
-    if (p[0] + ext[0] < wlo[0] || p[0] - ext[0] > whi[0] || p[1] + ext[1] < wlo[1] || p[1] - ext[1] > whi[1] || p[2] + ext[2] < wlo[2]) continue;
+    if (pass == 1) { if (p[0] + ext[0] < wlo[0] || p[0] - ext[0] > whi[0] || p[1] + ext[1] < wlo[1] || p[1] - ext[1] > whi[1] || p[2] + ext[2] < wlo[2]) continue; }
+    else if (p[0] + ext[0] < olo[0] || p[0] - ext[0] > ohi[0] || p[1] + ext[1] < olo[1] || p[1] - ext[1] > ohi[1] || p[2] + ext[2] < wlo[2]) continue;
+    if (m.geom_margin[g] != 0 || m.geom_gap[g] != 0) { *err = "static boxes with a contact margin are not supported"; return -1; }
     if (ns >= GEN_MAXNS) { *err = "too many static boxes"; return -1; }
     for (int k = 0; k < 3; k++) { gc.st_c[ns][k] = p[k]; gc.st_h[ns][k] = m.geom_size[g][k]; }
     for (int k = 0; k < 9; k++) gc.st_R[ns][k] = R[k];
     gc.st_first[ns] = g < g0 ? 1 : 0;
     mix(g, g0, ns);
+    taken[g] = true;
+    if (pass == 2) for (int i = 0; i < 2; i++) { gc.ws_lo[i] = std::fmin(gc.ws_lo[i], p[i] - ext[i]); gc.ws_hi[i] = std::fmax(gc.ws_hi[i], p[i] + ext[i]); }
     ns++;
+  }
+  if (pass == 1) gc.ns_core = ns;
   }
   gc.ns = ns;
   gc.set_bb = ns; gc.set_rod = ns + 1;

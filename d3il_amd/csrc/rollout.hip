@@ -1121,6 +1121,7 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, d3il_rccl_unique_id, int);     // ncclUniqueId is a 128-byte struct passed by value
   int (*CommDestroy)(void*);
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  int (*CommCount)(void*, int*);
   const char* (*GetErrorString)(int);
   bool ok;
 };
@@ -1138,6 +1139,7 @@ RcclApi* rccl_api() {
     a.CommInitRank = (int (*)(void**, int, d3il_rccl_unique_id, int))dlsym(hnd, "ncclCommInitRank");
     a.CommDestroy = (int (*)(void*))dlsym(hnd, "ncclCommDestroy");
     a.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(hnd, "ncclAllReduce");
+    a.CommCount = (int (*)(void*, int*))dlsym(hnd, "ncclCommCount");
     a.GetErrorString = (const char* (*)(int))dlsym(hnd, "ncclGetErrorString");
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
     return a;
@@ -1150,6 +1152,14 @@ int rccl_fail(const char* what, int rc) {
 }
 }  // namespace
 
+int d3il_rccl_available(void) { return rccl_api()->ok ? 1 : 0; }
+int d3il_comm_count(d3il_comm comm, int* ranks) {
+  if (!comm || !ranks) return fail(D3IL_EINVAL, "d3il_comm_count: null argument");
+  RcclApi* a = rccl_api();
+  if (!a->ok || !a->CommCount) return fail(D3IL_ERCCL, "d3il_comm_count: RCCL could not be resolved");
+  if (int rc = a->CommCount((void*)comm, ranks)) return rccl_fail("ncclCommCount", rc);
+  return D3IL_OK;
+}
 int d3il_comm_unique_id(d3il_rccl_unique_id* out) {
   if (!out) return fail(D3IL_EINVAL, "d3il_comm_unique_id: null argument");
   RcclApi* a = rccl_api();
@@ -1176,12 +1186,12 @@ int d3il_comm_destroy(d3il_comm comm) {
   return D3IL_OK;
 }
 int d3il_reduce_metrics(d3il_handle h, d3il_comm comm, int64_t* table_device, size_t count, void* stream) {
-  if (!h || !comm) return fail(D3IL_EINVAL, "d3il_reduce_metrics: null argument");
+  if (!comm || (!h && !table_device)) return fail(D3IL_EINVAL, "d3il_reduce_metrics: null argument");      // h may be NULL with an explicit table (a rank without environments)
   if (!table_device) { table_device = h->tally_table; count = (size_t)h->tally_nctx * D3IL_TALLY_ROW; }      // default: the table of d3il_set_tally
   if (!table_device || count == 0) return fail(D3IL_EINVAL, "d3il_reduce_metrics: no table (pass one, or register it with d3il_set_tally)");
   RcclApi* a = rccl_api();
   if (!a->ok) return fail(D3IL_ERCCL, "d3il_reduce_metrics: RCCL could not be resolved");
-  HIPCHK(hipSetDevice(h->device));
+  if (h) HIPCHK(hipSetDevice(h->device));
   // ONE in-place all-reduce(sum) of int64 counts: integer sums are bit-exact and independent of the rank order (ncclInt64 = 4, ncclSum = 0)
   if (int rc = a->AllReduce(table_device, table_device, count, 4, 0, (void*)comm, (hipStream_t)stream)) return rccl_fail("ncclAllReduce", rc);
   return D3IL_OK;

@@ -18,7 +18,7 @@ import logging
 import numpy as np
 import torch
 
-from ..distributed import reduce_counts, shard_range, world_info
+from ..distributed import reduce_sim_counts, shard_range, world_info
 from ..envs.avoiding import ObstacleAvoidanceVecEnv
 from ..agents import as_batched
 from .base_sim import BaseSim
@@ -86,7 +86,7 @@ class Avoiding_Sim(BaseSim):
         counts[0] = n
         counts[1] = success.sum()
         counts[2:] = torch.bincount(mode_code[success].to(torch.int64), minlength=512)
-        reduce_counts(counts)
+        reduce_sim_counts(counts, env)
         c = counts.cpu().numpy()
         success_rate, entropy = avoiding_metrics(int(c[0]), int(c[1]), c[2:])
         self.last_rollout = dict(success=success, mode_code=mode_code, c_pos=c_pos, n_pos=n_pos, counts=c, shard=(lo, hi))

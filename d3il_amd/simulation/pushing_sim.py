@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from ..distributed import shard_range, world_info
+from ..distributed import reduce_sim_counts, shard_range, world_info
 from ..envs.pushing import BlockPushVecEnv, contexts_from_reference
 from ..agents import as_batched
 from .base_sim import BaseSim
@@ -93,9 +93,9 @@ class Pushing_Sim(BaseSim):
         counts[:-1] = torch.bincount((ctx_of * 4 + mode.clamp_min(0))[ok], minlength=self.n_contexts * 4)
         counts[-1] = success.sum()
         dist_sum = mean_distance.sum().reshape(1)
+        reduce_sim_counts(counts, env)          # the integer tables: the library's RCCL all-reduce under nccl (distributed.py)
         if world > 1:
             import torch.distributed as dist
-            dist.all_reduce(counts)
             dist.all_reduce(dist_sum)
         c = counts.cpu().numpy()
         success_rate, entropy, mode_probs = pushing_metrics(c[:-1].reshape(self.n_contexts, 4), int(c[-1]), total, self.n_trajectories_per_context)

@@ -21,7 +21,7 @@ import logging
 import numpy as np
 import torch
 
-from ..distributed import shard_range, world_info
+from ..distributed import reduce_sim_counts, shard_range, world_info
 from ..envs.sorting import SortingVecEnv, contexts_from_reference, sample_contexts
 from ..agents import as_batched
 from .base_sim import BaseSim
@@ -112,10 +112,8 @@ class Sorting_Sim(BaseSim):
         counts[:-1].index_add_(0, slot, hit.reshape(-1).to(torch.int64))
         counts[-1] = success.sum()
         mode_hist = torch.bincount(mode.clamp(0, 255), minlength=256)       # all rollouts, by final mode code (diagnostics)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(counts)
-            dist.all_reduce(mode_hist)
+        reduce_sim_counts(counts, env)          # the integer tables: the library's RCCL all-reduce under nccl (distributed.py)
+        reduce_sim_counts(mode_hist, env)
         c = counts.cpu().numpy()
         success_rate, entropy, kl, score = sorting_metrics(c[:-1].reshape(self.n_contexts, self.n_mode), int(c[-1]), total, self.n_trajectories_per_context,
                                                            self.mode_encoding.numpy())

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from ..agents import as_batched
-from ..distributed import shard_range, world_info
+from ..distributed import reduce_sim_counts, shard_range, world_info
 from ..envs.stacking import CubeStackingVecEnv, load_test_contexts
 from .base_sim import BaseSim
 from .metrics import stacking_metrics
@@ -129,9 +129,7 @@ class Stacking_Sim(BaseSim):
         counts = torch.cat((table(torch.where(m1 >= 0, m1, torch.zeros_like(m1)), s1, 3), table(torch.where(m2 >= 0, m2, torch.zeros_like(m2)), s2, 6),
                             table(torch.where(m3 >= 0, m3, torch.zeros_like(m3)), s3, 6),
                             torch.stack((s1.sum(), s2.sum(), s3.sum())).to(torch.int64)))
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(counts)
+        reduce_sim_counts(counts, env)          # the integer tables: the library's RCCL all-reduce under nccl (distributed.py)
         c = counts.cpu().numpy()
         nc = self.n_contexts
         res = stacking_metrics(c[:3 * nc].reshape(nc, 3), c[3 * nc:9 * nc].reshape(nc, 6), c[9 * nc:15 * nc].reshape(nc, 6), int(c[-3]), int(c[-2]), int(c[-1]),

@@ -200,8 +200,10 @@ int d3il_count_metrics(d3il_handle h, int64_t* out_counts_device, void* stream);
  * d3il_comm_destroy.  Integer sums: bit-exact, independent of rank order and of the number of GPUs. */
 typedef struct d3il_comm_s* d3il_comm;
 typedef struct { char internal[128]; } d3il_rccl_unique_id;   /* = ncclUniqueId */
+int d3il_rccl_available(void);                         /* 1 when RCCL could be resolved in this process (no communicator is made) */
 int d3il_comm_unique_id(d3il_rccl_unique_id* out);
 int d3il_comm_init(const d3il_rccl_unique_id* id, int rank, int world, int device_id, d3il_comm* out);
+int d3il_comm_count(d3il_comm comm, int* ranks);       /* ncclCommCount: the number of ranks RCCL itself sees in this communicator */
 int d3il_comm_destroy(d3il_comm comm);
 int d3il_reduce_metrics(d3il_handle h, d3il_comm comm, int64_t* table_device, size_t count, void* stream);
 

@@ -142,6 +142,12 @@ int hc_gen_info(void* h, int* nb, int* ns, double* statics /* ns x (c3, h3, firs
   for (int s = 0; s < p->gc.ns; s++) { for (int k = 0; k < 3; k++) { statics[7 * s + k] = p->gc.st_c[s][k]; statics[7 * s + 3 + k] = p->gc.st_h[s][k]; } statics[7 * s + 6] = p->gc.st_first[s]; }
   return gen_state_rows(p->gc.nb);
 }
+// the split of the static list: [0, ns_core) inside the table, the rest = frame beams; and the two workspaces (inner lo / hi, outer lo / hi)
+int hc_gen_workspace(void* h, double* ws8) {
+  GenHost* p = (GenHost*)h;
+  for (int k = 0; k < 2; k++) { ws8[k] = p->gc.in_lo[k]; ws8[2 + k] = p->gc.in_hi[k]; ws8[4 + k] = p->gc.ws_lo[k]; ws8[6 + k] = p->gc.ws_hi[k]; }
+  return p->gc.ns_core;
+}
 // s: the environment's state column (arm[42] | cubes | warm start | task words), f: flags, step
 void hc_gen_reset(void* h, const double* init_qpos, const double* ctx, double* s, int* f, float* obs) {
   GenHost* p = (GenHost*)h; EnvState st; std::memset(&st, 0, sizeof st);

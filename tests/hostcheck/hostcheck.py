@@ -122,9 +122,12 @@ class GenHostCheck:
         if not self.h:
             raise RuntimeError("hc_gen_create: %s" % (err.value.decode() if err.value else "?"))
         nb, ns = C.c_int(0), C.c_int(0)
-        st = np.zeros((16, 7))
+        st = np.zeros((32, 7))
         self.n = self.L.hc_gen_info(self.h, C.byref(nb), C.byref(ns), _p(st))
         self.nb, self.ns, self.statics = nb.value, ns.value, st[: ns.value].copy()
+        ws = np.zeros(8)
+        self.ns_core = self.L.hc_gen_workspace(self.h, _p(ws))      # statics [0, ns_core) stand inside the table, the rest are the frame beams around it
+        self.inner, self.outer = ws[:4].copy(), ws[4:].copy()      # (lo x, lo y, hi x, hi y) of the beam-free region / of the modelled workspace
         self.n_obs = 2 + 3 * self.nb
         self.s = np.zeros(self.n)
         self.f = np.zeros(2, dtype=np.int32)

@@ -5,7 +5,16 @@ criterion for the contact tasks (two correct f64 implementations separate on a c
 file compares what the evaluation actually reports: for every BASELINE context the closed-loop scripted policy runs a full episode on
 the device (through the batched Sim class = the C ABI) AND on the CPU oracle (tests/oracle_episodes.py: the same policy object on a
 batch of one), and the per-context (success, mode code) tables - and the metric count tables built from them - are compared.
-Identical tables are asserted where they are identical; where a context differs the table is printed and a stated bound is asserted.
+
+What is asserted (round 4).  `tests/golden/oracle_outcome_sets.json` (made by tools/oracle_sensitivity.py on the CPU oracle
+alone) holds, per context, the set of (success, mode) outcomes the ORACLE ITSELF reaches when the context's cube positions are moved by
+multiples of 1e-12 m (Sorting: 1e-10 m) - far below the f32 observations the policy sees and below the one-step agreement of any two f64
+implementations of the soft-contact step.  A context with ONE outcome is *decided* at f64 resolution: there the device's (success, mode)
+must be IDENTICAL to the oracle's - no bound, no tolerance.  A context with several outcomes is one on which the oracle does not agree with
+itself; there no second implementation can be asked to agree with it (all of them are episodes of the scripted plan in which the cubes
+cross paths): the device's outcome is printed next to the oracle's set and not asserted.  Stacking: every context identical.
+tools/gpu_count_onset.py / gpu_count_onset_sorting.py show, for the differing contexts, that the oracle restarted from the device's state
+reproduces the device's next state at the conditioning level of the solve at EVERY step of the episode (profiles/r04/onset_*.json).
 """
 import json
 import os
@@ -30,19 +39,37 @@ def _dump(name, obj):
         pass
 
 
-def _compare(task, dev_rows, orc_rows, max_mismatch):
-    """rows: list of (success, mode) per context.  Prints the differing contexts; returns the summary that is also written to
-    gpurun_out/count_parity_<task>.json."""
+def _outcome_sets(task):
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_outcome_sets.json")) as f:
+        fx = json.load(f)[task]
+    return {int(i): [tuple(o) for o in outs] for i, outs in fx["outcomes"].items()}, fx
+
+
+def _compare(task, dev_rows, orc_rows, sets=None, max_undecided=None):
+    """rows: list of (success, mode) per context.  `sets` = the oracle's own outcome sets (None: every context must be identical).
+    Asserts identity on every decided context; prints the others; returns the summary that is also written to gpurun_out/count_parity_<task>.json."""
+    n = len(dev_rows)
     diff = [i for i, (a, b) in enumerate(zip(dev_rows, orc_rows)) if tuple(a) != tuple(b)]
-    summary = dict(task=task, contexts=len(dev_rows), identical=len(dev_rows) - len(diff), differing=diff,
+    undecided = [] if sets is None else [i for i in range(n) if len(sets[i]) > 1]
+    decided = [i for i in range(n) if i not in undecided]
+    bad = [i for i in diff if i in decided]
+    summary = dict(task=task, contexts=n, identical=n - len(diff), differing=diff, decided=len(decided), undecided=undecided, differing_decided=bad,
                    device=[list(map(str, r)) for r in dev_rows], oracle=[list(map(str, r)) for r in orc_rows],
+                   device_outside_oracle_set=[i for i in undecided if (bool(dev_rows[i][0]), int(dev_rows[i][1])) not in sets[i]],
                    device_successes=int(sum(bool(r[0]) for r in dev_rows)), oracle_successes=int(sum(bool(r[0]) for r in orc_rows)))
     _dump("count_parity_%s.json" % task, summary)
-    print("\n%s: %d of %d contexts with identical (success, mode); successes device %d / oracle %d" %
-          (task, summary["identical"], len(dev_rows), summary["device_successes"], summary["oracle_successes"]))
-    for i in diff:
-        print("  context %3d: device %s   oracle %s" % (i, dev_rows[i], orc_rows[i]))
-    assert len(diff) <= max_mismatch, "%s: %d contexts differ (bound %d)" % (task, len(diff), max_mismatch)
+    print("\n%s: %d of %d contexts with identical (success, mode) - all %d decided contexts must be; successes device %d / oracle %d" %
+          (task, summary["identical"], n, len(decided), summary["device_successes"], summary["oracle_successes"]))
+    for i in undecided:
+        print("  context %3d (the oracle's own outcomes under 1e-12 m perturbations: %s): device %s   oracle %s" % (i, sets[i], dev_rows[i], orc_rows[i]))
+    for i in bad:
+        print("  DECIDED context %3d differs: device %s   oracle %s" % (i, dev_rows[i], orc_rows[i]))
+    assert not bad, "%s: the device differs from the oracle on decided contexts %s" % (task, bad)
+    if sets is not None:
+        # the fixture must stay meaningful: the live oracle episode of a decided context is the fixture's outcome, and most contexts are decided
+        stale = [i for i in decided if (bool(orc_rows[i][0]), int(orc_rows[i][1])) != sets[i][0]]
+        assert not stale, "%s: tests/golden/oracle_outcome_sets.json is stale for contexts %s (regenerate with tools/oracle_sensitivity.py)" % (task, stale)
+        assert len(undecided) <= max_undecided, (len(undecided), max_undecided)
     return summary
 
 
@@ -63,15 +90,17 @@ def test_pushing_success_and_mode_tables_over_full_episodes():
     env.close()
     res = oe.run_many(oe.pushing_episode, [(i, ctx[i], q0, 400, i % 4) for i in range(60)])
     orc_rows = [(s, m) for _, s, m, _, _ in res]
-    s = _compare("pushing", dev_rows, orc_rows, max_mismatch=6)
-    # the metric's integer table (mode counts of the successful rollouts per context) from either side
+    sets, _ = _outcome_sets("pushing")
+    s = _compare("pushing", dev_rows, orc_rows, sets, max_undecided=8)
+    # the metric's integer table (mode counts of the successful rollouts per context): the rows of the decided contexts are identical
+    tab = np.zeros((60, 4), dtype=np.int64)
+    for i, (ok, m) in enumerate(orc_rows):
+        if ok and m >= 0:
+            tab[i, m] += 1
+    dec = [i for i in range(60) if i not in s["undecided"]]
+    assert np.array_equal(tab[dec], r["counts"][:-1].reshape(60, 4)[dec])
     if not s["differing"]:
-        tab = np.zeros((60, 4), dtype=np.int64)
-        for i, (ok, m) in enumerate(orc_rows):
-            if ok and m >= 0:
-                tab[i, m] += 1
-        assert np.array_equal(tab.reshape(-1), r["counts"][:-1]) and int(r["counts"][-1]) == s["oracle_successes"]
-    assert abs(s["device_successes"] - s["oracle_successes"]) <= 3
+        assert int(r["counts"][-1]) == s["oracle_successes"]
 
 
 def test_pushing_tables_on_sampled_contexts():
@@ -92,8 +121,9 @@ def test_pushing_tables_on_sampled_contexts():
     env.close()
     res = oe.run_many(oe.pushing_episode, [(i, ctx[i], q0, 400, i % 4) for i in range(n)])
     orc_rows = [(s, m) for _, s, m, _, _ in res]
-    s = _compare("pushing_sampled", dev_rows, orc_rows, max_mismatch=12)
-    assert abs(s["device_successes"] - s["oracle_successes"]) <= 5 and s["oracle_successes"] >= n // 2
+    sets, _ = _outcome_sets("pushing_sampled")
+    s = _compare("pushing_sampled", dev_rows, orc_rows, sets, max_undecided=16)
+    assert s["oracle_successes"] >= n // 2
 
 
 def test_sorting_success_and_mode_tables_over_full_episodes():
@@ -115,11 +145,11 @@ def test_sorting_success_and_mode_tables_over_full_episodes():
     env.close()
     res = oe.run_many(oe.sorting_episode, [(i, ctx[i], q0, 700) for i in range(60)])
     orc_rows = [(s, m) for _, s, m, _ in res]
-    s = _compare("sorting", dev_rows, orc_rows, max_mismatch=9)
+    sets, _ = _outcome_sets("sorting")
+    s = _compare("sorting", dev_rows, orc_rows, sets, max_undecided=8)
     hist_d = np.bincount(np.array([m for _, m in dev_rows]), minlength=256)
     hist_o = np.bincount(np.array([m for _, m in orc_rows]), minlength=256)
     print("  mode-code histogram L1 distance: %d of %d rollouts" % (int(np.abs(hist_d - hist_o).sum()) // 2, 60))
-    assert abs(s["device_successes"] - s["oracle_successes"]) <= 3
 
 
 def test_stacking_success_and_mode_tables_over_full_episodes():
@@ -146,6 +176,6 @@ def test_stacking_success_and_mode_tables_over_full_episodes():
     dev_rows = [(bool(s), mode_string(int(m))) for s, m in zip(r["success"].cpu().numpy(), r["mode"].cpu().numpy())]
     res = oe.run_many(oe.stacking_episode, [(i, ctx[i], q0, 1000, tables[i]) for i in range(nctx)])
     orc_rows = [(s, m) for _, s, m, _ in res]
-    s = _compare("stacking", dev_rows, orc_rows, max_mismatch=6)
+    s = _compare("stacking", dev_rows, orc_rows)          # every context identical: (success, order string) tables bit-exact
     assert s["oracle_successes"] >= nctx // 2, "the scripted pick-and-place should stack three boxes on most contexts"
-    assert abs(s["device_successes"] - s["oracle_successes"]) <= 3
+    assert s["device_successes"] == s["oracle_successes"]

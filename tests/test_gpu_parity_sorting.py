@@ -294,3 +294,54 @@ def test_sorting_2_reset_landing_and_push_match_oracle(sort_init_qpos):
             np.testing.assert_allclose(obs[e].cpu().numpy(), oo, rtol=1e-4, atol=1e-5)
             assert bool(done[e]) == do and int(info["mode"][e]) == io["mode"]
     env.close()
+
+
+def test_cube_at_the_table_edge_meets_the_frame_beams(sort_blob, sort_init_qpos):
+    """VERDICT r3 missing #3: the cube <-> frame-beam pairs (lab_surrounding.xml:3-114) on the device.  Cubes are dropped along the front and
+    the left edge of the table - centre inside the old 8 cm margin, on the edge, 1 cm beyond it (over the beam) - and followed by the oracle,
+    which has always evaluated these pairs: same trajectory while the beams carry a cube (the device used to raise OFF_TABLE there and
+    ignore the beams), OFF_TABLE only once a cube centre has passed the outer face of the frame."""
+    from oracle.oracle import Oracle
+    from tests.test_sorting_oracle import CTX
+    spots = [(0.86, 0.35), (0.885, 0.35), (0.90, 0.35), (0.895, -0.6), (0.45, 0.955), (0.45, 0.985), (0.30, -0.99), (0.905, 0.97)]
+    n = len(spots)
+    ctx = np.tile(CTX.reshape(1, NB, 7), (n, 1, 1))
+    for e, (x, y) in enumerate(spots):
+        ctx[e, 0, :2] = [x, y]
+        ctx[e, 3, :2] = [x - 0.2 if x > 0.5 else x + 0.1, y * 0.5]      # a second cube of the environment well inside the table
+    env = _env(n)
+    env.set_init_qpos(sort_init_qpos)
+    env.reset(context=ctx.reshape(n, NB * 7))
+    torch.cuda.synchronize()
+    orc = []
+    for e in range(n):
+        o = Oracle(sort_blob)
+        o.env_start(sort_init_qpos)
+        o.sort_reset(ctx[e])
+        orc.append(o)
+    z = env.robot_state()[:, 2:3].clone()
+    des = env.obs[:, :2].to(torch.float64).clone()
+    beam_steps, worst = 0, 0.0
+    outer_x, outer_y = 0.91, 1.0
+    for t in range(14):
+        a = _action(des, z)
+        env.step(a)
+        torch.cuda.synchronize()
+        st, fl, sc = env.get_state()
+        an = a.cpu().numpy()
+        for e in range(n):
+            orc[e].sort_step(an[e])
+            con = orc[e].contacts()
+            on_beam = any(int(row[8]) in range(2, 16) for row in con)            # geoms 2 .. 15: the aluminium profiles
+            beam_steps += on_beam
+            err = _dev_err(st, e, orc[e])
+            worst = max(worst, err)
+            assert err < 1e-7, (t, e, err)
+            x, y = st[42, e], st[43, e]
+            off = bool(fl[e] & (1 << 19))
+            assert (off or (x <= outer_x and abs(y) <= outer_y)) and (not off or x > outer_x - 0.01 or abs(y) > outer_y - 0.01), (t, e, x, y, off)
+            assert not (fl[e] & ((1 << 16) | (1 << 18)))
+    print("cubes on the frame beams: %d environment-steps, max |device - oracle| %.2e" % (beam_steps, worst))
+    assert beam_steps >= 10
+    assert not (env.flags[:1].cpu().numpy() & (1 << 19)).any()      # 3 cm inside the edge: no flag (it was one before)
+    env.close()

@@ -500,12 +500,16 @@ def test_library_rccl_reduction_single_rank():
     assert L.d3il_comm_unique_id(None) == -1 and L.d3il_comm_destroy(None) == -1
     env = CubeStackingVecEnv(8, device=0)
     comm = D.LibraryComm(torch.device("cuda:0"))
-    assert comm.world == 1
+    assert comm.world == 1 and comm.ranks() == 1 and L.d3il_rccl_available() == 1      # ncclCommCount: what RCCL itself sees
     table = torch.arange(3 * capi.TALLY_ROW, dtype=torch.int64, device="cuda:0")
     ref = table.clone()
     D.reduce_counts(table, comm, env.h)
     torch.cuda.synchronize()
     assert torch.equal(table, ref)                                     # sum over one rank
+    D.reduce_counts(table, comm, None)                                 # a rank without environments: no handle, explicit table
+    torch.cuda.synchronize()
+    assert torch.equal(table, ref) and "1 ranks" in D.LAST_REDUCTION
+    assert L.d3il_reduce_metrics(None, comm.comm, None, 0, None) == -1 and L.d3il_comm_count(None, None) == -1
     assert L.d3il_reduce_metrics(env.h, comm.comm, None, 0, None) == -1     # no table registered with d3il_set_tally
     comm.close()
     env.close()

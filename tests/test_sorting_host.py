@@ -20,10 +20,19 @@ def _state_err(h, o):
 
 def test_scene_constants(sort_blob):
     h = GenHostCheck(sort_blob)
-    assert (h.nb, h.ns) == (4, 11)
+    assert (h.nb, h.ns, h.ns_core) == (4, 19, 11)
     st = h.statics
     # table_plane and support_body precede the cubes in the model (geom 1 of a pair), walls and platform follow them
-    assert st[:, 6].tolist() == [1, 1] + [0] * 9
+    assert st[:11, 6].tolist() == [1, 1] + [0] * 9
+    # the frame around the table top (lab_surrounding.xml:3-114): four upper beams and four posts, all before the cubes in the model, their
+    # tops 1 mm BELOW the table top (z = -0.02 against -0.019) and reaching 2 cm beyond its edge: what a cube tipping over the edge lands
+    # on; in the list after everything that stands inside the table
+    rim = st[11:]
+    assert rim[:, 6].tolist() == [1] * 8
+    np.testing.assert_allclose(rim[:, 2] + rim[:, 5], -0.02, atol=1e-12)
+    assert sorted(np.round(rim[:, 3:5].max(axis=1), 3).tolist()) == [0.02] * 4 + [0.47] * 2 + [0.96] * 2
+    np.testing.assert_allclose(h.inner, [-0.01, -0.9, 0.81, 0.9], atol=1e-12)      # table footprint shrunk by 8 cm
+    np.testing.assert_allclose(h.outer, [-0.11, -1.0, 0.91, 1.0], atol=1e-12)      # outer faces of the frame
     np.testing.assert_allclose(st[0, :6], [0.4, 0, -0.02, 0.49, 0.98, 0.001], atol=1e-12)
     np.testing.assert_allclose(st[10, :6], [0.5, -0.1, 0.0, 0.3, 0.3, 0.1], atol=1e-12)
     assert sorted(np.round(st[2:10, 3:5].min(axis=1), 3).tolist()) == [0.005] * 6 + [0.01] * 2
@@ -85,7 +94,7 @@ def test_sorting_2_scene_tracks_the_oracle(sort_init_qpos):
     o = Oracle(m2)
     o.env_start(sort_init_qpos)
     h = GenHostCheck(m2)
-    assert (h.nb, h.ns, h.n) == (2, 11, 42 + 26 + 21 + 2)
+    assert (h.nb, h.ns, h.ns_core, h.n) == (2, 19, 11, 42 + 26 + 21 + 2)
     ctx = CTX[[0, 2]]
     obs_o, obs_h = o.sort_reset(ctx), h.reset(sort_init_qpos, ctx)
     assert obs_h.shape == (8,) and np.array_equal(obs_o, obs_h)
@@ -104,3 +113,34 @@ def test_sorting_2_scene_tracks_the_oracle(sort_init_qpos):
         oh, dh, ih = h.step(a)
         assert _state_err(h, o) < 1e-7 and np.abs(obs_o - oh).max() < 1e-6 and do == dh
         assert io["mode"] == ih["mode"] == 0b11000000 and not (ih["flags"] & 0x1F0000)      # two unset entries
+
+
+def test_cube_over_the_table_edge_meets_the_frame_beam(sort_blob, sort_init_qpos):
+    """VERDICT r3 missing #3: cube <-> frame-beam pairs (lab_surrounding.xml:3-114).  A cube dropped with its centre 1 cm beyond the table's
+    front edge comes down on the table edge, the support block and the front beam (top 1 mm below the table top, reaching 2 cm beyond its
+    edge), is kicked outwards by the push-out of its deep first penetration and slides off the frame.  The host build of the kernel math
+    evaluates the beam pair like the oracle - same trajectory while the beam carries the cube - and raises OFF_TABLE exactly when the
+    cube centre has passed the outer face of the frame (x > 0.91), not, as before, 8 cm inside the table edge."""
+    o = Oracle(sort_blob)
+    o.env_start(sort_init_qpos)
+    h = GenHostCheck(sort_blob)
+    ctx = CTX.copy()
+    ctx[0, :2] = [0.90, 0.35]                         # table edge at x = 0.89, beam 0.87 .. 0.91
+    ctx[1, :2] = [0.86, -0.55]                        # 3 cm inside the edge (inside the old 8 cm margin): table only, stays
+    obs_o, obs_h = o.sort_reset(ctx), h.reset(sort_init_qpos, ctx)
+    assert np.array_equal(obs_o, obs_h)
+    z = float(o.body(sort_blob.tcp_body)[0][2])
+    a = np.concatenate([obs_o[:2].astype(float), [z], [0, 1, 0, 0]])
+    beam_steps = 0
+    for t in range(12):
+        oo, do, io = o.sort_step(a)
+        oh, dh, ih = h.step(a)
+        con = o.contacts()
+        beam_steps += any(int(row[8]) == 2 for row in con)          # geom 2 = front_upper against a cube
+        assert _state_err(h, o) < 1e-7, (t, _state_err(h, o))
+        x0 = h.box(0)[0][0]
+        off = bool(ih["flags"] & (1 << 19))
+        assert (off or x0 <= h.outer[2]) and (not off or x0 > h.outer[2] - 0.01), (t, x0, off)      # raised at the outer face of the frame, not before
+        assert not (ih["flags"] & ((1 << 16) | (1 << 18)))
+    assert beam_steps >= 3, "the cube should have been carried by the front beam for a few steps"
+    assert h.box(0)[0][0] > 0.95 and abs(h.box(1)[0][0] - 0.86) < 1e-3 and abs(h.box(1)[0][2] - 0.011) < 1e-3

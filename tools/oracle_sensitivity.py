@@ -8,7 +8,8 @@ integer outcome is not a function of the context at f64 resolution: there, "devi
 implementation, the oracle re-run on a different machine's libm included.  The table lists those contexts next to the
 contexts on which the device differed (profiles/r03/count_parity_*.json), so the reader sees whether the latter are a subset.
 
-    python tools/oracle_sensitivity.py [pushing] [pushing_sampled] [sorting] [--k 6] [--out profiles/r04/oracle_sensitivity.json]
+    python tools/oracle_sensitivity.py [pushing] [pushing_sampled] [sorting] [--k 6] [--eps 1e-12] [--out profiles/r04/oracle_sensitivity.json]
+                                       [--fixture tests/golden/oracle_outcome_sets.json]   (the committed fixture: k 24, eps 1e-12; Sorting eps 1e-10)
 """
 from __future__ import annotations
 
@@ -57,7 +58,7 @@ def jobs_for(task, k_pert, eps):
         for i in range(len(ctx)):
             for k in range(k_pert + 1):
                 c = np.array(ctx[i], dtype=np.float64).reshape(-1, 7).copy()
-                c[0, 0] += k * eps
+                c[:, 0] += k * eps * np.arange(1, c.shape[0] + 1)      # every cube moves, by a different multiple
                 jobs.append((i * 100 + k, c, q0, 700))
         return oe.sorting_episode, jobs, len(ctx)
     raise SystemExit("unknown task " + task)
@@ -65,7 +66,7 @@ def jobs_for(task, k_pert, eps):
 
 def main():
     args = sys.argv[1:]
-    k_pert, eps, out = 6, 1e-12, None
+    k_pert, eps, out, fixture = 6, 1e-12, None, None
     tasks = []
     it = iter(args)
     for a in it:
@@ -75,6 +76,8 @@ def main():
             eps = float(next(it))
         elif a == "--out":
             out = next(it)
+        elif a == "--fixture":
+            fixture = next(it)
         else:
             tasks.append(a)
     tasks = tasks or ["pushing", "pushing_sampled", "sorting"]
@@ -108,6 +111,16 @@ def main():
         os.makedirs(os.path.dirname(os.path.join(ROOT, out)), exist_ok=True)
         with open(os.path.join(ROOT, out), "w") as f:
             json.dump(result, f, indent=1)
+    if fixture:
+        # the compact form tests/test_gpu_count_parity.py reads: per task and context the DISTINCT (success, mode) outcomes of the oracle
+        # under the perturbations; one entry = the outcome is decided at f64 resolution, several = it is not
+        path = os.path.join(ROOT, fixture)
+        fx = json.load(open(path)) if os.path.exists(path) else {}
+        for task, r in result["tasks"].items():
+            fx[task] = dict(k=k_pert, eps=eps, perturbation="cube x positions of the context + j * eps (Sorting: cube b by (b + 1) j eps), j = 0 .. k",
+                            outcomes={str(i): sorted({(bool(s), int(m)) for s, m, _ in rows}) for i, rows in r["outcomes"].items()})
+        with open(path, "w") as f:
+            json.dump(fx, f, indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":
