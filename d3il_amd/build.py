@@ -89,7 +89,7 @@ def build_stats_variant(verbose: bool = False) -> str:
 def build_variant(name: str, defines, verbose: bool = False) -> str:
     """Comparison / diagnostics builds of the Stacking kernel, loaded with D3IL_LIB_PATH=<file>:
     poison: every LDS word starts as a NaN and dead areas are poisoned again every sub-step (-DD3IL_SK_POISON);
-    raw: without the opaque move in sk_support1_group_pre - shows the position-dependence defect (-DD3IL_SK_PRELOAD_RAW);
+    raw: without the convergence fences (SK_CONVERGE, stack_step.h) - shows the position-dependence defect of DESIGN sections 17.3 / 18.2 (-DD3IL_SK_PRELOAD_RAW);
     nopreload: the table-reading support function (-DD3IL_SK_NO_PRELOAD)."""
     out = os.path.join(PKG, "libd3il_rollout_%s.so" % name)
     cmd = [hipcc()] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-o", out] + SOURCES

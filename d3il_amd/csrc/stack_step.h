@@ -761,6 +761,20 @@ __device__ __forceinline__ double sk_bcast(double v, int src /* wave-uniform */)
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
   const unsigned long long r = ((unsigned long long)hi << 32) | lo; double out; __builtin_memcpy(&out, &r, 8); return out;
 }
+// Convergence fence.  Every cross-lane sequence of this engine - a DPP butterfly, a ds_bpermute shuffle - is bracketed by
+// a side-effecting convergent no-op (llvm.amdgcn.wave.barrier: no instruction is emitted).  Without one between the group reduction and the
+// shuffle of sk_support1_group_pre, hipcc (ROCm 7.2) builds a kernel whose MPR results depend on the lane group a job runs on (the
+// -DD3IL_SK_PRELOAD_RAW build).  What the round-4 experiments established: the defect is deterministic; it survives every register
+// allocator (greedy / basic for VGPRs, SGPRs, WWM), the SLP vectoriser on or off, and waits / nops inserted into its ISA after every LDS,
+// DPP, lane, EXEC-writing and transcendental instruction (so: neither allocation nor a hardware hazard); making the shuffled values opaque
+// WITHOUT a side effect (a non-volatile asm) does not remove it, a fence that leaves them transparent does; with SimplifyCFG's
+// common-code sinking off (-mllvm -simplifycfg-sink-common=false) 1913 of the 1917 deviating environments of the probe disappear.  I.e. the
+// optimiser restructures the divergent if-chains around the group-wide operations unless a side effect pins them.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(D3IL_SK_NO_FENCE) && !defined(D3IL_SK_PRELOAD_RAW)
+#define SK_CONVERGE() __builtin_amdgcn_wave_barrier()
+#else
+#define SK_CONVERGE() ((void)0)
+#endif
 // Reductions over the 64 lanes (all active): butterfly inside the rows of 16 lanes with DPP moves (quad permutes, half-row and row
 // mirrors: no LDS crossbar round trips), then the four row results through v_readlane.  Every lane gets the result.
 __device__ __forceinline__ double sk_dpp_mov(double v, const int ctrl_sel) {
@@ -775,12 +789,18 @@ __device__ __forceinline__ double sk_dpp_mov(double v, const int ctrl_sel) {
   const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; double out; __builtin_memcpy(&out, &r, 8); return out;
 }
 __device__ __forceinline__ double sk_wave_sum(double v) {
+  SK_CONVERGE();
   v += sk_dpp_mov(v, 0); v += sk_dpp_mov(v, 1); v += sk_dpp_mov(v, 2); v += sk_dpp_mov(v, 3);      // every lane: the sum of its row of 16
-  return (sk_bcast(v, 0) + sk_bcast(v, 16)) + (sk_bcast(v, 32) + sk_bcast(v, 48));
+  const double r = (sk_bcast(v, 0) + sk_bcast(v, 16)) + (sk_bcast(v, 32) + sk_bcast(v, 48));
+  SK_CONVERGE();
+  return r;
 }
 __device__ __forceinline__ double sk_wave_max(double v) {
+  SK_CONVERGE();
   v = fmax(v, sk_dpp_mov(v, 0)); v = fmax(v, sk_dpp_mov(v, 1)); v = fmax(v, sk_dpp_mov(v, 2)); v = fmax(v, sk_dpp_mov(v, 3));
-  return fmax(fmax(sk_bcast(v, 0), sk_bcast(v, 16)), fmax(sk_bcast(v, 32), sk_bcast(v, 48)));
+  const double r = fmax(fmax(sk_bcast(v, 0), sk_bcast(v, 16)), fmax(sk_bcast(v, 32), sk_bcast(v, 48)));
+  SK_CONVERGE();
+  return r;
 }
 constexpr int SKC_NJ = 15;                       // columns of a contact row in the J area
 constexpr int SKC_JSIZE = 4 * SKC_NJ * SK_MAXCON;   // doubles per wave
@@ -878,13 +898,17 @@ __device__ __forceinline__ double sk_hbcast(double v, int j /* wave-uniform, 0 .
 #endif
 }
 __device__ __forceinline__ double sk_half_sum(double v, bool upper) {
+  SK_CONVERGE();
   v += sk_dpp_mov(v, 0); v += sk_dpp_mov(v, 1); v += sk_dpp_mov(v, 2); v += sk_dpp_mov(v, 3);      // every lane: the sum of its row of 16
   const double a = sk_bcast(v, 0) + sk_bcast(v, 16), b = sk_bcast(v, 32) + sk_bcast(v, 48);
+  SK_CONVERGE();
   return upper ? b : a;
 }
 __device__ __forceinline__ double sk_half_max(double v, bool upper) {
+  SK_CONVERGE();
   v = fmax(v, sk_dpp_mov(v, 0)); v = fmax(v, sk_dpp_mov(v, 1)); v = fmax(v, sk_dpp_mov(v, 2)); v = fmax(v, sk_dpp_mov(v, 3));
   const double a = fmax(sk_bcast(v, 0), sk_bcast(v, 16)), b = fmax(sk_bcast(v, 32), sk_bcast(v, 48));
+  SK_CONVERGE();
   return upper ? b : a;
 }
 // The constraint problems of TWO environments (e0 on the lower half wave, e0 + 1 on the upper one; act0 / act1: which of them is solved),
@@ -1456,15 +1480,18 @@ __device__ __forceinline__ int sk_dpp_movi(int v, const int ctrl_sel) {
   }
 }
 __device__ __forceinline__ double sk_group_max(double v) {
+  SK_CONVERGE();
 #if defined(D3IL_SK_SHFL_REDUCE)
 #pragma unroll
   for (int m = SKG / 2; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
 #else
   v = fmax(v, sk_dpp_mov(v, 0)); v = fmax(v, sk_dpp_mov(v, 1)); v = fmax(v, sk_dpp_mov(v, 2));
 #endif
+  SK_CONVERGE();
   return v;
 }
 __device__ __forceinline__ int sk_group_min(int v) {
+  SK_CONVERGE();
 #if defined(D3IL_SK_SHFL_REDUCE)
 #pragma unroll
   for (int m = SKG / 2; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
@@ -1472,6 +1499,7 @@ __device__ __forceinline__ int sk_group_min(int v) {
 #pragma unroll
   for (int st = 0; st < 3; st++) { const int o = sk_dpp_movi(v, st); v = o < v ? o : v; }
 #endif
+  SK_CONVERGE();
   return v;
 }
 __device__ __forceinline__ void sk_support1_group(const StackConsts& kc_, const SkShape& s, const double* dir, double margin, double* out, const int sub) {
@@ -1529,17 +1557,21 @@ __device__ __forceinline__ void sk_support1_group_pre(const StackConsts& kc_, co
 #pragma unroll
     for (int m = 0; m < SKG_NV; m++) if (m == bm) { mine[0] = hv[m][0]; mine[1] = hv[m][1]; mine[2] = hv[m][2]; }
     const int src = (threadIdx.x & ~(SKG - 1)) | (gbest & (SKG - 1));
-    // The selected vertex goes through an opaque register move before the shuffles.  Without it (-DD3IL_SK_PRELOAD_RAW) hipcc (ROCm 7.2, -O3, 512
-    // registers per lane, 224 B of scratch) produces a kernel whose results depend on the workgroup position of an environment: the fourth MPR lane
-    // group of a batch reports a finger <-> finger contact that the other three, on identical data, do not (and SOLVER_FAIL flags follow); the
-    // table-reading variant (-DD3IL_SK_NO_PRELOAD) shows the same defect at ~1e-6 per environment step.  Instrumented builds do not show it, the ISA
-    // of this sequence is correct in both builds: the register allocation differs, not the arithmetic.  This build is clean in
-    // 2e7 environment steps of tools/gpu_stack_perm.py; guards: tests/test_gpu_parity_stacking.py::test_random_policy_*, ::test_copies_*, ::test_permuted_*.
-#if !defined(D3IL_SK_PRELOAD_RAW)      // the build without the move, kept to show that the guards catch it
-    asm volatile("" : "+v"(mine[0]), "+v"(mine[1]), "+v"(mine[2]));
+    // Fenced on both sides (SK_CONVERGE above): this is the place where the -DD3IL_SK_PRELOAD_RAW build - no fence anywhere - goes wrong; rounds
+    // 2 - 3 shipped an opaque register move (asm volatile "+v") here, which worked because it is a side effect, not because it hides the values.
+#if defined(D3IL_SK_EXP) && D3IL_SK_EXP == 1      // the experiments of DESIGN section 18.2 (on the fence-less build): what about that move mattered?
+    asm("" : "+v"(mine[0]), "+v"(mine[1]), "+v"(mine[2]));            // opaque values, no side effect: still wrong
+#elif defined(D3IL_SK_EXP) && D3IL_SK_EXP == 2
+    asm volatile("" ::: "memory");                                     // a side effect, values transparent: right
+#elif defined(D3IL_SK_EXP) && D3IL_SK_EXP == 3
+    __builtin_amdgcn_wave_barrier();                                   // a convergent no-op: right
+#elif defined(D3IL_SK_EXP) && D3IL_SK_EXP == 4
+    asm volatile("" : "+v"(mine[0]));                                  // one of the three values through a volatile asm: right
 #endif
+    SK_CONVERGE();
 #pragma unroll
     for (int k = 0; k < 3; k++) loc[k] = __shfl(mine[k], src);
+    SK_CONVERGE();
   } else {
 #pragma unroll
     for (int k = 0; k < 3; k++) loc[k] = dl[k] >= -1e-10 ? s.half[k] : -s.half[k];
@@ -1790,10 +1822,12 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
     // results back to the owner lanes: owner L reads lane 8 * (rank of L in the batch)
     const bool mine = ((batch >> lane) & 1ull) != 0;
     const int from = mine ? SKG * __popcll(batch & ((1ull << lane) - 1ull)) : lane;
+    SK_CONVERGE();
     const int ghit = __shfl(hit, from);
     double g7[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) g7[k] = __shfl(r7[k], from);
+    SK_CONVERGE();
     if (mine && ghit) {
       sk_lds_double* stage = smem + lane * SKC_STAGE;
       stage[0] = g7[4]; stage[1] = g7[5]; stage[2] = g7[6];

@@ -36,6 +36,9 @@ def _q0(task):
     return q
 
 
+RANDOM = False
+
+
 def jobs_for(task, k_pert, eps):
     from tests import oracle_episodes as oe
     if task in ("pushing", "pushing_sampled"):
@@ -58,7 +61,10 @@ def jobs_for(task, k_pert, eps):
         for i in range(len(ctx)):
             for k in range(k_pert + 1):
                 c = np.array(ctx[i], dtype=np.float64).reshape(-1, 7).copy()
-                c[:, 0] += k * eps * np.arange(1, c.shape[0] + 1)      # every cube moves, by a different multiple
+                if RANDOM:      # every cube's x and y by an independent uniform draw in (-eps, eps): directions like an implementation's round-off, not one axis
+                    c[:, :2] += (np.random.default_rng(1000 * i + k).uniform(-eps, eps, size=(c.shape[0], 2)) if k else 0.0)
+                else:
+                    c[:, 0] += k * eps * np.arange(1, c.shape[0] + 1)      # every cube moves, by a different multiple
                 jobs.append((i * 100 + k, c, q0, 700))
         return oe.sorting_episode, jobs, len(ctx)
     raise SystemExit("unknown task " + task)
@@ -78,6 +84,9 @@ def main():
             out = next(it)
         elif a == "--fixture":
             fixture = next(it)
+        elif a == "--random":
+            global RANDOM
+            RANDOM = True
         else:
             tasks.append(a)
     tasks = tasks or ["pushing", "pushing_sampled", "sorting"]
@@ -117,7 +126,8 @@ def main():
         path = os.path.join(ROOT, fixture)
         fx = json.load(open(path)) if os.path.exists(path) else {}
         for task, r in result["tasks"].items():
-            fx[task] = dict(k=k_pert, eps=eps, perturbation="cube x positions of the context + j * eps (Sorting: cube b by (b + 1) j eps), j = 0 .. k",
+            fx[task] = dict(k=k_pert, eps=eps, perturbation=("x, y of every cube + independent uniform draws in (-eps, eps), k draws (rng seed 1000 ctx + j)" if RANDOM else
+                                          "cube x positions of the context + j * eps (Sorting: cube b by (b + 1) j eps), j = 0 .. k"),
                             outcomes={str(i): sorted({(bool(s), int(m)) for s, m, _ in rows}) for i, rows in r["outcomes"].items()})
         with open(path, "w") as f:
             json.dump(fx, f, indent=0, sort_keys=True)
