@@ -334,3 +334,59 @@ class ScriptedGoalPushPolicy:
         around = self.STEP * (0.8 * tang + 0.6 * (0.075 - rn) / 0.01 * away).clamp(-1.0, 1.0)
         step = torch.where(aligned, push, torch.where((rn < 0.08) & (dn > 0.02), around, walk))
         return step * active.unsqueeze(1).to(torch.float64)
+
+
+class ScriptedAlignPolicy:
+    """Scripted policy for the Aligning task (evaluation harness for the parity tests and the bench line; not part of the reference).  Interface of
+    the rollout loop of ``Aligning_Sim``: ``predict_batch([des_xyz, obs17]) -> delta_xyz``.  Two behaviours, chosen per lane by ``inside`` - they are
+    the two behaviour modes the task counts (aligning.py:288-312):
+
+    * inside  (mode 0): above the box centre, down between the walls (rod tip 2 cm above the plate), then the box is dragged towards the target;
+    * outside (mode 1): to a stand-off point 12 cm behind the box on the line box -> target (3 cm off-centre, so that the box also turns), down, then
+      a push along that line.
+
+    The way-points are fixed from the FIRST observation of an episode and the phases by the step count (40 steps travel, 40 steps descent, then 4 mm per
+    step), so the commanded path depends on the context only - the episode's outcome then measures the physics, not a feedback loop."""
+
+    HIGH, LOW = 0.25, 0.14
+
+    def __init__(self, inside=None, device="cuda"):
+        self.device = torch.device(device)
+        self.inside = None if inside is None else torch.as_tensor(inside, dtype=torch.bool, device=self.device)
+        self.t = None
+        self.way = None
+
+    def reset(self):
+        self.t, self.way = None, None
+
+    def begin_episodes(self, mask: torch.Tensor):
+        if self.t is not None:
+            self.t = torch.where(mask.bool(), torch.zeros_like(self.t), self.t)
+            self._fresh = mask.bool() if getattr(self, "_fresh", None) is None else (self._fresh | mask.bool())
+
+    @torch.no_grad()
+    def predict_batch(self, obs20: torch.Tensor) -> torch.Tensor:
+        x = obs20.to(torch.float64)
+        n, dev = x.shape[0], x.device
+        des, box, tgt = x[:, 0:3], x[:, 6:8], x[:, 13:15]
+        if self.t is None:
+            self.t = torch.zeros(n, dtype=torch.long, device=dev)
+            self._fresh = torch.ones(n, dtype=torch.bool, device=dev)
+        inside = self.inside if self.inside is not None else torch.ones(n, dtype=torch.bool, device=dev)
+        fresh = self._fresh | (self.t == 0)
+        d = tgt - box
+        u = d / d.norm(dim=1, keepdim=True).clamp_min(1e-9)
+        perp = torch.stack((-u[:, 1], u[:, 0]), dim=1)
+        start = torch.where(inside.unsqueeze(1), box, box - 0.12 * u + 0.03 * perp)
+        goal = torch.where(inside.unsqueeze(1), tgt, box + 0.8 * d + 0.03 * perp)
+        way = torch.cat((start, goal), dim=1)
+        self.way = way if self.way is None else torch.where(fresh.unsqueeze(1), way, self.way)
+        self._fresh = torch.zeros(n, dtype=torch.bool, device=dev)
+        t = self.t.unsqueeze(1)
+        z = torch.where(t < 40, torch.full((n, 1), self.HIGH, dtype=torch.float64, device=dev), torch.full((n, 1), self.LOW, dtype=torch.float64, device=dev))
+        xy = torch.where(t < 80, self.way[:, 0:2], self.way[:, 2:4])
+        step = torch.where(t < 80, torch.full((n, 1), 0.008, dtype=torch.float64, device=dev), torch.full((n, 1), 0.004, dtype=torch.float64, device=dev))
+        dd = torch.cat((xy, z), dim=1) - des
+        nn = dd.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        self.t = self.t + 1
+        return dd / nn * torch.minimum(nn, step)

@@ -27,7 +27,8 @@ FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
 # Pushing (D3IL_PUSH_STATE_* / D3IL_PFLAG_* in include/d3il_rollout.h)
 PUSH_STATE_BOX, PUSH_STATE_WARM, PUSH_STATE_F64 = 42, 68, 89
 PFLAG_FIRST_MASK, PFLAG_MODE_MASK, PFLAG_WARM_VALID, PFLAG_CON_OVERFLOW, PFLAG_OFF_TABLE = 0x7, 0x38, 1 << 6, 1 << 18, 1 << 19
-TASK_AVOIDING, TASK_PUSHING, TASK_SORTING, TASK_STACKING = 0, 1, 2, 3
+TASK_AVOIDING, TASK_PUSHING, TASK_SORTING, TASK_STACKING, TASK_ALIGNING = 0, 1, 2, 3, 4
+ALIGN_STATE_BOX, ALIGN_STATE_WARM, ALIGN_STATE_TARGET, ALIGN_STATE_F64 = 42, 55, 70, 77
 STACK_STATE_BOX, STACK_STATE_WARM, STACK_STATE_F64 = 28, 67, 94
 SFLAG_MODE_MASK, SFLAG_WARM_VALID, SFLAG_HAND_NEAR = 0xFF, 1 << 8, 1 << 20
 TALLY_ROW, TALLY_ALL = 514, 256

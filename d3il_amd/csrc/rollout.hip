@@ -580,6 +580,7 @@ static_assert(D3IL_STACK_STATE_BOX == SK_STATE_BOX && D3IL_STACK_STATE_WARM == S
 static_assert(D3IL_SFLAG_WARM_VALID == SKF_WARM_VALID && D3IL_SFLAG_HAND_NEAR == SKF_HAND_NEAR && D3IL_PFLAG_CON_OVERFLOW == SKF_CON_OVERFLOW && D3IL_PFLAG_OFF_TABLE == SKF_OFF_TABLE,
               "d3il_rollout.h: Stacking flag bits");
 static_assert(D3IL_SFLAG_MODE_MASK == (SKF_NMODE_MASK | (0x3Fu << SKF_IND_SHIFT)), "d3il_rollout.h: Stacking order code");
+static_assert(D3IL_ALIGN_STATE_BOX == AL_STATE_BOX && D3IL_ALIGN_STATE_WARM == AL_STATE_WARM && D3IL_ALIGN_STATE_TARGET == AL_STATE_TARGET && D3IL_ALIGN_STATE_F64 == AL_STATE_F64, "d3il_rollout.h: Aligning state layout");
 static_assert(D3IL_PUSH_STATE_F64 == PUSH_STATE_F64 && D3IL_TALLY_ALL + 256 <= D3IL_TALLY_ROW - 2, "d3il_rollout.h: Pushing state rows / tally row");
 
 struct d3il_handle_s {
@@ -589,6 +590,7 @@ struct d3il_handle_s {
   PushConsts pc;           // Pushing: cubes, table slabs, contact parameter sets, targets
   GenConsts gc;            // Sorting: cubes, static boxes, contact parameter sets (host copy; the device copy is the __constant__ object)
   StackConsts kc;          // Stacking: boxes, finger geoms, contact parameter sets (host copy; device: __constant__)
+  AlignTask atk;           // Aligning: success / mode thresholds (device: __constant__ g_align_task)
   double* d_scratch;       // Pushing: per-lane solver scratch [PG_SIZE][stride]
   int state_rows;          // f64 state fields per environment (42 Avoiding, 89 Pushing)
   double* d_init_qpos;
@@ -662,7 +664,8 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (n_envs <= 0) return fail(D3IL_EINVAL, "d3il_create: n_envs must be positive");
   const d3il_model_blob& m = *(const d3il_model_blob*)model_blob;
   if (task_id != m.task_id) return fail(D3IL_EINVAL, "d3il_create: task_id does not match the model blob");
-  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING && task_id != D3IL_TASK_STACKING) return fail(D3IL_EUNSUPPORTED, "d3il_create: unknown task id (Avoiding, Pushing, Sorting and Stacking are implemented)");
+  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING && task_id != D3IL_TASK_STACKING && task_id != D3IL_TASK_ALIGNING)
+    return fail(D3IL_EUNSUPPORTED, "d3il_create: unknown task id (Avoiding, Pushing, Sorting, Stacking and Aligning are implemented)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(D3IL_ENODEVICE, "d3il_create: no HIP device available (there is no CPU fallback)");
   if (device_id < 0 || device_id >= ndev || device_id >= 16) return fail(D3IL_ENODEVICE, "d3il_create: device_id out of range");
@@ -679,6 +682,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (task_id == D3IL_TASK_PUSHING && build_push_consts(m, h->pc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_SORTING && build_gen_consts(m, h->hc, h->gc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_STACKING && build_stack_consts(m, h->hc, h->kc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  if (task_id == D3IL_TASK_ALIGNING && build_coop_align_consts(m, h->hc, h->kc, h->atk, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   {  // the kernels are specialised at build time to the robot model (csrc/gen/avoiding_consts.inc): the runtime blob
      // must describe the same arm, controller and (Avoiding) obstacles.  n_substeps / max_steps stay run-time parameters.
     PandaConsts a = h->hc, b = task_id == D3IL_TASK_STACKING ? kStackingConsts : kAvoidingConsts;   // Stacking: the gripper robot without the rod
@@ -731,11 +735,12 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   }
   h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE;
   h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false;
-  h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : (stacking ? SK_STATE_F64 : D3IL_STATE_F64));
-  h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : (stacking ? 21 : 0));
+  const bool aligning = task_id == D3IL_TASK_ALIGNING;
+  h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : (stacking ? SK_STATE_F64 : (aligning ? AL_STATE_F64 : D3IL_STATE_F64)));
+  h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : (stacking ? 21 : (aligning ? AL_CTX : 0)));
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
-  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : 2)); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = pushing ? 2 : (stacking ? 1 : 0);
+  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : (aligning ? AL_OBS : 2))); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = (pushing || aligning) ? 2 : (stacking ? 1 : 0);
   HIPCHK_H(hipMalloc(&h->dc, sizeof(PandaConsts)));
   HIPCHK_H(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
   HIPCHK_H(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
@@ -806,6 +811,17 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     HIPCHK_H(hipMalloc(&h->d_scratch, S * SG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * SG_SIZE * sizeof(double)));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_step, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_reset, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS_RESET));
+  }
+  if (aligning) {
+    {   // the engine constants go through the g_stack_consts cache like the Stacking / cooperative Pushing ones; the task thresholds have their own object
+      std::lock_guard<std::mutex> lock(g_model_mutex);
+      h->kc_id = ++g_kc_counter;
+    }
+    HIPCHK_H(hipDeviceSynchronize());
+    HIPCHK_H(hipMemcpyToSymbol(HIP_SYMBOL(g_align_task), &h->atk, sizeof(AlignTask)));
+    HIPCHK_H(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
+    HIPCHK_H(hipMalloc(&h->d_scratch, S * SG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * SG_SIZE * sizeof(double)));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_aligning_step, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
   }
   h->task_id = task_id;
   HIPCHK_H(hipEventCreate(&h->ev0)); HIPCHK_H(hipEventCreate(&h->ev1));
@@ -896,6 +912,14 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
     HIPCHK(hipGetLastError());
     return D3IL_OK;
   }
+  if (h->task_id == D3IL_TASK_ALIGNING) {
+    if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Aligning task needs contexts (device f64 [n_envs][14]: box pos3 quat4 | target pos3 quat4)");
+    if (int rc = sync_stack_consts(h)) return rc;
+    hipLaunchKernelGGL(k_aligning_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, (hipStream_t)stream, b.state, b.flags, b.step_count, (const double*)nullptr, b.obs,
+                       b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, 1, h->hc.max_steps, 1, env_mask, h->d_init_qpos, contexts);
+    HIPCHK(hipGetLastError());
+    return D3IL_OK;
+  }
   if (contexts) return fail(D3IL_EUNSUPPORTED, "d3il_reset: the Avoiding task takes no contexts");
   hipLaunchKernelGGL(k_avoiding_reset, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->dc, h->d_init_qpos, env_mask, b.state, b.flags,
                      b.step_count, b.obs, b.done, b.success, b.mode, h->n, h->stride);
@@ -944,6 +968,15 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     if (int rc = sync_stack_consts(h)) return rc;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
+                       b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, 0, (const unsigned char*)nullptr, (const double*)nullptr, (const double*)nullptr);
+    HIPCHK(hipGetLastError());
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    return D3IL_OK;
+  }
+  if (h->task_id == D3IL_TASK_ALIGNING) {
+    if (int rc = sync_stack_consts(h)) return rc;
+    if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(k_aligning_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                        b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, 0, (const unsigned char*)nullptr, (const double*)nullptr, (const double*)nullptr);
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
@@ -1087,7 +1120,7 @@ int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream)
   if (h->tally_table || (!avoiding && episode_counts_device)) {
     // Avoiding counts its episodes in the fused reset kernel below
     hipLaunchKernelGGL(k_episode_tally, dim3((h->n + 255) / 256), dim3(256), 0, s, b.done, b.success, b.mode, h->tally_ctx, (long long*)h->tally_table,
-                       avoiding ? (long long*)nullptr : (long long*)episode_counts_device, h->n, h->tally_nctx, h->task_id == D3IL_TASK_PUSHING ? 1 : 0,
+                       avoiding ? (long long*)nullptr : (long long*)episode_counts_device, h->n, h->tally_nctx, (h->task_id == D3IL_TASK_PUSHING || h->task_id == D3IL_TASK_ALIGNING) ? 1 : 0,
                        h->task_id == D3IL_TASK_STACKING ? 1 : 0);
     HIPCHK(hipGetLastError());
   }

@@ -12,6 +12,7 @@
 // The reset kernel runs the one-lane solver (sk_solve) - it is the host build's code path and off the hot path.
 #pragma once
 #include "stack_step.h"
+#include "align_step.h"
 #include "push_kernels.h"
 
 namespace d3il {
@@ -82,15 +83,18 @@ __device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g,
   ss.arm.flags = flags;
   double tau[NARM], ff[NFING];
   const StackScratch sc{t, g};
-  if constexpr (V == SKV_PUSHING) {
+  if constexpr (V != SKV_STACKING) {
     // CartPosQuatImpedenceController (IKControllers.py:163-323): the virtual joint target advances open loop by three damped least-squares
     // iterations per sub-step, then the joint PD law with gravity compensation; fingers commanded open (gym_env_wrapper.py:67)
     double ikq[NARM], ikqd[NARM], des[7], vwarm[7];
     for (int k = 0; k < NARM; k++) { ikq[k] = t[ST_TIPR + SV_IKQ + k]; ikqd[k] = t[ST_TIPR + SV_IKQD + k]; des[k] = t[ST_TIPR + SV_DES + k]; vwarm[k] = t[ST_TIPR + SV_VWARM + k]; }
-    ik_update<true>(kAvoidingConsts, des, des + 3, ss.arm.q, ss.arm.flags, ikq, ikqd, vwarm);
-    for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ikq[k]; t[ST_TIPR + SV_IKQD + k] = ikqd[k]; t[ST_TIPR + SV_VWARM + k] = vwarm[k]; }
-    push_control(kAvoidingConsts, ss.arm, ikq, ikqd, 0.04, false, tau, ff);
-    stack_pre_kin<SKV_PUSHING>(kAvoidingConsts, g_stack_consts, ss, sc, tau, ff);
+    const bool hold = V == SKV_ALIGNING && t[ST_TIPR + SV_HOLD] != 0.0;      // the sub-step of env.reset(): joint PD hold at init_qpos (in the ik_q slots), fingers at 1 mm
+    if (!hold) {
+      ik_update<true>(kAvoidingConsts, des, des + 3, ss.arm.q, ss.arm.flags, ikq, ikqd, vwarm);
+      for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ikq[k]; t[ST_TIPR + SV_IKQD + k] = ikqd[k]; t[ST_TIPR + SV_VWARM + k] = vwarm[k]; }
+    }
+    push_control(kAvoidingConsts, ss.arm, ikq, ikqd, hold ? 0.001 : 0.04, false, tau, ff);
+    stack_pre_kin<V>(kAvoidingConsts, g_stack_consts, ss, sc, tau, ff);
   } else {
     double act[NARM];
     for (int k = 0; k < NARM; k++) act[k] = t[SE_ACT + k];
@@ -120,7 +124,7 @@ __device__ __forceinline__ void sk_phase_mid(sk_lds_double* t, sk_glb_double* g,
   t[SE_JSZ] = (double)jsz;
   bool any_lim = false;
   const StackScratch sc{t, g};
-  if constexpr (V == SKV_PUSHING) stack_pre_finish<true>(kAvoidingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
+  if constexpr (V != SKV_STACKING) stack_pre_finish<true>(kAvoidingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
   else stack_pre_finish<true>(kStackingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
   t[SE_NEED] = (ncon > 0 || any_lim) ? 1.0 : 0.0;
 }
@@ -131,7 +135,7 @@ __device__ __forceinline__ void sk_phase_post(sk_lds_double* t, sk_glb_double* g
   sk_state_from_lds(t, ss);
   ss.arm.flags = flags;
   const StackScratch sc{t, g};
-  if constexpr (V == SKV_PUSHING) stack_substep_post<true>(kAvoidingConsts, g_stack_consts, ss, sc);
+  if constexpr (V != SKV_STACKING) stack_substep_post<true>(kAvoidingConsts, g_stack_consts, ss, sc);
   else stack_substep_post<true>(kStackingConsts, g_stack_consts, ss, sc);
   for (int k = 0; k < NDOF; k++) { t[SE_Q + k] = ss.arm.q[k]; t[ST_VEL + SK_ARM0 + k] = ss.arm.v[k]; }
   for (int b = 0; b < SK_NB; b++) {
@@ -140,6 +144,48 @@ __device__ __forceinline__ void sk_phase_post(sk_lds_double* t, sk_glb_double* g
     for (int k = 0; k < 6; k++) t[ST_VEL + 6 * b + k] = ss.box[b].vel[k];
   }
   flags = ss.arm.flags;
+}
+
+__device__ __forceinline__ void align_load(const double* __restrict__ state, const unsigned* __restrict__ flags, const int* __restrict__ steps, int stride, int e, AlignState& as) {
+  const double* s = state + e;
+  EnvState& st = as.arm;
+  for (int i = 0; i < NDOF; i++) st.q[i] = s[(D3IL_STATE_QPOS + i) * (size_t)stride];
+  for (int i = 0; i < NDOF; i++) st.v[i] = s[(D3IL_STATE_QVEL + i) * (size_t)stride];
+  for (int i = 0; i < NARM; i++) st.bias[i] = s[(D3IL_STATE_BIAS + i) * (size_t)stride];
+  for (int i = 0; i < 3; i++) st.tcp[i] = s[(D3IL_STATE_TCP + i) * (size_t)stride];
+  for (int i = 0; i < NARM; i++) st.ikq[i] = s[(D3IL_STATE_IK_Q + i) * (size_t)stride];
+  for (int i = 0; i < NARM; i++) st.ikqd[i] = s[(D3IL_STATE_IK_QD + i) * (size_t)stride];
+  int k = AL_STATE_BOX;
+  for (int i = 0; i < 3; i++) as.box.pos[i] = s[(size_t)(k++) * stride];
+  for (int i = 0; i < 4; i++) as.box.quat[i] = s[(size_t)(k++) * stride];
+  for (int i = 0; i < 6; i++) as.box.vel[i] = s[(size_t)(k++) * stride];
+  for (int i = 0; i < 7; i++) as.target[i] = s[(size_t)(AL_STATE_TARGET + i) * stride];
+  st.flags = flags[e]; st.step = steps[e];
+}
+__device__ __forceinline__ void align_store(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps, int stride, int e, const AlignState& as) {
+  double* s = state + e;
+  const EnvState& st = as.arm;
+  for (int i = 0; i < NDOF; i++) s[(D3IL_STATE_QPOS + i) * (size_t)stride] = st.q[i];
+  for (int i = 0; i < NDOF; i++) s[(D3IL_STATE_QVEL + i) * (size_t)stride] = st.v[i];
+  for (int i = 0; i < NARM; i++) s[(D3IL_STATE_BIAS + i) * (size_t)stride] = st.bias[i];
+  for (int i = 0; i < 3; i++) s[(D3IL_STATE_TCP + i) * (size_t)stride] = st.tcp[i];
+  for (int i = 0; i < NARM; i++) s[(D3IL_STATE_IK_Q + i) * (size_t)stride] = st.ikq[i];
+  for (int i = 0; i < NARM; i++) s[(D3IL_STATE_IK_QD + i) * (size_t)stride] = st.ikqd[i];
+  int k = AL_STATE_BOX;
+  for (int i = 0; i < 3; i++) s[(size_t)(k++) * stride] = as.box.pos[i];
+  for (int i = 0; i < 4; i++) s[(size_t)(k++) * stride] = as.box.quat[i];
+  for (int i = 0; i < 6; i++) s[(size_t)(k++) * stride] = as.box.vel[i];
+  for (int i = 0; i < 7; i++) s[(size_t)(AL_STATE_TARGET + i) * stride] = as.target[i];
+  flags[e] = st.flags; steps[e] = st.step;
+}
+// the engine's three blocks for the Aligning task: block 0 = the compound body, blocks 1 and 2 parked and inert
+__device__ __forceinline__ void align_to_stack(const AlignState& as, StackState& ss) {
+  ss.arm = as.arm; ss.box[0] = as.box;
+  for (int b = 1; b < SK_NB; b++) {
+    for (int k = 0; k < 3; k++) ss.box[b].pos[k] = 100.0 * b;
+    ss.box[b].quat[0] = 1; ss.box[b].quat[1] = ss.box[b].quat[2] = ss.box[b].quat[3] = 0;
+    for (int k = 0; k < 6; k++) ss.box[b].vel[k] = 0;
+  }
 }
 
 // env.step(action[8]) for the Stacking task (stacking.py:331-393): 7 joint targets + gripper command
@@ -193,6 +239,59 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
     sk_state_to_lds(t, ss);
     for (int k = 0; k < NARM; k++) t[SE_ACT + k] = init_qpos[k];      // joint PD hold at init_qpos, open_fingers() (stacking.py:474)
     fl = 0; step = 0;
+  } else if (live && V == SKV_ALIGNING && reset) {
+    // Robot_Push_Env.reset(random=False, context) (aligning.py:344-372): robot beamed to init_qpos with closed fingers, the box at the context pose,
+    // controllers replaced (ik_q / ik_qd cleared, IK_VALID off), ONE physics sub-step under the joint PD hold; contexts f64 [n][14] = box pos3
+    // quat4 | target pos3 quat4
+    AlignState as;
+    EnvState& st = as.arm;
+    for (int k = 0; k < NDOF; k++) { st.q[k] = k < NARM ? init_qpos[k] : 0.0; st.v[k] = 0; }
+    for (int k = 0; k < NARM; k++) { st.ikq[k] = 0; st.ikqd[k] = 0; }
+    {
+      DynOut dyn;
+      dynamics(kAvoidingConsts, st.q, st.v, dyn);
+      for (int k = 0; k < NARM; k++) st.bias[k] = dyn.bias[k];
+      double tt[3]; mulE(dyn.R7, kAvoidingConsts.tcp7, tt);
+      for (int k = 0; k < 3; k++) st.tcp[k] = dyn.p7[k] + tt[k];
+    }
+    for (int k = 0; k < 3; k++) as.box.pos[k] = contexts[(size_t)e * AL_CTX + k];
+    for (int k = 0; k < 4; k++) as.box.quat[k] = contexts[(size_t)e * AL_CTX + 3 + k];
+    for (int k = 0; k < 6; k++) as.box.vel[k] = 0;
+    for (int k = 0; k < 7; k++) as.target[k] = contexts[(size_t)e * AL_CTX + 7 + k];
+    for (int i = 0; i < SK_NV; i++) t[ST_X + i] = 0;
+    StackState ss;
+    align_to_stack(as, ss);
+    sk_state_to_lds(t, ss);
+    for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = init_qpos[k]; t[ST_TIPR + SV_IKQD + k] = 0; t[ST_TIPR + SV_DES + k] = 0; t[ST_TIPR + SV_VWARM + k] = 0; }
+    t[ST_TIPR + SV_HOLD] = 1.0;
+    for (int k = 0; k < 7; k++) t[SE_ACT + k] = as.target[k];      // the target pose rides in the action slots of the environment region
+    fl = 0; step = 0;
+  } else if (live && V == SKV_ALIGNING) {
+    // Robot_Push_Env.step (aligning.py:282-286 over gym_env_wrapper.py:45-100): set-point, observation / reward / done BEFORE the physics
+    AlignState as;
+    align_load(state, flags, steps, stride, e, as);
+    double act[7], des[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
+    bad = sanitize_action(act, actions + (size_t)e * 7);
+    make_setpoint(act, des);
+    float o[AL_OBS]; unsigned char dn = 0; double reward = 0;
+    align_step_begin(g_align_task, as, o, &reward, &dn, max_steps);
+#pragma unroll
+    for (int k = 0; k < AL_OBS; k++) obs[(size_t)AL_OBS * e + k] = o[k];
+    done[e] = dn; info[(size_t)stride + e] = reward;
+    StackState ss;
+    align_to_stack(as, ss);
+    const double* sw = state + e + (size_t)AL_STATE_WARM * stride;      // warm start: box [6] arm [9]
+    for (int i = 0; i < 6; i++) t[ST_X + i] = sw[(size_t)i * stride];
+    for (int i = 6; i < 18; i++) t[ST_X + i] = 0;
+    for (int i = 0; i < NDOF; i++) t[ST_X + SK_ARM0 + i] = sw[(size_t)(6 + i) * stride];
+    sk_state_to_lds(t, ss);
+    for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = as.arm.ikq[k]; t[ST_TIPR + SV_IKQD + k] = as.arm.ikqd[k]; t[ST_TIPR + SV_DES + k] = des[k]; t[ST_TIPR + SV_VWARM + k] = 0; }
+    t[ST_TIPR + SV_HOLD] = 0.0;
+    for (int k = 0; k < 7; k++) t[SE_ACT + k] = as.target[k];
+    fl = as.arm.flags | ((as.arm.flags & PF_WARM_VALID) ? SKF_WARM_VALID : 0u);
+    step = as.arm.step;
   } else if (live && V == SKV_PUSHING) {
     // Block_Push_Env.step (pushing.py:335-339 over gym_env_wrapper.py:45-100): set-point, observation / reward / done BEFORE the physics
     PushState ps;
@@ -303,6 +402,38 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
   StackState ss;
   sk_state_from_lds(t, ss);
   ss.arm.flags = fl; ss.arm.step = step;
+  if constexpr (V == SKV_ALIGNING) {
+    AlignState as;
+    as.arm = ss.arm; as.box = ss.box[0];
+    for (int k = 0; k < 7; k++) as.target[k] = t[SE_ACT + k];
+    double* sw = state + e + (size_t)AL_STATE_WARM * stride;
+    for (int i = 0; i < 6; i++) sw[(size_t)i * stride] = t[ST_X + i];
+    for (int i = 0; i < NDOF; i++) sw[(size_t)(6 + i) * stride] = t[ST_X + SK_ARM0 + i];
+    if (reset) {
+      for (int k = 0; k < NARM; k++) { as.arm.ikq[k] = 0; as.arm.ikqd[k] = 0; }
+      as.arm.flags = (fl & ~(SKF_WARM_VALID | F_IK_VALID)) | PF_WARM_VALID;
+      float o[AL_OBS];
+      align_obs(as, o);
+      align_store(state, flags, steps, stride, e, as);
+#pragma unroll
+      for (int k = 0; k < AL_OBS; k++) obs[(size_t)AL_OBS * e + k] = o[k];
+      done[e] = 0; success[e] = 0; mode[e] = (unsigned short)(short)-1; info[e] = 0; info[(size_t)stride + e] = 0;
+      return;
+    }
+    for (int k = 0; k < NARM; k++) { as.arm.ikq[k] = t[ST_TIPR + SV_IKQ + k]; as.arm.ikqd[k] = t[ST_TIPR + SV_IKQD + k]; }
+    as.arm.flags = (fl & ~SKF_WARM_VALID) | F_IK_VALID | PF_WARM_VALID;
+    if (bad) as.arm.flags |= F_SOLVER_FAIL | F_TERMINATED;
+    double md = 0;
+    align_step_end(g_align_task, as, &md);
+    // pairs this engine does not evaluate: the box against the finger tips / hand (the rod is 30 cm long; only a policy that lowers the hand onto the box gets there)
+    // (finger-tip boxes reach 15 mm below the TCP, the walls 93.5 mm above the body origin: contact from a height difference of 0.1085 m down; 6.5 mm guard)
+    if (as.arm.tcp[2] - as.box.pos[2] < 0.115 && fabs(as.arm.tcp[0] - as.box.pos[0]) < 0.085 && fabs(as.arm.tcp[1] - as.box.pos[1]) < 0.085) as.arm.flags |= SKF_HAND_NEAR;      // walls reach 5.5 cm, tips 1 cm from the TCP axis; 2 cm guard
+    align_store(state, flags, steps, stride, e, as);
+    success[e] = (as.arm.flags & F_SUCCESS) ? 1 : 0;
+    mode[e] = (unsigned short)(short)((int)((as.arm.flags & PF_MODE_MASK) >> PF_MODE_SHIFT) - 1);
+    info[e] = md;
+    return;
+  }
   if constexpr (V == SKV_PUSHING) {
     PushState ps;
     ps.arm = ss.arm; ps.box[0] = ss.box[0]; ps.box[1] = ss.box[1];
@@ -355,6 +486,17 @@ __global__ __launch_bounds__(WAVE) void k_pushing_step_coop(double* __restrict__
                                                             unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
                                                             double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
   coop_step_body<SKV_PUSHING>(state, flags, steps, actions, obs, done, success, mode, info, scratch, n, stride, n_substeps, max_steps, 0, nullptr, nullptr, nullptr);
+}
+
+// env.step() / env.reset() for the Aligning task on the wave-cooperative engine, variant 2: the rod robot and one free compound
+// body of five box geoms; actions f64 [n][7] (the harness commands x, y and z), state layout D3IL_ALIGN_STATE_*, contexts f64 [n][14].
+__global__ __launch_bounds__(WAVE) void k_aligning_step(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+                                                        const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
+                                                        unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
+                                                        double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps,
+                                                        const int reset, const unsigned char* __restrict__ reset_mask, const double* __restrict__ init_qpos,
+                                                        const double* __restrict__ contexts) {
+  coop_step_body<SKV_ALIGNING>(state, flags, steps, actions, obs, done, success, mode, info, scratch, n, stride, n_substeps, max_steps, reset, reset_mask, init_qpos, contexts);
 }
 
 // env.reset(random=False, context) for masked environments; contexts: f64 [n][21] = 3 x (pos3, quat4), red green blue

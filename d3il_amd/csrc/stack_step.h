@@ -60,10 +60,23 @@ struct StackConsts {
   // Cartesian controller): rod cylinder in the link-7 frame, translational body_invweight0 of the rod body
   int variant, var_pad;
   double rod_c7[3], rod_u7[3], rod_r, rod_h, invw_rod;
+  double box_invw[SK_NB];      // translational body_invweight0 of the free bodies (1 / mass for a body whose centre of mass is its origin)
+  // Aligning variant (variant 2: the rod robot and ONE free compound body = block 0, robot_push_box.xml: a plate carrying four walls - AL_NG box
+  // geoms on one body, centre of mass al_c in the body frame).  The engine works in CENTRE-OF-MASS coordinates of that body (mass matrix
+  // diagonal, gravity torque-free): stack_pre_kin converts MuJoCo's (origin position, origin velocity) to them, stack_substep_post converts the
+  // accelerations back before the Euler step, and the contact rows' reference accelerations carry the centripetal term that separates
+  // J qacc of the two coordinate systems.
+  int al_ng, al_pad;
+  double al_gpos[5][3], al_ghalf[5][3], al_gr[5];      // geom centres in the body frame, half sizes, bounding radii
+  double al_c[3], al_r;                                // centre of mass in the body frame; bounding radius of the whole body about its origin
+  int al_set_static[5], al_set_rod[5];                 // contact parameter set of geom g against static s (+ s) / against the rod
 };
-enum { SKV_STACKING = 0, SKV_PUSHING = 1 };
+enum { SKV_STACKING = 0, SKV_PUSHING = 1, SKV_ALIGNING = 2 };
+constexpr int AL_NG = 5;
 // Pushing variant: the finger-geom tables of the t area are not needed; their place holds the rod pose and the controller state
 constexpr int SV_ROD = 0 /* + ST_TIPR: rod centre[3], axis[3] */, SV_IKQ = 6, SV_IKQD = 13, SV_DES = 20 /* desired pose pos[3] quat[4] */, SV_VWARM = 27 /* 7 */, SV_END = 34;
+// Aligning variant: + the centripetal acceleration of the body origin relative to the centre of mass, w x (w x R c) in the world frame [3], and the hold flag of a reset
+constexpr int SV_CEN = 34, SV_HOLD = 37, SV_END2 = 38;
 
 // flag bits of the Stacking task (EnvState::flags).  F_TERMINATED / F_SUCCESS / F_SOLVER_FAIL keep their positions.
 enum : unsigned {
@@ -526,7 +539,7 @@ D3IL_NOINLINE inline void sk_contact_dot(const StackConsts& kc_, const StackScra
   const double dist = SG(base + 12);
   const double imp = impedance(ps.solimp, dist - ps.margin);
   const int a = (int)SG(base + 13), b = (int)SG(base + 14);
-  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body == SKB_ROD ? kc.invw_rod : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])))); };
+  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? kc.box_invw[body] : (body == SKB_ROD ? kc.invw_rod : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])))); };
   const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
   const double R1 = R0 / fmax(1e-15, kc.impratio);
   for (int r = 0; r < 4; r++) {
@@ -867,13 +880,22 @@ __device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, 
   const double dist = rec[12];
   const double imp = impedance(ps.solimp, dist - ps.margin);
   const int a = (int)rec[13], b = (int)rec[14];
-  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? 1.0 / kc.box_mass[body] : (body == SKB_ROD ? kc.invw_rod : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])))); };
+  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? kc.box_invw[body] : (body == SKB_ROD ? kc.invw_rod : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])))); };
   const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
   const double R1 = R0 / fmax(1e-15, kc.impratio);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const double v = r < R.dim ? sk_dot(sc, R, r, ST_VEL) : 0.0;
     cc.aref[r] = r < R.dim ? -ps.B * v - (r == 0 ? ps.K * imp * (dist - ps.margin) : 0.0) : 0.0;
+  }
+  if (kc.variant == SKV_ALIGNING && (a == 0 || b == 0)) {
+    // MuJoCo's row residual is J_o qacc_o - aref with the free body's ORIGIN acceleration; this engine solves for the centre-of-mass acceleration
+    // a_c = a_o + alpha x R c + w x (w x R c), so J_o qacc_o = J_c qacc_c -/+ d . (w x (w x R c)) for the body as geom 2 / geom 1 of the pair:
+    // the velocity-dependent term moves into the reference acceleration
+    const double sgn = b == 0 ? 1.0 : -1.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      cc.aref[r] += sgn * (rec[3 + 3 * r] * sc.t[ST_TIPR + SV_CEN] + rec[4 + 3 * r] * sc.t[ST_TIPR + SV_CEN + 1] + rec[5 + 3 * r] * sc.t[ST_TIPR + SV_CEN + 2]);
   }
   cc.D[0] = 1 / R0; cc.D[1] = 1 / R1; cc.D[2] = 1 / R1; cc.D[3] = 1 / (R1 * ps.fric[0] * ps.fric[0] / (ps.fric[1] * ps.fric[1]));
   cc.mu = ps.fric[0] * sqrt(R1 / R0);
@@ -1253,7 +1275,7 @@ D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, 
     double R7[9], p7[3], ax[NARM][3], og[NARM][3];
     world_chain(c0, dyn.sn, dyn.cs, R7, p7, ax, og);
     for (int k = 0; k < NARM; k++) for (int i = 0; i < 3; i++) { SL(ST_Z + 3 * k + i) = ax[k][i]; SL(ST_O + 3 * k + i) = og[k][i]; }
-    if constexpr (V == SKV_PUSHING) {      // rod cylinder: centre and axis in the world
+    if constexpr (V == SKV_PUSHING || V == SKV_ALIGNING) {      // rod cylinder: centre and axis in the world
       double t3[3];
       mulE(R7, kc.rod_c7, t3);
       for (int i = 0; i < 3; i++) SL(ST_TIPR + SV_ROD + i) = p7[i] + t3[i];
@@ -1282,6 +1304,16 @@ D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, 
     quat2mat(qn, R);
     for (int k = 0; k < 9; k++) SL(ST_BR + 9 * b + k) = R[k];
     for (int k = 0; k < 3; k++) SL(ST_BP + 3 * b + k) = ss.box[b].pos[k];
+    if (V == SKV_ALIGNING && b == 0) {
+      // centre-of-mass coordinates of the compound body: p_c = p_o + R c, v_c = v_o + R (w x c) (w: body-frame angular velocity, MuJoCo's free-joint
+      // convention); centripetal term w_w x (w_w x R c) = R (w x (w x c)) for the contact rows and the conversion back
+      const double* wl = ss.box[0].vel + 3;
+      double wc[3], wwc[3], t3[3];
+      cross3(wl, kc.al_c, wc); cross3(wl, wc, wwc);
+      mulE(R, kc.al_c, t3); for (int k = 0; k < 3; k++) SL(ST_BP + k) = ss.box[0].pos[k] + t3[k];
+      mulE(R, wc, t3); for (int k = 0; k < 3; k++) ss.box[0].vel[k] += t3[k];
+      mulE(R, wwc, t3); for (int k = 0; k < 3; k++) SL(ST_TIPR + SV_CEN + k) = t3[k];
+    }
     const double* I = kc.box_inertia[b];
     const double* w = ss.box[b].vel + 3;
     const double Iw[3] = {I[0] * w[0], I[1] * w[1], I[2] * w[2]};
@@ -1637,6 +1669,41 @@ __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* s
   auto tip_shape = [&](int f, double* R, double* p, double* h) { ld(ST_TIPR + 9 * f, 9, R); ld(ST_TIPP + 3 * f, 3, p); for (int k = 0; k < 3; k++) h[k] = kc.tip_half[k]; };
   auto hull_shape = [&](int f, double* R, double* p, double* h) { ld(ST_HULR + 9 * f, 9, R); ld(ST_HULP + 3 * f, 3, p); h[0] = h[1] = h[2] = 0; };
   if (!act) return j;
+  if (kc.variant == SKV_ALIGNING) {
+    // lane groups 0 .. 4: geom g of the compound body against the static slabs (one per round); 5 .. 9: the rod cylinder against geom g (round 0).
+    // A geom's pose: the body's rotation, centre = centre of mass (ST_BP of block 0 in this variant) + R (geom centre - c)
+    const int g = grp < AL_NG ? grp : grp - AL_NG;
+    if (grp >= 2 * AL_NG || g >= kc.al_ng) return j;
+    ld(ST_BR, 9, RB);
+    {
+      double pc[3]; ld(ST_BP, 3, pc);
+      for (int k = 0; k < 3; k++) { pB[k] = pc[k] + RB[3 * k] * kc.al_gpos[g][0] + RB[3 * k + 1] * kc.al_gpos[g][1] + RB[3 * k + 2] * kc.al_gpos[g][2]; hB[k] = kc.al_ghalf[g][k]; }
+    }
+    if (grp < AL_NG) {
+      if (round < kc.ns) {
+        const int sidx = round;
+        double d[3] = {pB[0] - kc.st_c[sidx][0], pB[1] - kc.st_c[sidx][1], pB[2] - kc.st_c[sidx][2]}, ex = 0;
+        for (int i = 0; i < 3; i++) { double loc = kc.st_R[sidx][i] * d[0] + kc.st_R[sidx][3 + i] * d[1] + kc.st_R[sidx][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[sidx][i]; if (o > 0) ex += o * o; }
+        const int set = kc.al_set_static[g] + sidx;
+        const double rc = kc.al_gr[g] + kc.set[set].margin;
+        if (ex <= rc * rc) {
+          j.kind = 1; j.ba = SKB_STATIC; j.bb = 0; j.set = set;
+          for (int k = 0; k < 9; k++) RA[k] = kc.st_R[sidx][k];
+          for (int k = 0; k < 3; k++) { pA[k] = kc.st_c[sidx][k]; hA[k] = kc.st_h[sidx][k]; }
+        }
+      }
+    } else if (round == 0) {      // rod <-> geom: pA = rod centre, RA[0..2] = rod axis, hA = (radius, half length, -); the box geom is geom 1 of the pair
+      ld(ST_TIPR + SV_ROD, 3, pA); ld(ST_TIPR + SV_ROD + 3, 3, RA);
+      hA[0] = kc.rod_r; hA[1] = kc.rod_h; hA[2] = 0;
+      const int set = kc.al_set_rod[g];
+      const double w[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]};
+      const double al = fmin(fmax(w[0] * RA[0] + w[1] * RA[1] + w[2] * RA[2], -kc.rod_h), kc.rod_h);
+      const double dd[3] = {w[0] - al * RA[0], w[1] - al * RA[1], w[2] - al * RA[2]}, rc = kc.al_gr[g] + kc.rod_r + kc.set[set].margin;
+      if (dot3(dd, dd) <= rc * rc) { j.kind = 4; j.ba = 0; j.bb = SKB_ROD; j.set = set; }
+    }
+    if (j.kind != 0) j.margin = kc.set[j.set].margin;
+    return j;
+  }
   if (kc.variant == SKV_PUSHING) {
     if (grp < 2) {
       if (round < kc.ns) {
@@ -1875,7 +1942,7 @@ __device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_d
 #else
 #define SKP_TOC(slot) ((void)0)
 #endif
-  const int n_rounds = kc.variant == SKV_PUSHING ? kc.ns : (kc.ns > 4 ? kc.ns : 4);
+  const int n_rounds = kc.variant != SKV_STACKING ? kc.ns : (kc.ns > 4 ? kc.ns : 4);
   for (int round = 0; round < n_rounds; round++) {
     int r = sk_round_boxbox(kc, smem, lane, round, live_mask);
     SKP_TOC(14);
@@ -1916,6 +1983,7 @@ __device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_d
 template <bool WARM_LDS, class C>
 D3IL_HD void stack_substep_post(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc) {
   D3IL_REFRESH(c0, c);
+  D3IL_STACK_CONSTS(kc_, kc);
   EnvState& st = ss.arm;
   const double h = c.timestep;
   SK_TIC;
@@ -1933,10 +2001,19 @@ D3IL_HD void stack_substep_post(const C& c0, const StackConsts& kc_, StackState&
   for (int b = 0; b < SK_NB; b++) {
     double acc[6];
     for (int k = 0; k < 6; k++) acc[k] = SL(ST_X + 6 * b + k);
+    if (kc.variant == SKV_ALIGNING && b == 0) {
+      // the state read from the tables and the solution are in centre-of-mass coordinates (stack_pre_kin): back to MuJoCo's body origin
+      // before mj_Euler: p_o = p_c - R c, v_o = v_c - R (w x c), a_o = a_c - R (alpha x c) - w_w x (w_w x R c)
+      double R[9], t3[3], wc[3], ac[3];
+      for (int k = 0; k < 9; k++) R[k] = SL(ST_BR + k);
+      mulE(R, kc.al_c, t3); for (int k = 0; k < 3; k++) ss.box[0].pos[k] -= t3[k];
+      cross3(ss.box[0].vel + 3, kc.al_c, wc); mulE(R, wc, t3); for (int k = 0; k < 3; k++) ss.box[0].vel[k] -= t3[k];
+      cross3(acc + 3, kc.al_c, ac); mulE(R, ac, t3); for (int k = 0; k < 3; k++) acc[k] -= t3[k] + SL(ST_TIPR + SV_CEN + k);
+    }
     cube_integrate(ss.box[b], acc, h);
   }
   SK_TOC(5);
-  (void)kc_;
+  (void)kc;
 }
 // the sub-step on one lane (host build, reset kernel)
 template <class C>
@@ -2067,7 +2144,7 @@ D3IL_HOSTFN inline int build_stack_consts(const d3il_model_blob& m, const PandaC
     if (gb[b] < 0 || m.geom_type[gb[b]] != D3IL_GEOM_BOX) { *err = "task objects must be boxes"; return -1; }
     for (int k = 0; k < 3; k++) { kc.box_half[b][k] = m.geom_size[gb[b]][k]; kc.box_inertia[b][k] = m.body_inertia[bd][k]; if (m.geom_pos[gb[b]][k] != 0) { *err = "boxes must be centred on their bodies"; return -1; } }
     if (m.body_iquat[bd][0] != 1.0) { *err = "box inertial frames must be the body frames"; return -1; }
-    kc.box_mass[b] = m.body_mass[bd];
+    kc.box_mass[b] = m.body_mass[bd]; kc.box_invw[b] = 1.0 / kc.box_mass[b];
     if (b > 0 && gb[b] < gb[b - 1]) { *err = "unexpected geom order"; return -1; }
   }
   // world transforms of all bodies at q = 0
@@ -2251,7 +2328,7 @@ D3IL_HOSTFN inline int build_coop_push_consts(const PandaConsts& pcst, const Pus
   for (int b = 0; b < SK_NB; b++) {
     const bool real = b < PUSH_NB;
     for (int k = 0; k < 3; k++) { kc.box_half[b][k] = real ? pc.box_half[k] : 0.01; kc.box_inertia[b][k] = real ? pc.box_inertia : 1.0; }
-    kc.box_mass[b] = real ? pc.box_mass : 1.0;
+    kc.box_mass[b] = real ? pc.box_mass : 1.0; kc.box_invw[b] = 1.0 / kc.box_mass[b];
     kc.box_r[b] = std::sqrt(kc.box_half[b][0] * kc.box_half[b][0] + kc.box_half[b][1] * kc.box_half[b][1] + kc.box_half[b][2] * kc.box_half[b][2]);
   }
   if (std::fabs(pc.box_invw_t * pc.box_mass - 1.0) > 1e-12) { *err = "cube invweight"; return -1; }

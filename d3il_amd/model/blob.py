@@ -29,7 +29,7 @@ I32, U32, F64 = C.c_int32, C.c_uint32, C.c_double
 FIELDS = [
     ("magic", U32, (), "D3IL_BLOB_MAGIC"),
     ("version", U32, (), "D3IL_BLOB_VERSION"),
-    ("task_id", I32, (), "0 avoiding, 1 pushing, 2 sorting, 3 stacking, 4 aligning (oracle only)"),
+    ("task_id", I32, (), "0 avoiding, 1 pushing, 2 sorting, 3 stacking, 4 aligning"),
     ("nbody", I32, (), ""), ("njnt", I32, (), ""), ("ngeom", I32, (), ""),
     ("nu", I32, (), ""), ("nexclude", I32, (), ""), ("nchain", I32, (), ""),
     ("iterations", I32, (), "solver iteration cap (MuJoCo default 100)"),
@@ -121,7 +121,7 @@ def emit_header() -> str:
         "#define D3IL_MAXOBST %d" % MAXOBST, "#define D3IL_MAXMESH %d" % MAXMESH, "#define D3IL_MAXMVERT %d" % MAXMVERT, "",
         "enum { D3IL_JNT_FREE = 0, D3IL_JNT_HINGE = 2, D3IL_JNT_SLIDE = 3 };",
         "enum { D3IL_GEOM_PLANE = 0, D3IL_GEOM_SPHERE = 2, D3IL_GEOM_CYLINDER = 5, D3IL_GEOM_BOX = 6, D3IL_GEOM_MESH = 7 };",
-        "enum { D3IL_TASK_AVOIDING = 0, D3IL_TASK_PUSHING = 1, D3IL_TASK_SORTING = 2, D3IL_TASK_STACKING = 3 };",
+        "enum { D3IL_TASK_AVOIDING = 0, D3IL_TASK_PUSHING = 1, D3IL_TASK_SORTING = 2, D3IL_TASK_STACKING = 3, D3IL_TASK_ALIGNING = 4 };",
         "", "typedef struct d3il_model_blob {",
     ]
     for n, ct, sh, cm in FIELDS:

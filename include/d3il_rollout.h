@@ -36,7 +36,7 @@ enum {
   D3IL_ESTATE = -6, D3IL_ERCCL = -7
 };
 
-/* Tasks (task_id of d3il_create; the enum itself is D3IL_TASK_* in d3il_model_blob.h: 0 Avoiding, 1 Pushing, 2 Sorting, 3 Stacking) and
+/* Tasks (task_id of d3il_create; the enum itself is D3IL_TASK_* in d3il_model_blob.h: 0 Avoiding, 1 Pushing, 2 Sorting, 3 Stacking, 4 Aligning) and
  * their shapes:
  *   task      reference env (environments/d3il/envs/...)            action (device f64, row-major)              obs f32   contexts f64     state rows
  *   Avoiding  gym_avoiding/envs/avoiding.py ObstacleAvoidanceEnv    [n][7] desired TCP x y z qw qx qy qz        [n][2]    none             42
@@ -44,6 +44,7 @@ enum {
  *   Sorting   gym_sorting/envs/sorting.py Sorting_Env (2 / 4 boxes) [n][7] same                                 [n][2+3b] [n][7 b]         42+13b+(9+6b)+2
  *   Stacking  gym_stacking/envs/stacking.py CubeStacking_Env        [n][8] 7 desired joint positions + gripper   [n][12]   [n][21]          94
  *                                                                   command (open iff > 0.075, stacking.py:337-346)
+ *   Aligning  gym_aligning/envs/aligning.py Robot_Push_Env          [n][7] as Avoiding (the harness commands z)  [n][17]   [n][14]          77
  */
 
 /* f64 state fields per environment, in SoA order */
@@ -66,7 +67,13 @@ enum {
    * qfrc_bias 7, TCP 3), then per box pos[3] quat[4] vel[6] in the order red, green, blue (D3IL_STACK_STATE_BOX + 13 k), then the
    * constraint solver's warm start qacc[27] (box 0, box 1, box 2, arm 9).  The task state of CubeStacking_Env (order in which the boxes
    * reached the target zone, stacking.py:395-419) lives in the flag word (D3IL_SFLAG_*). */
-  D3IL_STACK_STATE_BOX = 28, D3IL_STACK_STATE_WARM = 67, D3IL_STACK_STATE_F64 = 94
+  D3IL_STACK_STATE_BOX = 28, D3IL_STACK_STATE_WARM = 67, D3IL_STACK_STATE_F64 = 94,
+  /* Aligning (gym_aligning/envs/aligning.py; the rod robot, Cartesian controller: rows 0..41 as for Avoiding): the free compound body
+   * (robot_push_box.xml: plate + four walls) pos[3] quat[4] vel[6] as MuJoCo's free joint holds them (body origin, body-frame angular velocity),
+   * the solver's warm start qacc[15] (box 6 - in centre-of-mass coordinates -, arm 9), the target pose pos[3] quat[4] of the context
+   * (aligning.py:107-122; it only enters observation, reward and success).  Flag word: the Pushing bits (mode + 1 in D3IL_PFLAG_MODE_MASK: 0 / 1 =
+   * rod inside / outside the walls, aligning.py:288-312; WARM_VALID, OFF_TABLE, CON_OVERFLOW) and D3IL_SFLAG_HAND_NEAR. */
+  D3IL_ALIGN_STATE_BOX = 42, D3IL_ALIGN_STATE_WARM = 55, D3IL_ALIGN_STATE_TARGET = 70, D3IL_ALIGN_STATE_F64 = 77
 };
 /* bits of the per-environment u32 flag word */
 enum {

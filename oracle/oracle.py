@@ -267,6 +267,16 @@ class Oracle:
         self.L.orc_align_step(self.h, _p(action), _p(obs), C.byref(done), C.byref(rew), C.byref(mode), C.byref(succ), C.byref(md))
         return obs, rew.value, bool(done.value), dict(mode=mode.value, success=bool(succ.value), mean_distance=md.value)
 
+    def align_set_state(self, s77, step=0, terminated=False, ik_valid=True):
+        """Load one environment's column of the HIP path's Aligning state buffer (+ step counter, flags)."""
+        s77 = np.ascontiguousarray(s77, float)
+        self.L.orc_align_set_state(self.h, _p(s77), int(step), int(terminated), int(ik_valid))
+
+    def align_state(self):
+        """(arm q[9] v[9], box pos3 quat4 vel6) of the oracle in the device layout."""
+        qp, qv = self.state()
+        return np.concatenate([qp[7:16], qv[6:15]]), np.concatenate([qp[0:7], qv[0:6]])
+
     def align_logic(self, box7, target7, tcp):
         box7, target7, tcp = (np.ascontiguousarray(x, float) for x in (box7, target7, tcp))
         obs = np.zeros(17, dtype=np.float32)

@@ -96,6 +96,29 @@ def stacking_episode(job):
     return i, bool(info["success"]), info["mode"], t + 1
 
 
+def aligning_episode(job):
+    """job = (index, ctx14, init_qpos, max_steps, inside) -> (index, success, mode, steps): the rollout loop of Aligning_Sim (aligning_sim.py:96-108)."""
+    i, ctx, q0, max_steps, inside = job
+    torch = _torch()
+    from d3il_amd.agents import ScriptedAlignPolicy
+    from d3il_amd.model import blob
+    from oracle.oracle import Oracle
+    b = blob.load("aligning")
+    o = Oracle(b)
+    o.env_start(q0)
+    obs = o.align_reset(ctx)
+    des = np.array(o.body(b.tcp_body)[0], dtype=np.float64)          # env.robot_state(): the measured TCP (f64), not its f32 observation
+    pol = ScriptedAlignPolicy(inside=[bool(inside)], device="cpu")
+    info, t = dict(mode=-1, success=False), 0
+    for t in range(max_steps):
+        x = torch.as_tensor(np.concatenate([des, obs.astype(np.float64)])[None], dtype=torch.float64)
+        des = des + pol.predict_batch(x)[0].numpy()
+        obs, _, done, info = o.align_step(np.concatenate([des, [0, 1, 0, 0]]))
+        if done:
+            break
+    return i, bool(info["success"]), int(info["mode"]), t + 1
+
+
 def n_workers() -> int:
     sys.path.insert(0, ROOT)
     from bench import _available_cores
