@@ -34,21 +34,23 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
-PROFILE_DIRS = ("r03", "r02", "r01")  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
+PROFILE_DIRS = ("r04", "r03", "r02", "r01")  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
 
 # Algorithmic HBM bytes per env step: SURVEY.md section 8(d)'s per-unit figures B_alg = 2 S + A + O + F (state read once + written once per
 # fused step, f64 state, f32 action / observation) - these define `roofline.achieved`.  IMPL_BYTES is what THIS implementation's state
 # column moves per env step (it also carries the flag / counter words, f64 actions, the stale-TCP / bias rows and - contact tasks - the
 # solver's warm start); reported next to it as `implementation_bytes_per_launch`, not used for `frac`.
-ALG_BYTES = {"avoiding": 704, "pushing": 1152, "sorting": 1620, "stacking": 1228}
+ALG_BYTES = {"avoiding": 704, "pushing": 1152, "sorting": 1620, "stacking": 1228,
+             "aligning": 2 * (8 * (16 + 15) + 168 + 56 + 8) + 28 + 68 + 12}      # SURVEY 8(d)'s formula for the 16 / 15 model of the Aligning task (S_task: the 7-double target + flags): 1068
 IMPL_BYTES = {
     "avoiding": 2 * (42 * 8 + 4 + 4) + 56 + 8 + 4,
     "pushing": 2 * (89 * 8 + 4 + 4) + 56 + 32 + 4 + 16,
     "sorting": 2 * (129 * 8 + 4 + 4) + 56 + 56 + 4,
     "stacking": 2 * (94 * 8 + 4 + 4) + 64 + 48 + 4 + 8,
+    "aligning": 2 * (77 * 8 + 4 + 4) + 56 + 68 + 4 + 16,
 }
-KERNEL = {"avoiding": "k_avoiding_step_split<true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step"}
-PMC_FILE = {"avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json"}
+KERNEL = {"avoiding": "k_avoiding_step_split<true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step", "aligning": "k_aligning_step"}
+PMC_FILE = {"aligning": "pmc_summary_aligning.json", "avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json"}
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline (oracle)
@@ -92,8 +94,25 @@ def _cpu_worker(task, blob_bytes, init_qpos, contexts, budget_s, seed):
                     break
         return n, time.perf_counter() - t0
     import torch
-    from d3il_amd.agents import RandomResidualMLPPolicy
     torch.set_num_threads(1)
+    if task == "aligning":      # the GPU workload's scripted policy (inside / outside pushes alternate over the contexts), episode after episode
+        from d3il_amd.agents import ScriptedAlignPolicy
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            c = ep % len(contexts)
+            obs = o.align_reset(contexts[c])
+            des = np.array(o.body(blob.tcp_body)[0], dtype=np.float64)
+            pol = ScriptedAlignPolicy(inside=[c % 2 == 0], device="cpu")
+            for t in range(400):
+                x = torch.as_tensor(np.concatenate([des, obs.astype(np.float64)])[None], dtype=torch.float64)
+                des = des + pol.predict_batch(x)[0].numpy()
+                obs, _, done, _ = o.align_step(np.concatenate([des, [0, 1, 0, 0]]))
+                n += 1
+                if done or time.perf_counter() - t0 >= budget_s:
+                    break
+            ep += 1
+        return n, time.perf_counter() - t0
+    from d3il_amd.agents import RandomResidualMLPPolicy
     pol = RandomResidualMLPPolicy(input_dim=10 if task == "pushing" else 16, device="cpu")
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
@@ -168,7 +187,7 @@ def cpu_baseline(task, blob, init_qpos, contexts, budget_s=10.0):
     res = [tuple(float(x) for x in o.decode().split()[-2:]) for o in outs if o.strip()]
     total = sum(r[0] for r in res)
     busy = max(r[1] for r in res) if res else float("nan")
-    pol = {"avoiding": "random policy", "stacking": "scripted pick-and-place"}.get(task, "ResidualMLP stand-in policy on the CPU")
+    pol = {"avoiding": "random policy", "stacking": "scripted pick-and-place", "aligning": "scripted inside / outside pushes"}.get(task, "ResidualMLP stand-in policy on the CPU")
     return {"value": total / busy, "unit": "env-steps/s", "cores": len(res), "kind": "port",
             "single_core_value": n1 / t1, "host_logical_cpus": logical,
             "sample": "one oracle environment per core on all %d cores this container may use (affinity capped by the cgroup CPU quota) (%s, %d env steps of 35 (Stacking: 30) sub-steps in %.1f s of stepping per worker, %.1f s wall "
@@ -244,6 +263,7 @@ POLICY_TEXT = {
     "ddpm": "DDPM policy of BASELINE config 4 (DiffusionMLP %d->256x8->2, t_dim 8, 4 denoising steps, fixed random weights, torch f32)",
     "beso": "BESO policy of BASELINE config 5 (DiffusionGPT 6 layers x 6 heads x 120, window 5, 16 Euler-ancestral steps, fixed random weights, torch f32)",
     "scripted_push": "scripted pushing policy (every rod drives a cube to its target / bin: the contact regime)",
+    "scripted_align": "scripted pushes from inside / outside the box walls (the two behaviour modes of the Aligning task)",
     "scripted_stack": "scripted pick-and-place policy (joint-space table from host IK: grasp, carry, stack - the contact regime of the task)",
 }
 
@@ -337,6 +357,10 @@ def run(args):
         from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
         env = SortingVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 700)     # configs/sorting_4_config.yaml:80
         ctx60 = sample_contexts(60, 4, seed=0)     # the reference's 4_test_contexts.pkl is not part of its tree
+    elif task == "aligning":
+        from d3il_amd.envs.aligning import RobotPushVecEnv, load_test_contexts as load_align_contexts
+        env = RobotPushVecEnv(n, device=dev)
+        ctx60 = load_align_contexts()
     else:
         from d3il_amd.envs.stacking import CubeStackingVecEnv, load_test_contexts as load_stack_contexts
         env = CubeStackingVecEnv(n, device=dev)
@@ -362,7 +386,7 @@ def run(args):
     table = env.set_tally(len(ctx60) if ctx60 is not None else 1, ctx_id)
     episodes = torch.zeros(2, dtype=torch.int64, device=dev)   # finished, successful
     actions = torch.zeros(n, env.action_dim, dtype=torch.float64, device=dev)
-    policy = args.policy or {"avoiding": "random", "stacking": "scripted_stack"}.get(task, "mlp")
+    policy = args.policy or {"avoiding": "random", "stacking": "scripted_stack", "aligning": "scripted_align"}.get(task, "mlp")
     pol = None
     last_cmd = None
     if task == "stacking":
@@ -378,6 +402,15 @@ def run(args):
         else:
             raise SystemExit("--policy %s is not available for task %s" % (policy, task))
         last_cmd = env.robot_state().to(torch.float32).clone()                      # stacking_sim.py:90-91
+    elif task == "aligning":
+        from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedAlignPolicy
+        if policy == "scripted_align":
+            pol = ScriptedAlignPolicy(inside=(ctx_id % 2 == 0), device=dev)
+        elif policy == "mlp":
+            pol = RandomResidualMLPPolicy(input_dim=20, output_dim=3, device=dev, bound=0.01)
+        else:
+            raise SystemExit("--policy %s is not available for task %s" % (policy, task))
+        actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
     elif task != "avoiding" or policy != "random":
         from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedPushPolicy
         if policy == "mlp":
@@ -403,6 +436,13 @@ def run(args):
             out = pol.predict_batch(obs20).to(torch.float32)
             last_cmd = torch.cat((out[:, :7] + obs20[:, :7], out[:, 7:8]), dim=1)   # stacking_sim.py:104
             actions.copy_(last_cmd)
+        elif task == "aligning":
+            if hasattr(pol, "begin_episodes"):
+                pol.begin_episodes(env.last_reset)
+            des3 = env.policy_des[:, :n]                                             # [3, n]: the library re-latches it to the TCP on auto-reset
+            obs_in = torch.cat((des3.t(), env.obs.to(torch.float64)), dim=1)        # np.concatenate((pred_action[:3], obs)), aligning_sim.py:99
+            des3.add_(pol.predict_batch(obs_in).to(torch.float64).t())              # aligning_sim.py:101-102: x, y and z are commanded
+            actions[:, 0:3] = des3.t()
         elif pol is None:
             env.policy_action(42, env_offset, t, actions)
         else:
@@ -473,11 +513,11 @@ def run(args):
     st, fl, sc = env.get_state()
     n_state = env.state_rows - (2 if task == "sorting" else 0)
     n_sub = env.n_substeps
-    finite = bool(np.isfinite(st[:n_state]).all())
+    finite = bool(np.isfinite(st[:n_state]).all())      # (the Aligning mean distance / reward may be NaN like the reference's: they are info rows, not state)
     flagged = {"solver_fail": int(((fl >> 16) & 1).sum())}
     if task != "avoiding":
         flagged.update(contact_overflow=int(((fl >> 18) & 1).sum()), off_table=int(((fl >> 19) & 1).sum()))
-    if task == "stacking":
+    if task in ("stacking", "aligning"):
         flagged.update(hand_near=int(((fl >> 20) & 1).sum()))
     if rank == 0:
         value = world * n * args.steps / dt
@@ -509,6 +549,8 @@ def run(args):
                        "400-step episodes with auto-reset" % (n, POLICY_TEXT[policy] % 10 if policy in ("mlp", "ddpm") else POLICY_TEXT[policy]),
             "sorting": "Sorting-4 task, %d envs per GPU, 60 contexts sampled like BlockContextManager.sample tiled, %s, 35 fused physics sub-steps per "
                        "env step, %d-step episodes with auto-reset" % (n, POLICY_TEXT[policy] % 16 if policy in ("mlp", "ddpm") else POLICY_TEXT[policy], max_steps),
+            "aligning": "Aligning task, %d envs per GPU, the 60 reference test contexts tiled, %s, 35 fused physics sub-steps per env step, 400-step episodes with "
+                        "auto-reset" % (n, POLICY_TEXT["scripted_align"] if policy == "scripted_align" else "ResidualMLP 20->128x6->3 (Mish) stand-in policy with fixed random weights (torch, f32)"),
             "stacking": "Stacking task, %d envs per GPU, the first %d of the reference's 100 test contexts tiled, %s, 30 fused physics sub-steps per env step, "
                         "1000-step episodes with auto-reset" % (n, len(ctx60) if ctx60 is not None else 0,
                                                                 POLICY_TEXT[policy] if policy != "mlp" else "ResidualMLP 20->128x6->8 (Mish) stand-in policy with fixed random weights (torch, f32)"),
@@ -547,12 +589,12 @@ def run(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting", "stacking"], help="avoiding = the headline configuration (BASELINE configs[1])")
+    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting", "stacking", "aligning"], help="avoiding = the headline configuration (BASELINE configs[1])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--policy", default=None, choices=["random", "mlp", "scripted_push", "scripted_stack", "ddpm", "beso"],
+    ap.add_argument("--policy", default=None, choices=["random", "mlp", "scripted_push", "scripted_stack", "scripted_align", "ddpm", "beso"],
                     help="default: random (Avoiding), mlp (Pushing / Sorting), scripted_stack (Stacking: pick-and-place, the contact regime of the task)")
     ap.add_argument("--max-steps", type=int, default=None, help="Sorting: episode cap (default 700 = configs/sorting_4_config.yaml:80; the Sim class default is 500)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

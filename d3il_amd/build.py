@@ -15,7 +15,7 @@ LIB = os.path.join(PKG, "libd3il_rollout.so")
 SOURCES = [os.path.join(PKG, "csrc", "rollout.hip")]
 DEPS = SOURCES + [os.path.join(PKG, "csrc", "panda_step.h"), os.path.join(PKG, "csrc", "panda_consts.h"),
                   os.path.join(PKG, "csrc", "push_step.h"), os.path.join(PKG, "csrc", "gen_step.h"), os.path.join(PKG, "csrc", "gen_kernels.h"), os.path.join(PKG, "csrc", "push_kernels.h"),
-                  os.path.join(PKG, "csrc", "stack_step.h"), os.path.join(PKG, "csrc", "stack_kernels.h"), os.path.join(PKG, "model", "blobs", "stacking.json"),
+                  os.path.join(PKG, "csrc", "stack_step.h"), os.path.join(PKG, "csrc", "stack_kernels.h"), os.path.join(PKG, "csrc", "align_step.h"), os.path.join(PKG, "model", "blobs", "stacking.json"),
                   os.path.join(PKG, "csrc", "gen_consts.cpp"), os.path.join(PKG, "model", "blobs", "avoiding.json"),
                   os.path.join(ROOT, "include", "d3il_rollout.h"), os.path.join(ROOT, "include", "d3il_model_blob.h")]
 # -disable-machine-licm / -disable-machine-sink: with the model constants baked in as literals, MachineLICM hoists
@@ -34,6 +34,25 @@ def hipcc() -> str:
     if not os.path.exists(exe):
         raise RuntimeError("hipcc not found: the HIP extension cannot be built")
     return exe
+
+
+# The Stacking / Aligning engine was validated (permutation soak, DESIGN sections 17.3 / 18.2) with the hipcc of ROCm 7.2: its optimiser needs the
+# convergence fences of stack_step.h around cross-lane operations; another compiler has to pass `python tools/gpu_stack_perm.py 8192 300` again.
+VALIDATED_HIP = "7.2"
+
+
+def check_compiler(verbose: bool = False) -> str:
+    """HIP version line of the compiler; warns when it is not the validated one (the kernels' correctness was established per compiler)."""
+    out = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout
+    line = next((l for l in out.splitlines() if l.startswith("HIP version")), "HIP version: unknown")
+    ver = line.split(":", 1)[1].strip()
+    if not ver.startswith(VALIDATED_HIP):
+        import warnings
+        warnings.warn("libd3il_rollout is validated with hipcc of HIP %s.x; this is %s - run tools/gpu_stack_perm.py (DESIGN section 18.2) before trusting the "
+                      "Stacking / Aligning kernels" % (VALIDATED_HIP, ver))
+    elif verbose:
+        print(line)
+    return ver
 
 
 def needs_build() -> bool:
@@ -68,6 +87,7 @@ def generate_consts(verbose: bool = False):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
+        check_compiler(verbose)
         generate_consts(verbose)
         cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB] + SOURCES
         if verbose:

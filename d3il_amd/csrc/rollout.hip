@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <memory>
 #include <mutex>
 #include <string>
 #include "../../include/d3il_rollout.h"
@@ -847,8 +848,11 @@ int d3il_start(d3il_handle h, const double* init_qpos7) {
   return D3IL_OK;
 }
 
-static int sync_stack_consts(d3il_handle_s* h) {
-  std::lock_guard<std::mutex> lock(g_model_mutex);
+// Loads this handle's engine constants into the device's g_stack_consts if another handle's are there.  The caller HOLDS g_model_mutex (StackLaunch
+// below) from here until its kernel launch has been enqueued: otherwise a second host thread whose handle has other constants could reload the object
+// between this handle's check and its launch.  A reload waits for everything in flight on the device first (hipDeviceSynchronize), so a
+// kernel already launched keeps the constants it was launched with.
+static int sync_stack_consts_locked(d3il_handle_s* h) {
   if (g_stack_loaded_id[h->device] == h->kc_id) return D3IL_OK;
   if (g_stack_loaded_id[h->device] != 0 && std::memcmp(&g_stack_loaded[h->device], &h->kc, sizeof(StackConsts)) == 0) { g_stack_loaded_id[h->device] = h->kc_id; return D3IL_OK; }
   HIPCHK(hipDeviceSynchronize());
@@ -857,6 +861,11 @@ static int sync_stack_consts(d3il_handle_s* h) {
   g_stack_loaded[h->device] = h->kc; g_stack_loaded_id[h->device] = h->kc_id;
   return D3IL_OK;
 }
+struct StackLaunch {      // scope = "constants checked ... kernel enqueued"
+  std::unique_lock<std::mutex> lock;
+  int rc;
+  explicit StackLaunch(d3il_handle_s* h) : lock(g_model_mutex), rc(sync_stack_consts_locked(h)) {}
+};
 
 // the contact solvers' stopping rule lives in one __constant__ object per device; a handle whose setting differs from what is
 // loaded re-loads it on its stream before launching (handles with different settings must not run concurrently on one device)
@@ -880,6 +889,8 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   if (!h->started) return fail(D3IL_ESTATE, "d3il_reset: d3il_start() has not been called (env.start() before env.reset())");
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
+  if (h->ctx_dim && !contexts) return fail(D3IL_EINVAL, "d3il_reset: this task needs contexts (device f64 [n_envs][ctx_dim]: Pushing 14, Sorting 7 n_boxes, Stacking 21, Aligning 14)");      // before anything is enqueued
+  if (!h->ctx_dim && contexts) return fail(D3IL_EUNSUPPORTED, "d3il_reset: the Avoiding task takes no contexts");
   if (int rc = sync_solver_tol(h, (hipStream_t)stream)) return rc;
   if (h->ctx_dim && contexts && contexts != h->d_ctx) {
     int tot = h->n * h->ctx_dim;
@@ -902,7 +913,8 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   }
   if (h->task_id == D3IL_TASK_STACKING) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Stacking task needs contexts (device f64 [n_envs][21])");
-    if (int rc = sync_stack_consts(h)) return rc;
+    StackLaunch guard(h);
+    if (guard.rc) return guard.rc;
     if (h->stack_reset_coop)      // the step kernel in reset mode: cooperative phases, workgroups without a masked environment leave at once
       hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, (hipStream_t)stream, b.state, b.flags, b.step_count, (const double*)nullptr, b.obs,
                          b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, 1, h->hc.max_steps, 1, env_mask, h->d_init_qpos, contexts);
@@ -914,7 +926,8 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   }
   if (h->task_id == D3IL_TASK_ALIGNING) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Aligning task needs contexts (device f64 [n_envs][14]: box pos3 quat4 | target pos3 quat4)");
-    if (int rc = sync_stack_consts(h)) return rc;
+    StackLaunch guard(h);
+    if (guard.rc) return guard.rc;
     hipLaunchKernelGGL(k_aligning_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, (hipStream_t)stream, b.state, b.flags, b.step_count, (const double*)nullptr, b.obs,
                        b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, 1, h->hc.max_steps, 1, env_mask, h->d_init_qpos, contexts);
     HIPCHK(hipGetLastError());
@@ -936,7 +949,8 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   if (int rc = sync_solver_tol(h, s)) return rc;
   if (h->task_id == D3IL_TASK_PUSHING) {
     int nwgp = (h->n + PUSH_LANES - 1) / PUSH_LANES;
-    if (h->push_coop && h->fast) { if (int rc = sync_stack_consts(h)) return rc; }
+    std::unique_ptr<StackLaunch> guard;
+    if (h->push_coop && h->fast) { guard.reset(new StackLaunch(h)); if (guard->rc) return guard->rc; }
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     if (h->push_coop && h->fast)
       hipLaunchKernelGGL(k_pushing_step_coop, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
@@ -965,7 +979,8 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     return D3IL_OK;
   }
   if (h->task_id == D3IL_TASK_STACKING) {
-    if (int rc = sync_stack_consts(h)) return rc;
+    StackLaunch guard(h);
+    if (guard.rc) return guard.rc;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                        b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, 0, (const unsigned char*)nullptr, (const double*)nullptr, (const double*)nullptr);
@@ -974,7 +989,8 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     return D3IL_OK;
   }
   if (h->task_id == D3IL_TASK_ALIGNING) {
-    if (int rc = sync_stack_consts(h)) return rc;
+    StackLaunch guard(h);
+    if (guard.rc) return guard.rc;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(k_aligning_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                        b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, 0, (const unsigned char*)nullptr, (const double*)nullptr, (const double*)nullptr);

@@ -1,9 +1,8 @@
-"""Aligning task (gym_aligning/envs/aligning.py), SURVEY section 8(f)-4: data side only.
+"""Aligning task (gym_aligning/envs/aligning.py), SURVEY section 8(f)-4: contexts.
 
-Round 3 holds the model blob (``d3il_amd/model/blobs/aligning.json``: one free compound body - plate + four walls - with its centre of mass off the
-body origin, and a geom-less target body), the CPU oracle env (``oracle.Oracle.align_reset / align_step``) and the task logic / metric tail pinned
-against the reference's Python (tests/test_aligning_oracle.py).  There is NO device engine for this task yet: ``d3il_create`` refuses task id 4, and
-nothing in the product imports this module (DESIGN section 17.8 says what the engine needs).
+The reference's 60 evaluation contexts as data, the reader of its pickle format and a sampler like ``BlockContextManager.sample``.  The environment
+itself is ``d3il_amd.envs.aligning.RobotPushVecEnv`` (device engine: d3il_amd/csrc/align_step.h), the evaluation harness
+``d3il_amd.simulation.aligning_sim.Aligning_Sim``; task logic and metric tail are pinned against the reference's Python (tests/test_aligning_oracle.py).
 
 Context layout (f64[14], the env format of the other box tasks): box (x, y, z = 0, quat wxyz) | target (x, y, 0, quat) - BlockContextManager.set_context,
 aligning.py:107-122."""

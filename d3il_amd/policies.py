@@ -202,6 +202,9 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
                 and os.environ.get("D3IL_POLICY_FUSED_MLP", "1") == "1")
 
     def _fused_ok(self, x):
+        # the matrix-core kernels are inference only (no autograd node): any caller that wants gradients - fine-tuning, a gradient check - takes the torch path
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
         return self._fused_static_ok() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 120 and x.data_ptr() % 16 == 0 and x.shape[1] <= 32
 
     def ensure_packed(self):
@@ -242,6 +245,8 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
             a = self.attn
             if not torch.cuda.is_current_stream_capturing():
                 self.ensure_packed()
+            else:
+                assert getattr(self, "_pack_key", None) is not None, "a captured graph replays the packed weight buffers: call ensure_packed() before capturing"
             qkv = torch.empty(B, T, 3 * C, dtype=torch.float32, device=x.device)
             capi.check(L.d3il_linear120_f32(x.data_ptr(), self.ln1.weight.data_ptr(), self.ln1.bias.data_ptr(), float(self.ln1.eps), self._wp_qkv.data_ptr(), self._b_qkv.data_ptr(), None,
                                             qkv.data_ptr(), M, 3 * C, st))

@@ -89,6 +89,15 @@ def main():
     sim4.test_agent(ScriptedStackPolicy(tables, torch.arange(lo, hi) // ntraj, device="cuda:0"))
     r4 = sim4.last_rollout
     out["stacking"] = dict(counts=[int(v) for v in r4["counts"]], shard=list(r4["shard"]), successes_1_box=r4["metrics"]["successes_1_box"])
+    # Aligning: scripted inside / outside pushes on 7 contexts x 2 rollouts; the policy's per-lane behaviour follows the GLOBAL rollout index
+    from d3il_amd.agents import ScriptedAlignPolicy
+    from d3il_amd.simulation.aligning_sim import Aligning_Sim
+    lo5, hi5 = shard_range(14, rank, world)
+    sim5 = Aligning_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=7, n_trajectories_per_context=2, max_steps_per_episode=110)
+    sim5.test_agent(ScriptedAlignPolicy(inside=(torch.arange(lo5, hi5) % 2 == 0), device="cuda:0"))
+    r5 = sim5.last_rollout
+    out["aligning"] = dict(counts=[int(v) for v in r5["counts"]], shard=list(r5["shard"]), mean_distance=r5["mean_distance_all"],
+                           modes=sorted(set(int(m) for m in r5["mode"].cpu().tolist())))
     if rank == 0:
         print("RESULT " + json.dumps(out), flush=True)
     if world > 1:

@@ -15,7 +15,10 @@ def _fixture():
 
 def test_structure_and_the_plan_of_the_undecided_contexts():
     fx = _fixture()
-    assert set(fx) >= {"pushing", "pushing_sampled"}
+    assert set(fx) >= {"pushing", "pushing_sampled", "sorting"}
+    so = fx["sorting"]["outcomes"]      # Sorting: independent uniform draws in (-1e-9, 1e-9) m on every cube's x, y - the size of the one-step device / oracle difference
+    assert sorted(map(int, so)) == list(range(60)) and fx["sorting"]["k"] >= 12 and fx["sorting"]["eps"] <= 1e-9
+    assert 1 <= sum(len(o) > 1 for o in so.values()) <= 8
     for task, n in (("pushing", 60), ("pushing_sampled", 120)):
         outs = fx[task]["outcomes"]
         assert sorted(map(int, outs)) == list(range(n)) and fx[task]["k"] >= 24 and fx[task]["eps"] <= 1e-12

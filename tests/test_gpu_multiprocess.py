@@ -31,6 +31,7 @@ def test_sim_metrics_do_not_depend_on_the_number_of_ranks():
     assert one["pushing"]["shard"] == [0, 18] and one["avoiding"]["shard"] == [0, 37] and one["sorting"]["shard"] == [0, 22]
     assert one["stacking"]["shard"] == [0, 10] and one["stacking"]["counts"][-3] >= 8        # the red box reaches the target zone on (almost) every rollout
     assert one["sorting"]["mode_hist"][112] > 0 and sum(one["sorting"]["mode_hist"]) == 22      # some scripted pushes deliver the red cube
+    assert one["aligning"]["shard"] == [0, 14] and one["aligning"]["modes"] == [0, 1]
     for world, port in ((2, 29531), (3, 29532)):
         many = _run(world, port)
         assert many["pushing"]["shard"][0] == 0 and many["pushing"]["shard"][1] < 18      # rank 0 owns a proper shard
@@ -41,4 +42,5 @@ def test_sim_metrics_do_not_depend_on_the_number_of_ranks():
         assert many["sorting"]["counts"] == one["sorting"]["counts"] and many["sorting"]["mode_hist"] == one["sorting"]["mode_hist"]
         assert many["pushing"]["success_rate"] == one["pushing"]["success_rate"] and many["pushing"]["entropy"] == one["pushing"]["entropy"]
         assert many["avoiding"]["entropy"] == one["avoiding"]["entropy"]
+        assert many["aligning"]["counts"] == one["aligning"]["counts"] and many["aligning"]["shard"][1] < 14 and abs(many["aligning"]["mean_distance"] - one["aligning"]["mean_distance"]) < 1e-12
         assert abs(many["pushing"]["mean_distance"] - one["pushing"]["mean_distance"]) < 1e-12

@@ -23,13 +23,14 @@ TASK_FUNCS = {
     "pushing": ("k_pushing_step_split", ["push_", "coupled_newton", "cube_newton", "jacobi_solve6", "solve_constraints"]),
     "sorting": ("k_sorting_step", ["gen_", "jacobi_solve6", "solve_constraints"]),
     "stacking": ("k_stacking_step", ["sk_coop_build"]),
+    "aligning": ("k_aligning_step", ["sk_coop_build", "jacobi_solve6"]),
 }
 FMA = re.compile(r"^v_(fma|fmac|mad)_f64")
 F64 = re.compile(r"^v_\w+_f64")
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03", "isa_fp64_mix.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04", "isa_fp64_mix.json")
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "rollout.s")
         flags = [f for f in build.HIPCC_FLAGS if f not in ("-fPIC", "-shared", "-Xarch_device")]
