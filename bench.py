@@ -49,7 +49,7 @@ IMPL_BYTES = {
     "stacking": 2 * (94 * 8 + 4 + 4) + 64 + 48 + 4 + 8,
     "aligning": 2 * (77 * 8 + 4 + 4) + 56 + 68 + 4 + 16,
 }
-KERNEL = {"avoiding": "k_avoiding_step_split<true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step", "aligning": "k_aligning_step"}
+KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step", "aligning": "k_aligning_step"}
 PMC_FILE = {"aligning": "pmc_summary_aligning.json", "avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json"}
 
 
@@ -372,6 +372,8 @@ def run(args):
         env.set_option("split_waves", args.split)
     if args.lds_pad is not None:
         env.set_option("lds_pad_bytes", args.lds_pad)
+    if args.serve_max_wg is not None:
+        env.set_option("serve_wave_max_workgroups", args.serve_max_wg)
     if args.solver_strict:
         env.set_option("solver_strict", 1)
     max_steps = env.max_steps_per_episode
@@ -605,6 +607,7 @@ def main():
     ap.add_argument("--solver-strict", action="store_true", help="contact solvers iterate to round-off like the oracle (parity A/B)")
     ap.add_argument("--lanes", type=int, default=None, help="environments per wave (default 64)")
     ap.add_argument("--split", type=int, default=None, help="1: two-wave controller||physics kernel, 0: fused kernel, default auto")
+    ap.add_argument("--serve-max-wg", type=int, default=None, help="Avoiding: workgroup count up to which the split kernel runs with its third wave (rare constraint paths); 0 = the two-wave kernel (A/B)")
     ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
     args = ap.parse_args()
 

@@ -1261,6 +1261,88 @@ D3IL_RARE void make_rod_contact(const C& c, const double* sn, const double* cs, 
   rc.aref[1] = -c.ct_B[bo] * vel[1]; rc.aref[2] = -c.ct_B[bo] * vel[2];
 }
 
+// Where the two rare constraint paths (rod contact; arm joint-limit rows) run.  RareInline: in this function (every caller but the split
+// Avoiding kernel).  A type with `remote == true` (RareXch, rollout.hip): the operands of the lanes that need a rare path go through an
+// exchange area to ANOTHER WAVE of the workgroup, which runs rare_serve() below and hands the constraint force back - the hot path then
+// carries none of the solvers' register pressure (192 spilled registers and 68 scratch operations per sub-step
+// in the physics wave's main block with the solvers inlined, none without them).
+struct RareInline { static constexpr bool remote = false; };
+constexpr int RX_M = 0, RX_FS = 45, RX_Q = 54, RX_V = 63, RX_SN = 72, RX_MD = 86, RX_BO = 87, RX_BD = 88, RX_BN = 89, RX_BP = 92, RX_FL = 95 /* fsign[2] fD[2] faref[2] */,
+              RX_ARM = 101, RX_ROWS = 102, RX_FC = 0 /* reply: fc[9], fail */;
+
+// The two rare constraint paths of physics_substep: a rod contact (+ the finger-limit rows) through the 5-dimensional constraint-space
+// Newton, or - with an arm joint inside a limit margin - all limit rows + the rod contact through the 9-dof primal Newton solver.
+// Operands: M / its LDL^T factors of this sub-step, fs = smooth force, the state, sin / cos of the arm joints, the deepest rod contact
+// (bo < 0: none), the finger rows.  Writes qfrc_constraint; false = a solver gave up.
+template <class C>
+D3IL_HD bool rare_constraints(const C& c0, const double* M, const double* L, const double* id, const double* fs, const double* q, const double* v, const double* sn, const double* cs,
+                              int bo, double bd, const double* bn, const double* bp, const double* fsign, const double* fD, const double* faref, bool arm_rows, double* fc, double* warm) {
+  D3IL_REFRESH(c0, c);
+  bool ok = true;
+  if (!arm_rows) {
+    double Lm[45], dm[NDOF], a0[NDOF], fcm[NDOF], vm[NDOF], fn = 0;
+    for (int i = 0; i < 45; i++) Lm[i] = L[i];
+    for (int k = 0; k < NDOF; k++) { dm[k] = id[k]; a0[k] = fs[k]; fn += fs[k] * fs[k]; vm[k] = v[k]; fcm[k] = 0; }
+    ldl9_solve(L, id, a0);
+    // gradient scale in acceleration units: |fs| / (mean diagonal of M)
+    double md = 0;
+    for (int k = 0; k < NDOF; k++) md += M[tri(k, k)];
+    double gscale = (1.0 + sqrt(fn)) / (md / NDOF);
+    RodContact rc; rc.active = false;
+    make_rod_contact(c0, sn, cs, vm, bo, bd, bn, bp, &rc);
+    ok = solve_contact5(Lm, dm, a0, rc, fsign, fD, faref, gscale, fcm, warm);
+    for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
+  } else {
+    double Mm[45], a0[NDOF], lim_sign[NDOF], lim_D[NDOF], lim_aref[NDOF], fcm[NDOF], fn = 0, vm[NDOF];
+    for (int i = 0; i < 45; i++) Mm[i] = M[i];
+    for (int k = 0; k < NDOF; k++) { a0[k] = fs[k]; fn += fs[k] * fs[k]; vm[k] = v[k]; }
+    fn = sqrt(fn);
+    ldl9_solve(L, id, a0);
+    for (int k = 0; k < NDOF; k++) {
+      double dlo = q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - q[k];
+      double sign = 0, dist = 0;
+      if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
+      else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
+      lim_sign[k] = sign; lim_D[k] = 0; lim_aref[k] = 0;
+      if (sign != 0) {
+        double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
+        lim_D[k] = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
+        lim_aref[k] = -c.lim_B[k] * (sign * v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
+      }
+    }
+    RodContact rc; rc.active = false;
+    if (bo >= 0) make_rod_contact(c0, sn, cs, vm, bo, bd, bn, bp, &rc);
+    double warm9[NDOF + 1]; warm9[NDOF] = 0.0;
+    ok = solve_constraints(Mm, a0, &fn, lim_sign, lim_D, lim_aref, rc, fcm, warm9);
+    for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
+  }
+  return ok;
+}
+
+// The serving side of a remote rare path (one lane = one environment of the requesting wave, same lane index): operands from the exchange
+// area, M factorised again by the same ldl9, the reply (qfrc_constraint[9], failure flag) into rows RX_FC...
+template <class C, class R> D3IL_HD void rare_serve(const C& c0, R* rare, double* warm) {
+  double M[45], L[45], d[NDOF], id[NDOF], fs[NDOF], q[NDOF], v[NDOF], sn[NARM], cs[NARM], bn[3], bp[3], fsign[NFING], fD[NFING], faref[NFING], fc[NDOF];
+#pragma unroll
+  for (int i = 0; i < 45; i++) M[i] = rare->get(RX_M + i);
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) { fs[k] = rare->get(RX_FS + k); q[k] = rare->get(RX_Q + k); v[k] = rare->get(RX_V + k); fc[k] = 0; }
+#pragma unroll
+  for (int k = 0; k < NARM; k++) { sn[k] = rare->get(RX_SN + k); cs[k] = rare->get(RX_SN + NARM + k); }
+  const int bo = (int)rare->get(RX_BO);
+  const double bd = rare->get(RX_BD);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { bn[k] = rare->get(RX_BN + k); bp[k] = rare->get(RX_BP + k); }
+#pragma unroll
+  for (int k = 0; k < NFING; k++) { fsign[k] = rare->get(RX_FL + k); fD[k] = rare->get(RX_FL + 2 + k); faref[k] = rare->get(RX_FL + 4 + k); }
+  const bool arm_rows = rare->get(RX_ARM) != 0.0;
+  bool ok = ldl9(M, L, d, id);
+  ok = rare_constraints(c0, M, L, id, fs, q, v, sn, cs, bo, bd, bn, bp, fsign, fD, faref, arm_rows, fc, warm) && ok;
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) rare->put(RX_FC + k, fc[k]);
+  rare->put(RX_FC + NDOF, ok ? 0.0 : 1.0);
+}
+
 // One mj_step (forward dynamics with the ctrl computed by the caller + semi-implicit Euler with implicit joint
 // damping) followed by the state read-back.  `tau` = controller torque WITHOUT gravity compensation for the arm,
 // `ffing` = raw finger command.  Updates q, v, bias (qfrc_bias of THIS forward pass), tcp (pre-integration pose).
@@ -1272,7 +1354,7 @@ D3IL_RARE void make_rod_contact(const C& c, const double* sn, const double* cs, 
 // active sets - no iteration.  The same factors, with the last two pivots updated for the implicit damping term h B,
 // give the integration solve: one 9x9 factorisation per sub-step.  Arm limit rows or a rod contact (rare) take the
 // general out-of-line Newton path.
-template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const double* tau, const double* ffing, double* warm, double* trig = nullptr) {
+template <class C, class R = RareInline> D3IL_HD void physics_substep(const C& c0, EnvState& st, const double* tau, const double* ffing, double* warm, double* trig = nullptr, R* rare = nullptr) {
   D3IL_DSTAT(7);
   DynOut dyn;
   dynamics(c0, st.q, st.v, dyn, trig);
@@ -1332,44 +1414,32 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
   double fc[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; k++) fc[k] = 0;
-  if (bo >= 0 && !arm_rows) {
-    // rod contact (+ finger limit rows): 5-dimensional constraint-space Newton, out of line
-    double Lm[45], dm[NDOF], a0[NDOF], fcm[NDOF], qm[NDOF], vm[NDOF], fn = 0;
-    for (int i = 0; i < 45; i++) Lm[i] = L[i];
-    for (int k = 0; k < NDOF; k++) { dm[k] = id[k]; a0[k] = fs[k]; fn += fs[k] * fs[k]; qm[k] = st.q[k]; vm[k] = st.v[k]; fcm[k] = 0; }
-    ldl9_solve(L, id, a0);
-    // gradient scale in acceleration units: |fs| / (mean diagonal of M)
-    double md = 0;
-    for (int k = 0; k < NDOF; k++) md += dyn.M[tri(k, k)];
-    double gscale = (1.0 + sqrt(fn)) / (md / NDOF);
-    RodContact rc; rc.active = false;
-    make_rod_contact(c0, dyn.sn, dyn.cs, vm, bo, bd, bn, bp, &rc);
-    if (!solve_contact5(Lm, dm, a0, rc, fsign, fD, faref, gscale, fcm, warm)) st.flags |= F_SOLVER_FAIL;
-    for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
-  } else if (arm_rows) {
-    // arm joint-limit rows (very rare): all limit rows + the rod contact through the 9-dof primal Newton solver
-    double Mm[45], a0[NDOF], lim_sign[NDOF], lim_D[NDOF], lim_aref[NDOF], fcm[NDOF], fn = 0, qm[NDOF], vm[NDOF];
-    for (int i = 0; i < 45; i++) Mm[i] = dyn.M[i];
-    for (int k = 0; k < NDOF; k++) { a0[k] = fs[k]; fn += fs[k] * fs[k]; qm[k] = st.q[k]; vm[k] = st.v[k]; }
-    fn = sqrt(fn);
-    ldl9_solve(L, id, a0);
-    for (int k = 0; k < NDOF; k++) {
-      double dlo = st.q[k] - c.jnt_range[k][0], dhi = c.jnt_range[k][1] - st.q[k];
-      double sign = 0, dist = 0;
-      if (dlo < c.lim_margin[k]) { sign = 1; dist = dlo; }
-      else if (dhi < c.lim_margin[k]) { sign = -1; dist = dhi; }
-      lim_sign[k] = sign; lim_D[k] = 0; lim_aref[k] = 0;
-      if (sign != 0) {
-        double imp = impedance(c.lim_solimp[k], dist - c.lim_margin[k]);
-        lim_D[k] = 1 / fmax(1e-15, (1 - imp) / imp * c.dof_invweight0[k]);
-        lim_aref[k] = -c.lim_B[k] * (sign * st.v[k]) - c.lim_K[k] * imp * (dist - c.lim_margin[k]);
-      }
+  bool delegated = false;
+  if constexpr (R::remote) {
+    delegated = bo >= 0 || arm_rows;
+    if (delegated) {
+#pragma unroll
+      for (int i = 0; i < 45; i++) rare->put(RX_M + i, dyn.M[i]);
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) { rare->put(RX_FS + k, fs[k]); rare->put(RX_Q + k, st.q[k]); rare->put(RX_V + k, st.v[k]); }
+#pragma unroll
+      for (int k = 0; k < NARM; k++) { rare->put(RX_SN + k, dyn.sn[k]); rare->put(RX_SN + NARM + k, dyn.cs[k]); }
+      rare->put(RX_BO, (double)bo); rare->put(RX_BD, bd);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { rare->put(RX_BN + k, bn[k]); rare->put(RX_BP + k, bp[k]); }
+#pragma unroll
+      for (int k = 0; k < NFING; k++) { rare->put(RX_FL + k, fsign[k]); rare->put(RX_FL + 2 + k, fD[k]); rare->put(RX_FL + 4 + k, faref[k]); }
+      rare->put(RX_ARM, arm_rows ? 1.0 : 0.0);
     }
-    RodContact rc; rc.active = false;
-    if (bo >= 0) make_rod_contact(c0, dyn.sn, dyn.cs, vm, bo, bd, bn, bp, &rc);
-    double warm9[NDOF + 1]; warm9[NDOF] = 0.0;
-    if (!solve_constraints(Mm, a0, &fn, lim_sign, lim_D, lim_aref, rc, fcm, warm9)) st.flags |= F_SOLVER_FAIL;
-    for (int k = 0; k < NDOF; k++) fc[k] = fcm[k];
+    if (rare->post(delegated) && delegated) {
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) fc[k] = rare->get(RX_FC + k);
+      if (rare->get(RX_FC + NDOF) != 0.0) st.flags |= F_SOLVER_FAIL;
+    }
+  }
+  if (delegated) {
+  } else if (!R::remote && (bo >= 0 || arm_rows)) {
+    if (!rare_constraints(c0, dyn.M, L, id, fs, st.q, st.v, dyn.sn, dyn.cs, bo, bd, bn, bp, fsign, fD, faref, arm_rows, fc, warm)) st.flags |= F_SOLVER_FAIL;
   } else if (fsign[0] != 0 || fsign[1] != 0) {
     // finger-limit rows only: exact active-set solution on the 2x2 block W = (M^-1)_FF
     D3IL_STAT(g_stats.newton_calls++);
@@ -1427,8 +1497,8 @@ template <class C> D3IL_HD void physics_substep(const C& c0, EnvState& st, const
 }
 
 // joint PD on the IK set-point + finger PD + one physics sub-step (the part of Scene.next_step after the IK update)
-template <class C>
-D3IL_HD void control_and_physics(const C& c, EnvState& st, const double* q_des, const double* qd_des, double set_width, bool grasp, double* warm, double* trig = nullptr) {
+template <class C, class R = RareInline>
+D3IL_HD void control_and_physics(const C& c, EnvState& st, const double* q_des, const double* qd_des, double set_width, bool grasp, double* warm, double* trig = nullptr, R* rare = nullptr) {
   double tau[NARM], ff[NFING];
 #pragma unroll
   for (int k = 0; k < NARM; k++) tau[k] = c.pd_p[k] * (q_des[k] - st.q[k]) + c.pd_d[k] * (qd_des[k] - st.v[k]);
@@ -1442,7 +1512,7 @@ D3IL_HD void control_and_physics(const C& c, EnvState& st, const double* q_des, 
     else f2 = clampd(500 * (set_width - w) - 10 * wv, -5, 5);
     ff[k] = f1 + f2;
   }
-  physics_substep(c, st, tau, ff, warm, trig);
+  physics_substep(c, st, tau, ff, warm, trig, rare);
 }
 
 // controllers feeding one physics sub-step (Scene.next_step, core/Scene.py:121-138)

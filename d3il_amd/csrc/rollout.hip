@@ -110,16 +110,55 @@ __global__ __launch_bounds__(WAVE) void k_avoiding_step(const PandaConsts* __res
 // and integration of sub-step s-1 meanwhile and picks the set-point up after one workgroup barrier per sub-step.
 // The critical path per sub-step drops from IK + physics to max(IK, physics); at small N (4096 envs = 64 workgroups on
 // 256 CUs) the extra wave runs on an otherwise idle SIMD.
-template <bool FAST>
-__global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaConsts* __restrict__ cp, double* __restrict__ state,
+//
+// SERVE = true adds a third wave: the rare constraint paths of the physics (a rod contact; arm joint-limit rows) run THERE.  The physics wave
+// posts, once per sub-step, the mask of its lanes that need one (operands through `rx`, RX_ROWS doubles per lane) and waits for the reply only
+// when the mask is non-zero; the serving wave polls that word with s_sleep.  With the solvers inlined into the physics wave its hot path
+// spilled 192 registers (68 scratch operations per sub-step in its main block) and a single environment in contact - about every second
+// launch at 4096 environments - stretched its workgroup, hence the launch, from 0.40 to 0.9 ms; both go away.
+struct RareXch {
+  static constexpr bool remote = true;
+  double* buf;     // LDS [RX_ROWS][WAVE]
+  int* ctl;        // LDS: [0] sequence number posted by the physics wave (sub-step + 1), [1] acknowledged by the serving wave, [2..3] lane mask
+  int lane, seq;
+  __device__ __forceinline__ void put(int k, double v) { buf[k * WAVE + lane] = v; }
+  __device__ __forceinline__ double get(int k) const { return buf[k * WAVE + lane]; }
+  // physics wave (all lanes): true when some lane asked and the reply is in
+  __device__ __forceinline__ bool post(bool need) {
+    const unsigned long long m = __ballot(need);
+    if (lane == 0) { ctl[2] = (int)(unsigned)m; ctl[3] = (int)(unsigned)(m >> 32); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&ctl[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (m == 0) return false;
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+  }
+  // serving wave: the mask of sub-step `seq` (waits until it is posted)
+  __device__ __forceinline__ unsigned long long wait_request() {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return (unsigned long long)(unsigned)ctl[2] | ((unsigned long long)(unsigned)ctl[3] << 32);
+  }
+  __device__ __forceinline__ void acknowledge() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&ctl[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+};
+constexpr size_t AVOID_LDS_SERVE = (size_t)RX_ROWS * WAVE * sizeof(double) + 4 * sizeof(int);
+
+template <bool FAST, bool SERVE>
+__global__ __launch_bounds__((SERVE ? 3 : 2) * WAVE) void k_avoiding_step_split(const PandaConsts* __restrict__ cp, double* __restrict__ state,
                                                                   unsigned* __restrict__ flags, int* __restrict__ steps,
                                                                   const double* __restrict__ actions, float* __restrict__ obs,
                                                                   unsigned char* __restrict__ done, unsigned char* __restrict__ success,
                                                                   unsigned short* __restrict__ mode, int n, int stride, int n_substeps, int max_steps) {
   __shared__ double xch[2][2 * NARM][WAVE];
   __shared__ double trg[2][2 * NARM + 1][WAVE];     // sin / cos of ikq (controller) and of the arm joints (physics) carried across the sub-steps: parked in LDS between them
+  extern __shared__ double rx_smem[];             // SERVE: the rare-path exchange area
   const int lane = threadIdx.x & (WAVE - 1);
-  const int role = threadIdx.x / WAVE;          // wave-uniform: 0 controller, 1 physics
+  const int role = threadIdx.x / WAVE;          // wave-uniform: 0 controller, 1 physics, 2 (SERVE) the rare constraint paths
+  RareXch rx; rx.buf = rx_smem; rx.ctl = (int*)(rx_smem + RX_ROWS * WAVE); rx.lane = lane; rx.seq = 0;
   int e = blockIdx.x * WAVE + lane;
   const bool live = e < n;
   if (!live) e = n - 1;                         // keep every lane in the barriers; dead lanes recompute env n-1 and store nothing
@@ -172,6 +211,29 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
 #pragma unroll
       for (int i = 0; i < NARM; i++) { so[(D3IL_STATE_IK_Q + i) * (size_t)stride] = ikq[i]; so[(D3IL_STATE_IK_QD + i) * (size_t)stride] = ikqd[i]; }
     }
+  } else if (SERVE && role == 2) {
+    double warm[6];
+    warm[5] = 0.0;
+    if (lane == 0) { rx.ctl[0] = 0; rx.ctl[1] = 0; }       // before the first barrier; the physics wave posts after it
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < n_substeps; s++) {
+      __syncthreads();
+      rx.seq = s + 1;
+      const unsigned long long m = rx.wait_request();
+      if (m != 0) {                                        // wave-uniform
+#if defined(D3IL_DEVICE_STATS)
+        unsigned long long tb = wall_clock64();
+#endif
+        if ((m >> lane) & 1ull) rare_serve(c, &rx, warm);
+        rx.acknowledge();
+#if defined(D3IL_DEVICE_STATS)
+        tw += wall_clock64() - tb;
+#endif
+      }
+    }
+#if defined(D3IL_DEVICE_STATS)
+    if (lane == 0 && blockIdx.x < 4096) g_dev_wave[blockIdx.x][7] = tw;      // the serving wave's busy ticks (replaces the sub-step counter of this slot: written last)
+#endif
   } else {
     EnvState st;
     load_state(state, flags, steps, stride, e, st);
@@ -197,7 +259,8 @@ __global__ __launch_bounds__(2 * WAVE) void k_avoiding_step_split(const PandaCon
       double trig[2 * NARM];
 #pragma unroll
       for (int k = 0; k < 2 * NARM; k++) trig[k] = trg[1][k][lane];
-      control_and_physics(c, st, qd, qdd, 0.04, false, warm, trig);
+      if constexpr (SERVE) { rx.seq = s + 1; control_and_physics(c, st, qd, qdd, 0.04, false, warm, trig, &rx); }
+      else control_and_physics(c, st, qd, qdd, 0.04, false, warm, trig);
 #pragma unroll
       for (int k = 0; k < 2 * NARM; k++) trg[1][k][lane] = trig[k];
     }
@@ -599,6 +662,7 @@ struct d3il_handle_s {
   d3il_buffers buf;
   bool fast, timing;
   int split;              // -1 auto, 0 fused single-wave kernel, 1 two-wave (controller || physics) kernel
+  int serve_max_wg;       // the split kernel runs with its third wave (rare constraint paths) up to this many workgroups (one per CU); 0: never
   int lanes;              // active lanes (environments) per wave: 64, or fewer to spread a small batch over more SIMDs
   int lds_pad;            // dynamic LDS bytes requested per workgroup: spreads the single-wave workgroups over CUs
   hipEvent_t ev0, ev1;
@@ -735,7 +799,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     }
   }
   h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE;
-  h->started = false; h->split = -1; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false;
+  h->started = false; h->split = -1; h->serve_max_wg = 256; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false;
   const bool aligning = task_id == D3IL_TASK_ALIGNING;
   h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : (stacking ? SK_STATE_F64 : (aligning ? AL_STATE_F64 : D3IL_STATE_F64)));
   h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : (stacking ? 21 : (aligning ? AL_CTX : 0)));
@@ -743,6 +807,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   d3il_buffers& b = h->buf;
   b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : (aligning ? AL_OBS : 2))); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = (pushing || aligning) ? 2 : (stacking ? 1 : 0);
   HIPCHK_H(hipMalloc(&h->dc, sizeof(PandaConsts)));
+  if (task_id == D3IL_TASK_AVOIDING) HIPCHK_H(hipFuncSetAttribute((const void*)k_avoiding_step_split<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AVOID_LDS_SERVE));
   HIPCHK_H(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
   HIPCHK_H(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
   HIPCHK_H(hipMalloc(&b.obs, S * b.obs_dim * sizeof(float)));
@@ -1011,8 +1076,12 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   // the two-wave kernel wins at every batch size measured (4096 ... 262144 envs: +64 % ... +20 %): at small N the second
   // wave uses an idle SIMD, at saturation its 256-VGPR roles run two waves per SIMD and hide FP64 latency
   bool split = h->fast && h->lanes == WAVE && h->split != 0;
-  if (split)
-    hipLaunchKernelGGL((k_avoiding_step_split<true>), dim3(nwg), dim3(2 * WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+  // the third wave (rare constraint paths) while a CU hosts one workgroup anyway; at saturation the two-wave form keeps two workgroups per CU
+  if (split && nwg <= h->serve_max_wg)
+    hipLaunchKernelGGL((k_avoiding_step_split<true, true>), dim3(nwg), dim3(3 * WAVE), AVOID_LDS_SERVE, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
+                       b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+  else if (split)
+    hipLaunchKernelGGL((k_avoiding_step_split<true, false>), dim3(nwg), dim3(2 * WAVE), 0, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                        b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
   else if (h->fast)
     hipLaunchKernelGGL((k_avoiding_step<true, true>), dim3(nwg), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
@@ -1308,6 +1377,7 @@ int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (std::strcmp(name, "stack_reset_coop") == 0) { h->stack_reset_coop = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "push_coop") == 0) { h->push_coop = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "split_waves") == 0) { h->split = value; return D3IL_OK; }
+  if (std::strcmp(name, "serve_wave_max_workgroups") == 0) { if (value < 0) return fail(D3IL_EINVAL, "serve_wave_max_workgroups must be >= 0"); h->serve_max_wg = value; return D3IL_OK; }
   if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }
   if (std::strcmp(name, "lanes_per_wave") == 0) { if (value < 1 || value > WAVE) return fail(D3IL_EINVAL, "lanes_per_wave must be in 1..64"); h->lanes = value; return D3IL_OK; }
   return fail(D3IL_EINVAL, std::string("d3il_set_option: unknown option ") + name);

@@ -220,6 +220,8 @@ int d3il_set_timing(d3il_handle h, int enabled);
 int d3il_last_step_ms(d3il_handle h, float* ms);
 
 /* "ik_fast_path" (default 1), "split_waves" (-1 auto, 0, 1), "lanes_per_wave", "lds_pad_bytes";
+ * "serve_wave_max_workgroups" (default 256): Avoiding - up to this many workgroups (64 environments each) the split kernel runs with a third wave that executes the
+ * rare constraint paths (rod contact, arm joint limits) for the physics wave; above it (more than one workgroup per CU) the two-wave form runs; 0 = always two waves (A/B);
  * "solver_strict" (default 0): 1 = the contact solvers of Pushing / Sorting / Stacking iterate to round-off like the CPU oracle (parity A/B);
  * "stack_reset_coop" (default 1): Stacking env.reset() through the step kernel's wave-cooperative phases, 0 = the one-lane reset kernel (A/B);
  * "push_coop" (default 0): 1 = Pushing env.step() on the Pushing variant of the wave-cooperative Stacking engine (4 environments per one-wave workgroup; a second,

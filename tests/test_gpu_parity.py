@@ -34,14 +34,18 @@ def test_start_computes_reference_init_qpos(lib_loaded):
     env.close()
 
 
-@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("fast", [1, 0, 2])
 @pytest.mark.parametrize("name", ["random", "collide", "succeed", "zigzag"])
 def test_golden_rollouts(lib_loaded, name, fast):
-    """Replay the committed oracle rollouts: every env of the batch gets the same actions."""
+    """Replay the committed oracle rollouts: every env of the batch gets the same actions.  fast = 1: the default kernel (three waves: controller,
+    physics, rare constraint paths - `collide` runs the rod contact through the serving wave), 2: the two-wave form used above 256 workgroups
+    (rare paths inlined in the physics wave), 0: the fused one-wave kernel with the Jacobi controller path."""
     g = np.load(os.path.join(G, "oracle_avoiding_rollout.npz"))
     n = 128
     env = _env(n)
-    env.set_option("ik_fast_path", fast)
+    env.set_option("ik_fast_path", 1 if fast else 0)
+    if fast == 2:
+        env.set_option("serve_wave_max_workgroups", 0)
     env.set_init_qpos(g["init_qpos"])
     obs = env.reset()
     torch.cuda.synchronize()

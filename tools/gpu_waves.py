@@ -10,7 +10,7 @@ L = capi.load()
 env.start(); env.reset(); env.policy_begin()
 a = torch.zeros(n, 7, dtype=torch.float64, device=env.device)
 W = np.zeros((64, 10), dtype=np.uint64)
-names = ["jacobi", "deflate", "general", "newton_it", "finger", "contact", "ls_it", "substep", "ik_busy", "ticks"]
+names = ["jacobi", "deflate", "general", "newton_it", "finger", "contact", "ls_it", "serve_busy", "ik_busy", "ticks"]   # slot 7: busy ticks of the serving wave (three-wave kernel)
 for t in range(260):
     env.policy_action(42, 0, t, a)
     L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), 64, 1)
@@ -23,4 +23,4 @@ for t in range(260):
         print("t", t, "busy ticks (100 MHz) per workgroup: ik min/med/max", np.min(W[:, 8]), int(np.median(W[:, 8])), np.max(W[:, 8]),
               "| physics min/med/max", np.min(W[:, 9]), int(np.median(W[:, 9])), np.max(W[:, 9]))
         for w in list(order[:2]) + list(order[30:32]) + list(order[-4:]):
-            print("   wg %2d ik %7d phys %7d " % (w, W[w, 8], W[w, 9]) + " ".join("%s %d" % (names[i], W[w, i]) for i in (0, 1, 2, 3, 5, 6)))
+            print("   wg %2d ik %7d phys %7d " % (w, W[w, 8], W[w, 9]) + " ".join("%s %d" % (names[i], W[w, i]) for i in (0, 1, 2, 3, 5, 6, 7)))
