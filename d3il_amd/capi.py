@@ -27,13 +27,14 @@ FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
 # Pushing (D3IL_PUSH_STATE_* / D3IL_PFLAG_* in include/d3il_rollout.h)
 PUSH_STATE_BOX, PUSH_STATE_WARM, PUSH_STATE_F64 = 42, 68, 89
 PFLAG_FIRST_MASK, PFLAG_MODE_MASK, PFLAG_WARM_VALID, PFLAG_CON_OVERFLOW, PFLAG_OFF_TABLE = 0x7, 0x38, 1 << 6, 1 << 18, 1 << 19
-TASK_AVOIDING, TASK_PUSHING, TASK_SORTING, TASK_STACKING, TASK_ALIGNING = 0, 1, 2, 3, 4
+TASK_AVOIDING, TASK_PUSHING, TASK_SORTING, TASK_STACKING, TASK_ALIGNING, TASK_INSERTING = 0, 1, 2, 3, 4, 5
 ALIGN_STATE_BOX, ALIGN_STATE_WARM, ALIGN_STATE_TARGET, ALIGN_STATE_F64 = 42, 55, 70, 77
 STACK_STATE_BOX, STACK_STATE_WARM, STACK_STATE_F64 = 28, 67, 94
 SFLAG_MODE_MASK, SFLAG_WARM_VALID, SFLAG_HAND_NEAR = 0xFF, 1 << 8, 1 << 20
 TALLY_ROW, TALLY_ALL = 514, 256
 ERCCL = -7
 SORT_STATE_BOX, SORT_STATE_WARM, SORT_STATE_TASK, SORT_STATE_F64 = 42, 94, 127, 129
+INS_STATE_BOX, INS_STATE_WARM, INS_STATE_TASK, INS_STATE_F64 = 42, 81, 108, 110
 
 EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
            "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_attention_causal_f32", "d3il_layernorm_f32", "d3il_mlp_gelu_residual_f32", "d3il_mlp_ln_gelu_residual_f32", "d3il_linear120_f32", "d3il_auto_reset", "d3il_set_tally", "d3il_count_metrics",

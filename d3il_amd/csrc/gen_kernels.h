@@ -11,7 +11,7 @@
 
 namespace d3il {
 
-constexpr int GEN_LDS_H = GL_SIZE * (GEN_LANES + 1) * 8;   // 960 x 17 doubles = 127.5 KiB
+constexpr int GEN_LDS_H = GL_SIZE * (GEN_LANES + 1) * 8;   // 1031 x 17 doubles = 137 KiB
 constexpr int GEN_LDS_X = 2 * 2 * NARM * GEN_LANES * 8;
 constexpr int GEN_LDS_STEP = GEN_LDS_H + GEN_LDS_X;
 
@@ -126,8 +126,9 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
       gen_sync();
       PUSH_TOC(1);
       if (plive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl);
+      if (plive && gc.rod_static) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, lfl);
       gen_sync();
-      if (arm_lane) gen_phase3b(c, gc, st, sc);
+      if (arm_lane) gen_phase3b(c, gc, st, sc, gc.nb, lfl);
       gen_sync();
       PUSH_TOC(2);
       if (plive) gen_phase4_single(gc, sc, l, warm_valid, lfl);
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(WAVE) void k_sorting_reset(const double* __restrict
   const int od = 2 + 3 * gc.nb;
   for (int k = 0; k < od; k++) obs[(size_t)od * e + k] = o[k];
   int code = 0;
-  for (int i = 0; i < gc.nb; i++) code |= 1 << (7 - i);        // np.packbits of the all -1 mode vector
+  if (gc.task == GEN_TASK_SORTING) for (int i = 0; i < gc.nb; i++) code |= 1 << (7 - i);        // np.packbits of the all -1 mode vector (Inserting: no letters yet)
   done[e] = 0; success[e] = 0; mode[e] = (unsigned short)code;
 }
 

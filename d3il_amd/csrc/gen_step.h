@@ -26,7 +26,12 @@
 
 namespace d3il {
 
-constexpr int GEN_MAXNB = 4, GEN_MAXNS = 20, GEN_SEG = 24, GEN_MAXCON = GEN_MAXNB * GEN_SEG, GEN_MAXSET = GEN_MAXNS + 2;
+constexpr int GEN_MAXNB = 4, GEN_MAXNS = 28, GEN_SEG = 24;
+constexpr int GEN_ARMSEG = GEN_MAXNB;                // segment of the contacts that involve no cube (rod <-> static box); GEN_ARMCON of them take part in a solve
+constexpr int GEN_ARMCON = 3, GEN_ARMLANE = 2;       // GEN_ARMLANE: what one lane of the group may find (it scans every nl-th static box)
+constexpr int GEN_MAXCON = (GEN_MAXNB + 1) * GEN_SEG;
+constexpr int GEN_MAXSET = 2 * GEN_MAXNS + 2;        // static s <-> cube: s;  cube <-> cube: ns;  rod <-> cube: ns + 1;  rod <-> static s: ns + 2 + s
+enum { GEN_TASK_SORTING = 0, GEN_TASK_INSERTING = 1 };
 constexpr int GEN_MAXNV = 6 * GEN_MAXNB + NDOF;     // 33
 constexpr int GEN_NH = GEN_MAXNV * (GEN_MAXNV + 1) / 2;   // 561
 #ifndef D3IL_GEN_LANES
@@ -37,6 +42,10 @@ constexpr int GEN_LANES = D3IL_GEN_LANES;     // environments per workgroup (x G
 struct GenConsts {
   int nb, ns, set_bb, set_rod;
   int ns_core;                    // statics [0, ns_core): everything inside the table; [ns_core, ns): the frame beams around the table edge (only tested near it)
+  int task;                       // GEN_TASK_SORTING / GEN_TASK_INSERTING: which task logic reads the cubes (sort_* / ins_* below)
+  int rod_static;                 // 1: the rod <-> static box pairs are evaluated (Inserting: the rod works between the walls of the gates)
+  int st_rod[GEN_MAXNS];          // the rod's collision bits match static s
+  double ins_target[9], ins_min_dist;      // Inserting: the three goal positions and target_min_dist (gate_insertion_objects.py:17-24, gate_insertion.py:276)
   double box_half[3], box_mass, box_inertia, box_invw_t;
   double st_c[GEN_MAXNS][3], st_h[GEN_MAXNS][3], st_R[GEN_MAXNS][9];
   int st_first[GEN_MAXNS];        // 1: the static geom precedes the cube geoms in the model (it is geom 1 of the pair)
@@ -75,15 +84,16 @@ D3IL_HD constexpr int gen_state_rows(int nb) { return 42 + 13 * nb + 6 * nb + ND
 #define GLS(i) sc.h[(i) * GEN_HS]
 constexpr int GL_H = 0, GL_X = GEN_NH, GL_P = GL_X + GEN_MAXNV, GL_G = GL_P + GEN_MAXNV, GL_A0 = GL_G + GEN_MAXNV, GL_VEL = GL_A0 + GEN_MAXNV;
 constexpr int GL_R = GL_VEL + GEN_MAXNV, GL_POS = GL_R + 9 * GEN_MAXNB, GL_M = GL_POS + 3 * GEN_MAXNB, GL_LIM = GL_M + 45, GL_JA = GL_LIM + 27;
-constexpr int GL_ROD = GL_JA + 21 * GEN_MAXNB;      // rod centre[3], axis[3]
-constexpr int GL_INFO = GL_ROD + 6;                 // [0..3] per cube: contact count | partner cubes << 5 | rod contact << 9;  [4] arm joint at a limit;  [5..7] flags of lanes 1..3
-constexpr int GL_RED = GL_INFO + 8;                  // line-search partial sums of the group's lanes, double buffered: 2 x 4 x (d1, d2)
-constexpr int GL_SIZE = GL_RED + 16;                // 960
+constexpr int GL_ROD = GL_JA + 21 * (GEN_MAXNB + GEN_ARMCON);      // rod centre[3], axis[3].  GL_JA: arm rows of the rod contact of cube b at 21 b, of rod <-> static contact j at 21 (GEN_MAXNB + j)
+constexpr int GL_INFO = GL_ROD + 6;                 // [0..3] per cube: contact count | partner cubes << 5 | rod contact << 9;  [4] arm joint at a limit;  [5..7] flags of lanes 1..3;
+                                                    // [8] rod <-> static contacts of this sub-step;  [9..12] what lanes 0..3 found of them
+constexpr int GL_RED = GL_INFO + 16;                 // line-search partial sums of the group's lanes, double buffered: 2 x 4 x (d1, d2)
+constexpr int GL_SIZE = GL_RED + 16;                // 1031
 // g area (HBM): contact records, GEN_SEG per cube
 constexpr int GG_CON = 0;
 constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn fric set | jar[3] jp[3]
 constexpr int GG_SIZE = GG_CON + GEN_MAXCON * GREC;
-enum { GK_STATIC = 0, GK_BOXBOX = 1, GK_ROD = 2 };
+enum { GK_STATIC = 0, GK_BOXBOX = 1, GK_ROD = 2, GK_RODST = 3 /* rod <-> static box: a = static, b = its slot of the GL_JA rows; no cube */ };
 
 D3IL_HD void gen_sync() {     // orders the LDS / HBM traffic of the lanes of a group between two phases
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -117,12 +127,24 @@ D3IL_HD int isl_rank(const Isl isl, int b) {   // position of block b in the isl
 
 // rows of a contact over the solver dofs; the contact normal points from geom 1 to geom 2 and the row is J(body 2) - J(body 1).
 // Block 1: the first cube (6 dofs, global offset o1, compact c1); block 2: the second cube or the arm (n2 = 0, 6 or 7 dofs)
-struct GRow { int o1, o2, n2, c1, c2; double v1[6], v2[7]; };
+struct GRow { int o1, o2, n1, n2, c1, c2; double v1[6], v2[7]; };      // n1 = 0: no first block (rod <-> static box)
 // rec: the first 16 fields of the contact's record (pos[3] frame[9] dist kind a b), fetched by the caller in one batch
 D3IL_HD void gen_rows(const GenConsts& gc_, const PushScratch sc, const Isl isl, const double* rec, GRow* rows) {
   D3IL_GEN_CONSTS(gc_, gc);
   const int arm0 = 6 * gc.nb;
   const int kind = (int)rec[13], a = (int)rec[14], b = (int)rec[15];
+  if (kind == GK_RODST) {          // static box (geom 1, fixed) -> rod (geom 2): the row is + J(arm)
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+      GRow& s = rows[rr];
+#pragma unroll
+      for (int k = 0; k < 6; k++) s.v1[k] = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) s.v2[k] = GLS(GL_JA + 21 * (GEN_MAXNB + b) + 7 * rr + k);
+      s.o1 = arm0; s.c1 = isl.m - NDOF; s.n1 = 0; s.o2 = arm0; s.n2 = 7; s.c2 = isl.m - NDOF;
+    }
+    return;
+  }
   const int cb1 = kind == GK_STATIC ? b : a;        // first cube of the row (static: b = cube, a = static index)
   double R[9], r[3];
 #pragma unroll
@@ -143,7 +165,7 @@ D3IL_HD void gen_rows(const GenConsts& gc_, const PushScratch sc, const Isl isl,
     for (int k = 0; k < 6; k++) s.v1[k] *= sign1;
 #pragma unroll
     for (int k = 0; k < 7; k++) s.v2[k] = 0;
-    s.o1 = 6 * cb1; s.c1 = c1; s.o2 = o2; s.n2 = n2; s.c2 = c2;
+    s.o1 = 6 * cb1; s.c1 = c1; s.n1 = 6; s.o2 = o2; s.n2 = n2; s.c2 = c2;
   }
   if (kind == GK_BOXBOX) {
     double R2[9], r2[3];
@@ -169,7 +191,7 @@ D3IL_HD void gen_rows(const GenConsts& gc_, const PushScratch sc, const Isl isl,
 D3IL_HD double grow_dot_g(const PushScratch sc, const GRow& s, int vec) {
   double acc = 0;
 #pragma unroll
-  for (int k = 0; k < 6; k++) acc += s.v1[k] * GLS(vec + s.o1 + k);
+  for (int k = 0; k < 6; k++) if (k < s.n1) acc += s.v1[k] * GLS(vec + s.o1 + k);
 #pragma unroll
   for (int k = 0; k < 7; k++) if (k < s.n2) acc += s.v2[k] * GLS(vec + s.o2 + k);
   return acc;
@@ -177,7 +199,7 @@ D3IL_HD double grow_dot_g(const PushScratch sc, const GRow& s, int vec) {
 D3IL_HD double grow_dot_c(const PushScratch sc, const GRow& s, int vec) {
   double acc = 0;
 #pragma unroll
-  for (int k = 0; k < 6; k++) acc += s.v1[k] * GLS(vec + s.c1 + k);
+  for (int k = 0; k < 6; k++) if (k < s.n1) acc += s.v1[k] * GLS(vec + s.c1 + k);
 #pragma unroll
   for (int k = 0; k < 7; k++) if (k < s.n2) acc += s.v2[k] * GLS(vec + s.c2 + k);
   return acc;
@@ -327,7 +349,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     bool found = false;
     for (int k = 0; k < isl.n; k++) {
       const int n = (int)((cpk >> (5 * k)) & 31u);
-      if (!found && t < n) { ci = ISL_BLK(k) * GEN_SEG + t; found = true; }
+      if (!found && t < n) { const int blk = ISL_BLK(k); ci = (blk < gc.nb ? blk : GEN_ARMSEG) * GEN_SEG + t; found = true; }      // the arm block's contacts: rod <-> static boxes
       t -= n;
     }
     return ci;
@@ -341,10 +363,10 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     double rec[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
-    const int kind = (int)rec[13], set = kind == GK_STATIC ? (int)rec[14] : (kind == GK_BOXBOX ? gc.set_bb : gc.set_rod);
+    const int kind = (int)rec[13], set = kind == GK_STATIC ? (int)rec[14] : (kind == GK_BOXBOX ? gc.set_bb : (kind == GK_ROD ? gc.set_rod : gc.ns + 2 + (int)rec[14]));
     const double dist = rec[12];
     double imp = impedance(gc.ct_solimp[set], dist);
-    double invw = kind == GK_STATIC ? gc.box_invw_t : (kind == GK_BOXBOX ? 2 * gc.box_invw_t : gc.box_invw_t + gc.rod_invw);
+    double invw = kind == GK_STATIC ? gc.box_invw_t : (kind == GK_BOXBOX ? 2 * gc.box_invw_t : (kind == GK_ROD ? gc.box_invw_t + gc.rod_invw : gc.rod_invw));
     GRow rows[3];
     gen_rows(gc, sc, isl, rec, rows);
     double v0 = grow_dot_g(sc, rows[0], GL_VEL), v1 = grow_dot_g(sc, rows[1], GL_VEL), v2 = grow_dot_g(sc, rows[2], GL_VEL);
@@ -397,14 +419,14 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
       const double Dn = rec[19], fric = rec[20];
       cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
       if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
-      const int c1 = rows[0].c1, c2 = rows[0].c2, n2 = rows[0].n2;
+      const int c1 = rows[0].c1, c2 = rows[0].c2, n1 = rows[0].n1, n2 = rows[0].n2;
 #pragma unroll
-      for (int k = 0; k < 6; k++) GLS_ADD(vg + c1 + k, -(rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2]));
+      for (int k = 0; k < 6; k++) if (k < n1) GLS_ADD(vg + c1 + k, -(rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2]));
 #pragma unroll
       for (int k = 0; k < 7; k++) if (k < n2) GLS_ADD(vg + c2 + k, -(rows[0].v2[k] * force[0] + rows[1].v2[k] * force[1] + rows[2].v2[k] * force[2]));
       // H += J' Hc J, block (1,1), then (2,1) and (2,2); c2 > c1 for every contact kind (second cube after the first, arm last)
 #pragma unroll
-      for (int a = 0; a < 6; a++) {
+      for (int a = 0; a < 6; a++) if (a < n1) {
         double ta[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v1[a] + Hc[3 * r + 1] * rows[1].v1[a] + Hc[3 * r + 2] * rows[2].v1[a];
@@ -417,7 +439,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
 #pragma unroll
         for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v2[a] + Hc[3 * r + 1] * rows[1].v2[a] + Hc[3 * r + 2] * rows[2].v2[a];
 #pragma unroll
-        for (int b = 0; b < 6; b++) GLS_ADD(hb + tri(c2 + a, c1 + b), ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b]);
+        for (int b = 0; b < 6; b++) if (b < n1) GLS_ADD(hb + tri(c2 + a, c1 + b), ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b]);
 #pragma unroll
         for (int b = 0; b < 7; b++) if (b <= a) GLS_ADD(hb + tri(c2 + a, c2 + b), ta[0] * rows[0].v2[b] + ta[1] * rows[1].v2[b] + ta[2] * rows[2].v2[b]);
       }
@@ -827,13 +849,53 @@ D3IL_NOINLINE inline void gen_phase3(const GenConsts& gc_, const PushScratch sc,
   }
   GLS(GL_INFO + c) = (double)((unsigned)cnt | (partners << 5) | (rod << 9));
 }
-// ---- phase 3b (lane 0): arm Jacobian rows of the rod contacts (the last record of a cube's segment)
+// ---- phase 3r (lane l of nl, only when gc.rod_static): the rod against the static boxes l, l + nl, ..  A box is skipped when the rod's capsule
+// lies beyond one of its faces (exact rejection in the box frame); what remains goes through cyl_box.  The lane parks its finds in its own
+// slots [GEN_ARMLANE l, ..) of the arm segment and publishes their number; lane 0 packs them in phase 3b.
+D3IL_NOINLINE inline void gen_phase3r(const GenConsts& gc_, const PushScratch sc, int l, int nl, double rod_r, double rod_h, unsigned& fl) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  double rodc[3], rodu[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { rodc[k] = GLS(GL_ROD + k); rodu[k] = GLS(GL_ROD + 3 + k); }
+  int cnt = 0;
+  for (int s = l; s < gc.ns_core; s += nl) {
+    if (!gc.st_rod[s]) continue;
+    bool apart = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double x = (rodc[0] - gc.st_c[s][0]) * gc.st_R[s][i] + (rodc[1] - gc.st_c[s][1]) * gc.st_R[s][3 + i] + (rodc[2] - gc.st_c[s][2]) * gc.st_R[s][6 + i];
+      const double u = rodu[0] * gc.st_R[s][i] + rodu[1] * gc.st_R[s][3 + i] + rodu[2] * gc.st_R[s][6 + i];
+      apart = apart || fabs(x) - rod_h * fabs(u) > gc.st_h[s][i] + rod_r;
+    }
+    if (apart) continue;
+    double r1[7];
+    if (!cyl_box(rodc, rodu, rod_r, rod_h, gc.st_c[s], gc.st_R[s], gc.st_h[s], 0.0, r1)) continue;      // the box is geom 1: normal box -> rod
+    if (cnt >= GEN_ARMLANE) { fl |= PF_CON_OVERFLOW; continue; }
+    int slot = GEN_ARMLANE * l + cnt;
+    gen_put(gc, sc, GEN_ARMSEG, slot, fl, r1, GK_RODST, s, 0, gc.ns + 2 + s);
+    cnt++;
+  }
+  GLS(GL_INFO + 9 + l) = (double)cnt;
+}
+// ---- phase 3b (lane 0): arm Jacobian rows of the rod contacts (the last record of a cube's segment; the packed rod <-> static contacts)
 template <class C>
-D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, const PushScratch sc) {
+D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, const PushScratch sc, int nl, unsigned& fl) {
   D3IL_GEN_CONSTS(gc_, gc);
   bool any = false;
   for (int b = 0; b < gc.nb; b++) any = any || (((unsigned)GLS(GL_INFO + b) >> 9) & 1);
-  if (!any) return;
+  int narm = 0;
+  if (gc.rod_static) {          // pack the lanes' finds to the front of the arm segment
+    for (int l = 0; l < nl; l++)
+      for (int j = 0, m = (int)GLS(GL_INFO + 9 + l); j < m; j++) {
+        if (narm >= GEN_ARMCON) { fl |= PF_CON_OVERFLOW; continue; }
+        const int src = GG_CON + (GEN_ARMSEG * GEN_SEG + GEN_ARMLANE * l + j) * GREC, dst = GG_CON + (GEN_ARMSEG * GEN_SEG + narm) * GREC;
+        if (src != dst) for (int k = 0; k < 22; k++) PGS(dst + k) = PGS(src + k);
+        PGS(dst + 15) = (double)narm;
+        narm++;
+      }
+  }
+  GLS(GL_INFO + 8) = (double)narm;
+  if (!any && narm == 0) return;
   double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3];
 #pragma unroll
   for (int i = 0; i < NARM; i++) sincos(st.q[i], &sn[i], &cs[i]);
@@ -847,6 +909,15 @@ D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, 
       double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
       cross3(ax[k], dd, col);
       for (int r = 0; r < 3; r++) GLS(GL_JA + 21 * b + 7 * r + k) = col[0] * PGS(base + 3 + 3 * r) + col[1] * PGS(base + 4 + 3 * r) + col[2] * PGS(base + 5 + 3 * r);
+    }
+  }
+  for (int j = 0; j < narm; j++) {
+    const int base = GG_CON + (GEN_ARMSEG * GEN_SEG + j) * GREC;
+    double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
+    for (int k = 0; k < NARM; k++) {
+      double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
+      cross3(ax[k], dd, col);
+      for (int r = 0; r < 3; r++) GLS(GL_JA + 21 * (GEN_MAXNB + j) + 7 * r + k) = col[0] * PGS(base + 3 + 3 * r) + col[1] * PGS(base + 4 + 3 * r) + col[2] * PGS(base + 5 + 3 * r);
     }
   }
 }
@@ -869,6 +940,7 @@ D3IL_HD void gen_islands(const GenConsts& gc_, const PushScratch sc, IslSet& out
 #pragma unroll
     for (int d = 0; d <= GEN_MAXNB; d++) if ((m >> d) & 1) adj[d] |= 1u << b;
   }
+  cnt[nb] = (unsigned)GLS(GL_INFO + 8);      // rod <-> static contacts: they belong to the arm block
   unsigned seen = 0;
   int hoff = 0, voff = 0;
   out.n = 0;
@@ -917,11 +989,12 @@ D3IL_HD void gen_phase4_single(const GenConsts& gc_, const PushScratch sc, int l
 D3IL_HD void gen_phase4_multi(const GenConsts& gc_, const PushScratch sc, int l, int nl, bool warm_valid, unsigned& fl) {
   D3IL_GEN_CONSTS(gc_, gc);
   if (gen_uncoupled(gc, sc)) {
-    if (GLS(GL_INFO + 4) == 0) return;                         // the usual case: nothing to do
-    Isl isl = gen_island(1u << gc.nb, gc.nb);                   // only the arm, with a joint at its limit
+    const unsigned narm = (unsigned)GLS(GL_INFO + 8);
+    if (GLS(GL_INFO + 4) == 0 && narm == 0) return;            // the usual case: nothing to do
+    Isl isl = gen_island(1u << gc.nb, gc.nb);                   // only the arm, with a joint at its limit or the rod on a static box
     GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);
     gen_sync();
-    if (!gen_solve(gc, sc, isl, 0u, l, nl)) fl |= F_SOLVER_FAIL;
+    if (!gen_solve(gc, sc, isl, narm, l, nl)) fl |= F_SOLVER_FAIL;
     gen_sync();
     return;
   }
@@ -933,7 +1006,7 @@ D3IL_HD void gen_phase4_multi(const GenConsts& gc_, const PushScratch sc, int l,
 #pragma unroll
   for (int k = 0; k <= GEN_MAXNB; k++) if (k < is.n) {
     const bool arm_alone = is.isl[k].n == 1 && is.isl[k].arm;
-    if (is.isl[k].n > 1 || (arm_alone && GLS(GL_INFO + 4) != 0)) { todo |= (unsigned)k << (4 * ntodo); ntodo++; }
+    if (is.isl[k].n > 1 || (arm_alone && (GLS(GL_INFO + 4) != 0 || GLS(GL_INFO + 8) != 0))) { todo |= (unsigned)k << (4 * ntodo); ntodo++; }
   }
   for (int j = 0; j < ntodo; j++) {
     const int k = (int)((todo >> (4 * j)) & 15u);
@@ -1005,7 +1078,8 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc_, EnvState& st
   gen_phase1(c0, gc, st, sc, tau, ffing);
   for (int l = 0; l < gc.nb; l++) cnt[l] = gen_phase2(gc, sc, l, grav, fl);
   for (int l = 0; l < gc.nb; l++) gen_phase3(gc, sc, l, cnt[l], c.rod_r, c.rod_h, fl);
-  gen_phase3b(c0, gc, st, sc);
+  if (gc.rod_static) for (int l = 0; l < gc.nb; l++) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, fl);
+  gen_phase3b(c0, gc, st, sc, gc.nb, fl);
   for (int l = 0; l < gc.nb; l++) gen_phase4_single(gc, sc, l, warm_valid, fl);
   gen_phase4_multi(gc, sc, 0, 1, warm_valid, fl);
   gen_phase5_arm(c0, gc, st, sc);
@@ -1069,6 +1143,46 @@ D3IL_HD int sort_check_mode(const GenConsts& gc_, unsigned* task, const double (
   return code;
 }
 
+// ------------------------------------------------------------------------------------------------ Inserting task (gate_insertion.py)
+// Gate_Insertion_Env on the same engine (three 5 cm cubes, seventeen static walls, the rod also meets the walls).  Task state: word 0 = number of
+// letters in `modes` | letter k (1 r, 2 g, 3 b) << (2 + 2 k); word 1 = mean_distance of the last step (a double, read back by the env class).
+// get_observation (gate_insertion.py:278-309), _check_early_termination (:475-498), check_mean_dist (:434-446): distances over the full 3-D positions
+D3IL_HD bool ins_obs_success(const GenConsts& gc_, const PushScratch sc, const double* tcp, float* obs, double* d3, double* mean_dist) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  obs[0] = (float)tcp[0]; obs[1] = (float)tcp[1];
+  bool ok = true;
+  double sum = 0;
+  for (int i = 0; i < 3; i++) {
+    double b[7];
+    for (int j = 0; j < 7; j++) b[j] = GBX(i, j);
+    obs[2 + 3 * i] = (float)b[0]; obs[3 + 3 * i] = (float)b[1]; obs[4 + 3 * i] = (float)push_tan_yaw(b + 3);
+    const double dx = b[0] - gc.ins_target[3 * i], dy = b[1] - gc.ins_target[3 * i + 1], dz = b[2] - gc.ins_target[3 * i + 2];
+    d3[i] = sqrt(dx * dx + dy * dy + dz * dz);
+    ok = ok && d3[i] <= gc.ins_min_dist;
+    sum += d3[i];
+  }
+  *mean_dist = sum / 3;
+  return ok;
+}
+// check_mode (:411-432) + step's info (:386-409): code = mode_dict[letters] (rgb 1, rbg 2, grb 3, gbr 4, brg 5, bgr 6) once all three letters are in, else 0;
+// reported as code | number of letters << 3 (one / two / three_box_success are that number >= 1 / 2 / 3)
+D3IL_HD int ins_check_mode(const GenConsts& gc_, unsigned* task, const double* d3) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  unsigned n = task[0] & 3u;
+  for (unsigned i = 0; i < 3; i++) {
+    bool have = false;
+    for (unsigned k = 0; k < n; k++) have = have || ((task[0] >> (2 + 2 * k)) & 3u) == i + 1;
+    if (d3[i] <= gc.ins_min_dist && !have) { task[0] |= (i + 1) << (2 + 2 * n); n++; }
+  }
+  task[0] = (task[0] & ~3u) | n;
+  int code = 0;
+  if (n == 3) {
+    const unsigned a = (task[0] >> 2) & 3u, b = (task[0] >> 4) & 3u;      // first and second letter decide
+    code = a == 1 ? (b == 2 ? 1 : 2) : (a == 2 ? (b == 1 ? 3 : 4) : (b == 1 ? 5 : 6));
+  }
+  return code | (int)(n << 3);
+}
+
 // ------------------------------------------------------------------------------------------------ env level
 template <class C>
 D3IL_HD void gen_control_and_physics(const C& c, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* q_des, const double* qd_des,
@@ -1099,6 +1213,7 @@ D3IL_HD void gen_env_reset(const C& c, const GenConsts& gc_, EnvState& st, const
   }
   double zero[NARM] = {0, 0, 0, 0, 0, 0, 0};
   gen_control_and_physics(c, gc, st, sc, init_qpos, zero, 0.001, false);
+  if (gc.task == GEN_TASK_INSERTING) { double d3[3], md; ins_obs_success(gc, sc, st.tcp, obs, d3, &md); return; }
   double box[6][7];
   sort_collect(gc, sc, box);
   sort_obs_success(gc, box, st.tcp, obs);
@@ -1106,9 +1221,13 @@ D3IL_HD void gen_env_reset(const C& c, const GenConsts& gc_, EnvState& st, const
 // before the physics of a step: observation and done (gym_env_wrapper.py:88-90,124-137)
 D3IL_HD void sort_step_begin(const GenConsts& gc_, EnvState& st, const PushScratch sc, float* obs, unsigned char* done, int max_steps) {
   D3IL_GEN_CONSTS(gc_, gc);
-  double box[6][7];
-  sort_collect(gc, sc, box);
-  bool succ = sort_obs_success(gc, box, st.tcp, obs);
+  bool succ;
+  if (gc.task == GEN_TASK_INSERTING) { double d3[3], md; succ = ins_obs_success(gc, sc, st.tcp, obs, d3, &md); }
+  else {
+    double box[6][7];
+    sort_collect(gc, sc, box);
+    succ = sort_obs_success(gc, box, st.tcp, obs);
+  }
   bool fin = (st.flags & F_TERMINATED) != 0;
   if (!fin && succ) { st.flags |= F_TERMINATED; fin = true; }
   if (!fin && st.step >= max_steps - 1) fin = true;
@@ -1118,7 +1237,18 @@ D3IL_HD void sort_step_begin(const GenConsts& gc_, EnvState& st, const PushScrat
 D3IL_HD void sort_step_end(const GenConsts& gc_, EnvState& st, const PushScratch sc, int* mode_code) {
   D3IL_GEN_CONSTS(gc_, gc);
   st.step++;
-  double box[6][7]; float dummy[GEN_SORT_OBS];
+  float dummy[GEN_SORT_OBS];
+  if (gc.task == GEN_TASK_INSERTING) {
+    double d3[3], md;
+    const bool succ = ins_obs_success(gc, sc, st.tcp, dummy, d3, &md);
+    st.flags &= ~F_SUCCESS;
+    if (succ) st.flags |= F_SUCCESS | F_TERMINATED;
+    unsigned task[1] = {(unsigned)GTASK(0)};
+    *mode_code = ins_check_mode(gc, task, d3);
+    GTASK(0) = (double)task[0]; GTASK(1) = md;
+    return;
+  }
+  double box[6][7];
   sort_collect(gc, sc, box);
   bool succ = sort_obs_success(gc, box, st.tcp, dummy);
   st.flags &= ~F_SUCCESS;
@@ -1186,6 +1316,7 @@ D3IL_HOSTFN inline int build_gen_consts(const d3il_model_blob& m, const PandaCon
   int ns = 0, table = -1;
   double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0}, olo[2] = {0, 0}, ohi[2] = {0, 0};
   bool taken[D3IL_MAXGEOM];
+  int st_geom[GEN_MAXNS];
   for (int g = 0; g < D3IL_MAXGEOM; g++) taken[g] = false;
   for (int pass = 0; pass < 3; pass++) {
   for (int g = 0; g < m.ngeom; g++) {
@@ -1226,6 +1357,7 @@ D3IL_HOSTFN inline int build_gen_consts(const d3il_model_blob& m, const PandaCon
     for (int k = 0; k < 3; k++) { gc.st_c[ns][k] = p[k]; gc.st_h[ns][k] = m.geom_size[g][k]; }
     for (int k = 0; k < 9; k++) gc.st_R[ns][k] = R[k];
     gc.st_first[ns] = g < g0 ? 1 : 0;
+    st_geom[ns] = g;
     mix(g, g0, ns);
     taken[g] = true;
     if (pass == 2) for (int i = 0; i < 2; i++) { gc.ws_lo[i] = std::fmin(gc.ws_lo[i], p[i] - ext[i]); gc.ws_hi[i] = std::fmax(gc.ws_hi[i], p[i] + ext[i]); }
@@ -1243,6 +1375,21 @@ D3IL_HOSTFN inline int build_gen_consts(const d3il_model_blob& m, const PandaCon
     if (g > m.rod_geom || (b + 1 < gc.nb && g > cube_geom(m.obj_body[b + 1])) || m.geom_margin[g] != 0) { *err = "unexpected geom order"; return -1; }
   }
   mix(g0, m.rod_geom, gc.set_rod);
+  gc.task = m.task_id == D3IL_TASK_INSERTING ? GEN_TASK_INSERTING : GEN_TASK_SORTING;
+  if (gc.task == GEN_TASK_INSERTING) {
+    if (gc.nb != 3) { *err = "the Inserting task has three push boxes"; return -1; }
+    for (int k = 0; k < 9; k++) gc.ins_target[k] = m.task_f[k];
+    gc.ins_min_dist = m.task_f[9];
+    // the rod works between the walls of the gates: rod <-> static box pairs (the oracle evaluates them for this task, oracle/d3il_oracle.c pair_supported)
+    gc.rod_static = 1;
+    if (m.geom_margin[m.rod_geom] != 0 || m.geom_gap[m.rod_geom] != 0) { *err = "a rod with a contact margin is not supported"; return -1; }
+    for (int s = 0; s < ns; s++) {
+      const int g = st_geom[s];
+      if (g > m.rod_geom) { *err = "unexpected geom order (static box after the rod)"; return -1; }
+      gc.st_rod[s] = ((m.geom_contype[g] & m.geom_conaffinity[m.rod_geom]) || (m.geom_contype[m.rod_geom] & m.geom_conaffinity[g])) ? 1 : 0;
+      mix(g, m.rod_geom, ns + 2 + s);
+    }
+  }
   for (int k = 0; k < 3; k++) gc.absent[k] = m.body_pos[m.nbody - 1][k];
   for (int k = 0; k < 4; k++) gc.absent[3 + k] = m.body_quat[m.nbody - 1][k];
   gc.impratio = m.impratio;

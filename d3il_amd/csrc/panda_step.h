@@ -58,6 +58,12 @@ namespace d3il { __device__ unsigned long long g_dev_stats[32]; __device__ unsig
 #define D3IL_STAT(x) ((void)0)
 #define D3IL_DSTAT(i) ((void)0)
 #endif
+// lane-level event counter of the diagnostics build (g_dev_stats[24 + slot]; 0: Rayleigh-quotient steps of the deflate path, 1: deflate solves that started from a warm vector)
+#if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define D3IL_DCOUNT(slot) atomicAdd(&d3il::g_dev_stats[24 + (slot)], 1ull)
+#else
+#define D3IL_DCOUNT(slot) ((void)0)
+#endif
 
 namespace d3il {
 
@@ -311,6 +317,7 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
         // changes little between IK iterations), else two inverse-iteration steps starting from b
         double v[6], w[6], nr = 0;
         if (vwarm && vwarm[6] != 0.0) {
+          D3IL_DCOUNT(1);
 #pragma unroll
           for (int i = 0; i < 6; i++) v[i] = vwarm[i];
         } else {
@@ -332,6 +339,7 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
 #pragma unroll
           for (int i = 0; i < 6; i++) res = fmax(res, fabs(w[i] - lam * v[i]));
           if (res <= 1e-14 * tr || it == 4) break;
+          D3IL_DCOUNT(0);
           double L2[21], d2[6], id2[6], u[6];
           int n2;
           ldl6(A, lam, L2, d2, id2, &n2);

@@ -647,6 +647,8 @@ static_assert(D3IL_SFLAG_MODE_MASK == (SKF_NMODE_MASK | (0x3Fu << SKF_IND_SHIFT)
 static_assert(D3IL_ALIGN_STATE_BOX == AL_STATE_BOX && D3IL_ALIGN_STATE_WARM == AL_STATE_WARM && D3IL_ALIGN_STATE_TARGET == AL_STATE_TARGET && D3IL_ALIGN_STATE_F64 == AL_STATE_F64, "d3il_rollout.h: Aligning state layout");
 static_assert(D3IL_PUSH_STATE_F64 == PUSH_STATE_F64 && D3IL_TALLY_ALL + 256 <= D3IL_TALLY_ROW - 2, "d3il_rollout.h: Pushing state rows / tally row");
 
+static inline bool gen_task(int task_id) { return task_id == D3IL_TASK_SORTING || task_id == D3IL_TASK_INSERTING; }   // the tasks of the generic engine (gen_step.h)
+
 struct d3il_handle_s {
   int task_id, n, stride, device;
   PandaConsts hc;          // host copy
@@ -710,7 +712,7 @@ static void free_handle(d3il_handle_s* h) {
   if (dev >= 0 && dev < 16) {
     std::lock_guard<std::mutex> lock(g_model_mutex);
     if (h->task_id == D3IL_TASK_PUSHING && g_active_push[dev].refs > 0) g_active_push[dev].refs--;
-    if (h->task_id == D3IL_TASK_SORTING && g_active_gen[dev].refs > 0) g_active_gen[dev].refs--;
+    if (gen_task(h->task_id) && g_active_gen[dev].refs > 0) g_active_gen[dev].refs--;
     if (h->task_id == D3IL_TASK_STACKING && g_active_stack[dev].refs > 0) g_active_stack[dev].refs--;
   }
   void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des,
@@ -729,7 +731,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (n_envs <= 0) return fail(D3IL_EINVAL, "d3il_create: n_envs must be positive");
   const d3il_model_blob& m = *(const d3il_model_blob*)model_blob;
   if (task_id != m.task_id) return fail(D3IL_EINVAL, "d3il_create: task_id does not match the model blob");
-  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING && task_id != D3IL_TASK_STACKING && task_id != D3IL_TASK_ALIGNING)
+  if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING && task_id != D3IL_TASK_STACKING && task_id != D3IL_TASK_ALIGNING && task_id != D3IL_TASK_INSERTING)
     return fail(D3IL_EUNSUPPORTED, "d3il_create: unknown task id (Avoiding, Pushing, Sorting, Stacking and Aligning are implemented)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(D3IL_ENODEVICE, "d3il_create: no HIP device available (there is no CPU fallback)");
@@ -745,7 +747,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   if (rc) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   finish_invweights(h->hc);
   if (task_id == D3IL_TASK_PUSHING && build_push_consts(m, h->pc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
-  if (task_id == D3IL_TASK_SORTING && build_gen_consts(m, h->hc, h->gc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  if (gen_task(task_id) && build_gen_consts(m, h->hc, h->gc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_STACKING && build_stack_consts(m, h->hc, h->kc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_ALIGNING && build_coop_align_consts(m, h->hc, h->kc, h->atk, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   {  // the kernels are specialised at build time to the robot model (csrc/gen/avoiding_consts.inc): the runtime blob
@@ -768,7 +770,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
                                                                  "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
   const bool pushing = task_id == D3IL_TASK_PUSHING;
-  const bool sorting = task_id == D3IL_TASK_SORTING;
+  const bool sorting = gen_task(task_id);       // Sorting and Inserting run on the generic engine (gen_step.h)
   // one Pushing / Sorting model per device while handles are alive (constant memory)
   if (pushing) {
     ActiveModel& am = g_active_push[device_id];
@@ -969,7 +971,7 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
     HIPCHK(hipGetLastError());
     return D3IL_OK;
   }
-  if (h->task_id == D3IL_TASK_SORTING) {
+  if (gen_task(h->task_id)) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Sorting task needs contexts (device f64 [n_envs][7 * n_boxes])");
     hipLaunchKernelGGL(k_sorting_reset, dim3((h->n + GEN_LANES - 1) / GEN_LANES), dim3(WAVE), GEN_LDS_H, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
                        b.flags, b.step_count, b.obs, b.done, b.success, b.mode, h->d_scratch, h->n, h->stride);
@@ -1030,7 +1032,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
     return D3IL_OK;
   }
-  if (h->task_id == D3IL_TASK_SORTING) {
+  if (gen_task(h->task_id)) {
     int nwgs = (h->n + GEN_LANES - 1) / GEN_LANES;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
     if (h->fast)
@@ -1206,7 +1208,7 @@ int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream)
     // Avoiding counts its episodes in the fused reset kernel below
     hipLaunchKernelGGL(k_episode_tally, dim3((h->n + 255) / 256), dim3(256), 0, s, b.done, b.success, b.mode, h->tally_ctx, (long long*)h->tally_table,
                        avoiding ? (long long*)nullptr : (long long*)episode_counts_device, h->n, h->tally_nctx, (h->task_id == D3IL_TASK_PUSHING || h->task_id == D3IL_TASK_ALIGNING) ? 1 : 0,
-                       h->task_id == D3IL_TASK_STACKING ? 1 : 0);
+                       (h->task_id == D3IL_TASK_STACKING || h->task_id == D3IL_TASK_INSERTING) ? 1 : 0);
     HIPCHK(hipGetLastError());
   }
   if (avoiding) {

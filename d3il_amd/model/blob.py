@@ -19,7 +19,7 @@ VERSION = 5
 MAXBODY, MAXJNT, MAXGEOM, MAXACT, MAXEXCL, MAXCHAIN, MAXOBST = 64, 16, 80, 12, 16, 16, 8
 MAXMESH, MAXMVERT = 2, 800
 
-TASK_IDS = {"avoiding": 0, "pushing": 1, "sorting": 2, "stacking": 3, "aligning": 4}
+TASK_IDS = {"avoiding": 0, "pushing": 1, "sorting": 2, "stacking": 3, "aligning": 4, "inserting": 5}
 JNT_TYPES = {"free": 0, "hinge": 2, "slide": 3}       # numeric values follow mjtJoint [ext]
 GEOM_TYPES = {"plane": 0, "sphere": 2, "cylinder": 5, "box": 6, "mesh": 7}  # mjtGeom [ext]
 
@@ -29,7 +29,7 @@ I32, U32, F64 = C.c_int32, C.c_uint32, C.c_double
 FIELDS = [
     ("magic", U32, (), "D3IL_BLOB_MAGIC"),
     ("version", U32, (), "D3IL_BLOB_VERSION"),
-    ("task_id", I32, (), "0 avoiding, 1 pushing, 2 sorting, 3 stacking, 4 aligning"),
+    ("task_id", I32, (), "0 avoiding, 1 pushing, 2 sorting, 3 stacking, 4 aligning, 5 inserting"),
     ("nbody", I32, (), ""), ("njnt", I32, (), ""), ("ngeom", I32, (), ""),
     ("nu", I32, (), ""), ("nexclude", I32, (), ""), ("nchain", I32, (), ""),
     ("iterations", I32, (), "solver iteration cap (MuJoCo default 100)"),
@@ -121,7 +121,7 @@ def emit_header() -> str:
         "#define D3IL_MAXOBST %d" % MAXOBST, "#define D3IL_MAXMESH %d" % MAXMESH, "#define D3IL_MAXMVERT %d" % MAXMVERT, "",
         "enum { D3IL_JNT_FREE = 0, D3IL_JNT_HINGE = 2, D3IL_JNT_SLIDE = 3 };",
         "enum { D3IL_GEOM_PLANE = 0, D3IL_GEOM_SPHERE = 2, D3IL_GEOM_CYLINDER = 5, D3IL_GEOM_BOX = 6, D3IL_GEOM_MESH = 7 };",
-        "enum { D3IL_TASK_AVOIDING = 0, D3IL_TASK_PUSHING = 1, D3IL_TASK_SORTING = 2, D3IL_TASK_STACKING = 3, D3IL_TASK_ALIGNING = 4 };",
+        "enum { D3IL_TASK_AVOIDING = 0, D3IL_TASK_PUSHING = 1, D3IL_TASK_SORTING = 2, D3IL_TASK_STACKING = 3, D3IL_TASK_ALIGNING = 4, D3IL_TASK_INSERTING = 5 };",
         "", "typedef struct d3il_model_blob {",
     ]
     for n, ct, sh, cm in FIELDS:
@@ -272,6 +272,12 @@ def pack(js: dict) -> ModelBlob:
         for k in range(3):
             b.task_f[k], b.task_f[3 + k] = tc["target_pos1"][k], tc["target_pos2"][k]
         b.task_f[6] = tc["target_min_dist"]
+    if js["task"] == "inserting":
+        # gate_insertion_objects.py:17-24 the three target positions (red, green, blue), gate_insertion.py:276 target_min_dist
+        for i in range(3):
+            for k in range(3):
+                b.task_f[3 * i + k] = tc["target_pos"][i][k]
+        b.task_f[9] = tc["target_min_dist"]
     if js["task"] == "aligning":
         b.task_f[0], b.task_f[1], b.task_f[2] = tc["pos_min_dist"], tc["rot_min_dist"], tc["robot_box_dist"]
         b.task_f[3] = bname[tc["target_body"]]

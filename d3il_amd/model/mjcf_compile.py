@@ -531,6 +531,49 @@ def build_aligning():
     return to_blob(m, "aligning", tc)
 
 
+def inserting_objects():
+    """gate_insertion_objects.py:5-288 restated as data, in the order gate_insertion.py:229-255 adds them to the scene: three free 5 cm cubes (push_box1..3,
+    50 g), three visual-only target boxes (unnamed in the reference: Box(None, ...); they only carry the goal positions), and the seventeen static
+    walls maze_3 .. maze_19 of the three gates (maze_1 / maze_2 are constructed but never added: commented out at gate_insertion.py:236-237).  Four walls
+    stand diagonally: their quaternions (0, 0.5, +-1, 0) are not unit length - the model compiler normalises them, as MuJoCo does."""
+    objs = [
+        prim_body("push_box1", "box", [0.4, -0.3, -0.0072], [0, 1, 0, 0], [0.025, 0.025, 0.025], mass=0.05),
+        prim_body("push_box2", "box", [0.55, -0.3, -0.0072], [0, 1, 0, 0], [0.025, 0.025, 0.025], mass=0.05),
+        prim_body("push_box3", "box", [0.5, -0.35, -0.0072], [0, 1, 0, 0], [0.025, 0.025, 0.025], mass=0.05),
+        prim_body("target_box1", "box", [0.3575, 0.276, 0.0], [0, 1, 0, 0], [0.025, 0.025, 0.02], static=True, visual_only=True),
+        prim_body("target_box2", "box", [0.525, 0.4535, 0.0], [0, 1, 0, 0], [0.025, 0.025, 0.02], static=True, visual_only=True),
+        prim_body("target_box3", "box", [0.6925, 0.276, 0.0], [0, 1, 0, 0], [0.025, 0.025, 0.02], static=True, visual_only=True),
+    ]
+    maze = {3: ([0.4, 0.17, 0.0], [0, 0.5, 1, 0], [0.03, 0.01, 0.03]), 4: ([0.65, 0.17, 0.0], [0, 0.5, -1, 0], [0.03, 0.01, 0.03]),
+            5: ([0.383, 0.2185, 0.0], [0, 1, 0, 0], [0.01, 0.03, 0.03]), 6: ([0.667, 0.2185, 0.0], [0, 1, 0, 0], [0.01, 0.03, 0.03]),
+            7: ([0.3525, 0.2385, 0.0], [0, 1, 0, 0], [0.04, 0.01, 0.03]), 8: ([0.6975, 0.2385, 0.0], [0, 1, 0, 0], [0.04, 0.01, 0.03]),
+            9: ([0.32, 0.276, 0.0], [0, 1, 0, 0], [0.01, 0.0475, 0.03]), 10: ([0.73, 0.276, 0.0], [0, 1, 0, 0], [0.01, 0.0475, 0.03]),
+            11: ([0.3525, 0.3135, 0.0], [0, 1, 0, 0], [0.04, 0.01, 0.03]), 12: ([0.6975, 0.3135, 0.0], [0, 1, 0, 0], [0.04, 0.01, 0.03]),
+            13: ([0.383, 0.3335, 0.0], [0, 1, 0, 0], [0.01, 0.03, 0.03]), 14: ([0.667, 0.3335, 0.0], [0, 1, 0, 0], [0.01, 0.03, 0.03]),
+            15: ([0.435, 0.3975, 0.0], [0, 0.5, 1, 0], [0.01, 0.07, 0.03]), 16: ([0.615, 0.3975, 0.0], [0, 0.5, -1, 0], [0.01, 0.07, 0.03]),
+            17: ([0.4875, 0.4585, 0.0], [0, 1, 0, 0], [0.01, 0.04, 0.03]), 18: ([0.5625, 0.4585, 0.0], [0, 1, 0, 0], [0.01, 0.04, 0.03]),
+            19: ([0.525, 0.491, 0.0], [0, 1, 0, 0], [0.0475, 0.01, 0.03])}
+    for i in range(3, 20):
+        pos, quat, size = maze[i]
+        objs.append(prim_body("maze_%d" % i, "box", pos, quat, size, mass=0.05, static=True))
+    return objs
+
+
+def build_inserting():
+    """Gate_Insertion_Env (gate_insertion.py:157-282): the rod robot, Cartesian controller, 35 sub-steps, 2000-step episode cap (the constructor default;
+    the reference ships no config / Sim class for this task)."""
+    m = build_scene("panda_rod_invisible.xml", inserting_objects(), "inserting")
+    tc = dict(
+        n_substeps=35, max_steps=2000,                       # gate_insertion.py:157-158
+        init_end_eff_pos=[0.525, -0.28, 0.12], init_end_eff_quat=[0, 1, 0, 0],   # gate_insertion_objects.py:5, gate_insertion.py:332-356
+        rod_geom="rod:geom_rb0", tcp_body="tcp_rb0",
+        objects=["push_box1", "push_box2", "push_box3"],
+        target_pos=[[0.3575, 0.276, 0.0], [0.525, 0.4535, 0.0], [0.6925, 0.276, 0.0]],    # gate_insertion_objects.py:17-24
+        target_min_dist=0.01,                                                              # gate_insertion.py:276
+    )
+    return to_blob(m, "inserting", tc)
+
+
 def load_stl_vertices(path):
     """Unique vertices of a binary STL file (models/mj/robot/assets/*.stl)."""
     import struct
@@ -618,6 +661,10 @@ def main():
     with open(os.path.join(out_dir, "aligning.json"), "w") as f:
         json.dump(blob, f, indent=1)
     print("aligning: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
+    blob = build_inserting()
+    with open(os.path.join(out_dir, "inserting.json"), "w") as f:
+        json.dump(blob, f, indent=1)
+    print("inserting: %d bodies, %d geoms, %d actuators" % (len(blob["bodies"]), len(blob["geoms"]), len(blob["actuators"])))
     blob = build_stacking()
     with open(os.path.join(out_dir, "stacking.json"), "w") as f:
         json.dump(blob, f, indent=1)

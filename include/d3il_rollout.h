@@ -36,7 +36,7 @@ enum {
   D3IL_ESTATE = -6, D3IL_ERCCL = -7
 };
 
-/* Tasks (task_id of d3il_create; the enum itself is D3IL_TASK_* in d3il_model_blob.h: 0 Avoiding, 1 Pushing, 2 Sorting, 3 Stacking, 4 Aligning) and
+/* Tasks (task_id of d3il_create; the enum itself is D3IL_TASK_* in d3il_model_blob.h: 0 Avoiding, 1 Pushing, 2 Sorting, 3 Stacking, 4 Aligning, 5 Inserting) and
  * their shapes:
  *   task      reference env (environments/d3il/envs/...)            action (device f64, row-major)              obs f32   contexts f64     state rows
  *   Avoiding  gym_avoiding/envs/avoiding.py ObstacleAvoidanceEnv    [n][7] desired TCP x y z qw qx qy qz        [n][2]    none             42
@@ -45,6 +45,7 @@ enum {
  *   Stacking  gym_stacking/envs/stacking.py CubeStacking_Env        [n][8] 7 desired joint positions + gripper   [n][12]   [n][21]          94
  *                                                                   command (open iff > 0.075, stacking.py:337-346)
  *   Aligning  gym_aligning/envs/aligning.py Robot_Push_Env          [n][7] as Avoiding (the harness commands z)  [n][17]   [n][14]          77
+ *   Inserting gym_inserting/envs/gate_insertion.py Gate_Insertion_Env [n][7] as Avoiding                          [n][11]   [n][21]          110
  */
 
 /* f64 state fields per environment, in SoA order */
@@ -73,7 +74,12 @@ enum {
    * the solver's warm start qacc[15] (box 6 - in centre-of-mass coordinates -, arm 9), the target pose pos[3] quat[4] of the context
    * (aligning.py:107-122; it only enters observation, reward and success).  Flag word: the Pushing bits (mode + 1 in D3IL_PFLAG_MODE_MASK: 0 / 1 =
    * rod inside / outside the walls, aligning.py:288-312; WARM_VALID, OFF_TABLE, CON_OVERFLOW) and D3IL_SFLAG_HAND_NEAR. */
-  D3IL_ALIGN_STATE_BOX = 42, D3IL_ALIGN_STATE_WARM = 55, D3IL_ALIGN_STATE_TARGET = 70, D3IL_ALIGN_STATE_F64 = 77
+  D3IL_ALIGN_STATE_BOX = 42, D3IL_ALIGN_STATE_WARM = 55, D3IL_ALIGN_STATE_TARGET = 70, D3IL_ALIGN_STATE_F64 = 77,
+  /* Inserting (gate_insertion.py; the Sorting layout with three cubes push_box1..3 = red, green, blue): cubes 13 each, warm start qacc[27], then the task
+   * state of Gate_Insertion_Env: word 0 = number of letters in `modes` | letter k (1 r, 2 g, 3 b) << (2 + 2 k) (gate_insertion.py:411-432); word 1 =
+   * info['mean_distance'] of the last step, a double (:434-446).  mode buffer: info['mode'] (mode_dict code once all three letters are in, else 0,
+   * :386-409) | number of letters << 3 (one / two / three_box_success = that number >= 1 / 2 / 3).  Contexts: 3 x (x, y, z = 0, quat) (:94-113). */
+  D3IL_INS_STATE_BOX = 42, D3IL_INS_STATE_WARM = 81, D3IL_INS_STATE_TASK = 108, D3IL_INS_STATE_F64 = 110
 };
 /* bits of the per-environment u32 flag word */
 enum {

@@ -304,6 +304,25 @@ class Oracle:
         state_col = np.ascontiguousarray(state_col, float)
         self.L.orc_sort_set_state(self.h, _p(state_col), C.c_uint(int(flags) & 0xFFFFFFFF), int(step))
 
+    # ---- env level (Inserting)
+    def ins_reset(self, ctx):
+        ctx = np.ascontiguousarray(ctx, float).reshape(21)
+        obs = np.zeros(11, dtype=np.float32)
+        self.L.orc_insenv_reset(self.h, _p(ctx), _p(obs))
+        return obs
+
+    def ins_step(self, action):
+        action = np.ascontiguousarray(action, float)
+        obs = np.zeros(11, dtype=np.float32)
+        done, code, nm, succ, md = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_double(0)
+        self.L.orc_insenv_step(self.h, _p(action), _p(obs), C.byref(done), C.byref(code), C.byref(nm), C.byref(succ), C.byref(md))
+        return obs, bool(done.value), dict(mode=code.value, n_mode=nm.value, success=bool(succ.value), mean_distance=md.value)
+
+    def ins_set_state(self, state_col, flags, step):
+        """Load one environment's column of the HIP path's Inserting state buffer (+ flags word, step counter)."""
+        state_col = np.ascontiguousarray(state_col, float)
+        self.L.orc_ins_set_state(self.h, _p(state_col), C.c_uint(int(flags) & 0xFFFFFFFF), int(step))
+
     # ---- env level (Stacking)
     def stack_reset(self, ctx):
         """ctx: 3 x (x, y, z = 0, quat) red, green, blue (BlockContextManager.set_context, stacking.py:99-125)."""
@@ -367,6 +386,27 @@ class SortLogic:
         succ, code = C.c_int(0), C.c_int(0)
         self.L.orc_sort_logic(self.st, _p(box42), _p(tcp), self.num_boxes, _p(obs), C.byref(succ), C.byref(code))
         return obs, bool(succ.value), code.value
+
+
+class InsertLogic:
+    """Inserting task logic with injected poses (oracle/d3il_oracle.c orc_ins_logic)."""
+
+    def __init__(self, targets, min_dist):
+        self.L = lib()
+        self.st = (C.c_int * 2)()
+        self.targets = np.ascontiguousarray(targets, float).reshape(9)
+        self.min_dist = float(min_dist)
+        self.reset()
+
+    def reset(self):
+        self.L.orc_ins_reset(self.st)
+
+    def step(self, box21, tcp):
+        box21, tcp = np.ascontiguousarray(box21, float).reshape(21), np.ascontiguousarray(tcp, float)
+        obs = np.zeros(11, dtype=np.float32)
+        succ, nm, code, md = C.c_int(0), C.c_int(0), C.c_int(0), C.c_double(0)
+        self.L.orc_ins_logic(self.st, _p(box21), _p(self.targets), C.c_double(self.min_dist), _p(tcp), _p(obs), C.byref(succ), C.byref(md), C.byref(nm), C.byref(code))
+        return obs, bool(succ.value), md.value, nm.value, code.value
 
 
 class StackLogic:

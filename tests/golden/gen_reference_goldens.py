@@ -577,6 +577,61 @@ def gen_aligning_task():
         logged["Metrics/successes"], logged["Metrics/entropy"], np.unique(mode), succ.sum(), len(ctx_arr)))
 
 
+def gen_inserting_task():
+    """Gate_Insertion_Env task logic (gate_insertion.py:278-309 get_observation, :386-409 step's info, :411-446 check_mode / check_mean_dist,
+    :475-498 _check_early_termination), driven with synthetic box poses through a fake scene.  The reference has no Sim class for this task."""
+    from envs.gym_inserting_env.gym_inserting.envs.gate_insertion import Gate_Insertion_Env
+
+    rng = np.random.default_rng(33)
+    env = object.__new__(Gate_Insertion_Env)
+    env.push_box1, env.push_box2, env.push_box3 = "b1", "b2", "b3"
+    env.target_box1, env.target_box2, env.target_box3 = "t1", "t2", "t3"
+    env.target_min_dist = 0.01
+    env.mode_dict = {'rgb': 1, 'rbg': 2, 'grb': 3, 'gbr': 4, 'brg': 5, 'bgr': 6}
+    tg = [np.array([0.3575, 0.276, 0.0]), np.array([0.525, 0.4535, 0.0]), np.array([0.6925, 0.276, 0.0])]
+    poses = {"t%d" % (i + 1): (tg[i].copy(), np.array([0.0, 1, 0, 0])) for i in range(3)}
+    scene = type("S", (), {})()
+    scene.get_obj_pos = lambda o: poses[o][0].copy()
+    scene.get_obj_quat = lambda o: poses[o][1].copy()
+    env.scene = scene
+    tcp = np.zeros(3)
+    env.robot_state = lambda: tcp.copy()
+    E, T = 48, 72
+    box = np.zeros((E, T, 3, 7)); rob = np.zeros((E, T, 3)); obs = np.zeros((E, T, 11), dtype=np.float32)
+    succ = np.zeros((E, T), dtype=bool); meand = np.zeros((E, T)); nmode = np.zeros((E, T), dtype=np.int64); code = np.zeros((E, T), dtype=np.int64)
+    rew = np.zeros((E, T))
+    for e in range(E):
+        env.modes = []; env.terminated = False
+        p = [np.array([rng.uniform(0.35, 0.5), rng.uniform(-0.2, -0.15), -0.0072]), np.array([rng.uniform(0.55, 0.7), rng.uniform(-0.1, -0.05), -0.0072]),
+             np.array([rng.uniform(0.35, 0.5), rng.uniform(0.0, 0.05), -0.0072])]
+        yaw = [rng.uniform(-np.pi / 2, np.pi / 2) for _ in range(3)]
+        order = list(rng.permutation(3))
+        stop_short = e % 6 == 5                                  # the last box never arrives
+        for t in range(T):
+            k = order[min(2, 3 * t // T)]
+            goal = tg[k] + np.array([0, 0, -0.0072 if e % 4 else 0.004])       # the z offset enters the 3-D distance (obj_distance on full positions)
+            if stop_short and k == order[2]:
+                goal = goal + np.array([0.03, 0, 0])
+            p[k] = p[k] + 0.2 * (goal - p[k]) + rng.normal(scale=0.0006, size=3) * (e % 3 != 1)
+            if e % 7 == 6 and t % 24 == 23:                      # a box is knocked out of its goal again: the mode list keeps it (sticky)
+                p[k] += np.array([0.05, 0, 0])
+            for j in range(3):
+                yaw[j] += rng.normal(scale=0.03)
+                q = np.array([np.cos(yaw[j] / 2), 0.003 * (e % 2), 0, np.sin(yaw[j] / 2)])
+                poses["b%d" % (j + 1)] = (p[j].copy(), q)
+                box[e, t, j, :3], box[e, t, j, 3:] = p[j], q
+            tcp[:] = rng.uniform([0.3, -0.4, 0.1], [0.8, 0.5, 0.14]); rob[e, t] = tcp
+            obs[e, t] = env.get_observation()
+            succ[e, t] = env._check_early_termination()
+            meand[e, t] = env.check_mean_dist()
+            mode = ''.join(env.check_mode())
+            nmode[e, t] = len(mode)
+            code[e, t] = env.mode_dict[mode] if len(mode) == 3 else 0
+            rew[e, t] = env.get_reward()
+    np.savez_compressed(os.path.join(HERE, "ref_inserting_task.npz"), box=box, rob=rob, obs=obs, succ=succ, mean_distance=meand, n_mode=nmode, code=code, reward=rew)
+    print("inserting task: successes %d, full mode codes %s, mode lengths %s" % (succ.sum(), np.unique(code), np.unique(nmode)))
+
+
 if __name__ == "__main__":
     gen_ik()
     gen_pd_finger()
@@ -586,3 +641,4 @@ if __name__ == "__main__":
     gen_sorting_stacking_metrics()
     gen_sort_stack_task()
     gen_aligning_task()
+    gen_inserting_task()

@@ -10,6 +10,8 @@ L = capi.load()
 env.start(); env.reset(); env.policy_begin()
 a = torch.zeros(n, 7, dtype=torch.float64, device=env.device)
 W = np.zeros((64, 10), dtype=np.uint64)
+G = (C.c_uint64 * 32)()
+L.d3il_debug_stats(G, 1)
 names = ["jacobi", "deflate", "general", "newton_it", "finger", "contact", "ls_it", "serve_busy", "ik_busy", "ticks"]   # slot 7: busy ticks of the serving wave (three-wave kernel)
 for t in range(260):
     env.policy_action(42, 0, t, a)
@@ -24,3 +26,5 @@ for t in range(260):
               "| physics min/med/max", np.min(W[:, 9]), int(np.median(W[:, 9])), np.max(W[:, 9]))
         for w in list(order[:2]) + list(order[30:32]) + list(order[-4:]):
             print("   wg %2d ik %7d phys %7d " % (w, W[w, 8], W[w, 9]) + " ".join("%s %d" % (names[i], W[w, i]) for i in (0, 1, 2, 3, 5, 6, 7)))
+L.d3il_debug_stats(G, 0)
+print("whole run (lane events): deflate solves %d, of which from a warm vector %d, Rayleigh-quotient steps %d (%.2f per deflate solve)" % (G[2], G[25], G[24], G[24] / max(1, G[2])))
