@@ -645,6 +645,7 @@ static_assert(D3IL_SFLAG_WARM_VALID == SKF_WARM_VALID && D3IL_SFLAG_HAND_NEAR ==
               "d3il_rollout.h: Stacking flag bits");
 static_assert(D3IL_SFLAG_MODE_MASK == (SKF_NMODE_MASK | (0x3Fu << SKF_IND_SHIFT)), "d3il_rollout.h: Stacking order code");
 static_assert(D3IL_ALIGN_STATE_BOX == AL_STATE_BOX && D3IL_ALIGN_STATE_WARM == AL_STATE_WARM && D3IL_ALIGN_STATE_TARGET == AL_STATE_TARGET && D3IL_ALIGN_STATE_F64 == AL_STATE_F64, "d3il_rollout.h: Aligning state layout");
+static_assert(D3IL_INS_STATE_BOX == 42 && D3IL_INS_STATE_WARM == 42 + 13 * 3 && D3IL_INS_STATE_TASK == 42 + 13 * 3 + 6 * 3 + NDOF && D3IL_INS_STATE_F64 == gen_state_rows(3), "d3il_rollout.h: Inserting state layout");
 static_assert(D3IL_PUSH_STATE_F64 == PUSH_STATE_F64 && D3IL_TALLY_ALL + 256 <= D3IL_TALLY_ROW - 2, "d3il_rollout.h: Pushing state rows / tally row");
 
 static inline bool gen_task(int task_id) { return task_id == D3IL_TASK_SORTING || task_id == D3IL_TASK_INSERTING; }   // the tasks of the generic engine (gen_step.h)
