@@ -41,16 +41,18 @@ PROFILE_DIRS = ("r04", "r03", "r02", "r01")  # committed rocprofv3 --pmc summari
 # column moves per env step (it also carries the flag / counter words, f64 actions, the stale-TCP / bias rows and - contact tasks - the
 # solver's warm start); reported next to it as `implementation_bytes_per_launch`, not used for `frac`.
 ALG_BYTES = {"avoiding": 704, "pushing": 1152, "sorting": 1620, "stacking": 1228,
-             "aligning": 2 * (8 * (16 + 15) + 168 + 56 + 8) + 28 + 68 + 12}      # SURVEY 8(d)'s formula for the 16 / 15 model of the Aligning task (S_task: the 7-double target + flags): 1068
+             "aligning": 2 * (8 * (16 + 15) + 168 + 56 + 8) + 28 + 68 + 12,      # SURVEY 8(d)'s formula for the 16 / 15 model of the Aligning task (S_task: the 7-double target + flags): 1068
+             "inserting": 2 * (8 * (30 + 27) + 168 + 16) + 28 + 44 + 8}          # the same formula for the 30 / 27 model of the Inserting task (three cubes; obs 11 f32): 1360
 IMPL_BYTES = {
     "avoiding": 2 * (42 * 8 + 4 + 4) + 56 + 8 + 4,
     "pushing": 2 * (89 * 8 + 4 + 4) + 56 + 32 + 4 + 16,
     "sorting": 2 * (129 * 8 + 4 + 4) + 56 + 56 + 4,
     "stacking": 2 * (94 * 8 + 4 + 4) + 64 + 48 + 4 + 8,
     "aligning": 2 * (77 * 8 + 4 + 4) + 56 + 68 + 4 + 16,
+    "inserting": 2 * (110 * 8 + 4 + 4) + 56 + 44 + 4,
 }
-KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step", "aligning": "k_aligning_step"}
-PMC_FILE = {"aligning": "pmc_summary_aligning.json", "avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json"}
+KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step", "aligning": "k_aligning_step", "inserting": "k_sorting_step<true>"}
+PMC_FILE = {"aligning": "pmc_summary_aligning.json", "avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json", "inserting": "pmc_summary_inserting.json"}
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline (oracle)
@@ -113,22 +115,27 @@ def _cpu_worker(task, blob_bytes, init_qpos, contexts, budget_s, seed):
             ep += 1
         return n, time.perf_counter() - t0
     from d3il_amd.agents import RandomResidualMLPPolicy
-    pol = RandomResidualMLPPolicy(input_dim=10 if task == "pushing" else 16, device="cpu")
+    pol = RandomResidualMLPPolicy(input_dim={"pushing": 10, "inserting": 13}.get(task, 16), device="cpu")
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         if task == "pushing":
             obs = o.push_reset(contexts[ep % len(contexts)])
             s, _ = o.push_state()
             des, z = s[25:27].copy(), s[27]
+        elif task == "inserting":
+            obs = o.ins_reset(contexts[ep % len(contexts)])
+            des, z = obs[:2].astype(np.float64), float(o.body(blob.tcp_body)[0][2])
         else:
             obs = o.sort_reset(contexts[ep % len(contexts)].reshape(-1, 7))
             des, z = obs[:2].astype(np.float64), float(o.body(blob.tcp_body)[0][2])
-        for t in range(400 if task == "pushing" else 500):
+        for t in range({"pushing": 400, "inserting": 2000}.get(task, 500)):
             x = torch.as_tensor(np.concatenate([des, obs.astype(np.float64)])[None], dtype=torch.float64)
             des = des + pol.predict_batch(x)[0].numpy().astype(np.float64)
             a = np.array([des[0], des[1], z, 0, 1, 0, 0])
             if task == "pushing":
                 obs, _, done, _ = o.push_step(a)
+            elif task == "inserting":
+                obs, done, _ = o.ins_step(a)
             else:
                 obs, done, _ = o.sort_step(a)
             n += 1
@@ -361,6 +368,10 @@ def run(args):
         from d3il_amd.envs.aligning import RobotPushVecEnv, load_test_contexts as load_align_contexts
         env = RobotPushVecEnv(n, device=dev)
         ctx60 = load_align_contexts()
+    elif task == "inserting":
+        from d3il_amd.envs.inserting import GateInsertionVecEnv, sample_contexts as sample_insert_contexts
+        env = GateInsertionVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 2000)     # gate_insertion.py:158 (the reference has no config for this task)
+        ctx60 = sample_insert_contexts(60, seed=0)
     else:
         from d3il_amd.envs.stacking import CubeStackingVecEnv, load_test_contexts as load_stack_contexts
         env = CubeStackingVecEnv(n, device=dev)
@@ -513,7 +524,7 @@ def run(args):
         torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
     dt = float(t_max.item())
     st, fl, sc = env.get_state()
-    n_state = env.state_rows - (2 if task == "sorting" else 0)
+    n_state = env.state_rows - (2 if task in ("sorting", "inserting") else 0)
     n_sub = env.n_substeps
     finite = bool(np.isfinite(st[:n_state]).all())      # (the Aligning mean distance / reward may be NaN like the reference's: they are info rows, not state)
     flagged = {"solver_fail": int(((fl >> 16) & 1).sum())}
@@ -551,6 +562,9 @@ def run(args):
                        "400-step episodes with auto-reset" % (n, POLICY_TEXT[policy] % 10 if policy in ("mlp", "ddpm") else POLICY_TEXT[policy]),
             "sorting": "Sorting-4 task, %d envs per GPU, 60 contexts sampled like BlockContextManager.sample tiled, %s, 35 fused physics sub-steps per "
                        "env step, %d-step episodes with auto-reset" % (n, POLICY_TEXT[policy] % 16 if policy in ("mlp", "ddpm") else POLICY_TEXT[policy], max_steps),
+            "inserting": "Inserting task (Gate_Insertion_Env; the reference defines no evaluation configuration for it), %d envs per GPU, 60 contexts sampled like "
+                         "BlockContextManager.sample tiled, %s, 35 fused physics sub-steps per env step, %d-step episodes with auto-reset"
+                         % (n, POLICY_TEXT[policy] % 13 if policy in ("mlp", "ddpm") else POLICY_TEXT[policy], max_steps),
             "aligning": "Aligning task, %d envs per GPU, the 60 reference test contexts tiled, %s, 35 fused physics sub-steps per env step, 400-step episodes with "
                         "auto-reset" % (n, POLICY_TEXT["scripted_align"] if policy == "scripted_align" else "ResidualMLP 20->128x6->3 (Mish) stand-in policy with fixed random weights (torch, f32)"),
             "stacking": "Stacking task, %d envs per GPU, the first %d of the reference's 100 test contexts tiled, %s, 30 fused physics sub-steps per env step, "
@@ -591,7 +605,7 @@ def run(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting", "stacking", "aligning"], help="avoiding = the headline configuration (BASELINE configs[1])")
+    ap.add_argument("--task", default="avoiding", choices=["avoiding", "pushing", "sorting", "stacking", "aligning", "inserting"], help="avoiding = the headline configuration (BASELINE configs[1])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)

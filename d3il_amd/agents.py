@@ -148,16 +148,21 @@ class RandomResidualMLPPolicy(torch.nn.Module):
 class ScriptedPushPolicy:
     """Scripted contact-regime policy for the measurement harness (bench.py --policy scripted_push, tools/): every rod walks
     behind a cube and pushes it - Pushing: the red cube to the red target, then the green cube to the green target (two-phase
-    script); Sorting: the first cube still on the platform over the platform edge into the bins.  Input / output like the
+    script); Sorting: the first cube still on the platform over the platform edge into the bins; Inserting: the red, green and blue cube one after the
+    other to the mouth of its gate and then into it (six-phase script; the walls are not planned around: cube and rod run into them, which is the
+    contact regime the measurement wants).  Input / output like the
     rollout loops of the sims: ``predict_batch([des_xy, obs]) -> delta_xy`` with |delta| <= 6 mm (the env's action box is +-1 cm).
     Per-lane phase state is re-latched by ``begin_episodes(mask)`` when a lane starts its next trajectory."""
 
     STEP = 0.006
 
     def __init__(self, task: str, device="cuda"):
-        assert task in ("pushing", "sorting")
+        assert task in ("pushing", "sorting", "inserting")
         self.task, self.device = task, torch.device(device)
         self.goals = torch.tensor([[0.42, 0.3], [0.63, 0.3]], dtype=torch.float64, device=self.device)   # pushing_objects.py:11-15 (x, y of the two targets)
+        if task == "inserting":      # per cube: the mouth of its gate, then its target (gate_insertion_objects.py:17-24; the gates open towards +x, -y, -x)
+            self.goals = torch.tensor([[0.45, 0.276], [0.3575, 0.276], [0.525, 0.33], [0.525, 0.4535], [0.60, 0.276], [0.6925, 0.276], [0.6925, 0.276]],
+                                      dtype=torch.float64, device=self.device)
         self.phase = None
 
     def reset(self):
@@ -181,6 +186,15 @@ class ScriptedPushPolicy:
             dist = togo.norm(dim=1, keepdim=True)
             self.phase = torch.where((dist.squeeze(1) < 0.03) & (self.phase == 0), torch.ones_like(self.phase), self.phase)
             dirn = togo / dist.clamp_min(1e-9)
+        elif self.task == "inserting":
+            cube = torch.clamp(self.phase // 2, max=2)
+            box = obs[:, 2:].reshape(n, 3, 3)[torch.arange(n, device=o.device), cube, :2]
+            togo = self.goals[self.phase] - box
+            dist = togo.norm(dim=1, keepdim=True)
+            reached = dist.squeeze(1) < torch.where(self.phase % 2 == 0, 0.012, 0.006)
+            self.phase = torch.where(reached & (self.phase < 6), self.phase + 1, self.phase)
+            dirn = togo / dist.clamp_min(1e-9)
+            dist = (self.phase < 6).to(torch.float64).unsqueeze(1)       # all three in: hold
         else:
             nb = (obs.shape[1] - 2) // 3
             xy = obs[:, 2:].reshape(n, nb, 3)[:, :, :2]
@@ -207,8 +221,8 @@ class ScriptedPushPolicy:
         tang = torch.stack((-away[:, 1], away[:, 0]), dim=1)
         tang = tang * torch.sign((tang * (behind - des)).sum(1, keepdim=True) + 1e-12)
         step = torch.where(near, self.STEP * (0.6 * tang + 0.4 * away), step)
-        if self.task == "sorting":
-            step = step * dist                                        # nothing left on the platform: hold
+        if self.task in ("sorting", "inserting"):
+            step = step * dist                                        # nothing left on the platform / all cubes in their gates: hold
         return step
 
 

@@ -1276,7 +1276,7 @@ D3IL_RARE void make_rod_contact(const C& c, const double* sn, const double* cs, 
 // in the physics wave's main block with the solvers inlined, none without them).
 struct RareInline { static constexpr bool remote = false; };
 constexpr int RX_M = 0, RX_FS = 45, RX_Q = 54, RX_V = 63, RX_SN = 72, RX_MD = 86, RX_BO = 87, RX_BD = 88, RX_BN = 89, RX_BP = 92, RX_FL = 95 /* fsign[2] fD[2] faref[2] */,
-              RX_ARM = 101, RX_ROWS = 102, RX_FC = 0 /* reply: fc[9], fail */;
+              RX_ARM = 101, RX_L = 102 /* LDL^T factors of M: L[45], 1 / d[9] */, RX_ID = 147, RX_ROWS = 156, RX_FC = 0 /* reply: fc[9], fail */;
 
 // The two rare constraint paths of physics_substep: a rod contact (+ the finger-limit rows) through the 5-dimensional constraint-space
 // Newton, or - with an arm joint inside a limit margin - all limit rows + the rod contact through the 9-dof primal Newton solver.
@@ -1327,12 +1327,14 @@ D3IL_HD bool rare_constraints(const C& c0, const double* M, const double* L, con
   return ok;
 }
 
-// The serving side of a remote rare path (one lane = one environment of the requesting wave, same lane index): operands from the exchange
-// area, M factorised again by the same ldl9, the reply (qfrc_constraint[9], failure flag) into rows RX_FC...
+// The serving side of a remote rare path (one lane = one environment of the requesting wave, same lane index): operands (incl. the LDL^T
+// factors of M the physics wave already has) from the exchange area, the reply (qfrc_constraint[9], failure flag) into rows RX_FC...
 template <class C, class R> D3IL_HD void rare_serve(const C& c0, R* rare, double* warm) {
-  double M[45], L[45], d[NDOF], id[NDOF], fs[NDOF], q[NDOF], v[NDOF], sn[NARM], cs[NARM], bn[3], bp[3], fsign[NFING], fD[NFING], faref[NFING], fc[NDOF];
+  double M[45], L[45], id[NDOF], fs[NDOF], q[NDOF], v[NDOF], sn[NARM], cs[NARM], bn[3], bp[3], fsign[NFING], fD[NFING], faref[NFING], fc[NDOF];
 #pragma unroll
-  for (int i = 0; i < 45; i++) M[i] = rare->get(RX_M + i);
+  for (int i = 0; i < 45; i++) { M[i] = rare->get(RX_M + i); L[i] = rare->get(RX_L + i); }
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) id[k] = rare->get(RX_ID + k);
 #pragma unroll
   for (int k = 0; k < NDOF; k++) { fs[k] = rare->get(RX_FS + k); q[k] = rare->get(RX_Q + k); v[k] = rare->get(RX_V + k); fc[k] = 0; }
 #pragma unroll
@@ -1344,8 +1346,7 @@ template <class C, class R> D3IL_HD void rare_serve(const C& c0, R* rare, double
 #pragma unroll
   for (int k = 0; k < NFING; k++) { fsign[k] = rare->get(RX_FL + k); fD[k] = rare->get(RX_FL + 2 + k); faref[k] = rare->get(RX_FL + 4 + k); }
   const bool arm_rows = rare->get(RX_ARM) != 0.0;
-  bool ok = ldl9(M, L, d, id);
-  ok = rare_constraints(c0, M, L, id, fs, q, v, sn, cs, bo, bd, bn, bp, fsign, fD, faref, arm_rows, fc, warm) && ok;
+  const bool ok = rare_constraints(c0, M, L, id, fs, q, v, sn, cs, bo, bd, bn, bp, fsign, fD, faref, arm_rows, fc, warm);      // a failed factorisation is flagged by the physics wave
 #pragma unroll
   for (int k = 0; k < NDOF; k++) rare->put(RX_FC + k, fc[k]);
   rare->put(RX_FC + NDOF, ok ? 0.0 : 1.0);
@@ -1438,6 +1439,10 @@ template <class C, class R = RareInline> D3IL_HD void physics_substep(const C& c
 #pragma unroll
       for (int k = 0; k < NFING; k++) { rare->put(RX_FL + k, fsign[k]); rare->put(RX_FL + 2 + k, fD[k]); rare->put(RX_FL + 4 + k, faref[k]); }
       rare->put(RX_ARM, arm_rows ? 1.0 : 0.0);
+#pragma unroll
+      for (int i = 0; i < 45; i++) rare->put(RX_L + i, L[i]);
+#pragma unroll
+      for (int k = 0; k < NDOF; k++) rare->put(RX_ID + k, id[k]);
     }
     if (rare->post(delegated) && delegated) {
 #pragma unroll

@@ -24,6 +24,7 @@ TASK_FUNCS = {
     "sorting": ("k_sorting_step", ["gen_", "jacobi_solve6", "solve_constraints"]),
     "stacking": ("k_stacking_step", ["sk_coop_build"]),
     "aligning": ("k_aligning_step", ["sk_coop_build", "jacobi_solve6"]),
+    "inserting": ("k_sorting_step", ["gen_", "jacobi_solve6", "solve_constraints"]),      # the Sorting kernels run the Inserting model
 }
 FMA = re.compile(r"^v_(fma|fmac|mad)_f64")
 F64 = re.compile(r"^v_\w+_f64")

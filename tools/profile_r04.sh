@@ -11,6 +11,7 @@ for T in $TASKS; do
   X=""; K=k_${T}_step
   if [ $T = stacking ]; then X="--steps 100 --warmup 5"; fi
   if [ $T = aligning ]; then X="--steps 200 --warmup 5"; fi
+  if [ $T = inserting ]; then X="--steps 100 --warmup 5 --preroll 300"; K=k_sorting_step; fi      # the Sorting kernels with the Inserting model; 2000-step episodes: a 300-step pre-roll
   N=$K; if [ $T = avoiding ]; then N=k_avoiding_step_split; fi; if [ $T = pushing ]; then N=k_pushing_step_split; fi
   F=pmc_summary_$T.json; if [ $T = avoiding ]; then F=pmc_summary_bench300.json; fi
   B=""; if [ $T = stacking ] || [ $T = aligning ]; then B="--bimodal"; fi
@@ -28,6 +29,7 @@ for T in $TASKS; do
   if [ $T = sorting ]; then python bench.py --task sorting --policy ddpm 2>/dev/null | tail -1 > $O/bench_line_sorting_ddpm.json; fi
   if [ $T = stacking ]; then python bench.py --task stacking --policy beso --steps 40 --warmup 5 --preroll 200 2>/dev/null | tail -1 > $O/bench_line_stacking_beso.json; fi
   if [ $T = aligning ]; then python bench.py --task aligning --policy mlp --steps 200 --warmup 5 2>/dev/null | tail -1 > $O/bench_line_aligning_mlp.json; fi
+  if [ $T = inserting ]; then python bench.py --task inserting --policy scripted_push --steps 100 --warmup 5 --preroll 300 2>/dev/null | tail -1 > $O/bench_line_inserting_scripted_push.json; fi
 done
 ls -la $O
 python - <<'PY'
