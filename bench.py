@@ -51,7 +51,7 @@ IMPL_BYTES = {
     "aligning": 2 * (77 * 8 + 4 + 4) + 56 + 68 + 4 + 16,
     "inserting": 2 * (110 * 8 + 4 + 4) + 56 + 44 + 4,
 }
-KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true>", "stacking": "k_stacking_step", "aligning": "k_aligning_step", "inserting": "k_sorting_step<true>"}
+KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true, false>", "stacking": "k_stacking_step", "aligning": "k_aligning_step", "inserting": "k_sorting_step<true, true>"}
 PMC_FILE = {"aligning": "pmc_summary_aligning.json", "avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json", "inserting": "pmc_summary_inserting.json"}
 
 

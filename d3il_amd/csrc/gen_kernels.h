@@ -42,8 +42,8 @@ __device__ __forceinline__ void gen_store_arm(double* __restrict__ state, unsign
   flags[e] = st.flags; steps[e] = st.step;
 }
 
-// env.step() for the Sorting task
-template <bool FAST>
+// env.step() for the Sorting task (RS = false) and the Inserting task (RS = true: the engine with contacts of the arm block, gen_step.h)
+template <bool FAST, bool RS>
 __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ state, unsigned* __restrict__ flags,
                                                            int* __restrict__ steps, const double* __restrict__ actions, float* __restrict__ obs,
                                                            unsigned char* __restrict__ done, unsigned char* __restrict__ success, unsigned short* __restrict__ mode,
@@ -126,15 +126,15 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
       gen_sync();
       PUSH_TOC(1);
       if (plive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl);
-      if (plive && gc.rod_static) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, lfl);
+      if (RS && plive) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, lfl);
       gen_sync();
-      if (arm_lane) gen_phase3b(c, gc, st, sc, gc.nb, lfl);
+      if (arm_lane) gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl);
       gen_sync();
       PUSH_TOC(2);
-      if (plive) gen_phase4_single(gc, sc, l, warm_valid, lfl);
+      if (plive) gen_phase4_single<RS>(gc, sc, l, warm_valid, lfl);
       gen_sync();
       PUSH_TOC(8);
-      if (plive) gen_phase4_multi(gc, sc, l, gc.nb, warm_valid, lfl);
+      if (plive) gen_phase4_multi<RS>(gc, sc, l, gc.nb, warm_valid, lfl);
       gen_sync();
       PUSH_TOC(9);
       if (arm_lane) gen_phase5_arm(c, gc, st, sc);

@@ -129,11 +129,14 @@ D3IL_HD int isl_rank(const Isl isl, int b) {   // position of block b in the isl
 // Block 1: the first cube (6 dofs, global offset o1, compact c1); block 2: the second cube or the arm (n2 = 0, 6 or 7 dofs)
 struct GRow { int o1, o2, n1, n2, c1, c2; double v1[6], v2[7]; };      // n1 = 0: no first block (rod <-> static box)
 // rec: the first 16 fields of the contact's record (pos[3] frame[9] dist kind a b), fetched by the caller in one batch
+// RS (here and below): the build of the engine that knows contacts of the arm block (rod <-> static boxes, Inserting); with RS = false the code is the
+// Sorting engine as it was - no empty-first-block guards in the row loops, no arm contact count anywhere
+template <bool RS>
 D3IL_HD void gen_rows(const GenConsts& gc_, const PushScratch sc, const Isl isl, const double* rec, GRow* rows) {
   D3IL_GEN_CONSTS(gc_, gc);
   const int arm0 = 6 * gc.nb;
   const int kind = (int)rec[13], a = (int)rec[14], b = (int)rec[15];
-  if (kind == GK_RODST) {          // static box (geom 1, fixed) -> rod (geom 2): the row is + J(arm)
+  if (RS && kind == GK_RODST) {          // static box (geom 1, fixed) -> rod (geom 2): the row is + J(arm)
 #pragma unroll
     for (int rr = 0; rr < 3; rr++) {
       GRow& s = rows[rr];
@@ -188,18 +191,20 @@ D3IL_HD void gen_rows(const GenConsts& gc_, const PushScratch sc, const Isl isl,
   }
 }
 // row . vector of the t area: globally indexed (x, velocities) or the island's compact vector at vec
+template <bool RS>
 D3IL_HD double grow_dot_g(const PushScratch sc, const GRow& s, int vec) {
   double acc = 0;
 #pragma unroll
-  for (int k = 0; k < 6; k++) if (k < s.n1) acc += s.v1[k] * GLS(vec + s.o1 + k);
+  for (int k = 0; k < 6; k++) if (!RS || k < s.n1) acc += s.v1[k] * GLS(vec + s.o1 + k);
 #pragma unroll
   for (int k = 0; k < 7; k++) if (k < s.n2) acc += s.v2[k] * GLS(vec + s.o2 + k);
   return acc;
 }
+template <bool RS>
 D3IL_HD double grow_dot_c(const PushScratch sc, const GRow& s, int vec) {
   double acc = 0;
 #pragma unroll
-  for (int k = 0; k < 6; k++) if (k < s.n1) acc += s.v1[k] * GLS(vec + s.c1 + k);
+  for (int k = 0; k < 6; k++) if (!RS || k < s.n1) acc += s.v1[k] * GLS(vec + s.c1 + k);
 #pragma unroll
   for (int k = 0; k < 7; k++) if (k < s.n2) acc += s.v2[k] * GLS(vec + s.c2 + k);
   return acc;
@@ -337,6 +342,7 @@ D3IL_HD void gen_chol_solve(const PushScratch sc, int hb, int m, int vec) {
 // counts of the island's blocks, 5 bits each in list order.  Work is dealt out by contact (lane l takes contacts l, l + nl, ..
 // of the island's concatenated segments) and by block row (Cholesky); everything else is computed by every lane from the same
 // LDS data, so all lanes take the same decisions.  Returns false when it did not converge.
+template <bool RS>
 D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, const Isl isl, unsigned cpk, int l, int nl) {
   D3IL_GEN_CONSTS(gc_, gc);
   const int arm0 = 6 * gc.nb, ca = isl.m - NDOF;       // global / compact offset of the arm block (when isl.arm)
@@ -349,7 +355,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     bool found = false;
     for (int k = 0; k < isl.n; k++) {
       const int n = (int)((cpk >> (5 * k)) & 31u);
-      if (!found && t < n) { const int blk = ISL_BLK(k); ci = (blk < gc.nb ? blk : GEN_ARMSEG) * GEN_SEG + t; found = true; }      // the arm block's contacts: rod <-> static boxes
+      if (!found && t < n) { const int blk = ISL_BLK(k); ci = (!RS || blk < gc.nb ? blk : GEN_ARMSEG) * GEN_SEG + t; found = true; }      // the arm block's contacts: rod <-> static boxes
       t -= n;
     }
     return ci;
@@ -363,13 +369,13 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     double rec[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
-    const int kind = (int)rec[13], set = kind == GK_STATIC ? (int)rec[14] : (kind == GK_BOXBOX ? gc.set_bb : (kind == GK_ROD ? gc.set_rod : gc.ns + 2 + (int)rec[14]));
+    const int kind = (int)rec[13], set = kind == GK_STATIC ? (int)rec[14] : (kind == GK_BOXBOX ? gc.set_bb : (!RS || kind == GK_ROD ? gc.set_rod : gc.ns + 2 + (int)rec[14]));
     const double dist = rec[12];
     double imp = impedance(gc.ct_solimp[set], dist);
-    double invw = kind == GK_STATIC ? gc.box_invw_t : (kind == GK_BOXBOX ? 2 * gc.box_invw_t : (kind == GK_ROD ? gc.box_invw_t + gc.rod_invw : gc.rod_invw));
+    double invw = kind == GK_STATIC ? gc.box_invw_t : (kind == GK_BOXBOX ? 2 * gc.box_invw_t : (!RS || kind == GK_ROD ? gc.box_invw_t + gc.rod_invw : gc.rod_invw));
     GRow rows[3];
-    gen_rows(gc, sc, isl, rec, rows);
-    double v0 = grow_dot_g(sc, rows[0], GL_VEL), v1 = grow_dot_g(sc, rows[1], GL_VEL), v2 = grow_dot_g(sc, rows[2], GL_VEL);
+    gen_rows<RS>(gc, sc, isl, rec, rows);
+    double v0 = grow_dot_g<RS>(sc, rows[0], GL_VEL), v1 = grow_dot_g<RS>(sc, rows[1], GL_VEL), v2 = grow_dot_g<RS>(sc, rows[2], GL_VEL);
     PGS(base + 16) = -gc.ct_B[set] * v0 - gc.ct_K[set] * imp * dist;
     PGS(base + 17) = -gc.ct_B[set] * v1; PGS(base + 18) = -gc.ct_B[set] * v2;
     PGS(base + 19) = 1 / fmax(1e-15, (1 - imp) / imp * invw);
@@ -412,21 +418,21 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
 #pragma unroll
       for (int k = 0; k < 21; k++) rec[k] = PGS(base + k);
       GRow rows[3];
-      gen_rows(gc, sc, isl, rec, rows);
+      gen_rows<RS>(gc, sc, isl, rec, rows);
       double jar[3], force[3], Hc[9];
 #pragma unroll
-      for (int r = 0; r < 3; r++) { jar[r] = grow_dot_g(sc, rows[r], GL_X) - rec[16 + r]; PGS(base + 22 + r) = jar[r]; }
+      for (int r = 0; r < 3; r++) { jar[r] = grow_dot_g<RS>(sc, rows[r], GL_X) - rec[16 + r]; PGS(base + 22 + r) = jar[r]; }
       const double Dn = rec[19], fric = rec[20];
       cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
       if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
-      const int c1 = rows[0].c1, c2 = rows[0].c2, n1 = rows[0].n1, n2 = rows[0].n2;
+      const int c1 = rows[0].c1, c2 = rows[0].c2, n1 = RS ? rows[0].n1 : 6, n2 = rows[0].n2;
 #pragma unroll
-      for (int k = 0; k < 6; k++) if (k < n1) GLS_ADD(vg + c1 + k, -(rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2]));
+      for (int k = 0; k < 6; k++) if (!RS || k < n1) GLS_ADD(vg + c1 + k, -(rows[0].v1[k] * force[0] + rows[1].v1[k] * force[1] + rows[2].v1[k] * force[2]));
 #pragma unroll
       for (int k = 0; k < 7; k++) if (k < n2) GLS_ADD(vg + c2 + k, -(rows[0].v2[k] * force[0] + rows[1].v2[k] * force[1] + rows[2].v2[k] * force[2]));
       // H += J' Hc J, block (1,1), then (2,1) and (2,2); c2 > c1 for every contact kind (second cube after the first, arm last)
 #pragma unroll
-      for (int a = 0; a < 6; a++) if (a < n1) {
+      for (int a = 0; a < 6; a++) if (!RS || a < n1) {
         double ta[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v1[a] + Hc[3 * r + 1] * rows[1].v1[a] + Hc[3 * r + 2] * rows[2].v1[a];
@@ -439,7 +445,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
 #pragma unroll
         for (int r = 0; r < 3; r++) ta[r] = Hc[3 * r] * rows[0].v2[a] + Hc[3 * r + 1] * rows[1].v2[a] + Hc[3 * r + 2] * rows[2].v2[a];
 #pragma unroll
-        for (int b = 0; b < 6; b++) if (b < n1) GLS_ADD(hb + tri(c2 + a, c1 + b), ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b]);
+        for (int b = 0; b < 6; b++) if (!RS || b < n1) GLS_ADD(hb + tri(c2 + a, c1 + b), ta[0] * rows[0].v1[b] + ta[1] * rows[1].v1[b] + ta[2] * rows[2].v1[b]);
 #pragma unroll
         for (int b = 0; b < 7; b++) if (b <= a) GLS_ADD(hb + tri(c2 + a, c2 + b), ta[0] * rows[0].v2[b] + ta[1] * rows[1].v2[b] + ta[2] * rows[2].v2[b]);
       }
@@ -470,9 +476,9 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
 #pragma unroll
       for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
       GRow rows[3];
-      gen_rows(gc, sc, isl, rec, rows);
+      gen_rows<RS>(gc, sc, isl, rec, rows);
 #pragma unroll
-      for (int r = 0; r < 3; r++) PGS(base + 25 + r) = grow_dot_c(sc, rows[r], vp);
+      for (int r = 0; r < 3; r++) PGS(base + 25 + r) = grow_dot_c<RS>(sc, rows[r], vp);
     }
     gen_sync();
     PUSH_TOC(6);
@@ -878,13 +884,13 @@ D3IL_NOINLINE inline void gen_phase3r(const GenConsts& gc_, const PushScratch sc
   GLS(GL_INFO + 9 + l) = (double)cnt;
 }
 // ---- phase 3b (lane 0): arm Jacobian rows of the rod contacts (the last record of a cube's segment; the packed rod <-> static contacts)
-template <class C>
+template <bool RS, class C>
 D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, const PushScratch sc, int nl, unsigned& fl) {
   D3IL_GEN_CONSTS(gc_, gc);
   bool any = false;
   for (int b = 0; b < gc.nb; b++) any = any || (((unsigned)GLS(GL_INFO + b) >> 9) & 1);
   int narm = 0;
-  if (gc.rod_static) {          // pack the lanes' finds to the front of the arm segment
+  if (RS && gc.rod_static) {          // pack the lanes' finds to the front of the arm segment
     for (int l = 0; l < nl; l++)
       for (int j = 0, m = (int)GLS(GL_INFO + 9 + l); j < m; j++) {
         if (narm >= GEN_ARMCON) { fl |= PF_CON_OVERFLOW; continue; }
@@ -894,7 +900,7 @@ D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, 
         narm++;
       }
   }
-  GLS(GL_INFO + 8) = (double)narm;
+  if (RS) GLS(GL_INFO + 8) = (double)narm;
   if (!any && narm == 0) return;
   double sn[NARM], cs[NARM], R7[9], p7[3], ax[NARM][3], og[NARM][3];
 #pragma unroll
@@ -924,6 +930,7 @@ D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, 
 // ---- phase 4: islands.  Every lane derives the connected components of {cubes, arm} under cube-cube and rod contacts from the
 // per-cube info words (identical result in all lanes), in the order of their first block, with their storage offsets.
 struct IslSet { Isl isl[GEN_MAXNB + 1]; unsigned cpk[GEN_MAXNB + 1]; int first[GEN_MAXNB + 1]; int n; };
+template <bool RS>
 D3IL_HD void gen_islands(const GenConsts& gc_, const PushScratch sc, IslSet& out) {
   D3IL_GEN_CONSTS(gc_, gc);
   const int nb = gc.nb;
@@ -940,7 +947,7 @@ D3IL_HD void gen_islands(const GenConsts& gc_, const PushScratch sc, IslSet& out
 #pragma unroll
     for (int d = 0; d <= GEN_MAXNB; d++) if ((m >> d) & 1) adj[d] |= 1u << b;
   }
-  cnt[nb] = (unsigned)GLS(GL_INFO + 8);      // rod <-> static contacts: they belong to the arm block
+  if (RS) cnt[nb] = (unsigned)GLS(GL_INFO + 8);      // rod <-> static contacts: they belong to the arm block
   unsigned seen = 0;
   int hoff = 0, voff = 0;
   out.n = 0;
@@ -971,42 +978,89 @@ D3IL_HD bool gen_uncoupled(const GenConsts& gc_, const PushScratch sc) {   // no
   for (int b = 0; b < GEN_MAXNB; b++) if (b < gc.nb) c |= (unsigned)GLS(GL_INFO + b) >> 5;
   return c == 0;
 }
+template <bool RS>
 D3IL_HD void gen_phase4_single(const GenConsts& gc_, const PushScratch sc, int l, bool warm_valid, unsigned& fl) {
   D3IL_GEN_CONSTS(gc_, gc);
   int cnt = -1;                                   // contact count of cube l when it is an island on its own
   if (gen_uncoupled(gc, sc)) cnt = (int)((unsigned)GLS(GL_INFO + l) & 31u);      // the usual case: no island bookkeeping needed
   else {
     IslSet is;
-    gen_islands(gc, sc, is);
+    gen_islands<RS>(gc, sc, is);
 #pragma unroll
     for (int k = 0; k <= GEN_MAXNB; k++) if (k < is.n && is.first[k] == l && is.isl[k].n == 1 && l < gc.nb) cnt = (int)(is.cpk[k] & 31u);
   }
   if (cnt == 0) for (int j = 0; j < 6; j++) GLS(GL_X + 6 * l + j) = GLS(GL_A0 + 6 * l + j);
   else if (cnt > 0 && !gen_solve_cube(gc, sc, l, cnt, warm_valid)) fl |= F_SOLVER_FAIL;
 }
+// The arm on its own with ONE rod <-> static box contact and no arm joint at a limit (the rod pressing on a wall of a gate): the situation of the
+// Avoiding task's rod <-> obstacle contact, solved the same way - panda_step.h's register-resident Newton in the 5-dimensional constraint space
+// (contact rows + the two finger-limit rows) on the group's lane 0 - instead of the four-lane island solver (every rod pressing on a wall with the
+// cubes out of its way: 1.45 ms per step at 4096 environments against 1.40 at rest, tools/gpu_gen_rest_time.py).  Same optimum: both minimise the
+// same strictly convex cost to the same tolerances.
+D3IL_NOINLINE inline bool gen_arm_contact1(const GenConsts& gc_, const PushScratch sc) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  const int arm0 = 6 * gc.nb, base = GG_CON + GEN_ARMSEG * GEN_SEG * GREC;
+  double M[45], L[45], d[NDOF], id[NDOF], a0[NDOF], va[NDOF], fsv[NDOF];
+#pragma unroll
+  for (int i = 0; i < 45; i++) M[i] = GLS(GL_M + i);
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) { a0[k] = GLS(GL_A0 + arm0 + k); va[k] = GLS(GL_VEL + arm0 + k); }
+  bool ok = ldl9(M, L, d, id);
+  symv9(M, a0, fsv);                                   // the smooth force M qacc_smooth, for the gradient scale
+  double fn = 0, md = 0;
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) { fn += fsv[k] * fsv[k]; md += M[tri(k, k)]; }
+  const double gscale = (1.0 + sqrt(fn)) / (md / NDOF);
+  RodContact rc;
+  rc.active = true;
+  const int set = gc.ns + 2 + (int)PGS(base + 14);
+  const double dist = PGS(base + 12);
+  double vel[3] = {0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < NARM; k++) { rc.J[r][k] = GLS(GL_JA + 21 * GEN_MAXNB + 7 * r + k); vel[r] += rc.J[r][k] * va[k]; }
+  const double imp = impedance(gc.ct_solimp[set], dist);
+  const double Rn = fmax(1e-15, (1 - imp) / imp * gc.rod_invw), Rt = Rn / fmax(1e-15, gc.impratio), f0 = gc.ct_fric[set];
+  rc.mu = f0 * sqrt(Rt / Rn); rc.fric[0] = f0; rc.fric[1] = f0;
+  rc.D[0] = 1 / Rn; rc.D[1] = 1 / Rt; rc.D[2] = 1 / Rt;
+  rc.aref[0] = -gc.ct_B[set] * vel[0] - gc.ct_K[set] * imp * dist;
+  rc.aref[1] = -gc.ct_B[set] * vel[1]; rc.aref[2] = -gc.ct_B[set] * vel[2];
+  double fsign[NFING], fD[NFING], faref[NFING], fc[NDOF], warm[6];
+#pragma unroll
+  for (int k = 0; k < NFING; k++) { fsign[k] = GLS(GL_LIM + 3 * (NARM + k)); fD[k] = GLS(GL_LIM + 3 * (NARM + k) + 1); faref[k] = GLS(GL_LIM + 3 * (NARM + k) + 2); }
+  warm[5] = 0.0;
+  ok = solve_contact5(L, id, a0, rc, fsign, fD, faref, gscale, fc, warm) && ok;
+  ldl9_solve(L, id, fc);                               // qacc = qacc_smooth + M^-1 qfrc_constraint
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) GLS(GL_X + arm0 + k) = a0[k] + fc[k];
+  return ok;
+}
 // phase 4b (all nl lanes of the group together, lane l): the islands with more than one block, one after the other, and the arm
-// on its own when one of its seven joints is at a limit (otherwise it keeps the phase-1 solution)
+// on its own when one of its seven joints is at a limit or its rod is on a static box (otherwise it keeps the phase-1 solution)
+template <bool RS>
 D3IL_HD void gen_phase4_multi(const GenConsts& gc_, const PushScratch sc, int l, int nl, bool warm_valid, unsigned& fl) {
   D3IL_GEN_CONSTS(gc_, gc);
   if (gen_uncoupled(gc, sc)) {
-    const unsigned narm = (unsigned)GLS(GL_INFO + 8);
+    const unsigned narm = RS ? (unsigned)GLS(GL_INFO + 8) : 0u;
     if (GLS(GL_INFO + 4) == 0 && narm == 0) return;            // the usual case: nothing to do
+    if (RS && GLS(GL_INFO + 4) == 0 && narm == 1) { if (l == 0 && !gen_arm_contact1(gc, sc)) fl |= F_SOLVER_FAIL; gen_sync(); return; }
     Isl isl = gen_island(1u << gc.nb, gc.nb);                   // only the arm, with a joint at its limit or the rod on a static box
     GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);
     gen_sync();
-    if (!gen_solve(gc, sc, isl, narm, l, nl)) fl |= F_SOLVER_FAIL;
+    if (!gen_solve<RS>(gc, sc, isl, narm, l, nl)) fl |= F_SOLVER_FAIL;
     gen_sync();
     return;
   }
   IslSet is;
-  gen_islands(gc, sc, is);
+  gen_islands<RS>(gc, sc, is);
   // the k-th island that needs the joint solver: packed so that the groups of a wave run their k-th solves side by side
   unsigned todo = 0;
   int ntodo = 0;
 #pragma unroll
   for (int k = 0; k <= GEN_MAXNB; k++) if (k < is.n) {
     const bool arm_alone = is.isl[k].n == 1 && is.isl[k].arm;
-    if (is.isl[k].n > 1 || (arm_alone && (GLS(GL_INFO + 4) != 0 || GLS(GL_INFO + 8) != 0))) { todo |= (unsigned)k << (4 * ntodo); ntodo++; }
+    if (is.isl[k].n > 1 || (arm_alone && (GLS(GL_INFO + 4) != 0 || (RS && GLS(GL_INFO + 8) != 0)))) { todo |= (unsigned)k << (4 * ntodo); ntodo++; }
   }
   for (int j = 0; j < ntodo; j++) {
     const int k = (int)((todo >> (4 * j)) & 15u);
@@ -1014,9 +1068,14 @@ D3IL_HD void gen_phase4_multi(const GenConsts& gc_, const PushScratch sc, int l,
     unsigned cpk = is.cpk[0];
 #pragma unroll
     for (int q = 1; q <= GEN_MAXNB; q++) if (q == k) { isl = is.isl[q]; cpk = is.cpk[q]; }
+    if (RS && isl.n == 1 && isl.arm && GLS(GL_INFO + 4) == 0 && cpk == 1u) {      // the arm on its own, the rod on one static box
+      if (l == 0 && !gen_arm_contact1(gc, sc)) fl |= F_SOLVER_FAIL;
+      gen_sync();
+      continue;
+    }
     GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);      // identical stores from every lane
     gen_sync();
-    if (!gen_solve(gc, sc, isl, cpk, l, nl)) fl |= F_SOLVER_FAIL;
+    if (!gen_solve<RS>(gc, sc, isl, cpk, l, nl)) fl |= F_SOLVER_FAIL;
     gen_sync();
   }
 }
@@ -1067,8 +1126,8 @@ D3IL_HD void gen_phase5_cube(const GenConsts& gc_, const PushScratch sc, int b, 
 }
 
 // one physics sub-step (mj_step) of arm + cubes with the group's lanes run one after the other (host build, reset kernel)
-template <class C>
-D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* tau, const double* ffing) {
+template <bool RS, class C>
+D3IL_HD void gen_physics_substep_t(const C& c0, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* tau, const double* ffing) {
   D3IL_GEN_CONSTS(gc_, gc);
   D3IL_REFRESH(c0, c);
   const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
@@ -1078,13 +1137,19 @@ D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc_, EnvState& st
   gen_phase1(c0, gc, st, sc, tau, ffing);
   for (int l = 0; l < gc.nb; l++) cnt[l] = gen_phase2(gc, sc, l, grav, fl);
   for (int l = 0; l < gc.nb; l++) gen_phase3(gc, sc, l, cnt[l], c.rod_r, c.rod_h, fl);
-  if (gc.rod_static) for (int l = 0; l < gc.nb; l++) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, fl);
-  gen_phase3b(c0, gc, st, sc, gc.nb, fl);
-  for (int l = 0; l < gc.nb; l++) gen_phase4_single(gc, sc, l, warm_valid, fl);
-  gen_phase4_multi(gc, sc, 0, 1, warm_valid, fl);
+  if (RS && gc.rod_static) for (int l = 0; l < gc.nb; l++) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, fl);
+  gen_phase3b<RS>(c0, gc, st, sc, gc.nb, fl);
+  for (int l = 0; l < gc.nb; l++) gen_phase4_single<RS>(gc, sc, l, warm_valid, fl);
+  gen_phase4_multi<RS>(gc, sc, 0, 1, warm_valid, fl);
   gen_phase5_arm(c0, gc, st, sc);
   for (int l = 0; l < gc.nb; l++) gen_phase5_cube(gc, sc, l, c.timestep);
   st.flags |= fl | PF_WARM_VALID;
+}
+template <class C>
+D3IL_HD void gen_physics_substep(const C& c0, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* tau, const double* ffing) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  if (gc.rod_static) gen_physics_substep_t<true>(c0, gc, st, sc, tau, ffing);
+  else gen_physics_substep_t<false>(c0, gc, st, sc, tau, ffing);
 }
 
 // ------------------------------------------------------------------------------------------------ Sorting task (sorting.py)

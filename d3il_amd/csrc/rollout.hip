@@ -864,8 +864,10 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
       am.refs++; h->task_id = task_id;
     }
     HIPCHK_H(hipMalloc(&h->d_scratch, S * GG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * GG_SIZE * sizeof(double)));
-    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
-    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
+    HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_reset, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_H));
   }
   if (stacking) {
@@ -1036,12 +1038,13 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   if (gen_task(h->task_id)) {
     int nwgs = (h->n + GEN_LANES - 1) / GEN_LANES;
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
-    if (h->fast)
-      hipLaunchKernelGGL((k_sorting_step<true>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
-                         h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
-    else
-      hipLaunchKernelGGL((k_sorting_step<false>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
-                         h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
+    // the engine with contacts of the arm block only for models that evaluate rod <-> static box pairs (Inserting): the Sorting scenes run the
+    // instantiation without that code
+#define D3IL_GEN_LAUNCH(F, R) hipLaunchKernelGGL((k_sorting_step<F, R>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, \
+                                                  b.success, b.mode, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps)
+    if (h->gc.rod_static) { if (h->fast) D3IL_GEN_LAUNCH(true, true); else D3IL_GEN_LAUNCH(false, true); }
+    else { if (h->fast) D3IL_GEN_LAUNCH(true, false); else D3IL_GEN_LAUNCH(false, false); }
+#undef D3IL_GEN_LAUNCH
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
     return D3IL_OK;

@@ -6,13 +6,15 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(task, n, wall=False):
+def run(task, n, wall=False, clear=False):
     if task == "sorting":
         from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
         env = SortingVecEnv(n, device=0, max_steps_per_episode=100000); ctx = sample_contexts(60, 4, seed=0)
     else:
         from d3il_amd.envs.inserting import GateInsertionVecEnv, sample_contexts
         env = GateInsertionVecEnv(n, device=0, max_steps_per_episode=100000); ctx = sample_contexts(60, seed=0)
+        if clear:      # the cubes out of the rod's way (right half of the table): the arm is alone with its wall contact
+            ctx = ctx.reshape(60, 3, 7).copy(); ctx[:, :, 0] = [0.66, 0.72, 0.64]; ctx[:, :, 1] = [-0.2, -0.08, 0.04]; ctx = ctx.reshape(60, 21)
     env.start()
     env.reset(context=ctx[np.arange(n) % 60])
     z = env.robot_state()[:, 2:3].clone(); des = env.obs[:, :2].to(torch.float64).clone()
@@ -29,9 +31,9 @@ def run(task, n, wall=False):
     for t in range(50): env.step(act())
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
     fl = env.flags[:n].cpu().numpy()
-    print("%s%s: %.3f ms per step at %d envs (%.3f M env-steps/s), flagged %d" % (task, " rod on wall" if wall else " at rest", dt * 1e3, n, n / dt / 1e6, int(((fl >> 16) & 0xD).astype(bool).sum())))
+    print("%s%s%s: %.3f ms per step at %d envs (%.3f M env-steps/s), flagged %d" % (task, " rod on wall" if wall else " at rest", " (cubes out of the way)" if clear else "", dt * 1e3, n, n / dt / 1e6, int(((fl >> 16) & 0xD).astype(bool).sum())))
     env.close()
 
 
 n = int(sys.argv[sys.argv.index("--envs") + 1]) if "--envs" in sys.argv else 4096
-run("sorting", n); run("inserting", n); run("inserting", n, wall=True)
+run("sorting", n); run("inserting", n); run("inserting", n, wall=True); run("inserting", n, wall=True, clear=True)
