@@ -68,3 +68,28 @@ def test_sorting_4096_envs_full_episode(policy):
     assert not seen.any(), "flagged envs: %d (bits %s)" % (int((seen != 0).sum()), hex(int(np.bitwise_or.reduce(seen))))
     assert np.isfinite(st[:94]).all() and counts[0] >= n
     env.close()
+
+
+@pytest.mark.parametrize("policy", ["mlp", "scripted_push"])
+def test_inserting_4096_envs_full_episode(policy):
+    """Inserting: 4096 environments, 60 sampled contexts, 300-step episodes with device auto-reset and tally; with the stand-in MLP the rods wander into
+    cubes and walls, the scripted policy pushes the cubes towards their gates.  No solver failure, contact overflow (incl. the three rod <-> wall
+    slots) or off-table flag; the tally row of every context adds up to its finished episodes."""
+    from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedPushPolicy
+    from d3il_amd.envs.inserting import GateInsertionVecEnv, sample_contexts
+    n = 4096
+    env = GateInsertionVecEnv(n, device=0, max_steps_per_episode=300)
+    env.set_init_qpos(G["avoiding__traj_last"].copy())
+    ids = np.arange(n) % 60
+    env.reset(context=sample_contexts(60, seed=0)[ids])
+    table = env.set_tally(60, torch.as_tensor(ids, dtype=torch.int32, device=env.device))
+    pol = RandomResidualMLPPolicy(input_dim=13, device=env.device) if policy == "mlp" else ScriptedPushPolicy("inserting", device=env.device)
+    seen, st, counts = _run(env, pol, 301)
+    assert not seen.any(), "flagged envs: %d (bits %s)" % (int((seen != 0).sum()), hex(int(np.bitwise_or.reduce(seen))))
+    assert np.isfinite(st[:81]).all() and counts[0] >= n
+    tb = table.cpu().numpy()
+    assert tb[:, 0].sum() == counts[0] and tb[:, 1].sum() == counts[1]
+    # every finished episode is also counted by its code (mode_dict code | letters << 3) in the upper half of the row
+    from d3il_amd import capi
+    assert tb[:, 2 + capi.TALLY_ALL:2 + capi.TALLY_ALL + 256].sum() == counts[0]
+    env.close()

@@ -48,12 +48,15 @@ def test_avoiding_permuted_batch():
     assert (runs[0][-1][-1].astype(np.int64) & (1 << 14)).any() or (runs[0][-1][-1].astype(np.int64) & (1 << 12)).any(), "no environment reached an obstacle"
 
 
-@pytest.mark.parametrize("task,steps", [("pushing", 220), ("sorting", 300)])
+@pytest.mark.parametrize("task,steps", [("pushing", 220), ("sorting", 300), ("inserting", 260)])
 def test_contact_tasks_permuted_batch(task, steps):
-    from d3il_amd.agents import ScriptedGoalPushPolicy
+    from d3il_amd.agents import ScriptedGoalPushPolicy, ScriptedPushPolicy
     n = 1024
     rng = np.random.default_rng(5)
-    if task == "pushing":
+    if task == "inserting":      # cube <-> wall, rod <-> cube and rod <-> wall contacts (the gates)
+        from d3il_amd.envs.inserting import GateInsertionVecEnv as Env, sample_contexts
+        ctx, plan = sample_contexts(n, seed=5), None
+    elif task == "pushing":
         from d3il_amd.envs.pushing import BlockPushVecEnv as Env, sample_contexts
         ctx, plan = sample_contexts(n, seed=5), rng.integers(0, 4, size=n)
     else:
@@ -66,7 +69,7 @@ def test_contact_tasks_permuted_batch(task, steps):
         env.start()
         obs = env.reset(random=False, context=ctx[order])
         dev = obs.device
-        pol = ScriptedGoalPushPolicy(task, plan=None if plan is None else plan[order], device=dev)
+        pol = ScriptedPushPolicy(task, device=dev) if task == "inserting" else ScriptedGoalPushPolicy(task, plan=None if plan is None else plan[order], device=dev)
         rs = env.robot_state()
         des, z = rs[:, :2].clone(), rs[:, 2:3].clone()
         quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
