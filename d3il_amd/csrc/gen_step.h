@@ -30,6 +30,7 @@ constexpr int GEN_MAXNB = 4, GEN_MAXNS = 28, GEN_SEG = 24;
 constexpr int GEN_ARMSEG = GEN_MAXNB;                // segment of the contacts that involve no cube (rod <-> static box); GEN_ARMCON of them take part in a solve
 constexpr int GEN_ARMCON = 3, GEN_ARMLANE = 2;       // GEN_ARMLANE: what one lane of the group may find (it scans every nl-th static box)
 constexpr int GEN_MAXCON = (GEN_MAXNB + 1) * GEN_SEG;
+static_assert(GEN_ARMLANE * GEN_MAXNB <= GEN_SEG && GEN_ARMCON <= GEN_SEG, "the lanes' parking slots and the packed rod <-> static contacts share one record segment");
 constexpr int GEN_MAXSET = 2 * GEN_MAXNS + 2;        // static s <-> cube: s;  cube <-> cube: ns;  rod <-> cube: ns + 1;  rod <-> static s: ns + 2 + s
 enum { GEN_TASK_SORTING = 0, GEN_TASK_INSERTING = 1 };
 constexpr int GEN_MAXNV = 6 * GEN_MAXNB + NDOF;     // 33
