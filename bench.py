@@ -337,6 +337,142 @@ def _beso_policy_roofline(pol, n, dev):
 
 
 # ---------------------------------------------------------------------------------------------------- the benchmark
+class _Shard:
+    """One sub-batch of this rank's environments: its own environment handle, policy state and HIP stream.  The rank's environments are stepped as
+    `--sub-batches` independent sub-batches: a launch lasts as long as its slowest workgroup (an environment in a rare path - rod contact,
+    clipped-eigenvalue IK, a hard contact island), and sub-batches on different streams do not wait for each other's tails."""
+
+    def __init__(self, args, task, dev, n, env_offset, ctx60, q, stack_tables):
+        import numpy as np
+        import torch
+        self.task, self.n, self.env_offset, self.dev = task, n, env_offset, dev
+        self.own_stream = args.sub_batches > 1
+        self.stream = torch.cuda.Stream(dev) if self.own_stream else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self.stream):
+            if task == "avoiding":
+                from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
+                env = ObstacleAvoidanceVecEnv(n, device=dev)
+            elif task == "pushing":
+                from d3il_amd.envs.pushing import BlockPushVecEnv
+                env = BlockPushVecEnv(n, device=dev)
+            elif task == "sorting":
+                from d3il_amd.envs.sorting import SortingVecEnv
+                env = SortingVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 700)     # configs/sorting_4_config.yaml:80
+            elif task == "aligning":
+                from d3il_amd.envs.aligning import RobotPushVecEnv
+                env = RobotPushVecEnv(n, device=dev)
+            elif task == "inserting":
+                from d3il_amd.envs.inserting import GateInsertionVecEnv
+                env = GateInsertionVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 2000)     # gate_insertion.py:158 (the reference has no config for this task)
+            else:
+                from d3il_amd.envs.stacking import CubeStackingVecEnv
+                env = CubeStackingVecEnv(n, device=dev)
+            self.env = env
+            if self.own_stream:
+                env.bind_stream(self.stream)      # the library launches this sub-batch's kernels on its stream; no stream context per call
+            env.set_init_qpos(q)
+            if args.lanes is not None:
+                env.set_option("lanes_per_wave", args.lanes)
+            if args.split is not None:
+                env.set_option("split_waves", args.split)
+            if args.lds_pad is not None:
+                env.set_option("lds_pad_bytes", args.lds_pad)
+            if args.serve_max_wg is not None:
+                env.set_option("serve_wave_max_workgroups", args.serve_max_wg)
+            if args.solver_strict:
+                env.set_option("solver_strict", 1)
+            ctx_id = None
+            if ctx60 is not None:
+                ids = (env_offset + np.arange(n)) % len(ctx60)
+                ctx_id = torch.as_tensor(ids, dtype=torch.int32, device=dev)
+                env.reset(context=ctx60[ids])
+            else:
+                env.reset()
+            env.policy_begin()
+            self.table = env.set_tally(len(ctx60) if ctx60 is not None else 1, ctx_id)
+            self.episodes = torch.zeros(2, dtype=torch.int64, device=dev)   # finished, successful
+            self.actions = actions = torch.zeros(n, env.action_dim, dtype=torch.float64, device=dev)
+            policy = self.policy = args.policy or {"avoiding": "random", "stacking": "scripted_stack", "aligning": "scripted_align"}.get(task, "mlp")
+            pol = None
+            self.last_cmd = None
+            if task == "stacking":
+                from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedStackPolicy
+                if policy == "scripted_stack":
+                    pol = ScriptedStackPolicy(stack_tables, ctx_id.to(torch.int64), device=dev)
+                elif policy == "mlp":
+                    pol = RandomResidualMLPPolicy(input_dim=20, output_dim=8, device=dev, bound=0.01)
+                elif policy == "beso":
+                    pol = _random_beso(dev)
+                else:
+                    raise SystemExit("--policy %s is not available for task %s" % (policy, task))
+                self.last_cmd = env.robot_state().to(torch.float32).clone()                      # stacking_sim.py:90-91
+            elif task == "aligning":
+                from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedAlignPolicy
+                if policy == "scripted_align":
+                    pol = ScriptedAlignPolicy(inside=(ctx_id % 2 == 0), device=dev)
+                elif policy == "mlp":
+                    pol = RandomResidualMLPPolicy(input_dim=20, output_dim=3, device=dev, bound=0.01)
+                else:
+                    raise SystemExit("--policy %s is not available for task %s" % (policy, task))
+                actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
+            elif task != "avoiding" or policy != "random":
+                from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedPushPolicy
+                if policy == "mlp":
+                    pol = RandomResidualMLPPolicy(input_dim=2 + env.obs.shape[1], device=dev)
+                elif policy == "scripted_push":
+                    pol = ScriptedPushPolicy(task, device=dev)
+                elif policy == "ddpm":
+                    pol = _random_ddpm(2 + env.obs.shape[1], dev)
+                else:
+                    raise SystemExit("--policy %s is not available for task %s" % (policy, task))
+                actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
+            self.pol = pol
+            self.des_xy = env.policy_des[:2, :n]                              # [2, n] view: the harness set-point the library re-latches on auto-reset
+            self.des_z = env.policy_des[2, :n]
+        self.auto_reset = not args.no_auto_reset
+
+    def one_step(self, t):
+        import torch
+        env, pol, n, task, actions = self.env, self.pol, self.n, self.task, self.actions
+        if pol is None and task == "avoiding":      # BASELINE config 2: the device random policy - policy, step and auto-reset in one library call
+            if self.auto_reset:
+                env.random_rollout_step(42, self.env_offset, t, actions, self.episodes)
+            else:
+                env.policy_action(42, self.env_offset, t, actions); env.step(actions)
+            return
+        if self.own_stream:
+            torch.cuda.set_stream(self.stream)       # the policy's torch kernels go to this sub-batch's stream
+        if task == "stacking":
+            if hasattr(pol, "begin_episodes"):
+                pol.begin_episodes(env.last_reset)
+            self.last_cmd = torch.where(env.last_reset.bool().unsqueeze(1), env.robot_state().to(torch.float32), self.last_cmd)
+            obs20 = torch.cat((self.last_cmd, env.obs), dim=1)                           # np.concatenate((pred_action, obs)), stacking_sim.py:99
+            out = pol.predict_batch(obs20).to(torch.float32)
+            self.last_cmd = torch.cat((out[:, :7] + obs20[:, :7], out[:, 7:8]), dim=1)   # stacking_sim.py:104
+            actions.copy_(self.last_cmd)
+        elif task == "aligning":
+            if hasattr(pol, "begin_episodes"):
+                pol.begin_episodes(env.last_reset)
+            des3 = env.policy_des[:, :n]                                             # [3, n]: the library re-latches it to the TCP on auto-reset
+            obs_in = torch.cat((des3.t(), env.obs.to(torch.float64)), dim=1)        # np.concatenate((pred_action[:3], obs)), aligning_sim.py:99
+            des3.add_(pol.predict_batch(obs_in).to(torch.float64).t())              # aligning_sim.py:101-102: x, y and z are commanded
+            actions[:, 0:3] = des3.t()
+        else:
+            if hasattr(pol, "begin_episodes"):
+                pol.begin_episodes(env.last_reset)
+            obs_in = torch.cat((self.des_xy.t(), env.obs.to(torch.float64)), dim=1)      # np.concatenate((pred_action[:2], obs)), pushing_sim.py:75
+            self.des_xy.add_(pol.predict_batch(obs_in).to(torch.float64).t())            # pushing_sim.py:78
+            actions[:, 0:2] = self.des_xy.t()
+            actions[:, 2] = self.des_z
+        if self.auto_reset:
+            env.step_auto_reset(actions, self.episodes)
+        else:
+            env.step(actions)
+
+
+DEFAULT_SUB_BATCHES = {"avoiding": 4, "pushing": 4, "sorting": 4, "inserting": 4}      # measured: tools/gpu_subbatch.py, DESIGN section 18.10
+
+
 def run(args):
     import numpy as np
     import torch
@@ -352,127 +488,50 @@ def run(args):
     n = args.envs
     env_offset = rank * n
     ctx60 = None
-    if task == "avoiding":
-        from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
-        env = ObstacleAvoidanceVecEnv(n, device=dev)
-    elif task == "pushing":
-        from d3il_amd.envs.pushing import BlockPushVecEnv
+    if task == "pushing":
         from d3il_amd.simulation.pushing_sim import load_test_contexts
-        env = BlockPushVecEnv(n, device=dev)
         ctx60 = load_test_contexts()
     elif task == "sorting":
-        from d3il_amd.envs.sorting import SortingVecEnv, sample_contexts
-        env = SortingVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 700)     # configs/sorting_4_config.yaml:80
+        from d3il_amd.envs.sorting import sample_contexts
         ctx60 = sample_contexts(60, 4, seed=0)     # the reference's 4_test_contexts.pkl is not part of its tree
     elif task == "aligning":
-        from d3il_amd.envs.aligning import RobotPushVecEnv, load_test_contexts as load_align_contexts
-        env = RobotPushVecEnv(n, device=dev)
+        from d3il_amd.envs.aligning import load_test_contexts as load_align_contexts
         ctx60 = load_align_contexts()
     elif task == "inserting":
-        from d3il_amd.envs.inserting import GateInsertionVecEnv, sample_contexts as sample_insert_contexts
-        env = GateInsertionVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 2000)     # gate_insertion.py:158 (the reference has no config for this task)
+        from d3il_amd.envs.inserting import sample_contexts as sample_insert_contexts
         ctx60 = sample_insert_contexts(60, seed=0)
-    else:
-        from d3il_amd.envs.stacking import CubeStackingVecEnv, load_test_contexts as load_stack_contexts
-        env = CubeStackingVecEnv(n, device=dev)
+    elif task == "stacking":
+        from d3il_amd.envs.stacking import load_test_contexts as load_stack_contexts
         ctx60 = load_stack_contexts()[:args.stack_contexts]     # the first contexts of the reference's 100 test contexts, tiled
-    q, iters, err = env.start()
-    if args.lanes is not None:
-        env.set_option("lanes_per_wave", args.lanes)
-    if args.split is not None:
-        env.set_option("split_waves", args.split)
-    if args.lds_pad is not None:
-        env.set_option("lds_pad_bytes", args.lds_pad)
-    if args.serve_max_wg is not None:
-        env.set_option("serve_wave_max_workgroups", args.serve_max_wg)
-    if args.solver_strict:
-        env.set_option("solver_strict", 1)
+    # sub-batches: the rank's environments as S independent sub-batches on S streams (1 = one launch per step over the whole batch)
+    S = args.sub_batches if args.sub_batches is not None else DEFAULT_SUB_BATCHES.get(task, 1)
+    if S < 1 or n % S != 0 or n // S < 64:
+        S = 1
+    args.sub_batches = S
+    # env.start(): the offline IK to the task's start pose (host, once)
+    from d3il_amd.controllers.offline_ik import offline_ik
+    from d3il_amd.kinematics import UrdfChain
+    from d3il_amd.model import blob as blob_mod
+    js = blob_mod.load_json(task)
+    c_, tc_ = js["controller"], js["task_const"]
+    q, iters, err = offline_ik(UrdfChain(js["urdf_chain"]), c_["default_qpos"], list(tc_["init_end_eff_pos"]) + list(tc_["init_end_eff_quat"]),
+                               np.array(c_["joint_pos_min"]), np.array(c_["joint_pos_max"]))
+    stack_tables = None
+    if task == "stacking" and (args.policy or "scripted_stack") == "scripted_stack":
+        from d3il_amd.controllers.scripted_stacking import build_trajectory
+        stack_tables = [build_trajectory(js, q, c, speed=0.5) for c in ctx60]     # host IK once per context (untimed set-up)
+    shards = [_Shard(args, task, dev, n // S, env_offset + i * (n // S), ctx60, q, stack_tables) for i in range(S)]
+    env = shards[0].env
+    policy, pol = shards[0].policy, shards[0].pol
     max_steps = env.max_steps_per_episode
-    ctx_id = None
-    if ctx60 is not None:
-        ids = (env_offset + np.arange(n)) % len(ctx60)
-        ctx_id = torch.as_tensor(ids, dtype=torch.int32, device=dev)
-        env.reset(context=ctx60[ids])
-    else:
-        env.reset()
-    env.policy_begin()
-    table = env.set_tally(len(ctx60) if ctx60 is not None else 1, ctx_id)
-    episodes = torch.zeros(2, dtype=torch.int64, device=dev)   # finished, successful
-    actions = torch.zeros(n, env.action_dim, dtype=torch.float64, device=dev)
-    policy = args.policy or {"avoiding": "random", "stacking": "scripted_stack", "aligning": "scripted_align"}.get(task, "mlp")
-    pol = None
-    last_cmd = None
-    if task == "stacking":
-        from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedStackPolicy
-        if policy == "scripted_stack":
-            from d3il_amd.controllers.scripted_stacking import build_trajectory
-            tables = [build_trajectory(env.js, q, c, speed=0.5) for c in ctx60]     # host IK once per context (untimed set-up)
-            pol = ScriptedStackPolicy(tables, ctx_id.to(torch.int64), device=dev)
-        elif policy == "mlp":
-            pol = RandomResidualMLPPolicy(input_dim=20, output_dim=8, device=dev, bound=0.01)
-        elif policy == "beso":
-            pol = _random_beso(dev)
-        else:
-            raise SystemExit("--policy %s is not available for task %s" % (policy, task))
-        last_cmd = env.robot_state().to(torch.float32).clone()                      # stacking_sim.py:90-91
-    elif task == "aligning":
-        from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedAlignPolicy
-        if policy == "scripted_align":
-            pol = ScriptedAlignPolicy(inside=(ctx_id % 2 == 0), device=dev)
-        elif policy == "mlp":
-            pol = RandomResidualMLPPolicy(input_dim=20, output_dim=3, device=dev, bound=0.01)
-        else:
-            raise SystemExit("--policy %s is not available for task %s" % (policy, task))
-        actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
-    elif task != "avoiding" or policy != "random":
-        from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedPushPolicy
-        if policy == "mlp":
-            pol = RandomResidualMLPPolicy(input_dim=2 + env.obs.shape[1], device=dev)
-        elif policy == "scripted_push":
-            pol = ScriptedPushPolicy(task, device=dev)
-        elif policy == "ddpm":
-            pol = _random_ddpm(2 + env.obs.shape[1], dev)
-        else:
-            raise SystemExit("--policy %s is not available for task %s" % (policy, task))
-        actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
-    des_xy = env.policy_des[:2, :n]                              # [2, n] view: the harness set-point the library re-latches on auto-reset
-    des_z = env.policy_des[2, :n]
-    evs = None
+
+    default_stream = torch.cuda.current_stream(dev)
 
     def one_step(t):
-        nonlocal last_cmd
-        if task == "stacking":
-            if hasattr(pol, "begin_episodes"):
-                pol.begin_episodes(env.last_reset)
-            last_cmd = torch.where(env.last_reset.bool().unsqueeze(1), env.robot_state().to(torch.float32), last_cmd)
-            obs20 = torch.cat((last_cmd, env.obs), dim=1)                           # np.concatenate((pred_action, obs)), stacking_sim.py:99
-            out = pol.predict_batch(obs20).to(torch.float32)
-            last_cmd = torch.cat((out[:, :7] + obs20[:, :7], out[:, 7:8]), dim=1)   # stacking_sim.py:104
-            actions.copy_(last_cmd)
-        elif task == "aligning":
-            if hasattr(pol, "begin_episodes"):
-                pol.begin_episodes(env.last_reset)
-            des3 = env.policy_des[:, :n]                                             # [3, n]: the library re-latches it to the TCP on auto-reset
-            obs_in = torch.cat((des3.t(), env.obs.to(torch.float64)), dim=1)        # np.concatenate((pred_action[:3], obs)), aligning_sim.py:99
-            des3.add_(pol.predict_batch(obs_in).to(torch.float64).t())              # aligning_sim.py:101-102: x, y and z are commanded
-            actions[:, 0:3] = des3.t()
-        elif pol is None:
-            env.policy_action(42, env_offset, t, actions)
-        else:
-            if hasattr(pol, "begin_episodes"):
-                pol.begin_episodes(env.last_reset)
-            obs_in = torch.cat((des_xy.t(), env.obs.to(torch.float64)), dim=1)      # np.concatenate((pred_action[:2], obs)), pushing_sim.py:75
-            des_xy.add_(pol.predict_batch(obs_in).to(torch.float64).t())            # pushing_sim.py:78
-            actions[:, 0:2] = des_xy.t()
-            actions[:, 2] = des_z
-        if evs is not None:      # events on the stream the kernel is launched on (torch's current stream), one pair per step
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); env.step(actions); e1.record()
-            evs.append((e0, e1))
-        else:
-            env.step(actions)
-        if not args.no_auto_reset:
-            env.auto_reset(episodes)
+        for sh in shards:
+            sh.one_step(t)
+        if S > 1:
+            torch.cuda.set_stream(default_stream)
 
     def barrier():
         if world > 1:
@@ -495,37 +554,45 @@ def run(args):
     if not args.no_preroll and not args.no_auto_reset:
         # steady-state phase mix: lane i pretends to be (i * 977) % max_steps steps into its episode, then one full episode length of
         # untimed steps: every lane is re-started at its own time
-        stagger = (torch.arange(n, device=dev, dtype=torch.int64) + env_offset) * 977 % max_steps
-        env.step_count[:n] = stagger.to(torch.int32)
+        for sh in shards:
+            with torch.cuda.stream(sh.stream):
+                stagger = (torch.arange(sh.n, device=dev, dtype=torch.int64) + sh.env_offset) * 977 % max_steps
+                sh.env.step_count[:sh.n] = stagger.to(torch.int32)
         preroll = max_steps if args.preroll is None else args.preroll
         for t in range(preroll):
             one_step(t_run); t_run += 1
     for t in range(args.warmup):
         one_step(t_run); t_run += 1
-    episodes.zero_(); table.zero_()
-    env.set_timing(True)
-    kernel_ms_lib = []
-    evs = []
+    barrier()
+    for sh in shards:
+        sh.episodes.zero_(); sh.table.zero_()
+        sh.env.set_timing(True)      # HIP events around EVERY step-kernel launch, on the stream it is launched on, kept in a ring inside the library
     barrier()
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(t_run); t_run += 1
-        # cross-check: HIP events recorded by the library around the step kernel on the launch stream; reading the
-        # previous pair costs one event sync on an already finished kernel every 16 steps
-        if t % 16 == 15:
-            kernel_ms_lib.append(env.last_step_ms())
+    torch.cuda.synchronize()                         # all sub-batch streams
+    table = shards[0].table
+    for sh in shards[1:]:
+        table += sh.table
+    episodes = sum(sh.episodes for sh in shards)
     D.reduce_counts(table, lib_comm, env.h)          # the one collective of the path: int64 episode tally, RCCL inside the library
     barrier()
     dt = time.perf_counter() - t0
-    env.set_timing(False)
-    kernel_ms = [a.elapsed_time(b) for a, b in evs]      # every launch of the timed region
+    tstats = [sh.env.timing_stats() for sh in shards]      # (sum, min, max, launches) over every launch of the timed region
+    for sh in shards:
+        sh.env.set_timing(False)
+    n_launches = sum(x[3] for x in tstats)
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
     dt = float(t_max.item())
-    st, fl, sc = env.get_state()
+    states = [sh.env.get_state() for sh in shards]
+    st = np.concatenate([x[0] for x in states], axis=1)
+    fl = np.concatenate([x[1] for x in states])
     n_state = env.state_rows - (2 if task in ("sorting", "inserting") else 0)
     n_sub = env.n_substeps
+    n_launch = n // S                                 # environments per launch of the step kernel
     finite = bool(np.isfinite(st[:n_state]).all())      # (the Aligning mean distance / reward may be NaN like the reference's: they are info rows, not state)
     flagged = {"solver_fail": int(((fl >> 16) & 1).sum())}
     if task != "avoiding":
@@ -534,10 +601,10 @@ def run(args):
         flagged.update(hand_near=int(((fl >> 20) & 1).sum()))
     if rank == 0:
         value = world * n * args.steps / dt
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        k_ms = sum(x[0] for x in tstats) / n_launches if n_launches else float("nan")
         alg = ALG_BYTES[task]
-        achieved = alg * n / (k_ms * 1e-3) / 1e9
-        pm, pm_path = _pmc(task, n)
+        achieved = alg * n_launch / (k_ms * 1e-3) / 1e9      # per launch of the step kernel: n_launch environments (one sub-batch)
+        pm, pm_path = _pmc(task, n) if S == DEFAULT_SUB_BATCHES.get(task, 1) else (None, None)      # the committed counter passes ran the default command: same launch size
         traffic, valu = None, None
         if pm is not None:
             traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
@@ -575,7 +642,12 @@ def run(args):
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "envs_per_gpu": n, "n_substeps": n_sub, "parallelism": "env-shard x%d" % world, "policy": policy,
+            "config": {"workload": workload, "envs_per_gpu": n, "sub_batches": S, "envs_per_launch": n_launch,
+                       "sub_batch_note": ("the %d environments of a GPU are stepped as %d independent sub-batches of %d on %d HIP streams (own handle, policy state, "
+                                          "tally; Philox counters and context ids by global environment index, so the work is that of one batch): a launch lasts as "
+                                          "long as its slowest workgroup and sub-batches do not wait for each other's rare-path tails; --sub-batches 1 = one launch "
+                                          "per step" % (n, S, n_launch, S)) if S > 1 else "one launch per step over the whole batch",
+                       "n_substeps": n_sub, "parallelism": "env-shard x%d" % world, "policy": policy,
                        "preroll_steps_untimed": preroll, "phase_mix": "steady state (staggered episode phases)" if preroll else "fresh reset",
                        "auto_reset": not args.no_auto_reset, "finite": finite, "flagged_envs": flagged,
                        "episodes_finished_all_ranks": int(tb[:, 0].sum()), "episodes_success_all_ranks": int(tb[:, 1].sum()),
@@ -584,10 +656,10 @@ def run(args):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run)" % pm_path) if pm_path else None,
                          "kernel": KERNEL[task], "kernel_ms": k_ms,
-                         "kernel_ms_library_events_every_16th": float(np.mean(kernel_ms_lib)) if kernel_ms_lib else None,
-                         "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms else None, "kernel_ms_max": float(np.max(kernel_ms)) if kernel_ms else None,
-                         "algorithmic_bytes_per_launch": alg * n, "algorithmic_bytes_per_env_step": alg,
-                         "implementation_bytes_per_launch": IMPL_BYTES[task] * n,
+                         "kernel_launches_timed": n_launches,
+                         "kernel_ms_min": min(x[1] for x in tstats) if n_launches else None, "kernel_ms_max": max(x[2] for x in tstats) if n_launches else None,
+                         "algorithmic_bytes_per_launch": alg * n_launch, "algorithmic_bytes_per_env_step": alg,
+                         "implementation_bytes_per_launch": IMPL_BYTES[task] * n_launch, "envs_per_launch": n_launch,
                          "note": "the path is FP64-VALU issue/latency bound, not HBM bound: < 2.2 KB of HBM per env step with all 35 sub-steps "
                                  "fused in registers / LDS (DESIGN.md sections 4, 12.3, 13.3); `frac` is the (structurally tiny) HBM fraction the contract asks for, "
                                  "`valu` the binding resource",
@@ -598,7 +670,8 @@ def run(args):
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(task, env.blob, q, ctx60)
         print(json.dumps(line))
-    env.close()          # (the library communicator is process-wide: distributed.auto_comm)
+    for sh in shards:
+        sh.env.close()          # (the library communicator is process-wide: distributed.auto_comm)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -622,8 +695,13 @@ def main():
     ap.add_argument("--lanes", type=int, default=None, help="environments per wave (default 64)")
     ap.add_argument("--split", type=int, default=None, help="1: two-wave controller||physics kernel, 0: fused kernel, default auto")
     ap.add_argument("--serve-max-wg", type=int, default=None, help="Avoiding: workgroup count up to which the split kernel runs with its third wave (rare constraint paths); 0 = the two-wave kernel (A/B)")
+    ap.add_argument("--sub-batches", type=int, default=None, help="step the GPU's environments as this many independent sub-batches on as many HIP streams "
+                    "(default: 4 for avoiding / pushing / sorting / inserting, 1 otherwise; 1 = one launch per step over the whole batch)")
     ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
     args = ap.parse_args()
+    # sub-batches run on their own HIP streams; with the runtime's default of four hardware queues two of four streams share a queue (the null stream
+    # holds one) and their launches serialise: measured 3.6 M instead of 7.2 M env-steps/s.  Must be set before the HIP runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_spawn(args.gpus))

@@ -668,8 +668,14 @@ struct d3il_handle_s {
   int serve_max_wg;       // the split kernel runs with its third wave (rare constraint paths) up to this many workgroups (one per CU); 0: never
   int lanes;              // active lanes (environments) per wave: 64, or fewer to spread a small batch over more SIMDs
   int lds_pad;            // dynamic LDS bytes requested per workgroup: spreads the single-wave workgroups over CUs
-  hipEvent_t ev0, ev1;
+  hipEvent_t ev0, ev1;     // the event pair of the LAST timed launch (aliases of a ring slot)
   bool ev_valid, ev_created;
+  // every timed launch gets its own event pair from a ring; a pair is read (and its time accumulated) when its slot comes round again or when
+  // d3il_timing_stats drains the ring - so the host never waits for a launch it has just enqueued
+  hipEvent_t ring0[128], ring1[128];
+  bool ring_created;
+  long ring_head, ring_drained, t_n;
+  double t_sum, t_min, t_max;
   int tol_mode;            // 0 production stopping rule of the contact solvers, 1 the oracle's (solver_strict)
   int stack_reset_coop;    // Stacking: 1 (default) env.reset() runs through the step kernel's cooperative phases, 0 the one-lane reset kernel
   int push_coop;           // Pushing: 1 env.step() on the wave-cooperative engine (k_pushing_step_coop), 0 (default) the two-wave kernel (k_pushing_step_split)
@@ -719,7 +725,7 @@ static void free_handle(d3il_handle_s* h) {
   void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des,
                   h->buf.info_f64, h->d_scratch, h->d_ctx, h->d_mask};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (h->ev_created) { (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); }
+  if (h->ring_created) for (int i = 0; i < 128; i++) { (void)hipEventDestroy(h->ring0[i]); (void)hipEventDestroy(h->ring1[i]); }
   delete h;
 }
 // inside d3il_create: every failure releases what has been allocated so far
@@ -741,7 +747,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   d3il_handle_s* h = new d3il_handle_s();
   std::memset(&h->buf, 0, sizeof h->buf);
   h->task_id = -1; h->device = device_id;      // task_id is set once the model reference is taken (free_handle)
-  h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr; h->d_ctx = nullptr; h->d_mask = nullptr; h->ev_created = false;
+  h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr; h->d_ctx = nullptr; h->d_mask = nullptr; h->ev_created = false; h->ring_created = false;
   h->tally_ctx = nullptr; h->tally_nctx = 0; h->tally_table = nullptr; h->tol_mode = 0; h->ctx_dim = 0; h->stack_reset_coop = 1; h->push_coop = 0; h->kc_id = 0;
   const char* err = "";
   int rc = build_panda_consts(m, h->hc, &err);
@@ -895,7 +901,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     HIPCHK_H(hipFuncSetAttribute((const void*)k_aligning_step, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
   }
   h->task_id = task_id;
-  HIPCHK_H(hipEventCreate(&h->ev0)); HIPCHK_H(hipEventCreate(&h->ev1));
+  h->ring_created = false; h->ring_head = h->ring_drained = h->t_n = 0; h->t_sum = 0; h->t_min = 1e300; h->t_max = 0;
   h->ev_created = true;
   *out = h;
   return D3IL_OK;
@@ -1010,6 +1016,22 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
   return D3IL_OK;
 }
 
+static int timing_drain_one(d3il_handle h) {
+  const int slot = (int)(h->ring_drained % 128);
+  float ms = 0;
+  HIPCHK(hipEventSynchronize(h->ring1[slot]));
+  HIPCHK(hipEventElapsedTime(&ms, h->ring0[slot], h->ring1[slot]));
+  h->t_sum += ms; h->t_n++; if (ms < h->t_min) h->t_min = ms; if (ms > h->t_max) h->t_max = ms;
+  h->ring_drained++;
+  return D3IL_OK;
+}
+static int timing_begin(d3il_handle h, hipStream_t s) {
+  if (h->ring_head - h->ring_drained >= 128) { if (int rc = timing_drain_one(h)) return rc; }      // the pair recorded 128 launches ago: long finished
+  const int slot = (int)(h->ring_head % 128);
+  h->ev0 = h->ring0[slot]; h->ev1 = h->ring1[slot];
+  HIPCHK(hipEventRecord(h->ev0, s));
+  return D3IL_OK;
+}
 int d3il_step(d3il_handle h, const double* actions, void* stream) {
   if (!h || !actions) return fail(D3IL_EINVAL, "d3il_step: null argument");
   if (!h->started) return fail(D3IL_ESTATE, "d3il_step: d3il_start() has not been called");
@@ -1021,7 +1043,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     int nwgp = (h->n + PUSH_LANES - 1) / PUSH_LANES;
     std::unique_ptr<StackLaunch> guard;
     if (h->push_coop && h->fast) { guard.reset(new StackLaunch(h)); if (guard->rc) return guard->rc; }
-    if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+    if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
     if (h->push_coop && h->fast)
       hipLaunchKernelGGL(k_pushing_step_coop, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                          b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
@@ -1032,12 +1054,12 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
       hipLaunchKernelGGL((k_pushing_step_split<false>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                          b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
     HIPCHK(hipGetLastError());
-    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; h->ring_head++; }
     return D3IL_OK;
   }
   if (gen_task(h->task_id)) {
     int nwgs = (h->n + GEN_LANES - 1) / GEN_LANES;
-    if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+    if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
     // the engine with contacts of the arm block only for models that evaluate rod <-> static box pairs (Inserting): the Sorting scenes run the
     // instantiation without that code
 #define D3IL_GEN_LAUNCH(F, R) hipLaunchKernelGGL((k_sorting_step<F, R>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, \
@@ -1046,27 +1068,27 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     else { if (h->fast) D3IL_GEN_LAUNCH(true, false); else D3IL_GEN_LAUNCH(false, false); }
 #undef D3IL_GEN_LAUNCH
     HIPCHK(hipGetLastError());
-    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; h->ring_head++; }
     return D3IL_OK;
   }
   if (h->task_id == D3IL_TASK_STACKING) {
     StackLaunch guard(h);
     if (guard.rc) return guard.rc;
-    if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+    if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
     hipLaunchKernelGGL(k_stacking_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                        b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, 0, (const unsigned char*)nullptr, (const double*)nullptr, (const double*)nullptr);
     HIPCHK(hipGetLastError());
-    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; h->ring_head++; }
     return D3IL_OK;
   }
   if (h->task_id == D3IL_TASK_ALIGNING) {
     StackLaunch guard(h);
     if (guard.rc) return guard.rc;
-    if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+    if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
     hipLaunchKernelGGL(k_aligning_step, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, b.success, b.mode,
                        b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, 0, (const unsigned char*)nullptr, (const double*)nullptr, (const double*)nullptr);
     HIPCHK(hipGetLastError());
-    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; h->ring_head++; }
     return D3IL_OK;
   }
   // Workgroup placement: a workgroup is one wave; the dispatcher packs several of them onto one CU (and SIMD) before
@@ -1078,7 +1100,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     lds = per_cu >= 8 ? 0 : (160 * 1024 / per_cu) - 1024;  // leave slack below the 160 KiB per-CU pool
     if (lds > 64 * 1024) lds = 64 * 1024;
   }
-  if (h->timing) HIPCHK(hipEventRecord(h->ev0, s));
+  if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
   // the two-wave kernel wins at every batch size measured (4096 ... 262144 envs: +64 % ... +20 %): at small N the second
   // wave uses an idle SIMD, at saturation its 256-VGPR roles run two waves per SIMD and hide FP64 latency
   bool split = h->fast && h->lanes == WAVE && h->split != 0;
@@ -1096,7 +1118,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     hipLaunchKernelGGL((k_avoiding_step<false, true>), dim3(nwg), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                        b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, h->lanes);
   HIPCHK(hipGetLastError());
-  if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+  if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; h->ring_head++; }
   return D3IL_OK;
 }
 
@@ -1323,8 +1345,30 @@ int d3il_reduce_metrics(d3il_handle h, d3il_comm comm, int64_t* table_device, si
 
 int d3il_set_timing(d3il_handle h, int enabled) {
   if (!h) return fail(D3IL_EINVAL, "d3il_set_timing: null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (enabled && !h->ring_created) {
+    for (int i = 0; i < 128; i++) { HIPCHK(hipEventCreate(&h->ring0[i])); HIPCHK(hipEventCreate(&h->ring1[i])); }
+    h->ring_created = true;
+  }
+  if (enabled) { HIPCHK(hipDeviceSynchronize()); h->ring_head = h->ring_drained = h->t_n = 0; h->t_sum = 0; h->t_min = 1e300; h->t_max = 0; }
   h->timing = enabled != 0; h->ev_valid = false;
   return D3IL_OK;
+}
+int d3il_timing_stats(d3il_handle h, double* out4) {
+  if (!h || !out4) return fail(D3IL_EINVAL, "d3il_timing_stats: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  while (h->ring_drained < h->ring_head) { if (int rc = timing_drain_one(h)) return rc; }
+  out4[0] = h->t_sum; out4[1] = h->t_n ? h->t_min : 0.0; out4[2] = h->t_max; out4[3] = (double)h->t_n;
+  return D3IL_OK;
+}
+int d3il_step_auto_reset(d3il_handle h, const double* actions, int64_t* episode_counts_device, void* stream) {
+  if (int rc = d3il_step(h, actions, stream)) return rc;
+  return d3il_auto_reset(h, episode_counts_device, stream);
+}
+int d3il_random_rollout_step(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* episode_counts_device, void* stream) {
+  if (int rc = d3il_policy_action(h, seed, env_offset, t, actions, stream)) return rc;
+  if (int rc = d3il_step(h, actions, stream)) return rc;
+  return d3il_auto_reset(h, episode_counts_device, stream);
 }
 int d3il_last_step_ms(d3il_handle h, float* ms) {
   if (!h || !ms) return fail(D3IL_EINVAL, "d3il_last_step_ms: null argument");

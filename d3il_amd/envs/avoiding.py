@@ -74,6 +74,7 @@ class ObstacleAvoidanceVecEnv:
         self.policy_des = _view(b.policy_des, (3, s), "<f8", dev, self)
         self.last_reset = _view(b.last_reset, (n,), "|u1", dev, self)   # environments reset by the last auto_reset()
         self._tally = None
+        self._bound_stream = None
         self.init_qpos = None
         self._started = False
 
@@ -94,7 +95,29 @@ class ObstacleAvoidanceVecEnv:
         self._started = True
 
     def _stream(self):
+        if self._bound_stream is not None:
+            return self._bound_stream
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def bind_stream(self, stream: "torch.cuda.Stream | None"):
+        """Launch this environment's kernels on ``stream`` from now on instead of torch's current stream (None: back to the current stream).  For harnesses
+        that step several environment batches on their own streams (bench.py --sub-batches) without a stream context per call."""
+        self._bound_stream = None if stream is None else C.c_void_p(stream.cuda_stream)
+
+    def step_auto_reset(self, action: torch.Tensor, episode_counts: torch.Tensor):
+        """env.step(action) followed by auto_reset(episode_counts) in ONE library call (d3il_step_auto_reset); returns nothing - read obs / done / ... from
+        the buffers.  The shape / dtype checks of step() are the caller's business here."""
+        capi.check(self.L.d3il_step_auto_reset(self.h, C.c_void_p(action.data_ptr()), C.c_void_p(episode_counts.data_ptr()), self._stream()))
+
+    def random_rollout_step(self, seed: int, env_offset: int, t: int, actions: torch.Tensor, episode_counts: torch.Tensor):
+        """policy_action + step + auto_reset of the random-policy harness (BASELINE config 2) in ONE library call (d3il_random_rollout_step)."""
+        capi.check(self.L.d3il_random_rollout_step(self.h, int(seed), int(env_offset), int(t), C.c_void_p(actions.data_ptr()), C.c_void_p(episode_counts.data_ptr()), self._stream()))
+
+    def timing_stats(self):
+        """(sum ms, min ms, max ms, launches) of the step-kernel launches since set_timing(True) (d3il_timing_stats; drains the event ring)."""
+        out = (C.c_double * 4)()
+        capi.check(self.L.d3il_timing_stats(self.h, out))
+        return float(out[0]), float(out[1]), float(out[2]), int(out[3])
 
     def reset(self, mask: torch.Tensor | None = None, random=True, context=None):
         """env.reset() for all environments, or for those with mask != 0 (device uint8/bool tensor).

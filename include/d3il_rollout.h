@@ -224,6 +224,13 @@ int d3il_reduce_metrics(d3il_handle h, d3il_comm comm, int64_t* table_device, si
  * enabled); used by bench.py for the roofline figure. */
 int d3il_set_timing(d3il_handle h, int enabled);
 int d3il_last_step_ms(d3il_handle h, float* ms);
+/* With timing enabled EVERY d3il_step launch gets its own event pair (a ring of 128; a pair is read when its slot comes round again, so the host never waits
+ * for a launch it has just enqueued).  Drains the ring and returns out4 = {sum of the launch durations in ms, min, max, number of launches} since d3il_set_timing(h, 1). */
+int d3il_timing_stats(d3il_handle h, double* out4);
+/* One host call for one iteration of the rollout loops (fewer trips through the binding when a GPU's environments are stepped as several sub-batches):
+ * d3il_step_auto_reset = d3il_step + d3il_auto_reset; d3il_random_rollout_step = d3il_policy_action + d3il_step + d3il_auto_reset (BASELINE config 2). */
+int d3il_step_auto_reset(d3il_handle h, const double* actions, int64_t* episode_counts_device, void* stream);
+int d3il_random_rollout_step(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* episode_counts_device, void* stream);
 
 /* "ik_fast_path" (default 1), "split_waves" (-1 auto, 0, 1), "lanes_per_wave", "lds_pad_bytes";
  * "serve_wave_max_workgroups" (default 256): Avoiding - up to this many workgroups (64 environments each) the split kernel runs with a third wave that executes the

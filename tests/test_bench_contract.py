@@ -69,7 +69,24 @@ def test_json_line_of_a_short_run():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["single_core_value"] > 0
     assert abs(line["value"] - 512 * 5 / (line["ms_per_step"] * 5e-3)) / line["value"] < 1e-6
-    assert r["algorithmic_bytes_per_env_step"] == 704 and r["algorithmic_bytes_per_launch"] == 704 * 512
+    cfg = line["config"]
+    assert cfg["sub_batches"] * cfg["envs_per_launch"] == 512 and cfg["sub_batches"] == 4      # the default: four sub-batches on four streams
+    assert r["algorithmic_bytes_per_env_step"] == 704 and r["algorithmic_bytes_per_launch"] == 704 * cfg["envs_per_launch"] == 704 * r["envs_per_launch"]
+
+
+@pytest.mark.gpu
+def test_sub_batches_do_the_same_work_as_one_batch():
+    """--sub-batches 4 (the default) and --sub-batches 1 step the same environments with the same policy stream (Philox counters and context ids go by the
+    global environment index): the integer episode tally of a steady-state run is identical."""
+    out = {}
+    for sb in (1, 4):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "2", "--preroll", "255", "--envs", "512", "--no-cpu-baseline",
+                            "--sub-batches", str(sb)], capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        assert line["config"]["sub_batches"] == sb and line["config"]["finite"] and line["config"]["flagged_envs"]["solver_fail"] == 0
+        out[sb] = (line["config"]["episodes_finished_all_ranks"], line["config"]["episodes_success_all_ranks"])
+    assert out[1] == out[4] and out[1][0] > 0, out
 
 
 @pytest.mark.gpu
