@@ -654,7 +654,9 @@ def run(args):
                        "episodes_finished_rank0": int(episodes[0].item()),
                        "metric_reduction": reduction, "rccl_ranks": rccl_ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run)" % pm_path) if pm_path else None,
+                         "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run%s)" % (pm_path, "; the counter passes serialise dispatches, so each launch "
+                                            "of %d environments was measured ALONE on the chip - with %d sub-batches in flight their combined working set competes for the L2 "
+                                            "(DESIGN section 18.10)" % (n_launch, S) if S > 1 else "")) if pm_path else None,
                          "kernel": KERNEL[task], "kernel_ms": k_ms,
                          "kernel_launches_timed": n_launches,
                          "kernel_ms_min": min(x[1] for x in tstats) if n_launches else None, "kernel_ms_max": max(x[2] for x in tstats) if n_launches else None,
