@@ -336,3 +336,64 @@ def test_batch_size_and_lane_position_do_not_change_results(ins_init_qpos):
     assert np.isfinite(st).all() and not (fl & BAD).any() and (sc == 20).all()
     assert np.array_equal(st[:, :80], st[:, 80:160]) and np.array_equal(st[:, :80], st[:, 8000:8080])
     big.close()
+
+
+def test_physically_produced_insertions_match_oracle(ins_blob, ins_init_qpos):
+    """Mode events produced by the PHYSICS (not by loaded states): the red cube starts in the mouth of its gate (x 0.41 .. 0.425, small y / yaw variations), the
+    rod comes up east of it and pushes it west between maze_5 / maze_13 until maze_9 stops it 2 mm from its goal - the env's `modes` list gets its 'r'.
+    One environment does the same with the green cube from (0.525, 0.36) north into its gate.  Four environments are followed by the oracle step by step:
+    same number of letters at every step, the letter appears at the same step, same final code; most of the batch inserts."""
+    from oracle.oracle import Oracle
+    n = 16
+    rng = np.random.default_rng(4)
+    park = np.array([[0.40, -0.17, 0, 1, 0, 0, 0], [0.62, -0.08, 0, 1, 0, 0, 0], [0.45, 0.02, 0, 1, 0, 0, 0]], float)
+    ctx = np.tile(park[None], (n, 1, 1))
+    for e in range(n - 1):
+        yaw = rng.uniform(-0.03, 0.03)
+        ctx[e, 0, :2] = [0.41 + 0.001 * e, 0.276 + rng.uniform(-0.001, 0.001)]
+        ctx[e, 0, 3:] = [np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+    ctx[n - 1, 1, :2] = [0.525, 0.36]
+    ctx[n - 1, 2, :2] = [0.40, 0.02]
+    way = np.zeros((n, 3, 2))
+    way[:] = np.array([(0.49, 0.10), (0.49, 0.276), (0.388, 0.276)])
+    way[n - 1] = np.array([(0.525, 0.30), (0.525, 0.425), (0.525, 0.425)])
+    env = _env(n)
+    env.set_init_qpos(ins_init_qpos)
+    env.reset(context=ctx.reshape(n, 21))
+    check = [0, 7, 14, 15]
+    oracles = {}
+    for e in check:
+        o = Oracle(ins_blob); o.env_start(ins_init_qpos); o.ins_reset(ctx[e]); oracles[e] = o
+    z = env.robot_state()[:, 2:3].clone()
+    des = env.obs[:, :2].to(torch.float64).clone()
+    wayt = torch.as_tensor(way, dtype=torch.float64, device=des.device)
+    wi = torch.zeros(n, dtype=torch.long, device=des.device)
+    ar = torch.arange(n, device=des.device)
+    first_dev, first_orc = {}, {}
+    for t in range(170):
+        d = wayt[ar, wi] - des
+        nn = d.norm(dim=1, keepdim=True)
+        wi = torch.where((nn[:, 0] < 1e-9) & (wi < 2), wi + 1, wi)
+        d = wayt[ar, wi] - des
+        nn = d.norm(dim=1, keepdim=True)
+        des = des + d / nn.clamp_min(1e-12) * torch.minimum(nn, torch.full_like(nn, 0.006))
+        a = _action(des, z)
+        obs, rew, done, info = env.step(a)
+        torch.cuda.synchronize()
+        assert not (env.flags[:n].cpu().numpy() & BAD).any()
+        nm = (env.mode.to(torch.int32) >> 3).cpu().numpy()
+        an = a.cpu().numpy()
+        for e in range(n):
+            if nm[e] and e not in first_dev:
+                first_dev[e] = t
+        for e in check:
+            oo, do, io = oracles[e].ins_step(an[e])
+            if io["n_mode"] and e not in first_orc:
+                first_orc[e] = t
+            assert nm[e] == io["n_mode"] and bool(done[e]) == do and bool(info["success"][e]) == io["success"], (t, e, nm[e], io)
+    letters = env.mode_letters()
+    print("inserting, physical insertions: first letter at step (device) %s, (oracle) %s, letters %s" % (first_dev, first_orc, letters))
+    assert {e: first_dev.get(e) for e in check} == {e: first_orc.get(e) for e in check}
+    assert sum(1 for e in range(n - 1) if letters[e] == "r") >= 10 and all(l in ("", "r") for l in letters[:n - 1]) and letters[n - 1] in ("", "g")
+    assert any(e in first_orc for e in check)
+    env.close()
