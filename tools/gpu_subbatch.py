@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 task = sys.argv[1] if len(sys.argv) > 1 else "avoiding"
 N = int(sys.argv[sys.argv.index("--envs") + 1]) if "--envs" in sys.argv else 4096
 K = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 300
-FUSED, TALLY = "--fused" in sys.argv, "--tally" in sys.argv
+FUSED, TALLY, GRAPH = "--fused" in sys.argv, "--tally" in sys.argv, "--graph" in sys.argv
 SLIST = [int(x) for x in sys.argv[sys.argv.index("--s") + 1].split(",")] if "--s" in sys.argv else [1, 2, 4, 8]
 dev = torch.device("cuda:0")
 
@@ -51,8 +51,37 @@ class Shard:
             ms = env.max_steps_per_episode
             env.step_count[:n] = ((torch.arange(n, device=dev, dtype=torch.int64) + off) * 977 % ms).to(torch.int32)
         self.t = 0
+        self.graph = None
+        if GRAPH and self.pol is not None:      # the policy's ~25 small torch kernels of one step as ONE graph replay on this sub-batch's stream
+            env.bind_stream(self.stream)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self.stream):
+                for _ in range(3):
+                    self._policy()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self._policy()
+            torch.cuda.synchronize()
+
+    def _policy(self):
+        env, n = self.env, self.n
+        des_xy = env.policy_des[:2, :n]
+        obs_in = torch.cat((des_xy.t(), env.obs.to(torch.float64)), dim=1)
+        des_xy.add_(self.pol.predict_batch(obs_in).to(torch.float64).t())
+        self.actions[:, 0:2] = des_xy.t()
+        self.actions[:, 2] = env.policy_des[2, :n]
 
     def step(self):
+        if self.graph is not None:
+            torch.cuda.set_stream(self.stream)
+            self.graph.replay()
+            self.env.step_auto_reset(self.actions, self.episodes)
+            self.t += 1
+            return
+        return self._step_eager()
+
+    def _step_eager(self):
         env, n = self.env, self.n
         if FUSED and self.pol is None:
             env.random_rollout_step(42, self.off, self.t, self.actions, self.episodes)
