@@ -379,6 +379,9 @@ class _Shard:
                 env.set_option("lds_pad_bytes", args.lds_pad)
             if args.serve_max_wg is not None:
                 env.set_option("serve_wave_max_workgroups", args.serve_max_wg)
+            elif task == "avoiding" and args.sub_batches > 1:
+                # the third wave pays while the GPU as a whole holds at most one workgroup per CU: the library sees one sub-batch, the harness all of them
+                env.set_option("serve_wave_max_workgroups", 256 // args.sub_batches)
             if args.solver_strict:
                 env.set_option("solver_strict", 1)
             ctx_id = None
@@ -657,7 +660,8 @@ def run(args):
                          "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run%s)" % (pm_path, "; the counter passes serialise dispatches, so each launch "
                                             "of %d environments was measured ALONE on the chip - with %d sub-batches in flight their combined working set competes for the L2 "
                                             "(DESIGN section 18.10)" % (n_launch, S) if S > 1 else "")) if pm_path else None,
-                         "kernel": KERNEL[task], "kernel_ms": k_ms,
+                         "kernel": ("k_avoiding_step_split<true, false>" if task == "avoiding" and (n_launch + 63) // 64 > (args.serve_max_wg if args.serve_max_wg is not None else 256 // S) else KERNEL[task]),
+                         "kernel_ms": k_ms,
                          "kernel_launches_timed": n_launches,
                          "kernel_ms_min": min(x[1] for x in tstats) if n_launches else None, "kernel_ms_max": max(x[2] for x in tstats) if n_launches else None,
                          "algorithmic_bytes_per_launch": alg * n_launch, "algorithmic_bytes_per_env_step": alg,
