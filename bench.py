@@ -552,6 +552,16 @@ def run(args):
             reduction = "libd3il_rollout d3il_reduce_metrics: one RCCL ncclAllReduce(sum, int64) of the tally table"
         else:
             reduction = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
+        # self-check of the multi-GPU run: under the nccl backend the reduction MUST be the library's RCCL call over exactly
+        # WORLD_SIZE ranks - anything else (fallback to torch.distributed, a communicator of another size) makes every rank fail loudly instead of
+        # printing a line that looks like a scaling result.  (auto_comm agrees on success / failure across ranks, so all ranks take the same branch.)
+        if torch.distributed.get_backend() == "nccl" and os.environ.get("D3IL_ALLOW_REDUCTION_FALLBACK") != "1":
+            if lib_comm is None or rccl_ranks != world:
+                if rank == 0:
+                    print("bench.py: multi-GPU self-check failed: metric reduction = %s, rccl_ranks = %s, WORLD_SIZE = %d (set D3IL_ALLOW_REDUCTION_FALLBACK=1 to run anyway)"
+                          % (reduction, rccl_ranks, world), file=sys.stderr)
+                torch.distributed.destroy_process_group()
+                sys.exit(3)
     t_run = 0
     preroll = 0
     if not args.no_preroll and not args.no_auto_reset:
@@ -587,7 +597,11 @@ def run(args):
         sh.env.set_timing(False)
     n_launches = sum(x[3] for x in tstats)
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dt_by_rank = [dt]
     if world > 1:
+        gathered = [torch.zeros_like(t_max) for _ in range(world)]
+        torch.distributed.all_gather(gathered, t_max)
+        dt_by_rank = [float(x.item()) for x in gathered]
         torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
     dt = float(t_max.item())
     states = [sh.env.get_state() for sh in shards]
@@ -655,7 +669,9 @@ def run(args):
                        "auto_reset": not args.no_auto_reset, "finite": finite, "flagged_envs": flagged,
                        "episodes_finished_all_ranks": int(tb[:, 0].sum()), "episodes_success_all_ranks": int(tb[:, 1].sum()),
                        "episodes_finished_rank0": int(episodes[0].item()),
-                       "metric_reduction": reduction, "rccl_ranks": rccl_ranks},
+                       "metric_reduction": reduction, "rccl_ranks": rccl_ranks,
+                       "ms_per_step_by_rank": {"min": min(dt_by_rank) / args.steps * 1e3, "max": max(dt_by_rank) / args.steps * 1e3,
+                                               "all": [x / args.steps * 1e3 for x in dt_by_rank]}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run%s)" % (pm_path, "; the counter passes serialise dispatches, so each launch "
                                             "of %d environments was measured ALONE on the chip - with %d sub-batches in flight their combined working set competes for the L2 "

@@ -128,10 +128,10 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
       if (plive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl);
       if (RS && plive) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, lfl);
       gen_sync();
-      if (arm_lane) gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl);
+      if (arm_lane) { gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl); gen_arm_reduce<RS>(gc, sc, warm_valid); }
       gen_sync();
       PUSH_TOC(2);
-      if (plive) gen_phase4_single<RS>(gc, sc, l, warm_valid, lfl);
+      if (plive) lfl |= gen_tree_solve<1>(gc, sc, l, warm_valid);
       gen_sync();
       PUSH_TOC(8);
       if (plive) gen_phase4_multi<RS>(gc, sc, l, gc.nb, warm_valid, lfl);

@@ -89,11 +89,14 @@ constexpr int GL_ROD = GL_JA + 21 * (GEN_MAXNB + GEN_ARMCON);      // rod centre
 constexpr int GL_INFO = GL_ROD + 6;                 // [0..3] per cube: contact count | partner cubes << 5 | rod contact << 9;  [4] arm joint at a limit;  [5..7] flags of lanes 1..3;
                                                     // [8] rod <-> static contacts of this sub-step;  [9..12] what lanes 0..3 found of them
 constexpr int GL_RED = GL_INFO + 16;                 // line-search partial sums of the group's lanes, double buffered: 2 x 4 x (d1, d2)
-constexpr int GL_SIZE = GL_RED + 16;                // 1031
+constexpr int GL_TR = GL_RED + 16;                  // tree solver (gen_tree.h): [0] 1 = the arm's reduction to the lambda node stands, 2 = the arm's island was solved through it; [1..5] lambda
+constexpr int GL_PAIR = GL_TR + 6;                  // cube pair (c, d), c < d: first record | count << 5 of their contacts in c's segment
+constexpr int GL_SIZE = GL_PAIR + 6;                // 1043
 // g area (HBM): contact records, GEN_SEG per cube
 constexpr int GG_CON = 0;
 constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn fric set | jar[3] jp[3]
 constexpr int GG_SIZE = GG_CON + GEN_MAXCON * GREC;
+D3IL_HD int gt_pair(int c, int d) { return c * (2 * GEN_MAXNB - c - 1) / 2 + (d - c - 1); }      // slot of the cube pair c < d in GL_PAIR
 enum { GK_STATIC = 0, GK_BOXBOX = 1, GK_ROD = 2, GK_RODST = 3 /* rod <-> static box: a = static, b = its slot of the GL_JA rows; no cube */ };
 
 D3IL_HD void gen_sync() {     // orders the LDS / HBM traffic of the lanes of a group between two phases
@@ -542,147 +545,9 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
   }
   return converged;
 }
-// Newton solve of a single-cube island (the cube touches static boxes only): the 6-dof system lives in registers, every
-// contact record is fetched from the g area in one batch of loads per pass.  Same iteration and stopping rules as gen_solve.
-D3IL_NOINLINE inline bool gen_solve_cube(const GenConsts& gc_, const PushScratch sc, int c, int cnt, bool warm_valid) {
-  D3IL_GEN_CONSTS(gc_, gc);
-  const double impr = gc.impratio, mt = gc.box_mass, mr = gc.box_inertia;
-  double R[9], pos[3], vel[6], a0[6], x[6];
-#pragma unroll
-  for (int k = 0; k < 9; k++) R[k] = GLS(GL_R + 9 * c + k);
-#pragma unroll
-  for (int k = 0; k < 3; k++) pos[k] = GLS(GL_POS + 3 * c + k);
-#pragma unroll
-  for (int k = 0; k < 6; k++) { vel[k] = GLS(GL_VEL + 6 * c + k); a0[k] = GLS(GL_A0 + 6 * c + k); }
-#pragma unroll
-  for (int k = 0; k < 6; k++) x[k] = warm_valid ? GWARM(6 * c + k) : a0[k];
-  const int seg = GG_CON + c * GEN_SEG * GREC;
-  // rows of the contact whose record (pos[3] frame[9]) is in rc; sign: J(body 2) - J(body 1) with the static as body 1 or 2
-  auto rows_of = [&](const double* rc, double sign, double (*J)[6]) {
-    double r[3] = {rc[0] - pos[0], rc[1] - pos[1], rc[2] - pos[2]};
-#pragma unroll
-    for (int rr = 0; rr < 3; rr++) {
-      box_row_r(R, r, rc + 3 + 3 * rr, J[rr]);
-#pragma unroll
-      for (int k = 0; k < 6; k++) J[rr][k] *= sign;
-    }
-  };
-  const double mu_scale = sqrt(1 / fmax(1e-15, impr));
-  bool converged = false;
-  D3IL_STAT(g_stats.newton_calls++);
-#pragma clang loop unroll(disable)
-  for (int it = 0; it < 60 && !converged; it++) {
-    D3IL_STAT(g_stats.newton_iters++);
-    double g[6], H[21];
-#pragma unroll
-    for (int i = 0; i < 21; i++) H[i] = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { double mm = k < 3 ? mt : mr; g[k] = mm * (x[k] - a0[k]); H[tri(k, k)] = mm; }
-#pragma clang loop unroll(disable)
-    for (int q = 0; q < cnt; q++) {
-      const int base = seg + q * GREC;
-      double rc[20];
-#pragma unroll
-      for (int k = 0; k < 20; k++) rc[k] = PGS(base + k);
-      const int set = (int)rc[14];
-      double J[3][6], jar[3], force[3], Hc[9];
-      rows_of(rc, gc.st_first[set] ? 1.0 : -1.0, J);
-      if (it == 0) {   // reference acceleration and regularisation of the contact, with the rows that are needed anyway
-        double v[3];
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++) { v[rr] = 0;
-#pragma unroll
-          for (int k = 0; k < 6; k++) v[rr] += J[rr][k] * vel[k]; }
-        const double dist = rc[12], imp = impedance(gc.ct_solimp[set], dist);
-        rc[16] = -gc.ct_B[set] * v[0] - gc.ct_K[set] * imp * dist;
-        rc[17] = -gc.ct_B[set] * v[1]; rc[18] = -gc.ct_B[set] * v[2];
-        rc[19] = 1 / fmax(1e-15, (1 - imp) / imp * gc.box_invw_t);
-        PGS(base + 16) = rc[16]; PGS(base + 17) = rc[17]; PGS(base + 18) = rc[18]; PGS(base + 19) = rc[19];
-      }
-#pragma unroll
-      for (int rr = 0; rr < 3; rr++) { double a = -rc[16 + rr];
-#pragma unroll
-        for (int k = 0; k < 6; k++) a += J[rr][k] * x[k];
-        jar[rr] = a; PGS(base + 22 + rr) = a; }
-      const double Dn = rc[19], fric = gc.ct_fric[set];
-      cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
-      if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
-#pragma unroll
-      for (int k = 0; k < 6; k++) g[k] -= J[0][k] * force[0] + J[1][k] * force[1] + J[2][k] * force[2];
-      acc_block(H, 0, 0, J, J, Hc, true);
-    }
-    {
-      double gm = 0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) gm = fmax(gm, fabs(g[k]));
-      if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
-    }
-    double d[6], id[6], p[6];
-    if (!ldl_n<6>(H, d, id)) return false;
-#pragma unroll
-    for (int k = 0; k < 6; k++) p[k] = -g[k];
-    ldl_solve_n<6>(H, id, p);
-    double pMp = 0, pMa = 0, gTp = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { double mm = k < 3 ? mt : mr; pMp += mm * p[k] * p[k]; pMa += mm * p[k] * (x[k] - a0[k]); gTp += g[k] * p[k]; }
-#pragma clang loop unroll(disable)
-    for (int q = 0; q < cnt; q++) {
-      const int base = seg + q * GREC;
-      double rc[15];
-#pragma unroll
-      for (int k = 0; k < 15; k++) rc[k] = PGS(base + k);
-      double J[3][6];
-      rows_of(rc, gc.st_first[(int)rc[14]] ? 1.0 : -1.0, J);
-#pragma unroll
-      for (int rr = 0; rr < 3; rr++) { double a = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) a += J[rr][k] * p[k];
-        PGS(base + 25 + rr) = a; }
-    }
-    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
-#pragma clang loop unroll(disable)
-    for (int ls = 0; ls < 50; ls++) {
-      D3IL_STAT(g_stats.ls_iters++);
-      double d1 = pMa + alpha * pMp, d2 = pMp;
-#pragma clang loop unroll(disable)
-      for (int q = 0; q < cnt; q++) {
-        const int base = seg + q * GREC;
-        double rc[9];     // Dn | - | set? no: 19 Dn, 22..24 jar, 25..27 jp (set is field 14)
-        rc[0] = PGS(base + 19); rc[1] = PGS(base + 14);
-#pragma unroll
-        for (int k = 0; k < 6; k++) rc[2 + k] = PGS(base + 22 + k);
-        double jp[3] = {rc[5], rc[6], rc[7]};
-        double jt[3] = {rc[2] + alpha * jp[0], rc[3] + alpha * jp[1], rc[4] + alpha * jp[2]}, ft[3], Hc[9];
-        const double Dn = rc[0], fric = gc.ct_fric[(int)rc[1]];
-        cone_eval(jt, Dn, Dn * impr, fric * mu_scale, fric, ft, Hc);
-#pragma unroll
-        for (int r = 0; r < 3; r++) { d1 -= ft[r] * jp[r];
-#pragma unroll
-          for (int qq = 0; qq < 3; qq++) d2 += jp[r] * Hc[3 * r + qq] * jp[qq]; }
-      }
-      best = alpha;
-      if (ls == 0 && d1 <= D3IL_TOL.ls_full * fabs(gTp)) break;
-      if (fabs(d1) <= D3IL_TOL.ls_c2 * fabs(gTp) || fabs(d1) <= D3IL_TOL.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
-      if (d1 < 0) lo = alpha; else hi = alpha;
-      double na = alpha - d1 * rcpd(d2);
-      if (hi >= 0) {
-        double wbr = hi - lo;
-        bool slow = wbr > 0.5 * wprev;
-        wprev = wbr;
-        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
-      } else if (na <= lo) na = 2 * lo + 1;
-      if (na == alpha) break;
-      alpha = na;
-    }
-    double smax = 0, xmax = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { double dxk = best * p[k]; x[k] += dxk; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(x[k])); }
-    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
-  }
-#pragma unroll
-  for (int k = 0; k < 6; k++) GLS(GL_X + 6 * c + k) = x[k];
-  return converged;
-}
+}  // namespace d3il
+#include "gen_tree.h"
+namespace d3il {
 
 // ---- phase 1 (lane 0): arm forward pass.  Publishes M, qacc_smooth, velocities, limit rows, rod pose; leaves the arm-alone
 // solution (finger limit rows by the exact active-set solution, as in panda_step.h) at GL_X
@@ -837,8 +702,9 @@ D3IL_NOINLINE inline void gen_phase3(const GenConsts& gc_, const PushScratch sc,
     for (int k = 0; k < 9; k++) Rd[k] = GLS(GL_R + 9 * d + k);
     double rec[8][7];
     int n = box_box(pc, Rc, gc.box_half, pd, Rd, gc.box_half, 0.0, rec, 8);
+    const int first = cnt;
     for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_BOXBOX, c, d, gc.set_bb);
-    if (n > 0) partners |= 1u << d;
+    if (cnt > first) { partners |= 1u << d; GLS(GL_PAIR + gt_pair(c, d)) = (double)((unsigned)first | ((unsigned)(cnt - first) << 5)); }
   }
   {
     double rodc[3], rodu[3], r1[7];
@@ -930,7 +796,10 @@ D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, 
 }
 // ---- phase 4: islands.  Every lane derives the connected components of {cubes, arm} under cube-cube and rod contacts from the
 // per-cube info words (identical result in all lanes), in the order of their first block, with their storage offsets.
-struct IslSet { Isl isl[GEN_MAXNB + 1]; unsigned cpk[GEN_MAXNB + 1]; int first[GEN_MAXNB + 1]; int n; };
+#if defined(D3IL_HOST_STATS)
+inline long g_isl_hist[80] = {0};      // host diagnostics: joint solves by island shape (cubes + 5 arm + 10 min(rod contacts, 3)); [40 + key]: their Newton iterations
+#endif
+struct IslSet { Isl isl[GEN_MAXNB + 1]; unsigned cpk[GEN_MAXNB + 1]; int first[GEN_MAXNB + 1]; bool fast[GEN_MAXNB + 1]; int n; };      // fast: a tree island, solved by gen_tree_solve
 template <bool RS>
 D3IL_HD void gen_islands(const GenConsts& gc_, const PushScratch sc, IslSet& out) {
   D3IL_GEN_CONSTS(gc_, gc);
@@ -966,32 +835,23 @@ D3IL_HD void gen_islands(const GenConsts& gc_, const PushScratch sc, IslSet& out
     int k = 0;
 #pragma unroll
     for (int d = 0; d <= GEN_MAXNB; d++) if ((mask >> d) & 1) { cpk |= cnt[d] << (5 * k); k++; }
+    {
+      unsigned cadj[GEN_MAXNB], rodm = 0;
+#pragma unroll
+      for (int d = 0; d < GEN_MAXNB; d++) { cadj[d] = adj[d] & ((1u << nb) - 1u); if ((adj[d] >> nb) & 1) rodm |= 1u << d; }
+      const unsigned cm = mask & ((1u << nb) - 1u);
+      out.fast[out.n] = cm != 0 && gt_island_fast(cadj, rodm, cm, nb, GLS(GL_TR) != 0.0);
+    }
     out.isl[out.n] = t; out.cpk[out.n] = cpk; out.first[out.n] = b; out.n++;
     hoff += t.m * (t.m + 1) / 2; voff += t.m;
   }
 }
-// phase 4a (lane l): a cube that forms an island on its own is solved by its lane - register-resident 6-dof Newton over its
-// static contacts (no contact: x = a0)
 D3IL_HD bool gen_uncoupled(const GenConsts& gc_, const PushScratch sc) {   // no cube-cube and no rod contact in this environment
   D3IL_GEN_CONSTS(gc_, gc);
   unsigned c = 0;
 #pragma unroll
   for (int b = 0; b < GEN_MAXNB; b++) if (b < gc.nb) c |= (unsigned)GLS(GL_INFO + b) >> 5;
   return c == 0;
-}
-template <bool RS>
-D3IL_HD void gen_phase4_single(const GenConsts& gc_, const PushScratch sc, int l, bool warm_valid, unsigned& fl) {
-  D3IL_GEN_CONSTS(gc_, gc);
-  int cnt = -1;                                   // contact count of cube l when it is an island on its own
-  if (gen_uncoupled(gc, sc)) cnt = (int)((unsigned)GLS(GL_INFO + l) & 31u);      // the usual case: no island bookkeeping needed
-  else {
-    IslSet is;
-    gen_islands<RS>(gc, sc, is);
-#pragma unroll
-    for (int k = 0; k <= GEN_MAXNB; k++) if (k < is.n && is.first[k] == l && is.isl[k].n == 1 && l < gc.nb) cnt = (int)(is.cpk[k] & 31u);
-  }
-  if (cnt == 0) for (int j = 0; j < 6; j++) GLS(GL_X + 6 * l + j) = GLS(GL_A0 + 6 * l + j);
-  else if (cnt > 0 && !gen_solve_cube(gc, sc, l, cnt, warm_valid)) fl |= F_SOLVER_FAIL;
 }
 // The arm on its own with ONE rod <-> static box contact and no arm joint at a limit (the rod pressing on a wall of a gate): the situation of the
 // Avoiding task's rod <-> obstacle contact, solved the same way - panda_step.h's register-resident Newton in the 5-dimensional constraint space
@@ -1061,6 +921,7 @@ D3IL_HD void gen_phase4_multi(const GenConsts& gc_, const PushScratch sc, int l,
 #pragma unroll
   for (int k = 0; k <= GEN_MAXNB; k++) if (k < is.n) {
     const bool arm_alone = is.isl[k].n == 1 && is.isl[k].arm;
+    if (is.fast[k]) continue;      // solved by the tree solver (gen_tree.h)
     if (is.isl[k].n > 1 || (arm_alone && (GLS(GL_INFO + 4) != 0 || (RS && GLS(GL_INFO + 8) != 0)))) { todo |= (unsigned)k << (4 * ntodo); ntodo++; }
   }
   for (int j = 0; j < ntodo; j++) {
@@ -1076,7 +937,15 @@ D3IL_HD void gen_phase4_multi(const GenConsts& gc_, const PushScratch sc, int l,
     }
     GEN_FOR_DOFS(ci, gi) GLS(GL_X + gi) = warm_valid ? GWARM(gi) : GLS(GL_A0 + gi);      // identical stores from every lane
     gen_sync();
+#if defined(D3IL_HOST_STATS)
+    int hkey_ = 0; long hit0_ = g_stats.newton_iters;
+    { int nrod = 0; GEN_FOR_BLOCKS(b) if (b < gc.nb && (((unsigned)GLS(GL_INFO + b) >> 9) & 1)) nrod++;
+      hkey_ = (isl.n - (isl.arm ? 1 : 0)) + (isl.arm ? 5 : 0) + 10 * (nrod > 3 ? 3 : nrod); g_isl_hist[hkey_]++; }
+#endif
     if (!gen_solve<RS>(gc, sc, isl, cpk, l, nl)) fl |= F_SOLVER_FAIL;
+#if defined(D3IL_HOST_STATS)
+    g_isl_hist[40 + hkey_] += g_stats.newton_iters - hit0_;
+#endif
     gen_sync();
   }
 }
@@ -1090,10 +959,25 @@ D3IL_HD void gen_phase5_arm(const C& c0, const GenConsts& gc_, EnvState& st, con
   double M[45], xa[NDOF], rhs[NDOF], L[45], d[NDOF], id[NDOF];
 #pragma unroll
   for (int i = 0; i < 45; i++) M[i] = GLS(GL_M + i);
+  const bool via_lambda = GLS(GL_TR) == 2.0;      // the arm's island went through the tree solver: x_a = a0 + M^-1 W' lambda, i.e. M x_a = M a0 + W' lambda
 #pragma unroll
-  for (int k = 0; k < NDOF; k++) { xa[k] = GLS(GL_X + arm0 + k); GWARM(arm0 + k) = xa[k]; }
+  for (int k = 0; k < NDOF; k++) xa[k] = GLS(via_lambda ? GL_A0 + arm0 + k : GL_X + arm0 + k);
   symv9(M, xa, rhs);
   if (!ldl9(M, L, d, id)) st.flags |= F_SOLVER_FAIL;
+  if (via_lambda) {
+    int rb = 0;
+#pragma unroll
+    for (int b = 0; b < GEN_MAXNB; b++) if (b < gc.nb && (((unsigned)GLS(GL_INFO + b) >> 9) & 1)) rb = b;
+#pragma unroll
+    for (int k = 0; k < NARM; k++) rhs[k] += GLS(GL_JA + 21 * rb + k) * GLS(GL_TR + 1) + GLS(GL_JA + 21 * rb + 7 + k) * GLS(GL_TR + 2) + GLS(GL_JA + 21 * rb + 14 + k) * GLS(GL_TR + 3);
+#pragma unroll
+    for (int f = 0; f < NFING; f++) { const double sg = GLS(GL_LIM + 3 * (NARM + f)); rhs[NARM + f] += (sg != 0 ? sg : 1.0) * GLS(GL_TR + 4 + f); }
+#pragma unroll
+    for (int k = 0; k < NDOF; k++) xa[k] = rhs[k];
+    ldl9_solve(L, id, xa);
+  }
+#pragma unroll
+  for (int k = 0; k < NDOF; k++) GWARM(arm0 + k) = xa[k];
   double hb0 = h * c.f_damping[0], hb1 = h * c.f_damping[1];
   double l87 = L[tri(8, 7)];
   double S11 = d[8] + l87 * l87 * d[7];
@@ -1140,7 +1024,8 @@ D3IL_HD void gen_physics_substep_t(const C& c0, const GenConsts& gc_, EnvState& 
   for (int l = 0; l < gc.nb; l++) gen_phase3(gc, sc, l, cnt[l], c.rod_r, c.rod_h, fl);
   if (RS && gc.rod_static) for (int l = 0; l < gc.nb; l++) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, fl);
   gen_phase3b<RS>(c0, gc, st, sc, gc.nb, fl);
-  for (int l = 0; l < gc.nb; l++) gen_phase4_single<RS>(gc, sc, l, warm_valid, fl);
+  gen_arm_reduce<RS>(gc, sc, warm_valid);
+  fl |= gen_tree_solve<GEN_MAXNB>(gc, sc, 0, warm_valid);
   gen_phase4_multi<RS>(gc, sc, 0, 1, warm_valid, fl);
   gen_phase5_arm(c0, gc, st, sc);
   for (int l = 0; l < gc.nb; l++) gen_phase5_cube(gc, sc, l, c.timestep);

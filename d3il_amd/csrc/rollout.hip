@@ -665,6 +665,7 @@ struct d3il_handle_s {
   d3il_buffers buf;
   bool fast, timing;
   int split;              // -1 auto, 0 fused single-wave kernel, 1 two-wave (controller || physics) kernel
+  bool serve_avail;       // the device grants the LDS the three-wave form needs
   int serve_max_wg;       // the split kernel runs with its third wave (rare constraint paths) up to this many workgroups (one per CU); 0: never
   int lanes;              // active lanes (environments) per wave: 64, or fewer to spread a small batch over more SIMDs
   int lds_pad;            // dynamic LDS bytes requested per workgroup: spreads the single-wave workgroups over CUs
@@ -739,7 +740,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   const d3il_model_blob& m = *(const d3il_model_blob*)model_blob;
   if (task_id != m.task_id) return fail(D3IL_EINVAL, "d3il_create: task_id does not match the model blob");
   if (task_id != D3IL_TASK_AVOIDING && task_id != D3IL_TASK_PUSHING && task_id != D3IL_TASK_SORTING && task_id != D3IL_TASK_STACKING && task_id != D3IL_TASK_ALIGNING && task_id != D3IL_TASK_INSERTING)
-    return fail(D3IL_EUNSUPPORTED, "d3il_create: unknown task id (Avoiding, Pushing, Sorting, Stacking and Aligning are implemented)");
+    return fail(D3IL_EUNSUPPORTED, "d3il_create: unknown task id (Avoiding, Pushing, Sorting, Stacking, Aligning and Inserting are implemented)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(D3IL_ENODEVICE, "d3il_create: no HIP device available (there is no CPU fallback)");
   if (device_id < 0 || device_id >= ndev || device_id >= 16) return fail(D3IL_ENODEVICE, "d3il_create: device_id out of range");
@@ -808,7 +809,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     }
   }
   h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE;
-  h->started = false; h->split = -1; h->serve_max_wg = 256; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false;
+  h->started = false; h->split = -1; h->serve_avail = true; h->serve_max_wg = 256; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false;
   const bool aligning = task_id == D3IL_TASK_ALIGNING;
   h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : (stacking ? SK_STATE_F64 : (aligning ? AL_STATE_F64 : D3IL_STATE_F64)));
   h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : (stacking ? 21 : (aligning ? AL_CTX : 0)));
@@ -816,7 +817,13 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   d3il_buffers& b = h->buf;
   b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : (aligning ? AL_OBS : 2))); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = (pushing || aligning) ? 2 : (stacking ? 1 : 0);
   HIPCHK_H(hipMalloc(&h->dc, sizeof(PandaConsts)));
-  if (task_id == D3IL_TASK_AVOIDING) HIPCHK_H(hipFuncSetAttribute((const void*)k_avoiding_step_split<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AVOID_LDS_SERVE));
+  if (task_id == D3IL_TASK_AVOIDING) {
+    // the three-wave form needs AVOID_LDS_SERVE of dynamic LDS on top of its static LDS; a device that cannot grant it runs the two-wave form
+    if (hipFuncSetAttribute((const void*)k_avoiding_step_split<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AVOID_LDS_SERVE) != hipSuccess) {
+      (void)hipGetLastError();
+      h->serve_avail = false; h->serve_max_wg = 0;
+    }
+  }
   HIPCHK_H(hipMemcpy(h->dc, &h->hc, sizeof(PandaConsts), hipMemcpyHostToDevice));
   HIPCHK_H(hipMalloc(&h->d_init_qpos, 7 * sizeof(double)));
   HIPCHK_H(hipMalloc(&b.obs, S * b.obs_dim * sizeof(float)));
@@ -894,8 +901,6 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
       std::lock_guard<std::mutex> lock(g_model_mutex);
       h->kc_id = ++g_kc_counter;
     }
-    HIPCHK_H(hipDeviceSynchronize());
-    HIPCHK_H(hipMemcpyToSymbol(HIP_SYMBOL(g_align_task), &h->atk, sizeof(AlignTask)));
     HIPCHK_H(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
     HIPCHK_H(hipMalloc(&h->d_scratch, S * SG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * SG_SIZE * sizeof(double)));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_aligning_step, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
@@ -928,7 +933,16 @@ int d3il_start(d3il_handle h, const double* init_qpos7) {
 // below) from here until its kernel launch has been enqueued: otherwise a second host thread whose handle has other constants could reload the object
 // between this handle's check and its launch.  A reload waits for everything in flight on the device first (hipDeviceSynchronize), so a
 // kernel already launched keeps the constants it was launched with.
+static AlignTask g_align_loaded[16];
+static bool g_align_loaded_valid[16];
 static int sync_stack_consts_locked(d3il_handle_s* h) {
+  if (h->task_id == D3IL_TASK_ALIGNING && (!g_align_loaded_valid[h->device] || std::memcmp(&g_align_loaded[h->device], &h->atk, sizeof(AlignTask)) != 0)) {
+    // the Aligning thresholds are a per-device __constant__ object like the engine constants: a handle whose blob carries other thresholds reloads them
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_align_task), &h->atk, sizeof(AlignTask)));
+    HIPCHK(hipDeviceSynchronize());
+    g_align_loaded[h->device] = h->atk; g_align_loaded_valid[h->device] = true;
+  }
   if (g_stack_loaded_id[h->device] == h->kc_id) return D3IL_OK;
   if (g_stack_loaded_id[h->device] != 0 && std::memcmp(&g_stack_loaded[h->device], &h->kc, sizeof(StackConsts)) == 0) { g_stack_loaded_id[h->device] = h->kc_id; return D3IL_OK; }
   HIPCHK(hipDeviceSynchronize());
@@ -1427,7 +1441,7 @@ int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (std::strcmp(name, "stack_reset_coop") == 0) { h->stack_reset_coop = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "push_coop") == 0) { h->push_coop = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "split_waves") == 0) { h->split = value; return D3IL_OK; }
-  if (std::strcmp(name, "serve_wave_max_workgroups") == 0) { if (value < 0) return fail(D3IL_EINVAL, "serve_wave_max_workgroups must be >= 0"); h->serve_max_wg = value; return D3IL_OK; }
+  if (std::strcmp(name, "serve_wave_max_workgroups") == 0) { if (value < 0) return fail(D3IL_EINVAL, "serve_wave_max_workgroups must be >= 0"); h->serve_max_wg = h->serve_avail ? value : 0; return D3IL_OK; }
   if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }
   if (std::strcmp(name, "lanes_per_wave") == 0) { if (value < 1 || value > WAVE) return fail(D3IL_EINVAL, "lanes_per_wave must be in 1..64"); h->lanes = value; return D3IL_OK; }
   return fail(D3IL_EINVAL, std::string("d3il_set_option: unknown option ") + name);

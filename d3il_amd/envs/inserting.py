@@ -87,13 +87,16 @@ class GateInsertionVecEnv(ObstacleAvoidanceVecEnv):
         boxes have been in their goals), the n-box successes are the number of letters in the env's ``modes`` list >= n."""
         if action.device != self.device or action.dtype != torch.float64 or tuple(action.shape) != (self.n_envs, 7) or not action.is_contiguous():
             raise ValueError("action must be a contiguous float64 tensor of shape (%d, 7) on %s" % (self.n_envs, self.device))
+        # obs / reward / done are sampled BEFORE the sub-steps (GymEnvWrapper.step, gym_env_wrapper.py:88-93): the reward of this call belongs to
+        # the state the step starts from, like the obs / done the kernel writes (sort_step_begin)
+        reward = self.get_reward()
         with torch.cuda.device(self.device):
             capi.check(self.L.d3il_step(self.h, C.c_void_p(action.data_ptr()), self._stream()))
         code = self.mode.to(torch.int32)
         nm = code >> 3
         info = dict(success=self.success, mean_distance=self.state[self.task_row + 1, :self.n_envs], mode=code & 7,
                     one_box_success=(nm >= 1).to(torch.uint8), two_box_success=(nm >= 2).to(torch.uint8), three_box_success=(nm >= 3).to(torch.uint8))
-        return self.obs, self.get_reward(), self.done, info
+        return self.obs, reward, self.done, info
 
     def get_reward(self):
         """-(min distance robot <-> box in xy + the three 3-D box <-> target distances) (gate_insertion.py:448-473), from the state buffer."""

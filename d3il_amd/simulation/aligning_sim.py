@@ -96,11 +96,14 @@ class Aligning_Sim(BaseSim):
         log.info("Successrate %s entropy %s mean distance %s", success_rate, entropy, float(dist_sum.item()) / total)
         if env is not None:
             env.close()
-        # the reference returns the full [n_contexts, n_trajectories] tables (aligning_sim.py:204)
+        # the reference returns (success_rate, mode_encoding[n_contexts, n_trajectories]) (aligning_sim.py:205); its tables are zero-initialised, so a
+        # rollout that never reported a mode reads 0 there.  The full tables stay available in self.last_rollout (+ "tables" below).
         full = torch.zeros(3, total, dtype=torch.float64, device=dev)
-        full[0, lo:hi], full[1, lo:hi], full[2, lo:hi] = success.to(torch.float64), mode.to(torch.float64), torch.nan_to_num(mean_distance, nan=0.0)
+        full[0, lo:hi], full[1, lo:hi], full[2, lo:hi] = success.to(torch.float64), mode.clamp_min(0).to(torch.float64), torch.nan_to_num(mean_distance, nan=0.0)
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(full)
         shape = (self.n_contexts, self.n_trajectories_per_context)
-        return full[0].to(torch.float32).reshape(shape), full[1].to(torch.float32).reshape(shape), full[2].to(torch.float32).reshape(shape)
+        self.last_rollout["tables"] = dict(successes=full[0].to(torch.float32).reshape(shape), mode_encoding=full[1].to(torch.float32).reshape(shape),
+                                           mean_distance=full[2].to(torch.float32).reshape(shape))
+        return success_rate, self.last_rollout["tables"]["mode_encoding"]

@@ -161,6 +161,7 @@ void hc_gen_step(void* h, double* s, int* f, const double* action, float* obs, u
   else gen_env_step<false>(p->c, p->gc, st, sc, action, obs, done, mode_code, p->c.n_substeps, p->c.max_steps);
   pack(st, s, f);
 }
+void hc_gen_island_hist(long* out, int reset) { for (int k = 0; k < 80; k++) { out[k] = g_isl_hist[k]; if (reset) g_isl_hist[k] = 0; } }
 void hc_gen_substep(void* h, double* s, int* f, const double* tau, const double* ffing) {
   GenHost* p = (GenHost*)h; EnvState st; unpack(s, f, st);
   PushScratch sc{p->h, p->g, 1, s + 42, 1};

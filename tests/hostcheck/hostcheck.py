@@ -11,7 +11,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libd3il_hostcheck.so")
-    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "push_step.h", "gen_step.h", "stack_step.h")]
+    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "push_step.h", "gen_step.h", "gen_tree.h", "stack_step.h")]
     srcs.append(os.path.join(_HERE, "..", "..", "include", "d3il_model_blob.h"))
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])

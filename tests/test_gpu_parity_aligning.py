@@ -224,8 +224,10 @@ def test_sim_tables_against_whole_oracle_episodes(ctx60):
     from d3il_amd.simulation.aligning_sim import Aligning_Sim
     from tests import oracle_episodes as oe
     sim = Aligning_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=60, n_trajectories_per_context=1, max_steps_per_episode=400)
-    sim.test_agent(ScriptedAlignPolicy(inside=np.arange(60) % 2 == 0, device="cuda:0"))
+    ret = sim.test_agent(ScriptedAlignPolicy(inside=np.arange(60) % 2 == 0, device="cuda:0"))
     r = sim.last_rollout
+    # the reference's return signature (aligning_sim.py:205): (success_rate, mode_encoding[n_contexts, n_trajectories])
+    assert len(ret) == 2 and isinstance(ret[0], float) and tuple(ret[1].shape) == (60, 1) and ret[0] == r["success_rate"]
     assert not (r["flags"].cpu().numpy() & BAD).any()
     dev_rows = list(zip(r["success"].cpu().numpy().astype(bool).tolist(), r["mode"].cpu().numpy().tolist()))
     env = _env(1)

@@ -133,6 +133,12 @@ def test_reset_matches_oracle_and_protocol(ins_blob, ins_init_qpos):
     tcp = env.robot_state().cpu().numpy()
     want = -(np.linalg.norm(p[:, :, :2] - tcp[:, None, :2], axis=2).min(1) + np.linalg.norm(p - tg[None], axis=2).sum(1))
     np.testing.assert_allclose(env.get_reward().cpu().numpy(), want, atol=1e-12)
+    # the reward a step returns is sampled BEFORE its physics, like obs / done (gym_env_wrapper.py:88-93)
+    des = des + 0.004
+    pre = env.get_reward().clone()
+    _, rew, _, _ = env.step(_action(des, z))
+    torch.cuda.synchronize()
+    assert torch.equal(rew, pre) and not torch.equal(env.get_reward(), pre)
     env.close()
 
 

@@ -15,7 +15,7 @@ des = env.robot_state()[:, :2].clone(); z = env.robot_state()[:, 2:3].clone()
 quat = torch.tensor([0.0, 1, 0, 0], dtype=torch.float64, device=env.device).expand(n, 4)
 NW = (n + 15) // 16
 W = np.zeros((NW, 10), dtype=np.uint64)
-names = ["p1.arm", "p2.statics", "p3.bb+rod", "s.setup", "s.grad+H", "s.chol", "s.jp", "s.linesearch", "p4.single", "p4.multi"]
+names = ["p1.arm", "p2.statics", "p3.bb+rod+reduce", "t.setup", "t.grad+H", "t.elim+solve", "t.jp", "t.linesearch+step", "p4.tree(total)", "p4.generic"]      # slots 3..7: inside the tree solver (gen_tree.h; the rare generic solves add to them)
 for t in range(60):
     box = env.obs[:, 2:4].to(torch.float64)
     if t >= 12:
