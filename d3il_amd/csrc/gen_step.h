@@ -390,6 +390,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
   int buf = 0;
   PUSH_TOC(3);
   D3IL_STAT(g_stats.newton_calls++);
+  PUSH_CNT(7);
   D3IL_STAT(g_stats.eig_calls += isl.m);
   for (int it = 0; it < 60 && !converged; it++) {
     D3IL_STAT(g_stats.newton_iters++);

@@ -173,29 +173,75 @@ D3IL_NOINLINE inline void gen_arm_reduce(const GenConsts& gc_, const PushScratch
   GLS(GL_TR) = 1.0;
 }
 
-// rows of cube c (rotation / centre in the t area) for the contact frame fr at point pos, times sign
-D3IL_HD void gt_rows(const PushScratch sc, int c, const double* pos, const double* fr, double sign, double (*J)[6]) {
-  double R[9], r[3];
+// ---- contact terms in point form.  Inside the solve a cube's six unknowns are its linear acceleration and its angular acceleration in WORLD axes
+// (the cubes' inertia is isotropic - build_gen_consts checks it -, so the smooth block m I | i I is the same in both frames; the iterate is turned
+// into the body axes of the free joint once, when the solve ends).  With r = contact position - cube centre the acceleration of the cube's material
+// point is  G y = y_lin + y_ang x r, G = [I, -[r]x], and a contact row is  sign f' G: everything a contact contributes follows from 3-vectors -
+//   jar = F u - aref,  u = sum over the two bodies of sign G y;    w = F' force,  S = F' Hc F  (world 3 x 3);
+//   gradient  -= sign [w, r x w];    diagonal block += G' S G = [S, -P; -P', Q],  P = S [r]x,  Q = -[r]x P;
+//   block between two bodies (signs multiply to -1)  = -[S, -Pc; -Pp', -[rp]x Pc]
+// - about a quarter of the multiply-adds of the 3 x 6 row form J' Hc J.
+D3IL_HD void gt_point(const double* y, const double* r, double sgn, double* u) {       // u += sgn (y_lin + y_ang x r)
+  u[0] += sgn * (y[0] + y[4] * r[2] - y[5] * r[1]);
+  u[1] += sgn * (y[1] + y[5] * r[0] - y[3] * r[2]);
+  u[2] += sgn * (y[2] + y[3] * r[1] - y[4] * r[0]);
+}
+D3IL_HD void gt_point_lds(const PushScratch sc, int off, const double* r, double sgn, double* u) {     // the same with y in the t area
+  double y[6];
 #pragma unroll
-  for (int k = 0; k < 9; k++) R[k] = GLS(GL_R + 9 * c + k);
+  for (int k = 0; k < 6; k++) y[k] = GLS(off + k);
+  gt_point(y, r, sgn, u);
+}
+D3IL_HD void gt_world_S(const double* F, const double* Hc, double* S) {      // S = F' Hc F, full 3 x 3 (symmetric)
+  double T[9];
 #pragma unroll
-  for (int k = 0; k < 3; k++) r[k] = pos[k] - GLS(GL_POS + 3 * c + k);
+  for (int a = 0; a < 3; a++)
 #pragma unroll
-  for (int rr = 0; rr < 3; rr++) {
-    box_row_r(R, r, fr + 3 * rr, J[rr]);
+    for (int j = 0; j < 3; j++) T[3 * a + j] = Hc[3 * a] * F[j] + Hc[3 * a + 1] * F[3 + j] + Hc[3 * a + 2] * F[6 + j];
 #pragma unroll
-    for (int k = 0; k < 6; k++) J[rr][k] *= sign;
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = i; j < 3; j++) { const double s = F[i] * T[j] + F[3 + i] * T[3 + j] + F[6 + i] * T[6 + j]; S[3 * i + j] = s; S[3 * j + i] = s; }
+}
+D3IL_HD void gt_SxR(const double* S, const double* r, double* P) {            // P = S [r]x
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    P[3 * i] = S[3 * i + 1] * r[2] - S[3 * i + 2] * r[1];
+    P[3 * i + 1] = S[3 * i + 2] * r[0] - S[3 * i] * r[2];
+    P[3 * i + 2] = S[3 * i] * r[1] - S[3 * i + 1] * r[0];
   }
 }
-// X(j, i) += sum_rs B(r, j) Hc(r, s) J(s, i): the block [rows: parent dofs j, columns: own dofs i]
-D3IL_HD void gt_acc_off(double* X, const double (*B)[6], const double (*J)[6], const double* Hc) {
+D3IL_HD void gt_add_diag(double* H, const double* S, const double* P, const double* r) {      // packed lower 6 x 6 += G' S G
 #pragma unroll
-  for (int j = 0; j < 6; j++) {
-    double tb[3];
+  for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int s = 0; s < 3; s++) tb[s] = B[0][j] * Hc[s] + B[1][j] * Hc[3 + s] + B[2][j] * Hc[6 + s];
+    for (int j = 0; j <= i; j++) H[tri(i, j)] += S[3 * i + j];
 #pragma unroll
-    for (int i = 0; i < 6; i++) X[6 * j + i] += tb[0] * J[0][i] + tb[1] * J[1][i] + tb[2] * J[2][i];
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int l = 0; l < 3; l++) H[tri(3 + a, l)] -= P[3 * l + a];
+  // Q(:, j) = -(r x P(:, j)), lower part
+  H[tri(3, 3)] -= r[1] * P[6] - r[2] * P[3];
+  H[tri(4, 3)] -= r[2] * P[0] - r[0] * P[6];
+  H[tri(5, 3)] -= r[0] * P[3] - r[1] * P[0];
+  H[tri(4, 4)] -= r[2] * P[1] - r[0] * P[7];
+  H[tri(5, 4)] -= r[0] * P[4] - r[1] * P[1];
+  H[tri(5, 5)] -= r[0] * P[5] - r[1] * P[2];
+}
+// X(j, i), rows: the parent's unknowns j, columns: this cube's i, += sg Gp' S Gc  (sg = product of the two signs); Pc = S [rc]x
+D3IL_HD void gt_add_off(double* X, const double* S, const double* Pc, const double* rp, double sg) {
+  double Pp[9];
+  gt_SxR(S, rp, Pp);
+#pragma unroll
+  for (int l = 0; l < 3; l++) {
+#pragma unroll
+    for (int m = 0; m < 3; m++) { X[6 * l + m] += sg * S[3 * l + m]; X[6 * l + 3 + m] -= sg * Pc[3 * l + m]; X[6 * (3 + l) + m] -= sg * Pp[3 * m + l]; }
+  }
+#pragma unroll
+  for (int b = 0; b < 3; b++) {      // -(rp x Pc(:, b))
+    X[6 * 3 + 3 + b] -= sg * (rp[1] * Pc[6 + b] - rp[2] * Pc[3 + b]);
+    X[6 * 4 + 3 + b] -= sg * (rp[2] * Pc[b] - rp[0] * Pc[6 + b]);
+    X[6 * 5 + 3 + b] -= sg * (rp[0] * Pc[3 + b] - rp[1] * Pc[b]);
   }
 }
 D3IL_HD double gt_symdot5(const double* A, const double* u, const double* v) {     // u' A v, A packed lower 5 x 5
@@ -205,6 +251,21 @@ D3IL_HD double gt_symdot5(const double* A, const double* u, const double* v) {  
 #pragma unroll
     for (int c = 0; c < 5; c++) s += u[r] * A[r >= c ? tri(r, c) : tri(c, r)] * v[c];
   return s;
+}
+// world axes <-> body axes of cube b's angular unknowns (R row-major, columns = body axes)
+D3IL_HD void gt_to_world(const PushScratch sc, int b, double* y) {
+  double R[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = GLS(GL_R + 9 * b + k);
+  const double a = y[3], bb = y[4], c = y[5];
+  y[3] = R[0] * a + R[1] * bb + R[2] * c; y[4] = R[3] * a + R[4] * bb + R[5] * c; y[5] = R[6] * a + R[7] * bb + R[8] * c;
+}
+D3IL_HD void gt_to_body(const PushScratch sc, int b, double* y) {
+  double R[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = GLS(GL_R + 9 * b + k);
+  const double a = y[3], bb = y[4], c = y[5];
+  y[3] = R[0] * a + R[3] * bb + R[6] * c; y[4] = R[1] * a + R[4] * bb + R[7] * c; y[5] = R[2] * a + R[5] * bb + R[8] * c;
 }
 
 #define GT_FOR(li) for (int li = 0; li < NL; li++)
@@ -229,7 +290,7 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
   const double impr = gc.impratio, mu_scale = sqrt(1 / fmax(1e-15, impr)), mt = gc.box_mass, mr = gc.box_inertia;
   const double grav2 = GLS(GL_A0 + 2);                 // every cube's smooth acceleration is gravity (gen_phase2)
   PUSH_TIC;
-  // ---- start point; reference acceleration and regularisation of the lane's own records
+  // ---- start point (world axes, see above); the cubes' velocities in world axes are published at GL_P for the partners' reference accelerations
   GT_FOR(li) {
     GTLane& T = t[li];
 #pragma unroll
@@ -242,11 +303,30 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
       for (int k = 0; k < 6; k++) GLS(GL_X + 6 * T.b + k) = GLS(GL_A0 + 6 * T.b + k);
       continue;
     }
+    gt_to_world(sc, T.b, T.x);
 #pragma unroll
     for (int k = 0; k < 6; k++) GLS(GL_X + 6 * T.b + k) = T.x[k];
+  }
+  GT_FOR(li) {
+    GTLane& T = t[li];
+    if (l0 + li >= gc.nb) continue;
     double vel[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) vel[k] = GLS(GL_VEL + 6 * T.b + k);
+    gt_to_world(sc, T.b, vel);
+#pragma unroll
+    for (int k = 0; k < 6; k++) GLS(GL_P + 6 * T.b + k) = vel[k];
+  }
+  gen_sync();
+  // ---- reference acceleration and regularisation of the lane's own records
+  GT_FOR(li) {
+    GTLane& T = t[li];
+    if (!T.active) continue;
+    double vel[6], pc[3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) vel[k] = GLS(GL_P + 6 * T.b + k);
+#pragma unroll
+    for (int k = 0; k < 3; k++) pc[k] = GLS(GL_POS + 3 * T.b + k);
 #pragma clang loop unroll(disable)
     for (int q = 0; q < T.cnt; q++) {
       const int base = GG_CON + (T.b * GEN_SEG + q) * GREC;
@@ -256,20 +336,16 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
       const int kind = (int)rec[13], a = (int)rec[14], bb = (int)rec[15];
       const int set = kind == GK_STATIC ? a : (kind == GK_BOXBOX ? gc.set_bb : gc.set_rod);
       const double invw = kind == GK_STATIC ? gc.box_invw_t : (kind == GK_BOXBOX ? 2 * gc.box_invw_t : gc.box_invw_t + gc.rod_invw);
-      double J[3][6], v[3];
-      gt_rows(sc, T.b, rec, rec + 3, kind == GK_STATIC ? (gc.st_first[a] ? 1.0 : -1.0) : -1.0, J);
-#pragma unroll
-      for (int r = 0; r < 3; r++) { v[r] = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) v[r] += J[r][k] * vel[k]; }
+      const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]};
+      double u[3] = {0, 0, 0}, v[3];
+      gt_point(vel, r1, kind == GK_STATIC ? (gc.st_first[a] ? 1.0 : -1.0) : -1.0, u);
       if (kind == GK_BOXBOX) {
-        double B[3][6];
-        gt_rows(sc, bb, rec, rec + 3, 1.0, B);
+        const double r2[3] = {rec[0] - GLS(GL_POS + 3 * bb), rec[1] - GLS(GL_POS + 3 * bb + 1), rec[2] - GLS(GL_POS + 3 * bb + 2)};
+        gt_point_lds(sc, GL_P + 6 * bb, r2, 1.0, u);
+      }
 #pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int k = 0; k < 6; k++) v[r] += B[r][k] * GLS(GL_VEL + 6 * bb + k);
-      } else if (kind == GK_ROD) {
+      for (int r = 0; r < 3; r++) v[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2];
+      if (kind == GK_ROD) {
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -287,6 +363,7 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
   int buf = 0;
   bool any = false;
   GT_FOR(li) any = any || t[li].active;
+  if (any) PUSH_CNT(6);
 #pragma clang loop unroll(disable)
   for (int it = 0; it < 60 && any; it++) {
     // ---- gradient and Hessian blocks at x: smooth part, own records, the cube <-> cube records of lower partners, the lambda node
@@ -294,6 +371,7 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
       GTLane& T = t[li];
       if (!T.active) continue;
       D3IL_STAT(g_stats.newton_iters++);
+      PUSH_CNT(0);
 #pragma unroll
       for (int i = 0; i < 21; i++) T.H[i] = 0;
 #pragma unroll
@@ -302,6 +380,9 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
       for (int k = 0; k < 6; k++) { const double mm = k < 3 ? mt : mr; T.g[k] = mm * (T.x[k] - (k == 2 ? grav2 : 0.0)); T.H[tri(k, k)] = mm; }
 #pragma unroll
       for (int k = 0; k < 5; k++) T.fl5[k] = 0;
+      double pc[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pc[k] = GLS(GL_POS + 3 * T.b + k);
 #pragma clang loop unroll(disable)
       for (int q = 0; q < T.cnt; q++) {
         const int base = GG_CON + (T.b * GEN_SEG + q) * GREC;
@@ -310,80 +391,96 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
         for (int k = 0; k < 20; k++) rec[k] = PGS(base + k);
         const int kind = (int)rec[13], a = (int)rec[14], bb = (int)rec[15];
         const int set = kind == GK_STATIC ? a : (kind == GK_BOXBOX ? gc.set_bb : gc.set_rod);
-        double J[3][6], B[3][6], jar[3], force[3], Hc[9];
-        gt_rows(sc, T.b, rec, rec + 3, kind == GK_STATIC ? (gc.st_first[a] ? 1.0 : -1.0) : -1.0, J);
-#pragma unroll
-        for (int r = 0; r < 3; r++) { double s = -rec[16 + r];
-#pragma unroll
-          for (int k = 0; k < 6; k++) s += J[r][k] * T.x[k];
-          jar[r] = s; }
+        PUSH_CNT(1);
+        const double sg = kind == GK_STATIC ? (gc.st_first[a] ? 1.0 : -1.0) : -1.0;
+        const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]};
+        double r2[3] = {0, 0, 0}, u[3] = {0, 0, 0}, jar[3], force[3], Hc[9], B[3][5];
+        gt_point(T.x, r1, sg, u);
         bool off = false;
         if (kind == GK_BOXBOX) {
-          gt_rows(sc, bb, rec, rec + 3, 1.0, B);
 #pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int k = 0; k < 6; k++) jar[r] += B[r][k] * GLS(GL_X + 6 * bb + k);
+          for (int k = 0; k < 3; k++) r2[k] = rec[k] - GLS(GL_POS + 3 * bb + k);
+          gt_point_lds(sc, GL_X + 6 * bb, r2, 1.0, u);
           off = bb == T.parent;
-        } else if (kind == GK_ROD) {      // the arm through the lambda node: J_a x_a = A(r, :) lambda + J_a a0
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) jar[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2] - rec[16 + r];
+        if (kind == GK_ROD) {      // the arm through the lambda node: J_a x_a = A(r, :) lambda + J_a a0
 #pragma unroll
           for (int r = 0; r < 3; r++) {
             double s = GLS(GT_CA + r);
 #pragma unroll
             for (int k = 0; k < 5; k++) { const double ak = GLS(GT_A + (r >= k ? tri(r, k) : tri(k, r))); B[r][k] = ak; s += ak * GLS(GT_LAM + k); }
-            B[r][5] = 0; jar[r] += s;
+            jar[r] += s;
           }
-          off = true;
         }
 #pragma unroll
         for (int r = 0; r < 3; r++) PGS(base + 22 + r) = jar[r];
         const double Dn = rec[19], fric = gc.ct_fric[set];
         cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
         if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
+        double w[3], S[9], P[9];
 #pragma unroll
-        for (int k = 0; k < 6; k++) T.g[k] -= J[0][k] * force[0] + J[1][k] * force[1] + J[2][k] * force[2];
-        acc_block(T.H, 0, 0, J, J, Hc, true);
-        if (off) gt_acc_off(T.Hpc, B, J, Hc);
-        if (kind == GK_ROD) {             // lambda's own block from this contact: A_r' Hc A_r, and the contact force for its gradient
+        for (int k = 0; k < 3; k++) w[k] = sg * (rec[3 + k] * force[0] + rec[6 + k] * force[1] + rec[9 + k] * force[2]);
+        T.g[0] -= w[0]; T.g[1] -= w[1]; T.g[2] -= w[2];
+        T.g[3] -= r1[1] * w[2] - r1[2] * w[1]; T.g[4] -= r1[2] * w[0] - r1[0] * w[2]; T.g[5] -= r1[0] * w[1] - r1[1] * w[0];
+        gt_world_S(rec + 3, Hc, S);
+        gt_SxR(S, r1, P);
+        gt_add_diag(T.H, S, P, r1);
+        if (off) gt_add_off(T.Hpc, S, P, r2, -1.0);
+        if (kind == GK_ROD) {             // lambda's own block from this contact: A_r' Hc A_r, the block between lambda and this cube, the force for lambda's gradient
 #pragma unroll
           for (int r = 0; r < 3; r++) T.fl5[r] = force[r];
 #pragma unroll
           for (int j = 0; j < 5; j++) {
-            double tb[3];
+            double tb[3], wv[3];
 #pragma unroll
             for (int s = 0; s < 3; s++) tb[s] = B[0][j] * Hc[s] + B[1][j] * Hc[3 + s] + B[2][j] * Hc[6 + s];
 #pragma unroll
             for (int i = 0; i <= j; i++) GLS(GT_HLL + tri(j, i)) = tb[0] * B[0][i] + tb[1] * B[1][i] + tb[2] * B[2][i];
+#pragma unroll
+            for (int k = 0; k < 3; k++) wv[k] = sg * (tb[0] * rec[3 + k] + tb[1] * rec[6 + k] + tb[2] * rec[9 + k]);
+            T.Hpc[6 * j] += wv[0]; T.Hpc[6 * j + 1] += wv[1]; T.Hpc[6 * j + 2] += wv[2];
+            T.Hpc[6 * j + 3] += r1[1] * wv[2] - r1[2] * wv[1]; T.Hpc[6 * j + 4] += r1[2] * wv[0] - r1[0] * wv[2]; T.Hpc[6 * j + 5] += r1[0] * wv[1] - r1[1] * wv[0];
           }
           GLS(GT_HLL + 24) = 1.0;         // marks "the rod contact is active" for the assembly below
         }
       }
-      // cube <-> cube records held by lower partners (this cube is their geom 2: rows + J)
+      // cube <-> cube records held by lower partners (this cube is their geom 2)
 #pragma unroll
       for (int c = 0; c < GEN_MAXNB; c++) if (c < T.b && (((unsigned)GLS(GL_INFO + c) >> (5 + T.b)) & 1)) {
         const unsigned pr = (unsigned)GLS(GL_PAIR + gt_pair(c, T.b));
         const int q0 = (int)(pr & 31u), q1 = q0 + (int)(pr >> 5);
+        double pp[3], xc[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pp[k] = GLS(GL_POS + 3 * c + k);
+#pragma unroll
+        for (int k = 0; k < 6; k++) xc[k] = GLS(GL_X + 6 * c + k);
 #pragma clang loop unroll(disable)
         for (int q = q0; q < q1; q++) {
           const int base = GG_CON + (c * GEN_SEG + q) * GREC;
           double rec[20];
 #pragma unroll
           for (int k = 0; k < 20; k++) rec[k] = PGS(base + k);
-          double J[3][6], B[3][6], jar[3], force[3], Hc[9];
-          gt_rows(sc, T.b, rec, rec + 3, 1.0, J);
-          gt_rows(sc, c, rec, rec + 3, -1.0, B);
+          const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]}, r2[3] = {rec[0] - pp[0], rec[1] - pp[1], rec[2] - pp[2]};
+          PUSH_CNT(2);
+          double u[3] = {0, 0, 0}, jar[3], force[3], Hc[9];
+          gt_point(T.x, r1, 1.0, u);
+          gt_point(xc, r2, -1.0, u);
 #pragma unroll
-          for (int r = 0; r < 3; r++) { double s = -rec[16 + r];
-#pragma unroll
-            for (int k = 0; k < 6; k++) s += J[r][k] * T.x[k] + B[r][k] * GLS(GL_X + 6 * c + k);
-            jar[r] = s; }
+          for (int r = 0; r < 3; r++) jar[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2] - rec[16 + r];
           const double Dn = rec[19], fric = gc.ct_fric[gc.set_bb];
           cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
           if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
+          double w[3], S[9], P[9];
 #pragma unroll
-          for (int k = 0; k < 6; k++) T.g[k] -= J[0][k] * force[0] + J[1][k] * force[1] + J[2][k] * force[2];
-          acc_block(T.H, 0, 0, J, J, Hc, true);
-          if (c == T.parent) gt_acc_off(T.Hpc, B, J, Hc);
+          for (int k = 0; k < 3; k++) w[k] = rec[3 + k] * force[0] + rec[6 + k] * force[1] + rec[9 + k] * force[2];
+          T.g[0] -= w[0]; T.g[1] -= w[1]; T.g[2] -= w[2];
+          T.g[3] -= r1[1] * w[2] - r1[2] * w[1]; T.g[4] -= r1[2] * w[0] - r1[0] * w[2]; T.g[5] -= r1[0] * w[1] - r1[1] * w[0];
+          gt_world_S(rec + 3, Hc, S);
+          gt_SxR(S, r1, P);
+          gt_add_diag(T.H, S, P, r1);
+          if (c == T.parent) gt_add_off(T.Hpc, S, P, r2, -1.0);
         }
       }
 #pragma unroll
@@ -547,6 +644,9 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
     GT_FOR(li) {
       GTLane& T = t[li];
       if (!T.active) continue;
+      double pc[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pc[k] = GLS(GL_POS + 3 * T.b + k);
 #pragma clang loop unroll(disable)
       for (int q = 0; q < T.cnt; q++) {
         const int base = GG_CON + (T.b * GEN_SEG + q) * GREC;
@@ -554,21 +654,17 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
 #pragma unroll
         for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
         const int kind = (int)rec[13], a = (int)rec[14], bb = (int)rec[15];
-        double J[3][6], jp[3];
-        gt_rows(sc, T.b, rec, rec + 3, kind == GK_STATIC ? (gc.st_first[a] ? 1.0 : -1.0) : -1.0, J);
-#pragma unroll
-        for (int r = 0; r < 3; r++) { double s = 0;
-#pragma unroll
-          for (int k = 0; k < 6; k++) s += J[r][k] * T.p[k];
-          jp[r] = s; }
+        const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]};
+        PUSH_CNT(5);
+        double u[3] = {0, 0, 0}, jp[3];
+        gt_point(T.p, r1, kind == GK_STATIC ? (gc.st_first[a] ? 1.0 : -1.0) : -1.0, u);
         if (kind == GK_BOXBOX) {
-          double B[3][6];
-          gt_rows(sc, bb, rec, rec + 3, 1.0, B);
+          const double r2[3] = {rec[0] - GLS(GL_POS + 3 * bb), rec[1] - GLS(GL_POS + 3 * bb + 1), rec[2] - GLS(GL_POS + 3 * bb + 2)};
+          gt_point_lds(sc, GL_P + 6 * bb, r2, 1.0, u);
+        }
 #pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int k = 0; k < 6; k++) jp[r] += B[r][k] * GLS(GL_P + 6 * bb + k);
-        } else if (kind == GK_ROD) {
+        for (int r = 0; r < 3; r++) jp[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2];
+        if (kind == GK_ROD) {
 #pragma unroll
           for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -611,11 +707,13 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
         GTLane& T = t[li];
         if (!ls_on[li]) continue;
         D3IL_STAT(g_stats.ls_iters++);
+        PUSH_CNT(3);
         const double alpha = ls_alpha[li];
         double p1 = 0, p2 = 0;
 #pragma clang loop unroll(disable)
         for (int q = 0; q < T.cnt; q++) {
           const int base = GG_CON + (T.b * GEN_SEG + q) * GREC;
+          PUSH_CNT(4);
           double rc[8];
           rc[0] = PGS(base + 19); rc[1] = PGS(base + 21);
 #pragma unroll
@@ -707,6 +805,11 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
     GTLane& T = t[li];
     if (!T.fast) continue;
     if (T.active || T.failed) fl |= F_SOLVER_FAIL;
+    if (T.cnt > 0 || T.members != (1u << T.b)) {      // the lane took part in a solve: its iterate goes back into the body axes of the free joint
+      gt_to_body(sc, T.b, T.x);
+#pragma unroll
+      for (int k = 3; k < 6; k++) GLS(GL_X + 6 * T.b + k) = T.x[k];
+    }
     if (T.lam) {
 #pragma unroll
       for (int k = 0; k < 5; k++) GLS(GL_TR + 1 + k) = GLS(GT_LAM + k);

@@ -46,7 +46,7 @@
 namespace d3il { struct Stats { long newton_calls, newton_iters, ls_iters, eig_calls, ik_calls, contact_calls; }; inline Stats g_stats = {0, 0, 0, 0, 0, 0}; }
 #elif defined(D3IL_DEVICE_STATS) && defined(__HIPCC__)
 // diagnostics build only (python -m d3il_amd.build --stats): counts lanes [2i] and waves [2i+1] entering rare paths
-namespace d3il { __device__ unsigned long long g_dev_stats[32]; __device__ unsigned long long g_dev_wave[4096][10]; }
+namespace d3il { __device__ unsigned long long g_dev_stats[32]; __device__ unsigned long long g_dev_wave[4096][10]; __device__ unsigned long long g_dev_cnt[4096][8]; }
 #define D3IL_STAT(x) ((void)0)
 #if !defined(__HIP_DEVICE_COMPILE__)
 #define D3IL_DSTAT(i) ((void)0)

@@ -1403,6 +1403,19 @@ int d3il_debug_wave_stats(uint64_t* out, int nwaves, int reset) {
 #endif
 }
 
+/* diagnostics build only: per-workgroup event counters of the generic engine's solver (PUSH_CNT), [nwaves][8] */
+int d3il_debug_wave_counts(uint64_t* out, int nwaves, int reset) {
+#if defined(D3IL_DEVICE_STATS)
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(d3il::g_dev_cnt), (size_t)nwaves * 8 * sizeof(unsigned long long)));
+  if (reset) { static unsigned long long z[4096][8]; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d3il::g_dev_cnt), z, sizeof z)); }
+  return D3IL_OK;
+#else
+  (void)out; (void)nwaves; (void)reset;
+  return fail(D3IL_EUNSUPPORTED, "d3il_debug_wave_counts: library built without D3IL_DEVICE_STATS");
+#endif
+}
+
 /* diagnostics build only: copies (and optionally clears) the device path counters; returns EUNSUPPORTED otherwise */
 int d3il_debug_stats(uint64_t* out32, int reset) {
 #if defined(D3IL_DEVICE_STATS)

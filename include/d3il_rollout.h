@@ -243,6 +243,7 @@ int d3il_set_option(d3il_handle h, const char* name, int value);
 /* Diagnostics builds only (-DD3IL_DEVICE_STATS): per-path lane/wave counters of the step kernel. */
 int d3il_debug_stats(uint64_t* out32, int reset);
 int d3il_debug_wave_stats(uint64_t* out_nwaves_x10, int nwaves, int reset);
+int d3il_debug_wave_counts(uint64_t* out_nwaves_x8, int nwaves, int reset);      /* generic engine: solver event counts per workgroup */
 /* Diagnostics: copies `count` doubles of one environment's solver scratch column (contact records of its last physics sub-step)
  * to the host; Pushing / Sorting / Stacking only. */
 int d3il_debug_scratch(d3il_handle h, int env, double* out, int count);

@@ -15,6 +15,8 @@ des = env.robot_state()[:, :2].clone(); z = env.robot_state()[:, 2:3].clone()
 quat = torch.tensor([0.0, 1, 0, 0], dtype=torch.float64, device=env.device).expand(n, 4)
 NW = (n + 15) // 16
 W = np.zeros((NW, 10), dtype=np.uint64)
+CN = np.zeros((NW, 8), dtype=np.uint64)
+cnames = ["newton its", "own-contact trips", "partner trips", "ls its", "ls contact trips", "jp trips", "sub-steps with a solve", "generic solves"]
 names = ["p1.arm", "p2.statics", "p3.bb+rod+reduce", "t.setup", "t.grad+H", "t.elim+solve", "t.jp", "t.linesearch+step", "p4.tree(total)", "p4.generic"]      # slots 3..7: inside the tree solver (gen_tree.h; the rare generic solves add to them)
 for t in range(60):
     box = env.obs[:, 2:4].to(torch.float64)
@@ -25,11 +27,16 @@ for t in range(60):
         des = des + d / nn.clamp_min(1e-9) * torch.minimum(nn, torch.full_like(nn, 0.006))
     torch.cuda.synchronize()
     L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), NW, 1)
+    L.d3il_debug_wave_counts(CN.ctypes.data_as(C.c_void_p), NW, 1)
     env.step(torch.cat([des, z, quat], dim=1).contiguous())
     torch.cuda.synchronize()
     L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), NW, 1)
+    L.d3il_debug_wave_counts(CN.ctypes.data_as(C.c_void_p), NW, 1)
     if t in (20, 39, 55):
         Wf = W.astype(np.float64)
         Wf /= 100.0                                       # ticks -> microseconds per env step; the other slots are counts (first active lane of the wave)
         for lab, v in (("median", np.median(Wf, axis=0)), ("p90", np.percentile(Wf, 90, axis=0)), ("max", Wf.max(axis=0))):
             print("t %2d %6s per workgroup: " % (t, lab) + "  ".join("%s %.0f" % (names[i], v[i]) for i in range(0, 10)), flush=True)
+        Cf = CN.astype(np.float64)
+        for lab, v in (("median", np.median(Cf, axis=0)), ("max", Cf.max(axis=0))):
+            print("t %2d %6s wave-level counts per env step: " % (t, lab) + "  ".join("%s %.0f" % (cnames[i], v[i]) for i in range(8)), flush=True)
