@@ -96,10 +96,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_stats_variant(verbose: bool = False) -> str:
-    """Diagnostics library with device-side path counters (not used by the product or the tests)."""
+def build_stats_variant(verbose: bool = False, counts: bool = False) -> str:
+    """Diagnostics library with device-side path counters and phase timers (not used by the product or the tests); counts: also the wave-level event
+    counters inside the generic engine's contact loops (d3il_debug_wave_counts; their atomics distort the timers)."""
     out = os.path.join(PKG, "libd3il_rollout_stats.so")
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-DD3IL_DEVICE_STATS", "-o", out] + SOURCES
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-DD3IL_DEVICE_STATS"] + (["-DD3IL_DEVICE_COUNTS"] if counts else []) + ["-o", out] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=ROOT)
@@ -124,8 +125,8 @@ VARIANTS = {"poison": ["D3IL_SK_POISON"], "raw": ["D3IL_SK_PRELOAD_RAW"], "nopre
 if __name__ == "__main__":
     import sys
     print(build(force=True, verbose=True))
-    if "--stats" in sys.argv:
-        print(build_stats_variant(verbose=True))
+    if "--stats" in sys.argv or "--counts" in sys.argv:
+        print(build_stats_variant(verbose=True, counts="--counts" in sys.argv))
     for name, defs in VARIANTS.items():
         if "--" + name in sys.argv:
             print(build_variant(name, defs, verbose=True))

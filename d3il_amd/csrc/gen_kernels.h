@@ -1,17 +1,19 @@
 // gen_kernels.h - HIP kernels of the Sorting task on the generic engine (included by rollout.hip).
 //
-// A workgroup owns GEN_LANES = 16 environments and runs two waves: the controller wave (open-loop IK chain, one lane per
-// environment) and the physics wave, in which every environment has a group of four lanes - lane l of the group owns cube l,
-// lane 0 also the arm (gen_step.h).  Lane = 16 l + column, so the 16 lanes that do the same job sit next to each other:
-// coalesced HBM rows, conflict-free LDS columns.  The physics wave keeps each environment's vectors, matrices and the dense
-// Newton Hessian in LDS (960 doubles per environment, 127.5 KiB per workgroup), the contact records in the HBM scratch area
-// and the cubes in the state buffer itself.  4096 environments are 256 workgroups: one per CU.
+// A workgroup owns GEN_LANES = 16 environments and runs three waves: the controller wave (open-loop IK chain, one lane per
+// environment) and GEN_NSUB = 2 physics waves of eight environments each, in which every environment has a group of four lane
+// PAIRS - pair l of the group owns cube l, pair 0 also the arm (gen_step.h).  The two lanes of a pair (sub-lanes, neighbours in
+// the wave: lane = 2 (8 l + column) + sub) share the cube's contacts in the solver's contact loops (every other record each, sums
+// exchanged by a DPP swap of neighbouring lanes) and hold identical copies of everything else; sub-lane 0 does the collision
+// phases and the integration.  The physics waves keep each environment's vectors, matrices and the dense
+// Newton Hessian in LDS (1059 doubles per environment, 141 KiB per workgroup), the contact records in the HBM scratch area
+// and the cubes in the state buffer itself.  4096 environments are 256 workgroups: one per CU, three of its four SIMDs busy.
 #pragma once
 #include "gen_step.h"
 
 namespace d3il {
 
-constexpr int GEN_LDS_H = GL_SIZE * (GEN_LANES + 1) * 8;   // 1031 x 17 doubles = 137 KiB
+constexpr int GEN_LDS_H = GL_SIZE * (GEN_LANES + 1) * 8;   // 1059 x 17 doubles = 141 KiB
 constexpr int GEN_LDS_X = 2 * 2 * NARM * GEN_LANES * 8;
 constexpr int GEN_LDS_STEP = GEN_LDS_H + GEN_LDS_X;
 
@@ -44,7 +46,7 @@ __device__ __forceinline__ void gen_store_arm(double* __restrict__ state, unsign
 
 // env.step() for the Sorting task (RS = false) and the Inserting task (RS = true: the engine with contacts of the arm block, gen_step.h)
 template <bool FAST, bool RS>
-__global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ state, unsigned* __restrict__ flags,
+__global__ __launch_bounds__((1 + GEN_NSUB) * WAVE) void k_sorting_step(double* __restrict__ state, unsigned* __restrict__ flags,
                                                            int* __restrict__ steps, const double* __restrict__ actions, float* __restrict__ obs,
                                                            unsigned char* __restrict__ done, unsigned char* __restrict__ success, unsigned short* __restrict__ mode,
                                                            double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
@@ -92,18 +94,21 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
       for (int i = 0; i < NARM; i++) { so[(D3IL_STATE_IK_Q + i) * (size_t)stride] = ikq[i]; so[(D3IL_STATE_IK_QD + i) * (size_t)stride] = ikqd[i]; }
     }
   } else {
-    const int col = lane & (GEN_LANES - 1), l = lane / GEN_LANES;   // group lane l of environment column col
+    constexpr int CPW = GEN_LANES / GEN_NSUB;                      // environment columns per physics wave
+    const int sub = lane & (GEN_NSUB - 1), pr = lane / GEN_NSUB;   // sub-lane of the pair, pair index in the wave
+    const int col = (role - 1) * CPW + (pr & (CPW - 1)), l = pr / CPW;   // pair l of environment column col
     const int e = blockIdx.x * GEN_LANES + col;
-    const bool plive = e < n && l < gc.nb;
+    const bool slive = e < n && l < gc.nb;                          // the lane takes part in the solver
+    const bool plive = slive && sub == 0;                           // ... and in the per-cube phases
     const bool arm_lane = plive && l == 0;
     const size_t ei = e < n ? e : 0;
-    PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + ei), stride, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
+    PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_SIZE * GEN_LANES + col), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
     EnvState st;
     float o[GEN_SORT_OBS]; unsigned char dn = 0;
     unsigned lfl = 0;
     bool warm_valid = false;
     const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
-    if (plive) warm_valid = (flags[e] & PF_WARM_VALID) != 0;
+    if (slive) warm_valid = (flags[e] & PF_WARM_VALID) != 0;
     if (arm_lane) {
       gen_load_arm(state, flags, steps, stride, e, st, false);
       sort_step_begin(gc, st, sc, o, &dn, max_steps);
@@ -131,10 +136,10 @@ __global__ __launch_bounds__(2 * WAVE) void k_sorting_step(double* __restrict__ 
       if (arm_lane) { gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl); gen_arm_reduce<RS>(gc, sc, warm_valid); }
       gen_sync();
       PUSH_TOC(2);
-      if (plive) lfl |= gen_tree_solve<1>(gc, sc, l, warm_valid);
+      if (slive) lfl |= gen_tree_solve<1, GEN_NSUB>(gc, sc, l, warm_valid, sub);
       gen_sync();
       PUSH_TOC(8);
-      if (plive) gen_phase4_multi<RS>(gc, sc, l, gc.nb, warm_valid, lfl);
+      if (slive) gen_phase4_multi<RS>(gc, sc, GEN_NSUB * l + sub, GEN_NSUB * gc.nb, warm_valid, lfl);
       gen_sync();
       PUSH_TOC(9);
       if (arm_lane) gen_phase5_arm(c, gc, st, sc);
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(WAVE) void k_sorting_reset(const double* __restrict
   double iq[NARM];
 #pragma unroll
   for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
-  PushScratch sc{(push_lds_double*)(smem + lane), (push_glb_double*)(scratch + e), stride, (push_glb_double*)(state + (size_t)42 * stride + e), stride};
+  PushScratch sc{(push_lds_double*)(smem + lane), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_SIZE * GEN_LANES + lane), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + e), stride};
   float o[GEN_SORT_OBS];
   st.flags = 0; st.step = 0;
   gen_env_reset(kAvoidingConsts, gc, st, sc, iq, contexts + (size_t)e * 7 * gc.nb, o);

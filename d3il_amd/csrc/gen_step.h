@@ -38,7 +38,16 @@ constexpr int GEN_NH = GEN_MAXNV * (GEN_MAXNV + 1) / 2;   // 561
 #ifndef D3IL_GEN_LANES
 #define D3IL_GEN_LANES 16
 #endif
-constexpr int GEN_LANES = D3IL_GEN_LANES;     // environments per workgroup (x GEN_MAXNB lanes each = one wavefront); a power of two
+constexpr int GEN_LANES = D3IL_GEN_LANES;     // environments per workgroup; a power of two
+// Sub-lanes: on the device a cube is owned by a PAIR of neighbouring lanes that deal the cube's contacts out between them in the solver's contact
+// loops and exchange their partial sums with a DPP swap (gen_tree.h; the joint solver gen_solve simply sees twice the lanes).  GEN_LANES / GEN_NSUB
+// environments x GEN_MAXNB cubes x GEN_NSUB sub-lanes are one wavefront; a workgroup runs GEN_NSUB such physics waves.  The host build has one.
+#if defined(__HIP_DEVICE_COMPILE__) || (defined(__HIPCC__) && !defined(D3IL_HOST_ONLY))
+#define D3IL_GEN_NSUB 2
+#else
+#define D3IL_GEN_NSUB 1
+#endif
+constexpr int GEN_NSUB = D3IL_GEN_NSUB;
 
 struct GenConsts {
   int nb, ns, set_bb, set_rod;
@@ -71,6 +80,14 @@ __constant__ GenConsts g_gen_consts;
 // The w area of the scratch views is the environment's object block of the state buffer (rows 42 ..): the cubes' pos[3] quat[4]
 // vel[6], then the solver's warm start [nv], then the two task words (stored as doubles).  The cubes stay there for the
 // whole step - only the arm lives in registers.
+// g area (contact records, HBM): on the device the 16 environments of a workgroup own one block, [record field][environment column] - a record's fields
+// are 128 bytes apart, so one 64-bit base address per record and immediate offsets address them (a row stride of n_envs x 8 bytes cost two
+// address instructions per field) and an environment's records share their cache lines with its workgroup only.  Host build: the caller's stride.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GRS(i) sc.g[(i) * GEN_LANES]
+#else
+#define GRS(i) sc.g[(long)(i) * sc.gs]
+#endif
 #define GBX(b, k) PWS(13 * (b) + (k))
 #define GWARM(k) PWS(13 * gc.nb + (k))
 #define GTASK(k) PWS(13 * gc.nb + 6 * gc.nb + NDOF + (k))
@@ -88,13 +105,14 @@ constexpr int GL_R = GL_VEL + GEN_MAXNV, GL_POS = GL_R + 9 * GEN_MAXNB, GL_M = G
 constexpr int GL_ROD = GL_JA + 21 * (GEN_MAXNB + GEN_ARMCON);      // rod centre[3], axis[3].  GL_JA: arm rows of the rod contact of cube b at 21 b, of rod <-> static contact j at 21 (GEN_MAXNB + j)
 constexpr int GL_INFO = GL_ROD + 6;                 // [0..3] per cube: contact count | partner cubes << 5 | rod contact << 9;  [4] arm joint at a limit;  [5..7] flags of lanes 1..3;
                                                     // [8] rod <-> static contacts of this sub-step;  [9..12] what lanes 0..3 found of them
-constexpr int GL_RED = GL_INFO + 16;                 // line-search partial sums of the group's lanes, double buffered: 2 x 4 x (d1, d2)
-constexpr int GL_TR = GL_RED + 16;                  // tree solver (gen_tree.h): [0] 1 = the arm's reduction to the lambda node stands, 2 = the arm's island was solved through it; [1..5] lambda
+constexpr int GL_RED = GL_INFO + 16;                 // line-search partial sums of the group's lanes, double buffered: 2 x (4 GEN_NSUB) x (d1, d2)
+constexpr int GL_NRED = 2 * GEN_MAXNB * GEN_NSUB;    // one buffer
+constexpr int GL_TR = GL_RED + 2 * GL_NRED;                  // tree solver (gen_tree.h): [0] 1 = the arm's reduction to the lambda node stands, 2 = the arm's island was solved through it; [1..5] lambda
 constexpr int GL_PAIR = GL_TR + 6;                  // cube pair (c, d), c < d: first record | count << 5 of their contacts in c's segment
 constexpr int GL_SIZE = GL_PAIR + 6;                // 1043
 // g area (HBM): contact records, GEN_SEG per cube
 constexpr int GG_CON = 0;
-constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn fric set | jar[3] jp[3]
+constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn fric sign | jar[3] jp[3]   (sign: of the segment's cube in the row, +1 = it is geom 2)
 constexpr int GG_SIZE = GG_CON + GEN_MAXCON * GREC;
 D3IL_HD int gt_pair(int c, int d) { return c * (2 * GEN_MAXNB - c - 1) / 2 + (d - c - 1); }      // slot of the cube pair c < d in GL_PAIR
 enum { GK_STATIC = 0, GK_BOXBOX = 1, GK_ROD = 2, GK_RODST = 3 /* rod <-> static box: a = static, b = its slot of the GL_JA rows; no cube */ };
@@ -372,7 +390,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     const int base = GG_CON + locate(t) * GREC;
     double rec[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
+    for (int k = 0; k < 16; k++) rec[k] = GRS(base + k);
     const int kind = (int)rec[13], set = kind == GK_STATIC ? (int)rec[14] : (kind == GK_BOXBOX ? gc.set_bb : (!RS || kind == GK_ROD ? gc.set_rod : gc.ns + 2 + (int)rec[14]));
     const double dist = rec[12];
     double imp = impedance(gc.ct_solimp[set], dist);
@@ -380,10 +398,10 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
     GRow rows[3];
     gen_rows<RS>(gc, sc, isl, rec, rows);
     double v0 = grow_dot_g<RS>(sc, rows[0], GL_VEL), v1 = grow_dot_g<RS>(sc, rows[1], GL_VEL), v2 = grow_dot_g<RS>(sc, rows[2], GL_VEL);
-    PGS(base + 16) = -gc.ct_B[set] * v0 - gc.ct_K[set] * imp * dist;
-    PGS(base + 17) = -gc.ct_B[set] * v1; PGS(base + 18) = -gc.ct_B[set] * v2;
-    PGS(base + 19) = 1 / fmax(1e-15, (1 - imp) / imp * invw);
-    PGS(base + 20) = gc.ct_fric[set];
+    GRS(base + 16) = -gc.ct_B[set] * v0 - gc.ct_K[set] * imp * dist;
+    GRS(base + 17) = -gc.ct_B[set] * v1; GRS(base + 18) = -gc.ct_B[set] * v2;
+    GRS(base + 19) = 1 / fmax(1e-15, (1 - imp) / imp * invw);
+    GRS(base + 20) = gc.ct_fric[set];
   }
   gen_sync();
   bool converged = false;
@@ -421,12 +439,12 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
       const int base = GG_CON + locate(t) * GREC;
       double rec[21];
 #pragma unroll
-      for (int k = 0; k < 21; k++) rec[k] = PGS(base + k);
+      for (int k = 0; k < 21; k++) rec[k] = GRS(base + k);
       GRow rows[3];
       gen_rows<RS>(gc, sc, isl, rec, rows);
       double jar[3], force[3], Hc[9];
 #pragma unroll
-      for (int r = 0; r < 3; r++) { jar[r] = grow_dot_g<RS>(sc, rows[r], GL_X) - rec[16 + r]; PGS(base + 22 + r) = jar[r]; }
+      for (int r = 0; r < 3; r++) { jar[r] = grow_dot_g<RS>(sc, rows[r], GL_X) - rec[16 + r]; GRS(base + 22 + r) = jar[r]; }
       const double Dn = rec[19], fric = rec[20];
       cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
       if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
@@ -479,11 +497,11 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
       const int base = GG_CON + locate(t) * GREC;
       double rec[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
+      for (int k = 0; k < 16; k++) rec[k] = GRS(base + k);
       GRow rows[3];
       gen_rows<RS>(gc, sc, isl, rec, rows);
 #pragma unroll
-      for (int r = 0; r < 3; r++) PGS(base + 25 + r) = grow_dot_c<RS>(sc, rows[r], vp);
+      for (int r = 0; r < 3; r++) GRS(base + 25 + r) = grow_dot_c<RS>(sc, rows[r], vp);
     }
     gen_sync();
     PUSH_TOC(6);
@@ -495,7 +513,7 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
         const int base = GG_CON + locate(t) * GREC;
         double rec[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) rec[k] = PGS(base + 19 + k);     // Dn fric set jar[3] jp[3]
+        for (int k = 0; k < 9; k++) rec[k] = GRS(base + 19 + k);     // Dn fric set jar[3] jp[3]
         double jp[3] = {rec[6], rec[7], rec[8]};
         double jt[3] = {rec[3] + alpha * jp[0], rec[4] + alpha * jp[1], rec[5] + alpha * jp[2]}, ft[3], Hc[9];
         const double Dn = rec[0], fric = rec[1];
@@ -505,10 +523,10 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
 #pragma unroll
           for (int q = 0; q < 3; q++) p2 += jp[r] * Hc[3 * r + q] * jp[q]; }
       }
-      GLS(GL_RED + 8 * buf + 2 * l) = p1; GLS(GL_RED + 8 * buf + 2 * l + 1) = p2;
+      GLS(GL_RED + GL_NRED * buf + 2 * l) = p1; GLS(GL_RED + GL_NRED * buf + 2 * l + 1) = p2;
       gen_sync();
       double d1 = pMa + alpha * pMp, d2 = pMp;
-      for (int j = 0; j < nl; j++) { d1 += GLS(GL_RED + 8 * buf + 2 * j); d2 += GLS(GL_RED + 8 * buf + 2 * j + 1); }
+      for (int j = 0; j < nl; j++) { d1 += GLS(GL_RED + GL_NRED * buf + 2 * j); d2 += GLS(GL_RED + GL_NRED * buf + 2 * j + 1); }
       buf ^= 1;
       if (isl.arm)
         for (int k = 0; k < NDOF; k++) {
@@ -644,8 +662,9 @@ D3IL_HD void gen_put(const GenConsts& gc_, const PushScratch sc, int cube, int& 
   double n[3] = {rec[4], rec[5], rec[6]}, t1[3], t2[3];
   make_frame(n, t1, t2);
 #pragma unroll
-  for (int k = 0; k < 3; k++) { PGS(base + k) = rec[1 + k]; PGS(base + 3 + k) = n[k]; PGS(base + 6 + k) = t1[k]; PGS(base + 9 + k) = t2[k]; }
-  PGS(base + 12) = rec[0]; PGS(base + 13) = kind; PGS(base + 14) = a; PGS(base + 15) = b; PGS(base + 21) = set;
+  for (int k = 0; k < 3; k++) { GRS(base + k) = rec[1 + k]; GRS(base + 3 + k) = n[k]; GRS(base + 6 + k) = t1[k]; GRS(base + 9 + k) = t2[k]; }
+  GRS(base + 12) = rec[0]; GRS(base + 13) = kind; GRS(base + 14) = a; GRS(base + 15) = b;
+  GRS(base + 20) = gc.ct_fric[set]; GRS(base + 21) = kind == GK_STATIC && gc.st_first[a] ? 1.0 : -1.0;      // with the record: no table look-ups by record content in the solver's loops
   cnt++;
 }
 // ---- phase 2 (lane c): cube c's pose into the t area, collision against the static boxes.  Returns the contact count.
@@ -763,8 +782,8 @@ D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, 
       for (int j = 0, m = (int)GLS(GL_INFO + 9 + l); j < m; j++) {
         if (narm >= GEN_ARMCON) { fl |= PF_CON_OVERFLOW; continue; }
         const int src = GG_CON + (GEN_ARMSEG * GEN_SEG + GEN_ARMLANE * l + j) * GREC, dst = GG_CON + (GEN_ARMSEG * GEN_SEG + narm) * GREC;
-        if (src != dst) for (int k = 0; k < 22; k++) PGS(dst + k) = PGS(src + k);
-        PGS(dst + 15) = (double)narm;
+        if (src != dst) for (int k = 0; k < 22; k++) GRS(dst + k) = GRS(src + k);
+        GRS(dst + 15) = (double)narm;
         narm++;
       }
   }
@@ -778,20 +797,20 @@ D3IL_HD void gen_phase3b(const C& c0, const GenConsts& gc_, const EnvState& st, 
     unsigned info = (unsigned)GLS(GL_INFO + b);
     if (!((info >> 9) & 1)) continue;
     const int base = GG_CON + (b * GEN_SEG + (int)(info & 31) - 1) * GREC;
-    double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
+    double p[3] = {GRS(base), GRS(base + 1), GRS(base + 2)};
     for (int k = 0; k < NARM; k++) {
       double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
       cross3(ax[k], dd, col);
-      for (int r = 0; r < 3; r++) GLS(GL_JA + 21 * b + 7 * r + k) = col[0] * PGS(base + 3 + 3 * r) + col[1] * PGS(base + 4 + 3 * r) + col[2] * PGS(base + 5 + 3 * r);
+      for (int r = 0; r < 3; r++) GLS(GL_JA + 21 * b + 7 * r + k) = col[0] * GRS(base + 3 + 3 * r) + col[1] * GRS(base + 4 + 3 * r) + col[2] * GRS(base + 5 + 3 * r);
     }
   }
   for (int j = 0; j < narm; j++) {
     const int base = GG_CON + (GEN_ARMSEG * GEN_SEG + j) * GREC;
-    double p[3] = {PGS(base), PGS(base + 1), PGS(base + 2)};
+    double p[3] = {GRS(base), GRS(base + 1), GRS(base + 2)};
     for (int k = 0; k < NARM; k++) {
       double dd[3] = {p[0] - og[k][0], p[1] - og[k][1], p[2] - og[k][2]}, col[3];
       cross3(ax[k], dd, col);
-      for (int r = 0; r < 3; r++) GLS(GL_JA + 21 * (GEN_MAXNB + j) + 7 * r + k) = col[0] * PGS(base + 3 + 3 * r) + col[1] * PGS(base + 4 + 3 * r) + col[2] * PGS(base + 5 + 3 * r);
+      for (int r = 0; r < 3; r++) GLS(GL_JA + 21 * (GEN_MAXNB + j) + 7 * r + k) = col[0] * GRS(base + 3 + 3 * r) + col[1] * GRS(base + 4 + 3 * r) + col[2] * GRS(base + 5 + 3 * r);
     }
   }
 }
@@ -875,8 +894,8 @@ D3IL_NOINLINE inline bool gen_arm_contact1(const GenConsts& gc_, const PushScrat
   const double gscale = (1.0 + sqrt(fn)) / (md / NDOF);
   RodContact rc;
   rc.active = true;
-  const int set = gc.ns + 2 + (int)PGS(base + 14);
-  const double dist = PGS(base + 12);
+  const int set = gc.ns + 2 + (int)GRS(base + 14);
+  const double dist = GRS(base + 12);
   double vel[3] = {0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 3; r++)

@@ -34,8 +34,11 @@ constexpr int GT_LAM = GT_DF + 2;                     // lambda
 constexpr int GT_PL = GT_LAM + 5;                     // its Newton direction
 constexpr int GT_HLL = GT_PL + 5;                     // lambda's own Hessian block (15) and gradient (5), then the original gradient (5)
 constexpr int GT_EX = GT_HLL + 25;                    // exchange slots: 2 buffers x GEN_MAXNB lanes x 3
-constexpr int GT_END = GT_EX + 6 * GEN_MAXNB;
-static_assert(GT_END - GL_H <= GEN_NH, "the tree solver's slots must fit the area they alias");
+constexpr int GT_LS = GT_EX + 6 * GEN_MAXNB;           // line-search data of the first GT_LSCAP records of every cube: jar[3] jp[3] Dn fric (later records: fields 19 .. 27 of the record in HBM)
+constexpr int GT_LSCAP = (GL_H + GEN_NH - GT_LS) / (8 * GEN_MAXNB);
+constexpr int GT_END = GT_LS + 8 * GEN_MAXNB * GT_LSCAP;
+static_assert(GT_END - GL_H <= GEN_NH && GT_LSCAP >= 8, "the tree solver's slots must fit the area they alias");
+#define GT_LSS(b, q, k) GLS(GT_LS + 8 * (GT_LSCAP * (b) + (q)) + (k))
 constexpr int GT_LAMNODE = GEN_MAXNB;                 // parent index that stands for the lambda node
 
 struct GTLane {
@@ -268,6 +271,30 @@ D3IL_HD void gt_to_body(const PushScratch sc, int b, double* y) {
   y[3] = R[0] * a + R[3] * bb + R[6] * c; y[4] = R[1] * a + R[4] * bb + R[7] * c; y[5] = R[2] * a + R[5] * bb + R[8] * c;
 }
 
+// v + the value of the pair's other sub-lane (device: DPP swap of neighbouring lanes - quad_perm [1, 0, 3, 2] -, the same sum in both lanes since
+// the addition commutes; host: one sub-lane, nothing to add).  The wave barriers keep the optimiser from moving code across the cross-lane
+// operation (common-code sinking around convergent operations).
+D3IL_HD double gt_pair_sum(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(GEN_NSUB == 2, "the exchange is a swap of lane pairs");
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false), phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+  return v + __hiloint2double(phi, plo);
+#else
+  return v;
+#endif
+}
+template <int N> D3IL_HD void gt_pair_sum_n(double* v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < N; k++) v[k] = gt_pair_sum(v[k]);
+  __builtin_amdgcn_wave_barrier();
+#else
+  (void)v;
+#endif
+}
+
 #define GT_FOR(li) for (int li = 0; li < NL; li++)
 
 // sum / max over the members of the lane's island of what the lanes put into exchange buffer `buf`
@@ -276,8 +303,10 @@ D3IL_HD void gt_to_body(const PushScratch sc, int b, double* y) {
 
 // Newton solve of the tree islands of the environment by the lanes of cubes l0 .. l0 + NL - 1 (device: NL = 1, this lane's cube; host and the
 // one-lane reset kernel: all cubes, one after the other in every step).  Returns the flags it raises.
-template <int NL>
-D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScratch sc, int l0, bool warm_valid) {
+// NS, sub: sub-lanes per cube and the lane's place in its pair (step kernel: NS = GEN_NSUB = 2; everywhere else one lane per cube).  The sub-lanes of a pair run this function with identical data and take
+// identical decisions; only the contact loops differ - sub-lane s evaluates records s, s + NS, .. - and their sums are exchanged (gt_pair_sum).
+template <int NL, int NS = 1>
+D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScratch sc, int l0, bool warm_valid, int sub = 0) {
   D3IL_GEN_CONSTS(gc_, gc);
   unsigned fl = 0;
   GTLane t[NL];
@@ -328,11 +357,11 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
 #pragma unroll
     for (int k = 0; k < 3; k++) pc[k] = GLS(GL_POS + 3 * T.b + k);
 #pragma clang loop unroll(disable)
-    for (int q = 0; q < T.cnt; q++) {
+    for (int q = sub; q < T.cnt; q += NS) {
       const int base = GG_CON + (T.b * GEN_SEG + q) * GREC;
       double rec[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
+      for (int k = 0; k < 16; k++) rec[k] = GRS(base + k);
       const int kind = (int)rec[13], a = (int)rec[14], bb = (int)rec[15];
       const int set = kind == GK_STATIC ? a : (kind == GK_BOXBOX ? gc.set_bb : gc.set_rod);
       const double invw = kind == GK_STATIC ? gc.box_invw_t : (kind == GK_BOXBOX ? 2 * gc.box_invw_t : gc.box_invw_t + gc.rod_invw);
@@ -352,9 +381,11 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
           for (int k = 0; k < NARM; k++) v[r] += GLS(GL_JA + 21 * T.b + 7 * r + k) * GLS(GL_VEL + arm0 + k);
       }
       const double dist = rec[12], imp = impedance(gc.ct_solimp[set], dist);
-      PGS(base + 16) = -gc.ct_B[set] * v[0] - gc.ct_K[set] * imp * dist;
-      PGS(base + 17) = -gc.ct_B[set] * v[1]; PGS(base + 18) = -gc.ct_B[set] * v[2];
-      PGS(base + 19) = 1 / fmax(1e-15, (1 - imp) / imp * invw);
+      GRS(base + 16) = -gc.ct_B[set] * v[0] - gc.ct_K[set] * imp * dist;
+      GRS(base + 17) = -gc.ct_B[set] * v[1]; GRS(base + 18) = -gc.ct_B[set] * v[2];
+      const double Dn = 1 / fmax(1e-15, (1 - imp) / imp * invw);
+      GRS(base + 19) = Dn;
+      if (q < GT_LSCAP) { GT_LSS(T.b, q, 6) = Dn; GT_LSS(T.b, q, 7) = gc.ct_fric[set]; }
     }
     D3IL_STAT(g_stats.newton_calls++);
   }
@@ -377,22 +408,21 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
 #pragma unroll
       for (int i = 0; i < 36; i++) T.Hpc[i] = 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) { const double mm = k < 3 ? mt : mr; T.g[k] = mm * (T.x[k] - (k == 2 ? grav2 : 0.0)); T.H[tri(k, k)] = mm; }
+      for (int k = 0; k < 6; k++) { const double mm = sub == 0 ? (k < 3 ? mt : mr) : 0.0; T.g[k] = mm * (T.x[k] - (k == 2 ? grav2 : 0.0)); T.H[tri(k, k)] = mm; }      // the smooth part once per pair
 #pragma unroll
       for (int k = 0; k < 5; k++) T.fl5[k] = 0;
       double pc[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) pc[k] = GLS(GL_POS + 3 * T.b + k);
 #pragma clang loop unroll(disable)
-      for (int q = 0; q < T.cnt; q++) {
+      for (int q = sub; q < T.cnt; q += NS) {
         const int base = GG_CON + (T.b * GEN_SEG + q) * GREC;
-        double rec[20];
+        double rec[22];
 #pragma unroll
-        for (int k = 0; k < 20; k++) rec[k] = PGS(base + k);
-        const int kind = (int)rec[13], a = (int)rec[14], bb = (int)rec[15];
-        const int set = kind == GK_STATIC ? a : (kind == GK_BOXBOX ? gc.set_bb : gc.set_rod);
+        for (int k = 0; k < 22; k++) rec[k] = GRS(base + k);
+        const int kind = (int)rec[13], bb = (int)rec[15];
         PUSH_CNT(1);
-        const double sg = kind == GK_STATIC ? (gc.st_first[a] ? 1.0 : -1.0) : -1.0;
+        const double sg = rec[21];
         const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]};
         double r2[3] = {0, 0, 0}, u[3] = {0, 0, 0}, jar[3], force[3], Hc[9], B[3][5];
         gt_point(T.x, r1, sg, u);
@@ -414,9 +444,14 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
             jar[r] += s;
           }
         }
+        if (q < GT_LSCAP) {
 #pragma unroll
-        for (int r = 0; r < 3; r++) PGS(base + 22 + r) = jar[r];
-        const double Dn = rec[19], fric = gc.ct_fric[set];
+          for (int r = 0; r < 3; r++) GT_LSS(T.b, q, r) = jar[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; r++) GRS(base + 22 + r) = jar[r];
+        }
+        const double Dn = rec[19], fric = rec[20];
         cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
         if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
         double w[3], S[9], P[9];
@@ -457,11 +492,11 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
 #pragma unroll
         for (int k = 0; k < 6; k++) xc[k] = GLS(GL_X + 6 * c + k);
 #pragma clang loop unroll(disable)
-        for (int q = q0; q < q1; q++) {
+        for (int q = q0 + sub; q < q1; q += NS) {
           const int base = GG_CON + (c * GEN_SEG + q) * GREC;
-          double rec[20];
+          double rec[21];
 #pragma unroll
-          for (int k = 0; k < 20; k++) rec[k] = PGS(base + k);
+          for (int k = 0; k < 21; k++) rec[k] = GRS(base + k);
           const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]}, r2[3] = {rec[0] - pp[0], rec[1] - pp[1], rec[2] - pp[2]};
           PUSH_CNT(2);
           double u[3] = {0, 0, 0}, jar[3], force[3], Hc[9];
@@ -469,7 +504,7 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
           gt_point(xc, r2, -1.0, u);
 #pragma unroll
           for (int r = 0; r < 3; r++) jar[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2] - rec[16 + r];
-          const double Dn = rec[19], fric = gc.ct_fric[gc.set_bb];
+          const double Dn = rec[19], fric = rec[20];
           cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
           if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
           double w[3], S[9], P[9];
@@ -482,6 +517,10 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
           gt_add_diag(T.H, S, P, r1);
           if (c == T.parent) gt_add_off(T.Hpc, S, P, r2, -1.0);
         }
+      }
+      if (NS > 1) {      // the pair's sums; the rod contact's lambda block and marker were stored by the sub-lane that holds the contact
+        gt_pair_sum_n<6>(T.g); gt_pair_sum_n<21>(T.H); gt_pair_sum_n<36>(T.Hpc); gt_pair_sum_n<3>(T.fl5);
+        gen_sync();
       }
 #pragma unroll
       for (int k = 0; k < 6; k++) T.g0[k] = T.g[k];
@@ -648,16 +687,17 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
 #pragma unroll
       for (int k = 0; k < 3; k++) pc[k] = GLS(GL_POS + 3 * T.b + k);
 #pragma clang loop unroll(disable)
-      for (int q = 0; q < T.cnt; q++) {
+      for (int q = sub; q < T.cnt; q += NS) {
         const int base = GG_CON + (T.b * GEN_SEG + q) * GREC;
-        double rec[16];
+        double rec[15];      // pos[3] frame[9] kind b sign
 #pragma unroll
-        for (int k = 0; k < 16; k++) rec[k] = PGS(base + k);
-        const int kind = (int)rec[13], a = (int)rec[14], bb = (int)rec[15];
+        for (int k = 0; k < 12; k++) rec[k] = GRS(base + k);
+        rec[12] = GRS(base + 13); rec[13] = GRS(base + 15); rec[14] = GRS(base + 21);
+        const int kind = (int)rec[12], bb = (int)rec[13];
         const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]};
         PUSH_CNT(5);
         double u[3] = {0, 0, 0}, jp[3];
-        gt_point(T.p, r1, kind == GK_STATIC ? (gc.st_first[a] ? 1.0 : -1.0) : -1.0, u);
+        gt_point(T.p, r1, rec[14], u);
         if (kind == GK_BOXBOX) {
           const double r2[3] = {rec[0] - GLS(GL_POS + 3 * bb), rec[1] - GLS(GL_POS + 3 * bb + 1), rec[2] - GLS(GL_POS + 3 * bb + 2)};
           gt_point_lds(sc, GL_P + 6 * bb, r2, 1.0, u);
@@ -670,8 +710,13 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
 #pragma unroll
             for (int k = 0; k < 5; k++) jp[r] += GLS(GT_A + (r >= k ? tri(r, k) : tri(k, r))) * GLS(GT_PL + k);
         }
+        if (q < GT_LSCAP) {
 #pragma unroll
-        for (int r = 0; r < 3; r++) PGS(base + 25 + r) = jp[r];
+          for (int r = 0; r < 3; r++) GT_LSS(T.b, q, 3 + r) = jp[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; r++) GRS(base + 25 + r) = jp[r];
+        }
       }
       double pMp = 0, pMa = 0, gTp = 0;
 #pragma unroll
@@ -711,22 +756,28 @@ D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScr
         const double alpha = ls_alpha[li];
         double p1 = 0, p2 = 0;
 #pragma clang loop unroll(disable)
-        for (int q = 0; q < T.cnt; q++) {
+        for (int q = sub; q < T.cnt; q += NS) {
           const int base = GG_CON + (T.b * GEN_SEG + q) * GREC;
           PUSH_CNT(4);
-          double rc[8];
-          rc[0] = PGS(base + 19); rc[1] = PGS(base + 21);
+          double rc[8];      // jar[3] jp[3] Dn fric
+          if (q < GT_LSCAP) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) rc[2 + k] = PGS(base + 22 + k);
-          const double jp[3] = {rc[5], rc[6], rc[7]};
-          double jt[3] = {rc[2] + alpha * jp[0], rc[3] + alpha * jp[1], rc[4] + alpha * jp[2]}, ft[3], Hc[9];
-          const double Dn = rc[0], fric = gc.ct_fric[(int)rc[1]];
+            for (int k = 0; k < 8; k++) rc[k] = GT_LSS(T.b, q, k);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) rc[k] = GRS(base + 22 + k);
+            rc[6] = GRS(base + 19); rc[7] = GRS(base + 20);
+          }
+          const double jp[3] = {rc[3], rc[4], rc[5]};
+          double jt[3] = {rc[0] + alpha * jp[0], rc[1] + alpha * jp[1], rc[2] + alpha * jp[2]}, ft[3], Hc[9];
+          const double Dn = rc[6], fric = rc[7];
           cone_eval(jt, Dn, Dn * impr, fric * mu_scale, fric, ft, Hc);
 #pragma unroll
           for (int r = 0; r < 3; r++) { p1 -= ft[r] * jp[r];
 #pragma unroll
             for (int qq = 0; qq < 3; qq++) p2 += jp[r] * Hc[3 * r + qq] * jp[qq]; }
         }
+        if (NS > 1) { double pp[2] = {p1, p2}; gt_pair_sum_n<2>(pp); p1 = pp[0]; p2 = pp[1]; }
         if (T.lam) {
 #pragma unroll
           for (int f = 0; f < NFING; f++) {

@@ -25,9 +25,14 @@
 #define PUSH_TOC(slot) do { unsigned long long t_now_ = wall_clock64(); \
     if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && blockIdx.x < 4096) \
       atomicAdd(&d3il::g_dev_wave[blockIdx.x][slot], t_now_ - t_tic_); t_tic_ = t_now_; } while (0)
-// wave-level event counter of the stats build: +1 per wave (its first active lane) each time the statement is reached
+// wave-level event counter of the counting build (-DD3IL_DEVICE_STATS -DD3IL_DEVICE_COUNTS; the atomics inside the contact loops distort the timers,
+// so the plain stats build leaves them out): +1 per wave (its first active lane) each time the statement is reached
+#if defined(D3IL_DEVICE_COUNTS)
 #define PUSH_CNT(slot) do { if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && blockIdx.x < 4096) \
       atomicAdd(&d3il::g_dev_cnt[blockIdx.x][slot], 1ull); } while (0)
+#else
+#define PUSH_CNT(slot) ((void)0)
+#endif
 #else
 #define PUSH_TIC ((void)0)
 #define PUSH_TOC(slot) ((void)0)

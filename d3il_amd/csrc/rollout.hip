@@ -1076,7 +1076,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
     // the engine with contacts of the arm block only for models that evaluate rod <-> static box pairs (Inserting): the Sorting scenes run the
     // instantiation without that code
-#define D3IL_GEN_LAUNCH(F, R) hipLaunchKernelGGL((k_sorting_step<F, R>), dim3(nwgs), dim3(2 * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, \
+#define D3IL_GEN_LAUNCH(F, R) hipLaunchKernelGGL((k_sorting_step<F, R>), dim3(nwgs), dim3((1 + GEN_NSUB) * WAVE), GEN_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done, \
                                                   b.success, b.mode, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps)
     if (h->gc.rod_static) { if (h->fast) D3IL_GEN_LAUNCH(true, true); else D3IL_GEN_LAUNCH(false, true); }
     else { if (h->fast) D3IL_GEN_LAUNCH(true, false); else D3IL_GEN_LAUNCH(false, false); }
@@ -1441,6 +1441,12 @@ int d3il_debug_scratch(d3il_handle h, int env, double* out, int count) {
   if (h->task_id == D3IL_TASK_STACKING) {     // contiguous per environment
     if (count > SG_SIZE) return fail(D3IL_EINVAL, "d3il_debug_scratch: count exceeds the environment's scratch area");
     HIPCHK(hipMemcpy(out, h->d_scratch + (size_t)env * SG_SIZE, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return D3IL_OK;
+  }
+  if (gen_task(h->task_id)) {     // blocked by workgroup: [environment / GEN_LANES][field][environment % GEN_LANES] (gen_step.h GRS)
+    if (count > GG_SIZE) return fail(D3IL_EINVAL, "d3il_debug_scratch: count exceeds the environment's scratch area");
+    HIPCHK(hipMemcpy2D(out, sizeof(double), h->d_scratch + (size_t)(env / GEN_LANES) * GG_SIZE * GEN_LANES + env % GEN_LANES, (size_t)GEN_LANES * sizeof(double), sizeof(double), (size_t)count,
+                       hipMemcpyDeviceToHost));
     return D3IL_OK;
   }
   HIPCHK(hipMemcpy2D(out, sizeof(double), h->d_scratch + env, (size_t)h->stride * sizeof(double), sizeof(double), (size_t)count, hipMemcpyDeviceToHost));

@@ -34,7 +34,7 @@ for t in range(60):
     L.d3il_debug_wave_counts(CN.ctypes.data_as(C.c_void_p), NW, 1)
     if t in (20, 39, 55):
         Wf = W.astype(np.float64)
-        Wf /= 100.0                                       # ticks -> microseconds per env step; the other slots are counts (first active lane of the wave)
+        Wf /= 200.0                                       # ticks -> microseconds per env step; the other slots are counts (first active lane of the wave)
         for lab, v in (("median", np.median(Wf, axis=0)), ("p90", np.percentile(Wf, 90, axis=0)), ("max", Wf.max(axis=0))):
             print("t %2d %6s per workgroup: " % (t, lab) + "  ".join("%s %.0f" % (names[i], v[i]) for i in range(0, 10)), flush=True)
         Cf = CN.astype(np.float64)
