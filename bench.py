@@ -337,39 +337,40 @@ def _beso_policy_roofline(pol, n, dev):
 
 
 # ---------------------------------------------------------------------------------------------------- the benchmark
+def _make_env(args, task, dev, n):
+    if task == "avoiding":
+        from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
+        return ObstacleAvoidanceVecEnv(n, device=dev)
+    if task == "pushing":
+        from d3il_amd.envs.pushing import BlockPushVecEnv
+        return BlockPushVecEnv(n, device=dev)
+    if task == "sorting":
+        from d3il_amd.envs.sorting import SortingVecEnv
+        return SortingVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 700)     # configs/sorting_4_config.yaml:80
+    if task == "aligning":
+        from d3il_amd.envs.aligning import RobotPushVecEnv
+        return RobotPushVecEnv(n, device=dev)
+    if task == "inserting":
+        from d3il_amd.envs.inserting import GateInsertionVecEnv
+        return GateInsertionVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 2000)     # gate_insertion.py:158 (the reference has no config for this task)
+    from d3il_amd.envs.stacking import CubeStackingVecEnv
+    return CubeStackingVecEnv(n, device=dev)
+
+
 class _Shard:
     """One sub-batch of this rank's environments: its own environment handle, policy state and HIP stream.  The rank's environments are stepped as
     `--sub-batches` independent sub-batches: a launch lasts as long as its slowest workgroup (an environment in a rare path - rod contact,
     clipped-eigenvalue IK, a hard contact island), and sub-batches on different streams do not wait for each other's tails."""
 
-    def __init__(self, args, task, dev, n, env_offset, ctx60, q, stack_tables):
+    def __init__(self, args, task, dev, sb, ctx60, q, stack_tables):
         import numpy as np
         import torch
+        # the handle, its stream and the serve-wave threshold are the product's (d3il_amd/envs/sub_batch.py SubBatchSet - what the Sim classes use)
+        n, env_offset = sb.n, args.rank_offset + sb.offset
         self.task, self.n, self.env_offset, self.dev = task, n, env_offset, dev
-        self.own_stream = args.sub_batches > 1
-        self.stream = torch.cuda.Stream(dev) if self.own_stream else torch.cuda.current_stream(dev)
+        self.own_stream, self.stream = sb.own_stream, sb.stream
         with torch.cuda.stream(self.stream):
-            if task == "avoiding":
-                from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
-                env = ObstacleAvoidanceVecEnv(n, device=dev)
-            elif task == "pushing":
-                from d3il_amd.envs.pushing import BlockPushVecEnv
-                env = BlockPushVecEnv(n, device=dev)
-            elif task == "sorting":
-                from d3il_amd.envs.sorting import SortingVecEnv
-                env = SortingVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 700)     # configs/sorting_4_config.yaml:80
-            elif task == "aligning":
-                from d3il_amd.envs.aligning import RobotPushVecEnv
-                env = RobotPushVecEnv(n, device=dev)
-            elif task == "inserting":
-                from d3il_amd.envs.inserting import GateInsertionVecEnv
-                env = GateInsertionVecEnv(n, device=dev, max_steps_per_episode=args.max_steps or 2000)     # gate_insertion.py:158 (the reference has no config for this task)
-            else:
-                from d3il_amd.envs.stacking import CubeStackingVecEnv
-                env = CubeStackingVecEnv(n, device=dev)
-            self.env = env
-            if self.own_stream:
-                env.bind_stream(self.stream)      # the library launches this sub-batch's kernels on its stream; no stream context per call
+            env = self.env = sb.env
             env.set_init_qpos(q)
             if args.lanes is not None:
                 env.set_option("lanes_per_wave", args.lanes)
@@ -377,11 +378,8 @@ class _Shard:
                 env.set_option("split_waves", args.split)
             if args.lds_pad is not None:
                 env.set_option("lds_pad_bytes", args.lds_pad)
-            if args.serve_max_wg is not None:
+            if args.serve_max_wg is not None:      # otherwise SubBatchSet's rule: 256 CUs / number of sub-batches (the library sees one sub-batch, the set all of them)
                 env.set_option("serve_wave_max_workgroups", args.serve_max_wg)
-            elif task == "avoiding" and args.sub_batches > 1:
-                # the third wave pays while the GPU as a whole holds at most one workgroup per CU: the library sees one sub-batch, the harness all of them
-                env.set_option("serve_wave_max_workgroups", 256 // args.sub_batches)
             if args.solver_strict:
                 env.set_option("solver_strict", 1)
             ctx_id = None
@@ -523,7 +521,10 @@ def run(args):
     if task == "stacking" and (args.policy or "scripted_stack") == "scripted_stack":
         from d3il_amd.controllers.scripted_stacking import build_trajectory
         stack_tables = [build_trajectory(js, q, c, speed=0.5) for c in ctx60]     # host IK once per context (untimed set-up)
-    shards = [_Shard(args, task, dev, n // S, env_offset + i * (n // S), ctx60, q, stack_tables) for i in range(S)]
+    from d3il_amd.envs.sub_batch import SubBatchSet
+    args.rank_offset = env_offset
+    batches = SubBatchSet(n, S, dev, lambda cnt, off: _make_env(args, task, dev, cnt))      # handles, streams, serve-wave threshold, hardware queues
+    shards = [_Shard(args, task, dev, sb, ctx60, q, stack_tables) for sb in batches]
     env = shards[0].env
     policy, pol = shards[0].policy, shards[0].pol
     max_steps = env.max_steps_per_episode

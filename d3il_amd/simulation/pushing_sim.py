@@ -19,7 +19,8 @@ import torch
 
 from ..distributed import reduce_sim_counts, shard_range, world_info
 from ..envs.pushing import BlockPushVecEnv, contexts_from_reference
-from ..agents import as_batched
+from ..envs.sub_batch import SubBatchSet
+from ._rollout import xy_rollout
 from .base_sim import BaseSim
 from .metrics import pushing_metrics
 
@@ -38,8 +39,10 @@ def load_test_contexts(path: str | None = None) -> np.ndarray:
 
 class Pushing_Sim(BaseSim):
     def __init__(self, seed: int, device: str, render: bool, n_cores: int = 1, n_contexts: int = 30,
-                 n_trajectories_per_context: int = 1, max_steps_per_episode: int = 400, contexts: np.ndarray | None = None):
+                 n_trajectories_per_context: int = 1, max_steps_per_episode: int = 400, contexts: np.ndarray | None = None, n_sub_batches: int = 1):
         super().__init__(seed, device, render, n_cores)
+        # the reference's n_cores worker processes (pushing_sim.py:129-165) become sub-batches of the GPU batch on their own streams (envs/sub_batch.py)
+        self.n_sub_batches = n_sub_batches
         self.n_contexts = n_contexts
         self.n_trajectories_per_context = n_trajectories_per_context
         self.max_steps_per_episode = max_steps_per_episode
@@ -57,36 +60,24 @@ class Pushing_Sim(BaseSim):
         n = hi - lo
         dev = torch.device(self.device)
         ctx_of = torch.arange(lo, hi, device=dev) // self.n_trajectories_per_context          # context index of each rollout
-        agent = as_batched(agent, n)
-        agent.reset()
-        quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
-        finished = torch.zeros(n, dtype=torch.bool, device=dev)
         mode = torch.full((n,), -1, dtype=torch.int64, device=dev)
         success = torch.zeros(n, dtype=torch.bool, device=dev)
         mean_distance = torch.zeros(n, dtype=torch.float64, device=dev)
-        env, flags = None, torch.zeros(0, dtype=torch.int32, device=dev)
+        env, batches, flags = None, None, torch.zeros(0, dtype=torch.int32, device=dev)
         if n > 0:      # a rank whose shard is empty (fewer rollouts than ranks) only takes part in the reductions below
-            env = BlockPushVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
-            env.start()
-            obs = env.reset(random=False, context=self.contexts[ctx_of.cpu().numpy()])
-            pred_action = env.robot_state().clone()                        # pushing_sim.py:69-70
-            fixed_z = pred_action[:, 2:3].clone()
-            des_xy = pred_action[:, :2].clone()
-            for t in range(self.max_steps_per_episode):
-                obs10 = torch.cat((des_xy, obs.to(torch.float64)), dim=1)   # np.concatenate((pred_action[:2], obs)), pushing_sim.py:75
-                delta = self._predict(agent, obs10)
-                des_new = delta + obs10[:, :2]                              # pushing_sim.py:78
-                des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
-                action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
-                obs, _, done, info = env.step(action)
-                newly = ~finished & done.bool()
-                mode = torch.where(newly, info["mode"].to(torch.int64), mode)
-                success = torch.where(newly, info["success"].bool(), success)
-                mean_distance = torch.where(newly, info["mean_distance"], mean_distance)
-                finished |= done.bool()
-                if t % 16 == 15 and bool(finished.all()):                  # the only host synchronisation of the loop
-                    break
-            flags = env.flags[:n].clone()
+            ctx_np = self.contexts[ctx_of.cpu().numpy()]
+
+            def make_env(cnt, off):
+                e = BlockPushVecEnv(cnt, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
+                e.start()
+                e.reset(random=False, context=ctx_np[off:off + cnt])
+                return e
+            batches = SubBatchSet(n, self.n_sub_batches, dev, make_env)
+            batches.fork_agents(agent)
+            # the rollout loop of pushing_sim.py:69-84 per sub-batch (simulation/_rollout.py)
+            res = xy_rollout(batches, self.max_steps_per_episode, {"mode": (torch.int64, -1), "success": (torch.bool, False), "mean_distance": (torch.float64, 0.0)}, predict=self._predict)
+            mode, success, mean_distance, flags = res["mode"], res["success"], res["mean_distance"], res["flags"]
+            env = batches.batches[0].env
         # integer tables: mode counts of the successful rollouts per context, number of successes; f64 distance sum
         counts = torch.zeros(self.n_contexts * 4 + 1, dtype=torch.int64, device=dev)
         ok = success & (mode >= 0)
@@ -103,8 +94,8 @@ class Pushing_Sim(BaseSim):
                                  success_rate=success_rate, entropy=entropy, mode_probs=mode_probs,
                                  mean_distance_all=float(dist_sum.item()) / total, flags=flags)
         log.info("Successrate %s entropy %s mean distance %s", success_rate, entropy, float(dist_sum.item()) / total)
-        if env is not None:
-            env.close()
+        if batches is not None:
+            batches.close()
         # the reference returns the full [n_contexts, n_trajectories] tables (pushing_sim.py:178): every rank fills its slice of a
         # zero table and the slices are summed (one more small all-reduce, outside the rollout)
         full = torch.zeros(3, total, dtype=torch.float64, device=dev)

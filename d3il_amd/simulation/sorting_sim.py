@@ -23,7 +23,8 @@ import torch
 
 from ..distributed import reduce_sim_counts, shard_range, world_info
 from ..envs.sorting import SortingVecEnv, contexts_from_reference, sample_contexts
-from ..agents import as_batched
+from ..envs.sub_batch import SubBatchSet
+from ._rollout import xy_rollout
 from .base_sim import BaseSim
 from .metrics import sorting_metrics
 
@@ -49,8 +50,10 @@ def load_reference_data(contexts_pkl: str, mode_prob_pkl: str, num_box: int = 4)
 class Sorting_Sim(BaseSim):
     def __init__(self, seed: int, device: str, render: bool, n_cores: int = 1, n_contexts: int = 30, n_trajectories_per_context: int = 1,
                  num_box: int = 4, if_vision: bool = False, max_steps_per_episode: int = 500, contexts: np.ndarray | None = None,
-                 mode_prob: dict | None = None):
+                 mode_prob: dict | None = None, n_sub_batches: int = 1):
         super().__init__(seed, device, render, n_cores, if_vision)
+        # the reference's n_cores worker processes (sorting_sim.py:160-189) become sub-batches of the GPU batch on their own streams (envs/sub_batch.py)
+        self.n_sub_batches = n_sub_batches
         if num_box not in (2, 4):
             raise NotImplementedError("this build carries the Sorting-2 and Sorting-4 scenes")
         self.n_contexts, self.n_trajectories_per_context = n_contexts, n_trajectories_per_context
@@ -76,34 +79,23 @@ class Sorting_Sim(BaseSim):
         n = hi - lo
         dev = torch.device(self.device)
         ctx_of = torch.arange(lo, hi, device=dev) // self.n_trajectories_per_context
-        agent = as_batched(agent, n)
-        agent.reset()
-        quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
-        finished = torch.zeros(n, dtype=torch.bool, device=dev)
         mode = torch.zeros(n, dtype=torch.int64, device=dev)
         success = torch.zeros(n, dtype=torch.bool, device=dev)
-        env, flags = None, torch.zeros(0, dtype=torch.int32, device=dev)
+        env, batches, flags = None, None, torch.zeros(0, dtype=torch.int32, device=dev)
         if n > 0:      # a rank whose shard is empty (fewer rollouts than ranks) only takes part in the reductions below
-            env = SortingVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode, num_boxes=self.num_box)
-            env.start()
-            obs = env.reset(random=False, context=self.test_contexts[ctx_of.cpu().numpy()])
-            pred_action = env.robot_state().clone()                        # sorting_sim.py:120-121
-            fixed_z = pred_action[:, 2:3].clone()
-            des_xy = pred_action[:, :2].clone()
-            for t in range(self.max_steps_per_episode):
-                obs_in = torch.cat((des_xy, obs.to(torch.float64)), dim=1)  # np.concatenate((pred_action[:2], obs)), sorting_sim.py:124
-                delta = self._predict(agent, obs_in)
-                des_new = delta + obs_in[:, :2]                             # sorting_sim.py:127
-                des_xy = torch.where(finished.unsqueeze(1), des_xy, des_new)
-                action = torch.cat((des_xy, fixed_z, quat), dim=1).contiguous()
-                obs, _, done, info = env.step(action)
-                newly = ~finished & done.bool()
-                mode = torch.where(newly, info["mode"].to(torch.int64), mode)
-                success = torch.where(newly, info["success"].bool(), success)
-                finished |= done.bool()
-                if t % 16 == 15 and bool(finished.all()):                  # the only host synchronisation of the loop
-                    break
-            flags = env.flags[:n].clone()
+            ctx_np = self.test_contexts[ctx_of.cpu().numpy()]
+
+            def make_env(cnt, off):
+                e = SortingVecEnv(cnt, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode, num_boxes=self.num_box)
+                e.start()
+                e.reset(random=False, context=ctx_np[off:off + cnt])
+                return e
+            batches = SubBatchSet(n, self.n_sub_batches, dev, make_env)
+            batches.fork_agents(agent)
+            # the rollout loop of sorting_sim.py:118-133 per sub-batch (simulation/_rollout.py)
+            res = xy_rollout(batches, self.max_steps_per_episode, {"mode": (torch.int64, 0), "success": (torch.bool, False)}, predict=self._predict)
+            mode, success, flags = res["mode"], res["success"], res["flags"]
+            env = batches.batches[0].env
         # integer table: per context, successful rollouts whose mode code is the k-th key of the prior; number of successes
         keys = torch.as_tensor(self.mode_keys, dtype=torch.int64, device=dev)
         hit = (mode.unsqueeze(1) == keys.unsqueeze(0)) & success.unsqueeze(1)                 # [n, n_mode]
@@ -119,7 +111,7 @@ class Sorting_Sim(BaseSim):
                                                            self.mode_encoding.numpy())
         self.last_rollout = dict(mode=mode, success=success, counts=c, mode_hist=mode_hist.cpu().numpy(), shard=(lo, hi), flags=flags)
         log.info("Successrate %s entropy %s KL %s", success_rate, entropy, kl)
-        if env is not None:
-            env.close()
+        if batches is not None:
+            batches.close()
         # the quantities the reference logs (sorting_sim.py:209-212)
         return {"score": score, "Metrics/successes": success_rate, "Metrics/KL": kl, "Metrics/entropy": entropy}

@@ -1,0 +1,111 @@
+"""Sub-batches in the product (envs/sub_batch.py, the Sim classes' ``n_sub_batches``): the reference's n_cores process fan-out
+(simulation/avoiding_sim.py:87-124, sorting_sim.py:160-189) as independent environment batches on their own HIP streams.
+
+CPU: the partition and the agent fork.  GPU: ``Avoiding_Sim`` / ``Sorting_Sim`` / ``Pushing_Sim`` with four sub-batches return the integer tables of one
+batch, bit for bit (rollouts are independent; the policies used here compute every row from that row alone, so nothing depends on which rows share a
+batch)."""
+import collections
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+def test_plan_partitions_contiguously():
+    from d3il_amd.envs.sub_batch import plan
+    assert plan(4096, 4) == [(0, 1024), (1024, 1024), (2048, 1024), (3072, 1024)]
+    assert plan(300, 4) == [(0, 75), (75, 75), (150, 75), (225, 75)]
+    assert plan(301, 4) == [(0, 76), (76, 75), (151, 75), (226, 75)]
+    assert plan(130, 4) == [(0, 65), (65, 65)]           # every sub-batch at least one wavefront of environments
+    assert plan(63, 4) == [(0, 63)] and plan(1, 1) == [(0, 1)] and plan(1000, 1) == [(0, 1000)]
+    for n in (64, 257, 1000, 4097):
+        for s in (1, 2, 3, 4, 8):
+            p = plan(n, s)
+            assert p[0][0] == 0 and sum(c for _, c in p) == n and all(p[i][0] + p[i][1] == p[i + 1][0] for i in range(len(p) - 1))
+
+
+def test_fork_agent_shares_weights_and_copies_episode_state():
+    from d3il_amd.envs.sub_batch import fork_agent
+
+    class Agent:
+        def __init__(self):
+            self.model = torch.nn.Linear(4, 2)
+            self.window = collections.deque(maxlen=3)
+            self.hist = torch.zeros(5)
+            self.scale = 2.0
+
+        def reset(self):
+            self.window.clear()
+
+        def predict_batch(self, o):
+            return o[:, :2]
+
+    a = Agent()
+    a.window.append(1)
+    b = fork_agent(a)
+    assert b.model is a.model and b.scale == a.scale
+    assert b.window is not a.window and list(b.window) == [1] and b.hist is not a.hist
+    b.window.append(2); b.hist += 1
+    assert list(a.window) == [1] and float(a.hist.sum()) == 0.0
+
+    class Forking(Agent):
+        def fork(self):
+            return "mine"
+    assert fork_agent(Forking()) == "mine"
+
+
+class RowPolicy:
+    """delta = 6 mm towards a goal that depends on the row's own observation and on WHICH rollout the row is (set_rollout_range)."""
+
+    def reset(self):
+        pass
+
+    def set_rollout_range(self, offset, count):
+        self.offset = offset
+
+    @torch.no_grad()
+    def predict_batch(self, obs_in):
+        o = obs_in.to(torch.float64)
+        des, tcp = o[:, :2], o[:, 2:4]
+        k = self.offset + torch.arange(o.shape[0], device=o.device, dtype=torch.float64)
+        goal = torch.stack((0.5 + 0.15 * torch.sin(0.37 * k + 40.0 * tcp[:, 1]), tcp[:, 1] + 0.05), dim=1)
+        d = goal - des
+        return d / d.norm(dim=1, keepdim=True).clamp_min(1e-9) * 0.006
+
+
+@pytest.mark.gpu
+def test_avoiding_sim_sub_batches_identical_tables():
+    from d3il_amd.simulation.avoiding_sim import Avoiding_Sim
+    out = []
+    for S in (1, 4):
+        sim = Avoiding_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_trajectories=320, max_steps_per_episode=120, n_sub_batches=S)
+        succ, ent = sim.test_agent(RowPolicy())
+        r = sim.last_rollout
+        out.append((succ.cpu().numpy(), ent, r["counts"].copy(), r["mode_code"].cpu().numpy(), r["n_pos"].cpu().numpy(), r["c_pos"].cpu().numpy()))
+    a, b = out
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])          # the logged TCP paths too: the sub-batches computed the same rollouts
+    assert len(np.unique(a[3])) > 1                                           # and the rollouts are not all alike
+
+
+@pytest.mark.gpu
+def test_sorting_and_pushing_sim_sub_batches_identical_tables():
+    from d3il_amd.agents import ScriptedPushPolicy
+    from d3il_amd.simulation.pushing_sim import Pushing_Sim
+    from d3il_amd.simulation.sorting_sim import Sorting_Sim
+    res = {}
+    for S in (1, 4):
+        sim = Sorting_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=60, n_trajectories_per_context=5, max_steps_per_episode=150, n_sub_batches=S)
+        m = sim.test_agent(ScriptedPushPolicy("sorting", device="cuda:0"))
+        r = sim.last_rollout
+        res["sorting", S] = (r["counts"].copy(), r["mode"].cpu().numpy(), r["success"].cpu().numpy(), r["mode_hist"].copy(), m["Metrics/entropy"])
+        assert not bool((r["flags"] & ((1 << 16) | (1 << 18))).any())
+        sim = Pushing_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=60, n_trajectories_per_context=5, max_steps_per_episode=200, n_sub_batches=S)
+        sim.test_agent(ScriptedPushPolicy("pushing", device="cuda:0"))
+        r = sim.last_rollout
+        res["pushing", S] = (r["counts"].copy(), r["mode"].cpu().numpy(), r["success"].cpu().numpy(), r["mean_distance"].cpu().numpy())
+    for task in ("sorting", "pushing"):
+        for x, y in zip(res[task, 1], res[task, 4]):
+            assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), task      # (the entropy of a table without successes is nan in both)
+    assert len(np.unique(res["sorting", 1][1])) > 1          # some cubes were delivered: the tables are not trivially equal
