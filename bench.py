@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
-PROFILE_DIRS = ("r04", "r03", "r02", "r01")  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
+PROFILE_DIRS = ("r05",)  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
 
 # Algorithmic HBM bytes per env step: SURVEY.md section 8(d)'s per-unit figures B_alg = 2 S + A + O + F (state read once + written once per
 # fused step, f64 state, f32 action / observation) - these define `roofline.achieved`.  IMPL_BYTES is what THIS implementation's state
@@ -52,7 +52,6 @@ IMPL_BYTES = {
     "inserting": 2 * (110 * 8 + 4 + 4) + 56 + 44 + 4,
 }
 KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true, false>", "stacking": "k_stacking_step", "aligning": "k_aligning_step", "inserting": "k_sorting_step<true, true>"}
-PMC_FILE = {"aligning": "pmc_summary_aligning.json", "avoiding": "pmc_summary_bench300.json", "pushing": "pmc_summary_pushing.json", "sorting": "pmc_summary_sorting.json", "stacking": "pmc_summary_stacking.json", "inserting": "pmc_summary_inserting.json"}
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline (oracle)
@@ -237,19 +236,25 @@ def _self_spawn(n_gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def _pmc(task, n):
-    """HBM traffic / VALU counters per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
-    (the PMC passes are separate runs by construction: counters cannot be collected inside the timed run)."""
+def _pmc(task, policy, n, S):
+    """Counters per launch of the step kernel from the committed rocprofv3 --pmc passes of THIS command line - same task, policy (regime), environments
+    per GPU and sub-batch count (tools/profile_r05.sh writes profiles/<round>/pmc/<task>_<policy>_sb<S>.json; the passes are separate runs by construction:
+    counters cannot be collected inside the timed run, and a counter pass serialises dispatches).  No borrowing across regimes: a line whose command was
+    not profiled carries no traffic figure."""
     if n != 4096:
         return None, None
     for d in PROFILE_DIRS:
-        path = os.path.join(ROOT, "profiles", d, PMC_FILE[task])
+        path = os.path.join(ROOT, "profiles", d, "pmc", "%s_%s_sb%d.json" % (task, policy, S))
         try:
             with open(path) as f:
                 return json.load(f), os.path.relpath(path, ROOT)
         except Exception:
             continue
     return None, None
+
+
+def _hbm_bytes(pm):
+    return (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0      # MI355X_MICROARCH.md: KiB units, FETCH_SIZE counts half on gfx950
 
 
 def _isa_mix(task):
@@ -622,10 +627,27 @@ def run(args):
         k_ms = sum(x[0] for x in tstats) / n_launches if n_launches else float("nan")
         alg = ALG_BYTES[task]
         achieved = alg * n_launch / (k_ms * 1e-3) / 1e9      # per launch of the step kernel: n_launch environments (one sub-batch)
-        pm, pm_path = _pmc(task, n) if S == DEFAULT_SUB_BATCHES.get(task, 1) else (None, None)      # the committed counter passes ran the default command: same launch size
-        traffic, valu = None, None
+        pm, pm_path = _pmc(task, policy, n, S)
+        traffic, traffic_isolated, traffic_note, valu = None, None, None, None
         if pm is not None:
-            traffic = (2 * pm["FETCH_SIZE"]["mean_per_dispatch"] + pm["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+            traffic_isolated = _hbm_bytes(pm)
+            if S == 1:
+                traffic = traffic_isolated
+                traffic_note = "%s: separate rocprofv3 --pmc passes of this command (not this run); one launch per step, alone on the chip in the timed run too" % pm_path
+            else:
+                # A counter pass serialises dispatches: each launch of a sub-batch was measured ALONE on the chip, its working set having the whole L2 to
+                # itself.  In the timed run the S launches of a step are in flight together and share the L2: their combined working set is that of ONE launch
+                # over all environments, which the --sub-batches 1 passes of the same command measured without serialisation artefacts (that launch is alone
+                # in the timed run as well).  traffic = that figure / S (per launch of a sub-batch, under the concurrency of this run); traffic_isolated = the
+                # serialised per-launch figure.
+                pm1, pm1_path = _pmc(task, policy, n, 1)
+                if pm1 is not None:
+                    traffic = _hbm_bytes(pm1) / S
+                    traffic_note = ("%s / %d: the %d launches of a step run concurrently and share the L2 - their combined working set is that of one launch over all %d "
+                                    "environments, measured by the --sub-batches 1 counter passes of this command; traffic_isolated (%s): the serialised counter passes of "
+                                    "this command, every launch of %d environments alone on the chip" % (pm1_path, S, S, n, pm_path, n_launch))
+                else:
+                    traffic_note = "%s holds the serialised per-launch figure only (traffic_isolated); no --sub-batches 1 pass of this command is committed" % pm_path
             if "SQ_INSTS_VALU" in pm and "SQ_WAVE_CYCLES" in pm:
                 # binding resource: FP64 VALU issue.  Dynamic VALU instruction count from the PMC pass x the flop per VALU instruction COUNTED in the
                 # kernel's ISA (tools/isa_fp64_mix.py -> profiles/<round>/isa_fp64_mix.json: FMA-class FP64 = 2 flop, other FP64 arithmetic = 1, the
@@ -674,9 +696,7 @@ def run(args):
                        "ms_per_step_by_rank": {"min": min(dt_by_rank) / args.steps * 1e3, "max": max(dt_by_rank) / args.steps * 1e3,
                                                "all": [x / args.steps * 1e3 for x in dt_by_rank]}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command, not this run%s)" % (pm_path, "; the counter passes serialise dispatches, so each launch "
-                                            "of %d environments was measured ALONE on the chip - with %d sub-batches in flight their combined working set competes for the L2 "
-                                            "(DESIGN section 18.10)" % (n_launch, S) if S > 1 else "")) if pm_path else None,
+                         "traffic": traffic, "traffic_isolated": traffic_isolated, "traffic_source": traffic_note,
                          "kernel": ("k_avoiding_step_split<true, false>" if task == "avoiding" and (n_launch + 63) // 64 > (args.serve_max_wg if args.serve_max_wg is not None else 256 // S) else KERNEL[task]),
                          "kernel_ms": k_ms,
                          "kernel_launches_timed": n_launches,

@@ -42,14 +42,19 @@ VALIDATED_HIP = "7.2"
 
 
 def check_compiler(verbose: bool = False) -> str:
-    """HIP version line of the compiler; warns when it is not the validated one (the kernels' correctness was established per compiler)."""
+    """HIP version line of the compiler.  A compiler other than the validated one is REFUSED (the Stacking / Aligning kernels' correctness was established
+    per compiler: DESIGN sections 17.3 / 18.2) unless D3IL_ALLOW_UNVALIDATED=1 is set - then it is a warning, and `python tools/gpu_stack_perm.py 8192 300`
+    has to pass on a GPU before the kernels are trusted."""
     out = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout
     line = next((l for l in out.splitlines() if l.startswith("HIP version")), "HIP version: unknown")
     ver = line.split(":", 1)[1].strip()
     if not ver.startswith(VALIDATED_HIP):
+        msg = ("libd3il_rollout is validated with hipcc of HIP %s.x; this is %s - run tools/gpu_stack_perm.py (DESIGN section 18.2) before trusting the "
+               "Stacking / Aligning kernels" % (VALIDATED_HIP, ver))
+        if os.environ.get("D3IL_ALLOW_UNVALIDATED") != "1":
+            raise RuntimeError(msg + "; set D3IL_ALLOW_UNVALIDATED=1 to build anyway")
         import warnings
-        warnings.warn("libd3il_rollout is validated with hipcc of HIP %s.x; this is %s - run tools/gpu_stack_perm.py (DESIGN section 18.2) before trusting the "
-                      "Stacking / Aligning kernels" % (VALIDATED_HIP, ver))
+        warnings.warn(msg)
     elif verbose:
         print(line)
     return ver

@@ -110,3 +110,25 @@ def test_python_binding_constants_agree_with_the_header():
         if decl:
             fields += [n.strip().lstrip("*") for n in decl.split(None, 1)[1].split(",")]
     assert fields == [f[0] for f in capi.Buffers._fields_]
+
+
+def test_build_refuses_an_unvalidated_compiler(monkeypatch):
+    """build.check_compiler raises for a hipcc whose HIP version is not the validated one unless D3IL_ALLOW_UNVALIDATED=1 (then it warns)."""
+    import subprocess
+    import warnings
+    from d3il_amd import build as b
+
+    class R:
+        stdout = "HIP version: 9.9.12345-abc\nclang version 99\n"
+    monkeypatch.setattr(b, "hipcc", lambda: "hipcc")
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
+    monkeypatch.delenv("D3IL_ALLOW_UNVALIDATED", raising=False)
+    with pytest.raises(RuntimeError, match="validated"):
+        b.check_compiler()
+    monkeypatch.setenv("D3IL_ALLOW_UNVALIDATED", "1")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert b.check_compiler() == "9.9.12345-abc" and len(w) == 1
+    R.stdout = "HIP version: %s.26015-fc0010cf6a\n" % b.VALIDATED_HIP
+    monkeypatch.delenv("D3IL_ALLOW_UNVALIDATED", raising=False)
+    assert b.check_compiler().startswith(b.VALIDATED_HIP)
