@@ -960,7 +960,9 @@ D3IL_HD void gen_phase4_multi(const GenConsts& gc_, const PushScratch sc, int l,
 #if defined(D3IL_HOST_STATS)
     int hkey_ = 0; long hit0_ = g_stats.newton_iters;
     { int nrod = 0; GEN_FOR_BLOCKS(b) if (b < gc.nb && (((unsigned)GLS(GL_INFO + b) >> 9) & 1)) nrod++;
-      hkey_ = (isl.n - (isl.arm ? 1 : 0)) + (isl.arm ? 5 : 0) + 10 * (nrod > 3 ? 3 : nrod); g_isl_hist[hkey_]++; }
+      hkey_ = (isl.n - (isl.arm ? 1 : 0)) + (isl.arm ? 5 : 0) + 10 * (nrod > 3 ? 3 : nrod); g_isl_hist[hkey_]++;
+      int nedge = 0; GEN_FOR_BLOCKS(b2) if (b2 < gc.nb) nedge += __builtin_popcount(((unsigned)GLS(GL_INFO + b2) >> 5) & 15u);      // cube <-> cube pairs in contact inside the island
+      if (nedge < 4) g_isl_hist[36 + nedge]++; }
 #endif
     if (!gen_solve<RS>(gc, sc, isl, cpk, l, nl)) fl |= F_SOLVER_FAIL;
 #if defined(D3IL_HOST_STATS)

@@ -125,6 +125,35 @@ def n_workers() -> int:
     return max(1, _available_cores()[0])
 
 
+def inserting_episode(job):
+    """job = (index, ctx [3 x 7], init_qpos, waypoints [3 x 2], steps) -> (index, letters, code, success, first step with a letter or -1).  The action
+    sequence is the open-loop waypoint walk of tests/test_gpu_count_parity.py (6 mm per step towards the current waypoint): a function of the job alone."""
+    i, ctx, q0, way, steps = job
+    from d3il_amd.model import blob
+    from oracle.oracle import Oracle
+    b = blob.load("inserting")
+    o = Oracle(b)
+    o.env_start(q0)
+    obs = o.ins_reset(np.asarray(ctx, dtype=np.float64).reshape(21))
+    tcp = o.body(b.tcp_body)[0]
+    z = float(tcp[2])
+    des = obs[:2].astype(np.float64)              # the harness latches the f32 observation of the TCP (like the device loop of the test)
+    way = np.asarray(way, dtype=np.float64)
+    wi, first, info = 0, -1, dict(n_mode=0, mode=0, success=False)
+    for t in range(steps):
+        d = way[wi] - des
+        nn = float(np.sqrt((d * d).sum()))
+        if nn < 1e-9 and wi < 2:
+            wi += 1
+            d = way[wi] - des
+            nn = float(np.sqrt((d * d).sum()))
+        des = des + d / max(nn, 1e-12) * min(nn, 0.006)
+        obs, done, info = o.ins_step(np.array([des[0], des[1], z, 0, 1, 0, 0]))
+        if info["n_mode"] and first < 0:
+            first = t
+    return i, int(info["n_mode"]), int(info["mode"]), bool(info["success"]), first
+
+
 def run_many(fn, jobs):
     """Results of fn over the jobs, in job order, on all host cores this container may use."""
     import concurrent.futures as cf

@@ -184,3 +184,78 @@ def test_stacking_success_and_mode_tables_over_full_episodes():
     s = _compare("stacking", dev_rows, orc_rows)          # every context identical: (success, order string) tables bit-exact
     assert s["oracle_successes"] >= nctx // 2, "the scripted pick-and-place should stack three boxes on most contexts"
     assert s["device_successes"] == s["oracle_successes"]
+
+
+def test_inserting_letter_tables_over_scripted_gate_pushes():
+    """Inserting (gate_insertion.py:386-432: the `modes` letters, the mode code, success) over whole scripted episodes, every context compared with the oracle
+    - the task has no Sim class in the reference, so the env protocol is the boundary (VERDICT r4 missing #7).  32 contexts: the red cube in the mouth of
+    its gate with small position / yaw variations, pushed west into the goal by an open-loop waypoint walk (the scenario of
+    test_gpu_parity_inserting.test_physically_produced_insertions_match_oracle); two contexts push the green cube north instead.
+    The table (letters, code, success) must be IDENTICAL on every context on which the oracle agrees with itself under K = 4 perturbations of 1e-12 m
+    (fixed beforehand; the rule of the other tasks), and inside the oracle's own outcome set on the others."""
+    from d3il_amd.envs.inserting import GateInsertionVecEnv
+    from tests import oracle_episodes as oe
+    n, steps, K = 32, 170, 4
+    rng = np.random.default_rng(11)
+    park = np.array([[0.40, -0.17, 0, 1, 0, 0, 0], [0.62, -0.08, 0, 1, 0, 0, 0], [0.45, 0.02, 0, 1, 0, 0, 0]], float)
+    ctx = np.tile(park[None], (n, 1, 1))
+    way = np.zeros((n, 3, 2))
+    way[:] = np.array([(0.49, 0.10), (0.49, 0.276), (0.388, 0.276)])
+    for e in range(n):
+        if e % 16 == 15:      # the green cube from the south into its gate
+            ctx[e, 1, :2] = [0.525 + rng.uniform(-0.001, 0.001), 0.36]
+            ctx[e, 2, :2] = [0.40, 0.02]
+            way[e] = np.array([(0.525, 0.30), (0.525, 0.425), (0.525, 0.425)])
+        else:
+            yaw = rng.uniform(-0.03, 0.03)
+            ctx[e, 0, :2] = [0.41 + 0.0005 * e, 0.276 + rng.uniform(-0.001, 0.001)]
+            ctx[e, 0, 3:] = [np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+    env = GateInsertionVecEnv(n, device=0)
+    q0 = env.start()[0]
+    env.reset(context=ctx.reshape(n, 21))
+    z = env.robot_state()[:, 2:3].clone()
+    des = env.obs[:, :2].to(torch.float64).clone()
+    wayt = torch.as_tensor(way, dtype=torch.float64, device=des.device)
+    wi = torch.zeros(n, dtype=torch.long, device=des.device)
+    ar = torch.arange(n, device=des.device)
+    quat = torch.tensor([0.0, 1, 0, 0], dtype=torch.float64, device=des.device).expand(n, 4)
+    first_dev = np.full(n, -1)
+    for t in range(steps):
+        d = wayt[ar, wi] - des
+        nn = d.norm(dim=1, keepdim=True)
+        wi = torch.where((nn[:, 0] < 1e-9) & (wi < 2), wi + 1, wi)
+        d = wayt[ar, wi] - des
+        nn = d.norm(dim=1, keepdim=True)
+        des = des + d / nn.clamp_min(1e-12) * torch.minimum(nn, torch.full_like(nn, 0.006))
+        obs, rew, done, info = env.step(torch.cat([des, z, quat], 1).contiguous())
+        nm = (env.mode.to(torch.int32) >> 3).cpu().numpy()
+        first_dev = np.where((first_dev < 0) & (nm > 0), t, first_dev)
+    torch.cuda.synchronize()
+    assert not (env.flags[:n].cpu().numpy() & ((1 << 16) | (1 << 18) | (1 << 19))).any()
+    code = env.mode.to(torch.int32).cpu().numpy()
+    dev_rows = [(int(code[e] >> 3), int(code[e] & 7), bool(env.success[e])) for e in range(n)]
+    env.close()
+    jobs = []
+    for e in range(n):
+        for k in range(K + 1):
+            c = ctx[e].copy()
+            c[0 if e % 16 != 15 else 1, 0] += k * 1e-12
+            jobs.append((e * 100 + k, c, q0, way[e], steps))
+    res = {i: (nl, cd, su, fs) for i, nl, cd, su, fs in oe.run_many(oe.inserting_episode, jobs)}
+    orc_rows = [res[e * 100][:3] for e in range(n)]
+    sets = {e: sorted({res[e * 100 + k][:3] for k in range(K + 1)}) for e in range(n)}
+    undecided = [e for e in range(n) if len(sets[e]) > 1]
+    diff = [e for e in range(n) if dev_rows[e] != orc_rows[e]]
+    summary = dict(task="inserting", contexts=n, identical=n - len(diff), differing=diff, undecided=undecided, K=K,
+                   device=[list(map(int, r)) for r in dev_rows], oracle=[list(map(int, r)) for r in orc_rows],
+                   first_letter_step_device=first_dev.tolist(), first_letter_step_oracle=[res[e * 100][3] for e in range(n)],
+                   device_outside_oracle_set=[e for e in undecided if dev_rows[e] not in sets[e]])
+    _dump("count_parity_inserting.json", summary)
+    print("\ninserting: %d of %d contexts with identical (letters, code, success); undecided under K = %d perturbations: %s; differing: %s" % (n - len(diff), n, K, undecided, diff))
+    assert not [e for e in diff if e not in undecided], summary
+    assert not summary["device_outside_oracle_set"], summary
+    assert len(undecided) <= 4
+    # the letters appear at the oracle's step on the decided contexts, and most of the batch does insert
+    dec = [e for e in range(n) if e not in undecided]
+    assert [int(first_dev[e]) for e in dec] == [res[e * 100][3] for e in dec]
+    assert sum(1 for r in dev_rows if r[0] >= 1) >= 20

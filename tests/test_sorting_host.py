@@ -144,3 +144,34 @@ def test_cube_over_the_table_edge_meets_the_frame_beam(sort_blob, sort_init_qpos
         assert not (ih["flags"] & ((1 << 16) | (1 << 18)))
     assert beam_steps >= 3, "the cube should have been carried by the front beam for a few steps"
     assert h.box(0)[0][0] > 0.95 and abs(h.box(1)[0][0] - 0.86) < 1e-3 and abs(h.box(1)[0][2] - 0.011) < 1e-3
+
+
+def test_rod_on_two_cubes(sort_blob, sort_init_qpos):
+    """A context in which the scripted push brings the rod against two cubes at once (env steps 73 ..): the island {arm, two cubes} is not one the tree
+    solver takes (two rod contacts: the six rows of two points on one rigid rod are dependent) - the joint solver runs next to the tree solver.
+    Same trajectory as the oracle's at the conditioning level of the contact regime."""
+    torch = pytest.importorskip("torch")
+    from d3il_amd.agents import ScriptedPushPolicy
+    from d3il_amd.envs.sorting import sample_contexts
+    from tests.hostcheck.hostcheck import lib, _p
+    ctx = sample_contexts(60, 4, seed=0)[1]
+    o = Oracle(sort_blob)
+    o.env_start(sort_init_qpos)
+    h = GenHostCheck(sort_blob)
+    obs = o.sort_reset(ctx.reshape(4, 7))
+    h.reset(sort_init_qpos, ctx)
+    pol = ScriptedPushPolicy("sorting", device="cpu")
+    des, z = np.array(obs[:2], dtype=float), float(h.s[27])
+    hist = np.zeros(80, dtype=np.int64)
+    lib().hc_gen_island_hist(_p(hist), 1)
+    worst = 0.0
+    for t in range(82):
+        des = des + pol.predict_batch(torch.as_tensor(np.concatenate([des, obs.astype(float)])[None]))[0].numpy()
+        a = np.concatenate([des, [z], [0, 1, 0, 0]])
+        obs, do, io = o.sort_step(a)
+        oh, dh, ih = h.step(a)
+        worst = max(worst, _state_err(h, o))
+        assert not (ih["flags"] & 0x1F0000) and np.allclose(obs, oh, atol=1e-6, rtol=0) and io["mode"] == ih["mode"]
+    lib().hc_gen_island_hist(_p(hist), 0)
+    assert worst < 2e-8, worst
+    assert int(hist[:36].sum()) > 0, hist[:36]           # the stretch does exercise the joint solver

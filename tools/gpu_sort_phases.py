@@ -18,7 +18,8 @@ W = np.zeros((NW, 10), dtype=np.uint64)
 CN = np.zeros((NW, 8), dtype=np.uint64)
 cnames = ["newton its", "own-contact trips", "partner trips", "ls its", "ls contact trips", "jp trips", "sub-steps with a solve", "generic solves"]
 names = ["p1.arm", "p2.statics", "p3.bb+rod+reduce", "t.setup", "t.grad+H", "t.elim+solve", "t.jp", "t.linesearch+step", "p4.tree(total)", "p4.generic"]      # slots 3..7: inside the tree solver (gen_tree.h; the rare generic solves add to them)
-for t in range(60):
+TS = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [20, 39, 55]
+for t in range(max(TS) + 1):
     box = env.obs[:, 2:4].to(torch.float64)
     if t >= 12:
         aligned = ((des[:, 0] - box[:, 0]).abs() < 0.008) & (des[:, 1] < box[:, 1] - 0.02)
@@ -32,7 +33,7 @@ for t in range(60):
     torch.cuda.synchronize()
     L.d3il_debug_wave_stats(W.ctypes.data_as(C.c_void_p), NW, 1)
     L.d3il_debug_wave_counts(CN.ctypes.data_as(C.c_void_p), NW, 1)
-    if t in (20, 39, 55):
+    if t in TS:
         Wf = W.astype(np.float64)
         Wf /= 200.0                                       # ticks -> microseconds per env step; the other slots are counts (first active lane of the wave)
         for lab, v in (("median", np.median(Wf, axis=0)), ("p90", np.percentile(Wf, 90, axis=0)), ("max", Wf.max(axis=0))):

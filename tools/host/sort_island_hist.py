@@ -54,7 +54,8 @@ def main():
         print("ctx %d: steps %d flags %x mode %d" % (i, t + 1, fl & 0x1F0000, info["mode"]), flush=True)
     L.hc_gen_island_hist(_p(hist), 0)
     print("sub-steps:", total_sub)
-    for key in range(40):
+    print("joint solves by cube <-> cube pairs in contact inside the island: 0: %d  1: %d  2: %d  3: %d" % tuple(hist[36:40]))
+    for key in range(36):
         if hist[key]:
             print("cubes %d arm %d rod-contacts %d: %8d solves (%.3f per sub-step), %.2f Newton iterations each" %
                   (key % 5, (key // 5) % 2, key // 10, hist[key], hist[key] / total_sub, hist[40 + key] / hist[key]))
