@@ -51,7 +51,8 @@ IMPL_BYTES = {
     "aligning": 2 * (77 * 8 + 4 + 4) + 56 + 68 + 4 + 16,
     "inserting": 2 * (110 * 8 + 4 + 4) + 56 + 44 + 4,
 }
-KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>", "sorting": "k_sorting_step<true, false>", "stacking": "k_stacking_step", "aligning": "k_aligning_step", "inserting": "k_sorting_step<true, true>"}
+KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>" if os.environ.get("D3IL_PUSH_ENGINE") == "legacy" else "k_sorting_step<true, false>",      # Pushing runs on the generic engine unless D3IL_PUSH_ENGINE=legacy
+          "sorting": "k_sorting_step<true, false>", "stacking": "k_stacking_step", "aligning": "k_aligning_step", "inserting": "k_sorting_step<true, true>"}
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline (oracle)

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(WAVE) void k_sorting_reset(const double* __restrict
   for (int k = 0; k < od; k++) obs[(size_t)od * e + k] = o[k];
   int code = 0;
   if (gc.task == GEN_TASK_SORTING) for (int i = 0; i < gc.nb; i++) code |= 1 << (7 - i);        // np.packbits of the all -1 mode vector (Inserting: no letters yet)
+  if (gc.task == GEN_TASK_PUSHING) code = -1;                                                    // no mode yet (int16 -1, pushing.py:341)
   done[e] = 0; success[e] = 0; mode[e] = (unsigned short)code;
 }
 

@@ -32,7 +32,7 @@ constexpr int GEN_ARMCON = 3, GEN_ARMLANE = 2;       // GEN_ARMLANE: what one la
 constexpr int GEN_MAXCON = (GEN_MAXNB + 1) * GEN_SEG;
 static_assert(GEN_ARMLANE * GEN_MAXNB <= GEN_SEG && GEN_ARMCON <= GEN_SEG, "the lanes' parking slots and the packed rod <-> static contacts share one record segment");
 constexpr int GEN_MAXSET = 2 * GEN_MAXNS + 2;        // static s <-> cube: s;  cube <-> cube: ns;  rod <-> cube: ns + 1;  rod <-> static s: ns + 2 + s
-enum { GEN_TASK_SORTING = 0, GEN_TASK_INSERTING = 1 };
+enum { GEN_TASK_SORTING = 0, GEN_TASK_INSERTING = 1, GEN_TASK_PUSHING = 2 };
 constexpr int GEN_MAXNV = 6 * GEN_MAXNB + NDOF;     // 33
 constexpr int GEN_NH = GEN_MAXNV * (GEN_MAXNV + 1) / 2;   // 561
 #ifndef D3IL_GEN_LANES
@@ -52,10 +52,10 @@ constexpr int GEN_NSUB = D3IL_GEN_NSUB;
 struct GenConsts {
   int nb, ns, set_bb, set_rod;
   int ns_core;                    // statics [0, ns_core): everything inside the table; [ns_core, ns): the frame beams around the table edge (only tested near it)
-  int task;                       // GEN_TASK_SORTING / GEN_TASK_INSERTING: which task logic reads the cubes (sort_* / ins_* below)
+  int task;                       // GEN_TASK_SORTING / GEN_TASK_INSERTING / GEN_TASK_PUSHING: which task logic reads the cubes (sort_* / ins_* / gpush_* below)
   int rod_static;                 // 1: the rod <-> static box pairs are evaluated (Inserting: the rod works between the walls of the gates)
   int st_rod[GEN_MAXNS];          // the rod's collision bits match static s
-  double ins_target[9], ins_min_dist;      // Inserting: the three goal positions and target_min_dist (gate_insertion_objects.py:17-24, gate_insertion.py:276)
+  double ins_target[9], ins_min_dist;      // Inserting: the three goal positions and target_min_dist (gate_insertion_objects.py:17-24, gate_insertion.py:276); Pushing: the red and the green target, min_dist (pushing_objects.py:11-15, pushing.py:251)
   double box_half[3], box_mass, box_inertia, box_invw_t;
   double st_c[GEN_MAXNS][3], st_h[GEN_MAXNS][3], st_R[GEN_MAXNS][9];
   int st_first[GEN_MAXNS];        // 1: the static geom precedes the cube geoms in the model (it is geom 1 of the pair)
@@ -1156,6 +1156,59 @@ D3IL_HD int ins_check_mode(const GenConsts& gc_, unsigned* task, const double* d
   return code | (int)(n << 3);
 }
 
+// ------------------------------------------------------------------------------------------------ Pushing task (pushing.py) on this engine
+// Block_Push_Env with its two cubes as the engine's cubes 0 (red) and 1 (green), the table slabs and the frame beams as static boxes.  Task state as in
+// push_step.h: first_visit + 1 and mode + 1 in the low flag bits (PF_FIRST_MASK / PF_MODE_MASK); the two task rows of the state buffer carry the step's
+// info['mean_distance'] and reward (they ARE the info_f64 rows of the boundary).  Same arithmetic as push_dists / push_step_begin / push_step_end.
+D3IL_HD void gpush_dists(const GenConsts& gc_, const PushScratch sc, double* d) {   // rr rg gr gg
+  D3IL_GEN_CONSTS(gc_, gc);
+  for (int b = 0; b < 2; b++) for (int t = 0; t < 2; t++) {
+    const double dx = GBX(b, 0) - gc.ins_target[3 * t], dy = GBX(b, 1) - gc.ins_target[3 * t + 1], dz = GBX(b, 2) - gc.ins_target[3 * t + 2];
+    d[2 * b + t] = sqrt(dx * dx + dy * dy + dz * dz);
+  }
+}
+D3IL_HD void gpush_obs(const PushScratch sc, const double* tcp, float* obs) {   // pushing.py:255-280
+  obs[0] = (float)tcp[0]; obs[1] = (float)tcp[1];
+  for (int b = 0; b < 2; b++) {
+    double q[4] = {GBX(b, 3), GBX(b, 4), GBX(b, 5), GBX(b, 6)};
+    obs[2 + 3 * b] = (float)GBX(b, 0); obs[3 + 3 * b] = (float)GBX(b, 1); obs[4 + 3 * b] = (float)push_tan_yaw(q);
+  }
+}
+// before the physics: obs, reward (get_reward, pushing.py:379-407), done (gym_env_wrapper.py:88-90,124-137)
+D3IL_HD bool gpush_step_begin(const GenConsts& gc_, const EnvState& st, const PushScratch sc, float* obs) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  gpush_obs(sc, st.tcp, obs);
+  double d[4]; gpush_dists(gc, sc, d);
+  const double dx = st.tcp[0] - GBX(0, 0), dy = st.tcp[1] - GBX(0, 1);
+  GTASK(1) = -(sqrt(dx * dx + dy * dy) + d[0]);
+  const double md = gc.ins_min_dist;
+  return (d[0] <= md && d[3] <= md) || (d[1] <= md && d[2] <= md);      // push_success, pushing.py:440-459
+}
+// after the physics: success, first-visit mode logic (pushing.py:335-377); returns the mode (-1 .. 3)
+D3IL_HD int gpush_step_end(const GenConsts& gc_, EnvState& st, const PushScratch sc) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  double d[4]; gpush_dists(gc, sc, d);
+  const double md = gc.ins_min_dist;
+  const bool succ = (d[0] <= md && d[3] <= md) || (d[1] <= md && d[2] <= md);
+  st.flags &= ~F_SUCCESS;
+  if (succ) st.flags |= F_SUCCESS | F_TERMINATED;
+  int first = (int)(st.flags & PF_FIRST_MASK) - 1, visit = -1, mode = -1;
+  if (d[0] <= md && first != 0) visit = 0;
+  else if (d[1] <= md && first != 1) visit = 1;
+  else if (d[2] <= md && first != 2) visit = 2;
+  else if (d[3] <= md && first != 3) visit = 3;
+  if (first == -1) first = visit;
+  else {
+    if (first == 0 && visit == 3) mode = 0;
+    else if (first == 3 && visit == 0) mode = 1;
+    else if (first == 1 && visit == 2) mode = 2;
+    else if (first == 2 && visit == 1) mode = 3;
+  }
+  st.flags = (st.flags & ~(PF_FIRST_MASK | PF_MODE_MASK)) | (unsigned)(first + 1) | ((unsigned)(mode + 1) << PF_MODE_SHIFT);
+  GTASK(0) = 0.5 * (fmin(d[0], d[1]) + fmin(d[2], d[3]));
+  return mode;
+}
+
 // ------------------------------------------------------------------------------------------------ env level
 template <class C>
 D3IL_HD void gen_control_and_physics(const C& c, const GenConsts& gc_, EnvState& st, const PushScratch sc, const double* q_des, const double* qd_des,
@@ -1187,6 +1240,7 @@ D3IL_HD void gen_env_reset(const C& c, const GenConsts& gc_, EnvState& st, const
   double zero[NARM] = {0, 0, 0, 0, 0, 0, 0};
   gen_control_and_physics(c, gc, st, sc, init_qpos, zero, 0.001, false);
   if (gc.task == GEN_TASK_INSERTING) { double d3[3], md; ins_obs_success(gc, sc, st.tcp, obs, d3, &md); return; }
+  if (gc.task == GEN_TASK_PUSHING) { gpush_obs(sc, st.tcp, obs); return; }
   double box[6][7];
   sort_collect(gc, sc, box);
   sort_obs_success(gc, box, st.tcp, obs);
@@ -1196,6 +1250,7 @@ D3IL_HD void sort_step_begin(const GenConsts& gc_, EnvState& st, const PushScrat
   D3IL_GEN_CONSTS(gc_, gc);
   bool succ;
   if (gc.task == GEN_TASK_INSERTING) { double d3[3], md; succ = ins_obs_success(gc, sc, st.tcp, obs, d3, &md); }
+  else if (gc.task == GEN_TASK_PUSHING) succ = gpush_step_begin(gc, st, sc, obs);
   else {
     double box[6][7];
     sort_collect(gc, sc, box);
@@ -1211,6 +1266,7 @@ D3IL_HD void sort_step_end(const GenConsts& gc_, EnvState& st, const PushScratch
   D3IL_GEN_CONSTS(gc_, gc);
   st.step++;
   float dummy[GEN_SORT_OBS];
+  if (gc.task == GEN_TASK_PUSHING) { *mode_code = gpush_step_end(gc, st, sc); return; }
   if (gc.task == GEN_TASK_INSERTING) {
     double d3[3], md;
     const bool succ = ins_obs_success(gc, sc, st.tcp, dummy, d3, &md);
@@ -1348,7 +1404,12 @@ D3IL_HOSTFN inline int build_gen_consts(const d3il_model_blob& m, const PandaCon
     if (g > m.rod_geom || (b + 1 < gc.nb && g > cube_geom(m.obj_body[b + 1])) || m.geom_margin[g] != 0) { *err = "unexpected geom order"; return -1; }
   }
   mix(g0, m.rod_geom, gc.set_rod);
-  gc.task = m.task_id == D3IL_TASK_INSERTING ? GEN_TASK_INSERTING : GEN_TASK_SORTING;
+  gc.task = m.task_id == D3IL_TASK_INSERTING ? GEN_TASK_INSERTING : (m.task_id == D3IL_TASK_PUSHING ? GEN_TASK_PUSHING : GEN_TASK_SORTING);
+  if (gc.task == GEN_TASK_PUSHING) {
+    if (gc.nb != 2) { *err = "the Pushing task has two cubes"; return -1; }
+    for (int k = 0; k < 6; k++) gc.ins_target[k] = m.task_f[k];
+    gc.ins_min_dist = m.task_f[6];
+  }
   if (gc.task == GEN_TASK_INSERTING) {
     if (gc.nb != 3) { *err = "the Inserting task has three push boxes"; return -1; }
     for (int k = 0; k < 9; k++) gc.ins_target[k] = m.task_f[k];

@@ -648,7 +648,16 @@ static_assert(D3IL_ALIGN_STATE_BOX == AL_STATE_BOX && D3IL_ALIGN_STATE_WARM == A
 static_assert(D3IL_INS_STATE_BOX == 42 && D3IL_INS_STATE_WARM == 42 + 13 * 3 && D3IL_INS_STATE_TASK == 42 + 13 * 3 + 6 * 3 + NDOF && D3IL_INS_STATE_F64 == gen_state_rows(3), "d3il_rollout.h: Inserting state layout");
 static_assert(D3IL_PUSH_STATE_F64 == PUSH_STATE_F64 && D3IL_TALLY_ALL + 256 <= D3IL_TALLY_ROW - 2, "d3il_rollout.h: Pushing state rows / tally row");
 
-static inline bool gen_task(int task_id) { return task_id == D3IL_TASK_SORTING || task_id == D3IL_TASK_INSERTING; }   // the tasks of the generic engine (gen_step.h)
+// Pushing runs on the generic engine (gen_step.h: its two cubes, the table slabs AND the frame beams as static boxes, the tree solver) unless the process
+// asks for the round-1 Pushing engine (push_step.h / push_kernels.h) with D3IL_PUSH_ENGINE=legacy - read once, when the first handle is created.
+static bool push_on_generic() {
+  static const bool v = [] { const char* e = std::getenv("D3IL_PUSH_ENGINE"); return !(e && std::strcmp(e, "legacy") == 0); }();
+  return v;
+}
+static inline bool gen_task(int task_id) {      // the tasks of the generic engine (gen_step.h)
+  return task_id == D3IL_TASK_SORTING || task_id == D3IL_TASK_INSERTING || (task_id == D3IL_TASK_PUSHING && push_on_generic());
+}
+static inline bool legacy_push(int task_id) { return task_id == D3IL_TASK_PUSHING && !push_on_generic(); }
 
 struct d3il_handle_s {
   int task_id, n, stride, device;
@@ -685,6 +694,7 @@ struct d3il_handle_s {
   int ctx_dim;
   uint8_t* d_mask;         // [stride] environments reset by the last d3il_auto_reset (buf.last_reset)
   const int32_t* tally_ctx; int tally_nctx; int64_t* tally_table;   // caller-owned device memory (d3il_set_tally)
+  bool info_is_view;       // buf.info_f64 points into buf.state (Pushing on the generic engine: its two task rows) - not freed on its own
 };
 
 // The Pushing / Sorting kernels read their model from one __constant__ object per device (scalar loads, no pointer across call
@@ -719,12 +729,12 @@ static void free_handle(d3il_handle_s* h) {
   int dev = h->device;
   if (dev >= 0 && dev < 16) {
     std::lock_guard<std::mutex> lock(g_model_mutex);
-    if (h->task_id == D3IL_TASK_PUSHING && g_active_push[dev].refs > 0) g_active_push[dev].refs--;
+    if (legacy_push(h->task_id) && g_active_push[dev].refs > 0) g_active_push[dev].refs--;
     if (gen_task(h->task_id) && g_active_gen[dev].refs > 0) g_active_gen[dev].refs--;
     if (h->task_id == D3IL_TASK_STACKING && g_active_stack[dev].refs > 0) g_active_stack[dev].refs--;
   }
   void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des,
-                  h->buf.info_f64, h->d_scratch, h->d_ctx, h->d_mask};
+                  h->info_is_view ? nullptr : (void*)h->buf.info_f64, h->d_scratch, h->d_ctx, h->d_mask};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ring_created) for (int i = 0; i < 128; i++) { (void)hipEventDestroy(h->ring0[i]); (void)hipEventDestroy(h->ring1[i]); }
   delete h;
@@ -754,7 +764,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   int rc = build_panda_consts(m, h->hc, &err);
   if (rc) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   finish_invweights(h->hc);
-  if (task_id == D3IL_TASK_PUSHING && build_push_consts(m, h->pc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
+  if (legacy_push(task_id) && build_push_consts(m, h->pc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (gen_task(task_id) && build_gen_consts(m, h->hc, h->gc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_STACKING && build_stack_consts(m, h->hc, h->kc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_ALIGNING && build_coop_align_consts(m, h->hc, h->kc, h->atk, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
@@ -777,8 +787,9 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     if (!same) { free_handle(h); return fail(D3IL_EUNSUPPORTED, "d3il_create: the model blob differs from the model this library was specialised for at build time; "
                                                                  "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
-  const bool pushing = task_id == D3IL_TASK_PUSHING;
-  const bool sorting = gen_task(task_id);       // Sorting and Inserting run on the generic engine (gen_step.h)
+  const bool pushing = legacy_push(task_id);
+  const bool sorting = gen_task(task_id);       // Sorting, Inserting and (by default) Pushing run on the generic engine (gen_step.h)
+  const bool gen_pushing = sorting && task_id == D3IL_TASK_PUSHING;
   // one Pushing / Sorting model per device while handles are alive (constant memory)
   if (pushing) {
     ActiveModel& am = g_active_push[device_id];
@@ -789,15 +800,8 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
       return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Pushing handle on this device uses a different model (the kernels read one model per device from constant memory); destroy it first");
     }
   }
-  if (sorting) {
-    ActiveModel& am = g_active_gen[device_id];
-    bool other;
-    { std::lock_guard<std::mutex> lock(g_model_mutex); other = am.refs > 0 && std::memcmp(&am.gc, &h->gc, sizeof(GenConsts)) != 0; }
-    if (other) {
-      free_handle(h);
-      return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Sorting handle on this device uses a different model, e.g. another num_boxes (the kernels read one model per device from constant memory); destroy it first");
-    }
-  }
+  // (handles of the generic engine with different models - Sorting-2 / 4, Inserting, Pushing - may live side by side: every launch checks the constants the
+  // device holds and reloads them when they are another handle's, sync_gen_consts_locked below)
   const bool stacking = task_id == D3IL_TASK_STACKING;
   if (stacking) {
     ActiveModel& am = g_active_stack[device_id];
@@ -815,7 +819,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : (stacking ? 21 : (aligning ? AL_CTX : 0)));
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
-  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : (aligning ? AL_OBS : 2))); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = (pushing || aligning) ? 2 : (stacking ? 1 : 0);
+  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : (aligning ? AL_OBS : 2))); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = (pushing || aligning || gen_pushing) ? 2 : (stacking ? 1 : 0);
   HIPCHK_H(hipMalloc(&h->dc, sizeof(PandaConsts)));
   if (task_id == D3IL_TASK_AVOIDING) {
     // the three-wave form needs AVOID_LDS_SERVE of dynamic LDS on top of its static LDS; a device that cannot grant it runs the two-wave form
@@ -866,17 +870,12 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_coop, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
   }
   if (sorting) {
-    ActiveModel& am = g_active_gen[device_id];
     {
-      std::unique_lock<std::mutex> lock(g_model_mutex);
-      if (am.refs == 0) {
-        hipError_t e1 = hipDeviceSynchronize(), e2 = hipMemcpyToSymbol(HIP_SYMBOL(g_gen_consts), &h->gc, sizeof(GenConsts));
-        if (e1 != hipSuccess || e2 != hipSuccess) { lock.unlock(); free_handle(h); return fail(D3IL_EHIP, "d3il_create: loading the Sorting model into constant memory failed"); }
-        am.gc = h->gc;
-      }
-      am.refs++; h->task_id = task_id;
+      std::lock_guard<std::mutex> lock(g_model_mutex);
+      g_active_gen[device_id].refs++; h->task_id = task_id;      // the constants go to the device with the first launch (GenLaunch)
     }
     HIPCHK_H(hipMalloc(&h->d_scratch, S * GG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * GG_SIZE * sizeof(double)));
+    if (gen_pushing) { b.info_f64 = b.state + (size_t)(gen_state_rows(h->gc.nb) - 2) * S; h->info_is_view = true; }      // info['mean_distance'], reward: the task rows of the state buffer (gen_step.h gpush_*)
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
@@ -957,6 +956,24 @@ struct StackLaunch {      // scope = "constants checked ... kernel enqueued"
   explicit StackLaunch(d3il_handle_s* h) : lock(g_model_mutex), rc(sync_stack_consts_locked(h)) {}
 };
 
+// g_gen_consts (one __constant__ object per device) is a cache of the generic engine's constants of the handle that launched last, like g_stack_consts:
+// a handle with another model (Sorting-2 / 4, Inserting, Pushing) reloads it before its launch, fenced by device synchronisations.
+static GenConsts g_gen_loaded[16];
+static bool g_gen_loaded_valid[16];
+static int sync_gen_consts_locked(d3il_handle_s* h) {
+  if (g_gen_loaded_valid[h->device] && std::memcmp(&g_gen_loaded[h->device], &h->gc, sizeof(GenConsts)) == 0) return D3IL_OK;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_gen_consts), &h->gc, sizeof(GenConsts)));
+  HIPCHK(hipDeviceSynchronize());
+  g_gen_loaded[h->device] = h->gc; g_gen_loaded_valid[h->device] = true;
+  return D3IL_OK;
+}
+struct GenLaunch {      // scope = "constants checked ... kernel enqueued"
+  std::unique_lock<std::mutex> lock;
+  int rc;
+  explicit GenLaunch(d3il_handle_s* h) : lock(g_model_mutex), rc(sync_gen_consts_locked(h)) {}
+};
+
 // the contact solvers' stopping rule lives in one __constant__ object per device; a handle whose setting differs from what is
 // loaded re-loads it on its stream before launching (handles with different settings must not run concurrently on one device)
 static int sync_solver_tol(d3il_handle_s* h, hipStream_t s) {
@@ -987,7 +1004,7 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
     hipLaunchKernelGGL(k_store_contexts, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_mask, contexts, h->d_ctx, h->n, h->ctx_dim);
     HIPCHK(hipGetLastError());
   }
-  if (h->task_id == D3IL_TASK_PUSHING) {
+  if (legacy_push(h->task_id)) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Pushing task needs contexts (device f64 [n_envs][14])");
     hipLaunchKernelGGL(k_pushing_reset, dim3((h->n + PUSH_LANES - 1) / PUSH_LANES), dim3(WAVE), PUSH_LDS_H, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
                        b.flags, b.step_count, b.obs, b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride);
@@ -995,7 +1012,9 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
     return D3IL_OK;
   }
   if (gen_task(h->task_id)) {
-    if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Sorting task needs contexts (device f64 [n_envs][7 * n_boxes])");
+    if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the task needs contexts (device f64 [n_envs][7 * n_boxes])");
+    GenLaunch guard(h);
+    if (guard.rc) return guard.rc;
     hipLaunchKernelGGL(k_sorting_reset, dim3((h->n + GEN_LANES - 1) / GEN_LANES), dim3(WAVE), GEN_LDS_H, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
                        b.flags, b.step_count, b.obs, b.done, b.success, b.mode, h->d_scratch, h->n, h->stride);
     HIPCHK(hipGetLastError());
@@ -1053,7 +1072,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   d3il_buffers& b = h->buf;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = sync_solver_tol(h, s)) return rc;
-  if (h->task_id == D3IL_TASK_PUSHING) {
+  if (legacy_push(h->task_id)) {
     int nwgp = (h->n + PUSH_LANES - 1) / PUSH_LANES;
     std::unique_ptr<StackLaunch> guard;
     if (h->push_coop && h->fast) { guard.reset(new StackLaunch(h)); if (guard->rc) return guard->rc; }
@@ -1073,6 +1092,8 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   }
   if (gen_task(h->task_id)) {
     int nwgs = (h->n + GEN_LANES - 1) / GEN_LANES;
+    GenLaunch guard(h);
+    if (guard.rc) return guard.rc;
     if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
     // the engine with contacts of the arm block only for models that evaluate rod <-> static box pairs (Inserting): the Sorting scenes run the
     // instantiation without that code

@@ -99,7 +99,8 @@ def test_bounded_horizon_rollout_matches_oracle(ctx60, init_qpos, pushing_blob, 
 
 
 def test_cooperative_engine_variant_follows_the_oracle(ctx60, init_qpos, pushing_blob):
-    """Option push_coop=1 runs Pushing on the Stacking task's wave-cooperative engine (k_pushing_step_coop: lane-per-pair collision with the
+    """(Legacy engine only - see test_legacy_pushing_engine_in_its_own_process; on the generic engine the option is accepted and has no effect.)
+    Option push_coop=1 runs Pushing on the Stacking task's wave-cooperative engine (k_pushing_step_coop: lane-per-pair collision with the
     rod as a cylinder job, two environments per wave in the solver) instead of the lock-step kernel - off by default because it is slower
     for this task, kept as a second implementation of the same step: bounded-horizon parity with the oracle through
     the first rod <-> cube contacts, and the same integer outputs."""
@@ -405,3 +406,16 @@ def test_random_contexts_and_large_batch(init_qpos):
     st, fl, sc = env.get_state()
     assert np.isfinite(st).all() and not np.any(fl & BAD) and np.all(sc == 3)
     env.close()
+
+
+def test_legacy_pushing_engine_in_its_own_process():
+    """Since round 5 the Pushing task runs on the generic engine (gen_step.h); the round-1 engine (push_step.h / push_kernels.h, and its cooperative variant
+    behind option push_coop) is still built and selected per PROCESS with D3IL_PUSH_ENGINE=legacy.  The reset, bounded-horizon and one-step parity tests of
+    this file pass on it too (run in a child process: the choice is read once, when the first handle is created)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, D3IL_PUSH_ENGINE="legacy")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        "-k", "reset_matches_oracle or bounded_horizon or cooperative_engine or one_step_parity or first_visit_mode"],
+                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

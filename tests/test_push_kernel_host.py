@@ -245,3 +245,41 @@ def test_box_box_face_clipping_regimes_equal_the_oracle():
         if n:
             np.testing.assert_allclose(out[:n], ref, atol=1e-12)
     assert counts[4] > 100 and counts[5:].sum() > 100 and counts[1] > 10, counts
+
+
+@pytest.mark.parametrize("ctx_id", [0, 7, 23])
+def test_pushing_on_the_generic_engine_matches_oracle(push_oracle, pushing_blob, init_qpos, push_contexts, ctx_id):
+    """The Pushing task on the generic engine (gen_step.h: GEN_TASK_PUSHING - the product's default engine for the task since round 5: its two cubes, the
+    table slabs and the frame beams as static boxes, the tree solver) on the host: same state layout as the Pushing engine (rows 0 .. 88), reward and
+    info['mean_distance'] in the two task rows behind it, first-visit / mode bits in the flag word; the same rollout as the oracle's."""
+    from tests.hostcheck.hostcheck import GenHostCheck
+    h = GenHostCheck(pushing_blob)
+    assert (h.nb, h.n_obs) == (2, 8) and h.n == 42 + 26 + 21 + 2 and h.ns > h.ns_core == 2      # the two slabs inside the table, the frame beams behind them
+    ctx = push_contexts[ctx_id]
+    push_oracle.env_start(init_qpos)
+    obs_o = push_oracle.push_reset(ctx)
+    obs_h = h.reset(init_qpos, ctx)
+    np.testing.assert_array_equal(obs_o, obs_h)
+    so, fo = push_oracle.push_state()
+    np.testing.assert_allclose(h.s[:68], so, atol=1e-11, rtol=0)
+    des = obs_o[:2].astype(float)
+    z = float(h.s[27])
+    moved = False
+    for t in range(45):
+        des = _chase(obs_o, des)
+        a = np.concatenate([des, [z], [0, 1, 0, 0]])
+        obs_o, rew_o, done_o, info_o = push_oracle.push_step(a)
+        obs_h, done_h, info_h = h.step(a)
+        so, fo = push_oracle.push_state()
+        sh = h.s[:68]
+        mode_h = info_h["mode"] if info_h["mode"] < 32768 else info_h["mode"] - 65536
+        assert done_o == done_h and info_o["mode"] == mode_h and info_o["success"] == info_h["success"]
+        assert not (info_h["flags"] & ((1 << 16) | (1 << 18) | (1 << 19))), hex(info_h["flags"])
+        np.testing.assert_allclose(obs_h, obs_o, atol=1e-6, rtol=1e-6)
+        pos_idx = list(range(0, 9)) + list(range(25, 28)) + list(range(42, 49)) + list(range(55, 62))
+        vel_idx = list(range(9, 18)) + list(range(49, 55)) + list(range(62, 68))
+        np.testing.assert_allclose(sh[pos_idx], so[pos_idx], atol=1e-7, rtol=0)
+        np.testing.assert_allclose(sh[vel_idx], so[vel_idx], atol=1e-4, rtol=0)
+        assert abs(rew_o - h.s[90]) < 1e-7 and abs(info_o["mean_distance"] - h.s[89]) < 1e-7      # the task rows: info['mean_distance'], reward
+        moved = moved or abs(so[43] - ctx[1]) > 0.02
+    assert moved
