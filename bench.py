@@ -388,6 +388,7 @@ class _Shard:
                 env.set_option("serve_wave_max_workgroups", args.serve_max_wg)
             if args.solver_strict:
                 env.set_option("solver_strict", 1)
+            self.graph = bool(args.graph_rollout) and task == "avoiding" and self.own_stream and (args.policy or "random") == "random" and not args.no_auto_reset
             ctx_id = None
             if ctx60 is not None:
                 ids = (env_offset + np.arange(n)) % len(ctx60)
@@ -434,6 +435,8 @@ class _Shard:
                     raise SystemExit("--policy %s is not available for task %s" % (policy, task))
                 actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
             self.pol = pol
+            if self.graph:
+                env.set_option("graph_rollout", 1)      # after set_tally / every other option: the first step captures what a step launches NOW
             self.des_xy = env.policy_des[:2, :n]                              # [2, n] view: the harness set-point the library re-latches on auto-reset
             self.des_z = env.policy_des[2, :n]
         self.auto_reset = not args.no_auto_reset
@@ -587,6 +590,8 @@ def run(args):
     for sh in shards:
         sh.episodes.zero_(); sh.table.zero_()
         sh.env.set_timing(True)      # HIP events around EVERY step-kernel launch, on the stream it is launched on, kept in a ring inside the library
+        if sh.graph:                 # the captured form of the step (with its event pairs) is built here, outside the timed region
+            sh.env.random_rollout_prepare(42, sh.env_offset, t_run, sh.actions, sh.episodes)
     barrier()
     t0 = time.perf_counter()
     for t in range(args.steps):
@@ -741,6 +746,7 @@ def main():
     ap.add_argument("--serve-max-wg", type=int, default=None, help="Avoiding: workgroup count up to which the split kernel runs with its third wave (rare constraint paths); 0 = the two-wave kernel (A/B)")
     ap.add_argument("--sub-batches", type=int, default=None, help="step the GPU's environments as this many independent sub-batches on as many HIP streams "
                     "(default: 4 for avoiding / pushing / sorting / inserting, 1 otherwise; 1 = one launch per step over the whole batch)")
+    ap.add_argument("--graph-rollout", type=int, default=0, help="Avoiding, random policy, sub-batches on their own streams: the rollout step as one captured HIP graph launch (0: eight runtime calls per step)")
     ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
     args = ap.parse_args()
     # sub-batches run on their own HIP streams; with the runtime's default of four hardware queues two of four streams share a queue (the null stream

@@ -589,6 +589,23 @@ __global__ void k_policy_action(double* __restrict__ des, double* __restrict__ a
   double* a = actions + (size_t)e * 7;
   a[0] = x; a[1] = y; a[2] = z; a[3] = 0; a[4] = 1; a[5] = 0; a[6] = 0;
 }
+// the same with the step counter t read from device memory (the captured form of the rollout step, d3il_random_rollout_step with option graph_rollout:
+// a graph's kernel arguments are fixed at capture time); k_inc_counter, the last node of the graph, advances it
+__global__ void k_policy_action_dev(double* __restrict__ des, double* __restrict__ actions, unsigned long long seed, unsigned long long env_offset,
+                                    const unsigned* __restrict__ t_dev, int n, int stride) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const unsigned t = *t_dev;
+  unsigned long long ge = env_offset + (unsigned long long)e;
+  unsigned r[4];
+  philox4x32_10((unsigned)seed, (unsigned)(seed >> 32), (unsigned)ge, (unsigned)(ge >> 32), t, 0u, r);
+  double u0 = r[0] * (1.0 / 4294967296.0), u1 = r[1] * (1.0 / 4294967296.0);
+  double x = des[e] + (0.02 * u0 - 0.01), y = des[(size_t)stride + e] + (0.02 * u1 - 0.01), z = des[2 * (size_t)stride + e];
+  des[e] = x; des[(size_t)stride + e] = y;
+  double* a = actions + (size_t)e * 7;
+  a[0] = x; a[1] = y; a[2] = z; a[3] = 0; a[4] = 1; a[5] = 0; a[6] = 0;
+}
+__global__ void k_inc_counter(unsigned* __restrict__ t_dev) { if (threadIdx.x == 0 && blockIdx.x == 0) *t_dev += 1u; }
 __global__ void k_count_metrics(const unsigned char* __restrict__ done, const unsigned* __restrict__ flags, long long* __restrict__ counts, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
@@ -659,6 +676,7 @@ static inline bool gen_task(int task_id) {      // the tasks of the generic engi
 }
 static inline bool legacy_push(int task_id) { return task_id == D3IL_TASK_PUSHING && !push_on_generic(); }
 
+constexpr int RG_SLOTS = 2, RG_SAMPLE = 8;
 struct d3il_handle_s {
   int task_id, n, stride, device;
   PandaConsts hc;          // host copy
@@ -694,6 +712,13 @@ struct d3il_handle_s {
   int ctx_dim;
   uint8_t* d_mask;         // [stride] environments reset by the last d3il_auto_reset (buf.last_reset)
   const int32_t* tally_ctx; int tally_nctx; int64_t* tally_table;   // caller-owned device memory (d3il_set_tally)
+  // captured rollout step (option graph_rollout; Avoiding random-policy harness): RG_SLOTS instantiated graphs of [policy, step, auto-reset, counter + 1],
+  // launched round robin - one runtime call per step instead of eight
+  bool rg_enabled, rg_ready, rg_capturing, rg_ev_made, rg_timing;
+  int rg_slot;
+  hipGraph_t rg_graph[RG_SLOTS]; hipGraphExec_t rg_exec[RG_SLOTS];
+  unsigned* rg_t_dev; uint32_t rg_next_t; long rg_launched, rg_drained;
+  uint64_t rg_seed, rg_off; double* rg_actions; int64_t* rg_counts; hipStream_t rg_stream;
   bool info_is_view;       // buf.info_f64 points into buf.state (Pushing on the generic engine: its two task rows) - not freed on its own
 };
 
@@ -724,6 +749,11 @@ const char* d3il_last_error(void) { return g_err.c_str(); }
 size_t d3il_blob_sizeof(void) { return sizeof(d3il_model_blob); }
 int d3il_version(void) { return 1; }
 
+static void rg_drop(d3il_handle_s* h);
+static void rg_drop_for_free(d3il_handle_s* h) {
+  if (h->rg_ready) for (int k = 0; k < RG_SLOTS; k++) { (void)hipGraphExecDestroy(h->rg_exec[k]); (void)hipGraphDestroy(h->rg_graph[k]); }
+  if (h->rg_t_dev) (void)hipFree(h->rg_t_dev);
+}
 static void free_handle(d3il_handle_s* h) {
   if (!h) return;
   int dev = h->device;
@@ -737,6 +767,7 @@ static void free_handle(d3il_handle_s* h) {
                   h->info_is_view ? nullptr : (void*)h->buf.info_f64, h->d_scratch, h->d_ctx, h->d_mask};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ring_created) for (int i = 0; i < 128; i++) { (void)hipEventDestroy(h->ring0[i]); (void)hipEventDestroy(h->ring1[i]); }
+  rg_drop_for_free(h);
   delete h;
 }
 // inside d3il_create: every failure releases what has been allocated so far
@@ -1135,7 +1166,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     lds = per_cu >= 8 ? 0 : (160 * 1024 / per_cu) - 1024;  // leave slack below the 160 KiB per-CU pool
     if (lds > 64 * 1024) lds = 64 * 1024;
   }
-  if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
+  if (h->timing && !h->rg_capturing) { if (int rc_ = timing_begin(h, s)) return rc_; }
   // the two-wave kernel wins at every batch size measured (4096 ... 262144 envs: +64 % ... +20 %): at small N the second
   // wave uses an idle SIMD, at saturation its 256-VGPR roles run two waves per SIMD and hide FP64 latency
   bool split = h->fast && h->lanes == WAVE && h->split != 0;
@@ -1153,7 +1184,7 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
     hipLaunchKernelGGL((k_avoiding_step<false, true>), dim3(nwg), dim3(WAVE), lds, s, h->dc, b.state, b.flags, b.step_count, actions, b.obs, b.done,
                        b.success, b.mode, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps, h->lanes);
   HIPCHK(hipGetLastError());
-  if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; h->ring_head++; }
+  if (h->timing && !h->rg_capturing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; h->ring_head++; }
   return D3IL_OK;
 }
 
@@ -1251,6 +1282,7 @@ int d3il_mlp_ln_gelu_residual_f32(const float* h, const float* ln_weight, const 
 int d3il_set_tally(d3il_handle h, const int32_t* ctx_id_device, int n_ctx, int64_t* table_device) {
   if (!h) return fail(D3IL_EINVAL, "d3il_set_tally: null handle");
   if (table_device && n_ctx <= 0) return fail(D3IL_EINVAL, "d3il_set_tally: n_ctx must be positive");
+  if (h->rg_ready) { HIPCHK(hipDeviceSynchronize()); rg_drop(h); }
   h->tally_ctx = ctx_id_device; h->tally_nctx = n_ctx; h->tally_table = table_device;
   return D3IL_OK;
 }
@@ -1385,6 +1417,7 @@ int d3il_set_timing(d3il_handle h, int enabled) {
     for (int i = 0; i < 128; i++) { HIPCHK(hipEventCreate(&h->ring0[i])); HIPCHK(hipEventCreate(&h->ring1[i])); }
     h->ring_created = true;
   }
+  if (h->rg_ready) { HIPCHK(hipDeviceSynchronize()); rg_drop(h); }
   if (enabled) { HIPCHK(hipDeviceSynchronize()); h->ring_head = h->ring_drained = h->t_n = 0; h->t_sum = 0; h->t_min = 1e300; h->t_max = 0; }
   h->timing = enabled != 0; h->ev_valid = false;
   return D3IL_OK;
@@ -1400,7 +1433,82 @@ int d3il_step_auto_reset(d3il_handle h, const double* actions, int64_t* episode_
   if (int rc = d3il_step(h, actions, stream)) return rc;
   return d3il_auto_reset(h, episode_counts_device, stream);
 }
+// ---- the captured rollout step (option graph_rollout).  One step of the random-policy harness is eight runtime calls (policy kernel, two event records, step
+// kernel, mask copy, tally kernel, auto-reset kernel) - ~85 us of host time, which bounds the number of sub-batches a process can keep in flight (S = 8:
+// host bound).  Captured once per handle into RG_SLOTS graphs (own event pair each; the step counter in device memory, advanced by the graph's last node), a
+// step is ONE hipGraphLaunch.  Anything that changes what a step launches (options, timing, tally, other arguments) drops the graphs; they are re-captured
+// by the next call.
+static void rg_drop(d3il_handle_s* h) {
+  if (!h->rg_ready) return;
+  for (int k = 0; k < RG_SLOTS; k++) { (void)hipGraphExecDestroy(h->rg_exec[k]); (void)hipGraphDestroy(h->rg_graph[k]); }
+  h->rg_ready = false;
+}
+static int rg_capture(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* counts, hipStream_t s) {
+  if (!h->rg_t_dev) HIPCHK(hipMalloc(&h->rg_t_dev, sizeof(unsigned)));
+  HIPCHK(hipMemcpyAsync(h->rg_t_dev, &t, sizeof(unsigned), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  h->rg_timing = h->timing;
+  for (int k = 0; k < RG_SLOTS; k++) {
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    h->rg_capturing = true; h->rg_slot = k;
+    hipLaunchKernelGGL(k_policy_action_dev, dim3((h->n + 255) / 256), dim3(256), 0, s, h->buf.policy_des, actions, (unsigned long long)seed, (unsigned long long)env_offset,
+                       (const unsigned*)h->rg_t_dev, h->n, h->stride);
+    int rc = d3il_step(h, actions, s);
+    if (!rc) rc = d3il_auto_reset(h, counts, s);
+    if (!rc) hipLaunchKernelGGL(k_inc_counter, dim3(1), dim3(64), 0, s, h->rg_t_dev);
+    h->rg_capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc || e != hipSuccess || !g) {
+      for (int j = 0; j < k; j++) { (void)hipGraphExecDestroy(h->rg_exec[j]); (void)hipGraphDestroy(h->rg_graph[j]); }
+      if (g) (void)hipGraphDestroy(g);
+      return rc ? rc : fail(D3IL_EHIP, std::string("graph_rollout: stream capture failed: ") + hipGetErrorString(e));
+    }
+    h->rg_graph[k] = g;
+    e = hipGraphInstantiate(&h->rg_exec[k], g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+      for (int j = 0; j < k; j++) { (void)hipGraphExecDestroy(h->rg_exec[j]); (void)hipGraphDestroy(h->rg_graph[j]); }
+      (void)hipGraphDestroy(g);
+      return fail(D3IL_EHIP, std::string("graph_rollout: hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+  }
+  h->rg_seed = seed; h->rg_off = env_offset; h->rg_actions = actions; h->rg_counts = counts; h->rg_stream = s; h->rg_next_t = t;
+  h->rg_launched = h->rg_drained = 0; h->rg_ready = true;
+  return D3IL_OK;
+}
+// captures the graphs of the NEXT d3il_random_rollout_step calls with these arguments without launching anything (a harness does this outside its timed region);
+// a no-op without option graph_rollout
+int d3il_random_rollout_prepare(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* episode_counts_device, void* stream) {
+  if (!h || !actions) return fail(D3IL_EINVAL, "d3il_random_rollout_prepare: null argument");
+  if (!(h->rg_enabled && h->task_id == D3IL_TASK_AVOIDING && stream != nullptr && h->started)) return D3IL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(h->device));
+  if (h->rg_ready && (h->rg_seed != seed || h->rg_off != env_offset || h->rg_actions != actions || h->rg_counts != episode_counts_device || h->rg_stream != s ||
+                      h->rg_timing != h->timing)) {
+    HIPCHK(hipStreamSynchronize(h->rg_stream));
+    rg_drop(h);
+  }
+  if (!h->rg_ready) return rg_capture(h, seed, env_offset, t, actions, episode_counts_device, s);
+  return D3IL_OK;
+}
 int d3il_random_rollout_step(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* episode_counts_device, void* stream) {
+  if (h && h->rg_enabled && h->task_id == D3IL_TASK_AVOIDING && stream != nullptr && actions && h->started) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = d3il_random_rollout_prepare(h, seed, env_offset, t, actions, episode_counts_device, stream)) return rc;
+    if (t != h->rg_next_t) { HIPCHK(hipMemcpyAsync(h->rg_t_dev, &t, sizeof(unsigned), hipMemcpyHostToDevice, s)); HIPCHK(hipStreamSynchronize(s)); }      // the caller jumped in time
+    // Launch durations: event-record nodes inside a captured graph give no usable timestamps with this runtime (hipEventElapsedTime: invalid resource
+    // handle), so with timing on every RG_SAMPLE-th step goes through the uncaptured sequence with the event ring around its step launch - a uniform
+    // 1-in-RG_SAMPLE sample of the launches of the timed region (d3il_timing_stats reports how many).
+    if (h->timing && h->rg_launched % RG_SAMPLE == RG_SAMPLE - 1) {
+      if (int rc = d3il_policy_action(h, seed, env_offset, t, actions, stream)) return rc;
+      if (int rc = d3il_step(h, actions, stream)) return rc;
+      if (int rc = d3il_auto_reset(h, episode_counts_device, stream)) return rc;
+      hipLaunchKernelGGL(k_inc_counter, dim3(1), dim3(64), 0, s, h->rg_t_dev);
+      HIPCHK(hipGetLastError());
+    } else HIPCHK(hipGraphLaunch(h->rg_exec[h->rg_launched % RG_SLOTS], s));
+    h->rg_launched++; h->rg_next_t = t + 1;
+    return D3IL_OK;
+  }
   if (int rc = d3il_policy_action(h, seed, env_offset, t, actions, stream)) return rc;
   if (int rc = d3il_step(h, actions, stream)) return rc;
   return d3il_auto_reset(h, episode_counts_device, stream);
@@ -1476,6 +1584,8 @@ int d3il_debug_scratch(d3il_handle h, int env, double* out, int count) {
 
 int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
+  if (h->rg_ready) { HIPCHK(hipDeviceSynchronize()); rg_drop(h); }      // an option may change what a step launches
+  if (std::strcmp(name, "graph_rollout") == 0) { h->rg_enabled = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "solver_strict") == 0) { h->tol_mode = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "stack_reset_coop") == 0) { h->stack_reset_coop = value != 0; return D3IL_OK; }

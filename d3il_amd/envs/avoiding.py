@@ -113,6 +113,10 @@ class ObstacleAvoidanceVecEnv:
         """policy_action + step + auto_reset of the random-policy harness (BASELINE config 2) in ONE library call (d3il_random_rollout_step)."""
         capi.check(self.L.d3il_random_rollout_step(self.h, int(seed), int(env_offset), int(t), C.c_void_p(actions.data_ptr()), C.c_void_p(episode_counts.data_ptr()), self._stream()))
 
+    def random_rollout_prepare(self, seed: int, env_offset: int, t: int, actions: torch.Tensor, episode_counts: torch.Tensor):
+        """With option graph_rollout: capture the HIP graphs the next random_rollout_step calls with these arguments launch (d3il_random_rollout_prepare)."""
+        capi.check(self.L.d3il_random_rollout_prepare(self.h, int(seed), int(env_offset), int(t), C.c_void_p(actions.data_ptr()), C.c_void_p(episode_counts.data_ptr()), self._stream()))
+
     def timing_stats(self):
         """(sum ms, min ms, max ms, launches) of the step-kernel launches since set_timing(True) (d3il_timing_stats; drains the event ring)."""
         out = (C.c_double * 4)()

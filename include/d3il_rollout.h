@@ -231,6 +231,8 @@ int d3il_timing_stats(d3il_handle h, double* out4);
  * d3il_step_auto_reset = d3il_step + d3il_auto_reset; d3il_random_rollout_step = d3il_policy_action + d3il_step + d3il_auto_reset (BASELINE config 2). */
 int d3il_step_auto_reset(d3il_handle h, const double* actions, int64_t* episode_counts_device, void* stream);
 int d3il_random_rollout_step(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* episode_counts_device, void* stream);
+/* Option "graph_rollout": captures the graphs the next d3il_random_rollout_step calls with these arguments will launch, without launching anything (outside a timed region). */
+int d3il_random_rollout_prepare(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* episode_counts_device, void* stream);
 
 /* "ik_fast_path" (default 1), "split_waves" (-1 auto, 0, 1), "lanes_per_wave", "lds_pad_bytes";
  * "serve_wave_max_workgroups" (default 256): Avoiding - up to this many workgroups (64 environments each) the split kernel runs with a third wave that executes the
@@ -238,7 +240,13 @@ int d3il_random_rollout_step(d3il_handle h, uint64_t seed, uint64_t env_offset, 
  * "solver_strict" (default 0): 1 = the contact solvers of Pushing / Sorting / Stacking iterate to round-off like the CPU oracle (parity A/B);
  * "stack_reset_coop" (default 1): Stacking env.reset() through the step kernel's wave-cooperative phases, 0 = the one-lane reset kernel (A/B);
  * "push_coop" (default 0): 1 = Pushing env.step() on the Pushing variant of the wave-cooperative Stacking engine (4 environments per one-wave workgroup; a second,
- * independent device implementation of the same step: parity-tested, measured SLOWER than the two-wave kernel - 0.50 vs 0.65 M env-steps/s -, kept for cross-checks) */
+ * independent device implementation of the same step: parity-tested, measured SLOWER than the two-wave kernel - 0.50 vs 0.65 M env-steps/s -, kept for cross-checks;
+ * only with the round-1 Pushing engine, D3IL_PUSH_ENGINE=legacy - by default Pushing runs on the generic engine of Sorting / Inserting);
+ * "graph_rollout" (default 0): Avoiding - d3il_random_rollout_step is captured once per handle (HIP graph: policy kernel with the step counter in device memory,
+ * step kernel, mask copy, tally, auto-reset, counter + 1) and a step becomes ONE hipGraphLaunch instead of eight runtime calls; needs a non-null stream
+ * (the legacy default stream cannot be captured); any later option / timing / tally change drops the graphs, the next call re-captures.  With timing enabled every
+ * eighth step runs uncaptured with the event pair around its step launch (event nodes inside a graph give no timestamps with this runtime): d3il_timing_stats
+ * then covers a uniform 1-in-8 sample of the launches. */
 int d3il_set_option(d3il_handle h, const char* name, int value);
 /* Diagnostics builds only (-DD3IL_DEVICE_STATS): per-path lane/wave counters of the step kernel. */
 int d3il_debug_stats(uint64_t* out32, int reset);

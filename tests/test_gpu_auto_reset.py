@@ -150,3 +150,41 @@ def test_handles_of_different_generic_models_live_side_by_side():
     for m, e in zip(mixed, envs):
         assert np.array_equal(m, e.get_state()[0])
         e.close()
+
+
+def test_captured_rollout_step_equals_the_eight_calls():
+    """Option graph_rollout: d3il_random_rollout_step as ONE HIP graph launch (policy kernel with the step counter in device memory, step kernel between an
+    event pair, mask copy, tally, auto-reset, counter + 1) gives bit-identical states, flags, tallies and episode counts to the uncaptured sequence - through
+    auto-resets, a jump of the caller's step counter, a timing switch (re-capture) and with the launch durations accounted for."""
+    from d3il_amd.envs.avoiding import ObstacleAvoidanceVecEnv
+    n = 192
+    out = []
+    for graph in (0, 1):
+        stream = torch.cuda.Stream(0)
+        with torch.cuda.stream(stream):
+            env = ObstacleAvoidanceVecEnv(n, device=0, max_steps_per_episode=40)
+            env.bind_stream(stream)
+            env.start(); env.reset(); env.policy_begin()
+            table = env.set_tally(1, None)
+            episodes = torch.zeros(2, dtype=torch.int64, device=env.device)
+            actions = torch.zeros(n, 7, dtype=torch.float64, device=env.device)
+            if graph:
+                env.set_option("graph_rollout", 1)
+            t = 0
+            for k in range(70):
+                if k == 30:
+                    t += 5                      # the caller skips counter values: the device copy follows
+                if k == 45:
+                    env.set_timing(True)        # changes what a step launches: graphs are dropped and captured again
+                    env.random_rollout_prepare(7, 1000, t, actions, episodes)
+                env.random_rollout_step(7, 1000, t, actions, episodes)
+                t += 1
+            stream.synchronize()
+            tsum, tmin, tmax, cnt = env.timing_stats()
+            assert (cnt == 25 if not graph else 2 <= cnt <= 4) and 0 < tmin <= tmax      # captured form: every eighth launch goes through the event ring
+            st, fl, sc = env.get_state()
+            out.append((st.copy(), fl.copy(), sc.copy(), table.cpu().numpy().copy(), episodes.cpu().numpy().copy(), actions.cpu().numpy().copy()))
+            env.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert out[0][4][0] >= n          # every environment finished at least one 40-step episode

@@ -20,7 +20,7 @@ from d3il_amd import build  # noqa: E402
 
 TASK_FUNCS = {
     "avoiding": ("k_avoiding_step_split", ["jacobi_solve6", "solve_constraints"]),
-    "pushing": ("k_pushing_step_split", ["push_", "coupled_newton", "cube_newton", "jacobi_solve6", "solve_constraints"]),
+    "pushing": ("k_sorting_step", ["gen_", "jacobi_solve6", "solve_constraints"]),      # Pushing runs on the generic engine since round 5
     "sorting": ("k_sorting_step", ["gen_", "jacobi_solve6", "solve_constraints"]),
     "stacking": ("k_stacking_step", ["sk_coop_build"]),
     "aligning": ("k_aligning_step", ["sk_coop_build", "jacobi_solve6"]),
@@ -31,7 +31,7 @@ F64 = re.compile(r"^v_\w+_f64")
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04", "isa_fp64_mix.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05", "isa_fp64_mix.json")
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "rollout.s")
         flags = [f for f in build.HIPCC_FLAGS if f not in ("-fPIC", "-shared", "-Xarch_device")]
