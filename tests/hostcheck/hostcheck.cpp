@@ -43,6 +43,8 @@ void* hc_create(const d3il_model_blob* blob, const char** err) {
 }
 void hc_destroy(void* c) { std::free(c); }
 void hc_stats(long* out, int reset) { out[0] = g_stats.newton_calls; out[1] = g_stats.newton_iters; out[2] = g_stats.ls_iters; out[3] = g_stats.eig_calls; out[4] = g_stats.ik_calls; out[5] = g_stats.contact_calls; if (reset) g_stats = Stats{0, 0, 0, 0, 0, 0}; }
+// 0: the production stopping rule of the contact solvers, 1: the oracle's (iterate to round-off) - the device's option solver_strict
+void hc_set_solver_strict(int strict) { host_solver_tol() = strict ? SOLVER_TOL_STRICT : SOLVER_TOL_PRODUCTION; }
 int hc_sizeof_consts() { return (int)sizeof(PandaConsts); }
 void hc_get_consts(const void* c, double* dof_invw, double* rod_invw, double* masses, double* coms) {
   const PandaConsts& p = *(const PandaConsts*)c;
