@@ -435,6 +435,8 @@ class _Shard:
                     raise SystemExit("--policy %s is not available for task %s" % (policy, task))
                 actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
             self.pol = pol
+            if task == "avoiding" and args.fuse_tail:
+                env.set_option("fuse_rollout_tail", 1)      # two launches per rollout step instead of five and a copy
             if self.graph:
                 env.set_option("graph_rollout", 1)      # after set_tally / every other option: the first step captures what a step launches NOW
             self.des_xy = env.policy_des[:2, :n]                              # [2, n] view: the harness set-point the library re-latches on auto-reset
@@ -746,6 +748,7 @@ def main():
     ap.add_argument("--serve-max-wg", type=int, default=None, help="Avoiding: workgroup count up to which the split kernel runs with its third wave (rare constraint paths); 0 = the two-wave kernel (A/B)")
     ap.add_argument("--sub-batches", type=int, default=None, help="step the GPU's environments as this many independent sub-batches on as many HIP streams "
                     "(default: 4 for avoiding / pushing / sorting / inserting, 1 otherwise; 1 = one launch per step over the whole batch)")
+    ap.add_argument("--fuse-tail", type=int, default=1, help="Avoiding, random policy: everything between two step launches (mask, tally, auto-reset, the next action) in one kernel")
     ap.add_argument("--graph-rollout", type=int, default=0, help="Avoiding, random policy, sub-batches on their own streams: the rollout step as one captured HIP graph launch (0: eight runtime calls per step)")
     ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
     args = ap.parse_args()

@@ -102,7 +102,7 @@ __global__ __launch_bounds__((1 + GEN_NSUB) * WAVE) void k_sorting_step(double* 
     const bool plive = slive && sub == 0;                           // ... and in the per-cube phases
     const bool arm_lane = plive && l == 0;
     const size_t ei = e < n ? e : 0;
-    PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_SIZE * GEN_LANES + col), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
+    PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * col), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
     EnvState st;
     float o[GEN_SORT_OBS]; unsigned char dn = 0;
     unsigned lfl = 0;
@@ -127,10 +127,10 @@ __global__ __launch_bounds__((1 + GEN_NSUB) * WAVE) void k_sorting_step(double* 
       }
       PUSH_TOC(0);
       int cnt = 0;
-      if (plive) cnt = gen_phase2(gc, sc, l, grav, lfl);
+      if (slive) cnt = gen_phase2(gc, sc, l, grav, lfl, GEN_NSUB > 1 ? sub : -1);      // both sub-lanes: identical work, each stores the record fields of its parity (gen_put)
       gen_sync();
       PUSH_TOC(1);
-      if (plive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl);
+      if (slive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl, GEN_NSUB > 1 ? sub : -1);
       if (RS && plive) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, lfl);
       gen_sync();
       if (arm_lane) { gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl); gen_arm_reduce<RS>(gc, sc, warm_valid); }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WAVE) void k_sorting_reset(const double* __restrict
   double iq[NARM];
 #pragma unroll
   for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
-  PushScratch sc{(push_lds_double*)(smem + lane), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_SIZE * GEN_LANES + lane), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + e), stride};
+  PushScratch sc{(push_lds_double*)(smem + lane), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * lane), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + e), stride};
   float o[GEN_SORT_OBS];
   st.flags = 0; st.step = 0;
   gen_env_reset(kAvoidingConsts, gc, st, sc, iq, contexts + (size_t)e * 7 * gc.nb, o);

@@ -42,10 +42,12 @@ constexpr int GEN_LANES = D3IL_GEN_LANES;     // environments per workgroup; a p
 // Sub-lanes: on the device a cube is owned by a PAIR of neighbouring lanes that deal the cube's contacts out between them in the solver's contact
 // loops and exchange their partial sums with a DPP swap (gen_tree.h; the joint solver gen_solve simply sees twice the lanes).  GEN_LANES / GEN_NSUB
 // environments x GEN_MAXNB cubes x GEN_NSUB sub-lanes are one wavefront; a workgroup runs GEN_NSUB such physics waves.  The host build has one.
+#if !defined(D3IL_GEN_NSUB)
 #if defined(__HIP_DEVICE_COMPILE__) || (defined(__HIPCC__) && !defined(D3IL_HOST_ONLY))
 #define D3IL_GEN_NSUB 2
 #else
 #define D3IL_GEN_NSUB 1
+#endif
 #endif
 constexpr int GEN_NSUB = D3IL_GEN_NSUB;
 
@@ -84,7 +86,10 @@ __constant__ GenConsts g_gen_consts;
 // are 128 bytes apart, so one 64-bit base address per record and immediate offsets address them (a row stride of n_envs x 8 bytes cost two
 // address instructions per field) and an environment's records share their cache lines with its workgroup only.  Host build: the caller's stride.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define GRS(i) sc.g[(i) * GEN_LANES]
+// fields 2 k and 2 k + 1 of a record sit next to each other, [field pair][environment column][2]: the sixteen lanes that own eight environments in a
+// physics wave (two sub-lanes each) store one field PAIR with one instruction - a full 128-byte line (gen_put).  Half-line stores (one field, eight
+// environments) are written through to memory by this L2: 13 x the write traffic (profiles/r05/README.md).
+#define GRS(i) sc.g[((i) >> 1) * (2 * GEN_LANES) + ((i) & 1)]
 #else
 #define GRS(i) sc.g[(long)(i) * sc.gs]
 #endif
@@ -114,6 +119,9 @@ constexpr int GL_SIZE = GL_PAIR + 6;                // 1043
 constexpr int GG_CON = 0;
 constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn fric sign | jar[3] jp[3]   (sign: of the segment's cube in the row, +1 = it is geom 2)
 constexpr int GG_SIZE = GG_CON + GEN_MAXCON * GREC;
+// rows of a workgroup's block: an ODD number of 128-byte rows, so that the same record field of neighbouring workgroups does not fall on the same L2
+// channel / set (with 3360 rows = 105 x 4 KiB every workgroup's hot lines shared their low address bits: 30 x the write-backs, profiles/r05/README.md)
+constexpr int GG_BLOCK = GG_SIZE + 1;
 D3IL_HD int gt_pair(int c, int d) { return c * (2 * GEN_MAXNB - c - 1) / 2 + (d - c - 1); }      // slot of the cube pair c < d in GL_PAIR
 enum { GK_STATIC = 0, GK_BOXBOX = 1, GK_ROD = 2, GK_RODST = 3 /* rod <-> static box: a = static, b = its slot of the GL_JA rows; no cube */ };
 
@@ -655,20 +663,27 @@ D3IL_HD void gen_phase1(const C& c0, const GenConsts& gc_, EnvState& st, const P
   for (int k = 0; k < NDOF; k++) GLS(GL_X + arm0 + k) = xa[k];
 }
 
-D3IL_HD void gen_put(const GenConsts& gc_, const PushScratch sc, int cube, int& cnt, unsigned& fl, const double* rec, int kind, int a, int b, int set) {
+// sub: -1 = this lane stores every field; 0 / 1 = the lane is one of the two sub-lanes of its cube's pair, both run the collision phase with identical
+// data and each stores the fields of its parity - one store instruction of the wave then covers field pairs of eight environments, i.e. whole lines
+D3IL_HD void gen_put(const GenConsts& gc_, const PushScratch sc, int cube, int& cnt, unsigned& fl, const double* rec, int kind, int a, int b, int set, int sub = -1) {
   D3IL_GEN_CONSTS(gc_, gc);
   if (cnt >= GEN_SEG) { fl |= PF_CON_OVERFLOW; return; }
   const int base = GG_CON + (cube * GEN_SEG + cnt) * GREC;
   double n[3] = {rec[4], rec[5], rec[6]}, t1[3], t2[3];
   make_frame(n, t1, t2);
+  const double f[22] = {rec[1], rec[2], rec[3], n[0], n[1], n[2], t1[0], t1[1], t1[2], t2[0], t2[1], t2[2], rec[0], (double)kind, (double)a, (double)b, 0, 0, 0, 0,
+                        gc.ct_fric[set], kind == GK_STATIC && gc.st_first[a] ? 1.0 : -1.0};      // friction and sign with the record: no table look-ups by record content in the solver's loops
+  if (sub < 0) {
 #pragma unroll
-  for (int k = 0; k < 3; k++) { GRS(base + k) = rec[1 + k]; GRS(base + 3 + k) = n[k]; GRS(base + 6 + k) = t1[k]; GRS(base + 9 + k) = t2[k]; }
-  GRS(base + 12) = rec[0]; GRS(base + 13) = kind; GRS(base + 14) = a; GRS(base + 15) = b;
-  GRS(base + 20) = gc.ct_fric[set]; GRS(base + 21) = kind == GK_STATIC && gc.st_first[a] ? 1.0 : -1.0;      // with the record: no table look-ups by record content in the solver's loops
+    for (int k = 0; k < 22; k++) if (k < 16 || k >= 20) GRS(base + k) = f[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 22; k += 2) if (k < 16 || k >= 20) GRS(base + k + sub) = sub ? f[k + 1] : f[k];
+  }
   cnt++;
 }
 // ---- phase 2 (lane c): cube c's pose into the t area, collision against the static boxes.  Returns the contact count.
-D3IL_NOINLINE inline int gen_phase2(const GenConsts& gc_, const PushScratch sc, int c, const double* gravity, unsigned& fl) {
+D3IL_NOINLINE inline int gen_phase2(const GenConsts& gc_, const PushScratch sc, int c, const double* gravity, unsigned& fl, int sub = -1) {
   D3IL_GEN_CONSTS(gc_, gc);
   double pc[3], Rc[9];
   {
@@ -699,12 +714,12 @@ D3IL_NOINLINE inline int gen_phase2(const GenConsts& gc_, const PushScratch sc, 
     if (d2 > rcirc2) continue;
     int n = gc.st_first[s] ? box_box(gc.st_c[s], gc.st_R[s], gc.st_h[s], pc, Rc, gc.box_half, 0.0, rec, 8)
                            : box_box(pc, Rc, gc.box_half, gc.st_c[s], gc.st_R[s], gc.st_h[s], 0.0, rec, 8);
-    for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_STATIC, s, c, s);
+    for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_STATIC, s, c, s, sub);
   }
   return cnt;
 }
 // ---- phase 3 (lane c): cube c against the cubes after it and against the rod; publishes the cube's info word
-D3IL_NOINLINE inline void gen_phase3(const GenConsts& gc_, const PushScratch sc, int c, int cnt, double rod_r, double rod_h, unsigned& fl) {
+D3IL_NOINLINE inline void gen_phase3(const GenConsts& gc_, const PushScratch sc, int c, int cnt, double rod_r, double rod_h, unsigned& fl, int sub = -1) {
   D3IL_GEN_CONSTS(gc_, gc);
   const double rcirc2 = gc.box_half[0] * gc.box_half[0] + gc.box_half[1] * gc.box_half[1] + gc.box_half[2] * gc.box_half[2];
   double pc[3], Rc[9];
@@ -723,7 +738,7 @@ D3IL_NOINLINE inline void gen_phase3(const GenConsts& gc_, const PushScratch sc,
     double rec[8][7];
     int n = box_box(pc, Rc, gc.box_half, pd, Rd, gc.box_half, 0.0, rec, 8);
     const int first = cnt;
-    for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_BOXBOX, c, d, gc.set_bb);
+    for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_BOXBOX, c, d, gc.set_bb, sub);
     if (cnt > first) { partners |= 1u << d; GLS(GL_PAIR + gt_pair(c, d)) = (double)((unsigned)first | ((unsigned)(cnt - first) << 5)); }
   }
   {
@@ -736,7 +751,7 @@ D3IL_NOINLINE inline void gen_phase3(const GenConsts& gc_, const PushScratch sc,
     double rr = sqrt(rcirc2) + rod_r;
     if (dot3(e, e) < rr * rr && cyl_box(rodc, rodu, rod_r, rod_h, pc, Rc, gc.box_half, 0.0, r1)) {   // cube is geom 1: normal cube -> rod
       const int before = cnt;
-      gen_put(gc, sc, c, cnt, fl, r1, GK_ROD, c, 0, gc.set_rod);
+      gen_put(gc, sc, c, cnt, fl, r1, GK_ROD, c, 0, gc.set_rod, sub);
       if (cnt > before) rod = 1;
     }
   }

@@ -275,8 +275,7 @@ D3IL_HD void gt_to_body(const PushScratch sc, int b, double* y) {
 // the addition commutes; host: one sub-lane, nothing to add).  The wave barriers keep the optimiser from moving code across the cross-lane
 // operation (common-code sinking around convergent operations).
 D3IL_HD double gt_pair_sum(double v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(GEN_NSUB == 2, "the exchange is a swap of lane pairs");
+#if defined(__HIP_DEVICE_COMPILE__) && D3IL_GEN_NSUB == 2
   const int lo = __double2loint(v), hi = __double2hiint(v);
   const int plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false), phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
   return v + __hiloint2double(phi, plo);
@@ -295,6 +294,15 @@ template <int N> D3IL_HD void gt_pair_sum_n(double* v) {
 #endif
 }
 
+// The solver as a function of its own saves and restores ~160 callee-saved registers around every call - 84 KB of scratch stores per wave and sub-step, which
+// this L2 does not keep (13 x the step's write traffic, profiles/r05/README.md).  -DD3IL_GT_INLINE builds it into its caller instead (A/B).
+#if defined(D3IL_GT_INLINE)
+#define D3IL_GT_SOLVE_ATTR D3IL_HD
+#elif defined(D3IL_GT_STATIC)
+#define D3IL_GT_SOLVE_ATTR static D3IL_NOINLINE      // internal linkage: inter-procedural register allocation may drop the callee-saved convention for it
+#else
+#define D3IL_GT_SOLVE_ATTR D3IL_NOINLINE
+#endif
 #define GT_FOR(li) for (int li = 0; li < NL; li++)
 
 // sum / max over the members of the lane's island of what the lanes put into exchange buffer `buf`
@@ -306,7 +314,7 @@ template <int N> D3IL_HD void gt_pair_sum_n(double* v) {
 // NS, sub: sub-lanes per cube and the lane's place in its pair (step kernel: NS = GEN_NSUB = 2; everywhere else one lane per cube).  The sub-lanes of a pair run this function with identical data and take
 // identical decisions; only the contact loops differ - sub-lane s evaluates records s, s + NS, .. - and their sums are exchanged (gt_pair_sum).
 template <int NL, int NS = 1>
-D3IL_NOINLINE inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScratch sc, int l0, bool warm_valid, int sub = 0) {
+D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const PushScratch sc, int l0, bool warm_valid, int sub = 0) {
   D3IL_GEN_CONSTS(gc_, gc);
   unsigned fl = 0;
   GTLane t[NL];

@@ -606,6 +606,62 @@ __global__ void k_policy_action_dev(double* __restrict__ des, double* __restrict
   a[0] = x; a[1] = y; a[2] = z; a[3] = 0; a[4] = 1; a[5] = 0; a[6] = 0;
 }
 __global__ void k_inc_counter(unsigned* __restrict__ t_dev) { if (threadIdx.x == 0 && blockIdx.x == 0) *t_dev += 1u; }
+// Everything the random-policy harness does between two step launches, in ONE launch (d3il_random_rollout_step): the mask of the environments that finished
+// (buf.last_reset), the episode counters and the per-context tally of the finished ones, their reset + re-latch (k_avoiding_auto_reset), and the policy's NEXT
+// action for every environment (k_policy_action with step counter t_next; a reset lane draws from its re-latched pose, as in the separate sequence).  A
+// rollout step is then two launches - step kernel, this kernel - instead of five and a copy.
+__global__ __launch_bounds__(WAVE) void k_avoiding_tail(const double* __restrict__ init_qpos, double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
+                                                        float* __restrict__ obs, unsigned char* __restrict__ done, unsigned char* __restrict__ success,
+                                                        unsigned short* __restrict__ mode, double* __restrict__ des, long long* __restrict__ episode_counts,
+                                                        unsigned char* __restrict__ mask, const int* __restrict__ ctx_id, long long* __restrict__ table, int n_ctx,
+                                                        double* __restrict__ actions, double* __restrict__ des_before, unsigned long long seed, unsigned long long env_offset, unsigned t_next, int n, int stride) {
+  int e = blockIdx.x * WAVE + threadIdx.x;
+  if (e >= n) return;
+  const bool fin = done[e] != 0;
+  mask[e] = fin ? 1 : 0;
+  if (fin) {
+    const bool ok = success[e] != 0;
+    atomicAdd((unsigned long long*)&episode_counts[0], 1ull);
+    if (ok) atomicAdd((unsigned long long*)&episode_counts[1], 1ull);
+    if (table) {
+      int c = ctx_id ? ctx_id[e] : 0;
+      if (c >= 0 && c < n_ctx) {
+        long long* row = table + (size_t)c * D3IL_TALLY_ROW;
+        atomicAdd((unsigned long long*)&row[0], 1ull);
+        const int code = (int)(short)mode[e];
+        if (ok) {
+          atomicAdd((unsigned long long*)&row[1], 1ull);
+          if (code >= 0 && code < D3IL_TALLY_ROW - 2) atomicAdd((unsigned long long*)&row[2 + code], 1ull);
+        }
+      }
+    }
+    EnvState st;
+    double iq[NARM];
+#pragma unroll
+    for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
+    float o[2];
+    env_reset(kAvoidingConsts, st, iq, o);
+    store_state(state, flags, steps, stride, e, st);
+    store_outputs(st, e, o, 0, obs, done, success, mode);
+#pragma unroll
+    for (int k = 0; k < 3; k++) des[k * (size_t)stride + e] = st.tcp[k];
+  }
+  unsigned long long ge = env_offset + (unsigned long long)e;
+  unsigned r[4];
+  philox4x32_10((unsigned)seed, (unsigned)(seed >> 32), (unsigned)ge, (unsigned)(ge >> 32), t_next, 0u, r);
+  double u0 = r[0] * (1.0 / 4294967296.0), u1 = r[1] * (1.0 / 4294967296.0);
+  des_before[e] = des[e]; des_before[(size_t)stride + e] = des[(size_t)stride + e];      // the pose this draw starts from: put back if the sequence is interrupted
+  double x = des[e] + (0.02 * u0 - 0.01), y = des[(size_t)stride + e] + (0.02 * u1 - 0.01), z = des[2 * (size_t)stride + e];
+  des[e] = x; des[(size_t)stride + e] = y;
+  double* a = actions + (size_t)e * 7;
+  a[0] = x; a[1] = y; a[2] = z; a[3] = 0; a[4] = 1; a[5] = 0; a[6] = 0;
+}
+__global__ void k_restore_des(double* __restrict__ des, const double* __restrict__ des_before, int n, int stride) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  des[e] = des_before[e]; des[(size_t)stride + e] = des_before[(size_t)stride + e];
+}
+
 __global__ void k_count_metrics(const unsigned char* __restrict__ done, const unsigned* __restrict__ flags, long long* __restrict__ counts, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
@@ -719,6 +775,8 @@ struct d3il_handle_s {
   hipGraph_t rg_graph[RG_SLOTS]; hipGraphExec_t rg_exec[RG_SLOTS];
   unsigned* rg_t_dev; uint32_t rg_next_t; long rg_launched, rg_drained;
   uint64_t rg_seed, rg_off; double* rg_actions; int64_t* rg_counts; hipStream_t rg_stream;
+  // fused tail of the Avoiding rollout step (k_avoiding_tail): the next step's action is already in `actions` when these match the next call
+  bool prep_valid; uint32_t prep_t; uint64_t prep_seed, prep_off; double* prep_actions; bool fuse_tail; double* d_des_before; hipStream_t prep_stream;
   bool info_is_view;       // buf.info_f64 points into buf.state (Pushing on the generic engine: its two task rows) - not freed on its own
 };
 
@@ -764,7 +822,7 @@ static void free_handle(d3il_handle_s* h) {
     if (h->task_id == D3IL_TASK_STACKING && g_active_stack[dev].refs > 0) g_active_stack[dev].refs--;
   }
   void* ptrs[] = {h->dc, h->d_init_qpos, h->buf.obs, h->buf.done, h->buf.success, h->buf.mode, h->buf.state, h->buf.flags, h->buf.step_count, h->buf.policy_des,
-                  h->info_is_view ? nullptr : (void*)h->buf.info_f64, h->d_scratch, h->d_ctx, h->d_mask};
+                  h->info_is_view ? nullptr : (void*)h->buf.info_f64, h->d_scratch, h->d_ctx, h->d_mask, h->d_des_before};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ring_created) for (int i = 0; i < 128; i++) { (void)hipEventDestroy(h->ring0[i]); (void)hipEventDestroy(h->ring1[i]); }
   rg_drop_for_free(h);
@@ -905,7 +963,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
       std::lock_guard<std::mutex> lock(g_model_mutex);
       g_active_gen[device_id].refs++; h->task_id = task_id;      // the constants go to the device with the first launch (GenLaunch)
     }
-    HIPCHK_H(hipMalloc(&h->d_scratch, S * GG_SIZE * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * GG_SIZE * sizeof(double)));
+    HIPCHK_H(hipMalloc(&h->d_scratch, S * GG_BLOCK * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * GG_BLOCK * sizeof(double)));
     if (gen_pushing) { b.info_f64 = b.state + (size_t)(gen_state_rows(h->gc.nb) - 2) * S; h->info_is_view = true; }      // info['mean_distance'], reward: the task rows of the state buffer (gen_step.h gpush_*)
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
     HIPCHK_H(hipFuncSetAttribute((const void*)k_sorting_step<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_STEP));
@@ -1022,8 +1080,20 @@ static int sync_solver_tol(d3il_handle_s* h, hipStream_t s) {
   return D3IL_OK;
 }
 
+// The fused rollout tail (k_avoiding_tail) has already drawn the NEXT step's action and advanced the harness pose by it.  Any other call that reads or writes
+// the pose / the actions ends that sequence: the pose goes back to where the draw started (on the stream of the sequence, ordered before whatever follows on
+// that stream; a caller that switches streams between calls synchronises them itself, as everywhere in this interface).
+static int drop_prepared_action(d3il_handle_s* h) {
+  if (!h->prep_valid) return D3IL_OK;
+  h->prep_valid = false;
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_restore_des, dim3((h->n + 255) / 256), dim3(256), 0, h->prep_stream, h->buf.policy_des, h->d_des_before, h->n, h->stride);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
 int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, void* stream) {
   if (!h) return fail(D3IL_EINVAL, "d3il_reset: null handle");
+  if (int rc_ = drop_prepared_action(h)) return rc_;
   if (!h->started) return fail(D3IL_ESTATE, "d3il_reset: d3il_start() has not been called (env.start() before env.reset())");
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
@@ -1098,6 +1168,7 @@ static int timing_begin(d3il_handle h, hipStream_t s) {
 }
 int d3il_step(d3il_handle h, const double* actions, void* stream) {
   if (!h || !actions) return fail(D3IL_EINVAL, "d3il_step: null argument");
+  if (int rc_ = drop_prepared_action(h)) return rc_;
   if (!h->started) return fail(D3IL_ESTATE, "d3il_step: d3il_start() has not been called");
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
@@ -1205,6 +1276,7 @@ int d3il_get_state(d3il_handle h, double* state, uint32_t* flags, int32_t* steps
 }
 int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, const int32_t* steps) {
   if (!h) return fail(D3IL_EINVAL, "d3il_set_state: null handle");
+  if (int rc_ = drop_prepared_action(h)) return rc_;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
   if (state) HIPCHK(hipMemcpy2D(h->buf.state, (size_t)h->stride * 8, state, (size_t)h->n * 8, (size_t)h->n * 8, h->state_rows, hipMemcpyHostToDevice));
@@ -1215,6 +1287,7 @@ int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, co
 
 int d3il_policy_begin(d3il_handle h, const uint8_t* env_mask, void* stream) {
   if (!h) return fail(D3IL_EINVAL, "d3il_policy_begin: null handle");
+  if (int rc_ = drop_prepared_action(h)) return rc_;
   HIPCHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_policy_begin, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_mask, h->buf.state, h->buf.policy_des, h->n, h->stride);
   HIPCHK(hipGetLastError());
@@ -1222,6 +1295,7 @@ int d3il_policy_begin(d3il_handle h, const uint8_t* env_mask, void* stream) {
 }
 int d3il_policy_action(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, void* stream) {
   if (!h || !actions) return fail(D3IL_EINVAL, "d3il_policy_action: null argument");
+  if (int rc_ = drop_prepared_action(h)) return rc_;
   if (h->buf.action_dim != 7) return fail(D3IL_EUNSUPPORTED, "d3il_policy_action: the random Cartesian policy writes 7-wide rows (Avoiding / Pushing / Sorting); Stacking actions are 8 wide");
   HIPCHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_policy_action, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->buf.policy_des, actions, (unsigned long long)seed,
@@ -1289,6 +1363,7 @@ int d3il_set_tally(d3il_handle h, const int32_t* ctx_id_device, int n_ctx, int64
 
 int d3il_auto_reset(d3il_handle h, int64_t* episode_counts_device, void* stream) {
   if (!h) return fail(D3IL_EINVAL, "d3il_auto_reset: null handle");
+  if (int rc_ = drop_prepared_action(h)) return rc_;
   if (!h->started) return fail(D3IL_ESTATE, "d3il_auto_reset: d3il_start() has not been called");
   HIPCHK(hipSetDevice(h->device));
   d3il_buffers& b = h->buf;
@@ -1509,6 +1584,22 @@ int d3il_random_rollout_step(d3il_handle h, uint64_t seed, uint64_t env_offset, 
     h->rg_launched++; h->rg_next_t = t + 1;
     return D3IL_OK;
   }
+  if (h && h->fuse_tail && h->task_id == D3IL_TASK_AVOIDING && actions && episode_counts_device && h->started) {
+    // two launches per step: the step kernel and k_avoiding_tail (mask, tally, auto-reset, the NEXT step's action); the first call of a sequence (or one
+    // whose arguments / step counter do not continue the previous call) starts with the separate policy kernel
+    const bool cont = h->prep_valid && h->prep_t == t && h->prep_seed == seed && h->prep_off == env_offset && h->prep_actions == actions && h->prep_stream == (hipStream_t)stream;
+    if (!h->d_des_before) { HIPCHK(hipSetDevice(h->device)); HIPCHK(hipMalloc(&h->d_des_before, (size_t)h->stride * 2 * sizeof(double))); }
+    if (cont) h->prep_valid = 0;          // consumed: the calls below must not put the pose back
+    else { if (int rc = d3il_policy_action(h, seed, env_offset, t, actions, stream)) return rc; }      // (d3il_policy_action drops a stale prepared action first)
+    if (int rc = d3il_step(h, actions, stream)) return rc;
+    d3il_buffers& b = h->buf;
+    hipLaunchKernelGGL(k_avoiding_tail, dim3(h->stride / WAVE), dim3(WAVE), 0, (hipStream_t)stream, h->d_init_qpos, b.state, b.flags, b.step_count, b.obs, b.done, b.success, b.mode,
+                       b.policy_des, (long long*)episode_counts_device, h->d_mask, h->tally_ctx, (long long*)h->tally_table, h->tally_nctx, actions, h->d_des_before,
+                       (unsigned long long)seed, (unsigned long long)env_offset, t + 1u, h->n, h->stride);
+    HIPCHK(hipGetLastError());
+    h->prep_valid = true; h->prep_t = t + 1u; h->prep_seed = seed; h->prep_off = env_offset; h->prep_actions = actions; h->prep_stream = (hipStream_t)stream;
+    return D3IL_OK;
+  }
   if (int rc = d3il_policy_action(h, seed, env_offset, t, actions, stream)) return rc;
   if (int rc = d3il_step(h, actions, stream)) return rc;
   return d3il_auto_reset(h, episode_counts_device, stream);
@@ -1574,8 +1665,10 @@ int d3il_debug_scratch(d3il_handle h, int env, double* out, int count) {
   }
   if (gen_task(h->task_id)) {     // blocked by workgroup: [environment / GEN_LANES][field][environment % GEN_LANES] (gen_step.h GRS)
     if (count > GG_SIZE) return fail(D3IL_EINVAL, "d3il_debug_scratch: count exceeds the environment's scratch area");
-    HIPCHK(hipMemcpy2D(out, sizeof(double), h->d_scratch + (size_t)(env / GEN_LANES) * GG_SIZE * GEN_LANES + env % GEN_LANES, (size_t)GEN_LANES * sizeof(double), sizeof(double), (size_t)count,
-                       hipMemcpyDeviceToHost));
+    // [workgroup][field pair][column][2]: the even and the odd fields are two strided copies
+    const double* base = h->d_scratch + (size_t)(env / GEN_LANES) * GG_BLOCK * GEN_LANES + 2 * (env % GEN_LANES);
+    HIPCHK(hipMemcpy2D(out, 2 * sizeof(double), base, (size_t)2 * GEN_LANES * sizeof(double), sizeof(double), (size_t)(count + 1) / 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(out + 1, 2 * sizeof(double), base + 1, (size_t)2 * GEN_LANES * sizeof(double), sizeof(double), (size_t)count / 2, hipMemcpyDeviceToHost));
     return D3IL_OK;
   }
   HIPCHK(hipMemcpy2D(out, sizeof(double), h->d_scratch + env, (size_t)h->stride * sizeof(double), sizeof(double), (size_t)count, hipMemcpyDeviceToHost));
@@ -1586,6 +1679,7 @@ int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
   if (h->rg_ready) { HIPCHK(hipDeviceSynchronize()); rg_drop(h); }      // an option may change what a step launches
   if (std::strcmp(name, "graph_rollout") == 0) { h->rg_enabled = value != 0; return D3IL_OK; }
+  if (std::strcmp(name, "fuse_rollout_tail") == 0) { if (int rc_ = drop_prepared_action(h)) return rc_; h->fuse_tail = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "solver_strict") == 0) { h->tol_mode = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "stack_reset_coop") == 0) { h->stack_reset_coop = value != 0; return D3IL_OK; }

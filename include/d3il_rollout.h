@@ -246,7 +246,10 @@ int d3il_random_rollout_prepare(d3il_handle h, uint64_t seed, uint64_t env_offse
  * step kernel, mask copy, tally, auto-reset, counter + 1) and a step becomes ONE hipGraphLaunch instead of eight runtime calls; needs a non-null stream
  * (the legacy default stream cannot be captured); any later option / timing / tally change drops the graphs, the next call re-captures.  With timing enabled every
  * eighth step runs uncaptured with the event pair around its step launch (event nodes inside a graph give no timestamps with this runtime): d3il_timing_stats
- * then covers a uniform 1-in-8 sample of the launches. */
+ * then covers a uniform 1-in-8 sample of the launches;
+ * "fuse_rollout_tail" (default 0): Avoiding - d3il_random_rollout_step as TWO launches: the step kernel and one kernel that does everything between two
+ * steps (last_reset mask, episode counters and tally of the finished environments, their reset and re-latch, and the policy's action for the NEXT step -
+ * which the next call of an uninterrupted sequence finds in `actions`); same results as the five launches and the copy it replaces. */
 int d3il_set_option(d3il_handle h, const char* name, int value);
 /* Diagnostics builds only (-DD3IL_DEVICE_STATS): per-path lane/wave counters of the step kernel. */
 int d3il_debug_stats(uint64_t* out32, int reset);
