@@ -517,6 +517,8 @@ def run(args):
         ctx60 = load_stack_contexts()[:args.stack_contexts]     # the first contexts of the reference's 100 test contexts, tiled
     # sub-batches: the rank's environments as S independent sub-batches on S streams (1 = one launch per step over the whole batch)
     S = args.sub_batches if args.sub_batches is not None else DEFAULT_SUB_BATCHES.get(task, 1)
+    if args.sub_batches is None and args.policy in ("ddpm", "beso"):
+        S = 1      # the diffusion policies launch dozens of torch kernels per step and sub-batch: with the round-5 step kernel four sub-batches are host bound (0.45 M against 0.66 M, profiles/r05)
     if S < 1 or n % S != 0 or n // S < 64:
         S = 1
     args.sub_batches = S

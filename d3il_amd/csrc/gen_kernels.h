@@ -44,6 +44,89 @@ __device__ __forceinline__ void gen_store_arm(double* __restrict__ state, unsign
   flags[e] = st.flags; steps[e] = st.step;
 }
 
+// The physics role of the step kernel (one wave; GEN_NSUB of them per workgroup).  Built into the kernel by default.  -DD3IL_GT_INLINE makes it a function of
+// its own - called ONCE per env step, with the tree solver built INTO it: the solver's callee-saved register block (84 KB of scratch stores per wave and call,
+// profiles/r05/README.md) is then saved once per step instead of once per sub-step, and the role gets a register allocation of its own.
+#if defined(D3IL_GT_INLINE)
+#define D3IL_GEN_ROLE_ATTR __device__ __attribute__((noinline))
+#else
+#define D3IL_GEN_ROLE_ATTR __device__ __forceinline__
+#endif
+template <bool FAST, bool RS>
+D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps, const double* __restrict__ actions,
+                                         float* __restrict__ obs, unsigned char* __restrict__ done, unsigned char* __restrict__ success, unsigned short* __restrict__ mode,
+                                         double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps, double* tbl,
+                                         double (*xch)[2 * NARM][GEN_LANES], int lane, int role) {
+  const PandaConsts& c = kAvoidingConsts;
+  const GenConsts& gc = g_gen_consts;
+  constexpr int CPW = GEN_LANES / GEN_NSUB;                      // environment columns per physics wave
+  const int sub = lane & (GEN_NSUB - 1), pr = lane / GEN_NSUB;   // sub-lane of the pair, pair index in the wave
+  const int col = (role - 1) * CPW + (pr & (CPW - 1)), l = pr / CPW;   // pair l of environment column col
+  const int e = blockIdx.x * GEN_LANES + col;
+  const bool slive = e < n && l < gc.nb;                          // the lane takes part in the solver
+  const bool plive = slive && sub == 0;                           // ... and in the per-cube phases
+  const bool arm_lane = plive && l == 0;
+  const size_t ei = e < n ? e : 0;
+  PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * col), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
+  EnvState st;
+  float o[GEN_SORT_OBS]; unsigned char dn = 0;
+  unsigned lfl = 0;
+  bool warm_valid = false;
+  const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
+  if (slive) warm_valid = (flags[e] & PF_WARM_VALID) != 0;
+  if (arm_lane) {
+    gen_load_arm(state, flags, steps, stride, e, st, false);
+    sort_step_begin(gc, st, sc, o, &dn, max_steps);
+  }
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < n_substeps; s++) {
+    __syncthreads();
+    PUSH_TIC;
+    if (arm_lane) {
+      const int b = s & 1;
+      double qd[NARM], qdd[NARM], tau[NARM], ff[NFING];
+#pragma unroll
+      for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][col]; qdd[k] = xch[b][NARM + k][col]; }
+      push_control(c, st, qd, qdd, 0.04, false, tau, ff);
+      gen_phase1(c, gc, st, sc, tau, ff);
+    }
+    PUSH_TOC(0);
+    int cnt = 0;
+    if (slive) cnt = gen_phase2(gc, sc, l, grav, lfl, GEN_NSUB > 1 ? sub : -1);      // both sub-lanes: identical work, each stores the record fields of its parity (gen_put)
+    gen_sync();
+    PUSH_TOC(1);
+    if (slive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl, GEN_NSUB > 1 ? sub : -1);
+    if (RS && plive) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, lfl);
+    gen_sync();
+    if (arm_lane) { gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl); gen_arm_reduce<RS>(gc, sc, warm_valid); }
+    gen_sync();
+    PUSH_TOC(2);
+    if (slive) lfl |= gen_tree_solve<1, GEN_NSUB>(gc, sc, l, warm_valid, sub);
+    gen_sync();
+    PUSH_TOC(8);
+    if (slive) gen_phase4_multi<RS>(gc, sc, GEN_NSUB * l + sub, GEN_NSUB * gc.nb, warm_valid, lfl);
+    gen_sync();
+    PUSH_TOC(9);
+    if (arm_lane) gen_phase5_arm(c, gc, st, sc);
+    if (plive) gen_phase5_cube(gc, sc, l, c.timestep);
+    gen_sync();
+    warm_valid = true;
+  }
+  if (plive && l > 0) GLS(GL_INFO + 4 + l) = (double)lfl;
+  gen_sync();
+  if (arm_lane) {
+    int code = 0;
+    for (int k = 1; k < gc.nb; k++) lfl |= (unsigned)GLS(GL_INFO + 4 + k);
+    st.flags |= F_IK_VALID | PF_WARM_VALID | lfl;
+    if (action_is_bad(actions + (size_t)e * 7)) st.flags |= F_SOLVER_FAIL | F_TERMINATED;
+    sort_step_end(gc, st, sc, &code);
+    gen_store_arm(state, flags, steps, stride, e, st, false);
+    const int od = 2 + 3 * gc.nb;
+    for (int k = 0; k < od; k++) obs[(size_t)od * e + k] = o[k];
+    done[e] = dn; success[e] = (st.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)code;
+  }
+}
+
 // env.step() for the Sorting task (RS = false) and the Inserting task (RS = true: the engine with contacts of the arm block, gen_step.h)
 template <bool FAST, bool RS>
 __global__ __launch_bounds__((1 + GEN_NSUB) * WAVE) void k_sorting_step(double* __restrict__ state, unsigned* __restrict__ flags,
@@ -94,72 +177,7 @@ __global__ __launch_bounds__((1 + GEN_NSUB) * WAVE) void k_sorting_step(double* 
       for (int i = 0; i < NARM; i++) { so[(D3IL_STATE_IK_Q + i) * (size_t)stride] = ikq[i]; so[(D3IL_STATE_IK_QD + i) * (size_t)stride] = ikqd[i]; }
     }
   } else {
-    constexpr int CPW = GEN_LANES / GEN_NSUB;                      // environment columns per physics wave
-    const int sub = lane & (GEN_NSUB - 1), pr = lane / GEN_NSUB;   // sub-lane of the pair, pair index in the wave
-    const int col = (role - 1) * CPW + (pr & (CPW - 1)), l = pr / CPW;   // pair l of environment column col
-    const int e = blockIdx.x * GEN_LANES + col;
-    const bool slive = e < n && l < gc.nb;                          // the lane takes part in the solver
-    const bool plive = slive && sub == 0;                           // ... and in the per-cube phases
-    const bool arm_lane = plive && l == 0;
-    const size_t ei = e < n ? e : 0;
-    PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * col), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
-    EnvState st;
-    float o[GEN_SORT_OBS]; unsigned char dn = 0;
-    unsigned lfl = 0;
-    bool warm_valid = false;
-    const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
-    if (slive) warm_valid = (flags[e] & PF_WARM_VALID) != 0;
-    if (arm_lane) {
-      gen_load_arm(state, flags, steps, stride, e, st, false);
-      sort_step_begin(gc, st, sc, o, &dn, max_steps);
-    }
-#pragma clang loop unroll(disable)
-    for (int s = 0; s < n_substeps; s++) {
-      __syncthreads();
-      PUSH_TIC;
-      if (arm_lane) {
-        const int b = s & 1;
-        double qd[NARM], qdd[NARM], tau[NARM], ff[NFING];
-#pragma unroll
-        for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][col]; qdd[k] = xch[b][NARM + k][col]; }
-        push_control(c, st, qd, qdd, 0.04, false, tau, ff);
-        gen_phase1(c, gc, st, sc, tau, ff);
-      }
-      PUSH_TOC(0);
-      int cnt = 0;
-      if (slive) cnt = gen_phase2(gc, sc, l, grav, lfl, GEN_NSUB > 1 ? sub : -1);      // both sub-lanes: identical work, each stores the record fields of its parity (gen_put)
-      gen_sync();
-      PUSH_TOC(1);
-      if (slive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl, GEN_NSUB > 1 ? sub : -1);
-      if (RS && plive) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, lfl);
-      gen_sync();
-      if (arm_lane) { gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl); gen_arm_reduce<RS>(gc, sc, warm_valid); }
-      gen_sync();
-      PUSH_TOC(2);
-      if (slive) lfl |= gen_tree_solve<1, GEN_NSUB>(gc, sc, l, warm_valid, sub);
-      gen_sync();
-      PUSH_TOC(8);
-      if (slive) gen_phase4_multi<RS>(gc, sc, GEN_NSUB * l + sub, GEN_NSUB * gc.nb, warm_valid, lfl);
-      gen_sync();
-      PUSH_TOC(9);
-      if (arm_lane) gen_phase5_arm(c, gc, st, sc);
-      if (plive) gen_phase5_cube(gc, sc, l, c.timestep);
-      gen_sync();
-      warm_valid = true;
-    }
-    if (plive && l > 0) GLS(GL_INFO + 4 + l) = (double)lfl;
-    gen_sync();
-    if (arm_lane) {
-      int code = 0;
-      for (int k = 1; k < gc.nb; k++) lfl |= (unsigned)GLS(GL_INFO + 4 + k);
-      st.flags |= F_IK_VALID | PF_WARM_VALID | lfl;
-      if (action_is_bad(actions + (size_t)e * 7)) st.flags |= F_SOLVER_FAIL | F_TERMINATED;
-      sort_step_end(gc, st, sc, &code);
-      gen_store_arm(state, flags, steps, stride, e, st, false);
-      const int od = 2 + 3 * gc.nb;
-      for (int k = 0; k < od; k++) obs[(size_t)od * e + k] = o[k];
-      done[e] = dn; success[e] = (st.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)code;
-    }
+    gen_physics_role<FAST, RS>(state, flags, steps, actions, obs, done, success, mode, scratch, n, stride, n_substeps, max_steps, tbl, xch, lane, role);
   }
 }
 

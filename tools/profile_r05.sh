@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05p; mkdir -p $O profiles/r05/pmc
 CASES=${@:-"avoiding:random: pushing:mlp: pushing:scripted_push:--steps=100 sorting:mlp: sorting:scripted_push:--steps=60 sorting:ddpm: inserting:scripted_push:--steps=60,--warmup=5,--preroll=300 stacking:scripted_stack:--steps=100,--warmup=5 aligning:scripted_align:--steps=200,--warmup=5"}
 declare -A KERN=( [avoiding]=k_avoiding_step_split [pushing]=k_sorting_step [sorting]=k_sorting_step [inserting]=k_sorting_step [stacking]=k_stacking_step [aligning]=k_aligning_step )
-declare -A DEFS=( [avoiding]=4 [pushing]=4 [sorting]=4 [inserting]=4 [stacking]=1 [aligning]=1 )
+declare -A DEFS=( [avoiding]=4 [pushing]=4 [sorting]=4 [inserting]=4 [stacking]=1 [aligning]=1 )      # (bench.py itself defaults to 1 for the ddpm / beso policies)
 for C in $CASES; do
   T=${C%%:*}; R=${C#*:}; P=${R%%:*}; X=${R#*:}; X=${X//,/ }
   K=${KERN[$T]}; B=""; if [ $T = stacking ] || [ $T = aligning ]; then B="--bimodal"; fi
