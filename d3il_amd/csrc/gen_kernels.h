@@ -101,7 +101,15 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
     if (arm_lane) { gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl); gen_arm_reduce<RS>(gc, sc, warm_valid); }
     gen_sync();
     PUSH_TOC(2);
-    if (slive) lfl |= gen_tree_solve<1, GEN_NSUB>(gc, sc, l, warm_valid, sub);
+    // environments without cube <-> cube and rod contacts (every cube on static boxes only) solve their cubes one by one in the kernel's own registers; a wave
+    // none of whose environments has a coupled island never calls the tree solver (and does not pay for its register save block).
+    // The choice is per ENVIRONMENT (a function of its own state), not per wave: the two solvers agree to solver tolerance, not bit for bit, and an
+    // environment's result must not depend on who shares its wave (tests/test_gpu_permutation.py).  A wave with both kinds of environments runs both
+    // solvers one after the other (measured with a per-wave choice instead: +6 % in the all-contact regime of Sorting, +11 % of Pushing - and 3707 of 4096
+    // environments whose results depend on their position; profiles/r05/lone_solver/).
+    const bool lone_env = gen_uncoupled(gc, sc);
+    if (slive && lone_env) lfl |= gen_lone_solve<GEN_NSUB>(gc, sc, l, warm_valid, sub);
+    if (slive && !lone_env) lfl |= gen_tree_solve<1, GEN_NSUB>(gc, sc, l, warm_valid, sub);
     gen_sync();
     PUSH_TOC(8);
     if (slive) gen_phase4_multi<RS>(gc, sc, GEN_NSUB * l + sub, GEN_NSUB * gc.nb, warm_valid, lfl);

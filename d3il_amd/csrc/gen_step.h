@@ -1062,7 +1062,8 @@ D3IL_HD void gen_physics_substep_t(const C& c0, const GenConsts& gc_, EnvState& 
   if (RS && gc.rod_static) for (int l = 0; l < gc.nb; l++) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, fl);
   gen_phase3b<RS>(c0, gc, st, sc, gc.nb, fl);
   gen_arm_reduce<RS>(gc, sc, warm_valid);
-  fl |= gen_tree_solve<GEN_MAXNB>(gc, sc, 0, warm_valid);
+  if (gen_uncoupled(gc, sc)) { for (int l = 0; l < gc.nb; l++) fl |= gen_lone_solve<1>(gc, sc, l, warm_valid, 0); }      // (the rule of the step kernel, gen_kernels.h)
+  else fl |= gen_tree_solve<GEN_MAXNB>(gc, sc, 0, warm_valid);
   gen_phase4_multi<RS>(gc, sc, 0, 1, warm_valid, fl);
   gen_phase5_arm(c0, gc, st, sc);
   for (int l = 0; l < gc.nb; l++) gen_phase5_cube(gc, sc, l, c.timestep);

@@ -879,4 +879,183 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
   return fl;
 }
 
+
+// ---- a cube on its own (an environment without cube <-> cube and rod contacts: every cube rests on static boxes only - the resting regime and most sub-steps
+// of an evaluation run): the single-node case of the tree solver as a function of its own.  No tree analysis, no messages, no exchange slots - and an
+// order fewer registers than gen_tree_solve, so it is built INTO the step kernel: an environment that needs nothing else never calls the big solver (whose
+// callee-saved register block is most of the engine's scratch traffic, profiles/r05/README.md).  Same cost function, point form, line search and stopping
+// rules; the aref / D of a record are kept in registers' reach (LDS line-search slots) and in the record.  NS, sub as in gen_tree_solve.
+template <int NS>
+D3IL_HD unsigned gen_lone_solve(const GenConsts& gc_, const PushScratch sc, int b, bool warm_valid, int sub) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  const int cnt = (int)((unsigned)GLS(GL_INFO + b) & 31u);
+  double x[6];
+  if (cnt == 0) {                                   // in free flight: x = a0
+#pragma unroll
+    for (int k = 0; k < 6; k++) GLS(GL_X + 6 * b + k) = GLS(GL_A0 + 6 * b + k);
+    return 0u;
+  }
+  const double impr = gc.impratio, mu_scale = sqrt(1 / fmax(1e-15, impr)), mt = gc.box_mass, mr = gc.box_inertia;
+  const double grav2 = GLS(GL_A0 + 2);
+#pragma unroll
+  for (int k = 0; k < 6; k++) x[k] = warm_valid ? GWARM(6 * b + k) : GLS(GL_A0 + 6 * b + k);
+  gt_to_world(sc, b, x);
+  double pc[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) pc[k] = GLS(GL_POS + 3 * b + k);
+  {   // reference acceleration and regularisation of the records (all of them cube <-> static box)
+    double vel[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) vel[k] = GLS(GL_VEL + 6 * b + k);
+    gt_to_world(sc, b, vel);
+#pragma clang loop unroll(disable)
+    for (int q = sub; q < cnt; q += NS) {
+      const int base = GG_CON + (b * GEN_SEG + q) * GREC;
+      double rec[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) rec[k] = GRS(base + k);
+      const int set = (int)rec[14];
+      const double sg = GRS(base + 21);
+      const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]};
+      double u[3] = {0, 0, 0}, v[3];
+      gt_point(vel, r1, sg, u);
+#pragma unroll
+      for (int r = 0; r < 3; r++) v[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2];
+      const double dist = rec[12], imp = impedance(gc.ct_solimp[set], dist);
+      const double Dn = 1 / fmax(1e-15, (1 - imp) / imp * gc.box_invw_t);
+      GRS(base + 16) = -gc.ct_B[set] * v[0] - gc.ct_K[set] * imp * dist;
+      GRS(base + 17) = -gc.ct_B[set] * v[1]; GRS(base + 18) = -gc.ct_B[set] * v[2];
+      GRS(base + 19) = Dn;
+      if (q < GT_LSCAP) { GT_LSS(b, q, 6) = Dn; GT_LSS(b, q, 7) = GRS(base + 20); }
+    }
+    D3IL_STAT(g_stats.newton_calls++);
+  }
+  bool converged = false, failed = false;
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < 60 && !converged; it++) {
+    D3IL_STAT(g_stats.newton_iters++);
+    double g[6], H[21];
+#pragma unroll
+    for (int i = 0; i < 21; i++) H[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const double mm = sub == 0 ? (k < 3 ? mt : mr) : 0.0; g[k] = mm * (x[k] - (k == 2 ? grav2 : 0.0)); H[tri(k, k)] = mm; }
+#pragma clang loop unroll(disable)
+    for (int q = sub; q < cnt; q += NS) {
+      const int base = GG_CON + (b * GEN_SEG + q) * GREC;
+      double rec[22];
+#pragma unroll
+      for (int k = 0; k < 22; k++) rec[k] = GRS(base + k);
+      const double sg = rec[21];
+      const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]};
+      double u[3] = {0, 0, 0}, jar[3], force[3], Hc[9];
+      gt_point(x, r1, sg, u);
+#pragma unroll
+      for (int r = 0; r < 3; r++) jar[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2] - rec[16 + r];
+      if (q < GT_LSCAP) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) GT_LSS(b, q, r) = jar[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; r++) GRS(base + 22 + r) = jar[r];
+      }
+      const double Dn = rec[19], fric = rec[20];
+      cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
+      if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
+      double w[3], S[9], P[9];
+#pragma unroll
+      for (int k = 0; k < 3; k++) w[k] = sg * (rec[3 + k] * force[0] + rec[6 + k] * force[1] + rec[9 + k] * force[2]);
+      g[0] -= w[0]; g[1] -= w[1]; g[2] -= w[2];
+      g[3] -= r1[1] * w[2] - r1[2] * w[1]; g[4] -= r1[2] * w[0] - r1[0] * w[2]; g[5] -= r1[0] * w[1] - r1[1] * w[0];
+      gt_world_S(rec + 3, Hc, S);
+      gt_SxR(S, r1, P);
+      gt_add_diag(H, S, P, r1);
+    }
+    if (NS > 1) { gt_pair_sum_n<6>(g); gt_pair_sum_n<21>(H); }
+    {
+      double gm = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) gm = fmax(gm, fabs(g[k]));
+      if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
+    }
+    double dd[6], idd[6], p[6];
+    if (!ldl_n<6>(H, dd, idd)) failed = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) p[k] = -g[k];
+    ldl_solve_n<6>(H, idd, p);
+    double pMp = 0, pMa = 0, gTp = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const double mm = k < 3 ? mt : mr; pMp += mm * p[k] * p[k]; pMa += mm * p[k] * (x[k] - (k == 2 ? grav2 : 0.0)); gTp += g[k] * p[k]; }
+#pragma clang loop unroll(disable)
+    for (int q = sub; q < cnt; q += NS) {      // directional derivatives of the rows
+      const int base = GG_CON + (b * GEN_SEG + q) * GREC;
+      double rec[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) rec[k] = GRS(base + k);
+      const double sg = GRS(base + 21);
+      const double r1[3] = {rec[0] - pc[0], rec[1] - pc[1], rec[2] - pc[2]};
+      double u[3] = {0, 0, 0}, jp[3];
+      gt_point(p, r1, sg, u);
+#pragma unroll
+      for (int r = 0; r < 3; r++) jp[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2];
+      if (q < GT_LSCAP) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) GT_LSS(b, q, 3 + r) = jp[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; r++) GRS(base + 25 + r) = jp[r];
+      }
+    }
+    double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
+#pragma clang loop unroll(disable)
+    for (int ls = 0; ls < 50; ls++) {
+      D3IL_STAT(g_stats.ls_iters++);
+      double p1 = 0, p2 = 0;
+#pragma clang loop unroll(disable)
+      for (int q = sub; q < cnt; q += NS) {
+        const int base = GG_CON + (b * GEN_SEG + q) * GREC;
+        double rc[8];      // jar[3] jp[3] Dn fric
+        if (q < GT_LSCAP) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) rc[k] = GT_LSS(b, q, k);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; k++) rc[k] = GRS(base + 22 + k);
+          rc[6] = GRS(base + 19); rc[7] = GRS(base + 20);
+        }
+        const double jp[3] = {rc[3], rc[4], rc[5]};
+        double jt[3] = {rc[0] + alpha * jp[0], rc[1] + alpha * jp[1], rc[2] + alpha * jp[2]}, ft[3], Hc[9];
+        cone_eval(jt, rc[6], rc[6] * impr, rc[7] * mu_scale, rc[7], ft, Hc);
+#pragma unroll
+        for (int r = 0; r < 3; r++) { p1 -= ft[r] * jp[r];
+#pragma unroll
+          for (int qq = 0; qq < 3; qq++) p2 += jp[r] * Hc[3 * r + qq] * jp[qq]; }
+      }
+      if (NS > 1) { double pp[2] = {p1, p2}; gt_pair_sum_n<2>(pp); p1 = pp[0]; p2 = pp[1]; }
+      const double d1 = pMa + alpha * pMp + p1, d2 = pMp + p2;
+      best = alpha;
+      if (ls == 0 && d1 <= D3IL_TOL.ls_full * fabs(gTp)) break;
+      if (fabs(d1) <= D3IL_TOL.ls_c2 * fabs(gTp) || fabs(d1) <= D3IL_TOL.ls_rel * d2 * alpha || fabs(d1) < 1e-14 * fmax(1.0, fabs(pMa))) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      double na = alpha - d1 * rcpd(d2);
+      if (hi >= 0) {
+        const double wbr = hi - lo;
+        const bool slow = wbr > 0.5 * wprev;
+        wprev = wbr;
+        if (slow || !(na > lo && na < hi)) na = 0.5 * (lo + hi);
+      } else if (na <= lo) na = 2 * lo + 1;
+      if (na == alpha) break;
+      alpha = na;
+    }
+    double smax = 0, xmax = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const double dxk = best * p[k]; x[k] += dxk; smax = fmax(smax, fabs(dxk)); xmax = fmax(xmax, fabs(x[k])); }
+    if (failed) break;
+    if (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= D3IL_TOL.step_rel * (1 + xmax))) converged = true;
+  }
+  gt_to_body(sc, b, x);
+#pragma unroll
+  for (int k = 0; k < 6; k++) GLS(GL_X + 6 * b + k) = x[k];
+  return (converged && !failed) ? 0u : (unsigned)F_SOLVER_FAIL;
+}
+
 }  // namespace d3il
