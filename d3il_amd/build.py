@@ -128,6 +128,7 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
 VARIANTS = {"gtstatic": ["D3IL_GT_STATIC"],
             "gtinline": ["D3IL_GT_INLINE"],      # the tree solver inlined into the step kernel (no callee-saved register traffic)
             "nsub1": ["D3IL_GEN_NSUB=1"],      # the generic engine with one lane per cube and one physics wave (A/B of the sub-lanes)
+            "loneenv": ["D3IL_LONE_PER_ENV=1"],      # lone-cube / tree solver chosen per environment instead of per wave (A/B)
             "poison": ["D3IL_SK_POISON"], "raw": ["D3IL_SK_PRELOAD_RAW"], "nopreload": ["D3IL_SK_NO_PRELOAD"], "poisonraw": ["D3IL_SK_POISON", "D3IL_SK_PRELOAD_RAW"]}
 
 if __name__ == "__main__":

@@ -103,11 +103,17 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
     PUSH_TOC(2);
     // environments without cube <-> cube and rod contacts (every cube on static boxes only) solve their cubes one by one in the kernel's own registers; a wave
     // none of whose environments has a coupled island never calls the tree solver (and does not pay for its register save block).
-    // The choice is per ENVIRONMENT (a function of its own state), not per wave: the two solvers agree to solver tolerance, not bit for bit, and an
-    // environment's result must not depend on who shares its wave (tests/test_gpu_permutation.py).  A wave with both kinds of environments runs both
-    // solvers one after the other (measured with a per-wave choice instead: +6 % in the all-contact regime of Sorting, +11 % of Pushing - and 3707 of 4096
-    // environments whose results depend on their position; profiles/r05/lone_solver/).
+    // The choice is per WAVE: a wave with one coupled environment sends all of its environments through the tree solver.  An environment's result must
+    // not depend on who shares its wave (tests/test_gpu_permutation.py), so the two solvers have to agree BIT FOR BIT on a one-node island: both are written
+    // over the same helpers in the same order and gen_tree.h is compiled with expression-level contraction (`fp contract(on)`), which leaves the compiler no
+    // freedom to fuse across statements differently in the two bodies (with hipcc's default, contract(fast), 3707 of 4096 environments depended on their
+    // position; with it, none - tools/gpu_perm_push_sort.py, profiles/r05/lone_solver/).  -DD3IL_LONE_PER_ENV: the choice per environment (a wave with
+    // both kinds runs both solvers one after the other: -7 % in the all-contact regime of Sorting, -11 % of Pushing).
+#if defined(D3IL_LONE_PER_ENV)
     const bool lone_env = gen_uncoupled(gc, sc);
+#else
+    const bool lone_env = !wave_any(slive && !gen_uncoupled(gc, sc));
+#endif
     if (slive && lone_env) lfl |= gen_lone_solve<GEN_NSUB>(gc, sc, l, warm_valid, sub);
     if (slive && !lone_env) lfl |= gen_tree_solve<1, GEN_NSUB>(gc, sc, l, warm_valid, sub);
     gen_sync();

@@ -25,6 +25,95 @@
 
 namespace d3il {
 
+
+// Floating-point contraction in this file is the EXPRESSION-level rule (a * b + c written as one expression becomes an fma, nothing is fused across statements):
+// gen_lone_solve and gen_tree_solve evaluate a cube on its own with the same expressions in the same order, and with this rule the same expressions become the
+// same instructions in both - which of the two a wave runs may then depend on the other environments of the wave without an environment's result depending
+// on them (tests/test_gpu_permutation.py, tools/gpu_perm_push_sort.py).  The helpers the two share are compiled here, under the same rule.
+#if defined(__clang__)
+#pragma clang fp contract(on)
+#endif
+D3IL_HD double gt_rsqrtd(double x) {   // rsqrtd (panda_step.h) with its two Newton steps written as explicit fused operations
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-(0.5 * x * y), y, 1.5);
+  y = y * fma(-(0.5 * x * y), y, 1.5);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+D3IL_HD double gt_cone_eval(const double* jar, double Dn, double Dt, double mu, double fric, double* force, double* Hc /* 3x3 */) {
+  if (Dn == 0) {   // inert row (inactive contact slot of this lane inside a wave-uniform loop)
+#pragma unroll
+    for (int i = 0; i < 9; i++) Hc[i] = 0;
+    force[0] = force[1] = force[2] = 0;
+    return 0;
+  }
+  double U0 = jar[0] * mu, U1 = jar[1] * fric, U2 = jar[2] * fric;
+  double T2 = U1 * U1 + U2 * U2;
+  double iT = T2 > 0 ? gt_rsqrtd(T2) : 0.0;
+  double N = U0, T = T2 * iT;
+#pragma unroll
+  for (int i = 0; i < 9; i++) Hc[i] = 0;
+  if (N >= mu * T || (T <= 0 && N >= 0)) { force[0] = force[1] = force[2] = 0; return 0; }
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    force[0] = -Dn * jar[0]; force[1] = -Dt * jar[1]; force[2] = -Dt * jar[2];
+    Hc[0] = Dn; Hc[4] = Dt; Hc[8] = Dt;
+    return 0.5 * (Dn * jar[0] * jar[0] + Dt * jar[1] * jar[1] + Dt * jar[2] * jar[2]);
+  }
+  double Dm = Dn * rcpd(fmax(1e-15, mu * mu * (1 + mu * mu))), NmT = N - mu * T;
+  double iT3 = iT * iT * iT;
+  double g[3] = {mu, -mu * fric * U1 * iT, -mu * fric * U2 * iT}, U[3] = {0, U1, U2};
+#pragma unroll
+  for (int j = 0; j < 3; j++) force[j] = -Dm * NmT * g[j];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double h = g[a] * g[b];
+      if (a > 0 && b > 0) h += NmT * (-mu) * fric * fric * ((a == b ? iT : 0) - U[a] * U[b] * iT3);
+      Hc[3 * a + b] = Dm * h;
+    }
+  return 0.5 * Dm * NmT * NmT;
+}
+
+template <int N> D3IL_HD bool gt_ldl_n(double* A, double* d, double* id) {   // in place: strict lower part of A becomes L
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double s = A[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= A[tri(j, k)] * A[tri(j, k)] * d[k];
+    if (!(s > 1e-300)) { s = 1; ok = false; }
+    d[j] = s;
+    double inv = rcpd(s);
+    id[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < N; i++) {
+      double t = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= A[tri(i, k)] * A[tri(j, k)] * d[k];
+      A[tri(i, j)] = t * inv;
+    }
+  }
+  return ok;
+}
+template <int N> D3IL_HD void gt_ldl_solve_n(const double* L, const double* id, double* x) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int k = 0; k < i; k++) x[i] -= L[tri(i, k)] * x[k];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] *= id[i];
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+#pragma unroll
+    for (int k = i + 1; k < N; k++) x[i] -= L[tri(k, i)] * x[k];
+  }
+}
+
 // LDS slots of the tree solver.  They alias the dense Hessian of gen_solve (GL_H), which runs after this phase.
 constexpr int GT_MSG = GL_H;                          // per cube: Schur message to its parent, dH[21] dg[6]
 constexpr int GT_A = GT_MSG + 27 * GEN_MAXNB;         // A = W M^-1 W', packed lower 5 x 5
@@ -460,7 +549,7 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
           for (int r = 0; r < 3; r++) GRS(base + 22 + r) = jar[r];
         }
         const double Dn = rec[19], fric = rec[20];
-        cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
+        gt_cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
         if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
         double w[3], S[9], P[9];
 #pragma unroll
@@ -513,7 +602,7 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
 #pragma unroll
           for (int r = 0; r < 3; r++) jar[r] = rec[3 + 3 * r] * u[0] + rec[4 + 3 * r] * u[1] + rec[5 + 3 * r] * u[2] - rec[16 + r];
           const double Dn = rec[19], fric = rec[20];
-          cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
+          gt_cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
           if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
           double w[3], S[9], P[9];
 #pragma unroll
@@ -593,11 +682,11 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
       GT_FOR(li) {
         GTLane& T = t[li];
         if (!T.active || T.depth != d) continue;
-        if (!ldl_n<6>(T.H, T.dd, T.idd)) T.failed = true;
+        if (!gt_ldl_n<6>(T.H, T.dd, T.idd)) T.failed = true;
         double v[6], dH[21], dg[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) v[k] = T.g[k];
-        ldl_solve_n<6>(T.H, T.idd, v);
+        gt_ldl_solve_n<6>(T.H, T.idd, v);
 #pragma unroll
         for (int j = 0; j < 6; j++) { double s = 0;
 #pragma unroll
@@ -608,7 +697,7 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
           double w[6];
 #pragma unroll
           for (int i = 0; i < 6; i++) w[i] = T.Hpc[6 * k + i];
-          ldl_solve_n<6>(T.H, T.idd, w);
+          gt_ldl_solve_n<6>(T.H, T.idd, w);
 #pragma unroll
           for (int j = k; j < 6; j++) { double s = 0;
 #pragma unroll
@@ -632,7 +721,7 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
 #pragma unroll
             for (int j = 0; j < 5; j++) s -= T.Hpc[6 * j + i] * gl[j];
             T.p[i] = s; }
-          ldl_solve_n<6>(T.H, T.idd, T.p);
+          gt_ldl_solve_n<6>(T.H, T.idd, T.p);
 #pragma unroll
           for (int k = 0; k < 6; k++) GLS(GL_P + 6 * T.b + k) = T.p[k];
         } else {
@@ -659,10 +748,10 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
     GT_FOR(li) {
       GTLane& T = t[li];
       if (!T.active || T.depth != 0) continue;
-      if (!ldl_n<6>(T.H, T.dd, T.idd)) T.failed = true;
+      if (!gt_ldl_n<6>(T.H, T.dd, T.idd)) T.failed = true;
 #pragma unroll
       for (int k = 0; k < 6; k++) T.p[k] = -T.g[k];
-      ldl_solve_n<6>(T.H, T.idd, T.p);
+      gt_ldl_solve_n<6>(T.H, T.idd, T.p);
 #pragma unroll
       for (int k = 0; k < 6; k++) GLS(GL_P + 6 * T.b + k) = T.p[k];
     }
@@ -680,7 +769,7 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
 #pragma unroll
           for (int j = 0; j < 6; j++) s -= T.Hpc[6 * j + i] * pp[j];
           T.p[i] = s; }
-        ldl_solve_n<6>(T.H, T.idd, T.p);
+        gt_ldl_solve_n<6>(T.H, T.idd, T.p);
 #pragma unroll
         for (int k = 0; k < 6; k++) GLS(GL_P + 6 * T.b + k) = T.p[k];
       }
@@ -779,7 +868,7 @@ D3IL_GT_SOLVE_ATTR inline unsigned gen_tree_solve(const GenConsts& gc_, const Pu
           const double jp[3] = {rc[3], rc[4], rc[5]};
           double jt[3] = {rc[0] + alpha * jp[0], rc[1] + alpha * jp[1], rc[2] + alpha * jp[2]}, ft[3], Hc[9];
           const double Dn = rc[6], fric = rc[7];
-          cone_eval(jt, Dn, Dn * impr, fric * mu_scale, fric, ft, Hc);
+          gt_cone_eval(jt, Dn, Dn * impr, fric * mu_scale, fric, ft, Hc);
 #pragma unroll
           for (int r = 0; r < 3; r++) { p1 -= ft[r] * jp[r];
 #pragma unroll
@@ -959,7 +1048,7 @@ D3IL_HD unsigned gen_lone_solve(const GenConsts& gc_, const PushScratch sc, int 
         for (int r = 0; r < 3; r++) GRS(base + 22 + r) = jar[r];
       }
       const double Dn = rec[19], fric = rec[20];
-      cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
+      gt_cone_eval(jar, Dn, Dn * impr, fric * mu_scale, fric, force, Hc);
       if (force[0] == 0 && force[1] == 0 && force[2] == 0) continue;
       double w[3], S[9], P[9];
 #pragma unroll
@@ -978,10 +1067,10 @@ D3IL_HD unsigned gen_lone_solve(const GenConsts& gc_, const PushScratch sc, int 
       if (gm <= PUSH_GRAD_TOL) { converged = true; break; }
     }
     double dd[6], idd[6], p[6];
-    if (!ldl_n<6>(H, dd, idd)) failed = true;
+    if (!gt_ldl_n<6>(H, dd, idd)) failed = true;
 #pragma unroll
     for (int k = 0; k < 6; k++) p[k] = -g[k];
-    ldl_solve_n<6>(H, idd, p);
+    gt_ldl_solve_n<6>(H, idd, p);
     double pMp = 0, pMa = 0, gTp = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) { const double mm = k < 3 ? mt : mr; pMp += mm * p[k] * p[k]; pMa += mm * p[k] * (x[k] - (k == 2 ? grav2 : 0.0)); gTp += g[k] * p[k]; }
@@ -1024,7 +1113,7 @@ D3IL_HD unsigned gen_lone_solve(const GenConsts& gc_, const PushScratch sc, int 
         }
         const double jp[3] = {rc[3], rc[4], rc[5]};
         double jt[3] = {rc[0] + alpha * jp[0], rc[1] + alpha * jp[1], rc[2] + alpha * jp[2]}, ft[3], Hc[9];
-        cone_eval(jt, rc[6], rc[6] * impr, rc[7] * mu_scale, rc[7], ft, Hc);
+        gt_cone_eval(jt, rc[6], rc[6] * impr, rc[7] * mu_scale, rc[7], ft, Hc);
 #pragma unroll
         for (int r = 0; r < 3; r++) { p1 -= ft[r] * jp[r];
 #pragma unroll
@@ -1059,3 +1148,6 @@ D3IL_HD unsigned gen_lone_solve(const GenConsts& gc_, const PushScratch sc, int 
 }
 
 }  // namespace d3il
+#if defined(__clang__)
+#pragma clang fp contract(fast)      // (what hipcc compiles the rest of the translation unit with)
+#endif
