@@ -298,6 +298,71 @@ D3IL_NOINLINE inline void jacobi_solve6(const double* A, const double* b, double
   for (int a = 0; a < 6; a++) { double s = 0;
     for (int i = 0; i < 6; i++) s += V[a][i] * y[i]; x[a] = s; }
 }
+// Path 2 of ik_solve6 (exactly one eigenvalue below lo): L, id = LDL^T(A), tr = trace(A).  Returns whether the eigenpair was accepted (x written).
+D3IL_HD bool ik_deflate(const double* A, const double* b, const double* L, const double* id, double tr, double minsv, double* x, double* vwarm) {
+  bool accepted = false;
+  // smallest eigenpair: two inverse-iteration steps starting from b, then Rayleigh-quotient iteration
+  D3IL_DSTAT(1);
+  // start vector: the eigenvector accepted by the previous solve of this environment if there is one (the matrix
+  // changes little between IK iterations), else two inverse-iteration steps starting from b
+  double v[6], w[6], nr = 0;
+  if (vwarm && vwarm[6] != 0.0) {
+    D3IL_DCOUNT(1);
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = vwarm[i];
+  } else {
+    ldl6_solve(L, id, b, w);
+    ldl6_solve(L, id, w, v);
+#pragma unroll
+    for (int i = 0; i < 6; i++) nr += v[i] * v[i];
+    nr = 1.0 / sqrt(nr);
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] *= nr;
+  }
+  double lam = 0, res = 0, vb = 0;
+  for (int it = 0; it < 5; it++) {
+    symv6(A, v, w);
+    lam = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) lam += v[i] * w[i];
+    res = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) res = fmax(res, fabs(w[i] - lam * v[i]));
+    if (res <= 1e-14 * tr || it == 4) break;
+    D3IL_DCOUNT(0);
+    double L2[21], d2[6], id2[6], u[6];
+    int n2;
+    ldl6(A, lam, L2, d2, id2, &n2);
+    ldl6_solve(L2, id2, v, u);
+    nr = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) nr += u[i] * u[i];
+    nr = 1.0 / sqrt(nr);
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = u[i] * nr;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) vb += v[i] * b[i];
+  if (res <= 1e-14 * tr && lam < minsv && lam > 0) {
+    // x = A^-1 (b - (v.b) v) + (v.b)/lo v : the clipped direction is removed BEFORE the solve (no cancellation)
+    double bp[6], xp[6], vx = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) bp[i] = b[i] - vb * v[i];
+    ldl6_solve(L, id, bp, xp);
+#pragma unroll
+    for (int i = 0; i < 6; i++) vx += v[i] * xp[i];
+    double g = vb / minsv - vx;
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = xp[i] + g * v[i];
+    accepted = true;
+    if (vwarm) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) vwarm[i] = v[i];
+      vwarm[6] = 1.0;
+    }
+  }
+  return accepted;
+}
 template <bool FAST>
 D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double maxsv, double* x, double* vwarm = nullptr) {
   bool need_eig = true;
@@ -311,66 +376,7 @@ D3IL_HD void ik_solve6(const double* A, const double* b, double minsv, double ma
       bool ok0 = ldl6(A, 0.0, L, d, id, &dummy);
       if (neg == 0) { ldl6_solve(L, id, b, x); need_eig = !ok0; }
       else if (ok0) {
-        // smallest eigenpair: two inverse-iteration steps starting from b, then Rayleigh-quotient iteration
-        D3IL_DSTAT(1);
-        // start vector: the eigenvector accepted by the previous solve of this environment if there is one (the matrix
-        // changes little between IK iterations), else two inverse-iteration steps starting from b
-        double v[6], w[6], nr = 0;
-        if (vwarm && vwarm[6] != 0.0) {
-          D3IL_DCOUNT(1);
-#pragma unroll
-          for (int i = 0; i < 6; i++) v[i] = vwarm[i];
-        } else {
-          ldl6_solve(L, id, b, w);
-          ldl6_solve(L, id, w, v);
-#pragma unroll
-          for (int i = 0; i < 6; i++) nr += v[i] * v[i];
-          nr = 1.0 / sqrt(nr);
-#pragma unroll
-          for (int i = 0; i < 6; i++) v[i] *= nr;
-        }
-        double lam = 0, res = 0, vb = 0;
-        for (int it = 0; it < 5; it++) {
-          symv6(A, v, w);
-          lam = 0;
-#pragma unroll
-          for (int i = 0; i < 6; i++) lam += v[i] * w[i];
-          res = 0;
-#pragma unroll
-          for (int i = 0; i < 6; i++) res = fmax(res, fabs(w[i] - lam * v[i]));
-          if (res <= 1e-14 * tr || it == 4) break;
-          D3IL_DCOUNT(0);
-          double L2[21], d2[6], id2[6], u[6];
-          int n2;
-          ldl6(A, lam, L2, d2, id2, &n2);
-          ldl6_solve(L2, id2, v, u);
-          nr = 0;
-#pragma unroll
-          for (int i = 0; i < 6; i++) nr += u[i] * u[i];
-          nr = 1.0 / sqrt(nr);
-#pragma unroll
-          for (int i = 0; i < 6; i++) v[i] = u[i] * nr;
-        }
-#pragma unroll
-        for (int i = 0; i < 6; i++) vb += v[i] * b[i];
-        if (res <= 1e-14 * tr && lam < minsv && lam > 0) {
-          // x = A^-1 (b - (v.b) v) + (v.b)/lo v : the clipped direction is removed BEFORE the solve (no cancellation)
-          double bp[6], xp[6], vx = 0;
-#pragma unroll
-          for (int i = 0; i < 6; i++) bp[i] = b[i] - vb * v[i];
-          ldl6_solve(L, id, bp, xp);
-#pragma unroll
-          for (int i = 0; i < 6; i++) vx += v[i] * xp[i];
-          double g = vb / minsv - vx;
-#pragma unroll
-          for (int i = 0; i < 6; i++) x[i] = xp[i] + g * v[i];
-          need_eig = false;
-          if (vwarm) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) vwarm[i] = v[i];
-            vwarm[6] = 1.0;
-          }
-        }
+        need_eig = !ik_deflate(A, b, L, id, tr, minsv, x, vwarm);
       }
     }
   }
