@@ -20,6 +20,9 @@ import torch
 
 MIN_ENVS = 64          # one wavefront of environments: below that a sub-batch only adds launches
 DEFAULT_HW_QUEUES = 4   # what the HIP runtime maps streams onto when GPU_MAX_HW_QUEUES is not set
+MAX_CONCURRENT = 4     # dispatches of different streams the MI355X runs side by side (measured: 8 / 16 / 32 sub-batches of the contact tasks take 2 / 4 / 8 rounds of
+                       # four - Pushing contact regime 7.6 / 18.0 / 27.5 / 46.5 ms per step at S = 4 / 8 / 16 / 32 although all 256 workgroups would fit the chip and
+                       # GPU_MAX_HW_QUEUES was raised; profiles/r05/subbatch_sweep/): more sub-batches than this only add launches
 CUS = 256              # MI355X: the Avoiding kernel's third ("serve") wave pays while the GPU holds at most one workgroup per CU
 
 
@@ -90,6 +93,8 @@ class SubBatchSet:
         S = len(self.parts)
         if S > 1:
             ensure_hw_queues(S)
+        if S > MAX_CONCURRENT:
+            warnings.warn("%d sub-batches: the GPU runs %d dispatches of different streams at a time, the others wait their turn (DESIGN section 19.6)" % (S, MAX_CONCURRENT))
         self.default_stream = torch.cuda.current_stream(self.device)
         self.batches = []
         for i, (off, cnt) in enumerate(self.parts):
