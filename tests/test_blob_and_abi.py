@@ -132,3 +132,20 @@ def test_build_refuses_an_unvalidated_compiler(monkeypatch):
     R.stdout = "HIP version: %s.26015-fc0010cf6a\n" % b.VALIDATED_HIP
     monkeypatch.delenv("D3IL_ALLOW_UNVALIDATED", raising=False)
     assert b.check_compiler().startswith(b.VALIDATED_HIP)
+
+
+def test_tree_solver_header_keeps_expression_level_contraction():
+    """gen_tree.h: the lone-cube solver and the tree solver's one-node path must compile to the same arithmetic (the per-wave choice between them,
+    gen_kernels.h).  That rests on the header being compiled under `fp contract(on)` and handing the translation unit back under
+    `contract(fast)`; the GPU guards are tests/test_gpu_permutation.py and the lane-position test of tests/test_gpu_parity_sorting.py."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "d3il_amd", "csrc", "gen_tree.h")).read()
+    pragmas = re.findall(r"#pragma clang fp contract\((\w+)\)", src)
+    assert pragmas == ["on", "fast"]
+    on, fast = src.index("fp contract(on)"), src.index("fp contract(fast)")
+    for name in ("gen_lone_solve", "gen_tree_solve", "gt_cone_eval", "gt_ldl_n", "gt_ldl_solve_n", "gt_rsqrtd"):      # definitions and calls (not the comments)
+        at = [m.start() for m in re.finditer(r"\b%s\s*[(<]" % name, src)]
+        assert at and all(on < a < fast for a in at), name
+    body = re.sub(r"gt_(cone_eval|ldl_n|ldl_solve_n|rsqrtd)", "", re.sub(r"//[^\n]*", "", src[on:fast]))
+    assert not re.search(r"\b(cone_eval|ldl_n\s*<\s*6\s*>|ldl_solve_n\s*<\s*6\s*>|rsqrtd)\s*\(", body)      # the shared helpers' contract(fast) originals are not called from here
