@@ -281,7 +281,7 @@ POLICY_TEXT = {
 }
 
 
-def _random_ddpm(obs_dim, dev):
+def _random_ddpm(obs_dim, dev, graph=False):
     """BASELINE config 4's policy: the reference's DDPM agent as scripts/sorting_4/ddpm_benchmark.sh configures it (DiffusionMLP obs
     16 -> act 2, hidden 256 x 8 layers, t_dim 8, n_timesteps 4, window 1) with fixed random weights (torch seed 0; no checkpoints
     offline), scaled actions clamped to +-1 = +-0.01 m (the env's action box, pushing.py:203-205)."""
@@ -290,7 +290,8 @@ def _random_ddpm(obs_dim, dev):
     torch.manual_seed(0)
     net = DiffusionMLP(action_dim=2, obs_dim=obs_dim, t_dim=8, hidden_dim=256, num_hidden_layers=8).to(dev)
     sc = Scaler([0.0] * obs_dim, [1.0] * obs_dim, [0.0, 0.0], [0.01, 0.01], y_bounds=[[-1.0, -1.0], [1.0, 1.0]], device=dev)
-    return DDPMPolicy(net, sc, n_timesteps=4, window_size=1)
+    pol = DDPMPolicy(net, sc, n_timesteps=4, window_size=1)
+    return pol.captured() if graph else pol
 
 
 def _random_beso(dev):
@@ -427,10 +428,13 @@ class _Shard:
                 from d3il_amd.agents import RandomResidualMLPPolicy, ScriptedPushPolicy
                 if policy == "mlp":
                     pol = RandomResidualMLPPolicy(input_dim=2 + env.obs.shape[1], device=dev)
+                    if args.policy_graph:
+                        from d3il_amd.policies import CapturedPolicy
+                        pol = CapturedPolicy(pol)
                 elif policy == "scripted_push":
                     pol = ScriptedPushPolicy(task, device=dev)
                 elif policy == "ddpm":
-                    pol = _random_ddpm(2 + env.obs.shape[1], dev)
+                    pol = _random_ddpm(2 + env.obs.shape[1], dev, graph=bool(args.policy_graph))
                 else:
                     raise SystemExit("--policy %s is not available for task %s" % (policy, task))
                 actions[:, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
@@ -517,8 +521,12 @@ def run(args):
         ctx60 = load_stack_contexts()[:args.stack_contexts]     # the first contexts of the reference's 100 test contexts, tiled
     # sub-batches: the rank's environments as S independent sub-batches on S streams (1 = one launch per step over the whole batch)
     S = args.sub_batches if args.sub_batches is not None else DEFAULT_SUB_BATCHES.get(task, 1)
-    if args.sub_batches is None and args.policy in ("ddpm", "beso"):
-        S = 1      # the diffusion policies launch dozens of torch kernels per step and sub-batch: with the round-5 step kernel four sub-batches are host bound (0.45 M against 0.66 M, profiles/r05)
+    if args.policy_graph is None:
+        args.policy_graph = 1 if args.policy == "ddpm" else 0      # (the stand-in MLP is ~25 kernels per step: not host bound, no gain from the capture)
+    if args.sub_batches is None and (args.policy == "beso" or (args.policy == "ddpm" and not args.policy_graph)):
+        S = 1      # the diffusion policies launch hundreds of torch kernels per step and sub-batch: issued one by one, four sub-batches are host bound (DDPM 0.53 M
+                   # against 0.67 M as one batch; captured as one graph per sub-batch - policies.CapturedPolicy - 0.81 M: profiles/r05/policy_graph/).  BESO's
+                   # history window regroups the lanes at every call: not a fixed chain, stays one batch
     if S < 1 or n % S != 0 or n // S < 64:
         S = 1
     args.sub_batches = S
@@ -697,7 +705,7 @@ def run(args):
                                           "tally; Philox counters and context ids by global environment index, so the work is that of one batch): a launch lasts as "
                                           "long as its slowest workgroup and sub-batches do not wait for each other's rare-path tails; --sub-batches 1 = one launch "
                                           "per step" % (n, S, n_launch, S)) if S > 1 else "one launch per step over the whole batch",
-                       "n_substeps": n_sub, "parallelism": "env-shard x%d" % world, "policy": policy,
+                       "n_substeps": n_sub, "parallelism": "env-shard x%d" % world, "policy": policy, "policy_captured_as_graph": bool(args.policy_graph),
                        "preroll_steps_untimed": preroll, "phase_mix": "steady state (staggered episode phases)" if preroll else "fresh reset",
                        "auto_reset": not args.no_auto_reset, "finite": finite, "flagged_envs": flagged,
                        "episodes_finished_all_ranks": int(tb[:, 0].sum()), "episodes_success_all_ranks": int(tb[:, 1].sum()),
@@ -752,6 +760,7 @@ def main():
                     "(default: 4 for avoiding / pushing / sorting / inserting, 1 otherwise; 1 = one launch per step over the whole batch)")
     ap.add_argument("--fuse-tail", type=int, default=1, help="Avoiding, random policy: everything between two step launches (mask, tally, auto-reset, the next action) in one kernel")
     ap.add_argument("--graph-rollout", type=int, default=0, help="Avoiding, random policy, sub-batches on their own streams: the rollout step as one captured HIP graph launch (0: eight runtime calls per step)")
+    ap.add_argument("--policy-graph", type=int, default=None, help="mlp / ddpm policy of the push tasks: the whole predict chain of a sub-batch as one captured HIP graph (policies.CapturedPolicy; default: on for ddpm)")
     ap.add_argument("--lds-pad", type=int, default=None, help="override the LDS bytes requested per workgroup (placement control)")
     args = ap.parse_args()
     # sub-batches run on their own HIP streams; with the runtime's default of four hardware queues two of four streams share a queue (the null stream

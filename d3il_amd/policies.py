@@ -353,6 +353,57 @@ class BCPolicy:
         return self.scaler.inverse_scale_output(torch.clamp(out, self.min_action, self.max_action))
 
 
+class CapturedPolicy:
+    """Any policy whose ``predict_batch`` is a fixed chain of device kernels on a fixed batch shape (no host round trip, no data-dependent shapes: BCPolicy,
+    the stand-in MLP of agents.py, DDPMPolicy with window_size 1) as ONE captured HIP graph: the first call of a batch shape warms the chain up on a side
+    stream and captures it, later calls copy the observation into the graph's static input and replay it on the caller's current stream.  Same kernels, same
+    results; the host issues one launch instead of dozens - which is what bounds several sub-batches on several streams.  Random
+    draws inside the chain (torch.randn on the device) come from the device generator at every replay.  The returned tensor is the graph's static output:
+    consume it before the next call (the rollout loops do)."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self._g, self._g_in, self._g_out = None, None, None
+
+    def reset(self):
+        if hasattr(self.inner, "reset"):
+            self.inner.reset()
+
+    def begin_episodes(self, mask):
+        if hasattr(self.inner, "begin_episodes"):
+            self.inner.begin_episodes(mask)
+
+    def set_rollout_range(self, offset, count):
+        if hasattr(self.inner, "set_rollout_range"):
+            self.inner.set_rollout_range(offset, count)
+
+    def fork(self):
+        """A clone for another sub-batch: the inner policy forked by its own rule, graph and static buffers its own."""
+        from .envs.sub_batch import fork_agent
+        return CapturedPolicy(fork_agent(self.inner))
+
+    @torch.no_grad()
+    def predict_batch(self, obs):
+        if not obs.is_cuda:
+            return self.inner.predict_batch(obs)
+        if self._g is None or self._g_in.shape != obs.shape or self._g_in.dtype != obs.dtype:
+            dev = obs.device
+            self._g_in = obs.clone()
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(dev)      # warm-up outside the capture: library workspaces and lazy initialisation must not happen inside it
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.inner.predict_batch(self._g_in)
+            cur.wait_stream(side)
+            self._g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g):
+                self._g_out = self.inner.predict_batch(self._g_in)
+        self._g_in.copy_(obs)
+        self._g.replay()
+        return self._g_out
+
+
 def cosine_beta_schedule(timesteps, s=0.008):     # agents/models/diffusion/utils.py:31-42 (float64 numpy -> float32)
     import numpy as np
     steps = timesteps + 1
@@ -383,6 +434,12 @@ class DDPMPolicy:
         self.noise_fn = noise_fn or (lambda shape: torch.randn(shape, device=dev))
         self.hist = None
         self.n_envs = n_envs
+
+    def captured(self):
+        """window_size 1: the whole predict chain (input scaling, the T denoising steps with their noise draws - ~60 torch kernels each -, clamp, output scaling)
+        as one captured graph (CapturedPolicy)."""
+        assert self.W <= 1, "a history window regroups the lanes by history length at every call: not a fixed chain"
+        return CapturedPolicy(self)
 
     def load_reference_state_dict(self, sd):
         """``Diffusion.state_dict()`` of the reference: the denoiser sits under ``model.``."""

@@ -109,3 +109,52 @@ def test_sorting_and_pushing_sim_sub_batches_identical_tables():
         for x, y in zip(res[task, 1], res[task, 4]):
             assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), task      # (the entropy of a table without successes is nan in both)
     assert len(np.unique(res["sorting", 1][1])) > 1          # some cubes were delivered: the tables are not trivially equal
+
+
+@pytest.mark.gpu
+def test_captured_policy_equals_the_eager_chain_and_forks_its_buffers():
+    """policies.CapturedPolicy: the predict chain of a batch as one HIP graph - same kernels, same numbers; a fork owns its graph and static buffers."""
+    from d3il_amd.agents import RandomResidualMLPPolicy
+    from d3il_amd.policies import CapturedPolicy, DDPMPolicy, DiffusionMLP, Scaler
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = DiffusionMLP(action_dim=2, obs_dim=22, t_dim=8, hidden_dim=256, num_hidden_layers=8).to(dev)
+    sc = Scaler([0.0] * 22, [1.0] * 22, [0.0, 0.0], [0.01, 0.01], y_bounds=[[-1.0, -1.0], [1.0, 1.0]], device=dev)
+    fixed = torch.randn(512, 2, device=dev)
+    ddpm = DDPMPolicy(net, sc, n_timesteps=4, window_size=1, noise_fn=lambda shape: fixed[:shape[0]])
+    mlp = RandomResidualMLPPolicy(input_dim=22, device=dev)
+    obs = [torch.randn(512, 22, device=dev, dtype=torch.float64) for _ in range(3)]
+    for pol in (ddpm, mlp):
+        cap = CapturedPolicy(pol)
+        for o in obs:
+            want = pol.predict_batch(o).clone()
+            got = cap.predict_batch(o)
+            assert torch.equal(want, got)
+        twin = cap.fork()
+        a = cap.predict_batch(obs[0]).clone()
+        b = twin.predict_batch(obs[1])
+        assert twin._g is not cap._g and twin._g_in.data_ptr() != cap._g_in.data_ptr() and b.data_ptr() != cap._g_out.data_ptr()
+        assert torch.equal(cap._g_out, a)                      # the twin's call did not touch the first one's output
+        assert torch.equal(b, pol.predict_batch(obs[1]))
+    with pytest.raises(AssertionError):
+        DDPMPolicy(net, sc, n_timesteps=4, window_size=4).captured()
+    # default noise: drawn inside the graph, fresh at every replay
+    cap = DDPMPolicy(net, sc, n_timesteps=4, window_size=1).captured()
+    x, y = cap.predict_batch(obs[0]).clone(), cap.predict_batch(obs[0]).clone()
+    assert not torch.equal(x, y) and bool(torch.isfinite(x).all())
+
+
+@pytest.mark.gpu
+def test_sorting_sim_with_a_captured_policy_in_four_sub_batches():
+    from d3il_amd.agents import RandomResidualMLPPolicy
+    from d3il_amd.policies import CapturedPolicy
+    from d3il_amd.simulation.sorting_sim import Sorting_Sim
+    res = []
+    for S, wrap in ((1, False), (4, True)):
+        pol = RandomResidualMLPPolicy(input_dim=2 + 2 + 3 * 4, device="cuda:0")      # desired xy || obs of Sorting-4 (robot xy + 3 per box)
+        sim = Sorting_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=60, n_trajectories_per_context=5, max_steps_per_episode=80, n_sub_batches=S)
+        sim.test_agent(CapturedPolicy(pol) if wrap else pol)
+        r = sim.last_rollout
+        res.append((r["counts"].copy(), r["mode"].cpu().numpy(), r["success"].cpu().numpy()))
+    for x, y in zip(*res):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
