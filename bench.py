@@ -273,7 +273,7 @@ def _isa_mix(task):
 POLICY_TEXT = {
     "random": "random policy",
     "mlp": "ResidualMLP %d->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)",
-    "ddpm": "DDPM policy of BASELINE config 4 (DiffusionMLP %d->256x8->2, t_dim 8, 4 denoising steps, fixed random weights, torch f32)",
+    "ddpm": "DDPM policy of BASELINE config 4 (DiffusionMLP %d->256x8->2, t_dim 8, 4 denoising steps, fixed random weights, f32: the sampling chain as one matrix-core kernel of the library, d3il_ddpm_mlp_f32; D3IL_POLICY_FUSED_DDPM=0 = the torch chain)",
     "beso": "BESO policy of BASELINE config 5 (DiffusionGPT 6 layers x 6 heads x 120, window 5, 16 Euler-ancestral steps, fixed random weights, torch f32)",
     "scripted_push": "scripted pushing policy (every rod drives a cube to its target / bin: the contact regime)",
     "scripted_align": "scripted pushes from inside / outside the box walls (the two behaviour modes of the Aligning task)",
@@ -525,8 +525,8 @@ def run(args):
         args.policy_graph = 1 if args.policy == "ddpm" else 0      # (the stand-in MLP is ~25 kernels per step: not host bound, no gain from the capture)
     if args.sub_batches is None and (args.policy == "beso" or (args.policy == "ddpm" and not args.policy_graph)):
         S = 1      # the diffusion policies launch hundreds of torch kernels per step and sub-batch: issued one by one, four sub-batches are host bound (DDPM 0.53 M
-                   # against 0.67 M as one batch; captured as one graph per sub-batch - policies.CapturedPolicy - 0.81 M: profiles/r05/policy_graph/).  BESO's
-                   # history window regroups the lanes at every call: not a fixed chain, stays one batch
+                   # against 0.67 M as one batch; captured as one graph per sub-batch - policies.CapturedPolicy - 0.81 M: profiles/r05/policy_graph/).  BESO
+                   # (Stacking: the cooperative engine fills the chip with one launch) stays one batch with its own captured sampling loop
     if S < 1 or n % S != 0 or n // S < 64:
         S = 1
     args.sub_batches = S

@@ -476,6 +476,119 @@ __global__ __launch_bounds__(256) void k_linear120_f32(const float* __restrict__
     __syncthreads();
   }
 }
+// The whole sampling chain of the reference's DDPM policy (agents/models/diffusion/gc_diffusion.py:101-216 over diffusion_models.py:20-118 and
+// common/mlp.py:9-46,114-182 as configs/agents/ddpm_agent.yaml + scripts/sorting_4/ddpm_benchmark.sh configure them: DiffusionMLP, hidden 256, 8 hidden layers =
+// 4 pre-activation residual blocks, Mish, t_dim 8, window 1) in ONE kernel, f32 on the matrix cores.  Rows are independent: a workgroup owns 16 rows for all T
+// denoising steps and all layers, its four waves each own FOUR of the 16 output tiles of every layer (wave w: outputs 64 w .. 64 w + 63).
+// D of v_mfma_f32_16x16x4_f32 (lane (g, j): outputs 4 g + r of row j) is a B operand of the next layer when step (t, r) sums the features {16 t + 4 g + r}, which only
+// fixes how the next weight matrix is packed (d3il_amd/policies.py pack_ddpm_weights): [T_out][t][lane (g, i)][r] = W[16 T_out + i][16 t + 4 g + r].  So a layer is: every
+// wave reads the 16 rows' 256 activations (16 float4 per lane) from LDS, runs 4 x 64 MFMAs with its own quarter of the weights streamed from L2 (64 KB per wave
+// and layer, no sharing needed), applies bias / residual / Mish to its four D registers and writes them to the other LDS buffer: one barrier per layer.
+// The first layer (x | time embedding | state = 26 -> 28 inputs, 7 steps per tile) and the output layer (2 of 16 outputs; every wave computes it for the DDPM
+// update of its copy of x) read their small packed matrices from L2.  The time embedding of step i is the same for every row (temb [T][8], evaluated once by the
+// caller); the noise of all T + 1 draws comes as one tensor.
+constexpr int DD_H = 256, DD_TILE_F4 = 16 * 64, DD_LAYER_F4 = 16 * DD_TILE_F4;      // float4 per packed output tile (16 KB), per packed layer
+__device__ __forceinline__ float dd_mish(float x) {      // x tanh(softplus(x)), softplus with torch's threshold 20; tanh(log(1 + n)) = (n^2 + 2 n) / (n^2 + 2 n + 2), n = e^x
+  if (x > 20.f) return x;
+  const float n = expf(x), p = n * (n + 2.f);
+  return x * (p / (p + 2.f));
+}
+// y[q] = (RES ? y[q] : 0) + bias + W m for the wave's four output tiles 4 w + q of one packed 256 x 256 layer (xin: the 16 rows' activations in LDS, B-operand order)
+template <bool RES>
+__device__ __forceinline__ void dd_layer4(const mlp_f4* __restrict__ wl, const float* __restrict__ bias, const mlp_f4* xin, mlp_f4* y, int w, int lane, int g) {
+  mlp_f4 m[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) m[t] = xin[t * 64 + lane];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int To = 4 * w + q;
+    const mlp_f4* wt = wl + (long)To * DD_TILE_F4 + lane;
+    mlp_f4 a[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) a[t] = wt[t * 64];
+    mlp_f4 acc_a = *(const mlp_f4*)(bias + 16 * To + 4 * g), acc_b = mlp_f4{0.f, 0.f, 0.f, 0.f};      // two accumulators: the dependent MFMA chain is half as long
+    if (RES) acc_b = y[q];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][0], m[t][0], acc_a, 0, 0, 0);
+      acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][1], m[t][1], acc_b, 0, 0, 0);
+      acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][2], m[t][2], acc_a, 0, 0, 0);
+      acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][3], m[t][3], acc_b, 0, 0, 0);
+    }
+    y[q] = acc_a + acc_b;
+  }
+}
+__global__ __launch_bounds__(256) void k_ddpm_mlp_f32(const float* __restrict__ state, const float* __restrict__ noise, const float* __restrict__ temb, const float* __restrict__ w_in,
+                                                       const float* __restrict__ b_in, const float* __restrict__ w_blk, const float* __restrict__ b_blk, const float* __restrict__ w_out,
+                                                       const float* __restrict__ b_out, const float* __restrict__ sched, const float* __restrict__ bounds, float* __restrict__ out,
+                                                       long n, int SD, int T, int nblk) {
+  __shared__ mlp_f4 xb[2][DD_TILE_F4];      // the 16 rows' 256 activations, [t][lane] float4 = features 16 t + 4 g + r of row j: written by the layer that produces them, read by the next
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
+  const long row = (long)blockIdx.x * 16 + j;
+  const bool live = row < n;
+  const long rr = live ? row : (n - 1);
+  float st_k[7];      // the lane's share of the input row: feature 4 s + g of [x (2) | time embedding (8) | state (SD)]
+#pragma unroll
+  for (int s2 = 0; s2 < 7; s2++) { const int f = 4 * s2 + g; st_k[s2] = (f >= 10 && f < 10 + SD) ? state[rr * SD + f - 10] : 0.f; }
+  const float lo0 = bounds[0], lo1 = bounds[1], hi0 = bounds[2], hi1 = bounds[3];
+  float x0 = noise[rr * 2], x1 = noise[rr * 2 + 1];
+  const mlp_f4* w_in4 = (const mlp_f4*)w_in;
+  const mlp_f4* w_out4 = (const mlp_f4*)w_out;
+  int buf = 0;
+#pragma clang loop unroll(disable)
+  for (int step = 0; step < T; step++) {
+    const int i = T - 1 - step;
+    float in_k[7];
+#pragma unroll
+    for (int s2 = 0; s2 < 7; s2++) { const int f = 4 * s2 + g; in_k[s2] = f == 0 ? x0 : (f == 1 ? x1 : (f < 10 ? temb[i * 8 + f - 2] : st_k[s2])); }
+    mlp_f4 xo[4];      // the wave's four tiles of the residual stream
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int To = 4 * w + q;
+      mlp_f4 acc = *(const mlp_f4*)(b_in + 16 * To + 4 * g);
+      const mlp_f4 a0 = w_in4[(To * 64 + lane) * 2], a1 = w_in4[(To * 64 + lane) * 2 + 1];
+#pragma unroll
+      for (int s2 = 0; s2 < 7; s2++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s2 < 4 ? a0[s2] : a1[s2 - 4], in_k[s2], acc, 0, 0, 0);
+      xo[q] = acc;
+    }
+#pragma clang loop unroll(disable)
+    for (int b = 0; b < nblk; b++) {      // x + l2(mish(l1(mish(x))))
+      mlp_f4 y[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) xb[buf][(4 * w + q) * 64 + lane] = mlp_f4{dd_mish(xo[q][0]), dd_mish(xo[q][1]), dd_mish(xo[q][2]), dd_mish(xo[q][3])};
+      __syncthreads();
+      dd_layer4<false>((const mlp_f4*)w_blk + (long)(2 * b) * DD_LAYER_F4, b_blk + (2 * b) * DD_H, xb[buf], y, w, lane, g);
+      buf ^= 1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) xb[buf][(4 * w + q) * 64 + lane] = mlp_f4{dd_mish(y[q][0]), dd_mish(y[q][1]), dd_mish(y[q][2]), dd_mish(y[q][3])};
+      __syncthreads();
+      dd_layer4<true>((const mlp_f4*)w_blk + (long)(2 * b + 1) * DD_LAYER_F4, b_blk + (2 * b + 1) * DD_H, xb[buf], xo, w, lane, g);      // the residual rides in the accumulator
+      buf ^= 1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) xb[buf][(4 * w + q) * 64 + lane] = xo[q];
+    __syncthreads();
+    mlp_f4 acc = mlp_f4{0.f, 0.f, 0.f, 0.f}, acc2 = mlp_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const mlp_f4 a4 = w_out4[t * 64 + lane], m4 = xb[buf][t * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], m4[0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], m4[1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], m4[2], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], m4[3], acc2, 0, 0, 0);
+    }
+    buf ^= 1;
+    acc += acc2;
+    // epsilon of row j sits in lane (0, j), registers 0 and 1: every lane group of every wave takes it and does the same update on its copy of x
+    const float e0 = __shfl(acc[0], j) + b_out[0], e1 = __shfl(acc[1], j) + b_out[1];
+    const float sra = sched[i * 5], srm1 = sched[i * 5 + 1], c1 = sched[i * 5 + 2], c2 = sched[i * 5 + 3], sig = sched[i * 5 + 4];
+    const float p0 = fminf(fmaxf(sra * x0 - srm1 * e0, lo0), hi0), p1 = fminf(fmaxf(sra * x1 - srm1 * e1, lo1), hi1);      // clipped x0 prediction
+    const float z0 = noise[((long)(step + 1) * n + rr) * 2], z1 = noise[((long)(step + 1) * n + rr) * 2 + 1];
+    x0 = (c1 * p0 + c2 * x0) + sig * z0;
+    x1 = (c1 * p1 + c2 * x1) + sig * z1;
+  }
+  if (live && w == 0 && g == 0) { out[row * 2] = fminf(fmaxf(x0, lo0), hi0); out[row * 2 + 1] = fminf(fmaxf(x1, lo1), hi1); }
+}
 __global__ __launch_bounds__(256) void k_layernorm_f32(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
                                                        long rows, int C, float eps) {
   const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -1335,6 +1448,20 @@ int d3il_linear120_f32(const float* xin, const float* ln_weight, const float* ln
   if (((uintptr_t)xin | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)resid | (uintptr_t)out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_linear120_f32: pointers must be 16-byte aligned");
   if (rows == 0) return D3IL_OK;
   hipLaunchKernelGGL(k_linear120_f32, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, xin, w_packed, bias, resid, out, rows, N, ln_weight, ln_bias, ln_eps);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_ddpm_mlp_f32(const float* state, const float* noise, const float* temb, const float* w_in, const float* b_in, const float* w_blocks, const float* b_blocks,
+                      const float* w_out, const float* b_out, const float* sched, const float* bounds, float* out, long rows, int state_dim, int n_timesteps, int hidden,
+                      int n_blocks, void* stream) {
+  if (!state || !noise || !temb || !w_in || !b_in || !w_blocks || !b_blocks || !w_out || !b_out || !sched || !bounds || !out) return fail(D3IL_EINVAL, "d3il_ddpm_mlp_f32: null argument");
+  if (hidden != DD_H) return fail(D3IL_EUNSUPPORTED, "d3il_ddpm_mlp_f32: built for hidden 256 (the DiffusionMLP of the DDPM configs)");
+  if (state_dim < 1 || state_dim > 18) return fail(D3IL_EUNSUPPORTED, "d3il_ddpm_mlp_f32: action 2 + time embedding 8 + state must fit 28 inputs (state_dim <= 18)");
+  if (n_timesteps < 1 || n_blocks < 0 || rows < 0) return fail(D3IL_EINVAL, "d3il_ddpm_mlp_f32: bad counts");
+  if (((uintptr_t)w_in | (uintptr_t)b_in | (uintptr_t)w_blocks | (uintptr_t)b_blocks | (uintptr_t)w_out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_ddpm_mlp_f32: weights and biases must be 16-byte aligned");
+  if (rows == 0) return D3IL_OK;
+  hipLaunchKernelGGL(k_ddpm_mlp_f32, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, state, noise, temb, w_in, b_in, w_blocks, b_blocks, w_out, b_out, sched, bounds, out,
+                     rows, state_dim, n_timesteps, n_blocks);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }

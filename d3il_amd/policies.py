@@ -353,6 +353,31 @@ class BCPolicy:
         return self.scaler.inverse_scale_output(torch.clamp(out, self.min_action, self.max_action))
 
 
+def pack_ddpm_weights(model: "DiffusionMLP") -> dict:
+    """DiffusionMLP (hidden 256, action 2, t_dim 8) in the operand order of k_ddpm_mlp_f32: lane (g, i) = 16 g + i of a wave holds, for output tile T_out and
+    input group t, the four weights W[16 T_out + i][16 t + 4 g + r] (r = 0..3) - the D registers of one layer are the B operands of the next."""
+    L = model.layers.layers
+    lin_in, blocks, lin_out = L[0], list(L[1:-1]), L[-1]
+    dev = lin_in.weight.device
+    ar = lambda k: torch.arange(k, device=dev)
+    To, t, g, i, r = ar(16)[:, None, None, None, None], ar(16)[None, :, None, None, None], ar(4)[None, None, :, None, None], ar(16)[None, None, None, :, None], ar(4)[None, None, None, None, :]
+    pack = lambda W: W[16 * To + i, 16 * t + 4 * g + r].reshape(16, 16, 64, 4)
+    wi = torch.zeros(256, 32, device=dev)
+    wi[:, :lin_in.in_features] = lin_in.weight
+    s8 = ar(8)[None, None, None, :]
+    w_in = wi[16 * ar(16)[:, None, None, None] + ar(16)[None, None, :, None], 4 * s8 + ar(4)[None, :, None, None]].reshape(16, 64, 8)
+    wo = torch.zeros(16, 256, device=dev)
+    wo[:2] = lin_out.weight
+    w_out = wo[i[0], 16 * t[0] + 4 * g[0] + r[0]].reshape(16, 64, 4)
+    if blocks:
+        w_blk = torch.stack([pack(l.weight) for b in blocks for l in (b.l1, b.l2)])
+        b_blk = torch.stack([l.bias for b in blocks for l in (b.l1, b.l2)])
+    else:
+        w_blk, b_blk = torch.zeros(1, 16, 16, 64, 4, device=dev), torch.zeros(1, 256, device=dev)
+    f = lambda x: x.detach().to(torch.float32).contiguous()
+    return {"w_in": f(w_in), "b_in": f(lin_in.bias), "w_blk": f(w_blk), "b_blk": f(b_blk), "w_out": f(w_out), "b_out": f(lin_out.bias), "n_blocks": len(blocks)}
+
+
 class CapturedPolicy:
     """Any policy whose ``predict_batch`` is a fixed chain of device kernels on a fixed batch shape (no host round trip, no data-dependent shapes: BCPolicy,
     the stand-in MLP of agents.py, DDPMPolicy with window_size 1) as ONE captured HIP graph: the first call of a batch shape warms the chain up on a side
@@ -431,9 +456,53 @@ class DDPMPolicy:
         self.post_logvar = torch.log(torch.clamp(post_var, min=1e-20))
         self.coef1, self.coef2 = betas * torch.sqrt(ac_prev) / (1.0 - ac), (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac)
         self.min_action, self.max_action = scaler.y_bounds[0], scaler.y_bounds[1]
+        self._custom_noise = noise_fn is not None
         self.noise_fn = noise_fn or (lambda shape: torch.randn(shape, device=dev))
         self.hist = None
         self.n_envs = n_envs
+
+    # ---- the whole chain in one kernel of the rollout library (csrc/rollout.hip k_ddpm_mlp_f32)
+    def fused_ok(self):
+        m = self.model
+        L = m.layers.layers
+        return (self.W <= 1 and isinstance(m, DiffusionMLP) and L[0].weight.is_cuda and L[0].weight.dtype == torch.float32 and L[0].out_features == 256 and L[-1].out_features == 2
+                and m.temp_layers[-1].out_features == 8 and 1 <= L[0].in_features - 10 <= 18 and all(isinstance(b, _ResBlock) for b in L[1:-1])
+                and os.environ.get("D3IL_POLICY_FUSED_DDPM", "1") == "1")
+
+    def ensure_packed(self):
+        """The denoiser's weights in the tile order of the kernel, the time embeddings of the T steps and the schedule table, in persistent device buffers
+        refreshed whenever a parameter has changed (tensor version counters) - e.g. after the EMA swap of a rollout."""
+        params = list(self.model.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if getattr(self, "_pack_key", None) == key:
+            return
+        L = self.model.layers.layers
+        dev = L[0].weight.device
+        with torch.no_grad():
+            self._fw = pack_ddpm_weights(self.model)
+            self._temb = self.model.temp_layers(torch.arange(self.T, device=dev)).to(torch.float32).contiguous()
+            sig = (0.5 * self.post_logvar).exp() * torch.cat((torch.zeros(1, device=dev), torch.ones(self.T - 1, device=dev)))
+            self._sched = torch.stack((self.sqrt_recip_ac, self.sqrt_recipm1_ac, self.coef1, self.coef2, sig), dim=1).to(torch.float32).contiguous()
+            self._bounds = torch.cat((self.min_action.reshape(-1), self.max_action.reshape(-1))).to(torch.float32).contiguous()
+        self._pack_key = key
+
+    def _sample_fused(self, state):
+        from . import capi
+        lib = capi.load()
+        n, sd = state.shape
+        if not torch.cuda.is_current_stream_capturing():
+            self.ensure_packed()
+        else:
+            assert getattr(self, "_pack_key", None) is not None, "a captured graph replays the packed weight buffers: call ensure_packed() before capturing"
+        shape = (n, 2)
+        noise = torch.stack([self.noise_fn(shape) for _ in range(self.T + 1)]).to(torch.float32).contiguous() if self._custom_noise else torch.randn((self.T + 1, n, 2), device=self.device)
+        out = torch.empty(n, 2, dtype=torch.float32, device=self.device)
+        w = self._fw
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        state = state.contiguous()
+        capi.check(lib.d3il_ddpm_mlp_f32(state.data_ptr(), noise.data_ptr(), self._temb.data_ptr(), w["w_in"].data_ptr(), w["b_in"].data_ptr(), w["w_blk"].data_ptr(), w["b_blk"].data_ptr(),
+                                         w["w_out"].data_ptr(), w["b_out"].data_ptr(), self._sched.data_ptr(), self._bounds.data_ptr(), out.data_ptr(), n, sd, self.T, 256, w["n_blocks"], st))
+        return out
 
     def captured(self):
         """window_size 1: the whole predict chain (input scaling, the T denoising steps with their noise draws - ~60 torch kernels each -, clamp, output scaling)
@@ -475,6 +544,8 @@ class DDPMPolicy:
     def predict_batch(self, obs):
         s = self.scaler.scale_input(obs.to(device=self.device, dtype=torch.float32))
         if self.W <= 1:
+            if s.is_cuda and s.dim() == 2 and self.fused_ok():
+                return self.scaler.inverse_scale_output(self._sample_fused(s))
             return self.scaler.inverse_scale_output(self._sample(s))
         if self.hist is None:
             self.hist = _History(s.shape[0], self.W, s.shape[1], self.device)

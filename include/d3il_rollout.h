@@ -188,6 +188,17 @@ int d3il_mlp_ln_gelu_residual_f32(const float* h, const float* ln_weight, const 
 int d3il_linear120_f32(const float* xin, const float* ln_weight, const float* ln_bias, float ln_eps, const float* w_packed, const float* bias, const float* resid, float* out,
                        long rows, int N, void* stream);
 
+/* The whole sampling chain of the reference's DDPM policy in one launch (agents/models/diffusion/gc_diffusion.py:101-216: epsilon prediction, clipped x0, posterior
+ * mean, n_timesteps ancestral steps, final clamp; the denoiser = DiffusionMLPNetwork, diffusion_models.py:20-118 over ResidualMLPNetwork, common/mlp.py:114-182: Linear,
+ * n_blocks pre-activation residual blocks with Mish, Linear; window 1), f32 on the matrix cores; rows are independent.  All device pointers, f32:
+ *   state [rows][state_dim] (scaled observation), noise [n_timesteps + 1][rows][2] (draw 0 = x_T, draw 1 + k = the k-th step's noise), temb [n_timesteps][8] (the time
+ *   embedding of step i, row i), sched [n_timesteps][5] = sqrt(1 / acp), sqrt(1 / acp - 1), posterior mean coefficients 1 and 2, sigma (0 for step 0), bounds = min[2] max[2],
+ *   out [rows][2] (scaled action); weights in the kernel's tile order (d3il_amd/policies.py pack_ddpm_weights): w_in [16][64][8], w_blocks [2 n_blocks][16][16][64][4],
+ *   w_out [16][64][4]; b_in [256], b_blocks [2 n_blocks][256], b_out [2].  Built for hidden 256, action 2, t_dim 8, state_dim <= 18 (D3IL_EUNSUPPORTED otherwise). */
+int d3il_ddpm_mlp_f32(const float* state, const float* noise, const float* temb, const float* w_in, const float* b_in, const float* w_blocks, const float* b_blocks,
+                      const float* w_out, const float* b_out, const float* sched, const float* bounds, float* out, long rows, int state_dim, int n_timesteps, int hidden,
+                      int n_blocks, void* stream);
+
 /* Per-context episode tally, filled by d3il_auto_reset before it resets: table i64 [n_ctx][D3IL_TALLY_ROW] (caller-owned device
  * memory, caller zeroes it), row ctx_id[env] (device i32[n_envs]; NULL = row 0) += {episodes, successes, successes by mode code}
  * with the mode code = Avoiding: 9-bit mode encoding; Pushing: info['mode'] + 1; Sorting: np.packbits code.  These are the
