@@ -496,26 +496,28 @@ __device__ __forceinline__ float dd_mish(float x) {      // x tanh(softplus(x)),
 // y[q] = (RES ? y[q] : 0) + bias + W m for the wave's four output tiles 4 w + q of one packed 256 x 256 layer (xin: the 16 rows' activations in LDS, B-operand order)
 template <bool RES>
 __device__ __forceinline__ void dd_layer4(const mlp_f4* __restrict__ wl, const float* __restrict__ bias, const mlp_f4* xin, mlp_f4* y, int w, int lane, int g) {
-  mlp_f4 m[16];
+  mlp_f4 m[16], a[2][16];      // the weights of tile q + 1 are on their way from L2 while tile q is multiplied
+  const mlp_f4* wt = wl + (long)(4 * w) * DD_TILE_F4 + lane;
+#pragma unroll
+  for (int t = 0; t < 16; t++) a[0][t] = wt[t * 64];
 #pragma unroll
   for (int t = 0; t < 16; t++) m[t] = xin[t * 64 + lane];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int To = 4 * w + q;
-    const mlp_f4* wt = wl + (long)To * DD_TILE_F4 + lane;
-    mlp_f4 a[16];
+    if (q + 1 < 4) {
 #pragma unroll
-    for (int t = 0; t < 16; t++) a[t] = wt[t * 64];
-    mlp_f4 acc_a = *(const mlp_f4*)(bias + 16 * To + 4 * g), acc_b = mlp_f4{0.f, 0.f, 0.f, 0.f};      // two accumulators: the dependent MFMA chain is half as long
-    if (RES) acc_b = y[q];
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][0], m[t][0], acc_a, 0, 0, 0);
-      acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][1], m[t][1], acc_b, 0, 0, 0);
-      acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][2], m[t][2], acc_a, 0, 0, 0);
-      acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][3], m[t][3], acc_b, 0, 0, 0);
+      for (int t = 0; t < 16; t++) a[(q + 1) & 1][t] = wt[(q + 1) * DD_TILE_F4 + t * 64];
     }
-    y[q] = acc_a + acc_b;
+    mlp_f4 acc[4];      // four accumulators: no MFMA waits for the one before it
+    acc[0] = *(const mlp_f4*)(bias + 16 * To + 4 * g);
+    acc[1] = RES ? y[q] : mlp_f4{0.f, 0.f, 0.f, 0.f};
+    acc[2] = mlp_f4{0.f, 0.f, 0.f, 0.f}; acc[3] = mlp_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 16; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][t][r], m[t][r], acc[r], 0, 0, 0);
+    y[q] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   }
 }
 __global__ __launch_bounds__(256) void k_ddpm_mlp_f32(const float* __restrict__ state, const float* __restrict__ noise, const float* __restrict__ temb, const float* __restrict__ w_in,
