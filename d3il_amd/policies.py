@@ -424,6 +424,8 @@ class CapturedPolicy:
             self._g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g):
                 self._g_out = self.inner.predict_batch(self._g_in)
+        if hasattr(self.inner, "ensure_packed"):
+            self.inner.ensure_packed()      # packed weight buffers of a fused policy follow the parameters (in place) - e.g. after the EMA swap of a rollout
         self._g_in.copy_(obs)
         self._g.replay()
         return self._g_out
@@ -479,11 +481,19 @@ class DDPMPolicy:
         L = self.model.layers.layers
         dev = L[0].weight.device
         with torch.no_grad():
-            self._fw = pack_ddpm_weights(self.model)
-            self._temb = self.model.temp_layers(torch.arange(self.T, device=dev)).to(torch.float32).contiguous()
+            fw = pack_ddpm_weights(self.model)
+            fw["temb"] = self.model.temp_layers(torch.arange(self.T, device=dev)).to(torch.float32).contiguous()
             sig = (0.5 * self.post_logvar).exp() * torch.cat((torch.zeros(1, device=dev), torch.ones(self.T - 1, device=dev)))
-            self._sched = torch.stack((self.sqrt_recip_ac, self.sqrt_recipm1_ac, self.coef1, self.coef2, sig), dim=1).to(torch.float32).contiguous()
-            self._bounds = torch.cat((self.min_action.reshape(-1), self.max_action.reshape(-1))).to(torch.float32).contiguous()
+            fw["sched"] = torch.stack((self.sqrt_recip_ac, self.sqrt_recipm1_ac, self.coef1, self.coef2, sig), dim=1).to(torch.float32).contiguous()
+            fw["bounds"] = torch.cat((self.min_action.reshape(-1), self.max_action.reshape(-1))).to(torch.float32).contiguous()
+            old = getattr(self, "_fw", None)
+            if old is not None and all(torch.is_tensor(v) == torch.is_tensor(old.get(k)) and (not torch.is_tensor(v) or v.shape == old[k].shape) for k, v in fw.items()):
+                for k, v in fw.items():      # in place: the addresses never change, a captured graph keeps reading the current weights
+                    if torch.is_tensor(v):
+                        old[k].copy_(v)
+            else:
+                self._fw = fw
+        self._temb, self._sched, self._bounds = self._fw["temb"], self._fw["sched"], self._fw["bounds"]
         self._pack_key = key
 
     def _sample_fused(self, state):

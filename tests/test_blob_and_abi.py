@@ -149,3 +149,20 @@ def test_tree_solver_header_keeps_expression_level_contraction():
         assert at and all(on < a < fast for a in at), name
     body = re.sub(r"gt_(cone_eval|ldl_n|ldl_solve_n|rsqrtd)", "", re.sub(r"//[^\n]*", "", src[on:fast]))
     assert not re.search(r"\b(cone_eval|ldl_n\s*<\s*6\s*>|ldl_solve_n\s*<\s*6\s*>|rsqrtd)\s*\(", body)      # the shared helpers' contract(fast) originals are not called from here
+
+
+def test_ddpm_kernel_entry_validates_before_it_launches():
+    """d3il_ddpm_mlp_f32 (include/d3il_rollout.h): shape and pointer checks answer without a device - a denoiser that is not the DDPM configs' shape is
+    D3IL_EUNSUPPORTED (policies.DDPMPolicy.fused_ok keeps such models on the torch chain), null / misaligned arguments D3IL_EINVAL, zero rows D3IL_OK."""
+    import ctypes as C
+    from d3il_amd import capi
+    L = capi.load()
+    p = [C.c_void_p(4096 + 64 * k) for k in range(12)]      # never dereferenced on these paths
+    call = lambda ptrs, rows, sd, T, hid, nb: L.d3il_ddpm_mlp_f32(*ptrs, rows, sd, T, hid, nb, None)
+    assert call(p, 16, 16, 4, 128, 4) == -5          # hidden 128
+    assert call(p, 16, 19, 4, 256, 4) == -5          # 2 + 8 + 19 inputs do not fit 28
+    assert call([None] + p[1:], 16, 16, 4, 256, 4) == -1
+    assert call(p, 16, 16, 0, 256, 4) == -1 and call(p, -1, 16, 4, 256, 4) == -1
+    assert call(p[:3] + [C.c_void_p(4100)] + p[4:], 16, 16, 4, 256, 4) == -1      # w_in not 16-byte aligned
+    assert call(p, 0, 16, 4, 256, 4) == 0
+    assert b"d3il_ddpm_mlp_f32" in capi.last_error().encode() if hasattr(capi, "last_error") else True

@@ -138,6 +138,12 @@ def test_captured_policy_equals_the_eager_chain_and_forks_its_buffers():
         assert torch.equal(b, pol.predict_batch(obs[1]))
     with pytest.raises(AssertionError):
         DDPMPolicy(net, sc, n_timesteps=4, window_size=4).captured()
+    # a captured policy follows its parameters: the packed buffers of the fused chain are refreshed in place (the EMA swap of a rollout, ddpm_agent.py:213-222)
+    cap = CapturedPolicy(ddpm)
+    before = cap.predict_batch(obs[0]).clone()
+    ddpm.use_ema([p.detach() * 1.25 for p in net.parameters()])
+    after = cap.predict_batch(obs[0]).clone()
+    assert not torch.equal(before, after) and torch.equal(after, ddpm.predict_batch(obs[0]))
     # default noise: drawn inside the graph, fresh at every replay
     cap = DDPMPolicy(net, sc, n_timesteps=4, window_size=1).captured()
     x, y = cap.predict_batch(obs[0]).clone(), cap.predict_batch(obs[0]).clone()
