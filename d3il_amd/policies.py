@@ -514,6 +514,15 @@ class DDPMPolicy:
                                          w["w_out"].data_ptr(), w["b_out"].data_ptr(), self._sched.data_ptr(), self._bounds.data_ptr(), out.data_ptr(), n, sd, self.T, 256, w["n_blocks"], st))
         return out
 
+    def fork(self):
+        """A clone for another sub-batch (envs/sub_batch.fork_agent): network, scaler and schedule shared, observation history and the packed buffers of the
+        fused chain its own (packed again at its first call)."""
+        import copy
+        c = copy.copy(self)
+        c.hist = copy.deepcopy(self.hist)
+        c._fw, c._pack_key = None, None
+        return c
+
     def captured(self):
         """window_size 1: the whole predict chain (input scaling, the T denoising steps with their noise draws - ~60 torch kernels each -, clamp, output scaling)
         as one captured graph (CapturedPolicy)."""

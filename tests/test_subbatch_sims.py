@@ -199,3 +199,25 @@ def test_fused_ddpm_chain_matches_the_torch_chain(n, obs_dim, layers):
     assert float(want.abs().max()) > 0.05 and float((want.abs() < 1.0).float().mean()) > 0.3      # the comparison is not one of clamped values only
     pol.noise_fn.k = 0
     assert torch.equal(pol.predict_batch(obs), sc.inverse_scale_output(got))                     # predict_batch takes the fused path
+
+
+@pytest.mark.gpu
+def test_sorting_sim_with_the_fused_ddpm_policy_in_four_sub_batches():
+    """BASELINE config 4 through the product classes: Sorting_Sim, four sub-batches, the DDPM policy (fused sampling chain, captured per sub-batch; fresh noise at
+    every call, so the tables are not comparable between runs - what is asserted: every rollout ran to its end, no solver flag, the forks own their buffers)."""
+    from d3il_amd.policies import DDPMPolicy, DiffusionMLP, Scaler
+    from d3il_amd.simulation.sorting_sim import Sorting_Sim
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = DiffusionMLP(action_dim=2, obs_dim=16, t_dim=8, hidden_dim=256, num_hidden_layers=8).to(dev)
+    sc = Scaler([0.0] * 16, [1.0] * 16, [0.0, 0.0], [0.01, 0.01], y_bounds=[[-1.0, -1.0], [1.0, 1.0]], device=dev)
+    pol = DDPMPolicy(net, sc, n_timesteps=4, window_size=1)
+    assert pol.fused_ok()
+    twin = pol.fork()
+    o = torch.zeros(64, 16, device=dev, dtype=torch.float64)
+    pol.predict_batch(o); twin.predict_batch(o)
+    assert twin._fw["w_blk"].data_ptr() != pol._fw["w_blk"].data_ptr() and torch.equal(twin._fw["w_blk"], pol._fw["w_blk"])
+    sim = Sorting_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=60, n_trajectories_per_context=5, max_steps_per_episode=60, n_sub_batches=4)
+    sim.test_agent(pol.captured())
+    r = sim.last_rollout
+    assert int(r["mode_hist"].sum()) == 300 and r["mode"].shape[0] == 300 and not bool((r["flags"] & ((1 << 16) | (1 << 18))).any())
