@@ -479,15 +479,16 @@ __global__ __launch_bounds__(256) void k_linear120_f32(const float* __restrict__
 // The whole sampling chain of the reference's DDPM policy (agents/models/diffusion/gc_diffusion.py:101-216 over diffusion_models.py:20-118 and
 // common/mlp.py:9-46,114-182 as configs/agents/ddpm_agent.yaml + scripts/sorting_4/ddpm_benchmark.sh configure them: DiffusionMLP, hidden 256, 8 hidden layers =
 // 4 pre-activation residual blocks, Mish, t_dim 8, window 1) in ONE kernel, f32 on the matrix cores.  Rows are independent: a workgroup owns 16 rows for all T
-// denoising steps and all layers, its four waves each own FOUR of the 16 output tiles of every layer (wave w: outputs 64 w .. 64 w + 63).
+// denoising steps and all layers, its DD_NW waves each own DD_TPW of the 16 output tiles of every layer (wave w: outputs 16 DD_TPW w .. 16 DD_TPW (w + 1) - 1).
 // D of v_mfma_f32_16x16x4_f32 (lane (g, j): outputs 4 g + r of row j) is a B operand of the next layer when step (t, r) sums the features {16 t + 4 g + r}, which only
 // fixes how the next weight matrix is packed (d3il_amd/policies.py pack_ddpm_weights): [T_out][t][lane (g, i)][r] = W[16 T_out + i][16 t + 4 g + r].  So a layer is: every
-// wave reads the 16 rows' 256 activations (16 float4 per lane) from LDS, runs 4 x 64 MFMAs with its own quarter of the weights streamed from L2 (64 KB per wave
-// and layer, no sharing needed), applies bias / residual / Mish to its four D registers and writes them to the other LDS buffer: one barrier per layer.
+// wave reads the 16 rows' 256 activations (16 float4 per lane) from LDS, runs DD_TPW x 64 MFMAs with its own share of the weights streamed from L2 (16 KB per tile,
+// no sharing needed), applies bias / residual / Mish to its D registers and writes them to the other LDS buffer: one barrier per layer.
 // The first layer (x | time embedding | state = 26 -> 28 inputs, 7 steps per tile) and the output layer (2 of 16 outputs; every wave computes it for the DDPM
 // update of its copy of x) read their small packed matrices from L2.  The time embedding of step i is the same for every row (temb [T][8], evaluated once by the
 // caller); the noise of all T + 1 draws comes as one tensor.
 constexpr int DD_H = 256, DD_TILE_F4 = 16 * 64, DD_LAYER_F4 = 16 * DD_TILE_F4;      // float4 per packed output tile (16 KB), per packed layer
+constexpr int DD_NW = 8, DD_TPW = 16 / DD_NW;      // waves per workgroup (16 rows), output tiles per wave: eight waves of two tiles - two waves per SIMD hide each other's weight loads
 __device__ __forceinline__ float dd_mish(float x) {      // x tanh(softplus(x)), softplus with torch's threshold 20; tanh(log(1 + n)) = (n^2 + 2 n) / (n^2 + 2 n + 2), n = e^x
   if (x > 20.f) return x;
   const float n = expf(x), p = n * (n + 2.f);
@@ -497,15 +498,15 @@ __device__ __forceinline__ float dd_mish(float x) {      // x tanh(softplus(x)),
 template <bool RES>
 __device__ __forceinline__ void dd_layer4(const mlp_f4* __restrict__ wl, const float* __restrict__ bias, const mlp_f4* xin, mlp_f4* y, int w, int lane, int g) {
   mlp_f4 m[16], a[2][16];      // the weights of tile q + 1 are on their way from L2 while tile q is multiplied
-  const mlp_f4* wt = wl + (long)(4 * w) * DD_TILE_F4 + lane;
+  const mlp_f4* wt = wl + (long)(DD_TPW * w) * DD_TILE_F4 + lane;
 #pragma unroll
   for (int t = 0; t < 16; t++) a[0][t] = wt[t * 64];
 #pragma unroll
   for (int t = 0; t < 16; t++) m[t] = xin[t * 64 + lane];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int To = 4 * w + q;
-    if (q + 1 < 4) {
+  for (int q = 0; q < DD_TPW; q++) {
+    const int To = DD_TPW * w + q;
+    if (q + 1 < DD_TPW) {
 #pragma unroll
       for (int t = 0; t < 16; t++) a[(q + 1) & 1][t] = wt[(q + 1) * DD_TILE_F4 + t * 64];
     }
@@ -520,7 +521,7 @@ __device__ __forceinline__ void dd_layer4(const mlp_f4* __restrict__ wl, const f
     y[q] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   }
 }
-__global__ __launch_bounds__(256) void k_ddpm_mlp_f32(const float* __restrict__ state, const float* __restrict__ noise, const float* __restrict__ temb, const float* __restrict__ w_in,
+__global__ __launch_bounds__(64 * DD_NW) void k_ddpm_mlp_f32(const float* __restrict__ state, const float* __restrict__ noise, const float* __restrict__ temb, const float* __restrict__ w_in,
                                                        const float* __restrict__ b_in, const float* __restrict__ w_blk, const float* __restrict__ b_blk, const float* __restrict__ w_out,
                                                        const float* __restrict__ b_out, const float* __restrict__ sched, const float* __restrict__ bounds, float* __restrict__ out,
                                                        long n, int SD, int T, int nblk) {
@@ -543,10 +544,10 @@ __global__ __launch_bounds__(256) void k_ddpm_mlp_f32(const float* __restrict__ 
     float in_k[7];
 #pragma unroll
     for (int s2 = 0; s2 < 7; s2++) { const int f = 4 * s2 + g; in_k[s2] = f == 0 ? x0 : (f == 1 ? x1 : (f < 10 ? temb[i * 8 + f - 2] : st_k[s2])); }
-    mlp_f4 xo[4];      // the wave's four tiles of the residual stream
+    mlp_f4 xo[DD_TPW];      // the wave's tiles of the residual stream
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int To = 4 * w + q;
+    for (int q = 0; q < DD_TPW; q++) {
+      const int To = DD_TPW * w + q;
       mlp_f4 acc = *(const mlp_f4*)(b_in + 16 * To + 4 * g);
       const mlp_f4 a0 = w_in4[(To * 64 + lane) * 2], a1 = w_in4[(To * 64 + lane) * 2 + 1];
 #pragma unroll
@@ -555,20 +556,20 @@ __global__ __launch_bounds__(256) void k_ddpm_mlp_f32(const float* __restrict__ 
     }
 #pragma clang loop unroll(disable)
     for (int b = 0; b < nblk; b++) {      // x + l2(mish(l1(mish(x))))
-      mlp_f4 y[4];
+      mlp_f4 y[DD_TPW];
 #pragma unroll
-      for (int q = 0; q < 4; q++) xb[buf][(4 * w + q) * 64 + lane] = mlp_f4{dd_mish(xo[q][0]), dd_mish(xo[q][1]), dd_mish(xo[q][2]), dd_mish(xo[q][3])};
+      for (int q = 0; q < DD_TPW; q++) xb[buf][(DD_TPW * w + q) * 64 + lane] = mlp_f4{dd_mish(xo[q][0]), dd_mish(xo[q][1]), dd_mish(xo[q][2]), dd_mish(xo[q][3])};
       __syncthreads();
       dd_layer4<false>((const mlp_f4*)w_blk + (long)(2 * b) * DD_LAYER_F4, b_blk + (2 * b) * DD_H, xb[buf], y, w, lane, g);
       buf ^= 1;
 #pragma unroll
-      for (int q = 0; q < 4; q++) xb[buf][(4 * w + q) * 64 + lane] = mlp_f4{dd_mish(y[q][0]), dd_mish(y[q][1]), dd_mish(y[q][2]), dd_mish(y[q][3])};
+      for (int q = 0; q < DD_TPW; q++) xb[buf][(DD_TPW * w + q) * 64 + lane] = mlp_f4{dd_mish(y[q][0]), dd_mish(y[q][1]), dd_mish(y[q][2]), dd_mish(y[q][3])};
       __syncthreads();
       dd_layer4<true>((const mlp_f4*)w_blk + (long)(2 * b + 1) * DD_LAYER_F4, b_blk + (2 * b + 1) * DD_H, xb[buf], xo, w, lane, g);      // the residual rides in the accumulator
       buf ^= 1;
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) xb[buf][(4 * w + q) * 64 + lane] = xo[q];
+    for (int q = 0; q < DD_TPW; q++) xb[buf][(DD_TPW * w + q) * 64 + lane] = xo[q];
     __syncthreads();
     mlp_f4 acc = mlp_f4{0.f, 0.f, 0.f, 0.f}, acc2 = mlp_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1462,7 +1463,7 @@ int d3il_ddpm_mlp_f32(const float* state, const float* noise, const float* temb,
   if (n_timesteps < 1 || n_blocks < 0 || rows < 0) return fail(D3IL_EINVAL, "d3il_ddpm_mlp_f32: bad counts");
   if (((uintptr_t)w_in | (uintptr_t)b_in | (uintptr_t)w_blocks | (uintptr_t)b_blocks | (uintptr_t)w_out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_ddpm_mlp_f32: weights and biases must be 16-byte aligned");
   if (rows == 0) return D3IL_OK;
-  hipLaunchKernelGGL(k_ddpm_mlp_f32, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, state, noise, temb, w_in, b_in, w_blocks, b_blocks, w_out, b_out, sched, bounds, out,
+  hipLaunchKernelGGL(k_ddpm_mlp_f32, dim3((unsigned)((rows + 15) / 16)), dim3(64 * DD_NW), 0, (hipStream_t)stream, state, noise, temb, w_in, b_in, w_blocks, b_blocks, w_out, b_out, sched, bounds, out,
                      rows, state_dim, n_timesteps, n_blocks);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
