@@ -306,6 +306,35 @@ def _random_beso(dev):
     return BESOPolicy(net, sc, window_size=5, num_sampling_steps=16, sigma_min=0.01, sigma_max=1.0, use_graph=os.environ.get("D3IL_POLICY_GRAPH", "1") == "1")
 
 
+def _ddpm_policy_roofline(pol, n_rows, dev):
+    """Config 4's policy kernel (d3il_ddpm_mlp_f32): one predict call of a sub-batch's rows, event-timed on the current stream after the
+    benchmark loop (alone on the GPU); algorithmic flops of the denoiser (4 steps x (26 x 256 + 8 x 256 x 256 + 256 x 2) multiply-adds per row) against the
+    dense f32 MFMA peak."""
+    import torch
+    F32_MFMA_PEAK_TFLOPS = 157.3
+    inner = getattr(pol, "inner", pol)
+    if not (hasattr(inner, "fused_ok") and inner.fused_ok()):
+        return None
+    sd = inner.model.layers.layers[0].in_features - 10
+    s = torch.randn(n_rows, sd, device=dev)
+    with torch.no_grad():
+        for _ in range(5):
+            inner._sample_fused(s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            inner._sample_fused(s)
+        e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / 50
+    nblk = len(inner.model.layers.layers) - 2
+    flops = 2.0 * n_rows * inner.T * ((10 + sd) * 256 + 2 * nblk * 256 * 256 + 256 * 2)
+    return {"bound": "mfma", "kernel": "k_ddpm_mlp_f32", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "kernel_ms": ms, "rows": n_rows, "launches_per_policy_step": 1,
+            "note": "one launch per predict call and sub-batch (+ one torch.randn); a call of <= 4096 rows is one workgroup's latency chain (16 rows per workgroup, at most "
+                    "256 workgroups): the fraction rises with the row count up to 0.5 at 16384 rows (tools/gpu_ddpm_kernel_time.py)"}
+
+
 def _beso_policy_roofline(pol, n, dev):
     """Config 5 is policy-bound: time of one policy step and of its dominant kernel (the fused transformer MLP on the f32 matrix cores, DESIGN section
     17.9), event-timed on the current stream after the benchmark loop; achieved TFLOP/s of that kernel against the dense f32 MFMA peak."""
@@ -728,6 +757,10 @@ def run(args):
         }
         if policy == "beso":
             line["policy_roofline"] = _beso_policy_roofline(pol, n, dev)
+        if policy == "ddpm":
+            pr = _ddpm_policy_roofline(pol, n // S, dev)
+            if pr is not None:
+                line["policy_roofline"] = pr
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(task, env.blob, q, ctx60)
         print(json.dumps(line))
