@@ -139,6 +139,13 @@ class RandomResidualMLPPolicy(torch.nn.Module):
 
     @torch.no_grad()
     def predict_batch(self, obs: torch.Tensor) -> torch.Tensor:
+        if obs.is_cuda and obs.dim() == 2:
+            if getattr(self, "_fused", None) is None:
+                from .policies import FusedResMLP
+                object.__setattr__(self, "_fused", FusedResMLP(lambda: (self.inp, [(b[0], b[1]) for b in self.blocks], self.out)))
+            x32 = obs.to(torch.float32)
+            if self._fused.ok(x32):
+                return self._fused(x32).clamp_(-self.bound, self.bound)      # one launch on the f32 matrix cores (policies.FusedResMLP)
         x = self.inp(obs.to(torch.float32))
         for l1, l2 in self.blocks:
             x = x + l2(self.act(l1(self.act(x))))

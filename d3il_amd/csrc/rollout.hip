@@ -592,6 +592,93 @@ __global__ __launch_bounds__(64 * DD_NW) void k_ddpm_mlp_f32(const float* __rest
   }
   if (live && w == 0 && g == 0) { out[row * 2] = fminf(fmaxf(x0, lo0), hi0); out[row * 2 + 1] = fminf(fmaxf(x1, lo1), hi1); }
 }
+// The reference's ResidualMLPNetwork (agents/models/common/mlp.py:114-182: Linear, n pre-activation residual blocks x + l2(mish(l1(mish(x)))), Linear - the network of
+// the BC agent, bc_agent.py:240-271, and the denoiser above without its sampling loop) in one launch, same operand scheme as k_ddpm_mlp_f32: 16 rows per
+// workgroup, eight waves share the HID / 16 output tiles of a layer, the activations go from layer to layer through LDS in B-operand order.  HID = 128 or 256,
+// at most 28 inputs and 16 outputs.
+template <int HID, bool RES>
+__device__ __forceinline__ void rm_layer(const mlp_f4* __restrict__ wl, const float* __restrict__ bias, const mlp_f4* xin, mlp_f4* y, int w, int lane, int g) {
+  constexpr int NT = HID / 16, TPW = NT / 8;
+  mlp_f4 m[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) m[t] = xin[t * 64 + lane];
+#pragma unroll
+  for (int q = 0; q < TPW; q++) {
+    const int To = TPW * w + q;
+    const mlp_f4* wt = wl + (long)To * (NT * 64) + lane;
+    mlp_f4 a[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) a[t] = wt[t * 64];
+    mlp_f4 acc[4];
+    acc[0] = *(const mlp_f4*)(bias + 16 * To + 4 * g);
+    acc[1] = RES ? y[q] : mlp_f4{0.f, 0.f, 0.f, 0.f};
+    acc[2] = mlp_f4{0.f, 0.f, 0.f, 0.f}; acc[3] = mlp_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][r], m[t][r], acc[r], 0, 0, 0);
+    y[q] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  }
+}
+template <int HID>
+__global__ __launch_bounds__(512) void k_resmlp_f32(const float* __restrict__ x, const float* __restrict__ w_in, const float* __restrict__ b_in, const float* __restrict__ w_blk,
+                                                     const float* __restrict__ b_blk, const float* __restrict__ w_out, const float* __restrict__ b_out, float* __restrict__ out,
+                                                     long n, int IN, int OUT, int nblk) {
+  constexpr int NT = HID / 16, TPW = NT / 8, LAYER_F4 = NT * NT * 64;
+  __shared__ mlp_f4 xb[2][NT * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
+  const long row = (long)blockIdx.x * 16 + j;
+  const bool live = row < n;
+  const long rr = live ? row : (n - 1);
+  float in_k[7];
+#pragma unroll
+  for (int s2 = 0; s2 < 7; s2++) { const int f = 4 * s2 + g; in_k[s2] = f < IN ? x[rr * IN + f] : 0.f; }
+  const mlp_f4* w_in4 = (const mlp_f4*)w_in;
+  const mlp_f4* w_out4 = (const mlp_f4*)w_out;
+  mlp_f4 xo[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; q++) {
+    const int To = TPW * w + q;
+    mlp_f4 acc = *(const mlp_f4*)(b_in + 16 * To + 4 * g);
+    const mlp_f4 a0 = w_in4[(To * 64 + lane) * 2], a1 = w_in4[(To * 64 + lane) * 2 + 1];
+#pragma unroll
+    for (int s2 = 0; s2 < 7; s2++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s2 < 4 ? a0[s2] : a1[s2 - 4], in_k[s2], acc, 0, 0, 0);
+    xo[q] = acc;
+  }
+  int buf = 0;
+#pragma clang loop unroll(disable)
+  for (int b = 0; b < nblk; b++) {
+    mlp_f4 y[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; q++) xb[buf][(TPW * w + q) * 64 + lane] = mlp_f4{dd_mish(xo[q][0]), dd_mish(xo[q][1]), dd_mish(xo[q][2]), dd_mish(xo[q][3])};
+    __syncthreads();
+    rm_layer<HID, false>((const mlp_f4*)w_blk + (long)(2 * b) * LAYER_F4, b_blk + (2 * b) * HID, xb[buf], y, w, lane, g);
+    buf ^= 1;
+#pragma unroll
+    for (int q = 0; q < TPW; q++) xb[buf][(TPW * w + q) * 64 + lane] = mlp_f4{dd_mish(y[q][0]), dd_mish(y[q][1]), dd_mish(y[q][2]), dd_mish(y[q][3])};
+    __syncthreads();
+    rm_layer<HID, true>((const mlp_f4*)w_blk + (long)(2 * b + 1) * LAYER_F4, b_blk + (2 * b + 1) * HID, xb[buf], xo, w, lane, g);
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int q = 0; q < TPW; q++) xb[buf][(TPW * w + q) * 64 + lane] = xo[q];
+  __syncthreads();
+  if (w != 0) return;      // (after the last barrier) the output tile is one wave's work
+  mlp_f4 acc = mlp_f4{0.f, 0.f, 0.f, 0.f}, acc2 = mlp_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const mlp_f4 a4 = w_out4[t * 64 + lane], m4 = xb[buf][t * 64 + lane];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], m4[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], m4[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], m4[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], m4[3], acc2, 0, 0, 0);
+  }
+  acc += acc2;
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (4 * g + r < OUT) out[row * OUT + 4 * g + r] = acc[r] + b_out[4 * g + r];
+  }
+}
 __global__ __launch_bounds__(256) void k_layernorm_f32(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
                                                        long rows, int C, float eps) {
   const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -1465,6 +1552,20 @@ int d3il_ddpm_mlp_f32(const float* state, const float* noise, const float* temb,
   if (rows == 0) return D3IL_OK;
   hipLaunchKernelGGL(k_ddpm_mlp_f32, dim3((unsigned)((rows + 15) / 16)), dim3(64 * DD_NW), 0, (hipStream_t)stream, state, noise, temb, w_in, b_in, w_blocks, b_blocks, w_out, b_out, sched, bounds, out,
                      rows, state_dim, n_timesteps, n_blocks);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_resmlp_f32(const float* x, const float* w_in, const float* b_in, const float* w_blocks, const float* b_blocks, const float* w_out, const float* b_out, float* out, long rows,
+                    int in_dim, int hidden, int n_blocks, int out_dim, void* stream) {
+  if (!x || !w_in || !b_in || !w_blocks || !b_blocks || !w_out || !b_out || !out) return fail(D3IL_EINVAL, "d3il_resmlp_f32: null argument");
+  if (hidden != 128 && hidden != 256) return fail(D3IL_EUNSUPPORTED, "d3il_resmlp_f32: built for hidden 128 and 256 (the ResidualMLPNetwork of the BC and DDPM configs)");
+  if (in_dim < 1 || in_dim > 28 || out_dim < 1 || out_dim > 16) return fail(D3IL_EUNSUPPORTED, "d3il_resmlp_f32: at most 28 inputs and 16 outputs");
+  if (n_blocks < 0 || rows < 0) return fail(D3IL_EINVAL, "d3il_resmlp_f32: bad counts");
+  if (((uintptr_t)w_in | (uintptr_t)b_in | (uintptr_t)w_blocks | (uintptr_t)b_blocks | (uintptr_t)w_out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_resmlp_f32: weights and biases must be 16-byte aligned");
+  if (rows == 0) return D3IL_OK;
+  const dim3 grid((unsigned)((rows + 15) / 16)), block(512);
+  if (hidden == 128) hipLaunchKernelGGL(k_resmlp_f32<128>, grid, block, 0, (hipStream_t)stream, x, w_in, b_in, w_blocks, b_blocks, w_out, b_out, out, rows, in_dim, out_dim, n_blocks);
+  else hipLaunchKernelGGL(k_resmlp_f32<256>, grid, block, 0, (hipStream_t)stream, x, w_in, b_in, w_blocks, b_blocks, w_out, b_out, out, rows, in_dim, out_dim, n_blocks);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }

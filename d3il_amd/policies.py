@@ -63,6 +63,11 @@ class ResidualMLP(nn.Module):
 
     def forward(self, x):
         x = x.to(torch.float32)
+        if x.dim() == 2 and x.is_cuda:
+            if getattr(self, "_fused", None) is None:
+                object.__setattr__(self, "_fused", FusedResMLP(lambda: (self.layers[0], [(b.l1, b.l2) for b in self.layers[1:-1]], self.layers[-1])))
+            if self._fused.ok(x):
+                return self._fused(x)      # one launch on the f32 matrix cores (D3IL_POLICY_FUSED_RESMLP=0: torch's layers)
         for layer in self.layers:
             x = layer(x)
         return x
@@ -351,6 +356,79 @@ class BCPolicy:
     def predict_batch(self, obs):
         out = self.model(self.scaler.scale_input(obs.to(torch.float32)))
         return self.scaler.inverse_scale_output(torch.clamp(out, self.min_action, self.max_action))
+
+
+def pack_resmlp_weights(lin_in, blocks, lin_out) -> dict:
+    """Linear, residual blocks [(l1, l2), ..], Linear of a ResidualMLPNetwork in the operand order of k_resmlp_f32 (the order of pack_ddpm_weights for any hidden
+    width that is a multiple of 16): [T_out][t][lane (g, i)][r] = W[16 T_out + i][16 t + 4 g + r]."""
+    dev = lin_in.weight.device
+    H = lin_in.out_features
+    NT = H // 16
+    ar = lambda k: torch.arange(k, device=dev)
+    To, t, g, i, r = ar(NT)[:, None, None, None, None], ar(NT)[None, :, None, None, None], ar(4)[None, None, :, None, None], ar(16)[None, None, None, :, None], ar(4)[None, None, None, None, :]
+    pack = lambda W: W[16 * To + i, 16 * t + 4 * g + r].reshape(NT, NT, 64, 4)
+    wi = torch.zeros(H, 32, device=dev)
+    wi[:, :lin_in.in_features] = lin_in.weight
+    w_in = wi[16 * ar(NT)[:, None, None, None] + ar(16)[None, None, :, None], 4 * ar(8)[None, None, None, :] + ar(4)[None, :, None, None]].reshape(NT, 64, 8)
+    wo = torch.zeros(16, H, device=dev)
+    wo[:lin_out.out_features] = lin_out.weight
+    w_out = wo[i[0], 16 * t[0] + 4 * g[0] + r[0]].reshape(NT, 64, 4)
+    bo = torch.zeros(16, device=dev)
+    bo[:lin_out.out_features] = lin_out.bias
+    if blocks:
+        w_blk = torch.stack([pack(l.weight) for b in blocks for l in b])
+        b_blk = torch.stack([l.bias for b in blocks for l in b])
+    else:
+        w_blk, b_blk = torch.zeros(1, NT, NT, 64, 4, device=dev), torch.zeros(1, H, device=dev)
+    f = lambda x: x.detach().to(torch.float32).contiguous()
+    return {"w_in": f(w_in), "b_in": f(lin_in.bias), "w_blk": f(w_blk), "b_blk": f(b_blk), "w_out": f(w_out), "b_out": f(bo), "n_blocks": len(blocks)}
+
+
+class FusedResMLP:
+    """The device path of a ResidualMLPNetwork (csrc/rollout.hip k_resmlp_f32 through d3il_resmlp_f32): packed weights in persistent buffers, refreshed in place
+    when a parameter's version counter has changed (a captured graph keeps reading current weights).  ``parts()`` -> (lin_in, [(l1, l2), ..], lin_out)."""
+
+    def __init__(self, parts):
+        self.parts, self._fw, self._key = parts, None, None
+
+    def ok(self, x):
+        lin_in, blocks, lin_out = self.parts()
+        w = lin_in.weight
+        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+            return False      # inference only: no autograd node
+        return (x.is_cuda and x.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and lin_in.out_features in (128, 256) and lin_in.in_features <= 28
+                and lin_out.out_features <= 16 and os.environ.get("D3IL_POLICY_FUSED_RESMLP", "1") == "1")
+
+    def ensure_packed(self):
+        lin_in, blocks, lin_out = self.parts()
+        params = [lin_in.weight, lin_in.bias, lin_out.weight, lin_out.bias] + [p for b in blocks for l in b for p in (l.weight, l.bias)]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._key == key:
+            return
+        with torch.no_grad():
+            fw = pack_resmlp_weights(lin_in, blocks, lin_out)
+            if self._fw is not None and all(not torch.is_tensor(v) or v.shape == self._fw[k].shape for k, v in fw.items()):
+                for k, v in fw.items():
+                    if torch.is_tensor(v):
+                        self._fw[k].copy_(v)
+            else:
+                self._fw = fw
+        self._key = key
+
+    def __call__(self, x):
+        from . import capi
+        lib = capi.load()
+        lin_in, blocks, lin_out = self.parts()
+        if not torch.cuda.is_current_stream_capturing():
+            self.ensure_packed()
+        else:
+            assert self._key is not None, "a captured graph replays the packed weight buffers: call ensure_packed() before capturing"
+        x = x.to(torch.float32).contiguous()
+        out = torch.empty(x.shape[0], lin_out.out_features, dtype=torch.float32, device=x.device)
+        w = self._fw
+        capi.check(lib.d3il_resmlp_f32(x.data_ptr(), w["w_in"].data_ptr(), w["b_in"].data_ptr(), w["w_blk"].data_ptr(), w["b_blk"].data_ptr(), w["w_out"].data_ptr(), w["b_out"].data_ptr(),
+                                       out.data_ptr(), x.shape[0], lin_in.in_features, lin_in.out_features, w["n_blocks"], lin_out.out_features, torch.cuda.current_stream(x.device).cuda_stream))
+        return out
 
 
 def pack_ddpm_weights(model: "DiffusionMLP") -> dict:

@@ -199,6 +199,13 @@ int d3il_ddpm_mlp_f32(const float* state, const float* noise, const float* temb,
                       const float* w_out, const float* b_out, const float* sched, const float* bounds, float* out, long rows, int state_dim, int n_timesteps, int hidden,
                       int n_blocks, void* stream);
 
+/* out[rows][out_dim] = the reference's ResidualMLPNetwork (agents/models/common/mlp.py:114-182: Linear, n_blocks pre-activation residual blocks with Mish, Linear; the
+ * network of BC_Agent.predict, bc_agent.py:240-271) of x [rows][in_dim] in one launch on the f32 matrix cores.  Weights in the kernel's tile order
+ * (d3il_amd/policies.py pack_resmlp_weights; NT = hidden / 16): w_in [NT][64][8], w_blocks [2 n_blocks][NT][NT][64][4], w_out [NT][64][4]; b_in [hidden],
+ * b_blocks [2 n_blocks][hidden], b_out [16] (padded).  Built for hidden 128 / 256, in_dim <= 28, out_dim <= 16 (D3IL_EUNSUPPORTED otherwise). */
+int d3il_resmlp_f32(const float* x, const float* w_in, const float* b_in, const float* w_blocks, const float* b_blocks, const float* w_out, const float* b_out, float* out, long rows,
+                    int in_dim, int hidden, int n_blocks, int out_dim, void* stream);
+
 /* Per-context episode tally, filled by d3il_auto_reset before it resets: table i64 [n_ctx][D3IL_TALLY_ROW] (caller-owned device
  * memory, caller zeroes it), row ctx_id[env] (device i32[n_envs]; NULL = row 0) += {episodes, successes, successes by mode code}
  * with the mode code = Avoiding: 9-bit mode encoding; Pushing: info['mode'] + 1; Sorting: np.packbits code.  These are the

@@ -166,3 +166,15 @@ def test_ddpm_kernel_entry_validates_before_it_launches():
     assert call(p[:3] + [C.c_void_p(4100)] + p[4:], 16, 16, 4, 256, 4) == -1      # w_in not 16-byte aligned
     assert call(p, 0, 16, 4, 256, 4) == 0
     assert b"d3il_ddpm_mlp_f32" in capi.last_error().encode() if hasattr(capi, "last_error") else True
+
+
+def test_resmlp_kernel_entry_validates_before_it_launches():
+    """d3il_resmlp_f32: the same contract as d3il_ddpm_mlp_f32 - unsupported shapes are D3IL_EUNSUPPORTED (policies.FusedResMLP.ok keeps them on torch's layers)."""
+    import ctypes as C
+    from d3il_amd import capi
+    L = capi.load()
+    p = [C.c_void_p(4096 + 64 * k) for k in range(8)]
+    call = lambda ptrs, rows, i, h, nb, o: L.d3il_resmlp_f32(*ptrs, rows, i, h, nb, o, None)
+    assert call(p, 16, 10, 64, 3, 2) == -5 and call(p, 16, 29, 128, 3, 2) == -5 and call(p, 16, 10, 128, 3, 17) == -5
+    assert call([None] + p[1:], 16, 10, 128, 3, 2) == -1 and call(p, 16, 10, 128, -1, 2) == -1
+    assert call(p, 0, 10, 256, 4, 2) == 0

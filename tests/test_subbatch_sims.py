@@ -168,7 +168,7 @@ def test_sorting_sim_with_a_captured_policy_in_four_sub_batches():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,obs_dim,layers", [(1000, 16, 8), (64, 10, 8), (37, 16, 2)])
-def test_fused_ddpm_chain_matches_the_torch_chain(n, obs_dim, layers):
+def test_fused_ddpm_chain_matches_the_torch_chain(n, obs_dim, layers, monkeypatch):
     """csrc/rollout.hip k_ddpm_mlp_f32 (the DDPM policy's whole sampling chain in one launch, f32 matrix cores) against the torch chain of the same policy on the
     same noise: f32 products in a different summation order and Mish through one exponential - 5e-5 of the scaled action range (measured 2e-5 at worst, 1e-7 typically) [-1, 1]."""
     from d3il_amd.policies import DDPMPolicy, DiffusionMLP, Scaler
@@ -191,7 +191,9 @@ def test_fused_ddpm_chain_matches_the_torch_chain(n, obs_dim, layers):
     obs = torch.randn(n, obs_dim, device=dev, dtype=torch.float64)
     s = sc.scale_input(obs.to(torch.float32))
     with torch.no_grad():
+        monkeypatch.setenv("D3IL_POLICY_FUSED_RESMLP", "0")      # the reference side of this comparison is torch's layers all the way down
         want = pol._sample(s)
+        monkeypatch.delenv("D3IL_POLICY_FUSED_RESMLP")
         pol.noise_fn.k = 0
         got = pol._sample_fused(s)
     assert got.shape == want.shape and bool(torch.isfinite(got).all())
@@ -221,3 +223,38 @@ def test_sorting_sim_with_the_fused_ddpm_policy_in_four_sub_batches():
     sim.test_agent(pol.captured())
     r = sim.last_rollout
     assert int(r["mode_hist"].sum()) == 300 and r["mode"].shape[0] == 300 and not bool((r["flags"] & ((1 << 16) | (1 << 18))).any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,inp,hid,layers,out", [(1000, 10, 128, 6, 2), (37, 20, 128, 6, 8), (4096, 16, 128, 6, 2), (300, 26, 256, 8, 2), (64, 28, 256, 2, 16)])
+def test_fused_residual_mlp_matches_torch_layers(n, inp, hid, layers, out, monkeypatch):
+    """csrc/rollout.hip k_resmlp_f32 (ResidualMLPNetwork, common/mlp.py:114-182, in one launch on the f32 matrix cores) against torch's layers: f32 sums in another
+    order, Mish through one exponential."""
+    from d3il_amd.policies import ResidualMLP
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = ResidualMLP(inp, hid, layers, out).to(dev).eval()
+    x = torch.randn(n, inp, device=dev)
+    with torch.no_grad():
+        monkeypatch.setenv("D3IL_POLICY_FUSED_RESMLP", "0")
+        want = net(x)
+        monkeypatch.delenv("D3IL_POLICY_FUSED_RESMLP")
+        got = net(x)
+        assert net._fused is not None and net._fused._key is not None            # the device path ran
+        assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), float((got - want).abs().max())
+        net.layers[0].weight.mul_(1.5)                                            # the packed copy follows the parameters
+        assert float((net(x) - got).abs().max()) > 1e-3
+    x.requires_grad_(True)
+    assert net(x).requires_grad                                                   # a caller that wants gradients gets torch's layers
+
+
+@pytest.mark.gpu
+def test_stand_in_mlp_policy_takes_the_fused_path(monkeypatch):
+    from d3il_amd.agents import RandomResidualMLPPolicy
+    pol = RandomResidualMLPPolicy(input_dim=16, device="cuda:0")
+    obs = torch.randn(777, 16, device="cuda:0", dtype=torch.float64) * 0.3
+    monkeypatch.setenv("D3IL_POLICY_FUSED_RESMLP", "0")
+    want = pol.predict_batch(obs).clone()
+    monkeypatch.delenv("D3IL_POLICY_FUSED_RESMLP")
+    got = pol.predict_batch(obs)
+    assert pol._fused._key is not None and float((got - want).abs().max()) < 1e-6 and float(want.abs().max()) > 1e-3
