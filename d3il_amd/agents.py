@@ -137,15 +137,23 @@ class RandomResidualMLPPolicy(torch.nn.Module):
     def reset(self):
         pass
 
+    def _parts(self):
+        return (self.inp, [(b[0], b[1]) for b in self.blocks], self.out)
+
+    def ensure_packed(self):
+        if getattr(self, "_fused", None) is not None and self._fused._key is not None:
+            self._fused.ensure_packed(self._parts())
+
     @torch.no_grad()
     def predict_batch(self, obs: torch.Tensor) -> torch.Tensor:
         if obs.is_cuda and obs.dim() == 2:
             if getattr(self, "_fused", None) is None:
                 from .policies import FusedResMLP
-                object.__setattr__(self, "_fused", FusedResMLP(lambda: (self.inp, [(b[0], b[1]) for b in self.blocks], self.out)))
+                object.__setattr__(self, "_fused", FusedResMLP())
             x32 = obs.to(torch.float32)
-            if self._fused.ok(x32):
-                return self._fused(x32).clamp_(-self.bound, self.bound)      # one launch on the f32 matrix cores (policies.FusedResMLP)
+            parts = self._parts()
+            if self._fused.ok(x32, parts):
+                return self._fused(x32, parts).clamp_(-self.bound, self.bound)      # one launch on the f32 matrix cores (policies.FusedResMLP)
         x = self.inp(obs.to(torch.float32))
         for l1, l2 in self.blocks:
             x = x + l2(self.act(l1(self.act(x))))

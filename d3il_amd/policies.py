@@ -61,13 +61,22 @@ class ResidualMLP(nn.Module):
         assert num_hidden_layers % 2 == 0
         self.layers = nn.ModuleList([nn.Linear(input_dim, hidden_dim)] + [_ResBlock(hidden_dim) for _ in range(1, num_hidden_layers, 2)] + [nn.Linear(hidden_dim, output_dim)])
 
+    def _parts(self):
+        return (self.layers[0], [(b.l1, b.l2) for b in self.layers[1:-1]], self.layers[-1])
+
+    def ensure_packed(self):
+        """Refresh the packed weight buffers of the device path (in place) if a parameter has changed - what a captured graph's owner calls before a replay."""
+        if getattr(self, "_fused", None) is not None and self._fused._key is not None:
+            self._fused.ensure_packed(self._parts())
+
     def forward(self, x):
         x = x.to(torch.float32)
         if x.dim() == 2 and x.is_cuda:
             if getattr(self, "_fused", None) is None:
-                object.__setattr__(self, "_fused", FusedResMLP(lambda: (self.layers[0], [(b.l1, b.l2) for b in self.layers[1:-1]], self.layers[-1])))
-            if self._fused.ok(x):
-                return self._fused(x)      # one launch on the f32 matrix cores (D3IL_POLICY_FUSED_RESMLP=0: torch's layers)
+                object.__setattr__(self, "_fused", FusedResMLP())
+            parts = self._parts()
+            if self._fused.ok(x, parts):
+                return self._fused(x, parts)      # one launch on the f32 matrix cores (D3IL_POLICY_FUSED_RESMLP=0: torch's layers)
         for layer in self.layers:
             x = layer(x)
         return x
@@ -352,6 +361,9 @@ class BCPolicy:
     def reset(self):
         pass
 
+    def ensure_packed(self):
+        self.model.ensure_packed()
+
     @torch.no_grad()
     def predict_batch(self, obs):
         out = self.model(self.scaler.scale_input(obs.to(torch.float32)))
@@ -386,21 +398,22 @@ def pack_resmlp_weights(lin_in, blocks, lin_out) -> dict:
 
 class FusedResMLP:
     """The device path of a ResidualMLPNetwork (csrc/rollout.hip k_resmlp_f32 through d3il_resmlp_f32): packed weights in persistent buffers, refreshed in place
-    when a parameter's version counter has changed (a captured graph keeps reading current weights).  ``parts()`` -> (lin_in, [(l1, l2), ..], lin_out)."""
+    when a parameter's version counter has changed (a captured graph keeps reading current weights).  Every call takes ``parts`` = (lin_in, [(l1, l2), ..],
+    lin_out) of the module it serves (no reference to the module is kept: a deep copy of the module gets its own buffers and packs ITS weights)."""
 
-    def __init__(self, parts):
-        self.parts, self._fw, self._key = parts, None, None
+    def __init__(self):
+        self._fw, self._key = None, None
 
-    def ok(self, x):
-        lin_in, blocks, lin_out = self.parts()
+    def ok(self, x, parts):
+        lin_in, blocks, lin_out = parts
         w = lin_in.weight
         if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
             return False      # inference only: no autograd node
         return (x.is_cuda and x.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and lin_in.out_features in (128, 256) and lin_in.in_features <= 28
                 and lin_out.out_features <= 16 and os.environ.get("D3IL_POLICY_FUSED_RESMLP", "1") == "1")
 
-    def ensure_packed(self):
-        lin_in, blocks, lin_out = self.parts()
+    def ensure_packed(self, parts):
+        lin_in, blocks, lin_out = parts
         params = [lin_in.weight, lin_in.bias, lin_out.weight, lin_out.bias] + [p for b in blocks for l in b for p in (l.weight, l.bias)]
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._key == key:
@@ -415,12 +428,12 @@ class FusedResMLP:
                 self._fw = fw
         self._key = key
 
-    def __call__(self, x):
+    def __call__(self, x, parts):
         from . import capi
         lib = capi.load()
-        lin_in, blocks, lin_out = self.parts()
+        lin_in, blocks, lin_out = parts
         if not torch.cuda.is_current_stream_capturing():
-            self.ensure_packed()
+            self.ensure_packed(parts)
         else:
             assert self._key is not None, "a captured graph replays the packed weight buffers: call ensure_packed() before capturing"
         x = x.to(torch.float32).contiguous()
@@ -556,6 +569,7 @@ class DDPMPolicy:
         key = tuple((p.data_ptr(), p._version) for p in params)
         if getattr(self, "_pack_key", None) == key:
             return
+        self.model.layers.ensure_packed()      # (the torch chain's inner network, if its device path has been used)
         L = self.model.layers.layers
         dev = L[0].weight.device
         with torch.no_grad():

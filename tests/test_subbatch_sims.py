@@ -244,6 +244,10 @@ def test_fused_residual_mlp_matches_torch_layers(n, inp, hid, layers, out, monke
         assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), float((got - want).abs().max())
         net.layers[0].weight.mul_(1.5)                                            # the packed copy follows the parameters
         assert float((net(x) - got).abs().max()) > 1e-3
+        import copy
+        twin = copy.deepcopy(net)                                                 # a deep copy packs ITS weights into ITS buffers
+        twin.layers[-1].bias.add_(1.0)
+        assert float((twin(x) - net(x) - 1.0).abs().max()) < 1e-5 and twin._fused._fw["w_blk"].data_ptr() != net._fused._fw["w_blk"].data_ptr()
     x.requires_grad_(True)
     assert net(x).requires_grad                                                   # a caller that wants gradients gets torch's layers
 
