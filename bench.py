@@ -51,7 +51,7 @@ IMPL_BYTES = {
     "aligning": 2 * (77 * 8 + 4 + 4) + 56 + 68 + 4 + 16,
     "inserting": 2 * (110 * 8 + 4 + 4) + 56 + 44 + 4,
 }
-KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_pushing_step_split<true>" if os.environ.get("D3IL_PUSH_ENGINE") == "legacy" else "k_sorting_step<true, false>",      # Pushing runs on the generic engine unless D3IL_PUSH_ENGINE=legacy
+KERNEL = {"avoiding": "k_avoiding_step_split<true, true>", "pushing": "k_sorting_step<true, false>",      # Pushing runs on the generic engine
           "sorting": "k_sorting_step<true, false>", "stacking": "k_stacking_step", "aligning": "k_aligning_step", "inserting": "k_sorting_step<true, true>"}
 
 
@@ -530,6 +530,22 @@ def run(args):
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d (the line reports n_gpus = WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda:%d" % local_rank)
+    if world > 1 and torch.distributed.get_backend() == "nccl":
+        # The first collective creates torch.distributed's own RCCL communicator: ranks that were given the SAME GPU (a launcher without LOCAL_RANK pinning, a
+        # one-GPU box) fail here ("Duplicate GPU detected") - on every rank alike, RCCL compares the bus ids of all ranks.  That is a set-up error of the launch,
+        # not of the path: exit code 3 (the documented multi-GPU self-check code) with a message instead of a stack trace per rank.
+        try:
+            probe = torch.ones(1, dtype=torch.int32, device=dev)
+            torch.distributed.all_reduce(probe)
+            torch.cuda.synchronize()
+            ok = int(probe.item()) == world
+        except Exception as exc:      # noqa: BLE001 - whatever RCCL / c10d raises
+            ok = False
+            if rank == 0:
+                print("bench.py: multi-GPU self-check failed: the RCCL communicator of %d ranks could not be created (%s: %s); one process per DISTINCT GPU is "
+                      "required under the nccl backend" % (world, type(exc).__name__, str(exc).splitlines()[0][:300]), file=sys.stderr)
+        if not ok:
+            sys.exit(3)
     n = args.envs
     env_offset = rank * n
     ctx60 = None
@@ -673,7 +689,12 @@ def run(args):
         value = world * n * args.steps / dt
         k_ms = sum(x[0] for x in tstats) / n_launches if n_launches else float("nan")
         alg = ALG_BYTES[task]
-        achieved = alg * n_launch / (k_ms * 1e-3) / 1e9      # per launch of the step kernel: n_launch environments (one sub-batch)
+        # `achieved` / `frac` are CHIP-level and per env step: the algorithmic bytes of all S launches of a step (alg x envs per GPU) over the
+        # wall time of a step on this GPU - comparable between --sub-batches 1 and 4 (the per-launch figure of a sub-batch over ITS duration fell with S although the
+        # step got faster).  The per-launch figure stays next to it (achieved_per_launch / frac_per_launch: one launch of n_launch environments over the mean launch duration).
+        ms_step = dt / args.steps * 1e3
+        achieved = alg * n / (ms_step * 1e-3) / 1e9
+        achieved_launch = alg * n_launch / (k_ms * 1e-3) / 1e9
         pm, pm_path = _pmc(task, policy, n, S)
         traffic, traffic_isolated, traffic_note, valu = None, None, None, None
         if pm is not None:
@@ -743,6 +764,9 @@ def run(args):
                        "ms_per_step_by_rank": {"min": min(dt_by_rank) / args.steps * 1e3, "max": max(dt_by_rank) / args.steps * 1e3,
                                                "all": [x / args.steps * 1e3 for x in dt_by_rank]}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "achieved_basis": "per env step, chip level: algorithmic_bytes_per_env_step x envs_per_gpu / ms_per_step (all sub-batch launches of a step, policy time included)",
+                         "achieved_per_launch": achieved_launch, "frac_per_launch": achieved_launch / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": alg * n,
                          "traffic": traffic, "traffic_isolated": traffic_isolated, "traffic_source": traffic_note,
                          "kernel": ("k_avoiding_step_split<true, false>" if task == "avoiding" and (n_launch + 63) // 64 > (args.serve_max_wg if args.serve_max_wg is not None else 256 // S) else KERNEL[task]),
                          "kernel_ms": k_ms,

@@ -141,8 +141,13 @@ class RandomResidualMLPPolicy(torch.nn.Module):
         return (self.inp, [(b[0], b[1]) for b in self.blocks], self.out)
 
     def ensure_packed(self):
-        if getattr(self, "_fused", None) is not None and self._fused._key is not None:
+        if getattr(self, "_fused", None) is not None and self._fused._fw is not None:
             self._fused.ensure_packed(self._parts())
+
+    def invalidate_packed(self):
+        """After ``param.data`` writes (invisible to the tensors' version counters): the next call repacks the device path's weights."""
+        if getattr(self, "_fused", None) is not None:
+            self._fused.invalidate()
 
     @torch.no_grad()
     def predict_batch(self, obs: torch.Tensor) -> torch.Tensor:
@@ -257,7 +262,13 @@ class ScriptedStackPolicy:
             tab[i, len(t):] = tt[-1]
         self.table = tab.to(self.device)
         self.ctx_id = torch.as_tensor(ctx_id, dtype=torch.int64, device=self.device)
+        self._ctx_all = self.ctx_id
         self.t = torch.zeros(len(self.ctx_id), dtype=torch.int64, device=self.device)
+
+    def set_rollout_range(self, offset, count):
+        """Rows 0 .. count-1 of this clone's batch are rollouts offset .. offset+count-1 (a sub-batch of the rank's batch, envs/sub_batch.py)."""
+        self.ctx_id = self._ctx_all[offset:offset + count]
+        self.t = torch.zeros(count, dtype=torch.int64, device=self.device)
 
     def reset(self):
         self.t.zero_()
@@ -382,8 +393,15 @@ class ScriptedAlignPolicy:
     def __init__(self, inside=None, device="cuda"):
         self.device = torch.device(device)
         self.inside = None if inside is None else torch.as_tensor(inside, dtype=torch.bool, device=self.device)
+        self._inside_all = self.inside
         self.t = None
         self.way = None
+
+    def set_rollout_range(self, offset, count):
+        """Rows 0 .. count-1 of this clone's batch are rollouts offset .. offset+count-1 (a sub-batch of the rank's batch, envs/sub_batch.py)."""
+        if self._inside_all is not None:
+            self.inside = self._inside_all[offset:offset + count]
+        self.t, self.way = None, None
 
     def reset(self):
         self.t, self.way = None, None

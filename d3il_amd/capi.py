@@ -25,7 +25,7 @@ STATE_QPOS, STATE_QVEL, STATE_BIAS, STATE_TCP, STATE_IK_Q, STATE_IK_QD = 0, 9, 1
 FLAG_MODE_MASK, FLAG_TERMINATED, FLAG_SUCCESS, FLAG_ROD_CONTACT = 0x1FF, 1 << 12, 1 << 13, 1 << 14
 FLAG_IK_VALID, FLAG_SOLVER_FAIL, FLAG_MULTI_CONTACT = 1 << 15, 1 << 16, 1 << 17
 # Pushing (D3IL_PUSH_STATE_* / D3IL_PFLAG_* in include/d3il_rollout.h)
-PUSH_STATE_BOX, PUSH_STATE_WARM, PUSH_STATE_F64 = 42, 68, 89
+PUSH_STATE_BOX, PUSH_STATE_WARM, PUSH_STATE_TASK, PUSH_STATE_F64 = 42, 68, 89, 91
 PFLAG_FIRST_MASK, PFLAG_MODE_MASK, PFLAG_WARM_VALID, PFLAG_CON_OVERFLOW, PFLAG_OFF_TABLE = 0x7, 0x38, 1 << 6, 1 << 18, 1 << 19
 TASK_AVOIDING, TASK_PUSHING, TASK_SORTING, TASK_STACKING, TASK_ALIGNING, TASK_INSERTING = 0, 1, 2, 3, 4, 5
 ALIGN_STATE_BOX, ALIGN_STATE_WARM, ALIGN_STATE_TARGET, ALIGN_STATE_F64 = 42, 55, 70, 77
@@ -69,8 +69,8 @@ def load():
         L.d3il_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.d3il_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.d3il_get_buffers.argtypes = [C.c_void_p, C.POINTER(Buffers)]
-        L.d3il_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.d3il_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.d3il_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.d3il_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.d3il_policy_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.d3il_policy_action.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.d3il_count_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

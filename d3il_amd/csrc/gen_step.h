@@ -22,7 +22,7 @@
 // state buffer itself (w area).  Same numerics as the oracle's generic engine up to solver tolerance
 // (tests/test_sorting_host.py, tests/test_gpu_parity_sorting.py).
 #pragma once
-#include "push_step.h"
+#include "rigid_common.h"
 
 namespace d3il {
 

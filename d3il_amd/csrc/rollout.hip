@@ -14,14 +14,13 @@
 #include <string>
 #include "../../include/d3il_rollout.h"
 #include "panda_step.h"
-#include "push_step.h"
+#include "rigid_common.h"
 #include "gen/avoiding_consts.inc"
 #include "gen/stacking_consts.inc"
 
 namespace d3il {
 constexpr int WAVE = 64;
 }
-#include "push_kernels.h"
 #include "gen_kernels.h"
 #include "stack_kernels.h"
 
@@ -922,30 +921,23 @@ static_assert(D3IL_SFLAG_WARM_VALID == SKF_WARM_VALID && D3IL_SFLAG_HAND_NEAR ==
 static_assert(D3IL_SFLAG_MODE_MASK == (SKF_NMODE_MASK | (0x3Fu << SKF_IND_SHIFT)), "d3il_rollout.h: Stacking order code");
 static_assert(D3IL_ALIGN_STATE_BOX == AL_STATE_BOX && D3IL_ALIGN_STATE_WARM == AL_STATE_WARM && D3IL_ALIGN_STATE_TARGET == AL_STATE_TARGET && D3IL_ALIGN_STATE_F64 == AL_STATE_F64, "d3il_rollout.h: Aligning state layout");
 static_assert(D3IL_INS_STATE_BOX == 42 && D3IL_INS_STATE_WARM == 42 + 13 * 3 && D3IL_INS_STATE_TASK == 42 + 13 * 3 + 6 * 3 + NDOF && D3IL_INS_STATE_F64 == gen_state_rows(3), "d3il_rollout.h: Inserting state layout");
-static_assert(D3IL_PUSH_STATE_F64 == PUSH_STATE_F64 && D3IL_TALLY_ALL + 256 <= D3IL_TALLY_ROW - 2, "d3il_rollout.h: Pushing state rows / tally row");
+static_assert(D3IL_PUSH_STATE_BOX == 42 && D3IL_PUSH_STATE_WARM == 42 + 13 * 2 && D3IL_PUSH_STATE_TASK == 42 + 13 * 2 + 6 * 2 + NDOF && D3IL_PUSH_STATE_F64 == gen_state_rows(2) && D3IL_TALLY_ALL + 256 <= D3IL_TALLY_ROW - 2,
+              "d3il_rollout.h: Pushing state rows / tally row");
 
-// Pushing runs on the generic engine (gen_step.h: its two cubes, the table slabs AND the frame beams as static boxes, the tree solver) unless the process
-// asks for the round-1 Pushing engine (push_step.h / push_kernels.h) with D3IL_PUSH_ENGINE=legacy - read once, when the first handle is created.
-static bool push_on_generic() {
-  static const bool v = [] { const char* e = std::getenv("D3IL_PUSH_ENGINE"); return !(e && std::strcmp(e, "legacy") == 0); }();
-  return v;
+static inline bool gen_task(int task_id) {      // the tasks of the generic engine (gen_step.h): Pushing = its two cubes, the table slabs AND the frame beams as static boxes
+  return task_id == D3IL_TASK_SORTING || task_id == D3IL_TASK_INSERTING || task_id == D3IL_TASK_PUSHING;
 }
-static inline bool gen_task(int task_id) {      // the tasks of the generic engine (gen_step.h)
-  return task_id == D3IL_TASK_SORTING || task_id == D3IL_TASK_INSERTING || (task_id == D3IL_TASK_PUSHING && push_on_generic());
-}
-static inline bool legacy_push(int task_id) { return task_id == D3IL_TASK_PUSHING && !push_on_generic(); }
 
 constexpr int RG_SLOTS = 2, RG_SAMPLE = 8;
 struct d3il_handle_s {
   int task_id, n, stride, device;
   PandaConsts hc;          // host copy
   PandaConsts* dc;         // device copy
-  PushConsts pc;           // Pushing: cubes, table slabs, contact parameter sets, targets
-  GenConsts gc;            // Sorting: cubes, static boxes, contact parameter sets (host copy; the device copy is the __constant__ object)
+  GenConsts gc;            // Sorting / Inserting / Pushing: cubes, static boxes, contact parameter sets (host copy; the device copy is the __constant__ object)
   StackConsts kc;          // Stacking: boxes, finger geoms, contact parameter sets (host copy; device: __constant__)
   AlignTask atk;           // Aligning: success / mode thresholds (device: __constant__ g_align_task)
-  double* d_scratch;       // Pushing: per-lane solver scratch [PG_SIZE][stride]
-  int state_rows;          // f64 state fields per environment (42 Avoiding, 89 Pushing)
+  double* d_scratch;       // contact records (generic engine: GG_BLOCK doubles per environment; cooperative engine: SG_SIZE)
+  int state_rows;          // f64 state fields per environment (42 Avoiding, 91 Pushing, ...: d3il_buffers.state_rows)
   double* d_init_qpos;
   bool started;
   d3il_buffers buf;
@@ -965,8 +957,7 @@ struct d3il_handle_s {
   double t_sum, t_min, t_max;
   int tol_mode;            // 0 production stopping rule of the contact solvers, 1 the oracle's (solver_strict)
   int stack_reset_coop;    // Stacking: 1 (default) env.reset() runs through the step kernel's cooperative phases, 0 the one-lane reset kernel
-  int push_coop;           // Pushing: 1 env.step() on the wave-cooperative engine (k_pushing_step_coop), 0 (default) the two-wave kernel (k_pushing_step_split)
-  unsigned long long kc_id; // identity of this handle's StackConsts in the device's g_stack_consts cache (Stacking, Pushing on the cooperative engine)
+  unsigned long long kc_id; // identity of this handle's StackConsts in the device's g_stack_consts cache (Stacking, Aligning)
   double* d_ctx;           // [n][ctx_dim] context of the last reset of every environment (Pushing 14, Sorting 7 nb)
   int ctx_dim;
   uint8_t* d_mask;         // [stride] environments reset by the last d3il_auto_reset (buf.last_reset)
@@ -983,17 +974,17 @@ struct d3il_handle_s {
   bool info_is_view;       // buf.info_f64 points into buf.state (Pushing on the generic engine: its two task rows) - not freed on its own
 };
 
-// The Pushing / Sorting kernels read their model from one __constant__ object per device (scalar loads, no pointer across call
-// boundaries: push_step.h).  Handles on one device therefore have to share the model: d3il_create refuses a different one while
-// another handle is alive (a second model would silently re-point the kernels of the first).
-struct ActiveModel { int refs; bool valid; PushConsts pc; GenConsts gc; StackConsts kc; };
-static ActiveModel g_active_push[16], g_active_gen[16], g_active_stack[16];
+// The Stacking kernels read their model from one __constant__ object per device (scalar loads, no pointer across call boundaries).  Stacking handles on one
+// device therefore have to share the model: d3il_create refuses a different one while another handle is alive (a second model would silently
+// re-point the kernels of the first).  Handles of the generic engine reload the constants per launch (GenLaunch).
+struct ActiveModel { int refs; bool valid; GenConsts gc; StackConsts kc; };
+static ActiveModel g_active_gen[16], g_active_stack[16];
 static int g_active_tol[16];   // solver tolerance set currently in the device's g_solver_tol (0 production)
 // g_active_* / g_active_tol are process-global (one __constant__ object per device): every read-modify-write of them - d3il_create,
 // d3il_destroy, the solver-rule switch - holds this mutex (two host threads with one handle each raced on them)
 static std::mutex g_model_mutex;
 
-// g_stack_consts (one __constant__ object per device) serves the Stacking engine AND its Pushing variant: it is a cache of the constants of
+// g_stack_consts (one __constant__ object per device) serves the Stacking engine AND its Aligning variant: it is a cache of the constants of
 // the handle that launched last.  A handle with other constants reloads it before its launch, fenced by device synchronisations (handles
 // with different engine constants must not have kernels in flight on one device at the same time - they never share a stream in practice).
 static unsigned long long g_stack_loaded_id[16];
@@ -1008,7 +999,7 @@ extern "C" {
 
 const char* d3il_last_error(void) { return g_err.c_str(); }
 size_t d3il_blob_sizeof(void) { return sizeof(d3il_model_blob); }
-int d3il_version(void) { return 1; }
+int d3il_version(void) { return 2; }
 
 static void rg_drop(d3il_handle_s* h);
 static void rg_drop_for_free(d3il_handle_s* h) {
@@ -1020,7 +1011,6 @@ static void free_handle(d3il_handle_s* h) {
   int dev = h->device;
   if (dev >= 0 && dev < 16) {
     std::lock_guard<std::mutex> lock(g_model_mutex);
-    if (legacy_push(h->task_id) && g_active_push[dev].refs > 0) g_active_push[dev].refs--;
     if (gen_task(h->task_id) && g_active_gen[dev].refs > 0) g_active_gen[dev].refs--;
     if (h->task_id == D3IL_TASK_STACKING && g_active_stack[dev].refs > 0) g_active_stack[dev].refs--;
   }
@@ -1051,12 +1041,11 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   std::memset(&h->buf, 0, sizeof h->buf);
   h->task_id = -1; h->device = device_id;      // task_id is set once the model reference is taken (free_handle)
   h->dc = nullptr; h->d_init_qpos = nullptr; h->d_scratch = nullptr; h->d_ctx = nullptr; h->d_mask = nullptr; h->ev_created = false; h->ring_created = false;
-  h->tally_ctx = nullptr; h->tally_nctx = 0; h->tally_table = nullptr; h->tol_mode = 0; h->ctx_dim = 0; h->stack_reset_coop = 1; h->push_coop = 0; h->kc_id = 0;
+  h->tally_ctx = nullptr; h->tally_nctx = 0; h->tally_table = nullptr; h->tol_mode = 0; h->ctx_dim = 0; h->stack_reset_coop = 1; h->kc_id = 0;
   const char* err = "";
   int rc = build_panda_consts(m, h->hc, &err);
   if (rc) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   finish_invweights(h->hc);
-  if (legacy_push(task_id) && build_push_consts(m, h->pc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (gen_task(task_id) && build_gen_consts(m, h->hc, h->gc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_STACKING && build_stack_consts(m, h->hc, h->kc, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
   if (task_id == D3IL_TASK_ALIGNING && build_coop_align_consts(m, h->hc, h->kc, h->atk, &err)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + err); }
@@ -1079,19 +1068,8 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     if (!same) { free_handle(h); return fail(D3IL_EUNSUPPORTED, "d3il_create: the model blob differs from the model this library was specialised for at build time; "
                                                                  "regenerate csrc/gen/*_consts.inc and rebuild (python -m d3il_amd.build)"); }
   }
-  const bool pushing = legacy_push(task_id);
-  const bool sorting = gen_task(task_id);       // Sorting, Inserting and (by default) Pushing run on the generic engine (gen_step.h)
+  const bool sorting = gen_task(task_id);       // Sorting, Inserting and Pushing run on the generic engine (gen_step.h)
   const bool gen_pushing = sorting && task_id == D3IL_TASK_PUSHING;
-  // one Pushing / Sorting model per device while handles are alive (constant memory)
-  if (pushing) {
-    ActiveModel& am = g_active_push[device_id];
-    bool other;
-    { std::lock_guard<std::mutex> lock(g_model_mutex); other = am.refs > 0 && std::memcmp(&am.pc, &h->pc, sizeof(PushConsts)) != 0; }
-    if (other) {
-      free_handle(h);
-      return fail(D3IL_EUNSUPPORTED, "d3il_create: another live Pushing handle on this device uses a different model (the kernels read one model per device from constant memory); destroy it first");
-    }
-  }
   // (handles of the generic engine with different models - Sorting-2 / 4, Inserting, Pushing - may live side by side: every launch checks the constants the
   // device holds and reloads them when they are another handle's, sync_gen_consts_locked below)
   const bool stacking = task_id == D3IL_TASK_STACKING;
@@ -1107,11 +1085,11 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   h->n = n_envs; h->stride = (n_envs + WAVE - 1) / WAVE * WAVE;
   h->started = false; h->split = -1; h->serve_avail = true; h->serve_max_wg = 256; h->lanes = WAVE; h->lds_pad = -1; h->fast = true; h->timing = false; h->ev_valid = false;
   const bool aligning = task_id == D3IL_TASK_ALIGNING;
-  h->state_rows = pushing ? PUSH_STATE_F64 : (sorting ? gen_state_rows(h->gc.nb) : (stacking ? SK_STATE_F64 : (aligning ? AL_STATE_F64 : D3IL_STATE_F64)));
-  h->ctx_dim = pushing ? 14 : (sorting ? 7 * h->gc.nb : (stacking ? 21 : (aligning ? AL_CTX : 0)));
+  h->state_rows = (sorting ? gen_state_rows(h->gc.nb) : (stacking ? SK_STATE_F64 : (aligning ? AL_STATE_F64 : D3IL_STATE_F64)));
+  h->ctx_dim = (sorting ? 7 * h->gc.nb : (stacking ? 21 : (aligning ? AL_CTX : 0)));
   size_t S = (size_t)h->stride;
   d3il_buffers& b = h->buf;
-  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = pushing ? PUSH_OBS : (sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : (aligning ? AL_OBS : 2))); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = (pushing || aligning || gen_pushing) ? 2 : (stacking ? 1 : 0);
+  b.n_envs = n_envs; b.stride = h->stride; b.obs_dim = sorting ? 2 + 3 * h->gc.nb : (stacking ? SK_OBS : (aligning ? AL_OBS : 2)); b.action_dim = stacking ? SK_ACT : 7; b.state_rows = h->state_rows; b.n_info_f64 = (aligning || gen_pushing) ? 2 : (stacking ? 1 : 0);
   HIPCHK_H(hipMalloc(&h->dc, sizeof(PandaConsts)));
   if (task_id == D3IL_TASK_AVOIDING) {
     // the three-wave form needs AVOID_LDS_SERVE of dynamic LDS on top of its static LDS; a device that cannot grant it runs the two-wave form
@@ -1136,31 +1114,6 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
   HIPCHK_H(hipMemset(b.flags, 0, S * sizeof(uint32_t))); HIPCHK_H(hipMemset(b.step_count, 0, S * sizeof(int32_t)));
   HIPCHK_H(hipMemset(b.policy_des, 0, S * 3 * sizeof(double)));
   if (h->ctx_dim) { HIPCHK_H(hipMalloc(&h->d_ctx, S * h->ctx_dim * sizeof(double))); HIPCHK_H(hipMemset(h->d_ctx, 0, S * h->ctx_dim * sizeof(double))); }
-  if (pushing) {
-    ActiveModel& am = g_active_push[device_id];
-    {
-      std::unique_lock<std::mutex> lock(g_model_mutex);
-      if (am.refs == 0) {
-        hipError_t e1 = hipDeviceSynchronize(), e2 = hipMemcpyToSymbol(HIP_SYMBOL(g_push_consts), &h->pc, sizeof(PushConsts));
-        if (e1 != hipSuccess || e2 != hipSuccess) { lock.unlock(); free_handle(h); return fail(D3IL_EHIP, "d3il_create: loading the Pushing model into constant memory failed"); }
-        am.pc = h->pc;
-      }
-      am.refs++; h->task_id = task_id;
-    }
-    HIPCHK_H(hipMalloc(&b.info_f64, S * 2 * sizeof(double))); HIPCHK_H(hipMemset(b.info_f64, 0, S * 2 * sizeof(double)));
-    { const size_t per = PG_SIZE > SG_SIZE ? PG_SIZE : SG_SIZE; HIPCHK_H(hipMalloc(&h->d_scratch, S * per * sizeof(double))); HIPCHK_H(hipMemset(h->d_scratch, 0, S * per * sizeof(double))); }
-    // the physics wave keeps the coupled solver's tables in LDS: 137.5 KiB + the set-point exchange, above the 64 KiB default cap
-    HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
-    HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_STEP));
-    HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_reset, hipFuncAttributeMaxDynamicSharedMemorySize, PUSH_LDS_H));
-    {   // the Pushing variant of the wave-cooperative engine
-      const char* e2 = "";
-      if (build_coop_push_consts(h->hc, h->pc, h->kc, &e2)) { free_handle(h); return fail(D3IL_EBLOB, std::string("d3il_create: ") + e2); }
-      std::lock_guard<std::mutex> lock(g_model_mutex);
-      h->kc_id = ++g_kc_counter;
-    }
-    HIPCHK_H(hipFuncSetAttribute((const void*)k_pushing_step_coop, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS));
-  }
   if (sorting) {
     {
       std::lock_guard<std::mutex> lock(g_model_mutex);
@@ -1188,7 +1141,7 @@ int d3il_create(int task_id, int n_envs, int device_id, const void* model_blob, 
     HIPCHK_H(hipFuncSetAttribute((const void*)k_stacking_reset, hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS_RESET));
   }
   if (aligning) {
-    {   // the engine constants go through the g_stack_consts cache like the Stacking / cooperative Pushing ones; the task thresholds have their own object
+    {   // the engine constants go through the g_stack_consts cache like the Stacking ones; the task thresholds have their own object
       std::lock_guard<std::mutex> lock(g_model_mutex);
       h->kc_id = ++g_kc_counter;
     }
@@ -1308,13 +1261,6 @@ int d3il_reset(d3il_handle h, const uint8_t* env_mask, const double* contexts, v
     hipLaunchKernelGGL(k_store_contexts, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_mask, contexts, h->d_ctx, h->n, h->ctx_dim);
     HIPCHK(hipGetLastError());
   }
-  if (legacy_push(h->task_id)) {
-    if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the Pushing task needs contexts (device f64 [n_envs][14])");
-    hipLaunchKernelGGL(k_pushing_reset, dim3((h->n + PUSH_LANES - 1) / PUSH_LANES), dim3(WAVE), PUSH_LDS_H, (hipStream_t)stream, h->d_init_qpos, env_mask, contexts, b.state,
-                       b.flags, b.step_count, b.obs, b.done, b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride);
-    HIPCHK(hipGetLastError());
-    return D3IL_OK;
-  }
   if (gen_task(h->task_id)) {
     if (!contexts) return fail(D3IL_EINVAL, "d3il_reset: the task needs contexts (device f64 [n_envs][7 * n_boxes])");
     GenLaunch guard(h);
@@ -1377,24 +1323,6 @@ int d3il_step(d3il_handle h, const double* actions, void* stream) {
   d3il_buffers& b = h->buf;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = sync_solver_tol(h, s)) return rc;
-  if (legacy_push(h->task_id)) {
-    int nwgp = (h->n + PUSH_LANES - 1) / PUSH_LANES;
-    std::unique_ptr<StackLaunch> guard;
-    if (h->push_coop && h->fast) { guard.reset(new StackLaunch(h)); if (guard->rc) return guard->rc; }
-    if (h->timing) { if (int rc_ = timing_begin(h, s)) return rc_; }
-    if (h->push_coop && h->fast)
-      hipLaunchKernelGGL(k_pushing_step_coop, dim3((h->n + SK_LANES - 1) / SK_LANES), dim3(WAVE), STACK_LDS, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
-                         b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
-    else if (h->fast)
-      hipLaunchKernelGGL((k_pushing_step_split<true>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
-                         b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
-    else
-      hipLaunchKernelGGL((k_pushing_step_split<false>), dim3(nwgp), dim3(2 * WAVE), PUSH_LDS_STEP, s, b.state, b.flags, b.step_count, actions, b.obs, b.done,
-                         b.success, b.mode, b.info_f64, h->d_scratch, h->n, h->stride, h->hc.n_substeps, h->hc.max_steps);
-    HIPCHK(hipGetLastError());
-    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, s)); h->ev_valid = true; h->ring_head++; }
-    return D3IL_OK;
-  }
   if (gen_task(h->task_id)) {
     int nwgs = (h->n + GEN_LANES - 1) / GEN_LANES;
     GenLaunch guard(h);
@@ -1468,8 +1396,15 @@ int d3il_get_buffers(d3il_handle h, d3il_buffers* out) {
   return D3IL_OK;
 }
 
-int d3il_get_state(d3il_handle h, double* state, uint32_t* flags, int32_t* steps) {
+static int check_state_rows(d3il_handle h, const void* state, int32_t state_rows, const char* who) {
+  if (state && state_rows != h->state_rows)
+    return fail(D3IL_EINVAL, std::string(who) + ": the caller's buffer has " + std::to_string(state_rows) + " state rows, this handle has " + std::to_string(h->state_rows) +
+                                 " (d3il_buffers.state_rows)");
+  return D3IL_OK;
+}
+int d3il_get_state(d3il_handle h, double* state, int32_t state_rows, uint32_t* flags, int32_t* steps) {
   if (!h) return fail(D3IL_EINVAL, "d3il_get_state: null handle");
+  if (int rc_ = check_state_rows(h, state, state_rows, "d3il_get_state")) return rc_;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
   if (state) HIPCHK(hipMemcpy2D(state, (size_t)h->n * 8, h->buf.state, (size_t)h->stride * 8, (size_t)h->n * 8, h->state_rows, hipMemcpyDeviceToHost));
@@ -1477,8 +1412,9 @@ int d3il_get_state(d3il_handle h, double* state, uint32_t* flags, int32_t* steps
   if (steps) HIPCHK(hipMemcpy(steps, h->buf.step_count, (size_t)h->n * 4, hipMemcpyDeviceToHost));
   return D3IL_OK;
 }
-int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, const int32_t* steps) {
+int d3il_set_state(d3il_handle h, const double* state, int32_t state_rows, const uint32_t* flags, const int32_t* steps) {
   if (!h) return fail(D3IL_EINVAL, "d3il_set_state: null handle");
+  if (int rc_ = check_state_rows(h, state, state_rows, "d3il_set_state")) return rc_;
   if (int rc_ = drop_prepared_action(h)) return rc_;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
@@ -1750,6 +1686,9 @@ static void rg_drop(d3il_handle_s* h) {
   h->rg_ready = false;
 }
 static int rg_capture(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* counts, hipStream_t s) {
+  // a prepared action left by a fused-tail step is dropped BEFORE the capture begins: inside it, d3il_step's own drop would record k_restore_des into the
+  // graph and every replay would put a stale harness pose back
+  if (int rc_ = drop_prepared_action(h)) return rc_;
   if (!h->rg_t_dev) HIPCHK(hipMalloc(&h->rg_t_dev, sizeof(unsigned)));
   HIPCHK(hipMemcpyAsync(h->rg_t_dev, &t, sizeof(unsigned), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -1800,6 +1739,7 @@ int d3il_random_rollout_prepare(d3il_handle h, uint64_t seed, uint64_t env_offse
 int d3il_random_rollout_step(d3il_handle h, uint64_t seed, uint64_t env_offset, uint32_t t, double* actions, int64_t* episode_counts_device, void* stream) {
   if (h && h->rg_enabled && h->task_id == D3IL_TASK_AVOIDING && stream != nullptr && actions && h->started) {
     hipStream_t s = (hipStream_t)stream;
+    if (int rc_ = drop_prepared_action(h)) return rc_;      // (the graph path draws its own action: a pending fused-tail draw ends here)
     if (int rc = d3il_random_rollout_prepare(h, seed, env_offset, t, actions, episode_counts_device, stream)) return rc;
     if (t != h->rg_next_t) { HIPCHK(hipMemcpyAsync(h->rg_t_dev, &t, sizeof(unsigned), hipMemcpyHostToDevice, s)); HIPCHK(hipStreamSynchronize(s)); }      // the caller jumped in time
     // Launch durations: event-record nodes inside a captured graph give no usable timestamps with this runtime (hipEventElapsedTime: invalid resource
@@ -1909,12 +1849,11 @@ int d3il_debug_scratch(d3il_handle h, int env, double* out, int count) {
 int d3il_set_option(d3il_handle h, const char* name, int value) {
   if (!h || !name) return fail(D3IL_EINVAL, "d3il_set_option: null argument");
   if (h->rg_ready) { HIPCHK(hipDeviceSynchronize()); rg_drop(h); }      // an option may change what a step launches
-  if (std::strcmp(name, "graph_rollout") == 0) { h->rg_enabled = value != 0; return D3IL_OK; }
+  if (std::strcmp(name, "graph_rollout") == 0) { if (int rc_ = drop_prepared_action(h)) return rc_; h->rg_enabled = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "fuse_rollout_tail") == 0) { if (int rc_ = drop_prepared_action(h)) return rc_; h->fuse_tail = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "ik_fast_path") == 0) { h->fast = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "solver_strict") == 0) { h->tol_mode = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "stack_reset_coop") == 0) { h->stack_reset_coop = value != 0; return D3IL_OK; }
-  if (std::strcmp(name, "push_coop") == 0) { h->push_coop = value != 0; return D3IL_OK; }
   if (std::strcmp(name, "split_waves") == 0) { h->split = value; return D3IL_OK; }
   if (std::strcmp(name, "serve_wave_max_workgroups") == 0) { if (value < 0) return fail(D3IL_EINVAL, "serve_wave_max_workgroups must be >= 0"); h->serve_max_wg = h->serve_avail ? value : 0; return D3IL_OK; }
   if (std::strcmp(name, "lds_pad_bytes") == 0) { h->lds_pad = value; return D3IL_OK; }

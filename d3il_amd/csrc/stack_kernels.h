@@ -13,7 +13,6 @@
 #pragma once
 #include "stack_step.h"
 #include "align_step.h"
-#include "push_kernels.h"
 
 namespace d3il {
 
@@ -292,33 +291,6 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
     for (int k = 0; k < 7; k++) t[SE_ACT + k] = as.target[k];
     fl = as.arm.flags | ((as.arm.flags & PF_WARM_VALID) ? SKF_WARM_VALID : 0u);
     step = as.arm.step;
-  } else if (live && V == SKV_PUSHING) {
-    // Block_Push_Env.step (pushing.py:335-339 over gym_env_wrapper.py:45-100): set-point, observation / reward / done BEFORE the physics
-    PushState ps;
-    push_load(state, flags, steps, stride, e, ps, true);
-    double act[7], des[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) act[k] = actions[(size_t)e * 7 + k];
-    bad = sanitize_action(act, actions + (size_t)e * 7);
-    make_setpoint(act, des);
-    float o[PUSH_OBS]; unsigned char dn = 0; double reward = 0;
-    push_step_begin(g_push_consts, ps, o, &reward, &dn, max_steps);
-#pragma unroll
-    for (int k = 0; k < PUSH_OBS; k++) obs[(size_t)PUSH_OBS * e + k] = o[k];
-    done[e] = dn; info[(size_t)stride + e] = reward;
-    StackState ss;
-    ss.arm = ps.arm; ss.box[0] = ps.box[0]; ss.box[1] = ps.box[1];
-    for (int k = 0; k < 3; k++) ss.box[2].pos[k] = 100.0;      // the engine's third block is not part of this task: parked, inert
-    ss.box[2].quat[0] = 1; ss.box[2].quat[1] = ss.box[2].quat[2] = ss.box[2].quat[3] = 0;
-    for (int k = 0; k < 6; k++) ss.box[2].vel[k] = 0;
-    const double* sw = state + e + (size_t)PUSH_STATE_WARM * stride;      // warm start: cube 1 [6] cube 2 [6] arm [9]
-    for (int i = 0; i < 12; i++) t[ST_X + i] = sw[(size_t)i * stride];
-    for (int i = 12; i < 18; i++) t[ST_X + i] = 0;
-    for (int i = 0; i < NDOF; i++) t[ST_X + SK_ARM0 + i] = sw[(size_t)(12 + i) * stride];
-    sk_state_to_lds(t, ss);
-    for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ps.arm.ikq[k]; t[ST_TIPR + SV_IKQD + k] = ps.arm.ikqd[k]; t[ST_TIPR + SV_DES + k] = des[k]; t[ST_TIPR + SV_VWARM + k] = 0; }
-    fl = ps.arm.flags | ((ps.arm.flags & PF_WARM_VALID) ? SKF_WARM_VALID : 0u);
-    step = ps.arm.step;
   } else if (live) {
     StackState ss;
     stack_load(state, flags, steps, stride, e, ss);
@@ -434,23 +406,6 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
     info[e] = md;
     return;
   }
-  if constexpr (V == SKV_PUSHING) {
-    PushState ps;
-    ps.arm = ss.arm; ps.box[0] = ss.box[0]; ps.box[1] = ss.box[1];
-    for (int k = 0; k < NARM; k++) { ps.arm.ikq[k] = t[ST_TIPR + SV_IKQ + k]; ps.arm.ikqd[k] = t[ST_TIPR + SV_IKQD + k]; }
-    ps.arm.flags = (fl & ~SKF_WARM_VALID) | F_IK_VALID | PF_WARM_VALID;
-    if (bad) ps.arm.flags |= F_SOLVER_FAIL | F_TERMINATED;
-    double md = 0;
-    push_step_end(g_push_consts, ps, &md);
-    push_store(state, flags, steps, stride, e, ps, true);
-    double* sw = state + e + (size_t)PUSH_STATE_WARM * stride;
-    for (int i = 0; i < 12; i++) sw[(size_t)i * stride] = t[ST_X + i];
-    for (int i = 0; i < NDOF; i++) sw[(size_t)(12 + i) * stride] = t[ST_X + SK_ARM0 + i];
-    success[e] = (ps.arm.flags & F_SUCCESS) ? 1 : 0;
-    mode[e] = (unsigned short)(short)((int)((ps.arm.flags & PF_MODE_MASK) >> PF_MODE_SHIFT) - 1);
-    info[e] = md;
-    return;
-  }
   for (int i = 0; i < SK_NV; i++) ss.warm[i] = t[ST_X + i];
   if (reset) {
     float o[SK_OBS];
@@ -477,17 +432,6 @@ __global__ __launch_bounds__(WAVE) void k_stacking_step(double* __restrict__ sta
                                                         const double* __restrict__ contexts) {
   coop_step_body<SKV_STACKING>(state, flags, steps, actions, obs, done, success, mode, info, scratch, n, stride, n_substeps, max_steps, reset, reset_mask, init_qpos, contexts);
 }
-// env.step() for the Pushing task on the wave-cooperative engine (variant 1 of the Stacking engine: the rod robot, two cubes + an inert third
-// block, rod <-> cube contacts by cyl_box, Cartesian controller evaluated by the environment's lane): 4 environments per one-wave workgroup,
-// 1024 workgroups for 4096 environments = every SIMD of the chip, where the two-wave kernel (k_pushing_step_split, 24 environments per
-// workgroup) runs on 171 CUs.  actions f64 [n][7], state layout of the Pushing task (D3IL_PUSH_STATE_*).
-__global__ __launch_bounds__(WAVE) void k_pushing_step_coop(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,
-                                                            const double* __restrict__ actions, float* __restrict__ obs, unsigned char* __restrict__ done,
-                                                            unsigned char* __restrict__ success, unsigned short* __restrict__ mode, double* __restrict__ info,
-                                                            double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
-  coop_step_body<SKV_PUSHING>(state, flags, steps, actions, obs, done, success, mode, info, scratch, n, stride, n_substeps, max_steps, 0, nullptr, nullptr, nullptr);
-}
-
 // env.step() / env.reset() for the Aligning task on the wave-cooperative engine, variant 2: the rod robot and one free compound
 // body of five box geoms; actions f64 [n][7] (the harness commands x, y and z), state layout D3IL_ALIGN_STATE_*, contexts f64 [n][14].
 __global__ __launch_bounds__(WAVE) void k_aligning_step(double* __restrict__ state, unsigned* __restrict__ flags, int* __restrict__ steps,

@@ -21,7 +21,7 @@
 // Execution: ONE LANE PER ENVIRONMENT (first, correctness-first version): vectors, the packed 27 x 27 Hessian and the kinematic tables
 // of a lane's environment sit in LDS (lane-strided), contact records in an HBM scratch area.  Host build: tests/hostcheck.
 #pragma once
-#include "push_step.h"
+#include "rigid_common.h"
 
 namespace d3il {
 
@@ -56,8 +56,8 @@ struct StackConsts {
   double hand_center[3], hand_r, invw_hand;              // centroid of the hull (seeds the MPR portal), bounding radius about it, translational body_invweight0 of the hand body
   int hand_nv, hand_pad;
   double hand_v[SK_MAXHANDV][3];                         // convex hull of handv.stl (773 vertices), geom frame
-  // Pushing variant of the engine (variant 1: the rod robot of panda_rod_invisible.xml, two free cubes + an inert third block, rod <-> cube contacts,
-  // Cartesian controller): rod cylinder in the link-7 frame, translational body_invweight0 of the rod body
+  // rod-robot variants of the engine (panda_rod_invisible.xml, Cartesian controller; today: Aligning): rod cylinder in the link-7 frame, translational
+  // body_invweight0 of the rod body
   int variant, var_pad;
   double rod_c7[3], rod_u7[3], rod_r, rod_h, invw_rod;
   double box_invw[SK_NB];      // translational body_invweight0 of the free bodies (1 / mass for a body whose centre of mass is its origin)
@@ -71,9 +71,9 @@ struct StackConsts {
   double al_c[3], al_r;                                // centre of mass in the body frame; bounding radius of the whole body about its origin
   int al_set_static[5], al_set_rod[5];                 // contact parameter set of geom g against static s (+ s) / against the rod
 };
-enum { SKV_STACKING = 0, SKV_PUSHING = 1, SKV_ALIGNING = 2 };
+enum { SKV_STACKING = 0, SKV_ALIGNING = 2 };      // (1 was the Pushing variant of rounds 3 - 5; Pushing runs on the generic engine)
 constexpr int AL_NG = 5;
-// Pushing variant: the finger-geom tables of the t area are not needed; their place holds the rod pose and the controller state
+// rod-robot variants: the finger-geom tables of the t area are not needed; their place holds the rod pose and the controller state
 constexpr int SV_ROD = 0 /* + ST_TIPR: rod centre[3], axis[3] */, SV_IKQ = 6, SV_IKQD = 13, SV_DES = 20 /* desired pose pos[3] quat[4] */, SV_VWARM = 27 /* 7 */, SV_END = 34;
 // Aligning variant: + the centripetal acceleration of the body origin relative to the centre of mass, w x (w x R c) in the world frame [3], and the hold flag of a reset
 constexpr int SV_CEN = 34, SV_HOLD = 37, SV_END2 = 38;
@@ -1275,7 +1275,7 @@ D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, 
     double R7[9], p7[3], ax[NARM][3], og[NARM][3];
     world_chain(c0, dyn.sn, dyn.cs, R7, p7, ax, og);
     for (int k = 0; k < NARM; k++) for (int i = 0; i < 3; i++) { SL(ST_Z + 3 * k + i) = ax[k][i]; SL(ST_O + 3 * k + i) = og[k][i]; }
-    if constexpr (V == SKV_PUSHING || V == SKV_ALIGNING) {      // rod cylinder: centre and axis in the world
+    if constexpr (V == SKV_ALIGNING) {      // rod cylinder: centre and axis in the world
       double t3[3];
       mulE(R7, kc.rod_c7, t3);
       for (int i = 0; i < 3; i++) SL(ST_TIPR + SV_ROD + i) = p7[i] + t3[i];
@@ -1651,9 +1651,6 @@ __device__ __forceinline__ void sk_support1_group_lp(const StackConsts& kc_, con
 // Results per environment: t[SE_NCON] = contacts kept (<= SK_MAXCON), t[SE_NEED] = 256 when contacts were dropped.
 constexpr int SKP_GROUPS = 16;
 static_assert(SKP_GROUPS * SK_LANES <= WAVE, "the lane-per-pair collision needs 16 lanes per environment");
-// Pushing variant: lane = group * SK_LANES + environment with group 0 .. 1: cube b against the static slabs (one per round), 2: the cube pair,
-// 3 .. 4: the rod cylinder against cube b (cyl_box: one contact, normal from the cube to the rod)
-constexpr int SKP_GROUPS_PUSH = 5;
 struct SkJob { int kind, ba, bb, set, hullA, hullB; double margin; };      // kind: 0 none, 1 box-box, 2 MPR (eight-lane group), 3 MPR against the hand hull (whole wave)
 // the job of lane L in a round (L may be another lane: the MPR groups rebuild their owner's job); shapes from the tables of L's environment
 __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* smem, const int L, const int round, const unsigned live_mask,
@@ -1702,40 +1699,6 @@ __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* s
       if (dot3(dd, dd) <= rc * rc) { j.kind = 4; j.ba = 0; j.bb = SKB_ROD; j.set = set; }
     }
     if (j.kind != 0) j.margin = kc.set[j.set].margin;
-    return j;
-  }
-  if (kc.variant == SKV_PUSHING) {
-    if (grp < 2) {
-      if (round < kc.ns) {
-        const int sidx = round, b = grp;
-        box_shape(b, RB, pB, hB);
-        double d[3] = {pB[0] - kc.st_c[sidx][0], pB[1] - kc.st_c[sidx][1], pB[2] - kc.st_c[sidx][2]}, ex = 0;
-        for (int i = 0; i < 3; i++) { double loc = kc.st_R[sidx][i] * d[0] + kc.st_R[sidx][3 + i] * d[1] + kc.st_R[sidx][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[sidx][i]; if (o > 0) ex += o * o; }
-        const double rc = kc.box_r[b] + kc.set[SKS_STATIC + sidx].margin;
-        if (ex <= rc * rc) {
-          j.kind = 1; j.ba = SKB_STATIC; j.bb = b; j.set = SKS_STATIC + sidx;
-          for (int k = 0; k < 9; k++) RA[k] = kc.st_R[sidx][k];
-          for (int k = 0; k < 3; k++) { pA[k] = kc.st_c[sidx][k]; hA[k] = kc.st_h[sidx][k]; }
-        }
-      }
-    } else if (grp == 2) {
-      if (round == 0) { box_shape(0, RA, pA, hA); box_shape(1, RB, pB, hB); j.kind = 1; j.ba = 0; j.bb = 1; j.set = SKS_BOXBOX; rsum = kc.box_r[0] + kc.box_r[1]; }
-    } else if (grp < SKP_GROUPS_PUSH) {
-      if (round == 0) {      // rod <-> cube: pA = rod centre, RA[0..2] = rod axis, hA = (radius, half length, -)
-        const int b = grp - 3;
-        box_shape(b, RB, pB, hB);
-        ld(ST_TIPR + SV_ROD, 3, pA); ld(ST_TIPR + SV_ROD + 3, 3, RA);
-        hA[0] = kc.rod_r; hA[1] = kc.rod_h; hA[2] = 0;
-        const double w[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]};
-        const double al = fmin(fmax(w[0] * RA[0] + w[1] * RA[1] + w[2] * RA[2], -kc.rod_h), kc.rod_h);      // closest point of the axis segment to the cube centre
-        const double dd[3] = {w[0] - al * RA[0], w[1] - al * RA[1], w[2] - al * RA[2]}, rc = kc.box_r[b] + kc.rod_r + kc.set[SKS_BOXROD].margin;
-        if (dot3(dd, dd) <= rc * rc) { j.kind = 4; j.ba = b; j.bb = SKB_ROD; j.set = SKS_BOXROD; }
-      }
-    }
-    if (j.kind != 0) {
-      j.margin = kc.set[j.set].margin;
-      if (rsum > 0) { const double d[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]}, rc = rsum + j.margin; if (dot3(d, d) > rc * rc) j.kind = 0; }
-    }
     return j;
   }
   if (grp < 3) {
@@ -2318,35 +2281,6 @@ D3IL_HOSTFN inline int build_stack_consts(const d3il_model_blob& m, const PandaC
       kc.invw_hand = std::fmax(1e-15, tr / 3);
     }
   }
-  return 0;
-}
-
-// Constants of the Pushing variant of the engine, from the Pushing constants (push_step.h) and the arm constants of the rod robot
-D3IL_HOSTFN inline int build_coop_push_consts(const PandaConsts& pcst, const PushConsts& pc, StackConsts& kc, const char** err) {
-  std::memset(&kc, 0, sizeof kc);
-  kc.variant = SKV_PUSHING; kc.nb = PUSH_NB; kc.ns = 2;
-  for (int b = 0; b < SK_NB; b++) {
-    const bool real = b < PUSH_NB;
-    for (int k = 0; k < 3; k++) { kc.box_half[b][k] = real ? pc.box_half[k] : 0.01; kc.box_inertia[b][k] = real ? pc.box_inertia : 1.0; }
-    kc.box_mass[b] = real ? pc.box_mass : 1.0; kc.box_invw[b] = 1.0 / kc.box_mass[b];
-    kc.box_r[b] = std::sqrt(kc.box_half[b][0] * kc.box_half[b][0] + kc.box_half[b][1] * kc.box_half[b][1] + kc.box_half[b][2] * kc.box_half[b][2]);
-  }
-  if (std::fabs(pc.box_invw_t * pc.box_mass - 1.0) > 1e-12) { *err = "cube invweight"; return -1; }
-  for (int s2 = 0; s2 < 2; s2++) {
-    for (int k = 0; k < 3; k++) { kc.st_c[s2][k] = pc.slab_c[s2][k]; kc.st_h[s2][k] = pc.slab_h[s2][k]; }
-    kc.st_R[s2][0] = kc.st_R[s2][4] = kc.st_R[s2][8] = 1.0;
-  }
-  auto fill = [&](StackSet& ps, int i) {
-    ps.K = pc.ct_K[i]; ps.B = pc.ct_B[i];
-    for (int k = 0; k < 5; k++) ps.solimp[k] = pc.ct_solimp[i][k];
-    ps.fric[0] = pc.ct_fric[i]; ps.fric[1] = 0.005; ps.fric[2] = 0.0001;      // condim 3: only the sliding coefficient enters
-    ps.margin = 0.0; ps.dim = 3;
-  };
-  fill(kc.set[SKS_STATIC + 0], 0); fill(kc.set[SKS_STATIC + 1], 0); fill(kc.set[SKS_BOXBOX], 1); fill(kc.set[SKS_BOXROD], 1);
-  kc.impratio = pc.impratio;
-  for (int k = 0; k < 2; k++) { kc.ws_lo[k] = pc.slab_c[0][k] - (pc.slab_h[0][k] - 0.06); kc.ws_hi[k] = pc.slab_c[0][k] + (pc.slab_h[0][k] - 0.06); }      // push_step.h: PF_OFF_TABLE
-  for (int k = 0; k < 3; k++) { kc.rod_c7[k] = pcst.rod_c7[k]; kc.rod_u7[k] = pcst.rod_u7[k]; }
-  kc.rod_r = pcst.rod_r; kc.rod_h = pcst.rod_h; kc.invw_rod = pcst.rod_invweight0;
   return 0;
 }
 

@@ -159,13 +159,13 @@ class ObstacleAvoidanceVecEnv:
         st = np.zeros((self.state_rows, self.n_envs))
         fl = np.zeros(self.n_envs, dtype=np.uint32)
         sc = np.zeros(self.n_envs, dtype=np.int32)
-        capi.check(self.L.d3il_get_state(self.h, st.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
+        capi.check(self.L.d3il_get_state(self.h, st.ctypes.data_as(C.c_void_p), st.shape[0], fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
         return st, fl, sc
 
     def set_state(self, st, fl, sc):
         st = np.ascontiguousarray(st, np.float64); fl = np.ascontiguousarray(fl, np.uint32); sc = np.ascontiguousarray(sc, np.int32)
-        assert st.shape == (self.state_rows, self.n_envs)
-        capi.check(self.L.d3il_set_state(self.h, st.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
+        assert st.ndim == 2 and st.shape[1] == self.n_envs      # the row count is checked by the library (D3IL_EINVAL on a mismatch)
+        capi.check(self.L.d3il_set_state(self.h, st.ctypes.data_as(C.c_void_p), st.shape[0], fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
 
     def policy_begin(self, mask: torch.Tensor | None = None):
         mp = None

@@ -5,8 +5,9 @@ The reference spreads an evaluation over ``n_cores`` worker processes, each step
 The counterpart on one GPU: the rollouts of a rank are cut into S contiguous sub-batches; each owns an environment handle
 (its own state buffers, tally and kernel launches), a HIP stream and a clone of the agent's per-episode state.  A step launch lasts as
 long as its slowest workgroup, and launches of different streams overlap - sub-batch B's physics runs while sub-batch A's policy does
-(DESIGN section 18.10).  Rollouts are independent of each other, so the integer result tables are those of one batch
-(tests/test_subbatch_sims_gpu.py).
+(DESIGN section 18.10).  Rollouts are independent of each other, so for a policy that computes every row from that row alone (deterministic, or seeded
+per rollout) the integer result tables are those of one batch (tests/test_subbatch_sims.py); a policy that draws from the process-wide torch generator
+(DDPM / BESO: torch.randn per predict call) draws in another order per sub-batch - the same distribution, not the same table.
 
 Used by the Sim classes (``n_sub_batches=``) and by ``bench.py`` (``--sub-batches``).
 """
@@ -124,10 +125,12 @@ class SubBatchSet:
         if len(self.batches) == 1:
             fn(self.batches[0])
             return
-        for b in self.batches:
-            torch.cuda.set_stream(b.stream)
-            fn(b)
-        torch.cuda.set_stream(self.default_stream)
+        try:
+            for b in self.batches:
+                torch.cuda.set_stream(b.stream)
+                fn(b)
+        finally:      # also when fn raises (a library error, an assert inside a policy): the process must not stay on a sub-batch stream
+            torch.cuda.set_stream(self.default_stream)
 
     def join(self):
         """The caller's stream waits for everything queued on the sub-batch streams (no host synchronisation)."""

@@ -66,8 +66,13 @@ class ResidualMLP(nn.Module):
 
     def ensure_packed(self):
         """Refresh the packed weight buffers of the device path (in place) if a parameter has changed - what a captured graph's owner calls before a replay."""
-        if getattr(self, "_fused", None) is not None and self._fused._key is not None:
+        if getattr(self, "_fused", None) is not None and self._fused._fw is not None:
             self._fused.ensure_packed(self._parts())
+
+    def invalidate_packed(self):
+        """After ``param.data`` writes (invisible to the version counters): the next call / ensure_packed() repacks."""
+        if getattr(self, "_fused", None) is not None:
+            self._fused.invalidate()
 
     def forward(self, x):
         x = x.to(torch.float32)
@@ -220,6 +225,10 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
         return self._fused_static_ok() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 120 and x.data_ptr() % 16 == 0 and x.shape[1] <= 32
+
+    def invalidate_packed(self):
+        """Force a repack at the next ensure_packed() (after ``param.data`` writes, which the version counters do not see)."""
+        self._pack_key = None
 
     def ensure_packed(self):
         """Packed copies of the block's weights in the tile order of the matrix-core kernels, in PERSISTENT device buffers refreshed in place whenever a
@@ -404,11 +413,17 @@ class FusedResMLP:
     def __init__(self):
         self._fw, self._key = None, None
 
+    def invalidate(self):
+        """Force a repack at the next ensure_packed().  Needed after writes that bypass the tensors' version counters - ``param.data.copy_(...)`` as the
+        reference's EMA helper does in copy_to / restore (agents/models/.../ema.py) - which the (data_ptr, _version) key cannot see; ``use_ema()``,
+        ``load_state_dict`` and in-place ops on the parameters themselves are detected without it."""
+        self._key = None
+
     def ok(self, x, parts):
         lin_in, blocks, lin_out = parts
         w = lin_in.weight
-        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
-            return False      # inference only: no autograd node
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for l in [lin_in, lin_out] + [m for b in blocks for m in b] for p in (l.weight, l.bias))):
+            return False      # inference only: no autograd node (ANY trainable layer sends the call to torch's layers, not only a trainable first one)
         return (x.is_cuda and x.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and lin_in.out_features in (128, 256) and lin_in.in_features <= 28
                 and lin_out.out_features <= 16 and os.environ.get("D3IL_POLICY_FUSED_RESMLP", "1") == "1")
 
@@ -561,6 +576,12 @@ class DDPMPolicy:
         return (self.W <= 1 and isinstance(m, DiffusionMLP) and L[0].weight.is_cuda and L[0].weight.dtype == torch.float32 and L[0].out_features == 256 and L[-1].out_features == 2
                 and m.temp_layers[-1].out_features == 8 and 1 <= L[0].in_features - 10 <= 18 and all(isinstance(b, _ResBlock) for b in L[1:-1])
                 and os.environ.get("D3IL_POLICY_FUSED_DDPM", "1") == "1")
+
+    def invalidate_packed(self):
+        """Force a repack at the next call.  Needed after writes through ``param.data`` (e.g. the reference EMA helper's copy_to / restore), which do not bump the
+        version counters ensure_packed() keys on; use_ema() and load_state_dict are seen without it."""
+        self._pack_key = None
+        self.model.layers.invalidate_packed()
 
     def ensure_packed(self):
         """The denoiser's weights in the tile order of the kernel, the time embeddings of the T steps and the schedule table, in persistent device buffers

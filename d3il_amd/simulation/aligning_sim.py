@@ -15,9 +15,10 @@ import logging
 import numpy as np
 import torch
 
-from ..agents import as_batched
 from ..distributed import reduce_sim_counts, shard_range, world_info
 from ..envs.aligning import RobotPushVecEnv, contexts_from_reference, load_test_contexts
+from ..envs.sub_batch import SubBatchSet
+from ._rollout import xyz_rollout
 from .base_sim import BaseSim
 from .metrics import pushing_metrics
 
@@ -27,8 +28,10 @@ N_MODES = 2
 
 class Aligning_Sim(BaseSim):
     def __init__(self, seed: int, device: str, render: bool, n_cores: int = 1, n_contexts: int = 30, n_trajectories_per_context: int = 1,
-                 if_vision: bool = False, max_steps_per_episode: int = 400, contexts: np.ndarray | None = None):
+                 if_vision: bool = False, max_steps_per_episode: int = 400, contexts: np.ndarray | None = None, n_sub_batches: int = 1):
         super().__init__(seed, device, render, n_cores, if_vision)
+        # the reference's n_cores worker processes (aligning_sim.py:125-160) become sub-batches of the GPU batch on their own streams (envs/sub_batch.py)
+        self.n_sub_batches = n_sub_batches
         if if_vision:
             raise NotImplementedError("the batched rollout path serves state observations (SURVEY section 2: vision is out of scope)")
         self.n_contexts = n_contexts
@@ -52,33 +55,25 @@ class Aligning_Sim(BaseSim):
         n = hi - lo
         dev = torch.device(self.device)
         ctx_of = torch.arange(lo, hi, device=dev) // self.n_trajectories_per_context
-        agent = as_batched(agent, n)
-        agent.reset()
-        quat = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev).expand(n, 4)
-        finished = torch.zeros(n, dtype=torch.bool, device=dev)
         mode = torch.full((n,), -1, dtype=torch.int64, device=dev)
         success = torch.zeros(n, dtype=torch.bool, device=dev)
         mean_distance = torch.zeros(n, dtype=torch.float64, device=dev)
-        env, flags = None, torch.zeros(0, dtype=torch.int32, device=dev)
+        batches, env, flags = None, None, torch.zeros(0, dtype=torch.int32, device=dev)
         if n > 0:      # a rank whose shard is empty only takes part in the reductions below
-            env = RobotPushVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
-            env.start()
-            obs = env.reset(random=False, context=self.contexts[ctx_of.cpu().numpy()])
-            des = env.robot_state().clone()                                  # pred_action = env.robot_state(), aligning_sim.py:96
-            for t in range(self.max_steps_per_episode):
-                obs20 = torch.cat((des, obs.to(torch.float64)), dim=1)       # np.concatenate((pred_action[:3], obs)), aligning_sim.py:99
-                des_new = self._predict(agent, obs20) + obs20[:, :3]          # aligning_sim.py:101-102
-                des = torch.where(finished.unsqueeze(1), des, des_new)
-                action = torch.cat((des, quat), dim=1).contiguous()
-                obs, _, done, info = env.step(action)
-                newly = ~finished & done.bool()
-                mode = torch.where(newly, info["mode"].to(torch.int64), mode)
-                success = torch.where(newly, info["success"].bool(), success)
-                mean_distance = torch.where(newly, info["mean_distance"], mean_distance)
-                finished |= done.bool()
-                if t % 16 == 15 and bool(finished.all()):                  # the only host synchronisation of the loop
-                    break
-            flags = env.flags[:n].clone()
+            ctx_np = self.contexts[ctx_of.cpu().numpy()]
+
+            def make_env(cnt, off):
+                e = RobotPushVecEnv(cnt, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
+                e.start()
+                e.reset(random=False, context=ctx_np[off:off + cnt])
+                return e
+            batches = SubBatchSet(n, self.n_sub_batches, dev, make_env)
+            batches.fork_agents(agent)
+            # the rollout loop of aligning_sim.py:96-108 per sub-batch (simulation/_rollout.py)
+            res = xyz_rollout(batches, self.max_steps_per_episode, {"mode": (torch.int64, -1), "success": (torch.bool, False), "mean_distance": (torch.float64, 0.0)},
+                              predict=self._predict)
+            mode, success, mean_distance, flags = res["mode"], res["success"], res["mean_distance"], res["flags"]
+            env = batches.batches[0].env
         # integer tables: mode counts of the successful rollouts per context, number of successes; f64 distance sum
         counts = torch.zeros(self.n_contexts * N_MODES + 1, dtype=torch.int64, device=dev)
         ok = success & (mode >= 0)
@@ -94,8 +89,8 @@ class Aligning_Sim(BaseSim):
         self.last_rollout = dict(mode=mode, success=success, mean_distance=mean_distance, counts=c, shard=(lo, hi), success_rate=success_rate, entropy=entropy,
                                  mode_probs=mode_probs, mean_distance_all=float(dist_sum.item()) / total, flags=flags, score=0.5 * (success_rate + entropy))
         log.info("Successrate %s entropy %s mean distance %s", success_rate, entropy, float(dist_sum.item()) / total)
-        if env is not None:
-            env.close()
+        if batches is not None:
+            batches.close()
         # the reference returns (success_rate, mode_encoding[n_contexts, n_trajectories]) (aligning_sim.py:205); its tables are zero-initialised, so a
         # rollout that never reported a mode reads 0 there.  The full tables stay available in self.last_rollout (+ "tables" below).
         full = torch.zeros(3, total, dtype=torch.float64, device=dev)

@@ -19,9 +19,10 @@ import os
 import numpy as np
 import torch
 
-from ..agents import as_batched
 from ..distributed import reduce_sim_counts, shard_range, world_info
 from ..envs.stacking import CubeStackingVecEnv, load_test_contexts
+from ..envs.sub_batch import SubBatchSet
+from ._rollout import joint_rollout
 from .base_sim import BaseSim
 from .metrics import stacking_metrics
 
@@ -70,8 +71,10 @@ def _code_tables(dev):
 
 class Stacking_Sim(BaseSim):
     def __init__(self, seed: int, device: str, render: bool, n_cores: int = 1, n_contexts: int = 30, n_trajectories_per_context: int = 1,
-                 max_steps_per_episode: int = 500, contexts: np.ndarray | None = None, mode_prob: dict | None = None):
+                 max_steps_per_episode: int = 500, contexts: np.ndarray | None = None, mode_prob: dict | None = None, n_sub_batches: int = 1):
         super().__init__(seed, device, render, n_cores)
+        # the reference's n_cores worker processes (stacking_sim.py:182-216) become sub-batches of the GPU batch on their own streams (envs/sub_batch.py)
+        self.n_sub_batches = n_sub_batches
         self.n_contexts, self.n_trajectories_per_context = n_contexts, n_trajectories_per_context
         self.max_steps_per_episode = max_steps_per_episode
         self.test_contexts = load_test_contexts() if contexts is None else np.asarray(contexts, dtype=np.float64)
@@ -87,32 +90,24 @@ class Stacking_Sim(BaseSim):
         n = hi - lo
         dev = torch.device(self.device)
         ctx_of = torch.arange(lo, hi, device=dev) // self.n_trajectories_per_context
-        agent = as_batched(agent, n)
-        agent.reset()
-        finished = torch.zeros(n, dtype=torch.bool, device=dev)
         mode = torch.zeros(n, dtype=torch.int64, device=dev)
         success = torch.zeros(n, dtype=torch.bool, device=dev)
         mean_distance = torch.zeros(n, dtype=torch.float64, device=dev)
-        env, flags = None, torch.zeros(0, dtype=torch.int32, device=dev)
+        batches, env, flags = None, None, torch.zeros(0, dtype=torch.int32, device=dev)
         if n > 0:      # a rank whose shard is empty only takes part in the reductions below
-            env = CubeStackingVecEnv(n, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
-            env.start()
-            obs = env.reset(random=False, context=self.test_contexts[ctx_of.cpu().numpy()])
-            pred_action = env.robot_state().to(torch.float32)              # stacking_sim.py:90-91
-            for t in range(self.max_steps_per_episode):
-                obs20 = torch.cat((pred_action, obs), dim=1)                # np.concatenate((pred_action, obs)), stacking_sim.py:99
-                out = agent.predict_batch(obs20).to(device=dev, dtype=torch.float32).reshape(n, 8)
-                new_action = torch.cat((out[:, :7] + obs20[:, :7], out[:, 7:8]), dim=1)   # pred_action[:7] += obs[:7], stacking_sim.py:104
-                pred_action = torch.where(finished.unsqueeze(1), pred_action, new_action)
-                obs, _, done, info = env.step(pred_action.to(torch.float64).contiguous())
-                newly = ~finished & done.bool()
-                mode = torch.where(newly, info["mode"].to(torch.int64), mode)
-                success = torch.where(newly, info["success"].bool(), success)
-                mean_distance = torch.where(newly, info["mean_distance"], mean_distance)
-                finished |= done.bool()
-                if t % 16 == 15 and bool(finished.all()):                   # the only host synchronisation of the loop
-                    break
-            flags = env.flags[:n].clone()
+            ctx_np = self.test_contexts[ctx_of.cpu().numpy()]
+
+            def make_env(cnt, off):
+                e = CubeStackingVecEnv(cnt, device=dev, render=False, max_steps_per_episode=self.max_steps_per_episode)
+                e.start()
+                e.reset(random=False, context=ctx_np[off:off + cnt])
+                return e
+            batches = SubBatchSet(n, self.n_sub_batches, dev, make_env)
+            batches.fork_agents(agent)
+            # the rollout loop of stacking_sim.py:88-109 per sub-batch (simulation/_rollout.py)
+            res = joint_rollout(batches, self.max_steps_per_episode, {"mode": (torch.int64, 0), "success": (torch.bool, False), "mean_distance": (torch.float64, 0.0)})
+            mode, success, mean_distance, flags = res["mode"], res["success"], res["mean_distance"], res["flags"]
+            env = batches.batches[0].env
         # integer tables (stacking_sim.py:118-136, 143-151): per context, rollouts by the index of their 1- / 2- / 3-letter colour order
         t1, t2, t3 = _code_tables(dev)
         m1, m2, m3 = t1[mode & 255], t2[mode & 255], t3[mode & 255]
@@ -136,8 +131,8 @@ class Stacking_Sim(BaseSim):
                                total, self.n_trajectories_per_context, self.mode_encoding_1, self.mode_encoding_2, self.mode_encoding_3)
         self.last_rollout = dict(mode=mode, success=success, success_1=s1, success_2=s2, mean_distance=mean_distance, counts=c, shard=(lo, hi), flags=flags, metrics=res)
         log.info("Successrate %s (1 box %s, 2 boxes %s)", res["successes"], res["successes_1_box"], res["successes_2_boxes"])
-        if env is not None:
-            env.close()
+        if batches is not None:
+            batches.close()
         # the reference returns (successes, mode_encoding) as [n_contexts, n_trajectories] tables (stacking_sim.py:257)
         full = torch.zeros(2, total, dtype=torch.float64, device=dev)
         full[0, lo:hi] = success.to(torch.float64)

@@ -40,7 +40,7 @@ enum {
  * their shapes:
  *   task      reference env (environments/d3il/envs/...)            action (device f64, row-major)              obs f32   contexts f64     state rows
  *   Avoiding  gym_avoiding/envs/avoiding.py ObstacleAvoidanceEnv    [n][7] desired TCP x y z qw qx qy qz        [n][2]    none             42
- *   Pushing   gym_pushing/envs/pushing.py Block_Push_Env            [n][7] same                                 [n][8]    [n][14]          89
+ *   Pushing   gym_pushing/envs/pushing.py Block_Push_Env            [n][7] same                                 [n][8]    [n][14]          91
  *   Sorting   gym_sorting/envs/sorting.py Sorting_Env (2 / 4 boxes) [n][7] same                                 [n][2+3b] [n][7 b]         42+13b+(9+6b)+2
  *   Stacking  gym_stacking/envs/stacking.py CubeStacking_Env        [n][8] 7 desired joint positions + gripper   [n][12]   [n][21]          94
  *                                                                   command (open iff > 0.075, stacking.py:337-346)
@@ -58,8 +58,10 @@ enum {
   D3IL_STATE_IK_QD = 35,  /* 7: CartPosQuatImpedenceController.old_des_joint_vel */
   D3IL_STATE_F64 = 42,
   /* Pushing appends: per cube pos[3] quat[4] vel[6] (qpos/qvel of its free joint: linear velocity in world axes, angular
-   * velocity in body axes), then the constraint solver's warm start qacc[21] (cube1, cube2, arm) */
-  D3IL_PUSH_STATE_BOX = 42, D3IL_PUSH_STATE_WARM = 68, D3IL_PUSH_STATE_F64 = 89,
+   * velocity in body axes), then the constraint solver's warm start qacc[21] (cube1, cube2, arm), then the two task rows info['mean_distance'] and reward
+   * (pushing.py:335-407) - d3il_buffers.info_f64 points AT these two rows (a view of the state buffer, no copy).  91 rows since the task runs on the generic
+   * engine (library version 2; 89 before: a version-1 checkpoint lacks the task rows).  Size state buffers from d3il_buffers.state_rows, not from a constant. */
+  D3IL_PUSH_STATE_BOX = 42, D3IL_PUSH_STATE_WARM = 68, D3IL_PUSH_STATE_TASK = 89, D3IL_PUSH_STATE_F64 = 91,
   /* Sorting-4 (sorting.py): per cube pos[3] quat[4] vel[6] in the order red_1, red_2, blue_1, blue_2, the solver's warm start
    * qacc[33] (cubes, arm), then the task state of Sorting_Env as two words stored as doubles: word 0 = mode[6], two bits each
    * (value + 1), | mode_step << 12;  word 1 = min_inds[6], three bits each (sorting.py:405-411, 460-507) */
@@ -115,7 +117,7 @@ typedef struct d3il_buffers {
   int32_t* step_count;   /* [stride] env_step_counter */
   double* policy_des;    /* [3][stride] random-policy harness state: desired x, y and fixed z */
   double* info_f64;      /* [n_info_f64][stride] extra f64 step outputs; Pushing: info['mean_distance'], reward (pushing.py:335-407); Stacking: info['mean_distance'] */
-  int32_t n_info_f64, state_rows;   /* state_rows: f64 state fields per environment (42 Avoiding, 89 Pushing, 129 Sorting-4, 94 Stacking) */
+  int32_t n_info_f64, state_rows;   /* state_rows: f64 state fields per environment (42 Avoiding, 91 Pushing, 129 Sorting-4, 94 Stacking, 77 Aligning, 110 Inserting) */
   uint8_t* last_reset;   /* [n_envs] environments reset by the last d3il_auto_reset (non-zero): per-lane harness / agent state re-latches from it */
 } d3il_buffers;
 
@@ -147,9 +149,11 @@ int d3il_step(d3il_handle h, const double* actions, void* stream);
 int d3il_get_buffers(d3il_handle h, d3il_buffers* out);
 
 /* Golden replay / checkpointing: copies the SoA state + flags + step counters to/from host memory
- * (state: f64[state_rows][n_envs] packed with stride n_envs; flags u32[n_envs]; steps i32[n_envs]). */
-int d3il_get_state(d3il_handle h, double* state, uint32_t* flags, int32_t* steps);
-int d3il_set_state(d3il_handle h, const double* state, const uint32_t* flags, const int32_t* steps);
+ * (state: f64[state_rows][n_envs] packed with stride n_envs; flags u32[n_envs]; steps i32[n_envs]; any of the three may be NULL).
+ * state_rows = the row count the CALLER's buffer was sized for; it must equal d3il_buffers.state_rows of the handle, otherwise nothing is copied
+ * and D3IL_EINVAL is returned (a buffer sized from a stale constant cannot be overrun, a checkpoint of another layout cannot be loaded). */
+int d3il_get_state(d3il_handle h, double* state, int32_t state_rows, uint32_t* flags, int32_t* steps);
+int d3il_set_state(d3il_handle h, const double* state, int32_t state_rows, const uint32_t* flags, const int32_t* steps);
 
 /* Device-side random-policy harness of BASELINE config 2, counterpart of the rollout loop in
  * simulation/avoiding_sim.py:51-66 with agent.predict := U(-0.01, 0.01)^2 (Philox4x32-10, key = seed,
@@ -257,9 +261,6 @@ int d3il_random_rollout_prepare(d3il_handle h, uint64_t seed, uint64_t env_offse
  * rare constraint paths (rod contact, arm joint limits) for the physics wave; above it (more than one workgroup per CU) the two-wave form runs; 0 = always two waves (A/B);
  * "solver_strict" (default 0): 1 = the contact solvers of Pushing / Sorting / Stacking iterate to round-off like the CPU oracle (parity A/B);
  * "stack_reset_coop" (default 1): Stacking env.reset() through the step kernel's wave-cooperative phases, 0 = the one-lane reset kernel (A/B);
- * "push_coop" (default 0): 1 = Pushing env.step() on the Pushing variant of the wave-cooperative Stacking engine (4 environments per one-wave workgroup; a second,
- * independent device implementation of the same step: parity-tested, measured SLOWER than the two-wave kernel - 0.50 vs 0.65 M env-steps/s -, kept for cross-checks;
- * only with the round-1 Pushing engine, D3IL_PUSH_ENGINE=legacy - by default Pushing runs on the generic engine of Sorting / Inserting);
  * "graph_rollout" (default 0): Avoiding - d3il_random_rollout_step is captured once per handle (HIP graph: policy kernel with the step counter in device memory,
  * step kernel, mask copy, tally, auto-reset, counter + 1) and a step becomes ONE hipGraphLaunch instead of eight runtime calls; needs a non-null stream
  * (the legacy default stream cannot be captured); any later option / timing / tally change drops the graphs, the next call re-captures.  With timing enabled every

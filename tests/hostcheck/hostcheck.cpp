@@ -91,44 +91,6 @@ void hc_env_step(const void* c, double* s, int* f, const double* action, float* 
   pack(st, s, f);
 }
 
-// ---------------------------------------------------------------- Pushing (push_step.h)
-struct PushHost { PandaConsts c; PushConsts pc; double h[PT_SIZE]; double g[PG_SIZE]; double w[PUSH_NV]; };
-void* hc_push_create(const d3il_model_blob* blob, const char** err) {
-  PushHost* p = (PushHost*)std::calloc(1, sizeof(PushHost));
-  static const char* e = "";
-  if (build_panda_consts(*blob, p->c, &e) || build_push_consts(*blob, p->pc, &e)) { *err = e; std::free(p); return nullptr; }
-  finish_invweights(p->c);
-  return p;
-}
-static void push_unpack(const double* s, const int* f, PushState& ps) {
-  unpack(s, f, ps.arm);
-  int k = PUSH_STATE_BOX;
-  for (int b = 0; b < PUSH_NB; b++) { for (int i = 0; i < 3; i++) ps.box[b].pos[i] = s[k++]; for (int i = 0; i < 4; i++) ps.box[b].quat[i] = s[k++]; for (int i = 0; i < 6; i++) ps.box[b].vel[i] = s[k++]; }
-}
-static void push_pack(const PushState& ps, double* s, int* f) {
-  pack(ps.arm, s, f);
-  int k = PUSH_STATE_BOX;
-  for (int b = 0; b < PUSH_NB; b++) { for (int i = 0; i < 3; i++) s[k++] = ps.box[b].pos[i]; for (int i = 0; i < 4; i++) s[k++] = ps.box[b].quat[i]; for (int i = 0; i < 6; i++) s[k++] = ps.box[b].vel[i]; }
-}
-int hc_push_state_size() { return PUSH_STATE_F64; }
-void hc_push_reset(void* h, const double* init_qpos, const double* ctx, double* s, int* f, float* obs) {
-  PushHost* p = (PushHost*)h; PushState ps; std::memset(&ps, 0, sizeof ps);
-  PushScratch sc{p->h, p->g, 1, p->w, 1};
-  push_env_reset(p->c, p->pc, ps, sc, init_qpos, ctx, obs); push_pack(ps, s, f); std::memcpy(s + PUSH_STATE_WARM, p->w, sizeof p->w);
-}
-void hc_push_step(void* h, double* s, int* f, const double* action, float* obs, double* reward, unsigned char* done, double* mean_distance, int fast) {
-  PushHost* p = (PushHost*)h; PushState ps; push_unpack(s, f, ps); std::memcpy(p->w, s + PUSH_STATE_WARM, sizeof p->w);
-  PushScratch sc{p->h, p->g, 1, p->w, 1};
-  if (fast) push_env_step<true>(p->c, p->pc, ps, sc, action, obs, reward, done, mean_distance, p->c.n_substeps, p->c.max_steps);
-  else push_env_step<false>(p->c, p->pc, ps, sc, action, obs, reward, done, mean_distance, p->c.n_substeps, p->c.max_steps);
-  push_pack(ps, s, f); std::memcpy(s + PUSH_STATE_WARM, p->w, sizeof p->w);
-}
-void hc_push_substep(void* h, double* s, int* f, const double* tau, const double* ffing, int* ncon_out) {
-  PushHost* p = (PushHost*)h; PushState ps; push_unpack(s, f, ps); std::memcpy(p->w, s + PUSH_STATE_WARM, sizeof p->w);
-  PushScratch sc{p->h, p->g, 1, p->w, 1};
-  push_physics_substep(p->c, p->pc, ps, sc, tau, ffing); push_pack(ps, s, f);
-  (void)ncon_out;
-}
 // ---------------------------------------------------------------- generic engine / Sorting (gen_step.h)
 struct GenHost { PandaConsts c; GenConsts gc; double h[GL_SIZE]; double g[GG_SIZE]; };
 void* hc_gen_create(const d3il_model_blob* blob, const char** err) {

@@ -11,7 +11,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libd3il_hostcheck.so")
-    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "push_step.h", "gen_step.h", "gen_tree.h", "stack_step.h")]
+    srcs = [os.path.join(_HERE, "hostcheck.cpp")] + [os.path.join(_HERE, "..", "..", "d3il_amd", "csrc", f) for f in ("panda_step.h", "panda_consts.h", "rigid_common.h", "gen_step.h", "gen_tree.h", "stack_step.h")]
     srcs.append(os.path.join(_HERE, "..", "..", "include", "d3il_model_blob.h"))
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
@@ -80,37 +80,6 @@ class HostCheck:
         return obs, bool(done[0])
 
 
-class PushHostCheck:
-    """Host build of the Pushing kernel math (d3il_amd/csrc/push_step.h), one environment."""
-
-    def __init__(self, blob):
-        self.L = lib()
-        self.L.hc_push_create.restype = C.c_void_p
-        err = C.c_char_p()
-        self.h = C.c_void_p(self.L.hc_push_create(C.byref(blob), C.byref(err)))
-        if not self.h:
-            raise RuntimeError("hc_push_create: %s" % (err.value.decode() if err.value else "?"))
-        self.n = self.L.hc_push_state_size()
-        self.s = np.zeros(self.n)
-        self.f = np.zeros(2, dtype=np.int32)
-
-    def reset(self, init_qpos, ctx):
-        init_qpos, ctx = np.ascontiguousarray(init_qpos, float), np.ascontiguousarray(ctx, float).reshape(14)
-        obs = np.zeros(8, dtype=np.float32)
-        self.L.hc_push_reset(self.h, _p(init_qpos), _p(ctx), _p(self.s), _p(self.f), _p(obs))
-        return obs
-
-    def step(self, action, fast=True):
-        action = np.ascontiguousarray(action, float)
-        obs = np.zeros(8, dtype=np.float32)
-        rew, md = C.c_double(0), C.c_double(0)
-        done = C.c_ubyte(0)
-        self.L.hc_push_step(self.h, _p(self.s), _p(self.f), _p(action), _p(obs), C.byref(rew), C.byref(done), C.byref(md), int(fast))
-        fl = int(self.f[0]) & 0xFFFFFFFF
-        info = dict(mode=((fl >> 3) & 7) - 1, success=bool(fl & (1 << 13)), mean_distance=md.value, first_visit=(fl & 7) - 1, flags=fl)
-        return obs, rew.value, bool(done.value), info
-
-
 class GenHostCheck:
     """Host build of the generic engine (d3il_amd/csrc/gen_step.h) running the Sorting task, one environment."""
 
@@ -153,6 +122,22 @@ class GenHostCheck:
     def box(self, b):
         o = 42 + 13 * b
         return self.s[o:o + 3], self.s[o + 3:o + 7], self.s[o + 7:o + 13]
+
+
+class PushHostCheck(GenHostCheck):
+    """The Pushing task on the host build of the generic engine (gen_step.h, GEN_TASK_PUSHING - the engine the product runs the task on; the round-1 Pushing
+    engine is gone), one environment, with the return values of Block_Push_Env.step: state rows 0 .. 88 = arm, cubes, warm start; row 89 info['mean_distance'],
+    row 90 the reward; first-visit / mode bits in the flag word."""
+
+    def __init__(self, blob):
+        super().__init__(blob)
+        assert (self.nb, self.n_obs, self.n) == (2, 8, 91)
+
+    def step(self, action, fast=True):
+        obs, done, info = super().step(action, fast)
+        fl = info["flags"]
+        mode = info["mode"] if info["mode"] < 32768 else info["mode"] - 65536
+        return obs, float(self.s[90]), done, dict(mode=mode, success=info["success"], mean_distance=float(self.s[89]), first_visit=(fl & 7) - 1, flags=fl)
 
 
 class StackHostCheck:

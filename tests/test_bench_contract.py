@@ -72,6 +72,10 @@ def test_json_line_of_a_short_run():
     cfg = line["config"]
     assert cfg["sub_batches"] * cfg["envs_per_launch"] == 512 and cfg["sub_batches"] == 4      # the default: four sub-batches on four streams
     assert r["algorithmic_bytes_per_env_step"] == 704 and r["algorithmic_bytes_per_launch"] == 704 * cfg["envs_per_launch"] == 704 * r["envs_per_launch"]
+    # `achieved` is per env step at chip level (comparable between sub-batch counts); the per-launch figure of one sub-batch stands next to it
+    assert r["algorithmic_bytes_per_step"] == 704 * 512 and abs(r["achieved"] - 704 * 512 / (line["ms_per_step"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
+    assert abs(r["achieved_per_launch"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved_per_launch"] < 1e-9
+    assert abs(r["frac_per_launch"] - r["achieved_per_launch"] / r["peak"]) < 1e-12
 
 
 @pytest.mark.gpu
@@ -108,3 +112,28 @@ def test_gpus_2_self_spawn_runs_two_ranks():
     assert "cpu_baseline" not in line                                  # rank 0 at N = 1 only
     assert line["config"]["episodes_finished_all_ranks"] >= line["config"]["episodes_finished_rank0"] > 0
     assert "torch.distributed" in line["config"]["metric_reduction"]
+
+
+@pytest.mark.gpu
+def test_gpus_2_under_nccl_reaches_rccl_or_exits_with_the_self_check_code():
+    """Multi-GPU readiness without a node: `bench.py --gpus 2` under the nccl backend - the backend of the driver's 8-GPU run - with
+    D3IL_ALLOW_REDUCTION_FALLBACK unset.  On a box with two GPUs the line must say that the library's own RCCL communicator saw both ranks (rccl_ranks == 2,
+    reduction by d3il_reduce_metrics); on the one-GPU box both ranks land on device 0, RCCL refuses the duplicate GPU and every rank leaves with the documented
+    exit code 3 and ONE message on rank 0 - no hang, no JSON line that looks like a scaling result."""
+    import torch
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "D3IL_ALLOW_REDUCTION_FALLBACK", "D3IL_DIST_BACKEND", "D3IL_BENCH_FORCE_DEVICE"):
+        env.pop(k, None)
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        env["D3IL_BENCH_FORCE_DEVICE"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--preroll", "270", "--envs", "256"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if two:
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
+        line = json.loads(lines[-1])
+        assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and "d3il_reduce_metrics" in line["config"]["metric_reduction"]
+    else:
+        assert p.returncode != 0 and not lines, p.stdout[-1500:] + p.stderr[-2500:]
+        assert "multi-GPU self-check failed" in p.stderr, p.stderr[-2500:]

@@ -88,7 +88,7 @@ def test_python_binding_constants_agree_with_the_header():
              "FLAG_MODE_MASK": "D3IL_FLAG_MODE_MASK", "FLAG_TERMINATED": "D3IL_FLAG_TERMINATED", "FLAG_SUCCESS": "D3IL_FLAG_SUCCESS",
              "FLAG_ROD_CONTACT": "D3IL_FLAG_ROD_CONTACT", "FLAG_IK_VALID": "D3IL_FLAG_IK_VALID", "FLAG_SOLVER_FAIL": "D3IL_FLAG_SOLVER_FAIL",
              "FLAG_MULTI_CONTACT": "D3IL_FLAG_MULTI_CONTACT",
-             "PUSH_STATE_BOX": "D3IL_PUSH_STATE_BOX", "PUSH_STATE_WARM": "D3IL_PUSH_STATE_WARM", "PUSH_STATE_F64": "D3IL_PUSH_STATE_F64",
+             "PUSH_STATE_BOX": "D3IL_PUSH_STATE_BOX", "PUSH_STATE_WARM": "D3IL_PUSH_STATE_WARM", "PUSH_STATE_TASK": "D3IL_PUSH_STATE_TASK", "PUSH_STATE_F64": "D3IL_PUSH_STATE_F64",
              "PFLAG_FIRST_MASK": "D3IL_PFLAG_FIRST_MASK", "PFLAG_MODE_MASK": "D3IL_PFLAG_MODE_MASK", "PFLAG_WARM_VALID": "D3IL_PFLAG_WARM_VALID",
              "PFLAG_CON_OVERFLOW": "D3IL_PFLAG_CON_OVERFLOW", "PFLAG_OFF_TABLE": "D3IL_PFLAG_OFF_TABLE",
              "SORT_STATE_BOX": "D3IL_SORT_STATE_BOX", "SORT_STATE_WARM": "D3IL_SORT_STATE_WARM", "SORT_STATE_TASK": "D3IL_SORT_STATE_TASK",

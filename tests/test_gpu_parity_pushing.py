@@ -98,44 +98,6 @@ def test_bounded_horizon_rollout_matches_oracle(ctx60, init_qpos, pushing_blob, 
     env.close()
 
 
-def test_cooperative_engine_variant_follows_the_oracle(ctx60, init_qpos, pushing_blob):
-    """(Legacy engine only - see test_legacy_pushing_engine_in_its_own_process; on the generic engine the option is accepted and has no effect.)
-    Option push_coop=1 runs Pushing on the Stacking task's wave-cooperative engine (k_pushing_step_coop: lane-per-pair collision with the
-    rod as a cylinder job, two environments per wave in the solver) instead of the lock-step kernel - off by default because it is slower
-    for this task, kept as a second implementation of the same step: bounded-horizon parity with the oracle through
-    the first rod <-> cube contacts, and the same integer outputs."""
-    from oracle.oracle import Oracle
-    n = 96
-    env = _env(n)
-    env.set_option("push_coop", 1)
-    env.set_init_qpos(init_qpos)
-    ctx = ctx60[np.arange(n) % 60]
-    env.reset(context=ctx)
-    check = [0, 23, 24, 47, 59, 95]
-    oracles = []
-    for e in check:
-        o = Oracle(pushing_blob); o.env_start(init_qpos); o.push_reset(ctx[e]); oracles.append(o)
-    des = env.robot_state()[:, :2].clone()
-    z = env.robot_state()[:, 2:3].clone()
-    box0 = env.get_state()[0][42:45].copy()
-    for t in range(34):
-        des = _chase(env, des)
-        act = _action(des, z)
-        obs, rew, done, info = env.step(act)
-        torch.cuda.synchronize()
-        st, fl, sc = env.get_state()
-        a = act.cpu().numpy()
-        for k, e in enumerate(check):
-            oo, ro, do, io = oracles[k].push_step(a[e])
-            so, fo = oracles[k].push_state()
-            assert not (fl[e] & BAD)
-            np.testing.assert_allclose(st[POS, e], so[POS], atol=1e-6, rtol=0, err_msg="t %d env %d" % (t, e))
-            np.testing.assert_allclose(obs[e].cpu().numpy(), oo, atol=2e-6, rtol=1e-5)
-            assert bool(done[e]) == do and int(info["mode"][e]) == io["mode"] and bool(info["success"][e]) == io["success"]
-    assert float(np.abs(st[42:45] - box0).max()) > 1e-4, "the horizon has to reach the rod <-> cube contact"
-    env.close()
-
-
 def test_north_star_horizon_of_free_running_rollouts(ctx60, init_qpos, pushing_blob):
     """Free-running rollouts (no state re-synchronisation) against the oracle, ALL state rows incl. velocities: the north star's
     1e-4 must hold through reset transient, approach and the first pushes (>= 40 env steps = 1400 sub-steps in every followed
@@ -406,16 +368,3 @@ def test_random_contexts_and_large_batch(init_qpos):
     st, fl, sc = env.get_state()
     assert np.isfinite(st).all() and not np.any(fl & BAD) and np.all(sc == 3)
     env.close()
-
-
-def test_legacy_pushing_engine_in_its_own_process():
-    """Since round 5 the Pushing task runs on the generic engine (gen_step.h); the round-1 engine (push_step.h / push_kernels.h, and its cooperative variant
-    behind option push_coop) is still built and selected per PROCESS with D3IL_PUSH_ENGINE=legacy.  The reset, bounded-horizon and one-step parity tests of
-    this file pass on it too (run in a child process: the choice is read once, when the first handle is created)."""
-    import subprocess
-    import sys
-    env = dict(os.environ, D3IL_PUSH_ENGINE="legacy")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                        "-k", "reset_matches_oracle or bounded_horizon or cooperative_engine or one_step_parity or first_visit_mode"],
-                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

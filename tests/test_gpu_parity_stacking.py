@@ -478,7 +478,7 @@ def test_raw_c_abi_stacking_create_reset_step(stack_blob, ctx100):
         oo, od, oi = o.stack_step(a)
     torch.cuda.synchronize()
     st = np.zeros((capi.STACK_STATE_F64, n)); fl = np.zeros(n, dtype=np.uint32); sc = np.zeros(n, dtype=np.int32)
-    assert L.d3il_get_state(h, st.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)) == 0
+    assert L.d3il_get_state(h, st.ctypes.data_as(C.c_void_p), st.shape[0], fl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)) == 0
     assert (sc == 3).all() and not (fl & (capi.FLAG_SOLVER_FAIL | capi.PFLAG_CON_OVERFLOW | capi.PFLAG_OFF_TABLE | capi.SFLAG_HAND_NEAR)).any()
     np.testing.assert_allclose(st[:capi.STACK_STATE_WARM, 2], o.stack_state(), atol=1e-9, rtol=0)
     hobs = np.zeros((n, 12), dtype=np.float32)

@@ -1,7 +1,7 @@
 """Sub-batches in the product (envs/sub_batch.py, the Sim classes' ``n_sub_batches``): the reference's n_cores process fan-out
 (simulation/avoiding_sim.py:87-124, sorting_sim.py:160-189) as independent environment batches on their own HIP streams.
 
-CPU: the partition and the agent fork.  GPU: ``Avoiding_Sim`` / ``Sorting_Sim`` / ``Pushing_Sim`` with four sub-batches return the integer tables of one
+CPU: the partition and the agent fork.  GPU: ``Avoiding_Sim`` / ``Sorting_Sim`` / ``Pushing_Sim`` / ``Stacking_Sim`` / ``Aligning_Sim`` with four sub-batches return the integer tables of one
 batch, bit for bit (rollouts are independent; the policies used here compute every row from that row alone, so nothing depends on which rows share a
 batch)."""
 import collections
@@ -109,6 +109,43 @@ def test_sorting_and_pushing_sim_sub_batches_identical_tables():
         for x, y in zip(res[task, 1], res[task, 4]):
             assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), task      # (the entropy of a table without successes is nan in both)
     assert len(np.unique(res["sorting", 1][1])) > 1          # some cubes were delivered: the tables are not trivially equal
+
+
+@pytest.mark.gpu
+def test_stacking_and_aligning_sim_sub_batches_identical_tables():
+    """The counterpart of the reference's n_cores fan-out in stacking_sim.py:182-216 / aligning_sim.py:125-160: ``n_sub_batches=4`` steps the rank's rollouts as
+    four environment batches on four streams and returns the tables of one batch, bit for bit (scripted policies: every row from that row alone; they learn which
+    rollouts their rows are through set_rollout_range)."""
+    from d3il_amd.agents import ScriptedAlignPolicy, ScriptedStackPolicy
+    from d3il_amd.controllers.scripted_stacking import build_trajectory
+    from d3il_amd.envs.stacking import CubeStackingVecEnv, load_test_contexts
+    from d3il_amd.model import blob
+    from d3il_amd.simulation.aligning_sim import Aligning_Sim
+    from d3il_amd.simulation.stacking_sim import Stacking_Sim
+    nctx, ntraj = 8, 40                                   # 320 rollouts: four sub-batches of 80
+    ctx = load_test_contexts()[:nctx]
+    env = CubeStackingVecEnv(1, device=0)
+    q0 = env.start()[0]
+    env.close()
+    js = blob.load_json("stacking")
+    orders = [(0, 1, 2), (1, 0, 2), (2, 1, 0), (0, 2, 1)]
+    tables = [build_trajectory(js, q0, c, order=orders[i % 4], speed=0.5) for i, c in enumerate(ctx)]
+    res = {}
+    for S in (1, 4):
+        sim = Stacking_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=nctx, n_trajectories_per_context=ntraj, max_steps_per_episode=260, contexts=ctx,
+                           n_sub_batches=S)
+        ret = sim.test_agent(ScriptedStackPolicy(tables, torch.arange(nctx * ntraj) // ntraj, device="cuda:0"))
+        r = sim.last_rollout
+        assert not bool((r["flags"] & ((1 << 16) | (1 << 18))).any())
+        res["stacking", S] = (r["counts"].copy(), r["mode"].cpu().numpy(), r["success"].cpu().numpy(), r["mean_distance"].cpu().numpy(), ret[0].cpu().numpy(), ret[1].cpu().numpy())
+        sim = Aligning_Sim(seed=0, device="cuda:0", render=False, n_cores=1, n_contexts=60, n_trajectories_per_context=5, max_steps_per_episode=180, n_sub_batches=S)
+        ret = sim.test_agent(ScriptedAlignPolicy(inside=(np.arange(300) // 5) % 2 == 0, device="cuda:0"))
+        r = sim.last_rollout
+        res["aligning", S] = (r["counts"].copy(), r["mode"].cpu().numpy(), r["success"].cpu().numpy(), r["mean_distance"].cpu().numpy(), np.float64(ret[0]), ret[1].cpu().numpy())
+    for task in ("stacking", "aligning"):
+        for x, y in zip(res[task, 1], res[task, 4]):
+            assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), task
+    assert len(np.unique(res["stacking", 1][1])) > 1 and len(np.unique(res["aligning", 1][3])) > 60      # boxes were placed / plates were moved: not trivially equal
 
 
 @pytest.mark.gpu
