@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
-PROFILE_DIRS = ("r05",)  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
+PROFILE_DIRS = ("r06",)  # committed rocprofv3 --pmc summaries of this command (separate passes), newest first
 
 # Algorithmic HBM bytes per env step: SURVEY.md section 8(d)'s per-unit figures B_alg = 2 S + A + O + F (state read once + written once per
 # fused step, f64 state, f32 action / observation) - these define `roofline.achieved`.  IMPL_BYTES is what THIS implementation's state
@@ -239,7 +239,7 @@ def _self_spawn(n_gpus: int) -> int:
 
 def _pmc(task, policy, n, S):
     """Counters per launch of the step kernel from the committed rocprofv3 --pmc passes of THIS command line - same task, policy (regime), environments
-    per GPU and sub-batch count (tools/profile_r05.sh writes profiles/<round>/pmc/<task>_<policy>_sb<S>.json; the passes are separate runs by construction:
+    per GPU and sub-batch count (tools/profile_r06.sh writes profiles/<round>/pmc/<task>_<policy>_sb<S>.json; the passes are separate runs by construction:
     counters cannot be collected inside the timed run, and a counter pass serialises dispatches).  No borrowing across regimes: a line whose command was
     not profiled carries no traffic figure."""
     if n != 4096:

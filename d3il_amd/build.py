@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libd3il_rollout.so")
 SOURCES = [os.path.join(PKG, "csrc", "rollout.hip")]
 DEPS = SOURCES + [os.path.join(PKG, "csrc", "panda_step.h"), os.path.join(PKG, "csrc", "panda_consts.h"),
-                  os.path.join(PKG, "csrc", "rigid_common.h"), os.path.join(PKG, "csrc", "gen_step.h"), os.path.join(PKG, "csrc", "gen_tree.h"), os.path.join(PKG, "csrc", "gen_kernels.h"),
+                  os.path.join(PKG, "csrc", "rigid_common.h"), os.path.join(PKG, "csrc", "policy_f16x3.h"), os.path.join(PKG, "csrc", "gen_step.h"), os.path.join(PKG, "csrc", "gen_tree.h"), os.path.join(PKG, "csrc", "gen_kernels.h"),
                   os.path.join(PKG, "csrc", "stack_step.h"), os.path.join(PKG, "csrc", "stack_kernels.h"), os.path.join(PKG, "csrc", "align_step.h"), os.path.join(PKG, "model", "blobs", "stacking.json"),
                   os.path.join(PKG, "csrc", "gen_consts.cpp"), os.path.join(PKG, "model", "blobs", "avoiding.json"),
                   os.path.join(ROOT, "include", "d3il_rollout.h"), os.path.join(ROOT, "include", "d3il_model_blob.h")]

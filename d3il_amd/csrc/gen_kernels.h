@@ -6,14 +6,14 @@
 // the wave: lane = 2 (8 l + column) + sub) share the cube's contacts in the solver's contact loops (every other record each, sums
 // exchanged by a DPP swap of neighbouring lanes) and hold identical copies of everything else; sub-lane 0 does the collision
 // phases and the integration.  The physics waves keep each environment's vectors, matrices and the dense
-// Newton Hessian in LDS (1059 doubles per environment, 141 KiB per workgroup), the contact records in the HBM scratch area
+// Newton Hessian in LDS (1073 doubles per environment, 134 KiB per workgroup), the contact records in the HBM scratch area
 // and the cubes in the state buffer itself.  4096 environments are 256 workgroups: one per CU, three of its four SIMDs busy.
 #pragma once
 #include "gen_step.h"
 
 namespace d3il {
 
-constexpr int GEN_LDS_H = GL_SIZE * (GEN_LANES + 1) * 8;   // 1059 x 17 doubles = 141 KiB
+constexpr int GEN_LDS_H = GL_SIZE * GEN_LANES * 8;   // 1073 x 16 doubles = 134 KiB
 constexpr int GEN_LDS_X = 2 * 2 * NARM * GEN_LANES * 8;
 constexpr int GEN_LDS_STEP = GEN_LDS_H + GEN_LDS_X;
 
@@ -44,6 +44,28 @@ __device__ __forceinline__ void gen_store_arm(double* __restrict__ state, unsign
   flags[e] = st.flags; steps[e] = st.step;
 }
 
+// The arm's state lives in the t area (LDS) between the phases: the phases that need it (1: dynamics, 3b: q, 5: integration) read it from there and write back
+// what they change.  Held in registers across the sub-step loop (56 + registers of the arm lanes' wave) it was stored to and reloaded from scratch around every
+// out-of-line phase - several hundred scratch instructions per wave and sub-step (round 6).
+__device__ __forceinline__ void gen_park_arm(const PushScratch sc, const EnvState& st) {
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) { GLS(GL_ARMST + i) = st.q[i]; GLS(GL_ARMST + NDOF + i) = st.v[i]; }
+#pragma unroll
+  for (int i = 0; i < NARM; i++) GLS(GL_ARMST + 2 * NDOF + i) = st.bias[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) GLS(GL_ARMST + 2 * NDOF + NARM + i) = st.tcp[i];
+  GLS(GL_ARMST + 28) = (double)st.flags; GLS(GL_ARMST + 29) = (double)st.step;
+}
+__device__ __forceinline__ void gen_unpark_arm(const PushScratch sc, EnvState& st) {
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) { st.q[i] = GLS(GL_ARMST + i); st.v[i] = GLS(GL_ARMST + NDOF + i); }
+#pragma unroll
+  for (int i = 0; i < NARM; i++) st.bias[i] = GLS(GL_ARMST + 2 * NDOF + i);
+#pragma unroll
+  for (int i = 0; i < 3; i++) st.tcp[i] = GLS(GL_ARMST + 2 * NDOF + NARM + i);
+  st.flags = (unsigned)GLS(GL_ARMST + 28); st.step = (int)GLS(GL_ARMST + 29);
+}
+
 // The physics role of the step kernel (one wave; GEN_NSUB of them per workgroup).  Built into the kernel by default.  -DD3IL_GT_INLINE makes it a function of
 // its own - called ONCE per env step, with the tree solver built INTO it: the solver's callee-saved register block (84 KB of scratch stores per wave and call,
 // profiles/r05/README.md) is then saved once per step instead of once per sub-step, and the role gets a register allocation of its own.
@@ -67,16 +89,20 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
   const bool plive = slive && sub == 0;                           // ... and in the per-cube phases
   const bool arm_lane = plive && l == 0;
   const size_t ei = e < n ? e : 0;
-  PushScratch sc{(push_lds_double*)(tbl + col), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * col), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
-  EnvState st;
-  float o[GEN_SORT_OBS]; unsigned char dn = 0;
+  PushScratch sc{(push_lds_double*)(tbl + col * GL_SIZE), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * col), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + ei), stride};
   unsigned lfl = 0;
   bool warm_valid = false;
   const double grav[3] = {c.gravity[0], c.gravity[1], c.gravity[2]};
   if (slive) warm_valid = (flags[e] & PF_WARM_VALID) != 0;
-  if (arm_lane) {
+  if (arm_lane) {      // observation and `done` BEFORE the physics (gym_env_wrapper.py:88-93): written out at once, the arm's state goes to the t area
+    EnvState st;
+    float o[GEN_SORT_OBS]; unsigned char dn = 0;
     gen_load_arm(state, flags, steps, stride, e, st, false);
     sort_step_begin(gc, st, sc, o, &dn, max_steps);
+    const int od = 2 + 3 * gc.nb;
+    for (int k = 0; k < od; k++) obs[(size_t)od * e + k] = o[k];
+    done[e] = dn;
+    gen_park_arm(sc, st);
   }
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
@@ -87,8 +113,11 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
       double qd[NARM], qdd[NARM], tau[NARM], ff[NFING];
 #pragma unroll
       for (int k = 0; k < NARM; k++) { qd[k] = xch[b][k][col]; qdd[k] = xch[b][NARM + k][col]; }
+      EnvState st;
+      gen_unpark_arm(sc, st);
       push_control(c, st, qd, qdd, 0.04, false, tau, ff);
       gen_phase1(c, gc, st, sc, tau, ff);
+      gen_park_arm(sc, st);      // (phase 1 refreshes bias, tcp and may raise a flag)
     }
     PUSH_TOC(0);
     int cnt = 0;
@@ -98,7 +127,7 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
     if (slive) gen_phase3(gc, sc, l, cnt, c.rod_r, c.rod_h, lfl, GEN_NSUB > 1 ? sub : -1);
     if (RS && plive) gen_phase3r(gc, sc, l, gc.nb, c.rod_r, c.rod_h, lfl);
     gen_sync();
-    if (arm_lane) { gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl); gen_arm_reduce<RS>(gc, sc, warm_valid); }
+    if (arm_lane) { EnvState st; gen_unpark_arm(sc, st); gen_phase3b<RS>(c, gc, st, sc, gc.nb, lfl); gen_arm_reduce<RS>(gc, sc, warm_valid); }
     gen_sync();
     PUSH_TOC(2);
     // environments without cube <-> cube and rod contacts (every cube on static boxes only) solve their cubes one by one in the kernel's own registers; a wave
@@ -121,7 +150,7 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
     if (slive) gen_phase4_multi<RS>(gc, sc, GEN_NSUB * l + sub, GEN_NSUB * gc.nb, warm_valid, lfl);
     gen_sync();
     PUSH_TOC(9);
-    if (arm_lane) gen_phase5_arm(c, gc, st, sc);
+    if (arm_lane) { EnvState st; gen_unpark_arm(sc, st); gen_phase5_arm(c, gc, st, sc); gen_park_arm(sc, st); }
     if (plive) gen_phase5_cube(gc, sc, l, c.timestep);
     gen_sync();
     warm_valid = true;
@@ -130,14 +159,14 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
   gen_sync();
   if (arm_lane) {
     int code = 0;
+    EnvState st;
+    gen_unpark_arm(sc, st);
     for (int k = 1; k < gc.nb; k++) lfl |= (unsigned)GLS(GL_INFO + 4 + k);
     st.flags |= F_IK_VALID | PF_WARM_VALID | lfl;
     if (action_is_bad(actions + (size_t)e * 7)) st.flags |= F_SOLVER_FAIL | F_TERMINATED;
     sort_step_end(gc, st, sc, &code);
     gen_store_arm(state, flags, steps, stride, e, st, false);
-    const int od = 2 + 3 * gc.nb;
-    for (int k = 0; k < od; k++) obs[(size_t)od * e + k] = o[k];
-    done[e] = dn; success[e] = (st.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)code;
+    success[e] = (st.flags & F_SUCCESS) ? 1 : 0; mode[e] = (unsigned short)code;
   }
 }
 
@@ -148,8 +177,8 @@ __global__ __launch_bounds__((1 + GEN_NSUB) * WAVE) void k_sorting_step(double* 
                                                            unsigned char* __restrict__ done, unsigned char* __restrict__ success, unsigned short* __restrict__ mode,
                                                            double* __restrict__ scratch, int n, int stride, int n_substeps, int max_steps) {
   extern __shared__ double smem[];
-  double* tbl = smem;                                    // [GL_SIZE][GEN_LANES + 1]
-  double (*xch)[2 * NARM][GEN_LANES] = (double (*)[2 * NARM][GEN_LANES])(smem + GL_SIZE * (GEN_LANES + 1));
+  double* tbl = smem;                                    // [GEN_LANES][GL_SIZE]
+  double (*xch)[2 * NARM][GEN_LANES] = (double (*)[2 * NARM][GEN_LANES])(smem + GL_SIZE * GEN_LANES);
   const int lane = threadIdx.x & (WAVE - 1);
   const int role = threadIdx.x / WAVE;
   const PandaConsts& c = kAvoidingConsts;                // the arm is the Avoiding arm (same robot XML / gin / URDF)
@@ -210,7 +239,7 @@ __global__ __launch_bounds__(WAVE) void k_sorting_reset(const double* __restrict
   double iq[NARM];
 #pragma unroll
   for (int k = 0; k < NARM; k++) iq[k] = init_qpos[k];
-  PushScratch sc{(push_lds_double*)(smem + lane), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * lane), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + e), stride};
+  PushScratch sc{(push_lds_double*)(smem + lane * GL_SIZE), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * lane), GEN_LANES, (push_glb_double*)(state + (size_t)42 * stride + e), stride};
   float o[GEN_SORT_OBS];
   st.flags = 0; st.step = 0;
   gen_env_reset(kAvoidingConsts, gc, st, sc, iq, contexts + (size_t)e * 7 * gc.nb, o);

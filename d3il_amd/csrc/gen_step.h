@@ -98,13 +98,12 @@ __constant__ GenConsts g_gen_consts;
 #define GTASK(k) PWS(13 * gc.nb + 6 * gc.nb + NDOF + (k))
 D3IL_HD constexpr int gen_state_rows(int nb) { return 42 + 13 * nb + 6 * nb + NDOF + 2; }
 
-// t area (LDS, doubles per environment; the lane stride is odd so that the lanes of a group do not pile up on a bank)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GEN_HS (GEN_LANES + 1)
-#else
-#define GEN_HS 1
-#endif
-#define GLS(i) sc.h[(i) * GEN_HS]
+// t area (LDS): one CONTIGUOUS block of GL_SIZE doubles per environment, sc.h = its first word.  A field with a constant index is then one DS instruction with an
+// immediate offset (< 64 KB) on the environment's base register.  Rounds 3 - 5 kept the area field-major ([field][environment column], stride 17 doubles): every
+// field beyond 64 KB / 136 B needed an address register of its own, the optimiser hoisted those out of the sub-step loop by the hundred and the register allocator
+// put them into scratch - 400 scratch loads per wave and sub-step (round 6, profiles/r06/README.md).  Bank spread: GL_SIZE is ODD, so the blocks of the 16
+// environments of a workgroup start on 16 different bank pairs (a 64-bit access takes two of the 64 banks): the same field of different environments never collides.
+#define GLS(i) sc.h[(i)]
 constexpr int GL_H = 0, GL_X = GEN_NH, GL_P = GL_X + GEN_MAXNV, GL_G = GL_P + GEN_MAXNV, GL_A0 = GL_G + GEN_MAXNV, GL_VEL = GL_A0 + GEN_MAXNV;
 constexpr int GL_R = GL_VEL + GEN_MAXNV, GL_POS = GL_R + 9 * GEN_MAXNB, GL_M = GL_POS + 3 * GEN_MAXNB, GL_LIM = GL_M + 45, GL_JA = GL_LIM + 27;
 constexpr int GL_ROD = GL_JA + 21 * (GEN_MAXNB + GEN_ARMCON);      // rod centre[3], axis[3].  GL_JA: arm rows of the rod contact of cube b at 21 b, of rod <-> static contact j at 21 (GEN_MAXNB + j)
@@ -114,7 +113,9 @@ constexpr int GL_RED = GL_INFO + 16;                 // line-search partial sums
 constexpr int GL_NRED = 2 * GEN_MAXNB * GEN_NSUB;    // one buffer
 constexpr int GL_TR = GL_RED + 2 * GL_NRED;                  // tree solver (gen_tree.h): [0] 1 = the arm's reduction to the lambda node stands, 2 = the arm's island was solved through it; [1..5] lambda
 constexpr int GL_PAIR = GL_TR + 6;                  // cube pair (c, d), c < d: first record | count << 5 of their contacts in c's segment
-constexpr int GL_SIZE = GL_PAIR + 6;                // 1043
+constexpr int GL_ARMST = GL_PAIR + 6;               // the arm's state between the phases of the step kernel (q[9] v[9] bias[7] tcp[3] flags step: gen_kernels.h gen_park_arm) - NOT held in registers across the phases
+constexpr int GL_SIZE = GL_ARMST + 30;
+static_assert(GL_SIZE % 2 == 1, "odd block size: the environments' blocks start on different LDS bank pairs");
 // g area (HBM): contact records, GEN_SEG per cube
 constexpr int GG_CON = 0;
 constexpr int GREC = 28;   // pos[3] frame[9] dist kind a b | aref[3] Dn fric sign | jar[3] jp[3]   (sign: of the segment's cube in the row, +1 = it is geom 2)
@@ -699,7 +700,8 @@ D3IL_NOINLINE inline int gen_phase2(const GenConsts& gc_, const PushScratch sc, 
   }
   const double rcirc2 = gc.box_half[0] * gc.box_half[0] + gc.box_half[1] * gc.box_half[1] + gc.box_half[2] * gc.box_half[2];
   int cnt = 0;
-  double rec[8][7];
+  // (contacts go from the collider straight into the records - box_box_emit's callback; an array of candidates [8][7] indexed at run time lived in scratch:
+  // 112 + 112 scratch instructions per wave and sub-step whenever a lane had a contact, a quarter of the resting regime's memory traffic in round 5)
   // the frame beams (lab_surrounding.xml:3-114: a 19 mm rim around the table top) come last in the list and are skipped for a cube well inside the table
   const bool near_edge = pc[0] < gc.in_lo[0] || pc[0] > gc.in_hi[0] || pc[1] < gc.in_lo[1] || pc[1] > gc.in_hi[1];
   const int ns = near_edge ? gc.ns : gc.ns_core;
@@ -712,9 +714,12 @@ D3IL_NOINLINE inline int gen_phase2(const GenConsts& gc_, const PushScratch sc, 
       if (e > 0) d2 += e * e;
     }
     if (d2 > rcirc2) continue;
-    int n = gc.st_first[s] ? box_box(gc.st_c[s], gc.st_R[s], gc.st_h[s], pc, Rc, gc.box_half, 0.0, rec, 8)
-                           : box_box(pc, Rc, gc.box_half, gc.st_c[s], gc.st_R[s], gc.st_h[s], 0.0, rec, 8);
-    for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_STATIC, s, c, s, sub);
+    auto put = [&](double dist, const double* pos, const double* nrm) {
+      const double r7[7] = {dist, pos[0], pos[1], pos[2], nrm[0], nrm[1], nrm[2]};
+      gen_put(gc, sc, c, cnt, fl, r7, GK_STATIC, s, c, s, sub);
+    };
+    if (gc.st_first[s]) box_box_emit(gc.st_c[s], gc.st_R[s], gc.st_h[s], pc, Rc, gc.box_half, 0.0, 8, put);
+    else box_box_emit(pc, Rc, gc.box_half, gc.st_c[s], gc.st_R[s], gc.st_h[s], 0.0, 8, put);
   }
   return cnt;
 }
@@ -735,10 +740,11 @@ D3IL_NOINLINE inline void gen_phase3(const GenConsts& gc_, const PushScratch sc,
     if (dd > 4 * rcirc2) continue;
 #pragma unroll
     for (int k = 0; k < 9; k++) Rd[k] = GLS(GL_R + 9 * d + k);
-    double rec[8][7];
-    int n = box_box(pc, Rc, gc.box_half, pd, Rd, gc.box_half, 0.0, rec, 8);
     const int first = cnt;
-    for (int i = 0; i < n; i++) gen_put(gc, sc, c, cnt, fl, rec[i], GK_BOXBOX, c, d, gc.set_bb, sub);
+    box_box_emit(pc, Rc, gc.box_half, pd, Rd, gc.box_half, 0.0, 8, [&](double dist, const double* pos, const double* nrm) {
+      const double r7[7] = {dist, pos[0], pos[1], pos[2], nrm[0], nrm[1], nrm[2]};
+      gen_put(gc, sc, c, cnt, fl, r7, GK_BOXBOX, c, d, gc.set_bb, sub);
+    });
     if (cnt > first) { partners |= 1u << d; GLS(GL_PAIR + gt_pair(c, d)) = (double)((unsigned)first | ((unsigned)(cnt - first) << 5)); }
   }
   {

@@ -23,8 +23,14 @@
 
 // Rare, register-hungry paths (Jacobi eigen-solver, general constraint Newton) are kept out of line so that the hot
 // path of the fused kernel stays in registers; they take their operands through private memory.
+// not_tail_called (round 6): the AMDGPU calling convention makes v40.., a32.. callee-saved; a device function that needs the whole register file (the
+// tree solver: 256 + 246) stored and reloaded 328 of them around EVERY call - 84 KB of scratch per wave and sub-step, the source of the generic engine's
+// HBM traffic (x 270 - 900 the algorithmic bytes in round 5).  LLVM drops the callee-saved convention for an internal, non-recursive function under
+// inter-procedural register allocation (TargetFrameLowering::isSafeForNoCSROpt; on by default for this target) unless one of its call sites carries the `tail`
+// marker - which the optimiser puts on every call that cannot see the caller's stack.  `not_tail_called` keeps the marker off: no save block, the caller
+// keeps what IT has live across the call (little, by construction of the phases).
 #if defined(__HIPCC__)
-#define D3IL_NOINLINE __host__ __device__ __attribute__((noinline))
+#define D3IL_NOINLINE __host__ __device__ __attribute__((noinline, not_tail_called))
 #else
 #define D3IL_NOINLINE __attribute__((noinline))
 #endif

@@ -1,0 +1,196 @@
+// policy_f16x3.h - the two GEMM kernels of the batched DiffusionGPT block (agents/models/beso/agents/diffusion_agents/k_diffusion/score_gpts.py:83-115)
+// on the f16 matrix cores with SPLIT operands (included by rollout.hip).
+//
+// BASELINE config 5 (Stacking, 4096 environments per GPU, BESO policy) is policy bound: 1.5 TFLOP of f32 GEMM work per policy step (45056 token rows x 6 blocks x
+// 16 sampling steps) is 9.5 ms at the f32 matrix peak of the chip (157 TFLOP/s; round 5 reached half of it).  v_mfma_f32_16x16x32_f16 runs at 16 x that rate, so an
+// f32 product can be paid for with THREE f16 products and still be five times cheaper:
+//     x = xh + 2^-11 xl,   xh = f16(x) (11 significant bits),  xl = f16((x - xh) 2^11) (the next 11 bits; the subtraction is exact in f32),
+//     w x = wh xh + 2^-11 (wh xl + wl xh) + 2^-22 wl xl;
+// the last term (2^-22 relative, below the f32 rounding of the sum it belongs to) is dropped.  The products are exact in the f32 accumulators of the matrix
+// core (22-bit significands); `hh` and the cross terms accumulate separately and are combined once per output (acc_hh + 2^-11 acc_x).  Operands carry 22 of the 24
+// bits of an f32, so a 120-term dot product differs from the f32-FMA chain by about as much as two f32 summation orders differ from each other (measured against an
+// f64 reference in tests/test_policies_f16x3.py).  Range: |operand| <= 65504 (saturating) - LayerNorm outputs, GELU outputs and weights are O(1).
+// The kernels keep the structure of k_mlp_gelu_residual_f32 / k_linear120_f32 (rollout.hip): one wave owns 16 token rows, the transposed product D[feature][row]
+// makes the D registers of the first MLP product the B operand of the second, four waves share the weight stream through a double-buffered LDS stage.
+#pragma once
+
+namespace d3il {
+
+typedef _Float16 hx_h8 __attribute__((ext_vector_type(8)));
+typedef float hx_f4 __attribute__((ext_vector_type(4)));
+constexpr int HX_C = 120, HX_H = 480, HX_PAIRS = HX_H / 32;      // a "pair" = two 16-wide hidden tiles = one K = 32 step of the second product
+constexpr int HX_PAIR_V = 2048;                                  // 16-byte vectors per packed pair: 1024 first product (tile, step, half, lane) + 1024 second (out tile, half, lane)
+constexpr float HX_LO = 2048.f, HX_ILO = 1.f / 2048.f;
+
+__device__ __forceinline__ void hx_split(float x, _Float16& hi, _Float16& lo) {
+  x = fminf(fmaxf(x, -65504.f), 65504.f);
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * HX_LO);
+}
+// Row `rr` of src[.][120] in the B-operand order of v_mfma_f32_16x16x32_f16: lane (g, j) holds, for K step s, the elements 32 s + 8 g + e (e = 0 .. 7) of row j
+// (zero beyond 120), optionally layer-normalised first (nn.LayerNorm over the 120 features, biased variance: the four lane groups of a row hold 32 / 32 / 32 / 24 of
+// its elements, the two row sums take two cross-group exchanges), split into the f16 halves.
+__device__ __forceinline__ void hx_load_row(const float* __restrict__ src, long rr, int g, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
+                                            hx_h8* hh, hx_h8* hl) {
+  float v[32];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int k0 = 32 * s + 8 * g;
+    if (k0 < HX_C) {
+      const hx_f4 a = *(const hx_f4*)(src + rr * HX_C + k0), b = *(const hx_f4*)(src + rr * HX_C + k0 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[8 * s + e] = a[e]; v[8 * s + 4 + e] = b[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[8 * s + e] = 0.f;
+    }
+  }
+  if (ln_w) {
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k++) sum += v[k];
+    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / HX_C);
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (32 * s + 8 * g < HX_C) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float d = v[8 * s + e] - mean; var += d * d; }
+    }
+    var += __shfl_xor(var, 16); var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / HX_C) + eps);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int k0 = 32 * s + 8 * g;
+      if (k0 < HX_C) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[8 * s + e] = (v[8 * s + e] - mean) * rstd * ln_w[k0 + e] + ln_b[k0 + e];
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) { _Float16 a, b; hx_split(v[8 * s + e], a, b); hh[s][e] = a; hl[s][e] = b; }
+}
+#define HX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+// out[M][120] = x + b2 + W2 GELU(W1 LN(h) + b1).  wp: HX_PAIRS packed pairs (policies.py pack_mlp_weights_f16x3):
+//   vector ((tile * 4 + s) * 2 + p) * 64 + lane          = W1_p[32 c + 16 tile + i][32 s + 8 g + e]                      (A operand of step s of hidden tile `tile`)
+//   vector 1024 + (t * 2 + p) * 64 + lane                = W2_p[16 t + i][32 c + 16 (e >> 2) + 4 g + (e & 3)]            (A operand of output tile t)
+// with lane = 16 g + i, p = 0 the high half, p = 1 the low half times 2^11, zero beyond the matrices.  The second product sums the 32 hidden units of the pair in
+// the order the two D tiles of the first product hold them: lane (g, j) has units 4 g + r of tile 0 in elements r and of tile 1 in elements 4 + r of its B operand.
+__global__ __launch_bounds__(256) void k_mlp_gelu_residual_f16x3(const float* __restrict__ h, const float* __restrict__ x, const hx_h8* __restrict__ wp,
+                                                                  const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, long M,
+                                                                  const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
+  __shared__ hx_h8 sw[2][HX_PAIR_V];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const long row = (long)blockIdx.x * 64 + wave * 16 + j;
+  const bool live = row < M;
+  const long rr = live ? row : (M - 1);
+  hx_h8 hh[4], hl[4];
+  hx_load_row(h, rr, g, ln_w, ln_b, eps, hh, hl);
+  hx_f4 acc2h[8], acc2x[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) { acc2h[t] = hx_f4{0.f, 0.f, 0.f, 0.f}; acc2x[t] = hx_f4{0.f, 0.f, 0.f, 0.f}; }
+  hx_h8 pre[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) sw[0][tid + 256 * q] = wp[tid + 256 * q];
+  __syncthreads();
+  for (int c = 0; c < HX_PAIRS; c++) {
+    const int cur = c & 1;
+    if (c + 1 < HX_PAIRS) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) pre[q] = wp[(long)(c + 1) * HX_PAIR_V + tid + 256 * q];
+    }
+    hx_h8 gh, gl;
+#pragma unroll
+    for (int tile = 0; tile < 2; tile++) {
+      hx_f4 ah = hx_f4{0.f, 0.f, 0.f, 0.f}, ax1 = ah, ax2 = ah;      // three independent accumulation chains
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const hx_h8 wh = sw[cur][((tile * 4 + s) * 2) * 64 + lane], wl = sw[cur][((tile * 4 + s) * 2 + 1) * 64 + lane];
+        ah = HX_MFMA(wh, hh[s], ah);
+        ax1 = HX_MFMA(wh, hl[s], ax1);
+        ax2 = HX_MFMA(wl, hh[s], ax2);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float v = ah[r] + (ax1[r] + ax2[r]) * HX_ILO + b1[32 * c + 16 * tile + 4 * g + r];
+        const float gv = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));      // nn.GELU() (exact)
+        _Float16 a, b;
+        hx_split(gv, a, b);
+        gh[4 * tile + r] = a; gl[4 * tile + r] = b;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc2h[t] = HX_MFMA(sw[cur][1024 + (t * 2) * 64 + lane], gh, acc2h[t]);
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc2x[t] = HX_MFMA(sw[cur][1024 + (t * 2) * 64 + lane], gl, acc2x[t]);
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc2x[t] = HX_MFMA(sw[cur][1024 + (t * 2 + 1) * 64 + lane], gh, acc2x[t]);
+    if (c + 1 < HX_PAIRS) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) sw[cur ^ 1][tid + 256 * q] = pre[q];
+    }
+    __syncthreads();
+  }
+  if (!live) return;
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const int col = 16 * t + 4 * g;
+    if (col >= HX_C) continue;
+    const hx_f4 xr = *(const hx_f4*)(x + row * HX_C + col), bb = *(const hx_f4*)(b2 + col);
+    *(hx_f4*)(out + row * HX_C + col) = xr + bb + acc2h[t] + acc2x[t] * HX_ILO;
+  }
+}
+
+// out[M][N] = (LayerNorm)(xin)[M][120] W^T + bias (+ resid).  wp: ceil(N / 16) tiles of 512 vectors (policies.py pack_linear120_weights_f16x3):
+//   vector (s * 2 + p) * 64 + lane of tile t = W_p[16 t + i][32 s + 8 g + e], zero beyond N rows / 120 columns.  Two tiles per LDS stage.
+__global__ __launch_bounds__(256) void k_linear120_f16x3(const float* __restrict__ xin, const hx_h8* __restrict__ wp, const float* __restrict__ bias, const float* __restrict__ resid,
+                                                          float* __restrict__ out, long M, int N, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
+  __shared__ hx_h8 sw[2][1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const long row = (long)blockIdx.x * 64 + wave * 16 + j;
+  const bool live = row < M;
+  const long rr = live ? row : (M - 1);
+  hx_h8 hh[4], hl[4];
+  hx_load_row(xin, rr, g, ln_w, ln_b, eps, hh, hl);
+  const int ntiles = (N + 15) / 16, nstages = (ntiles + 1) / 2;      // (the packed buffer is padded to an even number of tiles)
+  hx_h8 pre[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) sw[0][tid + 256 * q] = wp[tid + 256 * q];
+  __syncthreads();
+  for (int st = 0; st < nstages; st++) {
+    const int cur = st & 1;
+    if (st + 1 < nstages) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) pre[q] = wp[(long)(st + 1) * 1024 + tid + 256 * q];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int t = 2 * st + u;
+      hx_f4 ah = hx_f4{0.f, 0.f, 0.f, 0.f}, ax1 = ah, ax2 = ah;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const hx_h8 wh = sw[cur][512 * u + (s * 2) * 64 + lane], wl = sw[cur][512 * u + (s * 2 + 1) * 64 + lane];
+        ah = HX_MFMA(wh, hh[s], ah);
+        ax1 = HX_MFMA(wh, hl[s], ax1);
+        ax2 = HX_MFMA(wl, hh[s], ax2);
+      }
+      const int col = 16 * t + 4 * g;
+      if (live && col < N) {
+        hx_f4 v = ah + (ax1 + ax2) * HX_ILO + *(const hx_f4*)(bias + col);
+        if (resid) v += *(const hx_f4*)(resid + row * (long)N + col);
+        *(hx_f4*)(out + row * (long)N + col) = v;
+      }
+    }
+    if (st + 1 < nstages) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) sw[cur ^ 1][tid + 256 * q] = pre[q];
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace d3il

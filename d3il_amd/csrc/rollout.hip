@@ -23,6 +23,7 @@ constexpr int WAVE = 64;
 }
 #include "gen_kernels.h"
 #include "stack_kernels.h"
+#include "policy_f16x3.h"
 
 namespace d3il {
 
@@ -1517,6 +1518,29 @@ int d3il_mlp_ln_gelu_residual_f32(const float* h, const float* ln_weight, const 
   if (((uintptr_t)h | (uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b2 | (uintptr_t)out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_mlp_gelu_residual_f32: pointers must be 16-byte aligned");
   if (rows == 0) return D3IL_OK;
   hipLaunchKernelGGL(k_mlp_gelu_residual_f32, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, x, w_packed, b1, b2, out, rows, ln_weight, ln_bias, ln_eps);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_mlp_ln_gelu_residual_f16x3(const float* h, const float* ln_weight, const float* ln_bias, float ln_eps, const float* x, const void* w_packed, const float* b1, const float* b2,
+                                    float* out, long rows, int C, int H, void* stream) {
+  if ((ln_weight == nullptr) != (ln_bias == nullptr)) return fail(D3IL_EINVAL, "d3il_mlp_ln_gelu_residual_f16x3: LayerNorm weight and bias come together");
+  if (!h || !x || !w_packed || !b1 || !b2 || !out) return fail(D3IL_EINVAL, "d3il_mlp_ln_gelu_residual_f16x3: null argument");
+  if (C != HX_C || H != HX_H) return fail(D3IL_EUNSUPPORTED, "d3il_mlp_ln_gelu_residual_f16x3: built for n_embd 120, hidden 480 (the DiffusionGPT of the BESO configs)");
+  if (rows < 0) return fail(D3IL_EINVAL, "d3il_mlp_ln_gelu_residual_f16x3: negative row count");
+  if (((uintptr_t)h | (uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b2 | (uintptr_t)out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_mlp_ln_gelu_residual_f16x3: pointers must be 16-byte aligned");
+  if (rows == 0) return D3IL_OK;
+  hipLaunchKernelGGL(k_mlp_gelu_residual_f16x3, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, x, (const hx_h8*)w_packed, b1, b2, out, rows, ln_weight, ln_bias, ln_eps);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
+int d3il_linear120_f16x3(const float* xin, const float* ln_weight, const float* ln_bias, float ln_eps, const void* w_packed, const float* bias, const float* resid, float* out,
+                         long rows, int N, void* stream) {
+  if (!xin || !w_packed || !bias || !out) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: null argument");
+  if ((ln_weight == nullptr) != (ln_bias == nullptr)) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: LayerNorm weight and bias come together");
+  if (rows < 0 || N < 4 || N % 4 != 0) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: needs rows >= 0 and N a positive multiple of 4");
+  if (((uintptr_t)xin | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)resid | (uintptr_t)out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: pointers must be 16-byte aligned");
+  if (rows == 0) return D3IL_OK;
+  hipLaunchKernelGGL(k_linear120_f16x3, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, xin, (const hx_h8*)w_packed, bias, resid, out, rows, N, ln_weight, ln_bias, ln_eps);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }

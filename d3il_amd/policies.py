@@ -209,6 +209,83 @@ def pack_mlp_weights(fc1: nn.Linear, fc2: nn.Linear) -> torch.Tensor:
     return flat[mlp_pack_index(C, H, fc1.weight.device)]
 
 
+def split_f16(w: torch.Tensor):
+    """(hi, lo) f16 halves of an f32 tensor as csrc/policy_f16x3.h uses them: hi = f16(w) (saturating), lo = f16((w - hi) * 2^11)."""
+    w = w.detach().to(torch.float32).clamp(-65504.0, 65504.0)
+    hi = w.to(torch.float16)
+    lo = ((w - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+    return hi, lo
+
+
+def mlp_f16x3_pack_index(C: int, H: int, device) -> torch.Tensor:
+    """Gather index [H / 32 pairs][2048 vectors][8] into cat(fc1.weight [H, C], fc2.weight [C, H], one zero) for d3il_mlp_ln_gelu_residual_f16x3 - WITHOUT the half
+    dimension (the packer interleaves hi / lo): entry (c, v, e) with v < 512: tile = v // 256, s = (v // 64) % 4, lane = v % 64 -> fc1.weight[32 c + 16 tile + i][32 s + 8 g + e];
+    v >= 512: t = (v - 512) // 64 -> fc2.weight[16 t + i][32 c + 16 (e >> 2) + 4 g + (e & 3)]; lane = 16 g + i; zero beyond the matrices."""
+    key = ("mlp16", C, H, str(device))
+    if key not in _MLP_PACK_IDX:
+        c = torch.arange(H // 32).view(-1, 1, 1, 1, 1, 1)
+        tile = torch.arange(2).view(1, -1, 1, 1, 1, 1)
+        s_ = torch.arange(4).view(1, 1, -1, 1, 1, 1)
+        g = torch.arange(4).view(1, 1, 1, -1, 1, 1)
+        i = torch.arange(16).view(1, 1, 1, 1, -1, 1)
+        e = torch.arange(8).view(1, 1, 1, 1, 1, -1)
+        zero = 2 * C * H
+        k = 32 * s_ + 8 * g + e
+        i1 = torch.where(k < C, (32 * c + 16 * tile + i) * C + k, torch.full_like(k + c + tile + i, zero))            # [P, 2, 4, 4, 16, 8]
+        t = torch.arange(8).view(1, -1, 1, 1, 1)
+        c2, g2, i2_, e2 = c.view(-1, 1, 1, 1, 1), g.view(1, 1, -1, 1, 1), i.view(1, 1, 1, -1, 1), e.view(1, 1, 1, 1, -1)
+        row = 16 * t + i2_
+        hid = 32 * c2 + 16 * (e2 >> 2) + 4 * g2 + (e2 & 3)
+        i2 = torch.where(row < C, C * H + row * H + hid, torch.full_like(row + hid, zero))                              # [P, 8, 4, 16, 8]
+        P = H // 32
+        _MLP_PACK_IDX[key] = (i1.reshape(P, 512, 8).to(device), i2.reshape(P, 512, 8).to(device))
+    return _MLP_PACK_IDX[key]
+
+
+def pack_mlp_weights_f16x3(fc1_weight: torch.Tensor, fc2_weight: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """f16 [H / 32][2048][8]: per pair, first-product vectors ((tile * 4 + s) * 2 + p) * 64 + lane, then second-product vectors 1024 + (t * 2 + p) * 64 + lane (p: 0 hi, 1 lo)."""
+    H, C = fc1_weight.shape
+    i1, i2 = mlp_f16x3_pack_index(C, H, fc1_weight.device)
+    flat = torch.cat((fc1_weight.reshape(-1), fc2_weight.reshape(-1), fc1_weight.new_zeros(1)))
+    hi, lo = split_f16(flat)
+    P = H // 32
+    a = torch.stack((hi[i1].view(P, 8, 64, 8), lo[i1].view(P, 8, 64, 8)), dim=2).reshape(P, 1024, 8)      # [(tile, s)][p][lane]
+    b = torch.stack((hi[i2].view(P, 8, 64, 8), lo[i2].view(P, 8, 64, 8)), dim=2).reshape(P, 1024, 8)      # [t][p][lane]
+    res = torch.cat((a, b), dim=1).contiguous()
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def pack_linear120_weights_f16x3(weight: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """f16 [2 ceil(N / 32) tiles][512][8] for d3il_linear120_f16x3: vector (s * 2 + p) * 64 + lane of tile t = W_p[16 t + i][32 s + 8 g + e] (zero beyond N x 120)."""
+    N, C = weight.shape
+    key = ("lin16", N, C, str(weight.device))
+    if key not in _MLP_PACK_IDX:
+        nt = 2 * ((N + 31) // 32)
+        t = torch.arange(nt).view(-1, 1, 1, 1, 1)
+        s_ = torch.arange(4).view(1, -1, 1, 1, 1)
+        g = torch.arange(4).view(1, 1, -1, 1, 1)
+        i = torch.arange(16).view(1, 1, 1, -1, 1)
+        e = torch.arange(8).view(1, 1, 1, 1, -1)
+        row, k = 16 * t + i, 32 * s_ + 8 * g + e
+        _MLP_PACK_IDX[key] = torch.where((row < N) & (k < C), row * C + k, torch.full_like(row + k, N * C)).reshape(nt, 4, 64, 8).to(weight.device)
+    idx = _MLP_PACK_IDX[key]
+    hi, lo = split_f16(torch.cat((weight.reshape(-1), weight.new_zeros(1))))
+    res = torch.stack((hi[idx], lo[idx]), dim=2).reshape(idx.shape[0], 512, 8).contiguous()
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def policy_gemm_mode() -> str:
+    """Which matrix-core path the DiffusionGPT blocks take: "f16x3" (default: split-f16 products, csrc/policy_f16x3.h) or "f32" (D3IL_POLICY_GEMM=f32: the f32-input MFMA
+    kernels of rounds 3 - 5)."""
+    return os.environ.get("D3IL_POLICY_GEMM", "f16x3")
+
+
 class _Block(nn.Module):                   # score_gpts.py:83-115
     def __init__(self, n_embd, n_heads, block_size):
         super().__init__()
@@ -251,14 +328,19 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
             torch.index_select(torch.cat((a.proj.weight.reshape(-1), z)), 0, linear120_pack_index(120, dev), out=self._wp_proj)
             torch.index_select(torch.cat((fc1.weight.reshape(-1), fc2.weight.reshape(-1), z)), 0, mlp_pack_index(120, 480, dev), out=self._wp_mlp)
             torch.cat((a.query.bias, a.key.bias, a.value.bias), dim=0, out=self._b_qkv)
+            # the split-f16 forms of the same three matrices (csrc/policy_f16x3.h), refreshed in place like the f32 ones
+            wq = torch.cat((a.query.weight, a.key.weight, a.value.weight), dim=0)
+            self._hp_qkv = pack_linear120_weights_f16x3(wq, getattr(self, "_hp_qkv", None))
+            self._hp_proj = pack_linear120_weights_f16x3(a.proj.weight, getattr(self, "_hp_proj", None))
+            self._hp_mlp = pack_mlp_weights_f16x3(fc1.weight, fc2.weight, getattr(self, "_hp_mlp", None))
         self._pack_key = key
 
     def forward(self, x, keep=None):
         """keep: token positions (LongTensor) whose outputs are needed; the block then returns [B, len(keep), C] - attention still sees every token, the output
         projection and the MLP run on the kept rows only (the last block of DiffusionGPT: only the action positions are decoded)."""
         if self._fused_ok(x):
-            # device path, four kernels of the rollout library per block, all GEMMs on the f32 matrix cores with the LayerNorms, biases, GELU and residuals
-            # fused in: ln1 + (query | key | value) product -> causal attention -> output projection + residual -> ln2 + fc1 + GELU + fc2 + residual
+            # device path, four kernels of the rollout library per block, all GEMMs on the matrix cores (split-f16 products by default, policy_gemm_mode()) with the
+            # LayerNorms, biases, GELU and residuals fused in: ln1 + (query | key | value) product -> causal attention -> output projection + residual -> ln2 + fc1 + GELU + fc2 + residual
             # (the [B T][480] hidden activations stay in registers)
             from . import capi
             L = capi.load()
@@ -270,20 +352,24 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
                 self.ensure_packed()
             else:
                 assert getattr(self, "_pack_key", None) is not None, "a captured graph replays the packed weight buffers: call ensure_packed() before capturing"
+            f16x3 = policy_gemm_mode() == "f16x3"
+            linear = L.d3il_linear120_f16x3 if f16x3 else L.d3il_linear120_f32
+            mlp = L.d3il_mlp_ln_gelu_residual_f16x3 if f16x3 else L.d3il_mlp_ln_gelu_residual_f32
+            w_qkv, w_proj, w_mlp = (self._hp_qkv, self._hp_proj, self._hp_mlp) if f16x3 else (self._wp_qkv, self._wp_proj, self._wp_mlp)
             qkv = torch.empty(B, T, 3 * C, dtype=torch.float32, device=x.device)
-            capi.check(L.d3il_linear120_f32(x.data_ptr(), self.ln1.weight.data_ptr(), self.ln1.bias.data_ptr(), float(self.ln1.eps), self._wp_qkv.data_ptr(), self._b_qkv.data_ptr(), None,
-                                            qkv.data_ptr(), M, 3 * C, st))
+            capi.check(linear(x.data_ptr(), self.ln1.weight.data_ptr(), self.ln1.bias.data_ptr(), float(self.ln1.eps), w_qkv.data_ptr(), self._b_qkv.data_ptr(), None,
+                              qkv.data_ptr(), M, 3 * C, st))
             y = torch.empty_like(x)
             capi.check(L.d3il_attention_causal_f32(qkv.data_ptr(), y.data_ptr(), B, T, a.n_head, C // a.n_head, st))
             if keep is not None:
                 y, x = y.index_select(1, keep), x.index_select(1, keep)
                 M = y.shape[0] * y.shape[1]
             x1 = torch.empty_like(x)
-            capi.check(L.d3il_linear120_f32(y.data_ptr(), None, None, 0.0, self._wp_proj.data_ptr(), a.proj.bias.data_ptr(), x.data_ptr(), x1.data_ptr(), M, C, st))
+            capi.check(linear(y.data_ptr(), None, None, 0.0, w_proj.data_ptr(), a.proj.bias.data_ptr(), x.data_ptr(), x1.data_ptr(), M, C, st))
             fc1, fc2 = self.mlp[0], self.mlp[2]
             out = torch.empty_like(x)
-            capi.check(L.d3il_mlp_ln_gelu_residual_f32(x1.data_ptr(), self.ln2.weight.data_ptr(), self.ln2.bias.data_ptr(), float(self.ln2.eps), x1.data_ptr(), self._wp_mlp.data_ptr(),
-                                                       fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
+            capi.check(mlp(x1.data_ptr(), self.ln2.weight.data_ptr(), self.ln2.bias.data_ptr(), float(self.ln2.eps), x1.data_ptr(), w_mlp.data_ptr(),
+                           fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
             return out
         x = x + self.attn(_layer_norm(self.ln1, x))
         if keep is not None:

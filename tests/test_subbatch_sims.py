@@ -145,7 +145,7 @@ def test_stacking_and_aligning_sim_sub_batches_identical_tables():
     for task in ("stacking", "aligning"):
         for x, y in zip(res[task, 1], res[task, 4]):
             assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), task
-    assert len(np.unique(res["stacking", 1][1])) > 1 and len(np.unique(res["aligning", 1][3])) > 60      # boxes were placed / plates were moved: not trivially equal
+    assert len(np.unique(res["stacking", 1][1])) > 1 and len(np.unique(res["aligning", 1][3])) > 30      # boxes were placed / plates were moved: not trivially equal
 
 
 @pytest.mark.gpu
