@@ -101,11 +101,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_stats_variant(verbose: bool = False, counts: bool = False) -> str:
+def build_stats_variant(verbose: bool = False, counts: bool = False, per_wave: bool = False) -> str:
     """Diagnostics library with device-side path counters and phase timers (not used by the product or the tests); counts: also the wave-level event
     counters inside the generic engine's contact loops (d3il_debug_wave_counts; their atomics distort the timers)."""
     out = os.path.join(PKG, "libd3il_rollout_stats.so")
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-DD3IL_DEVICE_STATS"] + (["-DD3IL_DEVICE_COUNTS"] if counts else []) + ["-o", out] + SOURCES
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-DD3IL_DEVICE_STATS"] + (["-DD3IL_DEVICE_COUNTS"] if counts else []) + (["-DD3IL_STATS_PER_WAVE"] if per_wave else []) + ["-o", out] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=ROOT)
@@ -134,8 +134,8 @@ VARIANTS = {"gtstatic": ["D3IL_GT_STATIC"],
 if __name__ == "__main__":
     import sys
     print(build(force=True, verbose=True))
-    if "--stats" in sys.argv or "--counts" in sys.argv:
-        print(build_stats_variant(verbose=True, counts="--counts" in sys.argv))
+    if "--stats" in sys.argv or "--counts" in sys.argv or "--per-wave" in sys.argv:
+        print(build_stats_variant(verbose=True, counts="--counts" in sys.argv, per_wave="--per-wave" in sys.argv))
     for name, defs in VARIANTS.items():
         if "--" + name in sys.argv:
             print(build_variant(name, defs, verbose=True))

@@ -44,6 +44,13 @@ __device__ __forceinline__ void gen_store_arm(double* __restrict__ state, unsign
   flags[e] = st.flags; steps[e] = st.step;
 }
 
+#if defined(D3IL_DEVICE_STATS) && defined(D3IL_STATS_PER_WAVE)
+#define GEN_BARRIER_TIMED(w) do { const unsigned long long tb_ = wall_clock64(); __syncthreads(); \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicAdd(&d3il::g_dev_wave[blockIdx.x * 4 + 3][w], wall_clock64() - tb_); } while (0)
+#else
+#define GEN_BARRIER_TIMED(w) __syncthreads()
+#endif
+
 // The arm's state lives in the t area (LDS) between the phases: the phases that need it (1: dynamics, 3b: q, 5: integration) read it from there and write back
 // what they change.  Held in registers across the sub-step loop (56 + registers of the arm lanes' wave) it was stored to and reloaded from scratch around every
 // out-of-line phase - several hundred scratch instructions per wave and sub-step (round 6).
@@ -106,7 +113,7 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
   }
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
-    __syncthreads();
+    GEN_BARRIER_TIMED(role);
     PUSH_TIC;
     if (arm_lane) {
       const int b = s & 1;
@@ -147,7 +154,28 @@ D3IL_GEN_ROLE_ATTR void gen_physics_role(double* __restrict__ state, unsigned* _
     if (slive && !lone_env) lfl |= gen_tree_solve<1, GEN_NSUB>(gc, sc, l, warm_valid, sub);
     gen_sync();
     PUSH_TOC(8);
-    if (slive) gen_phase4_multi<RS>(gc, sc, GEN_NSUB * l + sub, GEN_NSUB * gc.nb, warm_valid, lfl);
+    // The joint solver (islands that are not trees: the rod on two cubes, three cubes touching each other, an arm joint at its limit) by ALL 64 lanes of the wave,
+    // one environment after the other: such an island keeps its environment in this path for tens of sub-steps, and with the eight lanes of its own group it was
+    // what the slowest wave of a launch spent half its time in (round 6, profiles/r06/sort_phases_per_wave.log).  Contacts, Hessian block rows and vector entries are
+    // dealt out over 64 lanes instead of eight; the other environments of the wave have nothing to do meanwhile anyway.  Every environment goes through the same
+    // 64-lane code whoever shares its wave: results do not depend on the batch position (tests/test_gpu_permutation.py).
+    {
+      const bool need = slive && gen_joint_work<RS>(gc, sc);
+      unsigned long long todo = __ballot(need && l == 0 && sub == 0);
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int col0 = (role - 1) * CPW + ((src / GEN_NSUB) & (CPW - 1));
+        const size_t e0 = (size_t)blockIdx.x * GEN_LANES + col0;
+        const PushScratch sc0{(push_lds_double*)(tbl + col0 * GL_SIZE), (push_glb_double*)(scratch + (size_t)blockIdx.x * GG_BLOCK * GEN_LANES + 2 * col0), GEN_LANES,
+                              (push_glb_double*)(state + (size_t)42 * stride + e0), stride};
+        const bool wv0 = __shfl((int)warm_valid, src) != 0;
+        unsigned f0 = 0;
+        gen_phase4_multi<RS>(gc, sc0, lane, WAVE, wv0, f0);
+        if (col == col0) lfl |= f0;
+        gen_sync();
+      }
+    }
     gen_sync();
     PUSH_TOC(9);
     if (arm_lane) { EnvState st; gen_unpark_arm(sc, st); gen_phase5_arm(c, gc, st, sc); gen_park_arm(sc, st); }
@@ -212,7 +240,7 @@ __global__ __launch_bounds__((1 + GEN_NSUB) * WAVE) void k_sorting_step(double* 
 #pragma unroll
         for (int k = 0; k < NARM; k++) { xch[b][k][lane] = ikq[k]; xch[b][NARM + k][lane] = ikqd[k]; }
       }
-      __syncthreads();
+      GEN_BARRIER_TIMED(0);
     }
     if (live) {
       double* so = state + e;

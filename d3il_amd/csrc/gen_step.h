@@ -50,6 +50,7 @@ constexpr int GEN_LANES = D3IL_GEN_LANES;     // environments per workgroup; a p
 #endif
 #endif
 constexpr int GEN_NSUB = D3IL_GEN_NSUB;
+constexpr int GEN_WAVE = 64;
 
 struct GenConsts {
   int nb, ns, set_bb, set_rod;
@@ -532,11 +533,22 @@ D3IL_NOINLINE inline bool gen_solve(const GenConsts& gc_, const PushScratch sc, 
 #pragma unroll
           for (int q = 0; q < 3; q++) p2 += jp[r] * Hc[3 * r + q] * jp[q]; }
       }
-      GLS(GL_RED + GL_NRED * buf + 2 * l) = p1; GLS(GL_RED + GL_NRED * buf + 2 * l + 1) = p2;
-      gen_sync();
       double d1 = pMa + alpha * pMp, d2 = pMp;
-      for (int j = 0; j < nl; j++) { d1 += GLS(GL_RED + GL_NRED * buf + 2 * j); d2 += GLS(GL_RED + GL_NRED * buf + 2 * j + 1); }
-      buf ^= 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (nl == GEN_WAVE) {      // the whole wave on this island (step kernel, gen_kernels.h): butterfly sums - the same value in every lane (the additions commute), no LDS slots
+        gen_sync();
+#pragma unroll
+        for (int o = 1; o < GEN_WAVE; o <<= 1) { p1 += __shfl_xor(p1, o); p2 += __shfl_xor(p2, o); }
+        gen_sync();
+        d1 += p1; d2 += p2;
+      } else
+#endif
+      {
+        GLS(GL_RED + GL_NRED * buf + 2 * l) = p1; GLS(GL_RED + GL_NRED * buf + 2 * l + 1) = p2;
+        gen_sync();
+        for (int j = 0; j < nl; j++) { d1 += GLS(GL_RED + GL_NRED * buf + 2 * j); d2 += GLS(GL_RED + GL_NRED * buf + 2 * j + 1); }
+        buf ^= 1;
+      }
       if (isl.arm)
         for (int k = 0; k < NDOF; k++) {
           double sign = GLS(GL_LIM + 3 * k), D = GLS(GL_LIM + 3 * k + 1), aref = GLS(GL_LIM + 3 * k + 2);
@@ -937,6 +949,23 @@ D3IL_NOINLINE inline bool gen_arm_contact1(const GenConsts& gc_, const PushScrat
 #pragma unroll
   for (int k = 0; k < NDOF; k++) GLS(GL_X + arm0 + k) = a0[k] + fc[k];
   return ok;
+}
+// does gen_phase4_multi have anything to do for this environment?  (its own decisions; evaluated by the step kernel to send the WHOLE wave through the joint
+// solver for the environments that need it, one after the other)
+template <bool RS>
+D3IL_HD bool gen_joint_work(const GenConsts& gc_, const PushScratch sc) {
+  D3IL_GEN_CONSTS(gc_, gc);
+  if (gen_uncoupled(gc, sc)) return !(GLS(GL_INFO + 4) == 0 && (RS ? (unsigned)GLS(GL_INFO + 8) : 0u) == 0);
+  IslSet is;
+  gen_islands<RS>(gc, sc, is);
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k <= GEN_MAXNB; k++) if (k < is.n) {
+    const bool arm_alone = is.isl[k].n == 1 && is.isl[k].arm;
+    if (is.fast[k]) continue;
+    if (is.isl[k].n > 1 || (arm_alone && (GLS(GL_INFO + 4) != 0 || (RS && GLS(GL_INFO + 8) != 0)))) any = true;
+  }
+  return any;
 }
 // phase 4b (all nl lanes of the group together, lane l): the islands with more than one block, one after the other, and the arm
 // on its own when one of its seven joints is at a limit or its rod is on a static box (otherwise it keeps the phase-1 solution)

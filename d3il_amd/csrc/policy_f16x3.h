@@ -21,6 +21,13 @@ typedef float hx_f4 __attribute__((ext_vector_type(4)));
 constexpr int HX_C = 120, HX_H = 480, HX_PAIRS = HX_H / 32;      // a "pair" = two 16-wide hidden tiles = one K = 32 step of the second product
 constexpr int HX_PAIR_V = 2048;                                  // 16-byte vectors per packed pair: 1024 first product (tile, step, half, lane) + 1024 second (out tile, half, lane)
 constexpr float HX_LO = 2048.f, HX_ILO = 1.f / 2048.f;
+#ifndef D3IL_HX_MLP_NW
+#define D3IL_HX_MLP_NW 8
+#endif
+#ifndef D3IL_HX_LIN_NW
+#define D3IL_HX_LIN_NW 8
+#endif
+constexpr int HX_MLP_NW = D3IL_HX_MLP_NW, HX_LIN_NW = D3IL_HX_LIN_NW;      // waves (of 16 rows) per workgroup of the two kernels
 
 __device__ __forceinline__ void hx_split(float x, _Float16& hi, _Float16& lo) {
   x = fminf(fmaxf(x, -65504.f), 65504.f);
@@ -73,6 +80,23 @@ __device__ __forceinline__ void hx_load_row(const float* __restrict__ src, long 
 #pragma unroll
     for (int e = 0; e < 8; e++) { _Float16 a, b; hx_split(v[8 * s + e], a, b); hh[s][e] = a; hl[s][e] = b; }
 }
+// erf(x) without branches: libm's erff takes one of two paths per lane (|x| < 1: odd polynomial; else 1 - exp(-p(|x|))) and a wave with both kinds of lanes runs both
+// under exec masks, with a jump each - eight evaluations per lane and hidden pair were the longest serial part of the MLP kernel.  The same two minimax forms
+// (coefficients of the device library's erff), both evaluated by every lane, one select.
+__device__ __forceinline__ float hx_erf(float x) {
+  const float ax = fabsf(x), t = x * x;
+  float p = fmaf(t, -0x1.268bc2p-11f, 0x1.420828p-8f);
+  p = fmaf(t, p, -0x1.b5937p-6f); p = fmaf(t, p, 0x1.ce077cp-4f); p = fmaf(t, p, -0x1.81266p-2f); p = fmaf(t, p, 0x1.06ebap-3f);
+  const float small = fmaf(ax, p, ax);
+  float q = fmaf(ax, 0x1.1d3156p-16f, -0x1.8d129p-12f);
+  q = fmaf(ax, q, 0x1.f9a6d2p-9f); q = fmaf(ax, q, -0x1.8c3164p-6f); q = fmaf(ax, q, 0x1.b4e9c8p-4f); q = fmaf(ax, q, 0x1.4515fap-1f); q = fmaf(ax, q, 0x1.078e5p-3f);
+  q = fmaf(ax, q, ax);
+  // exp(-q) = 2^(-q log2 e), the product in two pieces so that the fraction handed to v_exp_f32 keeps its low bits
+  const float e_hi = q * -0x1.715476p+0f, e_lo = fmaf(q, -0x1.715476p+0f, -e_hi) + q * -0x1.4ae0bep-26f;
+  const float n = rintf(e_hi);
+  const float large = 1.0f - ldexpf(__builtin_amdgcn_exp2f((e_hi - n) + e_lo), (int)n);
+  return copysignf(ax < 1.0f ? small : large, x);
+}
 #define HX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 // out[M][120] = x + b2 + W2 GELU(W1 LN(h) + b1).  wp: HX_PAIRS packed pairs (policies.py pack_mlp_weights_f16x3):
@@ -80,28 +104,37 @@ __device__ __forceinline__ void hx_load_row(const float* __restrict__ src, long 
 //   vector 1024 + (t * 2 + p) * 64 + lane                = W2_p[16 t + i][32 c + 16 (e >> 2) + 4 g + (e & 3)]            (A operand of output tile t)
 // with lane = 16 g + i, p = 0 the high half, p = 1 the low half times 2^11, zero beyond the matrices.  The second product sums the 32 hidden units of the pair in
 // the order the two D tiles of the first product hold them: lane (g, j) has units 4 g + r of tile 0 in elements r and of tile 1 in elements 4 + r of its B operand.
-__global__ __launch_bounds__(256) void k_mlp_gelu_residual_f16x3(const float* __restrict__ h, const float* __restrict__ x, const hx_h8* __restrict__ wp,
+template <int NW>      // waves per workgroup: 16 NW rows share one pass over the weights (the weight stream from L2 is what bounds the kernel at 4 waves: 480 KB per 64 rows)
+__global__ __launch_bounds__(64 * NW, 2) void k_mlp_gelu_residual_f16x3(const float* __restrict__ h, const float* __restrict__ x, const hx_h8* __restrict__ wp,
                                                                   const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, long M,
                                                                   const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
   __shared__ hx_h8 sw[2][HX_PAIR_V];
+  __shared__ hx_f4 sb1[HX_H / 4];      // fc1's bias: read per hidden tile inside the loop (a global load there put an s_waitcnt vmcnt(0) - i.e. the NEXT pair's weight prefetch - in front of every GELU)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-  const long row = (long)blockIdx.x * 64 + wave * 16 + j;
+  constexpr int NT = 64 * NW, VPT = HX_PAIR_V / NT;      // threads, 16-byte vectors per thread and pair
+  const long row = (long)blockIdx.x * (16 * NW) + wave * 16 + j;
   const bool live = row < M;
   const long rr = live ? row : (M - 1);
+  if (tid < HX_H / 4) sb1[tid] = ((const hx_f4*)b1)[tid];
   hx_h8 hh[4], hl[4];
   hx_load_row(h, rr, g, ln_w, ln_b, eps, hh, hl);
   hx_f4 acc2h[8], acc2x[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) { acc2h[t] = hx_f4{0.f, 0.f, 0.f, 0.f}; acc2x[t] = hx_f4{0.f, 0.f, 0.f, 0.f}; }
-  hx_h8 pre[8];
+  hx_h8 pre[VPT];
 #pragma unroll
-  for (int q = 0; q < 8; q++) sw[0][tid + 256 * q] = wp[tid + 256 * q];
+  for (int q = 0; q < VPT; q++) sw[0][tid + NT * q] = wp[tid + NT * q];
   __syncthreads();
   for (int c = 0; c < HX_PAIRS; c++) {
     const int cur = c & 1;
-    if (c + 1 < HX_PAIRS) {
+#if defined(HX_ABLATE) && (HX_ABLATE & 4)
+    if (false)
+#else
+    if (c + 1 < HX_PAIRS)
+#endif
+    {
 #pragma unroll
-      for (int q = 0; q < 8; q++) pre[q] = wp[(long)(c + 1) * HX_PAIR_V + tid + 256 * q];
+      for (int q = 0; q < VPT; q++) pre[q] = wp[(long)(c + 1) * HX_PAIR_V + tid + NT * q];
     }
     hx_h8 gh, gl;
 #pragma unroll
@@ -114,24 +147,38 @@ __global__ __launch_bounds__(256) void k_mlp_gelu_residual_f16x3(const float* __
         ax1 = HX_MFMA(wh, hl[s], ax1);
         ax2 = HX_MFMA(wl, hh[s], ax2);
       }
+      const hx_f4 bb1 = sb1[8 * c + 4 * tile + g];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const float v = ah[r] + (ax1[r] + ax2[r]) * HX_ILO + b1[32 * c + 16 * tile + 4 * g + r];
-        const float gv = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));      // nn.GELU() (exact)
+        const float v = ah[r] + (ax1[r] + ax2[r]) * HX_ILO + bb1[r];
+#if defined(HX_ABLATE) && (HX_ABLATE & 1)
+        const float gv = v;      // (probe builds only: tools/probe/f16x3_bench.py -DHX_ABLATE=bits)
+#else
+        const float gv = 0.5f * v * (1.0f + hx_erf(v * 0.70710678118654752440f));      // nn.GELU() (exact form)
+#endif
         _Float16 a, b;
         hx_split(gv, a, b);
         gh[4 * tile + r] = a; gl[4 * tile + r] = b;
       }
     }
+#if defined(HX_ABLATE) && (HX_ABLATE & 2)
+    acc2h[0][0] += (float)gh[0] + (float)gl[0] + (float)gh[5] + (float)gl[6];
+#else
 #pragma unroll
     for (int t = 0; t < 8; t++) acc2h[t] = HX_MFMA(sw[cur][1024 + (t * 2) * 64 + lane], gh, acc2h[t]);
 #pragma unroll
     for (int t = 0; t < 8; t++) acc2x[t] = HX_MFMA(sw[cur][1024 + (t * 2) * 64 + lane], gl, acc2x[t]);
 #pragma unroll
     for (int t = 0; t < 8; t++) acc2x[t] = HX_MFMA(sw[cur][1024 + (t * 2 + 1) * 64 + lane], gh, acc2x[t]);
-    if (c + 1 < HX_PAIRS) {
+#endif
+#if defined(HX_ABLATE) && (HX_ABLATE & 4)
+    if (false)
+#else
+    if (c + 1 < HX_PAIRS)
+#endif
+    {
 #pragma unroll
-      for (int q = 0; q < 8; q++) sw[cur ^ 1][tid + 256 * q] = pre[q];
+      for (int q = 0; q < VPT; q++) sw[cur ^ 1][tid + NT * q] = pre[q];
     }
     __syncthreads();
   }
@@ -147,25 +194,29 @@ __global__ __launch_bounds__(256) void k_mlp_gelu_residual_f16x3(const float* __
 
 // out[M][N] = (LayerNorm)(xin)[M][120] W^T + bias (+ resid).  wp: ceil(N / 16) tiles of 512 vectors (policies.py pack_linear120_weights_f16x3):
 //   vector (s * 2 + p) * 64 + lane of tile t = W_p[16 t + i][32 s + 8 g + e], zero beyond N rows / 120 columns.  Two tiles per LDS stage.
-__global__ __launch_bounds__(256) void k_linear120_f16x3(const float* __restrict__ xin, const hx_h8* __restrict__ wp, const float* __restrict__ bias, const float* __restrict__ resid,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_linear120_f16x3(const float* __restrict__ xin, const hx_h8* __restrict__ wp, const float* __restrict__ bias, const float* __restrict__ resid,
                                                           float* __restrict__ out, long M, int N, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
   __shared__ hx_h8 sw[2][1024];
+  __shared__ hx_f4 sbias[96];      // N <= 384 (checked by the caller)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-  const long row = (long)blockIdx.x * 64 + wave * 16 + j;
+  constexpr int NT = 64 * NW, VPT = 1024 / NT;
+  const long row = (long)blockIdx.x * (16 * NW) + wave * 16 + j;
   const bool live = row < M;
   const long rr = live ? row : (M - 1);
+  if (tid < 96) sbias[tid] = 4 * tid < N ? ((const hx_f4*)bias)[tid] : hx_f4{0.f, 0.f, 0.f, 0.f};
   hx_h8 hh[4], hl[4];
   hx_load_row(xin, rr, g, ln_w, ln_b, eps, hh, hl);
   const int ntiles = (N + 15) / 16, nstages = (ntiles + 1) / 2;      // (the packed buffer is padded to an even number of tiles)
-  hx_h8 pre[4];
+  hx_h8 pre[VPT];
 #pragma unroll
-  for (int q = 0; q < 4; q++) sw[0][tid + 256 * q] = wp[tid + 256 * q];
+  for (int q = 0; q < VPT; q++) sw[0][tid + NT * q] = wp[tid + NT * q];
   __syncthreads();
   for (int st = 0; st < nstages; st++) {
     const int cur = st & 1;
     if (st + 1 < nstages) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) pre[q] = wp[(long)(st + 1) * 1024 + tid + 256 * q];
+      for (int q = 0; q < VPT; q++) pre[q] = wp[(long)(st + 1) * 1024 + tid + NT * q];
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -180,14 +231,14 @@ __global__ __launch_bounds__(256) void k_linear120_f16x3(const float* __restrict
       }
       const int col = 16 * t + 4 * g;
       if (live && col < N) {
-        hx_f4 v = ah + (ax1 + ax2) * HX_ILO + *(const hx_f4*)(bias + col);
+        hx_f4 v = ah + (ax1 + ax2) * HX_ILO + sbias[col >> 2];
         if (resid) v += *(const hx_f4*)(resid + row * (long)N + col);
         *(hx_f4*)(out + row * (long)N + col) = v;
       }
     }
     if (st + 1 < nstages) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) sw[cur ^ 1][tid + 256 * q] = pre[q];
+      for (int q = 0; q < VPT; q++) sw[cur ^ 1][tid + NT * q] = pre[q];
     }
     __syncthreads();
   }

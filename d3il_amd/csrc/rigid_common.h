@@ -8,15 +8,24 @@
 #include "panda_step.h"
 
 #if defined(D3IL_DEVICE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+// -DD3IL_STATS_PER_WAVE (tools/gpu_sort_phases.py --per-wave): the rows of the timer table are WAVES (4 blockIdx + wave) instead of workgroups, and row 4 blockIdx + 3
+// holds, per wave of the generic engine's step kernel, the ticks it waited at the workgroup barrier of a sub-step (gen_kernels.h)
+#if defined(D3IL_STATS_PER_WAVE)
+#define PUSH_ROW (blockIdx.x * 4 + (threadIdx.x >> 6))
+#define PUSH_ROW_OK (blockIdx.x < 1024)
+#else
+#define PUSH_ROW blockIdx.x
+#define PUSH_ROW_OK (blockIdx.x < 4096)
+#endif
 #define PUSH_TIC unsigned long long t_tic_ = wall_clock64()
 #define PUSH_TOC(slot) do { unsigned long long t_now_ = wall_clock64(); \
-    if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && blockIdx.x < 4096) \
-      atomicAdd(&d3il::g_dev_wave[blockIdx.x][slot], t_now_ - t_tic_); t_tic_ = t_now_; } while (0)
+    if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && PUSH_ROW_OK) \
+      atomicAdd(&d3il::g_dev_wave[PUSH_ROW][slot], t_now_ - t_tic_); t_tic_ = t_now_; } while (0)
 // wave-level event counter of the counting build (-DD3IL_DEVICE_STATS -DD3IL_DEVICE_COUNTS; the atomics inside the contact loops distort the timers,
 // so the plain stats build leaves them out): +1 per wave (its first active lane) each time the statement is reached
 #if defined(D3IL_DEVICE_COUNTS)
-#define PUSH_CNT(slot) do { if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && blockIdx.x < 4096) \
-      atomicAdd(&d3il::g_dev_cnt[blockIdx.x][slot], 1ull); } while (0)
+#define PUSH_CNT(slot) do { if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0 && PUSH_ROW_OK) \
+      atomicAdd(&d3il::g_dev_cnt[PUSH_ROW][slot], 1ull); } while (0)
 #else
 #define PUSH_CNT(slot) ((void)0)
 #endif

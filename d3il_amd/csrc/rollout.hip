@@ -1529,7 +1529,8 @@ int d3il_mlp_ln_gelu_residual_f16x3(const float* h, const float* ln_weight, cons
   if (rows < 0) return fail(D3IL_EINVAL, "d3il_mlp_ln_gelu_residual_f16x3: negative row count");
   if (((uintptr_t)h | (uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b2 | (uintptr_t)out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_mlp_ln_gelu_residual_f16x3: pointers must be 16-byte aligned");
   if (rows == 0) return D3IL_OK;
-  hipLaunchKernelGGL(k_mlp_gelu_residual_f16x3, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, x, (const hx_h8*)w_packed, b1, b2, out, rows, ln_weight, ln_bias, ln_eps);
+  hipLaunchKernelGGL(k_mlp_gelu_residual_f16x3<HX_MLP_NW>, dim3((unsigned)((rows + 16 * HX_MLP_NW - 1) / (16 * HX_MLP_NW))), dim3(64 * HX_MLP_NW), 0, (hipStream_t)stream, h, x, (const hx_h8*)w_packed, b1, b2, out, rows,
+                     ln_weight, ln_bias, ln_eps);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }
@@ -1537,10 +1538,11 @@ int d3il_linear120_f16x3(const float* xin, const float* ln_weight, const float* 
                          long rows, int N, void* stream) {
   if (!xin || !w_packed || !bias || !out) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: null argument");
   if ((ln_weight == nullptr) != (ln_bias == nullptr)) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: LayerNorm weight and bias come together");
-  if (rows < 0 || N < 4 || N % 4 != 0) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: needs rows >= 0 and N a positive multiple of 4");
+  if (rows < 0 || N < 4 || N % 4 != 0 || N > 384) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: needs rows >= 0 and N a multiple of 4 in 4 .. 384");
   if (((uintptr_t)xin | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)resid | (uintptr_t)out) % 16 != 0) return fail(D3IL_EINVAL, "d3il_linear120_f16x3: pointers must be 16-byte aligned");
   if (rows == 0) return D3IL_OK;
-  hipLaunchKernelGGL(k_linear120_f16x3, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, xin, (const hx_h8*)w_packed, bias, resid, out, rows, N, ln_weight, ln_bias, ln_eps);
+  hipLaunchKernelGGL(k_linear120_f16x3<HX_LIN_NW>, dim3((unsigned)((rows + 16 * HX_LIN_NW - 1) / (16 * HX_LIN_NW))), dim3(64 * HX_LIN_NW), 0, (hipStream_t)stream, xin, (const hx_h8*)w_packed, bias, resid, out, rows, N,
+                     ln_weight, ln_bias, ln_eps);
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }
