@@ -274,7 +274,7 @@ POLICY_TEXT = {
     "random": "random policy",
     "mlp": "ResidualMLP %d->128x6->2 (Mish) stand-in policy with fixed random weights (torch, f32)",
     "ddpm": "DDPM policy of BASELINE config 4 (DiffusionMLP %d->256x8->2, t_dim 8, 4 denoising steps, fixed random weights, f32: the sampling chain as one matrix-core kernel of the library, d3il_ddpm_mlp_f32; D3IL_POLICY_FUSED_DDPM=0 = the torch chain)",
-    "beso": "BESO policy of BASELINE config 5 (DiffusionGPT 6 layers x 6 heads x 120, window 5, 16 Euler-ancestral steps, fixed random weights, torch f32)",
+    "beso": "BESO policy of BASELINE config 5 (DiffusionGPT 6 layers x 6 heads x 120, window 5, 16 Euler-ancestral steps, fixed random weights, f32; GEMMs on the matrix cores with split-f16 operands, f32 accumulate)",
     "scripted_push": "scripted pushing policy (every rod drives a cube to its target / bin: the contact regime)",
     "scripted_align": "scripted pushes from inside / outside the box walls (the two behaviour modes of the Aligning task)",
     "scripted_stack": "scripted pick-and-place policy (joint-space table from host IK: grasp, carry, stack - the contact regime of the task)",
@@ -336,25 +336,29 @@ def _ddpm_policy_roofline(pol, n_rows, dev):
 
 
 def _beso_policy_roofline(pol, n, dev):
-    """Config 5 is policy-bound: time of one policy step and of its dominant kernel (the fused transformer MLP on the f32 matrix cores, DESIGN section
-    17.9), event-timed on the current stream after the benchmark loop; achieved TFLOP/s of that kernel against the dense f32 MFMA peak."""
+    """Config 5 is policy-bound: the dominant kernel of a policy step (the fused transformer MLP of a DiffusionGPT block), event-timed on the current stream after the
+    benchmark loop.  Default GEMM mode (policies.policy_gemm_mode() == "f16x3"): the split-f16 kernel - `achieved` counts the f16 matrix flops it ISSUES (three f16
+    products per f32 product) against the dense f16 MFMA peak; `f32_equivalent_tflops` is the algorithmic rate (what an f32 GEMM of the same shape would be credited
+    with).  D3IL_POLICY_GEMM=f32: the f32-input MFMA kernel of rounds 3 - 5 against the dense f32 MFMA peak."""
     import torch
     from d3il_amd import capi
-    from d3il_amd.policies import pack_mlp_weights
-    F32_MFMA_PEAK_TFLOPS = 157.3
+    from d3il_amd.policies import pack_mlp_weights, pack_mlp_weights_f16x3, policy_gemm_mode
+    F32_MFMA_PEAK_TFLOPS, F16_MFMA_PEAK_TFLOPS = 157.3, 2500.0      # MI355X_MICROARCH.md: dense peaks
+    f16x3 = policy_gemm_mode() == "f16x3"
     blk = pol.inner.blocks[0]
     fc1, fc2 = blk.mlp[0], blk.mlp[2]
     T = 2 * pol.W + 1
     M = n * T
     x = torch.randn(M, 120, device=dev)
     out = torch.empty_like(x)
-    wp = pack_mlp_weights(fc1, fc2)
+    wp = pack_mlp_weights_f16x3(fc1.weight, fc2.weight) if f16x3 else pack_mlp_weights(fc1, fc2)
     L = capi.load()
+    fn = L.d3il_mlp_ln_gelu_residual_f16x3 if f16x3 else L.d3il_mlp_ln_gelu_residual_f32
     st = torch.cuda.current_stream(dev).cuda_stream
 
     def run():
-        capi.check(L.d3il_mlp_ln_gelu_residual_f32(x.data_ptr(), blk.ln2.weight.data_ptr(), blk.ln2.bias.data_ptr(), float(blk.ln2.eps), x.data_ptr(), wp.data_ptr(),
-                                                   fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
+        capi.check(fn(x.data_ptr(), blk.ln2.weight.data_ptr(), blk.ln2.bias.data_ptr(), float(blk.ln2.eps), x.data_ptr(), wp.data_ptr(),
+                      fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
     for _ in range(5):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -366,10 +370,14 @@ def _beso_policy_roofline(pol, n, dev):
     ms = e0.elapsed_time(e1) / 50
     flops = 2.0 * M * (120 * 480) * 2
     calls = len(pol.inner.blocks) * (len(pol.sigmas) - 1)
-    return {"bound": "mfma", "kernel": "k_mlp_gelu_residual_f32", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "kernel_ms": ms, "rows": M, "launches_per_policy_step": calls,
-            "note": "dense f32 MFMA peak of MI355X (MI355X_MICROARCH.md); the kernel runs %d times per policy step (6 blocks x 16 sampling steps), next to two linear "
-                    "kernels and the attention kernel per block" % calls}
+    issued = flops * (3.0 * 128 / 120 if f16x3 else 1.0)      # three f16 products per f32 product, K padded 120 -> 128 in the first product (counted for both, slightly high)
+    peak = F16_MFMA_PEAK_TFLOPS if f16x3 else F32_MFMA_PEAK_TFLOPS
+    return {"bound": "mfma", "kernel": "k_mlp_gelu_residual_f16x3<4>" if f16x3 else "k_mlp_gelu_residual_f32", "gemm_mode": "f16x3 (split-f16 operands, f32 accumulate)" if f16x3 else "f32",
+            "achieved": issued / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": issued / (ms * 1e-3) / 1e12 / peak,
+            "f32_equivalent_tflops": flops / (ms * 1e-3) / 1e12, "kernel_ms": ms, "rows": M, "launches_per_policy_step": calls,
+            "note": "dense MFMA peak of the operand type (MI355X_MICROARCH.md); the kernel runs %d times per policy step (6 blocks x 16 sampling steps), next to two linear "
+                    "kernels and the attention kernel per block; counters (profiles/r06/f16x3_mlp_pmc.log): the wave is issue / dependency bound at two waves per SIMD, the "
+                    "matrix pipe is busy a fifth of the kernel" % calls}
 
 
 # ---------------------------------------------------------------------------------------------------- the benchmark

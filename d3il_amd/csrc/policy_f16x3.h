@@ -22,10 +22,10 @@ constexpr int HX_C = 120, HX_H = 480, HX_PAIRS = HX_H / 32;      // a "pair" = t
 constexpr int HX_PAIR_V = 2048;                                  // 16-byte vectors per packed pair: 1024 first product (tile, step, half, lane) + 1024 second (out tile, half, lane)
 constexpr float HX_LO = 2048.f, HX_ILO = 1.f / 2048.f;
 #ifndef D3IL_HX_MLP_NW
-#define D3IL_HX_MLP_NW 8
+#define D3IL_HX_MLP_NW 4
 #endif
 #ifndef D3IL_HX_LIN_NW
-#define D3IL_HX_LIN_NW 8
+#define D3IL_HX_LIN_NW 4
 #endif
 constexpr int HX_MLP_NW = D3IL_HX_MLP_NW, HX_LIN_NW = D3IL_HX_LIN_NW;      // waves (of 16 rows) per workgroup of the two kernels
 
@@ -97,70 +97,115 @@ __device__ __forceinline__ float hx_erf(float x) {
   const float large = 1.0f - ldexpf(__builtin_amdgcn_exp2f((e_hi - n) + e_lo), (int)n);
   return copysignf(ax < 1.0f ? small : large, x);
 }
+// the same on two values at once: packed f32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) halves the instruction count of the two polynomials - the
+// MLP kernel is VALU bound in its GELU (profiles/r06/f16x3_mlp_ablation.log)
+typedef float hx_f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hx_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hx_f2 hx_erf2(hx_f2 x) {
+  const hx_f2 ax = __builtin_elementwise_abs(x), t = x * x;
+  auto F = [](hx_f2 a, hx_f2 b, float c) { return __builtin_elementwise_fma(a, b, hx_f2{c, c}); };
+  hx_f2 p = F(t, hx_f2{-0x1.268bc2p-11f, -0x1.268bc2p-11f}, 0x1.420828p-8f);
+  p = F(t, p, -0x1.b5937p-6f); p = F(t, p, 0x1.ce077cp-4f); p = F(t, p, -0x1.81266p-2f); p = F(t, p, 0x1.06ebap-3f);
+  const hx_f2 small = __builtin_elementwise_fma(ax, p, ax);
+  hx_f2 q = F(ax, hx_f2{0x1.1d3156p-16f, 0x1.1d3156p-16f}, -0x1.8d129p-12f);
+  q = F(ax, q, 0x1.f9a6d2p-9f); q = F(ax, q, -0x1.8c3164p-6f); q = F(ax, q, 0x1.b4e9c8p-4f); q = F(ax, q, 0x1.4515fap-1f); q = F(ax, q, 0x1.078e5p-3f);
+  q = __builtin_elementwise_fma(ax, q, ax);
+  // exp(-q) = 2^(-q log2 e) by ONE v_exp_f32 per value: the product's rounding (2^-24 |e|) costs 2^-24 |e| ln 2 2^-|e| of the result - below 2e-8 wherever this branch
+  // is taken (|x| >= 1: e >= 2.6) - so the two-piece product and the rint / ldexp range reduction of libm's expf are not needed here
+  const hx_f2 e = q * hx_f2{-0x1.715476p+0f, -0x1.715476p+0f};
+  hx_f2 r;
+#pragma unroll
+  for (int k = 0; k < 2; k++) r[k] = copysignf(ax[k] < 1.0f ? small[k] : 1.0f - __builtin_amdgcn_exp2f(e[k]), x[k]);
+  return r;
+}
+// two values at once into their f16 halves (one packed conversion each way)
+__device__ __forceinline__ void hx_split2(hx_f2 v, hx_h2& hi, hx_h2& lo) {
+  v[0] = __builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f); v[1] = __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f);
+  hi = __builtin_convertvector(v, hx_h2);
+  const hx_f2 back = __builtin_convertvector(hi, hx_f2);
+  lo = __builtin_convertvector((v - back) * HX_LO, hx_h2);
+}
 #define HX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
-// out[M][120] = x + b2 + W2 GELU(W1 LN(h) + b1).  wp: HX_PAIRS packed pairs (policies.py pack_mlp_weights_f16x3):
-//   vector ((tile * 4 + s) * 2 + p) * 64 + lane          = W1_p[32 c + 16 tile + i][32 s + 8 g + e]                      (A operand of step s of hidden tile `tile`)
-//   vector 1024 + (t * 2 + p) * 64 + lane                = W2_p[16 t + i][32 c + 16 (e >> 2) + 4 g + (e & 3)]            (A operand of output tile t)
-// with lane = 16 g + i, p = 0 the high half, p = 1 the low half times 2^11, zero beyond the matrices.  The second product sums the 32 hidden units of the pair in
+// out[M][120] = x + b2 + W2 GELU(W1 LN(h) + b1).  wp: HX_STAGES = HX_PAIRS + 1 packed stages of 2048 vectors (policies.py pack_mlp_weights_f16x3):
+//   stage k, vector ((tile * 4 + s) * 2 + p) * 64 + lane     = W1_p[32 k + 16 tile + i][32 s + 8 g + e]                     (first product of hidden pair k; zero for k = HX_PAIRS)
+//   stage k, vector 1024 + (t * 2 + p) * 64 + lane           = W2_p[16 t + i][32 (k - 1) + 16 (e >> 2) + 4 g + (e & 3)]      (second product of hidden pair k - 1; zero for k = 0)
+// with lane = 16 g + i, p = 0 the high half, p = 1 the low half times 2^11, zero beyond the matrices.  The second product sums the 32 hidden units of a pair in
 // the order the two D tiles of the first product hold them: lane (g, j) has units 4 g + r of tile 0 in elements r and of tile 1 in elements 4 + r of its B operand.
-template <int NW>      // waves per workgroup: 16 NW rows share one pass over the weights (the weight stream from L2 is what bounds the kernel at 4 waves: 480 KB per 64 rows)
+// SOFTWARE PIPELINE: stage k issues the first product of pair k, the GELU of pair k - 1 and the second product of pair k - 1.  The three are independent inside a
+// stage, so the matrix pipe works on one pair while the vector pipe computes the other's GELU (as one chain - first product, GELU, second product per pair - a
+// wave's matrix and vector work did not overlap at all: profiles/r06/f16x3_mlp_ablation.log).  The two empty half stages (k = 0: zero W2, k = HX_PAIRS: zero W1)
+// run like every other - no branches inside the loop body.
+constexpr int HX_STAGES = HX_PAIRS + 1;
+template <int NW>      // waves per workgroup: 16 NW rows share one pass over the weights
 __global__ __launch_bounds__(64 * NW, 2) void k_mlp_gelu_residual_f16x3(const float* __restrict__ h, const float* __restrict__ x, const hx_h8* __restrict__ wp,
-                                                                  const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, long M,
-                                                                  const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
+                                                                          const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, long M,
+                                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
   __shared__ hx_h8 sw[2][HX_PAIR_V];
-  __shared__ hx_f4 sb1[HX_H / 4];      // fc1's bias: read per hidden tile inside the loop (a global load there put an s_waitcnt vmcnt(0) - i.e. the NEXT pair's weight prefetch - in front of every GELU)
+  __shared__ hx_f4 sb1[HX_H / 4 + 8];      // fc1's bias, one zero row of 32 in front (the GELU of "pair -1" in stage 0 reads it)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-  constexpr int NT = 64 * NW, VPT = HX_PAIR_V / NT;      // threads, 16-byte vectors per thread and pair
+  constexpr int NT = 64 * NW, VPT = HX_PAIR_V / NT;      // threads, 16-byte vectors per thread and stage
   const long row = (long)blockIdx.x * (16 * NW) + wave * 16 + j;
   const bool live = row < M;
   const long rr = live ? row : (M - 1);
-  if (tid < HX_H / 4) sb1[tid] = ((const hx_f4*)b1)[tid];
+  if (tid < 8) sb1[tid] = hx_f4{0.f, 0.f, 0.f, 0.f};
+  if (tid < HX_H / 4) sb1[8 + tid] = ((const hx_f4*)b1)[tid];
   hx_h8 hh[4], hl[4];
   hx_load_row(h, rr, g, ln_w, ln_b, eps, hh, hl);
   hx_f4 acc2h[8], acc2x[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) { acc2h[t] = hx_f4{0.f, 0.f, 0.f, 0.f}; acc2x[t] = hx_f4{0.f, 0.f, 0.f, 0.f}; }
+  hx_f4 ch[2], cx[2];      // first-product accumulators of the PREVIOUS pair (hh and cross terms), consumed by this stage's GELU
+#pragma unroll
+  for (int tile = 0; tile < 2; tile++) { ch[tile] = hx_f4{0.f, 0.f, 0.f, 0.f}; cx[tile] = ch[tile]; }
   hx_h8 pre[VPT];
 #pragma unroll
   for (int q = 0; q < VPT; q++) sw[0][tid + NT * q] = wp[tid + NT * q];
   __syncthreads();
-  for (int c = 0; c < HX_PAIRS; c++) {
-    const int cur = c & 1;
+  for (int k = 0; k < HX_STAGES; k++) {
+    const int cur = k & 1;
 #if defined(HX_ABLATE) && (HX_ABLATE & 4)
     if (false)
 #else
-    if (c + 1 < HX_PAIRS)
+    if (k + 1 < HX_STAGES)
 #endif
     {
 #pragma unroll
-      for (int q = 0; q < VPT; q++) pre[q] = wp[(long)(c + 1) * HX_PAIR_V + tid + NT * q];
+      for (int q = 0; q < VPT; q++) pre[q] = wp[(long)(k + 1) * HX_PAIR_V + tid + NT * q];
     }
-    hx_h8 gh, gl;
+    // ---- first product of pair k (results are used by the NEXT stage)
+    hx_f4 nh[2], nx1[2], nx2[2];
 #pragma unroll
     for (int tile = 0; tile < 2; tile++) {
-      hx_f4 ah = hx_f4{0.f, 0.f, 0.f, 0.f}, ax1 = ah, ax2 = ah;      // three independent accumulation chains
+      nh[tile] = hx_f4{0.f, 0.f, 0.f, 0.f}; nx1[tile] = nh[tile]; nx2[tile] = nh[tile];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         const hx_h8 wh = sw[cur][((tile * 4 + s) * 2) * 64 + lane], wl = sw[cur][((tile * 4 + s) * 2 + 1) * 64 + lane];
-        ah = HX_MFMA(wh, hh[s], ah);
-        ax1 = HX_MFMA(wh, hl[s], ax1);
-        ax2 = HX_MFMA(wl, hh[s], ax2);
-      }
-      const hx_f4 bb1 = sb1[8 * c + 4 * tile + g];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float v = ah[r] + (ax1[r] + ax2[r]) * HX_ILO + bb1[r];
-#if defined(HX_ABLATE) && (HX_ABLATE & 1)
-        const float gv = v;      // (probe builds only: tools/probe/f16x3_bench.py -DHX_ABLATE=bits)
-#else
-        const float gv = 0.5f * v * (1.0f + hx_erf(v * 0.70710678118654752440f));      // nn.GELU() (exact form)
-#endif
-        _Float16 a, b;
-        hx_split(gv, a, b);
-        gh[4 * tile + r] = a; gl[4 * tile + r] = b;
+        nh[tile] = HX_MFMA(wh, hh[s], nh[tile]);
+        nx1[tile] = HX_MFMA(wh, hl[s], nx1[tile]);
+        nx2[tile] = HX_MFMA(wl, hh[s], nx2[tile]);
       }
     }
+    // ---- GELU of pair k - 1
+    hx_h8 gh, gl;
+#pragma unroll
+    for (int tile = 0; tile < 2; tile++) {
+      const hx_f4 bb1 = sb1[8 * k + 4 * tile + g];      // (row 8 (k - 1) + 8 of the padded table)
+      const hx_f4 v4 = ch[tile] + cx[tile] * HX_ILO + bb1;
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const hx_f2 v = hx_f2{v4[r], v4[r + 1]};
+#if defined(HX_ABLATE) && (HX_ABLATE & 1)
+        const hx_f2 gv = v;      // (probe builds only: tools/probe/f16x3_bench.py -DHX_ABLATE=bits)
+#else
+        const hx_f2 gv = (v * 0.5f) * (hx_erf2(v * 0.70710678118654752440f) + 1.0f);      // nn.GELU() (exact form)
+#endif
+        hx_h2 a2, b2;
+        hx_split2(gv, a2, b2);
+        gh[4 * tile + r] = a2[0]; gh[4 * tile + r + 1] = a2[1]; gl[4 * tile + r] = b2[0]; gl[4 * tile + r + 1] = b2[1];
+      }
+    }
+    // ---- second product of pair k - 1
 #if defined(HX_ABLATE) && (HX_ABLATE & 2)
     acc2h[0][0] += (float)gh[0] + (float)gl[0] + (float)gh[5] + (float)gl[6];
 #else
@@ -171,10 +216,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mlp_gelu_residual_f16x3(const fl
 #pragma unroll
     for (int t = 0; t < 8; t++) acc2x[t] = HX_MFMA(sw[cur][1024 + (t * 2 + 1) * 64 + lane], gh, acc2x[t]);
 #endif
+#pragma unroll
+    for (int tile = 0; tile < 2; tile++) { ch[tile] = nh[tile]; cx[tile] = nx1[tile] + nx2[tile]; }
 #if defined(HX_ABLATE) && (HX_ABLATE & 4)
     if (false)
 #else
-    if (c + 1 < HX_PAIRS)
+    if (k + 1 < HX_STAGES)
 #endif
     {
 #pragma unroll

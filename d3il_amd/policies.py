@@ -243,7 +243,8 @@ def mlp_f16x3_pack_index(C: int, H: int, device) -> torch.Tensor:
 
 
 def pack_mlp_weights_f16x3(fc1_weight: torch.Tensor, fc2_weight: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """f16 [H / 32][2048][8]: per pair, first-product vectors ((tile * 4 + s) * 2 + p) * 64 + lane, then second-product vectors 1024 + (t * 2 + p) * 64 + lane (p: 0 hi, 1 lo)."""
+    """f16 [H / 32 + 1 stages][2048][8]: stage k = first-product vectors ((tile * 4 + s) * 2 + p) * 64 + lane of hidden pair k (zero for the last stage), then the
+    second-product vectors 1024 + (t * 2 + p) * 64 + lane of pair k - 1 (zero for stage 0); p: 0 hi, 1 lo - the software pipeline of k_mlp_gelu_residual_f16x3."""
     H, C = fc1_weight.shape
     i1, i2 = mlp_f16x3_pack_index(C, H, fc1_weight.device)
     flat = torch.cat((fc1_weight.reshape(-1), fc2_weight.reshape(-1), fc1_weight.new_zeros(1)))
@@ -251,7 +252,8 @@ def pack_mlp_weights_f16x3(fc1_weight: torch.Tensor, fc2_weight: torch.Tensor, o
     P = H // 32
     a = torch.stack((hi[i1].view(P, 8, 64, 8), lo[i1].view(P, 8, 64, 8)), dim=2).reshape(P, 1024, 8)      # [(tile, s)][p][lane]
     b = torch.stack((hi[i2].view(P, 8, 64, 8), lo[i2].view(P, 8, 64, 8)), dim=2).reshape(P, 1024, 8)      # [t][p][lane]
-    res = torch.cat((a, b), dim=1).contiguous()
+    z = torch.zeros_like(a[:1])
+    res = torch.cat((torch.cat((a, z), dim=0), torch.cat((z, b), dim=0)), dim=1).contiguous()      # [P + 1, 2048, 8]
     if out is not None:
         out.copy_(res)
         return out
@@ -392,6 +394,30 @@ class DiffusionGPT(nn.Module):
         self.action_emb = nn.Linear(action_dim, embed_dim)
         self.action_pred = nn.Linear(embed_dim, action_dim) if linear_output else nn.Sequential(nn.Linear(embed_dim, 100), nn.SiLU(), nn.Linear(100, action_dim))
         self.obs_seq_len, self.embed_dim = obs_seq_len, embed_dim
+
+    # ---- the sampling loop's form (BESOPolicy._sample on the device): everything that does not change between the sampling steps of one predict call is computed
+    # once (state tokens, position rows, the sigma embeddings of the whole schedule), the token buffer [b, 2 t + 1, C] is filled in place - 3 small kernels per
+    # step in front of the blocks instead of ~12 (mul, 2 linear, 2 add, log, div, full, stack, permute copy, cat)
+    def begin_sampling(self, states, sigmas):
+        b, t, _ = states.size()
+        C = self.embed_dim
+        pos = self.pos_emb[0, :t, :]
+        xbuf = torch.empty(b, 2 * t + 1, C, dtype=torch.float32, device=states.device)
+        torch.add(self.tok_emb(states), pos, out=xbuf[:, 1::2])                              # state tokens: the same in every sampling step
+        emb_all = self.sigma_emb(sigmas.reshape(-1, 1).log() / 4)                                # [steps, C]; sigmas: a DEVICE tensor (no host copy inside a captured loop)
+        bias_pos = (self.action_emb.bias + pos).repeat(b, 1)                                  # [b t, C]: action_emb's bias + position rows
+        return dict(xbuf=xbuf, emb_all=emb_all, bias_pos=bias_pos, keep=torch.arange(2, 2 * t + 1, 2, device=states.device), t=t, b=b)
+
+    def forward_step(self, ctx, actions, i: int, c_in: float):
+        """The network on (states of begin_sampling, c_in * actions, sigma_i): same numbers as forward() up to f32 rounding of c_in (W a) against W (c_in a)."""
+        b, t, xbuf = ctx["b"], ctx["t"], ctx["xbuf"]
+        xbuf[:, 0] = ctx["emb_all"][i]
+        xbuf[:, 2::2] = torch.addmm(ctx["bias_pos"], actions.reshape(b * t, -1), self.action_emb.weight.t(), alpha=c_in).view(b, t, -1)
+        x = xbuf
+        for blk in self.blocks[:-1]:
+            x = blk(x)
+        x = _layer_norm(self.ln_f, self.blocks[-1](x, keep=ctx["keep"]).contiguous())
+        return self.action_pred(x)
 
     def forward(self, states, actions, sigma):
         b, t, _ = states.size()
@@ -827,7 +853,29 @@ class BESOPolicy:
         s_in = torch.full((actions.shape[0],), sigma, device=self.device)
         return self.inner(states, actions * c_in, s_in) * c_out + actions * c_skip
 
+    def _sample_device(self, states, x):
+        """_sample for the device: step-invariant work hoisted (DiffusionGPT.begin_sampling), the Karras combination and the Euler-ancestral update of a step
+        merged algebraically - den = c_out net + c_skip x;  x' = x + (x - den) (s_down - s_from) / s_from  =  (1 + k (1 - c_skip)) x - k c_out net  with
+        k = (s_down - s_from) / s_from - two element-wise kernels instead of seven (f32 rounding differs from the step-by-step form at the 1e-7 level)."""
+        sigmas, sd2 = self.sigmas, self.sigma_data ** 2
+        if getattr(self, "_sig_dev", None) is None or self._sig_dev.device != states.device:
+            self._sig_dev = torch.tensor(sigmas[:-1], dtype=torch.float32, device=states.device)
+        ctx = self.inner.begin_sampling(states, self._sig_dev)
+        for i in range(len(sigmas) - 1):
+            s_from, s_to = sigmas[i], sigmas[i + 1]
+            c_skip, c_out, c_in = sd2 / (s_from ** 2 + sd2), s_from * self.sigma_data / (s_from ** 2 + sd2) ** 0.5, 1 / (s_from ** 2 + sd2) ** 0.5
+            net = self.inner.forward_step(ctx, x, i, c_in)
+            s_up = min(s_to, (s_to ** 2 * (s_from ** 2 - s_to ** 2) / s_from ** 2) ** 0.5)
+            s_down = (s_to ** 2 - s_up ** 2) ** 0.5
+            k = (s_down - s_from) / s_from
+            x = torch.add(x * (1.0 + k * (1.0 - c_skip)), net, alpha=-k * c_out)
+            if s_down > 0:
+                x = torch.add(x, self.noise_fn(tuple(x.shape)), alpha=s_up)
+        return x
+
     def _sample(self, states, x):
+        if states.is_cuda and os.environ.get("D3IL_POLICY_BESO_FUSED_GLUE", "1") == "1" and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.inner.parameters())):
+            return self._sample_device(states, x)
         sigmas = self.sigmas
         for i in range(len(sigmas) - 1):
             s_from, s_to = sigmas[i], sigmas[i + 1]
@@ -878,6 +926,8 @@ class BESOPolicy:
     def predict_batch(self, obs):
         s = self.scaler.scale_input(obs.to(device=self.device, dtype=torch.float32))
         n, act_dim = s.shape[0], self.min_action.shape[0]
+        if s.is_cuda and getattr(self, "_sig_dev", None) is None:
+            self._sig_dev = torch.tensor(self.sigmas[:-1], dtype=torch.float32, device=s.device)      # (made here, outside a captured sampling loop)
         if s.is_cuda:                          # packed weight copies of the fused blocks: refreshed here, OUTSIDE a captured sampling loop (an EMA swap changes them)
             for blk in self.inner.blocks:
                 if blk._fused_static_ok():

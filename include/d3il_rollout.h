@@ -195,7 +195,7 @@ int d3il_linear120_f32(const float* xin, const float* ln_weight, const float* ln
 /* The same two products on the f16 matrix cores with SPLIT operands (csrc/policy_f16x3.h): every f32 operand x = xh + 2^-11 xl as two f16 numbers (22 of the 24
  * significant bits), w x = wh xh + 2^-11 (wh xl + wl xh) in f32 accumulators - three v_mfma_f32_16x16x32_f16 per f32 product instead of sixteen f32-MFMA issue slots.
  * Agreement with an f64 reference is that of an f32 FMA chain (tests/test_policies_f16x3.py); operands saturate at +-65504.  w_packed: f16 halves in the kernels' tile
- * order (d3il_amd/policies.py pack_mlp_weights_f16x3: 15 pairs of 2048 x 16 bytes; pack_linear120_weights_f16x3: an even number of tiles of 512 x 16 bytes). */
+ * order (d3il_amd/policies.py pack_mlp_weights_f16x3: 16 stages of 2048 x 16 bytes; pack_linear120_weights_f16x3: an even number of tiles of 512 x 16 bytes). */
 int d3il_mlp_ln_gelu_residual_f16x3(const float* h, const float* ln_weight, const float* ln_bias, float ln_eps, const float* x, const void* w_packed, const float* b1, const float* b2,
                                     float* out, long rows, int C, int H, void* stream);
 int d3il_linear120_f16x3(const float* xin, const float* ln_weight, const float* ln_bias, float ln_eps, const void* w_packed, const float* bias, const float* resid, float* out,

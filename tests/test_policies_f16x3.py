@@ -28,7 +28,8 @@ def test_packed_tile_order():
     random.seed(1)
     W1, W2 = torch.randn(480, 120) * 0.05, torch.randn(120, 480) * 0.05
     p = pack_mlp_weights_f16x3(W1, W2)
-    assert tuple(p.shape) == (15, 2048, 8) and p.dtype == torch.float16
+    assert tuple(p.shape) == (16, 2048, 8) and p.dtype == torch.float16      # 15 hidden pairs, staged for the software pipeline: stage k = W1 of pair k | W2 of pair k - 1
+    assert float(p[15, :1024].abs().max()) == 0.0 and float(p[0, 1024:].abs().max()) == 0.0
     h1, h2 = split_f16(W1), split_f16(W2)
     for _ in range(3000):
         c, tile, s, pp, lane, e, t = (random.randrange(k) for k in (15, 2, 4, 2, 64, 8, 8))
@@ -36,7 +37,7 @@ def test_packed_tile_order():
         k = 32 * s + 8 * g + e
         assert float(p[c, ((tile * 4 + s) * 2 + pp) * 64 + lane, e]) == (0.0 if k >= 120 else float(h1[pp][32 * c + 16 * tile + i, k]))
         row, hid = 16 * t + i, 32 * c + 16 * (e >> 2) + 4 * g + (e & 3)
-        assert float(p[c, 1024 + (t * 2 + pp) * 64 + lane, e]) == (0.0 if row >= 120 else float(h2[pp][row, hid]))
+        assert float(p[c + 1, 1024 + (t * 2 + pp) * 64 + lane, e]) == (0.0 if row >= 120 else float(h2[pp][row, hid]))
     for N in (120, 360):
         W = torch.randn(N, 120) * 0.05
         q = pack_linear120_weights_f16x3(W)

@@ -38,7 +38,7 @@ for t in range(max(TS) + 1):
     L.d3il_debug_wave_counts(CN.ctypes.data_as(C.c_void_p), NW, 1)
     if t in TS:
         Wf = W.astype(np.float64)
-        Wf /= 200.0
+        Wf /= (100.0 if PER_WAVE else 200.0)      # per workgroup: the mean of its two physics waves
         if PER_WAVE:      # per PHYSICS wave: busy microseconds (timed phases), barrier wait; per workgroup: the slower wave's busy + wait ~ the workgroup's duration
             R = Wf.reshape(-1, 4, 10)
             busy = R[:, 1:3, [0, 1, 2, 8, 9]].sum(axis=2)                  # [wg, 2 physics waves]
