@@ -339,16 +339,12 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
 #endif
     if (live) sk_phase_mid<V>(t, g, fl);
     __syncthreads();
-    // the solver takes two environments at a time, one per half wave; a pair whose contact rows do not fit the shared J area together is
-    // solved one environment after the other (job 2 p: pair p or its first environment, job 2 p + 1: its second environment).  ONE call
-    // site: the solver is inlined once
+    // the solver takes two environments at a time, one per half wave (contacts in wrench form: no row area whose size could force a pair apart).
+    // ONE call site: the solver is inlined once
 #pragma clang loop unroll(disable)
-    for (int job = 0; job < SK_LANES; job++) {
-      const int e0 = job & ~1;
-      const bool n0 = ((live_mask >> e0) & 1u) && sk_env_view(sm, e0)[SE_NEED] != 0.0;
-      const bool n1 = ((live_mask >> (e0 + 1)) & 1u) && sk_env_view(sm, e0 + 1)[SE_NEED] != 0.0;
-      const bool split = n0 && n1 && (int)sk_env_view(sm, e0)[SE_JSZ] + (int)sk_env_view(sm, e0 + 1)[SE_JSZ] > SKC_JSIZE;
-      const bool a0 = (job & 1) ? false : n0, a1 = (job & 1) ? (split && n1) : (n1 && !split);
+    for (int e0 = 0; e0 < SK_LANES; e0 += 2) {
+      const bool a0 = ((live_mask >> e0) & 1u) && sk_env_view(sm, e0)[SE_NEED] != 0.0;
+      const bool a1 = ((live_mask >> (e0 + 1)) & 1u) && sk_env_view(sm, e0 + 1)[SE_NEED] != 0.0;
       if (!a0 && !a1) continue;
       const unsigned failed = sk_solve_dual(g_stack_consts, sm, e0, lane, a0, a1);
       if (((failed & 1u) && lane == e0) || ((failed & 2u) && lane == e0 + 1)) fl |= F_SOLVER_FAIL;

@@ -841,67 +841,31 @@ constexpr int SKC_STAGE = 36;                   // staging doubles per lane in t
 static_assert(SKC_STAGE * 16 * SK_LANES <= SKC_SHARED, "contact staging must fit the shared area");
 static_assert(SK_LANES % 2 == 0, "the solver takes the environments of a workgroup in pairs");
 __device__ __forceinline__ sk_lds_double* sk_env_view(sk_lds_double* smem, int e) { return smem + SKC_SHARED + e * SE_SIZE - ST_HEAD; }
-// Contact rows in the J area: contact c owns 4 x ncol doubles at jbase (ncol = columns of body 1, 0 or 6, + columns of body 2, 6 or 9), so
-// that the rows of TWO environments fit the area in all but extreme cases (a resting box needs 24 doubles per contact, a grasp contact 60).
-// k: local column 0 .. 14 (0 .. 5 body 1, 6 .. 14 body 2); columns the contact does not have must not be addressed (sk_jcol_ok).
-#define SKJ(r, k) Jw[jbase + (r) * jncol + ((k) - jskip)]
-struct SkCoopCon { int oa, ob, na, nb, dim; double aref[4], D[4], mu, imu, fr[3]; };
-template <int NA, int NB>
-__device__ __attribute__((noinline)) void sk_coop_build(const StackConsts& kc_, const StackScratch sc, sk_lds_double* Jw, int ci, int jbase, SkCoopCon& cc) {
-  constexpr int jncol = NA + NB, jskip = NA ? 0 : 6;
-  D3IL_STACK_CONSTS(kc_, kc);
-  SkRows<NA, NB> R; int set;
-  double rec[16];
-  {   // compact record -> position, frame, distance, bodies, parameter set
-    const sk_lds_double* r = sc.t + SE_REC + ci * SREC2;
-    double n[3] = {r[3], r[4], r[5]}, t1[3], t2[3];
-    make_frame(n, t1, t2);
-    rec[0] = r[0]; rec[1] = r[1]; rec[2] = r[2];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { rec[3 + k] = n[k]; rec[6 + k] = t1[k]; rec[9 + k] = t2[k]; }
-    rec[12] = r[6];
-    const int meta = (int)r[7];
-    rec[13] = (double)(meta & 15); rec[14] = (double)((meta >> 4) & 15); rec[15] = (double)(meta >> 8);
-  }
-  sk_build_rows_rec(kc, sc, rec, R, &set);
-  const StackSet& ps = kc.set[set];
-  cc.oa = R.oa; cc.ob = R.ob; cc.na = NA; cc.nb = NB; cc.dim = R.dim;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const bool live = r < R.dim;
-    if constexpr (NA > 0) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) SKJ(r, k) = live ? -R.A[r][k] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < NB; k++) SKJ(r, 6 + k) = live ? R.B[r][k] : 0.0;
-  }
-  // mj_makeImpedance for an elliptic contact [ext] (sk_contact_dot, mode 1)
-  const double dist = rec[12];
-  const double imp = impedance(ps.solimp, dist - ps.margin);
-  const int a = (int)rec[13], b = (int)rec[14];
-  auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? kc.box_invw[body] : (body == SKB_ROD ? kc.invw_rod : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])))); };
-  const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(a) + invw(b)));
-  const double R1 = R0 / fmax(1e-15, kc.impratio);
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const double v = r < R.dim ? sk_dot(sc, R, r, ST_VEL) : 0.0;
-    cc.aref[r] = r < R.dim ? -ps.B * v - (r == 0 ? ps.K * imp * (dist - ps.margin) : 0.0) : 0.0;
-  }
-  if (kc.variant == SKV_ALIGNING && (a == 0 || b == 0)) {
-    // MuJoCo's row residual is J_o qacc_o - aref with the free body's ORIGIN acceleration; this engine solves for the centre-of-mass acceleration
-    // a_c = a_o + alpha x R c + w x (w x R c), so J_o qacc_o = J_c qacc_c -/+ d . (w x (w x R c)) for the body as geom 2 / geom 1 of the pair:
-    // the velocity-dependent term moves into the reference acceleration
-    const double sgn = b == 0 ? 1.0 : -1.0;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-      cc.aref[r] += sgn * (rec[3 + 3 * r] * sc.t[ST_TIPR + SV_CEN] + rec[4 + 3 * r] * sc.t[ST_TIPR + SV_CEN + 1] + rec[5 + 3 * r] * sc.t[ST_TIPR + SV_CEN + 2]);
-  }
-  cc.D[0] = 1 / R0; cc.D[1] = 1 / R1; cc.D[2] = 1 / R1; cc.D[3] = 1 / (R1 * ps.fric[0] * ps.fric[0] / (ps.fric[1] * ps.fric[1]));
-  cc.mu = ps.fric[0] * sqrt(R1 / R0);
-  cc.imu = 1.0 / fmax(1e-15, cc.mu * cc.mu * (1 + cc.mu * cc.mu));
-  sk_row_fric(ps, cc.fr);
-}
+// Contacts in wrench form (round 6).  The constraint rows of a contact are never materialised.  With spatial quantities about the fixed
+// reference point SKW_REF (angular part first), the row r of a contact at p with direction d_r is the wrench W_r = [(p - ref) x d_r ; d_r]
+// (the torsional row: [n ; 0]), every dof i has the motion-subspace column s_i (box: linear [0 ; e_k], angular [R e_k ; (c - ref) x R e_k];
+// arm joint k: [z_k ; (o_k - ref) x z_k]; finger slide: [0 ; axis]), and J_r[i] = +/- W_r . s_i for the dofs that move body 2 / body 1
+// (sk_box_rows / sk_arm_rows written out).  So
+//   J x      = W . (T_B - T_A),  T_body = sum of s_i x_i over the dofs that move the body (six twists per environment and vector),
+//   J' f     = +/- s_i . F,      F = sum_r f_r W_r (one 6-vector per contact),
+//   J' Hc J  = s_i' K s_j,       K = W' Hc W (one symmetric 6 x 6 per contact),
+// and contacts of the same body pair ADD in F and K before anything is projected onto the dofs: a contact lane issues 27 LDS additions
+// per pass (21 + 6 into the slot of its body pair) instead of the 15 + 120 of a box <-> finger row block, the dof lanes build their Hessian
+// row in registers from the (aggregated) pair matrices - H[i][j] = s_i' Keff(class i, class j) s_j -, and the J area of rounds 3 - 5 is gone.
+// LDS of one half wave (its environment) inside the workgroup's shared W area:
+constexpr int SKW_HALF = SKC_JSIZE / 2;
+constexpr int SKW_KST = 22;                           // a packed symmetric 6 x 6 (21 entries) + pad: tables start on 16-byte boundaries
+constexpr int SKW_SCOL = 0;                           // s_i, 27 x 6
+constexpr int SKW_TW = SKW_SCOL + 6 * SK_NV;          // twists of the generalised bodies box 0 | 1 | 2 | hand (joints 0 .. 6) | finger 0 | finger 1
+constexpr int SKW_SLOTK = SKW_TW + 36;                // K of the body pairs: static-box b (b) | box-box 01 02 12 (3 ..) | box-hand (6 + b) | box-finger (9 + 2 b + f) | finger-finger (15)
+constexpr int SKW_SLOTF = SKW_SLOTK + 16 * SKW_KST;   // F of the body pairs, oriented body 1 -> body 2 of the slot
+constexpr int SKW_AGGK = SKW_SLOTF + 16 * 6;          // Kd_b (all pairs of box b) [3] | K_b,arm [3] | Kd'_f (box pairs of finger f) [2] | Kd_f = Kd'_f + FF [2] | K_rev
+constexpr int SKW_AGGN = SKW_AGGK + 11 * SKW_KST;     // net wrench per dof class: box 0 | 1 | 2 | joints 0 .. 6 | slide 0 | slide 1
+constexpr int SKW_END = SKW_AGGN + 36;
+static_assert(SKW_END <= SKW_HALF, "the wrench tables of two environments must fit the shared area");
+__device__ constexpr double SKW_REF[3] = {0.5, 0.0, 0.0};
+__device__ __forceinline__ int sk_tri6(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+__device__ __forceinline__ int sk_genbody(int body) { return body < SK_NB ? body : (sk_finger_of(body) < 0 ? 3 : 4 + sk_finger_of(body)); }
 
 #if defined(D3IL_DEVICE_STATS)
 #define D3IL_SD_COUNT(slot) atomicAdd(&g_dev_stats[16 + (slot)], 1ull)
@@ -934,11 +898,10 @@ __device__ __forceinline__ double sk_half_max(double v, bool upper) {
   return upper ? b : a;
 }
 // The constraint problems of TWO environments (e0 on the lower half wave, e0 + 1 on the upper one; act0 / act1: which of them is solved),
-// same algorithm, stopping rule, line search and tolerances as sk_solve_island.  Per half: lane hl < ncon owns contact hl (its rows are
-// built once per solve into row slot slot0 + hl of the workgroup's J area, reference accelerations / regularisation / residuals stay in
-// its registers), lane hl < 27 owns dof hl (gradient entry, row of the Hessian and of the Cholesky factor in registers, columns broadcast
-// inside the half with v_readlane).  The two halves iterate in lock step until both have finished; a finished half idles (no LDS writes).
-// The two environments share the SK_MAXCON row slots: the caller solves them one after the other when they have more contacts than that.
+// same algorithm, stopping rule, line search and tolerances as sk_solve_island.  Per half: lane hl < ncon owns contact hl (frame, wrench
+// arms, reference accelerations / regularisation / residuals in its registers), lane hl < 27 owns dof hl (its column s_i, gradient entry,
+// row of the Hessian and of the Cholesky factor in registers, columns broadcast inside the half).  The two halves iterate in lock step
+// until both have finished; a finished half idles.
 // Returns bit 0 / bit 1: the solve of the lower / upper half FAILED (non-positive pivot or iteration cap).
 __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds_double* smem, const int e0, const int lane, const bool act0, const bool act1) {
   D3IL_STACK_CONSTS(kc_, kc);
@@ -946,28 +909,17 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
   const int hl = lane & 31;
   sk_lds_double* const t = sk_env_view(smem, e0 + (upper ? 1 : 0));
   sk_lds_double* const Hs = smem + (upper ? ST_HEAD : 0);
-  sk_lds_double* const Gs = Hs + ST_G;
   sk_lds_double* const Ps = Hs + ST_P;
-  sk_lds_double* const Jw = smem + 2 * ST_HEAD;
-  const StackScratch sc{t, nullptr};
+  sk_lds_double* const Wb = smem + 2 * ST_HEAD + (upper ? SKW_HALF : 0);
   const bool active = upper ? act1 : act0;
   const int ncon = active ? (int)t[SE_NCON] : 0;
   const bool con = hl < ncon;
-  // base of this lane's contact in the J area: the upper half's rows follow the lower half's; inside a half, prefix sum of the sizes
-  // (through the half's H area, which is free until the first gradient pass)
-  int jncol = 15, jskip = 0, jbase = 0;
-  {
-    int sz = 0;
-    if (con) { const int meta = (int)t[SE_REC + hl * SREC2 + 7]; const int a = meta & 15, bdy = (meta >> 4) & 15; jncol = sk_jcols(a, bdy); jskip = (a == SKB_STATIC || a >= SKB_FINGER) ? 6 : 0; sz = 4 * jncol; }
-    Hs[hl] = (double)sz;
-    __syncthreads();
-    for (int c = 0; c < hl; c++) jbase += (int)Hs[c];
-    if (upper && act0) jbase += (int)sk_env_view(smem, e0)[SE_JSZ];
-    __syncthreads();
-  }
   const int i = hl;                         // dof owned by this lane (within its half)
   const bool row = active && hl < SK_NV, armrow = row && hl >= SK_ARM0;
   const int ia = armrow ? hl - SK_ARM0 : 0;
+  const int bi = hl >= SK_ARM0 ? SK_NB : hl / 6;      // block of the dof: box 0 | 1 | 2 | arm
+  const bool slide = armrow && ia >= NARM;
+  const int fs = slide ? ia - NARM : 0;
 #if defined(D3IL_DEVICE_STATS)
   unsigned long long sd_t0 = wall_clock64();
 #define SD_TOC(slot) do { unsigned long long t_ = wall_clock64(); if (lane == 0 && blockIdx.x == 0) atomicAdd(&g_dev_stats[16 + (slot)], t_ - sd_t0); sd_t0 = t_; } while (0)
@@ -975,17 +927,50 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
 #else
 #define SD_TOC(slot) ((void)0)
 #endif
-  // ---- contacts: rows, reference accelerations, regularisation
-  SkCoopCon cc;
-  cc.oa = 0; cc.ob = 0; cc.na = 0; cc.nb = 6; cc.dim = 3; cc.mu = 1; cc.imu = 0.5;
+  // ---- dof lanes: motion-subspace column s_i (registers + LDS)
+  double si[6] = {0, 0, 0, 0, 0, 0};
+  if (row) {
+    if (!armrow) {
+      const int b = hl / 6, k = hl - 6 * b;
+      if (k < 3) { si[3] = k == 0 ? 1.0 : 0.0; si[4] = k == 1 ? 1.0 : 0.0; si[5] = k == 2 ? 1.0 : 0.0; }
+      else {
+        const double w[3] = {t[ST_BR + 9 * b + (k - 3)], t[ST_BR + 9 * b + 3 + (k - 3)], t[ST_BR + 9 * b + 6 + (k - 3)]};      // body axis k - 3 in the world frame
+        const double c[3] = {t[ST_BP + 3 * b] - SKW_REF[0], t[ST_BP + 3 * b + 1] - SKW_REF[1], t[ST_BP + 3 * b + 2] - SKW_REF[2]};
+        si[0] = w[0]; si[1] = w[1]; si[2] = w[2];
+        si[3] = c[1] * w[2] - c[2] * w[1]; si[4] = c[2] * w[0] - c[0] * w[2]; si[5] = c[0] * w[1] - c[1] * w[0];
+      }
+    } else if (!slide) {
+      const double z[3] = {t[ST_Z + 3 * ia], t[ST_Z + 3 * ia + 1], t[ST_Z + 3 * ia + 2]};
+      const double o[3] = {t[ST_O + 3 * ia] - SKW_REF[0], t[ST_O + 3 * ia + 1] - SKW_REF[1], t[ST_O + 3 * ia + 2] - SKW_REF[2]};
+      si[0] = z[0]; si[1] = z[1]; si[2] = z[2];
+      si[3] = o[1] * z[2] - o[2] * z[1]; si[4] = o[2] * z[0] - o[0] * z[2]; si[5] = o[0] * z[1] - o[1] * z[0];
+    } else { si[3] = t[ST_FAX + 3 * fs]; si[4] = t[ST_FAX + 3 * fs + 1]; si[5] = t[ST_FAX + 3 * fs + 2]; }
 #pragma unroll
-  for (int r = 0; r < 4; r++) { cc.aref[r] = 0; cc.D[r] = 1; }
-  cc.fr[0] = cc.fr[1] = cc.fr[2] = 1;
+    for (int a = 0; a < 6; a++) Wb[SKW_SCOL + 6 * i + a] = si[a];
+  }
+  // ---- contact lanes: frame, wrench arms, slot of the body pair, twist addresses
+  double cd[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}}, cm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};      // d_r (normal, tangent 1, tangent 2), m_r = (p - ref) x d_r
+  int tA = -1, tB = SKW_TW, slot = 0, cdim = 3, cset = 0, cba = -1, cbb = 0, cbodya = SKB_STATIC, cbodyb = 0;
+  double sgF = 1, cdist = 0;
   if (con) {
-    const int meta = (int)t[SE_REC + hl * SREC2 + 7];
-    const int kind = sk_kind(meta & 15, (meta >> 4) & 15);
-    if (kind == 0) sk_coop_build<0, 6>(kc, sc, Jw, hl, jbase, cc); else if (kind == 1) sk_coop_build<6, 6>(kc, sc, Jw, hl, jbase, cc);
-    else if (kind == 2) sk_coop_build<6, 9>(kc, sc, Jw, hl, jbase, cc); else sk_coop_build<0, 9>(kc, sc, Jw, hl, jbase, cc);
+    const sk_lds_double* r = t + SE_REC + hl * SREC2;
+    const double p[3] = {r[0] - SKW_REF[0], r[1] - SKW_REF[1], r[2] - SKW_REF[2]};
+    cd[0][0] = r[3]; cd[0][1] = r[4]; cd[0][2] = r[5];
+    make_frame(cd[0], cd[1], cd[2]);
+#pragma unroll
+    for (int q = 0; q < 3; q++) { cm[q][0] = p[1] * cd[q][2] - p[2] * cd[q][1]; cm[q][1] = p[2] * cd[q][0] - p[0] * cd[q][2]; cm[q][2] = p[0] * cd[q][1] - p[1] * cd[q][0]; }
+    cdist = r[6];
+    const int meta = (int)r[7];
+    cbodya = meta & 15; cbodyb = (meta >> 4) & 15; cset = meta >> 8;
+    cdim = kc.set[cset].dim;
+    cba = sk_blk_of(cbodya); cbb = sk_blk_of(cbodyb);
+    const int ga = cbodya == SKB_STATIC ? -1 : sk_genbody(cbodya), gb = sk_genbody(cbodyb);
+    tB = SKW_TW + 6 * gb; tA = ga < 0 ? -1 : SKW_TW + 6 * ga;
+    if (ga < 0) slot = gb;                                                        // static <-> box
+    else if (ga < 3 && gb < 3) { slot = 3 + ga + gb - 1; sgF = ga < gb ? 1.0 : -1.0; }      // box <-> box, stored with the lower box as body 1
+    else if (ga < 3) slot = gb == 3 ? 6 + ga : 9 + 2 * ga + (gb - 4);            // box <-> hand / rod, box <-> finger
+    else if (gb < 3) { slot = ga == 3 ? 6 + gb : 9 + 2 * gb + (ga - 4); sgF = -1.0; }
+    else { slot = 15; sgF = (ga == 5 && gb == 4) ? -1.0 : 1.0; }                  // finger <-> finger, stored finger 0 -> finger 1
   }
   // ---- rows of the block-diagonal mass matrix and the joint-limit row of this lane's dof
   double mdiag = 0, Ma[NDOF];
@@ -998,10 +983,61 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
   }
   double lsg = 0, lD = 0, lar = 0;
   if (armrow) { lsg = t[ST_LIM + 3 * ia]; lD = t[ST_LIM + 3 * ia + 1]; lar = t[ST_LIM + 3 * ia + 2]; }
+  bool fin = !active;      // this half has finished (converged, failed, or nothing to do); half-uniform
+  bool okh = true;
+  // twists of the six generalised bodies for a dof vector v (LDS): lane (body, component) of 24 sums s_i[component] v_i over the body's dofs
+  auto twists = [&](const sk_lds_double* v) {
+    if (hl < 24 && !fin) {
+      const int body = hl / 6, comp = hl - 6 * body, i0 = body < SK_NB ? 6 * body : SK_ARM0;
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < NARM; k++) if (k < 6 || body == SK_NB) s += Wb[SKW_SCOL + 6 * (i0 + k) + comp] * v[i0 + k];
+      Wb[SKW_TW + 6 * body + comp] = s;
+      if (body == SK_NB) {
+        Wb[SKW_TW + 24 + comp] = s + Wb[SKW_SCOL + 6 * (SK_ARM0 + NARM) + comp] * v[SK_ARM0 + NARM];
+        Wb[SKW_TW + 30 + comp] = s + Wb[SKW_SCOL + 6 * (SK_ARM0 + NARM + 1) + comp] * v[SK_ARM0 + NARM + 1];
+      }
+    }
+  };
+  // W . (T_B - T_A) of this lane's contact with the twists in the table
+  auto wdot = [&](double* out) {
+    double dw[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) dw[a] = Wb[tB + a] - (tA >= 0 ? Wb[tA + a] : 0.0);
+#pragma unroll
+    for (int q = 0; q < 3; q++) out[q] = cm[q][0] * dw[0] + cm[q][1] * dw[1] + cm[q][2] * dw[2] + cd[q][0] * dw[3] + cd[q][1] * dw[4] + cd[q][2] * dw[5];
+    out[3] = cdim > 3 ? cd[0][0] * dw[0] + cd[0][1] * dw[1] + cd[0][2] * dw[2] : 0.0;
+  };
   __syncthreads();
+  twists(t + ST_VEL);
+  __syncthreads();
+  // ---- contacts: reference accelerations, regularisation (mj_makeImpedance for an elliptic contact [ext]; sk_contact_dot, mode 1)
+  double aref[4] = {0, 0, 0, 0}, cD[4] = {1, 1, 1, 1}, cmu = 1, cimu = 0.5, cfr[3] = {1, 1, 1};
+  if (con) {
+    const StackSet& ps = kc.set[cset];
+    const double imp = impedance(ps.solimp, cdist - ps.margin);
+    auto invw = [&](int body) { return body == SKB_STATIC ? 0.0 : (body < SK_NB ? kc.box_invw[body] : (body == SKB_ROD ? kc.invw_rod : (body >= SKB_HAND ? kc.invw_hand : (body >= SKB_TIP ? kc.invw_tip[(body - SKB_FINGER) & 1] : kc.invw_finger[(body - SKB_FINGER) & 1])))); };
+    const double R0 = fmax(1e-15, (1 - imp) / imp * (invw(cbodya) + invw(cbodyb)));
+    const double R1 = R0 / fmax(1e-15, kc.impratio);
+    double jv[4];
+    wdot(jv);
+#pragma unroll
+    for (int r = 0; r < 4; r++) aref[r] = r < cdim ? -ps.B * jv[r] - (r == 0 ? ps.K * imp * (cdist - ps.margin) : 0.0) : 0.0;
+    if (kc.variant == SKV_ALIGNING && (cbodya == 0 || cbodyb == 0)) {
+      // MuJoCo's row residual is J_o qacc_o - aref with the free body's ORIGIN acceleration; this engine solves for the centre-of-mass acceleration
+      // a_c = a_o + alpha x R c + w x (w x R c), so J_o qacc_o = J_c qacc_c -/+ d . (w x (w x R c)) for the body as geom 2 / geom 1 of the pair:
+      // the velocity-dependent term moves into the reference acceleration
+      const double sgn = cbodyb == 0 ? 1.0 : -1.0;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        aref[r] += sgn * (cd[r][0] * t[ST_TIPR + SV_CEN] + cd[r][1] * t[ST_TIPR + SV_CEN + 1] + cd[r][2] * t[ST_TIPR + SV_CEN + 2]);
+    }
+    cD[0] = 1 / R0; cD[1] = 1 / R1; cD[2] = 1 / R1; cD[3] = 1 / (R1 * ps.fric[0] * ps.fric[0] / (ps.fric[1] * ps.fric[1]));
+    cmu = ps.fric[0] * sqrt(R1 / R0);
+    cimu = 1.0 / fmax(1e-15, cmu * cmu * (1 + cmu * cmu));
+    sk_row_fric(ps, cfr);
+  }
   SD_TOC(3);
-  auto col = [&](int k) { return k < 6 ? cc.oa + k : cc.ob + k - 6; };
-  auto jcol_ok = [&](int k) { return k < 6 ? jskip == 0 : k - 6 < jncol - (jskip ? 0 : 6); };      // does the contact have local column k
   auto m_times = [&](const sk_lds_double* va, const sk_lds_double* vb) -> double {      // (M (v_a - v_b))_i
     if (!row) return 0.0;
     if (!armrow) return mdiag * (va[i] - (vb ? vb[i] : 0.0));
@@ -1010,96 +1046,171 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     for (int k = 0; k < NDOF; k++) sum += Ma[k] * (va[SK_ARM0 + k] - (vb ? vb[SK_ARM0 + k] : 0.0));
     return sum;
   };
-  double jar[4] = {0, 0, 0, 0}, gi = 0, mxa = 0, xi = row ? t[ST_X + i] : 0.0;
-  bool fin = !active;      // this half has finished (converged, failed, or nothing to do); half-uniform
-  bool okh = true;
-  // gradient and Hessian at x: g -> Gs and gi, H -> Hs; returns max |g| of the half
-  auto grad_pass = [&]() -> double {
-    if (!fin) for (int q = hl; q < SK_NH; q += 32) Hs[q] = 0;
-    __syncthreads();
-    mxa = m_times(t + ST_X, t + ST_A0);
-    double gl = mxa;
-    if (row && !fin) {
-      if (!armrow) Hs[tri(i, i)] = mdiag;
-      else {
+  // Block structure, union over the two halves: blocks box 0 | 1 | 2 | arm.  cpl0 bit (4 bi + bk), bk <= bi: a contact touches both blocks
+  // (bk == bi: the block has a contact at all); cpl: the same below the diagonal after fill closure = the structure of the Cholesky factor
+  unsigned cpl0 = 0, cpl = 0;
+  {
 #pragma unroll
-        for (int k = 0; k < NDOF; k++) if (k <= ia) Hs[tri(i, SK_ARM0 + k)] = Ma[k];
+    for (int bq = 0; bq <= SK_NB; bq++) {
+      if (__any(con && (cba == bq || cbb == bq))) cpl0 |= 1u << (5 * bq);
+#pragma unroll
+      for (int bk = 0; bk < bq; bk++) if (__any(con && ((cba == bk && cbb == bq) || (cba == bq && cbb == bk)))) cpl0 |= 1u << (4 * bq + bk);
+    }
+    cpl = cpl0;
+#pragma unroll
+    for (int k = 0; k < SK_NB; k++) {
+#pragma unroll
+      for (int bq = k + 1; bq <= SK_NB; bq++) {
+#pragma unroll
+        for (int bj = k + 1; bj < bq; bj++) if (((cpl >> (4 * bq + k)) & 1u) && ((cpl >> (4 * bj + k)) & 1u)) cpl |= 1u << (4 * bq + bj);
       }
     }
-    if (lsg != 0) { const double lj = lsg * xi - lar; if (lj < 0) { gl += lsg * lD * lj; if (!fin) Hs[tri(i, i)] += lD; } }
-    if (row && !fin) Gs[i] = gl;
+  }
+  const bool has_ff = __any(con && slot == 15);
+  double jar[4] = {0, 0, 0, 0}, gi = 0, mxa = 0, xi = row ? t[ST_X + i] : 0.0;
+  double Hr[SK_NV];
+  // gradient and Hessian at x: g -> gi, H row -> Hr (registers of the dof lane); returns max |g| of the half
+  auto grad_pass = [&]() -> double {
+    if (!fin) {
+#pragma unroll
+      for (int q = 0; q < (16 * SKW_KST + 16 * 6 + 31) / 32; q++) { const int w = hl + 32 * q; if (w < 16 * SKW_KST + 16 * 6) Wb[SKW_SLOTK + w] = 0; }
+    }
+    twists(t + ST_X);
+    mxa = m_times(t + ST_X, t + ST_A0);
     __syncthreads();
     if (con && !fin) {
-      // block offsets re-read per pass through an opaque move: the row / column addresses derived from them are then recomputed here
-      // instead of being hoisted out of the Newton loop and spilled (a scratch reload + full wait in front of every LDS add otherwise)
-      int oa = cc.oa, ob = cc.ob;
-      asm volatile("" : "+v"(oa), "+v"(ob));
-      auto col = [&](int k) { return k < 6 ? oa + k : ob + k - 6; };
-      double J[4][SKC_NJ], xk[SKC_NJ], f[4], Hc[16];
+      double f[4], Hc[16];
+      wdot(jar);
 #pragma unroll
-      for (int k = 0; k < SKC_NJ; k++) xk[k] = jcol_ok(k) ? t[ST_X + col(k)] : 0.0;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        double sum = 0;
-#pragma unroll
-        for (int k = 0; k < SKC_NJ; k++) { J[r][k] = jcol_ok(k) ? SKJ(r, k) : 0.0; sum += J[r][k] * xk[k]; }
-        jar[r] = sum - cc.aref[r];
-      }
-      sk_cone_pre(cc.dim, jar, cc.D, cc.mu, cc.imu, cc.fr, f, Hc);
+      for (int r = 0; r < 4; r++) jar[r] -= aref[r];
+      sk_cone_pre(cdim, jar, cD, cmu, cimu, cfr, f, Hc);
       bool any = false;
 #pragma unroll
       for (int q = 0; q < 16; q++) any = any || Hc[q] != 0;
       if (any) {
+        // W rows: r < 3: [cm[r] ; cd[r]], r = 3: [cd[0] ; 0].  G = Hc W (4 x 6), K = W' G (lower triangle), F = W' f
+        double G[4][6];
 #pragma unroll
-        for (int k = 0; k < SKC_NJ; k++) {
-          if (k >= 6 + cc.nb || (k < 6 && cc.na == 0)) continue;      // structural zeros: columns beyond body 2's block, a static body 1
-          const double acc = J[0][k] * f[0] + J[1][k] * f[1] + J[2][k] * f[2] + J[3][k] * f[3];
-          (void)__hip_atomic_fetch_add(&Gs[col(k)], -acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            G[r][a] = Hc[4 * r] * cm[0][a] + Hc[4 * r + 1] * cm[1][a] + Hc[4 * r + 2] * cm[2][a] + Hc[4 * r + 3] * cd[0][a];
+            G[r][3 + a] = Hc[4 * r] * cd[0][a] + Hc[4 * r + 1] * cd[1][a] + Hc[4 * r + 2] * cd[2][a];
+          }
+        }
+        sk_lds_double* const Ks = Wb + SKW_SLOTK + slot * SKW_KST;
+        sk_lds_double* const Fs = Wb + SKW_SLOTF + slot * 6;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+          for (int b = 0; b <= a; b++) {
+            double v;
+            if (a < 3) v = cm[0][a] * G[0][b] + cm[1][a] * G[1][b] + cm[2][a] * G[2][b] + cd[0][a] * G[3][b];
+            else v = cd[0][a - 3] * G[0][b] + cd[1][a - 3] * G[1][b] + cd[2][a - 3] * G[2][b];
+            (void)__hip_atomic_fetch_add(&Ks[a * (a + 1) / 2 + b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
 #pragma unroll
-        for (int a = 0; a < SKC_NJ; a++) {
-          if (a >= 6 + cc.nb) continue;
-          double w[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) w[q] = J[0][a] * Hc[q] + J[1][a] * Hc[4 + q] + J[2][a] * Hc[8 + q] + J[3][a] * Hc[12 + q];
-          if (w[0] == 0 && w[1] == 0 && w[2] == 0 && w[3] == 0) continue;      // zero column (body 1 static, the other finger's slide dof)
-          const int ra = col(a);
-          // column index <= row index in dof order: body 1's block precedes body 2's.  No test per entry: the blocks are dense
-          if (a >= 6 && cc.na > 0) {
-#pragma unroll
-            for (int b = 0; b < 6; b++)
-              (void)__hip_atomic_fetch_add(&Hs[tri(ra, oa + b)], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-#pragma unroll
-          for (int b = (a < 6 ? 0 : 6); b <= a; b++)
-            (void)__hip_atomic_fetch_add(&Hs[tri(ra, col(b))], w[0] * J[0][b] + w[1] * J[1][b] + w[2] * J[2][b] + w[3] * J[3][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int a = 0; a < 3; a++) {
+          (void)__hip_atomic_fetch_add(&Fs[a], sgF * (f[0] * cm[0][a] + f[1] * cm[1][a] + f[2] * cm[2][a] + f[3] * cd[0][a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_add(&Fs[3 + a], sgF * (f[0] * cd[0][a] + f[1] * cd[1][a] + f[2] * cd[2][a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
     }
     __syncthreads();
-    gi = (row && !fin) ? Gs[i] : 0.0;
-    return sk_half_max(fabs(gi), upper);
-  };
-  // Block structure of the Cholesky factor, union over the two halves: blocks box 0 | 1 | 2 | arm; cpl bit (4 bi + bk), bk < bi: block row bi
-  // of the factor has entries in column block bk (a contact couples the two blocks, or fill: an earlier block couples with both)
-  unsigned cpl = 0;
-  {
-    int ba = -1, bb = 0;
-    if (con) { const int meta = (int)t[SE_REC + hl * SREC2 + 7]; ba = sk_blk_of(meta & 15); bb = sk_blk_of((meta >> 4) & 15); }
+    // aggregation: lane e < 21 sums entry e of the pair matrices into the tables the dof lanes read; lanes 21 .. 26: the net wrenches
+    if (!fin && active) {
+      if (hl < 21) {
+        double v[16];
 #pragma unroll
-    for (int bi = 1; bi <= SK_NB; bi++) {
+        for (int s = 0; s < 16; s++) v[s] = Wb[SKW_SLOTK + s * SKW_KST + hl];
+        const double a0 = v[6] + v[9] + v[10], a1 = v[7] + v[11] + v[12], a2 = v[8] + v[13] + v[14];
+        const double f0 = v[9] + v[11] + v[13], f1 = v[10] + v[12] + v[14];
+        sk_lds_double* const A = Wb + SKW_AGGK + hl;
+        A[0] = v[0] + v[3] + v[4] + a0; A[SKW_KST] = v[1] + v[3] + v[5] + a1; A[2 * SKW_KST] = v[2] + v[4] + v[5] + a2;
+        A[3 * SKW_KST] = a0; A[4 * SKW_KST] = a1; A[5 * SKW_KST] = a2;
+        A[6 * SKW_KST] = f0; A[7 * SKW_KST] = f1; A[8 * SKW_KST] = f0 + v[15]; A[9 * SKW_KST] = f1 + v[15];
+        A[10 * SKW_KST] = a0 + a1 + a2;
+      } else if (hl < 27) {
+        const int c = hl - 21;
+        double v[16];
 #pragma unroll
-      for (int bk = 0; bk < bi; bk++) if (__any(con && ((ba == bk && bb == bi) || (ba == bi && bb == bk)))) cpl |= 1u << (4 * bi + bk);
-    }
-#pragma unroll
-    for (int k = 0; k < SK_NB; k++) {
-#pragma unroll
-      for (int bi = k + 1; bi <= SK_NB; bi++) {
-#pragma unroll
-        for (int bj = k + 1; bj < bi; bj++) if (((cpl >> (4 * bi + k)) & 1u) && ((cpl >> (4 * bj + k)) & 1u)) cpl |= 1u << (4 * bi + bj);
+        for (int s = 0; s < 16; s++) v[s] = Wb[SKW_SLOTF + 6 * s + c];
+        const double n3 = v[6] + v[7] + v[8], n4 = v[9] + v[11] + v[13] - v[15], n5 = v[10] + v[12] + v[14] + v[15];
+        sk_lds_double* const N = Wb + SKW_AGGN + c;
+        N[0] = v[0] - v[6] - v[9] - v[10] - v[3] - v[4];
+        N[6] = v[1] - v[7] - v[11] - v[12] + v[3] - v[5];
+        N[12] = v[2] - v[8] - v[13] - v[14] + v[4] + v[5];
+        N[18] = n3 + n4 + n5; N[24] = n4; N[30] = n5;
       }
     }
-  }
+    __syncthreads();
+    // dof lanes: gradient entry and Hessian row
+    double gl = mxa;
+    bool limact = false;
+    if (lsg != 0) { const double lj = lsg * xi - lar; if (lj < 0) { gl += lsg * lD * lj; limact = true; } }
+    {
+      const int cls = armrow ? (slide ? 4 + fs : 3) : bi;
+      const sk_lds_double* const N = Wb + SKW_AGGN + 6 * cls;
+      gl -= si[0] * N[0] + si[1] * N[1] + si[2] * N[2] + si[3] * N[3] + si[4] * N[4] + si[5] * N[5];
+    }
+    gi = (row && !fin) ? gl : 0.0;
+#pragma unroll
+    for (int k = 0; k < SK_NV; k++) {
+      double m = 0;
+      if (k < SK_ARM0) m = (row && !armrow && k == i) ? mdiag : 0.0;
+      else m = (armrow && k - SK_ARM0 <= ia) ? Ma[k - SK_ARM0] : 0.0;
+      if (limact && k == i) m += lD;
+      Hr[k] = m;
+    }
+#pragma unroll
+    for (int cb = 0; cb <= SK_NB; cb++) {
+      const bool mine = row && !fin && cb <= bi && ((cpl0 >> (4 * bi + cb)) & 1u);
+      if (!__any(mine)) continue;
+      int koff; double sgn = 1;
+      if (cb < SK_NB) {
+        if (bi < SK_NB) { koff = cb == bi ? SKW_AGGK + bi * SKW_KST : SKW_SLOTK + (3 + bi + cb - 1) * SKW_KST; sgn = cb == bi ? 1.0 : -1.0; }
+        else if (!slide) { koff = SKW_AGGK + (3 + cb) * SKW_KST; sgn = -1.0; }
+        else { koff = SKW_SLOTK + (9 + 2 * cb + fs) * SKW_KST; sgn = -1.0; }
+      } else koff = slide ? SKW_AGGK + (6 + fs) * SKW_KST : SKW_AGGK + 10 * SKW_KST;
+      if (!mine) { koff = SKW_AGGK; sgn = 0; }
+      const sk_lds_double* const Kp = Wb + koff;
+      double Kv[21], u[6];
+#pragma unroll
+      for (int q = 0; q < 21; q++) Kv[q] = Kp[q];
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+        double s = 0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) s += Kv[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * si[b];
+        u[a] = sgn * s;
+      }
+      constexpr int dummy = 0; (void)dummy;
+      const int j0 = cb < SK_NB ? 6 * cb : SK_ARM0, nj = cb < SK_NB ? 6 : NDOF;
+#pragma unroll
+      for (int jj = 0; jj < NDOF; jj++) {
+        if (jj >= nj) continue;
+        const int j = j0 + jj;
+        const sk_lds_double* const sj = Wb + SKW_SCOL + 6 * j;
+        const double h = u[0] * sj[0] + u[1] * sj[1] + u[2] * sj[2] + u[3] * sj[3] + u[4] * sj[4] + u[5] * sj[5];
+        if (mine && j <= i) Hr[j] += h;
+      }
+    }
+    // finger slides: dof 25 does not move finger 1 and vice versa, the finger <-> finger pair couples the two slides only
+    if (slide && fs == 1) Hr[SK_ARM0 + NARM] = 0;
+    if (has_ff) {
+      const sk_lds_double* const Kp = Wb + SKW_SLOTK + 15 * SKW_KST;
+      double uF[3];      // lower-right 3 x 3 block of FF times the slide axis
+#pragma unroll
+      for (int a = 0; a < 3; a++) uF[a] = Kp[sk_tri6(3 + a, 3)] * si[3] + Kp[sk_tri6(3 + a, 4)] * si[4] + Kp[sk_tri6(3 + a, 5)] * si[5];
+      const sk_lds_double* const s25 = Wb + SKW_SCOL + 6 * (SK_ARM0 + NARM);
+      const double hd = uF[0] * si[3] + uF[1] * si[4] + uF[2] * si[5], hx = uF[0] * s25[3] + uF[1] * s25[4] + uF[2] * s25[5];
+      if (slide && !fin) {
+        if (fs == 0) Hr[SK_ARM0 + NARM] += hd; else { Hr[SK_ARM0 + NARM + 1] += hd; Hr[SK_ARM0 + NARM] = -hx; }
+      }
+    }
+    return sk_half_max(fabs(gi), upper);
+  };
   for (int it = 0; it < 60 && __any(!fin); it++) {
     const double gm = grad_pass();
     SD_TOC(8);
@@ -1109,9 +1220,6 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     // ---- Cholesky: lane i of a half holds row i
     double Lr[SK_NV], dinv = 1;
     {
-      double Hr[SK_NV];
-#pragma unroll
-      for (int k = 0; k < SK_NV; k++) { const bool in = row && k <= i; const double v = Hs[(in ? tri(i, k) : 0)]; Hr[k] = in ? v : 0.0; }
 #pragma unroll
       for (int j = 0; j < SK_NV; j++) {
         double sum = Hr[j], s2 = 0;      // two accumulators: the dependent FMA chain is half as long
@@ -1164,21 +1272,12 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     __syncthreads();
     SD_TOC(10);
     // ---- line search: phi'(alpha) = p' M (x - a0) + alpha p' M p - sum f(jar + alpha Jp) . Jp, safeguarded Newton on alpha
+    twists(Ps);
     const double Mp = fin ? 0.0 : m_times(Ps, nullptr);
     const double gTp = sk_half_sum(gi * pi, upper), pMp = sk_half_sum(pi * Mp, upper), pMa = sk_half_sum(pi * mxa, upper);
+    __syncthreads();
     double jp[4] = {0, 0, 0, 0};
-    if (con && !fin) {
-      double pk[SKC_NJ];
-#pragma unroll
-      for (int k = 0; k < SKC_NJ; k++) pk[k] = jcol_ok(k) ? Ps[col(k)] : 0.0;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        double sum = 0;
-#pragma unroll
-        for (int k = 0; k < SKC_NJ; k++) sum += (jcol_ok(k) ? SKJ(r, k) : 0.0) * pk[k];
-        jp[r] = sum;
-      }
-    }
+    if (con && !fin) wdot(jp);
     const double ljp = lsg * pi, ljar = lsg * xi - lar;
     SD_TOC(11);
     double alpha = 1, lo = 0, hi = -1, best = 1, wprev = 1e300;
@@ -1190,7 +1289,7 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
         double jt[4], f[4], Hc[16];
 #pragma unroll
         for (int r = 0; r < 4; r++) jt[r] = jar[r] + alpha * jp[r];
-        sk_cone_pre(cc.dim, jt, cc.D, cc.mu, cc.imu, cc.fr, f, Hc);
+        sk_cone_pre(cdim, jt, cD, cmu, cimu, cfr, f, Hc);
 #pragma unroll
         for (int r = 0; r < 4; r++) { d1c -= f[r] * jp[r];
 #pragma unroll
@@ -1225,7 +1324,6 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
   const unsigned long long bad = __ballot(active && !okh);
   return (unsigned)((bad & 0xFFFFFFFFull) != 0 ? 1u : 0u) | (unsigned)((bad >> 32) != 0 ? 2u : 0u);
 }
-#undef SKJ
 #endif
 
 // ------------------------------------------------------------------------------------------------ sub-step
