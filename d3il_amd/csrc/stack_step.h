@@ -1067,22 +1067,28 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     }
   }
   const bool has_ff = __any(con && slot == 15);
-  double jar[4] = {0, 0, 0, 0}, gi = 0, mxa = 0, xi = row ? t[ST_X + i] : 0.0;
+  double jar[4] = {0, 0, 0, 0}, gi = 0, xi = row ? t[ST_X + i] : 0.0;
   double Hr[SK_NV];
+  // row residuals J x - aref and M (x - a0) at the start point; every Newton step then moves them along the step (J p and M p are at hand from the
+  // line search), so a pass neither forms the twists of x nor reads x again.  The pair slots start at zero; a pass clears them behind its last reader.
+  __syncthreads();
+  if (!fin) {
+#pragma unroll
+    for (int q = 0; q < (16 * SKW_KST + 16 * 6 + 31) / 32; q++) { const int w = hl + 32 * q; if (w < 16 * SKW_KST + 16 * 6) Wb[SKW_SLOTK + w] = 0; }
+  }
+  twists(t + ST_X);
+  double mxa = m_times(t + ST_X, t + ST_A0);
+  __syncthreads();
+  if (con) {
+    wdot(jar);
+#pragma unroll
+    for (int r = 0; r < 4; r++) jar[r] -= aref[r];
+  }
+  SD_TOC(0);
   // gradient and Hessian at x: g -> gi, H row -> Hr (registers of the dof lane); returns max |g| of the half
   auto grad_pass = [&]() -> double {
-    if (!fin) {
-#pragma unroll
-      for (int q = 0; q < (16 * SKW_KST + 16 * 6 + 31) / 32; q++) { const int w = hl + 32 * q; if (w < 16 * SKW_KST + 16 * 6) Wb[SKW_SLOTK + w] = 0; }
-    }
-    twists(t + ST_X);
-    mxa = m_times(t + ST_X, t + ST_A0);
-    __syncthreads();
     if (con && !fin) {
       double f[4], Hc[16];
-      wdot(jar);
-#pragma unroll
-      for (int r = 0; r < 4; r++) jar[r] -= aref[r];
       sk_cone_pre(cdim, jar, cD, cmu, cimu, cfr, f, Hc);
       bool any = false;
 #pragma unroll
@@ -1118,6 +1124,7 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
       }
     }
     __syncthreads();
+    SD_TOC(1);
     // aggregation: lane e < 21 sums entry e of the pair matrices into the tables the dof lanes read; lanes 21 .. 26: the net wrenches
     if (!fin && active) {
       if (hl < 21) {
@@ -1145,6 +1152,7 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
       }
     }
     __syncthreads();
+    SD_TOC(2);
     // dof lanes: gradient entry and Hessian row
     double gl = mxa;
     bool limact = false;
@@ -1152,7 +1160,8 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     {
       const int cls = armrow ? (slide ? 4 + fs : 3) : bi;
       const sk_lds_double* const N = Wb + SKW_AGGN + 6 * cls;
-      gl -= si[0] * N[0] + si[1] * N[1] + si[2] * N[2] + si[3] * N[3] + si[4] * N[4] + si[5] * N[5];
+      const double n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3], n4 = N[4], n5 = N[5];
+      gl -= (si[0] * n0 + si[1] * n1 + si[2] * n2) + (si[3] * n3 + si[4] * n4 + si[5] * n5);
     }
     gi = (row && !fin) ? gl : 0.0;
 #pragma unroll
@@ -1178,22 +1187,32 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
       double Kv[21], u[6];
 #pragma unroll
       for (int q = 0; q < 21; q++) Kv[q] = Kp[q];
+      const double sa[6] = {sgn * si[0], sgn * si[1], sgn * si[2], sgn * si[3], sgn * si[4], sgn * si[5]};
 #pragma unroll
       for (int a = 0; a < 6; a++) {
-        double s = 0;
+        double s0 = 0, s1 = 0;      // two chains
 #pragma unroll
-        for (int b = 0; b < 6; b++) s += Kv[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * si[b];
-        u[a] = sgn * s;
+        for (int b = 0; b < 3; b++) s0 += Kv[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * sa[b];
+#pragma unroll
+        for (int b = 3; b < 6; b++) s1 += Kv[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * sa[b];
+        u[a] = s0 + s1;
       }
-      constexpr int dummy = 0; (void)dummy;
       const int j0 = cb < SK_NB ? 6 * cb : SK_ARM0, nj = cb < SK_NB ? 6 : NDOF;
 #pragma unroll
-      for (int jj = 0; jj < NDOF; jj++) {
-        if (jj >= nj) continue;
-        const int j = j0 + jj;
-        const sk_lds_double* const sj = Wb + SKW_SCOL + 6 * j;
-        const double h = u[0] * sj[0] + u[1] * sj[1] + u[2] * sj[2] + u[3] * sj[3] + u[4] * sj[4] + u[5] * sj[5];
-        if (mine && j <= i) Hr[j] += h;
+      for (int jg = 0; jg < NDOF; jg += 3) {      // three columns at a time: their 18 words are read first, then used
+        if (jg >= nj) continue;
+        double sj[3][6];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#pragma unroll
+          for (int a = 0; a < 6; a++) sj[c][a] = Wb[SKW_SCOL + 6 * (j0 + jg + c) + a];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const int j = j0 + jg + c;
+          const double h = (u[0] * sj[c][0] + u[1] * sj[c][1] + u[2] * sj[c][2]) + (u[3] * sj[c][3] + u[4] * sj[c][4] + u[5] * sj[c][5]);
+          if (mine && j <= i) Hr[j] += h;
+        }
       }
     }
     // finger slides: dof 25 does not move finger 1 and vice versa, the finger <-> finger pair couples the two slides only
@@ -1209,6 +1228,11 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
         if (fs == 0) Hr[SK_ARM0 + NARM] += hd; else { Hr[SK_ARM0 + NARM + 1] += hd; Hr[SK_ARM0 + NARM] = -hx; }
       }
     }
+    if (!fin) {      // the pair slots are clear again for the next pass (the dof lanes above were their last readers; the next additions come after a barrier)
+#pragma unroll
+      for (int q = 0; q < (16 * SKW_KST + 16 * 6 + 31) / 32; q++) { const int w = hl + 32 * q; if (w < 16 * SKW_KST + 16 * 6) Wb[SKW_SLOTK + w] = 0; }
+    }
+    SD_TOC(4);
     return sk_half_max(fabs(gi), upper);
   };
   for (int it = 0; it < 60 && __any(!fin); it++) {
@@ -1218,7 +1242,9 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     if (!fin && gm <= g_solver_tol.grad_tol) fin = true;      // converged
     if (!__any(!fin)) break;
     // ---- Cholesky: lane i of a half holds row i
+    // the forward substitution L y = -g rides along: the numerator of y_j is complete in lane j when column j is factorised and is broadcast together with the pivot
     double Lr[SK_NV], dinv = 1;
+    double y = (row && !fin) ? -gi : 0.0;
     {
 #pragma unroll
       for (int j = 0; j < SK_NV; j++) {
@@ -1238,21 +1264,18 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
         }
         sum += s2;
         double sj = sk_hbcast(sum, j, upper);
+        const double yn = sk_hbcast(y, j, upper);
         if (!(sj > 0)) { if (!fin) okh = false; sj = 1; }
         const double di = rsqrtd(sj), d = sj * di;      // v_rsq_f64 + two Newton steps instead of a square root and a division
         Lr[j] = i == j ? d : (i > j ? sum * di : 0.0);
         if (i == j) dinv = di;
+        const double yj = yn * di;
+        y = i == j ? yj : (i > j ? y - Lr[j] * yj : y);
       }
     }
     if (!okh) fin = true;      // non-positive pivot: this half gives up
     SD_TOC(9);
-    // ---- p = -H^-1 g: forward substitution with the rows, backward with the columns (factor handed over through Hs)
-    double y = (row && !fin) ? -gi : 0.0;
-#pragma unroll
-    for (int j = 0; j < SK_NV; j++) {
-      const double yj = sk_hbcast(y * dinv, j, upper);
-      y = i == j ? yj : (i > j ? y - Lr[j] * yj : y);
-    }
+    // ---- p = -H^-1 g: backward substitution with the columns of the factor (handed over through Hs)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SK_NV; k++) if (row && !fin && k <= i) Hs[tri(i, k)] = Lr[k];
@@ -1314,6 +1337,11 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     SD_TOC(12);
     const double dx = fin ? 0.0 : best * pi;
     xi += dx;
+    if (!fin) {
+      mxa += best * Mp;
+#pragma unroll
+      for (int r = 0; r < 4; r++) jar[r] += best * jp[r];
+    }
     if (row && !fin) t[ST_X + i] = xi;
     const double smax = sk_half_max(fabs(dx), upper), xmax = sk_half_max(fabs(xi), upper);
     if (!fin && (smax <= 1e-12 * (1 + xmax) || (best == 1.0 && smax <= g_solver_tol.step_rel * (1 + xmax)))) fin = true;      // converged
