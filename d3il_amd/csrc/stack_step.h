@@ -883,6 +883,16 @@ __device__ __forceinline__ double sk_hbcast(double v, int j /* wave-uniform, 0 .
   return __shfl(v, (upper ? 32 : 0) | j);
 #endif
 }
+// the same value through v_readlane (two reads per word + a select): few cycles of latency instead of an LDS round trip - for the broadcasts the
+// next instruction of a dependent chain waits for (pivot of a factorisation column, the entry a substitution step hands on)
+__device__ __forceinline__ double sk_hbcast_chain(double v, int j /* compile-time, 0 .. 31 */, bool upper) {
+  const double a = sk_bcast(v, j), b = sk_bcast(v, 32 + j);
+  return upper ? b : a;
+}
+__device__ __forceinline__ double sk_rsqrt1(double x) {      // 1 / sqrt(x) with ONE Newton step: for the factor's pivots, whose rounding only shapes the search direction
+  double y = __builtin_amdgcn_rsq(x);
+  return y * (1.5 - 0.5 * x * y * y);
+}
 __device__ __forceinline__ double sk_half_sum(double v, bool upper) {
   SK_CONVERGE();
   v += sk_dpp_mov(v, 0); v += sk_dpp_mov(v, 1); v += sk_dpp_mov(v, 2); v += sk_dpp_mov(v, 3);      // every lane: the sum of its row of 16
@@ -1263,10 +1273,14 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
           for (int k = k0; k < k1; k++) if (k < j) { if (k & 1) s2 -= Lr[k] * bc[k - k0]; else sum -= Lr[k] * bc[k - k0]; }
         }
         sum += s2;
-        double sj = sk_hbcast(sum, j, upper);
+        double sj = sk_hbcast_chain(sum, j, upper);
         const double yn = sk_hbcast(y, j, upper);
         if (!(sj > 0)) { if (!fin) okh = false; sj = 1; }
+#if defined(D3IL_SK_PIVOT_2NEWTON)
         const double di = rsqrtd(sj), d = sj * di;      // v_rsq_f64 + two Newton steps instead of a square root and a division
+#else
+        const double di = sk_rsqrt1(sj), d = sj * di;
+#endif
         Lr[j] = i == j ? d : (i > j ? sum * di : 0.0);
         if (i == j) dinv = di;
         const double yj = yn * di;
@@ -1827,9 +1841,12 @@ __device__ __forceinline__ SkJob sk_job(const StackConsts& kc_, sk_lds_double* s
     if (j.kind != 0) j.margin = kc.set[j.set].margin;
     return j;
   }
-  if (grp < 3) {
-    if (round < kc.ns) {
-      const int sidx = round, b = grp;
+  if (grp < 3 || (grp >= 13 && round == 0)) {
+    // box <-> static slabs: slab 0 in round 0 on the groups 0 .. 2, slab 1 in the SAME round on the groups 13 .. 15 (idle there: their hand job belongs to
+    // round 1), further slabs one per later round - a box on the table top lies inside the bounds of both slabs of the table, and every round with a
+    // box-box job costs the whole wave one pass through box_box_emit
+    const int b = grp < 3 ? grp : grp - 13, sidx = grp < 3 ? (round == 0 ? 0 : round + 1) : 1;
+    if (sidx < kc.ns) {
       box_shape(b, RB, pB, hB);
       double d[3] = {pB[0] - kc.st_c[sidx][0], pB[1] - kc.st_c[sidx][1], pB[2] - kc.st_c[sidx][2]}, ex = 0;
       for (int i = 0; i < 3; i++) { double loc = kc.st_R[sidx][i] * d[0] + kc.st_R[sidx][3 + i] * d[1] + kc.st_R[sidx][6 + i] * d[2]; double o = fabs(loc) - kc.st_h[sidx][i]; if (o > 0) ex += o * o; }
@@ -2031,7 +2048,14 @@ __device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_d
 #else
 #define SKP_TOC(slot) ((void)0)
 #endif
-  const int n_rounds = kc.variant != SKV_STACKING ? kc.ns : (kc.ns > 4 ? kc.ns : 4);
+  // rounds: 0 = slabs 0 and 1, box pairs, box <-> tip, tip <-> tip; 1 = slab 2, box <-> hull / hand, hull <-> hull; 2, 3 = further slabs and the remaining
+  // finger <-> finger pairs - those two rounds are run only when a slab or a (nearly) closed gripper of the workgroup needs them (wave-uniform)
+  int n_rounds = kc.ns;
+  if (kc.variant == SKV_STACKING) {
+    const bool closed = __any(act && t[ST_AUX] < 0.004);
+    n_rounds = closed ? 4 : 2;
+    if (kc.ns - 1 > n_rounds) n_rounds = kc.ns - 1;
+  }
   for (int round = 0; round < n_rounds; round++) {
     int r = sk_round_boxbox(kc, smem, lane, round, live_mask);
     SKP_TOC(14);
