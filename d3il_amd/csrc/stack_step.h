@@ -1079,6 +1079,7 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
   const bool has_ff = __any(con && slot == 15);
   double jar[4] = {0, 0, 0, 0}, gi = 0, xi = row ? t[ST_X + i] : 0.0;
   double Hr[SK_NV];
+  bool limact = false;      // this lane's joint-limit row is active at x
   // row residuals J x - aref and M (x - a0) at the start point; every Newton step then moves them along the step (J p and M p are at hand from the
   // line search), so a pass neither forms the twists of x nor reads x again.  The pair slots start at zero; a pass clears them behind its last reader.
   __syncthreads();
@@ -1165,7 +1166,7 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     SD_TOC(2);
     // dof lanes: gradient entry and Hessian row
     double gl = mxa;
-    bool limact = false;
+    limact = false;
     if (lsg != 0) { const double lj = lsg * xi - lar; if (lj < 0) { gl += lsg * lD * lj; limact = true; } }
     {
       const int cls = armrow ? (slide ? 4 + fs : 3) : bi;
@@ -1174,6 +1175,11 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
       gl -= (si[0] * n0 + si[1] * n1 + si[2] * n2) + (si[3] * n3 + si[4] * n4 + si[5] * n5);
     }
     gi = (row && !fin) ? gl : 0.0;
+    SD_TOC(4);
+    return sk_half_max(fabs(gi), upper);
+  };
+  // the Hessian rows (only for a half that goes on: the pass that finds the gradient below the tolerance builds none)
+  auto assemble = [&]() {
 #pragma unroll
     for (int k = 0; k < SK_NV; k++) {
       double m = 0;
@@ -1242,8 +1248,6 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
 #pragma unroll
       for (int q = 0; q < (16 * SKW_KST + 16 * 6 + 31) / 32; q++) { const int w = hl + 32 * q; if (w < 16 * SKW_KST + 16 * 6) Wb[SKW_SLOTK + w] = 0; }
     }
-    SD_TOC(4);
-    return sk_half_max(fabs(gi), upper);
   };
   for (int it = 0; it < 60 && __any(!fin); it++) {
     const double gm = grad_pass();
@@ -1251,6 +1255,8 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
     if (lane == 0 && blockIdx.x == 0) { D3IL_SD_COUNT(7); }
     if (!fin && gm <= g_solver_tol.grad_tol) fin = true;      // converged
     if (!__any(!fin)) break;
+    assemble();
+    SD_TOC(5);
     // ---- Cholesky: lane i of a half holds row i
     // the forward substitution L y = -g rides along: the numerator of y_j is complete in lane j when column j is factorised and is broadcast together with the pivot
     double Lr[SK_NV], dinv = 1;
