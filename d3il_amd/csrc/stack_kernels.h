@@ -76,9 +76,11 @@ __device__ __forceinline__ void sk_state_from_lds(const sk_lds_double* t, StackS
 }
 // phase 1 (lane = environment): control law + arm forward pass, kinematic tables, smooth accelerations
 template <int V>
-__device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g, unsigned& flags, bool open) {
+__device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g, unsigned& flags, bool open, const sk_lds_double* trig_lds) {
   StackState ss;
   sk_state_from_lds(t, ss);
+  double trig[2 * NARM];
+  for (int k = 0; k < 2 * NARM; k++) trig[k] = trig_lds[k];
   ss.arm.flags = flags;
   double tau[NARM], ff[NFING];
   const StackScratch sc{t, g};
@@ -93,12 +95,12 @@ __device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g,
       for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ikq[k]; t[ST_TIPR + SV_IKQD + k] = ikqd[k]; t[ST_TIPR + SV_VWARM + k] = vwarm[k]; }
     }
     push_control(kAvoidingConsts, ss.arm, ikq, ikqd, hold ? 0.001 : 0.04, false, tau, ff);
-    stack_pre_kin<V>(kAvoidingConsts, g_stack_consts, ss, sc, tau, ff);
+    stack_pre_kin<V>(kAvoidingConsts, g_stack_consts, ss, sc, tau, ff, trig);
   } else {
     double act[NARM];
     for (int k = 0; k < NARM; k++) act[k] = t[SE_ACT + k];
     stack_control(kStackingConsts, ss.arm, act, open ? 0.04 : 0.0, !open, tau, ff);
-    stack_pre_kin<SKV_STACKING>(kStackingConsts, g_stack_consts, ss, sc, tau, ff);
+    stack_pre_kin<SKV_STACKING>(kStackingConsts, g_stack_consts, ss, sc, tau, ff, trig);
   }
   for (int k = 0; k < NARM; k++) t[SE_BIAS + k] = ss.arm.bias[k];
   for (int k = 0; k < 3; k++) t[SE_TCP + k] = ss.arm.tcp[k];
@@ -129,13 +131,20 @@ __device__ __forceinline__ void sk_phase_mid(sk_lds_double* t, sk_glb_double* g,
 }
 // phase 5 (lane = environment): mj_Euler
 template <int V>
-__device__ __forceinline__ void sk_phase_post(sk_lds_double* t, sk_glb_double* g, unsigned& flags) {
+__device__ __forceinline__ void sk_phase_post(sk_lds_double* t, sk_glb_double* g, unsigned& flags, sk_lds_double* trig_lds) {
   StackState ss;
   sk_state_from_lds(t, ss);
   ss.arm.flags = flags;
   const StackScratch sc{t, g};
+  double q_old[NARM];
+  for (int k = 0; k < NARM; k++) q_old[k] = ss.arm.q[k];
   if constexpr (V != SKV_STACKING) stack_substep_post<true>(kAvoidingConsts, g_stack_consts, ss, sc);
   else stack_substep_post<true>(kStackingConsts, g_stack_consts, ss, sc);
+  for (int k = 0; k < NARM; k++) {      // |dq| = h |v| <= 1e-3 x a few rad/s: the increment that was actually applied
+    double sn = trig_lds[k], cs = trig_lds[NARM + k];
+    trig_advance(ss.arm.q[k] - q_old[k], sn, cs);
+    trig_lds[k] = sn; trig_lds[NARM + k] = cs;
+  }
   for (int k = 0; k < NDOF; k++) { t[SE_Q + k] = ss.arm.q[k]; t[ST_VEL + SK_ARM0 + k] = ss.arm.v[k]; }
   for (int b = 0; b < SK_NB; b++) {
     for (int k = 0; k < 3; k++) t[ST_BP + 3 * b + k] = ss.box[b].pos[k];
@@ -314,12 +323,16 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
     fl = ss.arm.flags; step = ss.arm.step;
   }
   const unsigned live_mask = (unsigned)(__ballot(live) & ((1ull << SK_LANES) - 1ull));
+  sk_lds_double* const trig_lds = sm + 2 * ST_HEAD + SKW_TRIG + 2 * NARM * (live ? lane : 0);
+  if (live) {      // sin / cos of the arm joints at the start of the step (then advanced with the joints)
+    for (int k = 0; k < NARM; k++) { double sn, cs; sincos((double)t[SE_Q + k], &sn, &cs); trig_lds[k] = sn; trig_lds[NARM + k] = cs; }
+  }
   __syncthreads();
 #pragma clang loop unroll(disable)
   for (int s = 0; s < n_substeps; s++) {
 #if defined(D3IL_SK_POISON)
     if (V == SKV_STACKING) {
-      for (int q = lane; q < SKC_SHARED; q += WAVE) poison(q);
+      for (int q = lane; q < 2 * ST_HEAD + SKW_TRIG; q += WAVE) poison(q);
       if (live) {
         const int base = SKC_SHARED + lane * SE_SIZE - ST_HEAD;
         for (int q = ST_A0; q < ST_A0 + SK_NV; q++) poison(base + q);
@@ -330,7 +343,7 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
       __syncthreads();
     }
 #endif
-    if (live) sk_phase_pre<V>(t, g, fl, open);
+    if (live) sk_phase_pre<V>(t, g, fl, open, trig_lds);
     __syncthreads();
 #if defined(D3IL_DEVICE_STATS)
     sk_collide_coop(g_stack_consts, sm, lane, live_mask, scratch + (size_t)blockIdx.x * SK_LANES * SG_SIZE);
@@ -350,7 +363,7 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
       if (((failed & 1u) && lane == e0) || ((failed & 2u) && lane == e0 + 1)) fl |= F_SOLVER_FAIL;
     }
     __syncthreads();
-    if (live) sk_phase_post<V>(t, g, fl);
+    if (live) sk_phase_post<V>(t, g, fl, trig_lds);
     __syncthreads();
   }
   if (!live) return;

@@ -862,7 +862,11 @@ constexpr int SKW_SLOTF = SKW_SLOTK + 16 * SKW_KST;   // F of the body pairs, or
 constexpr int SKW_AGGK = SKW_SLOTF + 16 * 6;          // Kd_b (all pairs of box b) [3] | K_b,arm [3] | Kd'_f (box pairs of finger f) [2] | Kd_f = Kd'_f + FF [2] | K_rev
 constexpr int SKW_AGGN = SKW_AGGK + 11 * SKW_KST;     // net wrench per dof class: box 0 | 1 | 2 | joints 0 .. 6 | slide 0 | slide 1
 constexpr int SKW_END = SKW_AGGN + 36;
-static_assert(SKW_END <= SKW_HALF, "the wrench tables of two environments must fit the shared area");
+// the upper half's tables follow the lower half's directly; behind them (and behind everything the collision phase stages) the sin / cos of the arm joints of
+// the workgroup's environments, carried from sub-step to sub-step (trig_advance) instead of seven sincos evaluations per environment and sub-step
+constexpr int SKW_TRIG = 2 * SKW_END;                  // offset in the W area: SK_LANES x 14 doubles
+static_assert(SKW_TRIG + 2 * NARM * SK_LANES <= SKC_JSIZE, "the wrench tables of two environments and the trig table must fit the shared area");
+static_assert(2 * ST_HEAD + SKW_TRIG >= SKC_STAGE * 16 * SK_LANES, "the trig table must lie behind the collision phase's staging area");
 __device__ constexpr double SKW_REF[3] = {0.5, 0.0, 0.0};
 __device__ __forceinline__ int sk_tri6(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 __device__ __forceinline__ int sk_genbody(int body) { return body < SK_NB ? body : (sk_finger_of(body) < 0 ? 3 : 4 + sk_finger_of(body)); }
@@ -920,7 +924,7 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
   sk_lds_double* const t = sk_env_view(smem, e0 + (upper ? 1 : 0));
   sk_lds_double* const Hs = smem + (upper ? ST_HEAD : 0);
   sk_lds_double* const Ps = Hs + ST_P;
-  sk_lds_double* const Wb = smem + 2 * ST_HEAD + (upper ? SKW_HALF : 0);
+  sk_lds_double* const Wb = smem + 2 * ST_HEAD + (upper ? SKW_END : 0);
   const bool active = upper ? act1 : act0;
   const int ncon = active ? (int)t[SE_NCON] : 0;
   const bool con = hl < ncon;
@@ -1392,7 +1396,7 @@ D3IL_HD void sk_add_contact(const StackConsts& kc_, const StackScratch sc, int& 
 // sk_solve_coop by the whole wave), stack_substep_post (mj_Euler).  WARM_LDS: the warm start is the x vector left in the t area by
 // the previous sub-step (device step kernel) instead of ss.warm.
 template <int V = SKV_STACKING, class C>
-D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing) {
+D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, const StackScratch sc, const double* tau, const double* ffing, const double* trig = nullptr) {
   D3IL_STACK_CONSTS(kc_, kc);
   D3IL_REFRESH(c0, c);
   EnvState& st = ss.arm;
@@ -1400,7 +1404,7 @@ D3IL_HD void stack_pre_kin(const C& c0, const StackConsts& kc_, StackState& ss, 
   SK_TIC;
   // ---- arm forward pass
   DynOut dyn;
-  dynamics(c0, st.q, st.v, dyn);
+  dynamics(c0, st.q, st.v, dyn, trig);
   double fs[NDOF];
   for (int k = 0; k < NARM; k++) fs[k] = clampd(tau[k] + st.bias[k], c.force_lo[k], c.force_hi[k]) - dyn.bias[k];
   for (int k = 0; k < NFING; k++) fs[NARM + k] = clampd(ffing[k], c.force_lo[NARM + k], c.force_hi[NARM + k]) - dyn.bias[NARM + k] - c.f_damping[k] * st.v[NARM + k];
