@@ -1966,8 +1966,14 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
     mine_kind = j.kind; mine_meta = j.ba | (j.bb << 4) | (j.set << 8);
   }
   int m = 0;
+#if defined(D3IL_DEVICE_STATS)
+  unsigned long long mp_t0 = wall_clock64();
+#endif
   for (unsigned long long pend = __ballot(mine_kind == 2); pend != 0;) {
     const int grp8 = lane >> 3, sub = lane & 7;
+#if defined(D3IL_DEVICE_STATS)
+    if (lane == 0 && blockIdx.x == 0) atomicAdd(&g_dev_stats[8], 1ull);
+#endif
     int owner = -1;      // owner lane of this group's job (-1: no job in this batch)
     unsigned long long batch = 0, rest = pend;
     for (int k = 0; k < WAVE / SKG && rest != 0; k++) { const int L = __builtin_ctzll(rest); rest &= rest - 1; batch |= 1ull << L; if (k == grp8) owner = L; }
@@ -2019,8 +2025,14 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
     }
   }
   // box <-> hand jobs (rare: only inside the hull's bounding box): one at a time by the whole wave, the 773 hull vertices spread over the lanes
+#if defined(D3IL_DEVICE_STATS)
+  if (lane == 0 && blockIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_dev_stats[11], t_ - mp_t0); mp_t0 = t_; }
+#endif
   for (unsigned long long pendh = __ballot(mine_kind == 3); pendh != 0; pendh &= pendh - 1) {
     const int owner = __builtin_ctzll(pendh);
+#if defined(D3IL_DEVICE_STATS)
+    if (lane == 0 && blockIdx.x == 0) atomicAdd(&g_dev_stats[9], 1ull);
+#endif
     const int oe = owner % SK_LANES, bx = owner / SK_LANES - 13;
     const sk_lds_double* to = sk_env_view(smem, oe);
     SkShapeL A;
@@ -2033,6 +2045,9 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
       const double nd[3] = {-dir[0], -dir[1], -dir[2]};
       sk_support1_group_l(kc, A, dir, um, pt.v1, lane & 7);      // a box: no vertex table, every lane evaluates it
       sk_support_hand_wave(kc, B.R, B.p, nd, um, pt.v2, lane);
+#if defined(D3IL_DEVICE_STATS)
+      if (lane == 0 && blockIdx.x == 0) atomicAdd(&g_dev_stats[10], 1ull);
+#endif
 #pragma unroll
       for (int k = 0; k < 3; k++) pt.v[k] = pt.v1[k] - pt.v2[k];
     });
@@ -2043,6 +2058,9 @@ __device__ __forceinline__ int sk_round_mpr(const StackConsts& kc_, sk_lds_doubl
       m = 1;
     }
   }
+#if defined(D3IL_DEVICE_STATS)
+  if (lane == 0 && blockIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_dev_stats[12], t_ - mp_t0); }
+#endif
   return m | (mine_meta << 8);
 }
 __device__ __forceinline__ void sk_collide_coop(const StackConsts& kc_, sk_lds_double* smem, const int lane, const unsigned live_mask, double* dbg = nullptr) {

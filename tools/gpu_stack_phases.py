@@ -29,7 +29,7 @@ def snap():
     capi.check(env.L.d3il_debug_scratch(env.h, 0, buf.ctypes.data_as(C.c_void_p), len(buf)))
     st = (C.c_uint64 * 32)()
     capi.check(env.L.d3il_debug_stats(st, 0))
-    return buf[32 * 36 + 4:32 * 36 + 17].copy(), np.array([st[16 + k] for k in (13, 14, 15, 3, 8, 9, 10, 11, 12, 6, 7, 0, 1, 2, 4, 5)], dtype=float)
+    return buf[32 * 36 + 4:32 * 36 + 17].copy(), np.array([st[16 + k] for k in (13, 14, 15, 3, 8, 9, 10, 11, 12, 6, 7, 0, 1, 2, 4, 5)] + [st[k] for k in (8, 9, 10, 11, 12)], dtype=float)
 
 
 t = 0
@@ -55,4 +55,5 @@ for lo, hi, label in windows:
     print("    dual solves per sub-step and workgroup %.2f (Newton iterations %.2f): build rows %.0f, g+H pass %.0f, cholesky %.0f, tri solves %.0f, Jp %.0f, line search %.0f ticks per sub-step and workgroup" % (
         dc[9], dc[10], dc[3], dc[4], dc[5], dc[6], dc[7], dc[8]))
     print("    start point (twists of x, J x - aref) %.0f; per pass: contact lanes (cone, K, F, LDS adds) %.0f, aggregation %.0f, gradient %.0f; Hessian rows (passes that go on) %.0f; max |g| is 'g+H pass'" % (dc[11], dc[12], dc[13], dc[14], dc[15]))
+    print("    MPR phase of workgroup 0 per sub-step: finger-hull batches %.2f (%.0f ticks incl. the job set-up), hand jobs %.2f with %.1f hand support calls (%.0f ticks)" % (dc[16], dc[19], dc[17], dc[18], dc[20]))
     print("    kernel time per sub-step: %.0f ticks" % (np.mean(ms) * 1e-3 / 30 * 1e8))
