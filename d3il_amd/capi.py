@@ -37,7 +37,7 @@ SORT_STATE_BOX, SORT_STATE_WARM, SORT_STATE_TASK, SORT_STATE_F64 = 42, 94, 127, 
 INS_STATE_BOX, INS_STATE_WARM, INS_STATE_TASK, INS_STATE_F64 = 42, 81, 108, 110
 
 EXPORTS = ["d3il_create", "d3il_destroy", "d3il_start", "d3il_reset", "d3il_step", "d3il_get_buffers", "d3il_get_state",
-           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_attention_causal_f32", "d3il_layernorm_f32", "d3il_mlp_gelu_residual_f32", "d3il_mlp_ln_gelu_residual_f32", "d3il_linear120_f32", "d3il_mlp_ln_gelu_residual_f16x3", "d3il_linear120_f16x3", "d3il_ddpm_mlp_f32", "d3il_resmlp_f32", "d3il_auto_reset", "d3il_set_tally", "d3il_count_metrics",
+           "d3il_set_state", "d3il_policy_begin", "d3il_policy_action", "d3il_attention_causal_f32", "d3il_layernorm_f32", "d3il_mlp_gelu_residual_f32", "d3il_mlp_ln_gelu_residual_f32", "d3il_linear120_f32", "d3il_mlp_ln_gelu_residual_f16x3", "d3il_linear120_f16x3", "d3il_attn_half_f16x3", "d3il_ddpm_mlp_f32", "d3il_resmlp_f32", "d3il_auto_reset", "d3il_set_tally", "d3il_count_metrics",
            "d3il_rccl_available", "d3il_comm_unique_id", "d3il_comm_init", "d3il_comm_count", "d3il_comm_destroy", "d3il_reduce_metrics", "d3il_set_timing",
            "d3il_last_step_ms", "d3il_timing_stats", "d3il_step_auto_reset", "d3il_random_rollout_step", "d3il_random_rollout_prepare", "d3il_set_option", "d3il_debug_stats", "d3il_debug_wave_stats", "d3il_debug_wave_counts", "d3il_debug_scratch", "d3il_last_error", "d3il_blob_sizeof", "d3il_version"]
 
@@ -80,6 +80,7 @@ def load():
         L.d3il_linear120_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
         L.d3il_mlp_ln_gelu_residual_f16x3.argtypes = L.d3il_mlp_ln_gelu_residual_f32.argtypes
         L.d3il_linear120_f16x3.argtypes = L.d3il_linear120_f32.argtypes
+        L.d3il_attn_half_f16x3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.d3il_ddpm_mlp_f32.argtypes = [C.c_void_p] * 12 + [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.d3il_resmlp_f32.argtypes = [C.c_void_p] * 8 + [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.d3il_mlp_gelu_residual_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]

@@ -291,4 +291,118 @@ __global__ __launch_bounds__(64 * NW) void k_linear120_f16x3(const float* __rest
   }
 }
 
+// The attention half of a DiffusionGPT block as ONE kernel: x1 = x + proj(causal_attention(ln1(x) Wqkv' + bqkv)) + bproj  (score_gpts.py:35-80, 103-107).
+// As three kernels (ln1 + qkv product -> attention -> projection + residual) the half moved 65 MB of q | k | v out to HBM and back plus the attention output
+// (21.6 MB each way) per block and sampling step at 45056 token rows - those kernels ran at 3 - 3.5 TB/s, i.e. memory bound (profiles/r06/beso_profile_final.log).
+// Here ONE WAVE OWNS ONE SEQUENCE (T <= 16 tokens = the 16 rows of a matrix-core tile; T = 11 for the BESO policy: 5 of 16 rows are padding, which costs matrix
+// work the half has to spare): the q | k | v rows of the sequence go from the D registers of the first product into LDS, the attention reads them there with the
+// arithmetic of k_attention_causal_f32 in the same order (online softmax, key 0 peeled; lane (g, j) serves token j and the heads g and g + 4), writes its output over
+// the q part of the row, and the projection takes its B operand from those rows.  HBM sees x once in and x1 once out.
+// wp: 32 packed tiles (16 LDS stages of two): the 24 tiles of pack_linear120_weights_f16x3(cat(Wq, Wk, Wv)) followed by the 8 tiles of the projection.
+// Two instantiations: <8 sequences, 11 rows> for T <= 11 (the BESO policy: 145 KB of LDS = one workgroup of eight waves per CU, two waves per SIMD) and <4, 16> for
+// T <= 16.  The weight stream: two tiles (16 KB) per stage, double buffered.  At 45056 token rows: 59.9 us against 69.5 us for the three kernels it replaces
+// (87.9 us with four waves per workgroup and one lane per (token, head pair); 65.4 us as two workgroups of four waves per CU with a single weight buffer and
+// two barriers per tile - profiles/r06/attn_half/).
+template <int NW, int TR>
+__global__ __launch_bounds__(64 * NW) void k_attn_half_f16x3(const float* __restrict__ x, const hx_h8* __restrict__ wp, const float* __restrict__ bqkv, const float* __restrict__ bproj,
+                                                             float* __restrict__ out, long B, int T, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps) {
+  constexpr int C = HX_C, H = 6, D = 20, QKV_STAGES = 12, STAGES = 16, RS = 3 * HX_C;
+  __shared__ hx_h8 sw[2][1024];
+  __shared__ hx_f4 sbias[96 + 32];      // q | k | v bias (90 vectors, zero padded to 96), then the projection's (30, padded to 32)
+  __shared__ float qs[NW][TR][RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  constexpr int NT = 64 * NW, VPT = 1024 / NT;
+  const long seq = (long)blockIdx.x * NW + wave;
+  const bool live = seq < B && j < T;
+  const long row = (seq < B ? seq : B - 1) * T + (j < T ? j : T - 1);
+  for (int q = tid; q < 128; q += NT) sbias[q] = q < 90 ? ((const hx_f4*)bqkv)[q] : (q >= 96 && q < 126 ? ((const hx_f4*)bproj)[q - 96] : hx_f4{0.f, 0.f, 0.f, 0.f});
+  hx_h8 hh[4], hl[4];
+  hx_load_row(x, row, g, ln_w, ln_b, eps, hh, hl);
+  hx_h8 pre[VPT];
+#pragma unroll
+  for (int q = 0; q < VPT; q++) sw[0][tid + NT * q] = wp[tid + NT * q];
+  __syncthreads();
+  float (*const my)[RS] = qs[wave];
+  for (int st = 0; st < STAGES; st++) {
+    const int cur = st & 1;
+    if (st + 1 < STAGES) {
+#pragma unroll
+      for (int q = 0; q < VPT; q++) pre[q] = wp[(long)(st + 1) * 1024 + tid + NT * q];
+    }
+    if (st == QKV_STAGES) {
+      // ---- causal attention of this wave's sequence on the rows in LDS (every lane of the workgroup has passed the barrier of stage 11: the rows are complete).
+      // Lane (head h, pair p) serves the queries p and T - 1 - p: T + 1 key steps whatever p is (as k_attention_causal_f32)
+      const float scale = 1.0f / sqrtf((float)D);
+      const int TP = (T + 1) / 2, h = lane / TP, p = lane - h * TP;
+      if (h < H) {
+        auto ld = [&](const float* ptr, float* r) {
+#pragma unroll
+          for (int c = 0; c < D / 4; c++) { const hx_f4 t4 = *(const hx_f4*)(ptr + 4 * c); r[4 * c] = t4[0]; r[4 * c + 1] = t4[1]; r[4 * c + 2] = t4[2]; r[4 * c + 3] = t4[3]; }
+        };
+        for (int half = 0; half < 2; half++) {
+          const int i = half == 0 ? p : T - 1 - p;
+          if (half == 1 && i == p) break;      // the middle query of an odd T
+          float q[D], acc[D], kk[D], vv[D];
+          ld(&my[i][h * D], q);
+#pragma unroll
+          for (int d = 0; d < D; d++) q[d] *= scale;
+          ld(&my[0][C + h * D], kk); ld(&my[0][2 * C + h * D], acc);
+          float m = 0.0f, l = 1.0f;
+#pragma unroll
+          for (int d = 0; d < D; d++) m += q[d] * kk[d];
+          for (int jj = 1; jj <= i; jj++) {
+            ld(&my[jj][C + h * D], kk); ld(&my[jj][2 * C + h * D], vv);
+            float sc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; d++) sc += q[d] * kk[d];
+            const float mn = fmaxf(m, sc), corr = __expf(m - mn), pj = __expf(sc - mn);
+            l = l * corr + pj;
+#pragma unroll
+            for (int d = 0; d < D; d++) acc[d] = acc[d] * corr + pj * vv[d];
+            m = mn;
+          }
+          const float inv = 1.0f / l;
+#pragma unroll
+          for (int c = 0; c < D / 4; c++) *(hx_f4*)(&my[i][h * D + 4 * c]) = hx_f4{acc[4 * c] * inv, acc[4 * c + 1] * inv, acc[4 * c + 2] * inv, acc[4 * c + 3] * inv};
+        }
+      }
+      __syncthreads();
+      // ---- the attention output of token j as the B operand of the projection
+      const int jr = j < T ? j : T - 1;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int k0 = 32 * s + 8 * g;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float v = k0 < C ? my[jr][k0 + e] : 0.f;
+          _Float16 a, b; hx_split(v, a, b); hh[s][e] = a; hl[s][e] = b;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      hx_f4 ah = hx_f4{0.f, 0.f, 0.f, 0.f}, ax1 = ah, ax2 = ah;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const hx_h8 wh = sw[cur][512 * u + (s * 2) * 64 + lane], wl = sw[cur][512 * u + (s * 2 + 1) * 64 + lane];
+        ah = HX_MFMA(wh, hh[s], ah);
+        ax1 = HX_MFMA(wh, hl[s], ax1);
+        ax2 = HX_MFMA(wl, hh[s], ax2);
+      }
+      if (st < QKV_STAGES) {
+        const int col = 16 * (2 * st + u) + 4 * g;
+        if (j < T && col < 3 * C) *(hx_f4*)(&my[j][col]) = ah + (ax1 + ax2) * HX_ILO + sbias[col >> 2];
+      } else {
+        const int col = 16 * (2 * (st - QKV_STAGES) + u) + 4 * g;
+        if (live && col < C) *(hx_f4*)(out + row * C + col) = ah + (ax1 + ax2) * HX_ILO + sbias[96 + (col >> 2)] + *(const hx_f4*)(x + row * C + col);
+      }
+    }
+    if (st + 1 < STAGES) {
+#pragma unroll
+      for (int q = 0; q < VPT; q++) sw[cur ^ 1][tid + NT * q] = pre[q];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace d3il

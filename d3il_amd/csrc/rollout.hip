@@ -1546,6 +1546,21 @@ int d3il_linear120_f16x3(const float* xin, const float* ln_weight, const float* 
   HIPCHK(hipGetLastError());
   return D3IL_OK;
 }
+int d3il_attn_half_f16x3(const float* x, const float* ln_weight, const float* ln_bias, float ln_eps, const void* w_packed, const float* b_qkv, const float* b_proj, float* out,
+                         long n_seq, int T, int n_head, int C, void* stream) {
+  if (!x || !ln_weight || !ln_bias || !w_packed || !b_qkv || !b_proj || !out) return fail(D3IL_EINVAL, "d3il_attn_half_f16x3: null argument");
+  if (C != HX_C || n_head != 6) return fail(D3IL_EUNSUPPORTED, "d3il_attn_half_f16x3: built for 120 features in 6 heads (the DiffusionGPT of the BESO configs)");
+  if (n_seq < 0 || T < 1 || T > 16) return fail(D3IL_EINVAL, "d3il_attn_half_f16x3: needs n_seq >= 0 and 1 <= T <= 16 (one sequence per matrix-core tile)");
+  if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_qkv | (uintptr_t)b_proj | (uintptr_t)out | (uintptr_t)ln_weight | (uintptr_t)ln_bias) % 16 != 0) return fail(D3IL_EINVAL, "d3il_attn_half_f16x3: pointers must be 16-byte aligned");
+  if (x == out) return fail(D3IL_EINVAL, "d3il_attn_half_f16x3: out must not alias x (the residual is read after other rows have been written)");
+  if (n_seq == 0) return D3IL_OK;
+  if (T <= 11)
+    hipLaunchKernelGGL((k_attn_half_f16x3<8, 11>), dim3((unsigned)((n_seq + 7) / 8)), dim3(512), 0, (hipStream_t)stream, x, (const hx_h8*)w_packed, b_qkv, b_proj, out, n_seq, T, ln_weight, ln_bias, ln_eps);
+  else
+    hipLaunchKernelGGL((k_attn_half_f16x3<4, 16>), dim3((unsigned)((n_seq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (const hx_h8*)w_packed, b_qkv, b_proj, out, n_seq, T, ln_weight, ln_bias, ln_eps);
+  HIPCHK(hipGetLastError());
+  return D3IL_OK;
+}
 int d3il_set_tally(d3il_handle h, const int32_t* ctx_id_device, int n_ctx, int64_t* table_device) {
   if (!h) return fail(D3IL_EINVAL, "d3il_set_tally: null handle");
   if (table_device && n_ctx <= 0) return fail(D3IL_EINVAL, "d3il_set_tally: n_ctx must be positive");

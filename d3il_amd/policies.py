@@ -335,6 +335,10 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
             self._hp_qkv = pack_linear120_weights_f16x3(wq, getattr(self, "_hp_qkv", None))
             self._hp_proj = pack_linear120_weights_f16x3(a.proj.weight, getattr(self, "_hp_proj", None))
             self._hp_mlp = pack_mlp_weights_f16x3(fc1.weight, fc2.weight, getattr(self, "_hp_mlp", None))
+            # (query | key | value) tiles followed by the projection's: the weight stream of the one-kernel attention half (d3il_attn_half_f16x3)
+            if getattr(self, "_hp_attn", None) is None or self._hp_attn.device != dev:
+                self._hp_attn = torch.empty(self._hp_qkv.shape[0] + self._hp_proj.shape[0], 512, 8, dtype=self._hp_qkv.dtype, device=dev)
+            torch.cat((self._hp_qkv, self._hp_proj), dim=0, out=self._hp_attn)
         self._pack_key = key
 
     def forward(self, x, keep=None):
@@ -358,18 +362,27 @@ class _Block(nn.Module):                   # score_gpts.py:83-115
             linear = L.d3il_linear120_f16x3 if f16x3 else L.d3il_linear120_f32
             mlp = L.d3il_mlp_ln_gelu_residual_f16x3 if f16x3 else L.d3il_mlp_ln_gelu_residual_f32
             w_qkv, w_proj, w_mlp = (self._hp_qkv, self._hp_proj, self._hp_mlp) if f16x3 else (self._wp_qkv, self._wp_proj, self._wp_mlp)
-            qkv = torch.empty(B, T, 3 * C, dtype=torch.float32, device=x.device)
-            capi.check(linear(x.data_ptr(), self.ln1.weight.data_ptr(), self.ln1.bias.data_ptr(), float(self.ln1.eps), w_qkv.data_ptr(), self._b_qkv.data_ptr(), None,
-                              qkv.data_ptr(), M, 3 * C, st))
-            y = torch.empty_like(x)
-            capi.check(L.d3il_attention_causal_f32(qkv.data_ptr(), y.data_ptr(), B, T, a.n_head, C // a.n_head, st))
-            if keep is not None:
-                y, x = y.index_select(1, keep), x.index_select(1, keep)
-                M = y.shape[0] * y.shape[1]
-            x1 = torch.empty_like(x)
-            capi.check(linear(y.data_ptr(), None, None, 0.0, w_proj.data_ptr(), a.proj.bias.data_ptr(), x.data_ptr(), x1.data_ptr(), M, C, st))
+            if f16x3 and T <= 16 and a.n_head == 6 and self._hp_attn.shape[0] == 32 and os.environ.get("D3IL_POLICY_FUSED_ATTN", "1") == "1":
+                # the attention half in ONE launch, one wave per sequence: q | k | v and the attention output never leave the CU (csrc/policy_f16x3.h k_attn_half_f16x3)
+                x1 = torch.empty_like(x)
+                capi.check(L.d3il_attn_half_f16x3(x.data_ptr(), self.ln1.weight.data_ptr(), self.ln1.bias.data_ptr(), float(self.ln1.eps), self._hp_attn.data_ptr(),
+                                                  self._b_qkv.data_ptr(), a.proj.bias.data_ptr(), x1.data_ptr(), B, T, a.n_head, C, st))
+                if keep is not None:
+                    x1 = x1.index_select(1, keep)
+                    M = x1.shape[0] * x1.shape[1]
+            else:
+                qkv = torch.empty(B, T, 3 * C, dtype=torch.float32, device=x.device)
+                capi.check(linear(x.data_ptr(), self.ln1.weight.data_ptr(), self.ln1.bias.data_ptr(), float(self.ln1.eps), w_qkv.data_ptr(), self._b_qkv.data_ptr(), None,
+                                  qkv.data_ptr(), M, 3 * C, st))
+                y = torch.empty_like(x)
+                capi.check(L.d3il_attention_causal_f32(qkv.data_ptr(), y.data_ptr(), B, T, a.n_head, C // a.n_head, st))
+                if keep is not None:
+                    y, x = y.index_select(1, keep), x.index_select(1, keep)
+                    M = y.shape[0] * y.shape[1]
+                x1 = torch.empty_like(x)
+                capi.check(linear(y.data_ptr(), None, None, 0.0, w_proj.data_ptr(), a.proj.bias.data_ptr(), x.data_ptr(), x1.data_ptr(), M, C, st))
             fc1, fc2 = self.mlp[0], self.mlp[2]
-            out = torch.empty_like(x)
+            out = torch.empty_like(x1)
             capi.check(mlp(x1.data_ptr(), self.ln2.weight.data_ptr(), self.ln2.bias.data_ptr(), float(self.ln2.eps), x1.data_ptr(), w_mlp.data_ptr(),
                            fc1.bias.data_ptr(), fc2.bias.data_ptr(), out.data_ptr(), M, 120, 480, st))
             return out

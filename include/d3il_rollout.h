@@ -200,6 +200,12 @@ int d3il_mlp_ln_gelu_residual_f16x3(const float* h, const float* ln_weight, cons
                                     float* out, long rows, int C, int H, void* stream);
 int d3il_linear120_f16x3(const float* xin, const float* ln_weight, const float* ln_bias, float ln_eps, const void* w_packed, const float* bias, const float* resid, float* out,
                          long rows, int N, void* stream);
+/* The attention half of a DiffusionGPT block (score_gpts.py:35-80 CausalSelfAttention, 103-107 Block.forward first line) in one launch:
+ * out = x + proj(causal_attention(LayerNorm(x) Wqkv' + b_qkv)) + b_proj for n_seq sequences of T <= 16 tokens x 120 features, 6 heads; one wave per sequence,
+ * q | k | v never leave the CU.  w_packed: the 24 tiles of the packed (query | key | value) weight followed by the 8 tiles of the packed projection weight
+ * (policies.pack_linear120_weights_f16x3 of both, concatenated).  out must not alias x. */
+int d3il_attn_half_f16x3(const float* x, const float* ln_weight, const float* ln_bias, float ln_eps, const void* w_packed, const float* b_qkv, const float* b_proj, float* out,
+                         long n_seq, int T, int n_head, int C, void* stream);
 
 /* The whole sampling chain of the reference's DDPM policy in one launch (agents/models/diffusion/gc_diffusion.py:101-216: epsilon prediction, clipped x0, posterior
  * mean, n_timesteps ancestral steps, final clamp; the denoiser = DiffusionMLPNetwork, diffusion_models.py:20-118 over ResidualMLPNetwork, common/mlp.py:114-182: Linear,

@@ -135,3 +135,29 @@ def test_block_in_both_gemm_modes_and_against_torch(monkeypatch):
             err = float((outs[mode][k] - ref).abs().max()) / scale
             assert err < 2e-5, (mode, k, err)
     assert tuple(outs["f16x3"][1].shape) == (700, 5, 120)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(1, 11), (3, 11), (4, 16), (257, 11), (4096, 11), (5, 1), (6, 7)])
+def test_one_kernel_attention_half_equals_the_three_kernel_path(monkeypatch, B, T):
+    """d3il_attn_half_f16x3 (one wave per sequence, q | k | v in LDS) runs the same matrix-core products and the same attention arithmetic in the same order as
+    ln1 + qkv product -> d3il_attention_causal_f32 -> projection + residual: the block's output is bit-identical, with and without `keep`; and it stays within the
+    f32-level distance of torch's layers."""
+    from d3il_amd import policies as P
+    torch.manual_seed(B * 100 + T)
+    blk = P._Block(120, 6, 16).cuda().eval()
+    for p_ in blk.parameters():
+        p_.data.normal_(0.0, 0.08)
+    x = torch.randn(B, T, 120, device="cuda")
+    keep = torch.arange(T // 2, T, device="cuda")
+    with torch.no_grad():
+        monkeypatch.setenv("D3IL_POLICY_FUSED_ATTN", "1")
+        y1, k1 = blk(x), blk(x, keep=keep)
+        monkeypatch.setenv("D3IL_POLICY_FUSED_ATTN", "0")
+        y0, k0 = blk(x), blk(x, keep=keep)
+        monkeypatch.setenv("D3IL_POLICY_FUSED_MLP", "0")
+        yt = blk(x)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0) and torch.equal(k1, k0)
+    assert torch.equal(k1, y1.index_select(1, keep))
+    assert float((y1 - yt).abs().max()) < 2e-4 * float(yt.abs().max().clamp_min(1.0))
