@@ -22,8 +22,8 @@ TASK_FUNCS = {
     "avoiding": ("k_avoiding_step_split", ["jacobi_solve6", "solve_constraints"]),
     "pushing": ("k_sorting_step", ["gen_", "jacobi_solve6", "solve_constraints"]),      # Pushing runs on the generic engine since round 5
     "sorting": ("k_sorting_step", ["gen_", "jacobi_solve6", "solve_constraints"]),
-    "stacking": ("k_stacking_step", ["sk_coop_build"]),
-    "aligning": ("k_aligning_step", ["sk_coop_build", "jacobi_solve6"]),
+    "stacking": ("k_stacking_step", []),      # (the solver is inlined since the wrench-form rewrite of round 6)
+    "aligning": ("k_aligning_step", ["jacobi_solve6"]),
     "inserting": ("k_sorting_step", ["gen_", "jacobi_solve6", "solve_constraints"]),      # the Sorting kernels run the Inserting model
 }
 FMA = re.compile(r"^v_(fma|fmac|mad)_f64")
@@ -31,7 +31,7 @@ F64 = re.compile(r"^v_\w+_f64")
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05", "isa_fp64_mix.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06", "isa_fp64_mix.json")
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "rollout.s")
         flags = [f for f in build.HIPCC_FLAGS if f not in ("-fPIC", "-shared", "-Xarch_device")]
