@@ -248,7 +248,10 @@ def _pmc(task, policy, n, S):
         path = os.path.join(ROOT, "profiles", d, "pmc", "%s_%s_sb%d.json" % (task, policy, S))
         try:
             with open(path) as f:
-                return json.load(f), os.path.relpath(path, ROOT)
+                pm = json.load(f)
+            if "FETCH_SIZE" not in pm or "WRITE_SIZE" not in pm:      # an incomplete counter summary (a pass that did not finish) is no evidence
+                continue
+            return pm, os.path.relpath(path, ROOT)
         except Exception:
             continue
     return None, None
