@@ -4,7 +4,7 @@
 // parts of a sub-step (arm dynamics, collision, limit rows, integration: one lane per environment, the other lanes idle) alternate
 // with the wave-cooperative constraint solve (sk_solve_dual: the 64 lanes work on TWO environments at a time, one per half wave - a
 // 27-dof system with at most 32 contacts fits 32 lanes -, the workgroup's two pairs one after the other; a half that has converged
-// idles until the other one has).  LDS (layout: stack_step.h SE_*): the workgroup's shared Hessian + contact-row / staging area, and per environment its
+// idles until the other one has).  LDS (layout: stack_step.h SE_*): the workgroup's shared Hessian + wrench-table / staging area, and per environment its
 // vectors, kinematic tables, STATE and compact contact records = 38.2 KiB per workgroup, four workgroups per CU.  An environment's
 // state is in registers only inside a phase; between the phases of a sub-step everything is LDS resident and nothing goes through HBM
 // (the round-2 kernel kept 134 VGPRs of state live across the cooperative phases and its contact records in an HBM scratch area).  The arm is the gripper robot of panda_invisible.xml, its
@@ -115,14 +115,11 @@ __device__ __forceinline__ void sk_phase_mid(sk_lds_double* t, sk_glb_double* g,
   const int ncon = (int)t[SE_NCON];
   if (t[SE_NEED] != 0.0) flags |= SKF_CON_OVERFLOW;      // the collision phase dropped contacts
   unsigned has = 0;
-  int jsz = 0;
   for (int ci = 0; ci < ncon; ci++) {
     const int meta = (int)t[SE_REC + ci * SREC2 + 7];
     const int ba = sk_blk_of(meta & 15);
     has |= 1u << sk_blk_of((meta >> 4) & 15); if (ba >= 0) has |= 1u << ba;
-    jsz += 4 * sk_jcols(meta & 15, (meta >> 4) & 15);
   }
-  t[SE_JSZ] = (double)jsz;
   bool any_lim = false;
   const StackScratch sc{t, g};
   if constexpr (V != SKV_STACKING) stack_pre_finish<true>(kAvoidingConsts, g_stack_consts, ss, sc, ncon, has, any_lim);
@@ -370,7 +367,7 @@ __device__ __forceinline__ void coop_step_body(double* __restrict__ state, unsig
 #if defined(D3IL_DEVICE_STATS)
   {   // diagnostics build: the contact records of the last sub-step (count, then 8 doubles per contact) into the environment's scratch column
     const int nc = (int)t[SE_NCON];
-    g[0] = (double)nc; g[1] = t[SE_NEED]; g[2] = t[SE_JSZ];
+    g[0] = (double)nc; g[1] = t[SE_NEED]; g[2] = 0;
     for (int i = 0; i < nc * SREC2; i++) g[8 + i] = t[SE_REC + i];
     for (int i = 0; i < 48; i++) g[500 + i] = t[ST_TIPR + i];
     for (int i = 0; i < 42; i++) g[560 + i] = t[ST_Z + i];

@@ -459,7 +459,6 @@ D3IL_HD void sk_row_fric(const StackSet& ps, double* fr) { fr[0] = ps.fric[0]; f
 #else
 #define SL_ADD(i, v) (SL(i) += (v))
 #endif
-D3IL_HD int sk_jcols(int a, int b) { return (a == SKB_STATIC || a >= SKB_FINGER ? 0 : 6) + (b < SK_NB ? 6 : NDOF); }      // J columns of a contact between bodies a, b
 D3IL_HD int sk_kind(int a, int b) { return b < SK_NB ? (a == SKB_STATIC ? 0 : 1) : (a < SK_NB ? 2 : 3); }
 D3IL_HD int sk_blk_of(int body) { return body == SKB_STATIC ? -1 : (body < SK_NB ? body : SK_NB); }
 D3IL_HD int sk_blk(int dof) { return dof >= SK_ARM0 ? SK_NB : dof / 6; }
@@ -758,14 +757,12 @@ D3IL_HD bool sk_solve(const StackConsts& kc, const StackScratch sc, int ncon, bo
 
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------------------------------------ wave-cooperative Newton solve
-// The same problem as sk_solve, solved for ONE environment by the 64 lanes of its wave (the kernel runs it for the environments of the
-// workgroup one after the other):
-//   * lane c < ncon owns contact c: its rows are built once per solve into the wave's J area ([4 x 15][SK_MAXCON] doubles, body 1's six
-//     columns negated | body 2's nine), reference accelerations / regularisation / residuals stay in the lane's registers; the passes
-//     over the contacts (gradient + Hessian, J p, every trial of the line search) run on all contacts at once, sums through LDS atomics
-//     or wave reductions;
-//   * lane i < 27 owns dof i: its gradient entry, its row of the Hessian and of the Cholesky factor (registers, columns broadcast with
-//     v_readlane, all loops unrolled over the 27 x 27 lower triangle), its entry of the search direction;
+// The same problem as sk_solve, solved for TWO environments at a time by the 64 lanes of their wave, one per half wave (sk_solve_dual below):
+//   * lane c < ncon owns contact c: frame, wrench arms, reference accelerations / regularisation / residuals in the lane's registers (contacts in
+//     wrench form since round 6: no constraint rows); the passes over the contacts (pair matrices and wrenches for gradient + Hessian, J p, every
+//     trial of the line search) run on all contacts at once, sums through LDS additions into body-pair slots or half-wave reductions;
+//   * lane i < 27 owns dof i: its motion-subspace column, its gradient entry, its row of the Hessian and of the Cholesky factor (registers, columns
+//     broadcast inside the half, all loops unrolled over the 27 x 27 lower triangle), its entry of the search direction;
 //   * no islands: the block-diagonal system is factorised as a whole (MuJoCo 2.3.2 solves it as a whole too); blocks without
 //     constraints start at their smooth acceleration with zero gradient and do not move.
 // Same stopping rule, line search and tolerances as sk_solve_island.
@@ -815,13 +812,12 @@ __device__ __forceinline__ double sk_wave_max(double v) {
   SK_CONVERGE();
   return r;
 }
-constexpr int SKC_NJ = 15;                       // columns of a contact row in the J area
-constexpr int SKC_JSIZE = 4 * SKC_NJ * SK_MAXCON;   // doubles per wave
+constexpr int SKC_JSIZE = 4 * 15 * SK_MAXCON;   // doubles per wave of the shared W area (rounds 3 - 5: the contact rows, 4 x 15 per contact; now the wrench tables, SKW_*)
 // LDS layout of the step kernel (one wave = one workgroup = SK_LANES environments):
 //   shared by the workgroup : two solver heads (H [SK_NH] packed Hessian / Cholesky factor | G gradient | P direction) - the constraint
-//                             solver works on TWO environments at a time, one per half wave - | J [SKC_JSIZE] their contact rows (the two
-//                             environments share the SK_MAXCON row slots).  During the collision phase: per-lane staging of the contacts
-//                             a pair test emits.
+//                             solver works on TWO environments at a time, one per half wave - | W [SKC_JSIZE] their wrench tables (SKW_*: motion-
+//                             subspace columns, twists, body-pair slots, aggregates) and the workgroup's carried sin / cos table.  During the
+//                             collision phase: per-lane staging of the contacts a pair test emits.
 //   per environment         : the t area of the one-lane code WITHOUT its head (vectors, mass matrix, kinematic tables, limit rows; the
 //                             view pointer is shifted by ST_HEAD so that the ST_* offsets stay valid), then the part of the state that is
 //                             not in a table already (q, qfrc_bias, TCP, box quaternions - velocities and box positions live in ST_VEL /
@@ -832,7 +828,6 @@ constexpr int SREC2 = 8;
 constexpr int SE_Q = ST_SIZE, SE_BIAS = SE_Q + NDOF, SE_TCP = SE_BIAS + NARM, SE_BQ = SE_TCP + 3, SE_ACT = SE_BQ + 4 * SK_NB;
 constexpr int SE_NCON = SE_ACT + NARM;          // contact count of this sub-step
 constexpr int SE_NEED = SE_NCON + 1;            // 1: constraints present (contacts or joint limits) -> the solver runs; + 256: contacts were dropped
-constexpr int SE_JSZ = ST_AUX + 1;              // (the spare word of the t area) doubles of the J area the contact rows of this sub-step take: 4 rows x (columns of body 1 + body 2) per contact
 constexpr int SE_REC = SE_NEED + 1;
 constexpr int SE_END = SE_REC + SK_MAXCON * SREC2;
 constexpr int SE_SIZE = ((SE_END - ST_HEAD) | 1);  // doubles per environment (odd: the environments start on different banks)
