@@ -661,10 +661,30 @@ def run(args):
         if sh.graph:                 # the captured form of the step (with its event pairs) is built here, outside the timed region
             sh.env.random_rollout_prepare(42, sh.env_offset, t_run, sh.actions, sh.episodes)
     barrier()
+    stats_lib = os.environ.get("D3IL_STATS_LIB") == "1"      # diagnostics library (device-side phase timers): its counters over the timed region go to stderr
+    if stats_lib:
+        import ctypes as _C
+        from d3il_amd import capi
+        _st = (_C.c_uint64 * 32)()
+        capi.check(capi.load().d3il_debug_stats(_st, 1))
+
+        def _diag0():      # per-environment phase timers of environment 0 (cooperative engine: SG_DIAG + 4 ..; accumulated since creation)
+            buf = np.zeros(32 * 36 + 24)
+            if capi.load().d3il_debug_scratch(env.h, 0, buf.ctypes.data_as(_C.c_void_p), len(buf)) != 0:
+                return None
+            return buf[32 * 36 + 4:32 * 36 + 17].copy()
+        _d0 = _diag0() if task in ("stacking", "aligning") else None
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(t_run); t_run += 1
     torch.cuda.synchronize()                         # all sub-batch streams
+    if stats_lib:
+        capi.check(capi.load().d3il_debug_stats(_st, 0))
+        print("device stats (g_dev_stats[0..31], timed region of %d steps): %s" % (args.steps, json.dumps([int(v) for v in _st])), file=sys.stderr)
+        if _d0 is not None:
+            _d1 = _diag0()
+            if _d1 is not None:
+                print("environment 0 phase ticks (slots 0 .. 12: 0 control + arm dynamics + tables, 3 limit rows / start point, 5 integration): %s" % json.dumps([float(v) for v in (_d1 - _d0)]), file=sys.stderr)
     table = shards[0].table
     for sh in shards[1:]:
         table += sh.table

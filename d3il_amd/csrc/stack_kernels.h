@@ -77,34 +77,49 @@ __device__ __forceinline__ void sk_state_from_lds(const sk_lds_double* t, StackS
 // phase 1 (lane = environment): control law + arm forward pass, kinematic tables, smooth accelerations
 template <int V>
 __device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g, unsigned& flags, bool open, const sk_lds_double* trig_lds) {
-  StackState ss;
-  sk_state_from_lds(t, ss);
-  double trig[2 * NARM];
-  for (int k = 0; k < 2 * NARM; k++) trig[k] = trig_lds[k];
-  ss.arm.flags = flags;
   double tau[NARM], ff[NFING];
   const StackScratch sc{t, g};
   if constexpr (V != SKV_STACKING) {
     // CartPosQuatImpedenceController (IKControllers.py:163-323): the virtual joint target advances open loop by three damped least-squares
-    // iterations per sub-step, then the joint PD law with gravity compensation; fingers commanded open (gym_env_wrapper.py:67)
-    double ikq[NARM], ikqd[NARM], des[7], vwarm[7];
-    for (int k = 0; k < NARM; k++) { ikq[k] = t[ST_TIPR + SV_IKQ + k]; ikqd[k] = t[ST_TIPR + SV_IKQD + k]; des[k] = t[ST_TIPR + SV_DES + k]; vwarm[k] = t[ST_TIPR + SV_VWARM + k]; }
+    // iterations per sub-step, then the joint PD law with gravity compensation; fingers commanded open (gym_env_wrapper.py:67).
+    // The controller runs FIRST, with nothing of the environment's state in registers yet (it needs the joint angles only when the target is
+    // initialised): its three IK iterations are the longest dependent chain of the sub-step, and with the 60 doubles of the state live across
+    // them the chain ran through scratch reloads (round 6: the per-environment phases were two thirds of the Aligning sub-step)
+    double ikq[NARM], ikqd[NARM];
     const bool hold = V == SKV_ALIGNING && t[ST_TIPR + SV_HOLD] != 0.0;      // the sub-step of env.reset(): joint PD hold at init_qpos (in the ik_q slots), fingers at 1 mm
-    if (!hold) {
-      ik_update<true>(kAvoidingConsts, des, des + 3, ss.arm.q, ss.arm.flags, ikq, ikqd, vwarm);
-      for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ikq[k]; t[ST_TIPR + SV_IKQD + k] = ikqd[k]; t[ST_TIPR + SV_VWARM + k] = vwarm[k]; }
+    {
+      double des[7], vwarm[7], cq[NARM];
+      for (int k = 0; k < NARM; k++) { ikq[k] = t[ST_TIPR + SV_IKQ + k]; ikqd[k] = t[ST_TIPR + SV_IKQD + k]; des[k] = t[ST_TIPR + SV_DES + k]; vwarm[k] = t[ST_TIPR + SV_VWARM + k]; cq[k] = t[SE_Q + k]; }
+      if (!hold) {
+        ik_update<true>(kAvoidingConsts, des, des + 3, cq, flags, ikq, ikqd, vwarm);
+        for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ikq[k]; t[ST_TIPR + SV_IKQD + k] = ikqd[k]; t[ST_TIPR + SV_VWARM + k] = vwarm[k]; }
+      }
     }
+    asm volatile("" ::: "memory");      // the state is loaded AFTER the controller, not hoisted above it
+    StackState ss;
+    sk_state_from_lds(t, ss);
+    ss.arm.flags = flags;
+    double trig[2 * NARM];
+    for (int k = 0; k < 2 * NARM; k++) trig[k] = trig_lds[k];
     push_control(kAvoidingConsts, ss.arm, ikq, ikqd, hold ? 0.001 : 0.04, false, tau, ff);
     stack_pre_kin<V>(kAvoidingConsts, g_stack_consts, ss, sc, tau, ff, trig);
+    for (int k = 0; k < NARM; k++) t[SE_BIAS + k] = ss.arm.bias[k];
+    for (int k = 0; k < 3; k++) t[SE_TCP + k] = ss.arm.tcp[k];
+    flags = ss.arm.flags;
   } else {
+    StackState ss;
+    sk_state_from_lds(t, ss);
+    double trig[2 * NARM];
+    for (int k = 0; k < 2 * NARM; k++) trig[k] = trig_lds[k];
+    ss.arm.flags = flags;
     double act[NARM];
     for (int k = 0; k < NARM; k++) act[k] = t[SE_ACT + k];
     stack_control(kStackingConsts, ss.arm, act, open ? 0.04 : 0.0, !open, tau, ff);
     stack_pre_kin<SKV_STACKING>(kStackingConsts, g_stack_consts, ss, sc, tau, ff, trig);
+    for (int k = 0; k < NARM; k++) t[SE_BIAS + k] = ss.arm.bias[k];
+    for (int k = 0; k < 3; k++) t[SE_TCP + k] = ss.arm.tcp[k];
+    flags = ss.arm.flags;
   }
-  for (int k = 0; k < NARM; k++) t[SE_BIAS + k] = ss.arm.bias[k];
-  for (int k = 0; k < 3; k++) t[SE_TCP + k] = ss.arm.tcp[k];
-  flags = ss.arm.flags;
 }
 // phase 3 (lane = environment): joint-limit rows, start point of the solver, "does the solver run"
 template <int V>
