@@ -684,7 +684,7 @@ def run(args):
         if _d0 is not None:
             _d1 = _diag0()
             if _d1 is not None:
-                print("environment 0 phase ticks (slots 0 .. 12: 0 control + arm dynamics + tables, 3 limit rows / start point, 5 integration): %s" % json.dumps([float(v) for v in (_d1 - _d0)]), file=sys.stderr)
+                print("environment 0 phase ticks (slots 0 .. 12: 0 arm dynamics + tables, 1 Cartesian controller (Aligning), 3 limit rows / start point, 5 integration): %s" % json.dumps([float(v) for v in (_d1 - _d0)]), file=sys.stderr)
     table = shards[0].table
     for sh in shards[1:]:
         table += sh.table

@@ -1870,7 +1870,7 @@ int d3il_debug_scratch(d3il_handle h, int env, double* out, int count) {
   if (!h->d_scratch || env < 0 || env >= h->n) return fail(D3IL_EINVAL, "d3il_debug_scratch: no scratch area / env out of range");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
-  if (h->task_id == D3IL_TASK_STACKING) {     // contiguous per environment
+  if (h->task_id == D3IL_TASK_STACKING || h->task_id == D3IL_TASK_ALIGNING) {     // contiguous per environment (the cooperative engine)
     if (count > SG_SIZE) return fail(D3IL_EINVAL, "d3il_debug_scratch: count exceeds the environment's scratch area");
     HIPCHK(hipMemcpy(out, h->d_scratch + (size_t)env * SG_SIZE, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
     return D3IL_OK;

@@ -87,6 +87,7 @@ __device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g,
     // them the chain ran through scratch reloads (round 6: the per-environment phases were two thirds of the Aligning sub-step)
     double ikq[NARM], ikqd[NARM];
     const bool hold = V == SKV_ALIGNING && t[ST_TIPR + SV_HOLD] != 0.0;      // the sub-step of env.reset(): joint PD hold at init_qpos (in the ik_q slots), fingers at 1 mm
+    SK_TIC;
     {
       double des[7], vwarm[7], cq[NARM];
       for (int k = 0; k < NARM; k++) { ikq[k] = t[ST_TIPR + SV_IKQ + k]; ikqd[k] = t[ST_TIPR + SV_IKQD + k]; des[k] = t[ST_TIPR + SV_DES + k]; vwarm[k] = t[ST_TIPR + SV_VWARM + k]; cq[k] = t[SE_Q + k]; }
@@ -95,6 +96,7 @@ __device__ __forceinline__ void sk_phase_pre(sk_lds_double* t, sk_glb_double* g,
         for (int k = 0; k < NARM; k++) { t[ST_TIPR + SV_IKQ + k] = ikq[k]; t[ST_TIPR + SV_IKQD + k] = ikqd[k]; t[ST_TIPR + SV_VWARM + k] = vwarm[k]; }
       }
     }
+    SK_TOC(1);      // (diagnostics build: the controller's share of the per-environment phase)
     asm volatile("" ::: "memory");      // the state is loaded AFTER the controller, not hoisted above it
     StackState ss;
     sk_state_from_lds(t, ss);
