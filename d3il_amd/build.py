@@ -125,6 +125,18 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
     return out
 
 
+def build_poison(force: bool = False, verbose: bool = False) -> str:
+    """The NaN-poison build of the cooperative engine (libd3il_rollout_poison.so), rebuilt when a source is newer: tests/test_gpu_poison_build.py runs the
+    Stacking / Aligning parity files on it - a phase that reads an LDS word its launch has not written shows up as a NaN on EVERY box instead of as a result
+    that depends on what the LDS held before (round 6: the slide axes of the rod-robot variants)."""
+    out = os.path.join(PKG, "libd3il_rollout_poison.so")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(p) for p in DEPS):
+        check_compiler(verbose)
+        generate_consts(verbose)
+        build_variant("poison", VARIANTS["poison"], verbose)
+    return out
+
+
 VARIANTS = {"gtstatic": ["D3IL_GT_STATIC"],
             "gtinline": ["D3IL_GT_INLINE"],      # the tree solver inlined into the step kernel (no callee-saved register traffic)
             "nsub1": ["D3IL_GEN_NSUB=1"],      # the generic engine with one lane per cube and one physics wave (A/B of the sub-lanes)

@@ -953,7 +953,10 @@ __device__ __forceinline__ unsigned sk_solve_dual(const StackConsts& kc_, sk_lds
       const double o[3] = {t[ST_O + 3 * ia] - SKW_REF[0], t[ST_O + 3 * ia + 1] - SKW_REF[1], t[ST_O + 3 * ia + 2] - SKW_REF[2]};
       si[0] = z[0]; si[1] = z[1]; si[2] = z[2];
       si[3] = o[1] * z[2] - o[2] * z[1]; si[4] = o[2] * z[0] - o[0] * z[2]; si[5] = o[0] * z[1] - o[1] * z[0];
-    } else { si[3] = t[ST_FAX + 3 * fs]; si[4] = t[ST_FAX + 3 * fs + 1]; si[5] = t[ST_FAX + 3 * fs + 2]; }
+    } else if (kc.variant == SKV_STACKING) { si[3] = t[ST_FAX + 3 * fs]; si[4] = t[ST_FAX + 3 * fs + 1]; si[5] = t[ST_FAX + 3 * fs + 2]; }
+    // (the rod-robot variants have no finger geoms: stack_pre_kin writes no slide axes there, no contact touches a finger body, the column stays zero -
+    // reading the unwritten table words made the slide rows of the Hessian depend on what the LDS held before: NaN on some boxes of the pool, found with the
+    // poison build, profiles/r06/aligning_uninitialised_lds/)
 #pragma unroll
     for (int a = 0; a < 6; a++) Wb[SKW_SCOL + 6 * i + a] = si[a];
   }
