@@ -96,7 +96,7 @@ def test_pushing_success_and_mode_tables_over_full_episodes():
     res = oe.run_many(oe.pushing_episode, [(i, ctx[i], q0, 400, i % 4) for i in range(60)])
     orc_rows = [(s, m) for _, s, m, _, _ in res]
     sets, _ = _outcome_sets("pushing")
-    s = _compare("pushing", dev_rows, orc_rows, sets, max_undecided=8)
+    s = _compare("pushing", dev_rows, orc_rows, sets, max_undecided=7)      # exactly the fixture's undecided contexts (6, 10, 22, 26, 30, 34, 54): the set may not grow unnoticed
     # the metric's integer table (mode counts of the successful rollouts per context): the rows of the decided contexts are identical
     tab = np.zeros((60, 4), dtype=np.int64)
     for i, (ok, m) in enumerate(orc_rows):
@@ -127,7 +127,7 @@ def test_pushing_tables_on_sampled_contexts():
     res = oe.run_many(oe.pushing_episode, [(i, ctx[i], q0, 400, i % 4) for i in range(n)])
     orc_rows = [(s, m) for _, s, m, _, _ in res]
     sets, _ = _outcome_sets("pushing_sampled")
-    s = _compare("pushing_sampled", dev_rows, orc_rows, sets, max_undecided=16)
+    s = _compare("pushing_sampled", dev_rows, orc_rows, sets, max_undecided=12)      # exactly the fixture's undecided contexts
     assert s["oracle_successes"] >= n // 2
 
 
@@ -151,7 +151,7 @@ def test_sorting_success_and_mode_tables_over_full_episodes():
     res = oe.run_many(oe.sorting_episode, [(i, ctx[i], q0, 700) for i in range(60)])
     orc_rows = [(s, m) for _, s, m, _ in res]
     sets, _ = _outcome_sets("sorting")
-    s = _compare("sorting", dev_rows, orc_rows, sets, max_undecided=8)
+    s = _compare("sorting", dev_rows, orc_rows, sets, max_undecided=3)      # exactly the fixture's undecided contexts (34, 45, 52)
     hist_d = np.bincount(np.array([m for _, m in dev_rows]), minlength=256)
     hist_o = np.bincount(np.array([m for _, m in orc_rows]), minlength=256)
     print("  mode-code histogram L1 distance: %d of %d rollouts" % (int(np.abs(hist_d - hist_o).sum()) // 2, 60))
